@@ -1,0 +1,252 @@
+"""Generate the golden fixtures in this directory by running the UNMODIFIED reference.
+
+Run in the build container only (needs /root/reference):  python tests/golden/make_golden.py
+Every array written here is an output of the reference's own classes
+(`gops.create_pkg.create_env_model.create_env_model`, `gops.algorithm.fhadp.FHADP`,
+`gops.algorithm.infadp.INFADP`) on inputs from `gops_amd.utils.synthetic`.  The fixtures are what
+pins `oracle/adp_oracle.py` and, through it (and directly), the HIP path.
+"""
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import _ref_import  # noqa: E402
+
+_ref_import.install()
+
+from gops.algorithm.fhadp import FHADP  # noqa: E402
+from gops.algorithm.infadp import INFADP  # noqa: E402
+from gops.create_pkg.create_env_model import create_env_model  # noqa: E402
+
+from gops_amd.utils.synthetic import CONFIGS, act_dim_of, make_batch, obs_dim_of  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def alg_kwargs(cfg, seed, **extra):
+    A = act_dim_of(cfg)
+    kw = dict(
+        algorithm=cfg["alg"], trainer="off_serial_trainer", seed=seed, cnn_shared=False,
+        env_id=cfg["env_id"], obsv_dim=obs_dim_of(cfg), action_dim=A, action_type="continu",
+        action_high_limit=np.ones(A, dtype=np.float32), action_low_limit=-np.ones(A, dtype=np.float32),
+        policy_func_type="MLP",
+        policy_func_name="FiniteHorizonPolicy" if cfg["alg"] == "FHADP" else "DetermPolicy",
+        policy_hidden_sizes=list(cfg["hidden"]), policy_hidden_activation=cfg["act"],
+        policy_act_distribution="default", policy_learning_rate=1e-3, use_gpu=False,
+    )
+    if cfg["alg"] == "INFADP":
+        kw.update(value_func_type="MLP", value_func_name="StateValue",
+                  value_hidden_sizes=list(cfg["hidden"]), value_hidden_activation=cfg["act"],
+                  value_learning_rate=1e-3)
+    if "pre_horizon" in cfg or cfg["alg"] == "FHADP":
+        kw["pre_horizon"] = cfg.get("pre_horizon", cfg["horizon"])
+    if "lq_config" in cfg:
+        kw["lq_config"] = cfg["lq_config"]
+    kw.update(extra)
+    return kw
+
+
+def sd_to_np(sd, prefix="sd/"):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def build_alg(cfg, seed, **extra):
+    torch.manual_seed(seed)
+    kw = alg_kwargs(cfg, seed, **extra)
+    if cfg["alg"] == "FHADP":
+        alg = FHADP(**kw)
+        alg.gamma = cfg.get("gamma", 1.0)
+    else:
+        alg = INFADP(**kw)
+        alg.gamma = cfg.get("gamma", 0.99)
+        alg.forward_step = cfg["horizon"]
+    return alg
+
+
+def grads_of(module):
+    return [p.grad.detach().clone() for p in module.parameters()]
+
+
+def sample_idx(n, k, seed):
+    return np.random.RandomState(seed).choice(n, size=min(k, n), replace=False)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ------------------------------------------------------------------------------------------
+# 1. single wrapped env-model steps (next_obs / reward / done; next state for veh3dof)
+# ------------------------------------------------------------------------------------------
+def golden_steps():
+    cases = {
+        "step_lq_s4a2": (dict(env_id="pyth_lq", lq_config="s4a2"), {}),
+        "step_lq_s6a3": (dict(env_id="pyth_lq", lq_config="s6a3"), {}),
+        "step_lq_s2a1_shaped": (dict(env_id="pyth_lq", lq_config="s2a1"),
+                                dict(reward_scale=0.5, reward_shift=1.0)),
+        "step_idp": (dict(env_id="pyth_idpendulum"), dict(reward_scale=1)),
+        "step_veh_p10": (dict(env_id="pyth_veh3dofconti", pre_horizon=10), {}),
+        "step_veh_p30": (dict(env_id="pyth_veh3dofconti", pre_horizon=30), {}),
+    }
+    for name, (cfg, extra) in cases.items():
+        B, nsteps = 48, 6
+        data = make_batch(dict(cfg, batch=B), seed=7)
+        model = create_env_model(**cfg, **extra)
+        g = torch.Generator().manual_seed(11)
+        A = act_dim_of(cfg)
+        # a third of the batch starts done; observations far enough out to hit obs clipping (lq)
+        done = (torch.rand(B, generator=g) < 0.3).float()
+        obs = data["obs"].clone()
+        if cfg["env_id"] == "pyth_lq":
+            obs[:8] *= 8.0
+        if cfg["env_id"] == "pyth_idpendulum":
+            obs[:6, 1] = 1.2  # tips over -> done from the model
+        info = {k: v.clone() for k, v in data.items()}
+        out = {"in/obs": obs.numpy().copy(), "in/done": done.numpy().copy()}
+        for k in ("state", "ref_points", "path_num", "u_num", "ref_time"):
+            if k in data:
+                out["in/" + k] = data[k].numpy().copy()
+        o, d = obs, done
+        for s in range(nsteps):
+            a = torch.rand(B, A, generator=g) * 2.6 - 1.3  # beyond [-1,1]: exercises the clamps
+            o, r, d, info = model.forward(o, a, d, info)
+            out[f"s{s}/act"] = a.numpy()
+            out[f"s{s}/obs"] = o.numpy().copy()
+            out[f"s{s}/rew"] = r.numpy().copy()
+            out[f"s{s}/done"] = d.numpy().copy()
+            if "state" in info and info["state"] is not None:
+                out[f"s{s}/state"] = info["state"].numpy().copy()
+                out[f"s{s}/ref_last"] = info["ref_points"][:, -1].numpy().copy()
+        out["meta/nsteps"] = nsteps
+        out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra=extra))
+        save(name, **out)
+
+
+# ------------------------------------------------------------------------------------------
+# 2. small FHADP / INFADP gradient cases with full inputs, weights and gradients
+# ------------------------------------------------------------------------------------------
+SMALL = {
+    "fhadp_lq_s4a2_tanh": (dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=40, horizon=12,
+                                hidden=(64, 64), act="tanh", gamma=0.97), {}),
+    "fhadp_lq_s6a3_relu": (dict(alg="FHADP", env_id="pyth_lq", lq_config="s6a3", batch=33, horizon=8,
+                                hidden=(32, 64, 32), act="relu", gamma=1.0), {}),
+    "fhadp_idp_gelu": (dict(alg="FHADP", env_id="pyth_idpendulum", batch=64, horizon=10,
+                            hidden=(64, 64), act="gelu", gamma=1.0), dict(reward_scale=1)),
+    "fhadp_idp_selu_shaped": (dict(alg="FHADP", env_id="pyth_idpendulum", batch=24, horizon=16,
+                                   hidden=(64, 64), act="selu", gamma=0.95),
+                              dict(reward_scale=0.1, reward_shift=-2.0)),
+    "fhadp_veh_p10_elu": (dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=48, horizon=10,
+                               pre_horizon=10, hidden=(64, 64), act="elu", gamma=1.0), {}),
+    "fhadp_veh_p30_sigmoid": (dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=20, horizon=30,
+                                   pre_horizon=30, hidden=(128, 128), act="sigmoid", gamma=0.99), {}),
+    "infadp_lq_s4a2_gelu": (dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=64, horizon=10,
+                                 hidden=(64, 64), act="gelu", gamma=0.99), {}),
+    "infadp_idp_gelu": (dict(alg="INFADP", env_id="pyth_idpendulum", batch=40, horizon=10,
+                             hidden=(64, 64), act="gelu", gamma=0.99), {}),
+    "infadp_veh_p10_relu": (dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=32, horizon=10,
+                                 pre_horizon=10, hidden=(64, 64, 64), act="relu", gamma=0.99), {}),
+}
+
+
+def perturb_targets(alg, seed):
+    """Targets equal the online nets right after construction; move them so that tests can tell
+    V from V_target (as after a few Polyak updates)."""
+    g = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for p in alg.networks.v_target.parameters():
+            p.add_(0.05 * (torch.rand(p.shape, generator=g) - 0.5))
+
+
+def golden_small():
+    for name, (cfg, extra) in SMALL.items():
+        seed = zlib.crc32(name.encode()) % 1000
+        alg = build_alg(cfg, seed, **extra)
+        data = make_batch(cfg, seed)
+        if "idp" in name:
+            data["obs"][:5, 1] = 0.9  # some trajectories fall over within the horizon
+            data["obs2"] = data["obs"].clone()
+        if cfg["env_id"] == "pyth_veh3dofconti":
+            data["state"][:3, 1] += 9.3  # |delta_y| crosses 10 m within the horizon -> done
+            from gops_amd.utils.synthetic import veh_obs_f32
+            data["obs"] = torch.from_numpy(veh_obs_f32(data["state"].numpy(), data["ref_points"].numpy()))
+            data["obs2"] = data["obs"].clone()
+        data["done"][-3:] = 1.0  # already-done rows in the batch
+        out = {"in/" + k: v.numpy().copy() for k, v in data.items()}
+        out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra=extra, seed=seed))
+        if cfg["alg"] == "FHADP":
+            out.update(sd_to_np(alg.networks.state_dict()))
+            alg._compute_gradient(data)
+            for i, gr in enumerate(grads_of(alg.networks.policy)):
+                out[f"grad/{i}"] = gr.numpy()
+            out["loss"] = alg.tb_info["Loss/Actor loss-RL iter"]
+        else:
+            perturb_targets(alg, seed)
+            out.update(sd_to_np(alg.networks.state_dict()))
+            _, info = alg.get_remote_update_info(data, 0)  # PEV
+            for i, gr in enumerate(info["v"]):
+                out[f"pev_grad/{i}"] = gr.detach().numpy().copy()
+            out["pev_loss"] = alg.tb_info["Loss/Critic loss-RL iter"]
+            out["pev_vmean"] = alg.tb_info["Train/Critic avg value-RL iter"]
+            _, info = alg.get_remote_update_info(data, 1)  # PIM
+            for i, gr in enumerate(info["policy"]):
+                out[f"pim_grad/{i}"] = gr.detach().numpy().copy()
+            out["pim_loss"] = alg.tb_info["Loss/Actor loss-RL iter"]
+        save(name, **out)
+
+
+# ------------------------------------------------------------------------------------------
+# 3. BASELINE.json shapes: inputs/weights are regenerated from the seed by the tests, the
+#    fixture holds checksums of them plus loss, per-parameter gradient norms and samples.
+# ------------------------------------------------------------------------------------------
+def golden_big():
+    for name, cfg in CONFIGS.items():
+        seed = 0
+        alg = build_alg(cfg, seed)
+        data = make_batch(cfg, seed)
+        out = {"chk/obs_sum": data["obs"].double().sum().item()}
+        params0 = [p.detach().clone() for p in alg.networks.policy.parameters()]
+        out["chk/policy_w0_sum"] = params0[0].double().sum().item()
+        out["chk/policy_wlast_sum"] = params0[-2].double().sum().item()
+
+        def pack(prefix, grads):
+            out[prefix + "norms"] = np.array([g.double().norm().item() for g in grads])
+            for i, g in enumerate(grads):
+                flat = g.reshape(-1)
+                idx = sample_idx(flat.numel(), 256, 100 + i)
+                out[f"{prefix}idx{i}"] = idx
+                out[f"{prefix}val{i}"] = flat[idx].numpy()
+
+        if cfg["alg"] == "FHADP":
+            alg._compute_gradient(data)
+            pack("grad/", grads_of(alg.networks.policy))
+            out["loss"] = alg.tb_info["Loss/Actor loss-RL iter"]
+        else:
+            perturb_targets(alg, seed)
+            out["chk/vt_w0_sum"] = next(alg.networks.v_target.parameters()).double().sum().item()
+            _, info = alg.get_remote_update_info(data, 0)
+            pack("pev_grad/", [g.detach() for g in info["v"]])
+            out["pev_loss"] = alg.tb_info["Loss/Critic loss-RL iter"]
+            _, info = alg.get_remote_update_info(data, 1)
+            pack("pim_grad/", [g.detach() for g in info["policy"]])
+            out["pim_loss"] = alg.tb_info["Loss/Actor loss-RL iter"]
+        save("big_" + name, **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["steps", "small", "big"]
+    if "steps" in which:
+        golden_steps()
+    if "small" in which:
+        golden_small()
+    if "big" in which:
+        golden_big()

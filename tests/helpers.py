@@ -1,0 +1,64 @@
+"""Shared test helpers: build oracle-side envs / nets from a golden fixture."""
+import numpy as np
+import torch
+
+from oracle import adp_oracle as orc
+
+INFO_KEYS = ("state", "ref_points", "path_num", "u_num", "ref_time")
+
+
+def oracle_env(cfg, extra):
+    return orc.make_env(cfg["env_id"], lq_config=cfg.get("lq_config", "s4a2"),
+                        pre_horizon=cfg.get("pre_horizon", 10),
+                        reward_scale=extra.get("reward_scale"), reward_shift=extra.get("reward_shift"))
+
+
+def data_from_golden(g, prefix="in/"):
+    return {k[len(prefix):]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith(prefix)}
+
+
+def nets_from_golden(g, cfg):
+    sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("sd/")}
+    act = cfg["act"]
+    nets = {}
+    pol = orc.net_from_state_dict(sd, "policy.pi", act)
+    pol["act_high"], pol["act_low"] = sd["policy.act_high_lim"], sd["policy.act_low_lim"]
+    nets["policy"] = pol
+    if "v.v.0.weight" in sd:
+        nets["v"] = orc.net_from_state_dict(sd, "v.v", act)
+        nets["v_target"] = orc.net_from_state_dict(sd, "v_target.v", act, requires_grad=False)
+    return nets, sd
+
+
+def reference_init_nets(cfg, seed, obs_dim, act_dim):
+    """Re-create the reference's random init: torch.manual_seed(seed) then nn.Linear layers in
+    the reference's construction order (fhadp.py:42-44; infadp.py:41-45: value first)."""
+    torch.manual_seed(seed)
+
+    def linears(sizes):
+        return [torch.nn.Linear(sizes[i], sizes[i + 1]) for i in range(len(sizes) - 1)]
+
+    def to_net(layers, **kw):
+        return dict(w=[l.weight.detach().clone().requires_grad_(True) for l in layers],
+                    b=[l.bias.detach().clone().requires_grad_(True) for l in layers], act=cfg["act"], **kw)
+
+    hid = list(cfg["hidden"])
+    lim = dict(act_high=torch.ones(act_dim), act_low=-torch.ones(act_dim))
+    nets = {}
+    if cfg["alg"] == "FHADP":
+        nets["policy"] = to_net(linears([obs_dim + 1] + hid + [act_dim]), **lim)
+    else:
+        v = linears([obs_dim] + hid + [1])
+        p = linears([obs_dim] + hid + [act_dim])
+        nets["v"] = to_net(v)
+        nets["policy"] = to_net(p, **lim)
+        vt = to_net(v)
+        g = torch.Generator().manual_seed(seed + 1000)  # make_golden.perturb_targets
+        with torch.no_grad():
+            for w_, b_ in zip(vt["w"], vt["b"]):
+                for p_ in (w_, b_):
+                    p_.add_(0.05 * (torch.rand(p_.shape, generator=g) - 0.5))
+        for p_ in vt["w"] + vt["b"]:
+            p_.requires_grad_(False)
+        nets["v_target"] = vt
+    return nets

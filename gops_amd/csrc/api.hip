@@ -1,0 +1,397 @@
+// Host side of the C ABI (include/gops_hip.h): argument checking, workspace carving, launch
+// sequencing.  Nothing here allocates device memory or synchronises the stream.
+#include <math.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+hipError_t launch_rollout_fwd(const RolloutParams& p, hipStream_t stream);
+hipError_t launch_rollout_bwd(const RolloutParams& p, hipStream_t stream);
+size_t rollout_fwd_lds_bytes(int ldx, int ldh);
+size_t rollout_bwd_lds_bytes(int ldx, int ldh);
+hipError_t launch_pack(const float* W, int N, int K, int Kp, float* wp, float* wpt, hipStream_t s);
+hipError_t launch_ref_table(int B, int P, int H, const GopsRolloutIn& in, float pdt, float* table, hipStream_t s);
+hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
+                          int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s);
+hipError_t launch_dw_out(const float* dy, const float* h, int K, int A, long long S, int splits,
+                         float* part, float* part_b, hipStream_t s);
+hipError_t launch_reduce(const float* part, int splits, int rows, int cols, int ld, float* out, hipStream_t s);
+hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s);
+
+namespace {
+
+inline int pad16(int x) { return (x + 15) & ~15; }
+constexpr size_t kAlign = 256;   // bytes
+
+// ---- opt-in kernel timing (bench.py) ---------------------------------------------------------
+struct ProfState {
+    std::mutex mu;
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];
+} g_prof;
+
+struct ProfScope {
+    int id;
+    hipStream_t s;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_) {
+        if (g_prof.on) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~ProfScope() {
+        if (a != nullptr) {
+            (void)hipEventRecord(b, s);
+            std::lock_guard<std::mutex> lk(g_prof.mu);
+            g_prof.ev[id].emplace_back(a, b);
+        }
+    }
+};
+
+// ---- workspace plan ----------------------------------------------------------------------------
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+    float* take(size_t nfloats) {
+        off = (off + kAlign - 1) / kAlign * kAlign;
+        float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+        off += nfloats * sizeof(float);
+        return p;
+    }
+};
+
+struct DwPlan {
+    int splits, chunks_per_split;
+    bool big;
+};
+
+DwPlan plan_dw(int N, int Kp, long long S) {
+    DwPlan d;
+    d.big = (N >= 128 && Kp >= 128);
+    const int T = d.big ? 128 : 64;
+    const int tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
+    const long long chunks = (S + DW_SC_HOST - 1) / DW_SC_HOST;
+    long long splits = (1024 + tiles - 1) / tiles;
+    if (splits > chunks) splits = chunks;
+    if (splits < 1) splits = 1;
+    d.chunks_per_split = (int)((chunks + splits - 1) / splits);
+    d.splits = (int)((chunks + d.chunks_per_split - 1) / d.chunks_per_split);
+    return d;
+}
+
+int check_mlp(const GopsMlp& m, int in_dim, int out_dim) {
+    if (m.n_layers < 2 || m.n_layers > GOPS_MAX_LAYERS) return GOPS_ERR_UNSUPPORTED;
+    if (m.sizes[0] != in_dim || m.sizes[m.n_layers] != out_dim) return GOPS_ERR_BAD_ARG;
+    if (out_dim < 1 || out_dim > GOPS_MAX_ACT) return GOPS_ERR_UNSUPPORTED;
+    for (int j = 1; j < m.n_layers; ++j)
+        if (m.sizes[j] < 16 || (m.sizes[j] & 15)) return GOPS_ERR_UNSUPPORTED;
+    if (m.hidden_act < GOPS_ACT_LINEAR || m.hidden_act > GOPS_ACT_TANH) return GOPS_ERR_BAD_ARG;
+    for (int j = 0; j < m.n_layers; ++j)
+        if (m.weight[j] == nullptr || m.bias[j] == nullptr) return GOPS_ERR_BAD_ARG;
+    return GOPS_OK;
+}
+
+void fill_mlp(MlpDev& d, const GopsMlp& m) {
+    memset(&d, 0, sizeof(d));
+    d.nl = m.n_layers;
+    d.act = m.hidden_act;
+    for (int j = 0; j <= m.n_layers; ++j) d.dims[j] = m.sizes[j];
+    for (int j = 0; j < m.n_layers; ++j) {
+        d.kp[j] = pad16(m.sizes[j]);
+        d.w[j] = m.weight[j];
+        d.b[j] = m.bias[j];
+    }
+}
+
+void carve_packs(Carver& c, MlpDev& d) {
+    for (int j = 0; j < d.nl - 1; ++j) {
+        const size_t n = (size_t)d.dims[j + 1] * d.kp[j];
+        d.wp[j] = reinterpret_cast<const f32x4*>(c.take(n));
+        d.wpt[j] = reinterpret_cast<const f32x4*>(c.take(n));
+    }
+}
+
+struct Plan {
+    RolloutParams p;
+    float* dw_part = nullptr;
+    float* dw_part_b = nullptr;
+    size_t bytes = 0;
+};
+
+// Builds kernel parameters and carves the workspace.  ws == nullptr: size query only.
+int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
+    RolloutParams& p = plan.p;
+    memset(&p, 0, sizeof(p));
+    const GopsEnv& e = desc.env;
+    if (desc.batch < 1 || desc.horizon < 1 || desc.horizon > GOPS_MAX_HORIZON) return GOPS_ERR_BAD_ARG;
+    if (e.kind < GOPS_ENV_NONE || e.kind > GOPS_ENV_VEH3DOFCONTI) return GOPS_ERR_BAD_ARG;
+    if (e.obs_dim < 1) return GOPS_ERR_BAD_ARG;
+    const int pol_out = (e.kind == GOPS_ENV_NONE) ? 1 : e.act_dim;
+    int rc = check_mlp(desc.policy, e.obs_dim + (desc.finite_horizon ? 1 : 0), pol_out);
+    if (rc != GOPS_OK) return rc;
+    if (desc.tail_value && (rc = check_mlp(desc.value, e.obs_dim, 1)) != GOPS_OK) return rc;
+    if (e.kind == GOPS_ENV_NONE && (desc.horizon != 1 || desc.tail_value || desc.finite_horizon)) return GOPS_ERR_BAD_ARG;
+    if (e.kind == GOPS_ENV_LQ && (e.obs_dim > GOPS_MAX_LQ_STATE || e.act_dim > GOPS_MAX_ACT)) return GOPS_ERR_UNSUPPORTED;
+    if (e.kind == GOPS_ENV_IDPENDULUM && (e.obs_dim != 6 || e.act_dim != 1 || e.clip_obs)) return GOPS_ERR_BAD_ARG;
+    if (e.kind == GOPS_ENV_VEH3DOFCONTI &&
+        (e.act_dim != 2 || e.pre_horizon < 1 || e.obs_dim != 6 + 4 * e.pre_horizon || e.clip_obs))
+        return GOPS_ERR_BAD_ARG;
+    if (e.clip_obs && e.obs_dim > 8) return GOPS_ERR_UNSUPPORTED;
+
+    p.B = desc.batch;
+    p.H = desc.horizon;
+    p.fh = desc.finite_horizon ? 1 : 0;
+    p.need_grad = desc.need_grad ? 1 : 0;
+    p.tail = desc.tail_value ? 1 : 0;
+    p.env = e;
+    fill_mlp(p.pol, desc.policy);
+    if (p.tail) fill_mlp(p.val, desc.value);
+    int kp0 = p.pol.kp[0], hmax = 16;
+    if (p.tail && p.val.kp[0] > kp0) kp0 = p.val.kp[0];
+    for (int j = 1; j < p.pol.nl; ++j) hmax = p.pol.dims[j] > hmax ? p.pol.dims[j] : hmax;
+    if (p.tail)
+        for (int j = 1; j < p.val.nl; ++j) hmax = p.val.dims[j] > hmax ? p.val.dims[j] : hmax;
+    p.ldx = kp0 + 4;
+    p.ldh = hmax + 4;
+    if (rollout_fwd_lds_bytes(p.ldx, p.ldh) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh) > 160 * 1024)
+        return GOPS_ERR_UNSUPPORTED;
+    for (int t = 0; t <= p.H; ++t) p.gpow[t] = (float)pow(desc.gamma, (double)t);
+
+    Carver c(ws);
+    carve_packs(c, p.pol);
+    if (p.tail) carve_packs(c, p.val);
+    const long long S = (long long)p.B * p.H;
+    if (e.kind == GOPS_ENV_VEH3DOFCONTI) p.ref_table = c.take((size_t)p.B * (e.pre_horizon + 1 + p.H) * 4);
+    if (p.need_grad) {
+        const bool gelu = p.pol.act == GOPS_ACT_GELU;
+        p.st.x = c.take((size_t)S * p.pol.kp[0]);
+        for (int j = 1; j < p.pol.nl; ++j) {
+            p.st.h[j] = c.take((size_t)S * p.pol.dims[j]);
+            p.st.d[j] = c.take((size_t)S * p.pol.dims[j]);
+            if (gelu) p.st.z[j] = c.take((size_t)S * p.pol.dims[j]);
+        }
+        p.st.dy = c.take((size_t)S * 4);
+        p.st.env = c.take((size_t)S * ENV_STASH);
+        if (p.tail) {
+            for (int j = 1; j < p.val.nl; ++j) {
+                p.st.tail_h[j] = c.take((size_t)p.B * p.val.dims[j]);
+                if (p.val.act == GOPS_ACT_GELU) p.st.tail_z[j] = c.take((size_t)p.B * p.val.dims[j]);
+            }
+        }
+        p.st.tail_done = c.take((size_t)p.B);
+        // scratch for split-K partials of the weight-gradient GEMMs (largest layer)
+        size_t part = 0, part_b = 0;
+        for (int j = 0; j < p.pol.nl - 1; ++j) {
+            const DwPlan d = plan_dw(p.pol.dims[j + 1], p.pol.kp[j], S);
+            const size_t n = (size_t)d.splits * p.pol.dims[j + 1] * p.pol.kp[j];
+            part = n > part ? n : part;
+            const size_t nb = (size_t)d.splits * p.pol.dims[j + 1];
+            part_b = nb > part_b ? nb : part_b;
+        }
+        const size_t nout = (size_t)DW_OUT_SPLITS * GOPS_MAX_ACT * p.pol.dims[p.pol.nl - 1];
+        part = nout > part ? nout : part;
+        part_b = (size_t)DW_OUT_SPLITS * GOPS_MAX_ACT > part_b ? (size_t)DW_OUT_SPLITS * GOPS_MAX_ACT : part_b;
+        plan.dw_part = c.take(part);
+        plan.dw_part_b = c.take(part_b);
+    }
+    plan.bytes = c.off + kAlign;
+    return GOPS_OK;
+}
+
+int pack_all(const MlpDev& d, hipStream_t s) {
+    for (int j = 0; j < d.nl - 1; ++j) {
+        hipError_t e = launch_pack(d.w[j], d.dims[j + 1], d.dims[j], d.kp[j],
+                                   const_cast<float*>(reinterpret_cast<const float*>(d.wp[j])),
+                                   const_cast<float*>(reinterpret_cast<const float*>(d.wpt[j])), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    return GOPS_OK;
+}
+
+float pdt_of(const GopsEnv& e) { return (float)((double)e.pre_horizon * 0.1); }
+
+int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const GopsRolloutOut& out,
+                void* ws, size_t ws_bytes, hipStream_t s) {
+    Plan plan;
+    int rc = build_plan(desc, ws, plan);
+    if (rc != GOPS_OK) return rc;
+    if (ws == nullptr || ws_bytes < plan.bytes) return GOPS_ERR_WORKSPACE;
+    if (in.obs == nullptr || out.v_pi == nullptr) return GOPS_ERR_BAD_ARG;
+    if (desc.env.kind == GOPS_ENV_VEH3DOFCONTI &&
+        (!in.state || !in.ref_points || !in.path_num || !in.u_num || !in.ref_time)) return GOPS_ERR_BAD_ARG;
+    RolloutParams& p = plan.p;
+    p.in = in;
+    p.out = out;
+    if ((rc = pack_all(p.pol, s)) != GOPS_OK) return rc;
+    if (p.tail && (rc = pack_all(p.val, s)) != GOPS_OK) return rc;
+    if (desc.env.kind == GOPS_ENV_VEH3DOFCONTI) {
+        hipError_t e = launch_ref_table(p.B, desc.env.pre_horizon, p.H, in, pdt_of(desc.env),
+                                        const_cast<float*>(p.ref_table), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    ProfScope scope(0, s);
+    return (int)launch_rollout_fwd(p, s);
+}
+
+int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const float* grad_v,
+                 const GopsMlpGrad& grad, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!desc.need_grad || grad_v == nullptr) return GOPS_ERR_BAD_ARG;
+    Plan plan;
+    int rc = build_plan(desc, ws, plan);
+    if (rc != GOPS_OK) return rc;
+    if (ws == nullptr || ws_bytes < plan.bytes) return GOPS_ERR_WORKSPACE;
+    RolloutParams& p = plan.p;
+    p.in = in;
+    p.grad_v = grad_v;
+    for (int j = 0; j < p.pol.nl; ++j)
+        if (grad.weight[j] == nullptr || grad.bias[j] == nullptr) return GOPS_ERR_BAD_ARG;
+    hipError_t e;
+    {
+        ProfScope scope(1, s);
+        if ((e = launch_rollout_bwd(p, s)) != hipSuccess) return (int)e;
+    }
+    ProfScope scope(2, s);
+    const long long S = (long long)p.B * p.H;
+    const int L = p.pol.nl - 1;
+    for (int j = 0; j < L; ++j) {   // dW_j = D_{j+1}^T * (j == 0 ? X : H_j)
+        const int N = p.pol.dims[j + 1], Kp = p.pol.kp[j], K = p.pol.dims[j];
+        const DwPlan d = plan_dw(N, Kp, S);
+        const float* X = (j == 0) ? p.st.x : p.st.h[j];
+        if ((e = launch_dw_gemm(p.st.d[j + 1], N, X, Kp, S, d.splits, d.chunks_per_split, plan.dw_part,
+                                plan.dw_part_b, d.big, s)) != hipSuccess) return (int)e;
+        if ((e = launch_reduce(plan.dw_part, d.splits, N, K, Kp, grad.weight[j], s)) != hipSuccess) return (int)e;
+        if ((e = launch_reduce(plan.dw_part_b, d.splits, 1, N, N, grad.bias[j], s)) != hipSuccess) return (int)e;
+    }
+    {
+        const int K = p.pol.dims[L], A = p.pol.dims[p.pol.nl];
+        long long splits = DW_OUT_SPLITS;
+        if (splits > S) splits = S;
+        if ((e = launch_dw_out(p.st.dy, p.st.h[L], K, A, S, (int)splits, plan.dw_part, plan.dw_part_b, s)) != hipSuccess) return (int)e;
+        if ((e = launch_reduce(plan.dw_part, (int)splits, A, K, K, grad.weight[L], s)) != hipSuccess) return (int)e;
+        if ((e = launch_reduce(plan.dw_part_b, (int)splits, 1, A, A, grad.bias[L], s)) != hipSuccess) return (int)e;
+    }
+    return GOPS_OK;
+}
+
+GopsRolloutDesc value_desc(const GopsMlp& value, int batch) {
+    GopsRolloutDesc d;
+    memset(&d, 0, sizeof(d));
+    d.batch = batch;
+    d.horizon = 1;
+    d.need_grad = 1;
+    d.gamma = 1.0;
+    d.env.kind = GOPS_ENV_NONE;
+    d.env.obs_dim = value.sizes[0];
+    d.env.act_dim = 1;
+    d.policy = value;
+    return d;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gops_hip_version(void) { return GOPS_HIP_ABI_VERSION; }
+
+size_t gops_rollout_workspace_bytes(const GopsRolloutDesc* desc) {
+    if (desc == nullptr) return 0;
+    Plan plan;
+    if (build_plan(*desc, nullptr, plan) != GOPS_OK) return 0;
+    return plan.bytes;
+}
+
+int gops_rollout_forward(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const GopsRolloutOut* out,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (!desc || !in || !out) return GOPS_ERR_BAD_ARG;
+    return run_forward(*desc, *in, *out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int gops_rollout_backward(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const float* grad_v,
+                          const GopsMlpGrad* policy_grad, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    if (!desc || !in || !policy_grad) return GOPS_ERR_BAD_ARG;
+    return run_backward(*desc, *in, grad_v, *policy_grad, workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream));
+}
+
+int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream) {
+    if (!env || !io || batch < 1) return GOPS_ERR_BAD_ARG;
+    if (env->kind < GOPS_ENV_LQ || env->kind > GOPS_ENV_VEH3DOFCONTI) return GOPS_ERR_BAD_ARG;
+    if (!io->obs || !io->action || !io->next_obs || !io->reward || !io->next_done) return GOPS_ERR_BAD_ARG;
+    if (env->kind == GOPS_ENV_VEH3DOFCONTI &&
+        (!io->state || !io->ref_points || !io->path_num || !io->u_num || !io->ref_time ||
+         !io->next_state || !io->next_ref_points || !io->next_ref_time)) return GOPS_ERR_BAD_ARG;
+    if (env->kind == GOPS_ENV_LQ && env->obs_dim > GOPS_MAX_LQ_STATE) return GOPS_ERR_UNSUPPORTED;
+    return (int)launch_env_step(*env, batch, *io, pdt_of(*env), static_cast<hipStream_t>(stream));
+}
+
+size_t gops_value_workspace_bytes(const GopsMlp* value, int32_t batch) {
+    if (!value) return 0;
+    const GopsRolloutDesc d = value_desc(*value, batch);
+    return gops_rollout_workspace_bytes(&d);
+}
+
+int gops_value_forward(const GopsMlp* value, int32_t batch, const float* obs, float* v, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (!value || !obs || !v) return GOPS_ERR_BAD_ARG;
+    const GopsRolloutDesc d = value_desc(*value, batch);
+    GopsRolloutIn in;
+    memset(&in, 0, sizeof(in));
+    in.obs = obs;
+    GopsRolloutOut out;
+    memset(&out, 0, sizeof(out));
+    out.v_pi = v;
+    return run_forward(d, in, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int gops_value_backward(const GopsMlp* value, int32_t batch, const float* obs, const float* grad_v,
+                        const GopsMlpGrad* grad, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!value || !obs || !grad_v || !grad) return GOPS_ERR_BAD_ARG;
+    const GopsRolloutDesc d = value_desc(*value, batch);
+    GopsRolloutIn in;
+    memset(&in, 0, sizeof(in));
+    in.obs = obs;
+    return run_backward(d, in, grad_v, *grad, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+void gops_profile_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.on = on != 0;
+}
+
+void gops_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (auto& v : g_prof.ev) {
+        for (auto& pr : v) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        v.clear();
+    }
+}
+
+int gops_profile_read(int32_t kernel_id, double* avg_ms, int64_t* launches) {
+    if (kernel_id < 0 || kernel_id > 2 || !avg_ms || !launches) return GOPS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    double tot = 0.0;
+    int64_t n = 0;
+    for (auto& pr : g_prof.ev[kernel_id]) {
+        if (hipEventSynchronize(pr.second) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            tot += ms;
+            ++n;
+        }
+    }
+    *avg_ms = n ? tot / n : 0.0;
+    *launches = n;
+    return GOPS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,359 @@
+// Support kernels around the rollout: MFMA-fragment weight packing, the veh3dofconti reference
+// table, the weight-gradient GEMMs (dW = delta^T * input over all B*H samples), partial-sum
+// reduction, and the single-step env-model entry point.
+#include "common.h"
+#include "env_models.h"
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing.  For Linear layer W [N][K] (torch layout):
+//   fwd:  element ((nt*kch + c)*64 + lane)*4 + i  =  W[16nt + (lane&15)][16c + 4(lane>>4) + i]
+//   bwd:  element ((nt*kch + c)*64 + lane)*4 + i  =  W[16c + 4(lane>>4) + i][16nt + (lane&15)]
+// (zero where the input index is in the padding), so that lane `lane` fetches with one dwordx4 the
+// B operands of four consecutive v_mfma_f32_16x16x4_f32.
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ W, int N, int K, int Kp,
+                                    float* __restrict__ wp, float* __restrict__ wpt) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * Kp) return;
+    const int i = e & 3, lane = (e >> 2) & 63, blk = e >> 8;
+    {   // forward: n tiles over N, chunks over Kp
+        const int kch = Kp >> 4, nt = blk / kch, c = blk - nt * kch;
+        const int n = 16 * nt + (lane & 15), k = 16 * c + 4 * (lane >> 4) + i;
+        wp[e] = (k < K) ? W[(size_t)n * K + k] : 0.f;
+    }
+    {   // backward: n tiles over Kp (input index), chunks over N (output index)
+        const int kch = N >> 4, nt = blk / kch, c = blk - nt * kch;
+        const int kin = 16 * nt + (lane & 15), nout = 16 * c + 4 * (lane >> 4) + i;
+        wpt[e] = (kin < K) ? W[(size_t)nout * K + kin] : 0.f;
+    }
+}
+
+hipError_t launch_pack(const float* W, int N, int K, int Kp, float* wp, float* wpt, hipStream_t s) {
+    const int total = N * Kp;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, W, N, K, Kp, wp, wpt);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reference trajectories of pyth_veh3dofconti (ref_traj_model.py:26-232).  Every operation is
+// rounded separately in fp32, in the reference's order (no FMA contraction): the heading is a
+// 1 ms finite difference whose cancellation noise is part of the reference's result.
+// ---------------------------------------------------------------------------------------------
+#define RMUL(a, b) __fmul_rn((a), (b))
+#define RADD(a, b) __fadd_rn((a), (b))
+#define RSUB(a, b) __fsub_rn((a), (b))
+
+__device__ __forceinline__ float ref_arc(float t, int u_num) {
+    const float W = (float)(2.0 * 3.14159265358979323846 / 10.0);
+    if (u_num == 0) {
+        const float c1 = (float)(-1.0 / (2.0 * 3.14159265358979323846 / 10.0));
+        const float c2 = (float)(1.0 / (2.0 * 3.14159265358979323846 / 10.0));
+        return RADD(RADD(RMUL(c1, cosf(RMUL(W, t))), RMUL(5.0f, t)), c2);
+    }
+    return RMUL(5.0f, t);
+}
+
+__device__ __forceinline__ void ref_xy(float t, int path, int u_num, float& x, float& y) {
+    const float W = (float)(2.0 * 3.14159265358979323846 / 10.0);
+    const float s = ref_arc(t, u_num);
+    if (path == 0) {
+        x = s;
+        y = RMUL(1.5f, sinf(RMUL(W, t)));
+    } else if (path == 1) {
+        x = s;
+        if (t <= 5.0f) y = 0.f;
+        else if (t <= 9.0f) y = RADD(RMUL(0.875f, RSUB(t, 5.0f)), 0.f);
+        else if (t <= 14.0f) y = 3.5f;
+        else if (t <= 18.0f) y = RADD(RMUL(-0.875f, RSUB(t, 14.0f)), 3.5f);
+        else y = 0.f;
+    } else if (path == 2) {
+        x = s;
+        float sm = fmodf(t, 10.0f);
+        if (sm < 0.f) sm += 10.0f;
+        if (sm <= 5.0f) y = RMUL(0.6f, sm);
+        else if (sm < 10.0f) y = RMUL(-0.6f, RSUB(sm, 10.0f));
+        else y = 0.f;
+    } else {
+        const float q = s / 100.0f;
+        x = RMUL(100.0f, sinf(q));
+        y = RMUL(100.0f, RSUB(cosf(q), 1.0f));
+    }
+}
+
+__device__ __forceinline__ f32x4 ref_point(float t, int path, int u_num) {
+    const float W = (float)(2.0 * 3.14159265358979323846 / 10.0);
+    float x0, y0, x1, y1;
+    ref_xy(t, path, u_num, x0, y0);
+    ref_xy(RADD(t, 0.001f), path, u_num, x1, y1);
+    const float phi = atan2f(RSUB(y1, y0), RSUB(x1, x0));
+    const float u = (u_num == 0) ? RADD(sinf(RMUL(W, t)), 5.0f) : 5.0f;
+    f32x4 r = {x0, y0, phi, u};
+    return r;
+}
+
+// table[b][i] : i <= P copies info["ref_points"][b][i]; i = P + s (s >= 1) is the point the model
+// appends at rollout step s-1: evaluated at (t0 + s*dt accumulated in fp32) + P*dt.
+__global__ void ref_table_kernel(int B, int P, int H, const float* __restrict__ ref_points,
+                                 const float* __restrict__ path_num, const float* __restrict__ u_num,
+                                 const float* __restrict__ ref_time, float pdt, float* __restrict__ table) {
+    const int TL = P + 1 + H;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * TL) return;
+    const int b = idx / TL, i = idx - b * TL;
+    f32x4 v;
+    if (i <= P) {
+        v = reinterpret_cast<const f32x4*>(ref_points)[(size_t)b * (P + 1) + i];
+    } else {
+        float t = ref_time[b];
+        for (int s = 0; s < i - P; ++s) t = RADD(t, 0.1f);
+        const float pn = path_num[b], un = u_num[b];
+        const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : (pn == 3.f) ? 3 : -1;
+        const int us = (un == 0.f) ? 0 : (un == 1.f) ? 1 : -1;
+        if (path < 0 || us < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};   // ids outside the registered sets
+        else v = ref_point(RADD(t, pdt), path, us);
+    }
+    reinterpret_cast<f32x4*>(table)[idx] = v;
+}
+
+hipError_t launch_ref_table(int B, int P, int H, const GopsRolloutIn& in, float pdt, float* table,
+                            hipStream_t s) {
+    const int total = B * (P + 1 + H);
+    hipLaunchKernelGGL(ref_table_kernel, dim3((total + 255) / 256), dim3(256), 0, s, B, P, H,
+                       in.ref_points, in.path_num, in.u_num, in.ref_time, pdt, table);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// dW GEMM:  part[split][n][k] = sum_{s in split} D[s][n] * X[s][k]      (n < N, k < Kp)
+// Workgroup tile (32R x 32R) outputs, 2x2 waves, each wave R x R MFMA 16x16 tiles, samples staged
+// through LDS 32 at a time with a register prefetch of the next chunk.  Workgroups whose k-tile is
+// 0 also accumulate the bias gradient (column sums of D).
+// ---------------------------------------------------------------------------------------------
+#define DW_SC 32   // samples per staged chunk
+
+template <int R>
+__global__ __launch_bounds__(NTHREADS) void dw_gemm_kernel(const float* __restrict__ D, int N,
+                                                           const float* __restrict__ X, int Kp,
+                                                           long long S, int chunks_per_split,
+                                                           float* __restrict__ part,
+                                                           float* __restrict__ part_b) {
+    constexpr int T = 32 * R;          // tile edge
+    constexpr int LD = T + 16;         // (LD % 32 == 16): conflict-free ds_read_b32 fragments
+    constexpr int V = (DW_SC * T / 4) / NTHREADS;   // float4 per thread per operand per chunk
+    __shared__ __attribute__((aligned(16))) float Ds[DW_SC * LD];
+    __shared__ __attribute__((aligned(16))) float Xs[DW_SC * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_k = (Kp + T - 1) / T;
+    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+    const int n0 = tile_n * T, k0 = tile_k * T;
+    const int split = blockIdx.y;
+    const long long s_begin = (long long)split * chunks_per_split * DW_SC;
+    const int wn = wave >> 1, wk = wave & 1;
+
+    f32x4 acc[R][R] = {};
+    float bsum = 0.f;
+    f32x4 dreg[V], xreg[V];
+
+    auto gload = [&](long long s0) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const int idx = tid + q * NTHREADS;
+            const int row = idx / (T / 4), c4 = idx - row * (T / 4);
+            const long long s = s0 + row;
+            const int n = n0 + 4 * c4, k = k0 + 4 * c4;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            dreg[q] = (s < S && n < N) ? *reinterpret_cast<const f32x4*>(D + s * N + n) : z;
+            xreg[q] = (s < S && k < Kp) ? *reinterpret_cast<const f32x4*>(X + s * Kp + k) : z;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const int idx = tid + q * NTHREADS;
+            const int row = idx / (T / 4), c4 = idx - row * (T / 4);
+            *reinterpret_cast<f32x4*>(Ds + row * LD + 4 * c4) = dreg[q];
+            *reinterpret_cast<f32x4*>(Xs + row * LD + 4 * c4) = xreg[q];
+        }
+    };
+
+    gload(s_begin);
+    for (int c = 0; c < chunks_per_split; ++c) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (c + 1 < chunks_per_split) gload(s_begin + (long long)(c + 1) * DW_SC);
+        if (part_b != nullptr && tile_k == 0 && tid < T) {
+#pragma unroll
+            for (int r = 0; r < DW_SC; ++r) bsum += Ds[r * LD + tid];
+        }
+        const float* dbase = Ds + (lane >> 4) * LD + wn * 16 * R + (lane & 15);
+        const float* xbase = Xs + (lane >> 4) * LD + wk * 16 * R + (lane & 15);
+#pragma unroll
+        for (int kk = 0; kk < DW_SC / 4; ++kk) {
+            float a[R], b[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) a[i] = dbase[kk * 4 * LD + 16 * i];
+#pragma unroll
+            for (int j = 0; j < R; ++j) b[j] = xbase[kk * 4 * LD + 16 * j];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* pbase = part + (size_t)split * N * Kp;
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int k = k0 + wk * 16 * R + 16 * j + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 16 * R + 16 * i + 4 * (lane >> 4) + r;
+                if (n < N && k < Kp) pbase[(size_t)n * Kp + k] = acc[i][j][r];
+            }
+        }
+    if (part_b != nullptr && tile_k == 0 && tid < T && n0 + tid < N) part_b[(size_t)split * N + n0 + tid] = bsum;
+}
+
+hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
+                          int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s) {
+    if (big) {
+        const int T = 128, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
+        hipLaunchKernelGGL(dw_gemm_kernel<4>, dim3(tiles, splits), dim3(NTHREADS), 0, s, D, N, X, Kp, S,
+                           chunks_per_split, part, part_b);
+    } else {
+        const int T = 64, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
+        hipLaunchKernelGGL(dw_gemm_kernel<2>, dim3(tiles, splits), dim3(NTHREADS), 0, s, D, N, X, Kp, S,
+                           chunks_per_split, part, part_b);
+    }
+    return hipGetLastError();
+}
+
+// Output layer (width A <= 4) on the VALU: part[split][a][k] = sum_s dy[s][a] * h[s][k].
+__global__ __launch_bounds__(NTHREADS) void dw_out_kernel(const float* __restrict__ dy,
+                                                          const float* __restrict__ h, int K, int A,
+                                                          long long S, long long per_split,
+                                                          float* __restrict__ part, float* __restrict__ part_b) {
+    const int split = blockIdx.x;
+    const long long s0 = split * per_split, s1 = min(S, s0 + per_split);
+    for (int k = threadIdx.x; k < K; k += NTHREADS) {
+        float acc[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, accb[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
+        for (long long s = s0; s < s1; ++s) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + s * 4);
+            const float hv = h[s * K + k];
+#pragma unroll
+            for (int a = 0; a < GOPS_MAX_ACT; ++a) { acc[a] += g[a] * hv; accb[a] += g[a]; }
+        }
+        for (int a = 0; a < A; ++a) part[((size_t)split * A + a) * K + k] = acc[a];
+        if (k == 0)
+            for (int a = 0; a < A; ++a) part_b[(size_t)split * A + a] = accb[a];
+    }
+}
+
+hipError_t launch_dw_out(const float* dy, const float* h, int K, int A, long long S, int splits,
+                         float* part, float* part_b, hipStream_t s) {
+    const long long per = (S + splits - 1) / splits;
+    hipLaunchKernelGGL(dw_out_kernel, dim3(splits), dim3(NTHREADS), 0, s, dy, h, K, A, S, per, part, part_b);
+    return hipGetLastError();
+}
+
+// out[r][c] = sum_split part[split][r][c]   for c < cols (row stride `ld` inside a split)
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int splits, int rows, int cols,
+                                       int ld, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int r = idx / cols, c = idx - r * cols;
+    const size_t stride = (size_t)rows * ld;
+    const float* p = part + (size_t)r * ld + c;
+    float acc = 0.f;
+    for (int s = 0; s < splits; ++s) acc += p[s * stride];
+    out[idx] = acc;
+}
+
+hipError_t launch_reduce(const float* part, int splits, int rows, int cols, int ld, float* out, hipStream_t s) {
+    const int total = rows * cols;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, splits,
+                       rows, cols, ld, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single wrapped env-model step (pyth_base_model.py:59-67 contract), one thread per trajectory.
+// ---------------------------------------------------------------------------------------------
+__global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, float pdt) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int O = env.obs_dim, A = env.act_dim;
+    float u[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < A; ++a) u[a] = wrap_action(env, a, io.action[(size_t)b * A + a]);
+    const bool dn = io.done != nullptr && io.done[b] != 0.f;
+    float r = 0.f;
+    bool done_m = false;
+    const float* ob = io.obs + (size_t)b * O;
+    float* nob = io.next_obs + (size_t)b * O;
+    if (env.kind == GOPS_ENV_LQ) {
+        float x[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xn[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < O; ++i) x[i] = ob[i];
+        lq_forward(env, x, u, xn, r);
+        for (int i = 0; i < O; ++i) {
+            const float v = dn ? x[i] : xn[i];
+            nob[i] = env.clip_obs ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
+        }
+    } else if (env.kind == GOPS_ENV_IDPENDULUM) {
+        const IdpConst IC = idp_const();
+        float s[6], sn[6], s0[6];
+        for (int i = 0; i < 6; ++i) s0[i] = s[i] = ob[i];
+        IdpSub w;
+        for (int k = 0; k < 5; ++k) {
+            idp_substep(IC, s, 500.f * u[0], 0.002f, sn, w);
+            for (int i = 0; i < 6; ++i) s[i] = sn[i];
+        }
+        r = idp_reward(s, u[0]);
+        done_m = idp_done(IC, s);
+        for (int i = 0; i < 6; ++i) nob[i] = dn ? s0[i] : s[i];
+    } else if (env.kind == GOPS_ENV_VEH3DOFCONTI) {
+        const VehConst VC = veh_const();
+        const int P = env.pre_horizon;
+        float s[6], sn[6], o6[6];
+        for (int i = 0; i < 6; ++i) { s[i] = io.state[(size_t)b * 6 + i]; o6[i] = ob[i]; }
+        VehStep w;
+        veh_f_xu(VC, s, u[0], u[1], sn, w);
+        r = veh_reward(o6, u[0], u[1]);
+        const float nt = RADD(io.ref_time[b], 0.1f);
+        const float pn = io.path_num[b], un = io.u_num[b];
+        const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : 3;
+        const f32x4 newp = ref_point(RADD(nt, pdt), path, un == 0.f ? 0 : 1);
+        const f32x4* rin = reinterpret_cast<const f32x4*>(io.ref_points) + (size_t)b * (P + 1);
+        f32x4* rout = reinterpret_cast<f32x4*>(io.next_ref_points) + (size_t)b * (P + 1);
+        float cn, snn;
+        sincosf(-sn[2], &snn, &cn);
+        for (int j = 0; j <= P; ++j) {
+            const f32x4 rp = (j < P) ? rin[j + 1] : newp;
+            rout[j] = rp;
+            const float dx = rp[0] - sn[0], dy = rp[1] - sn[1];
+            const float xtf = dx * cn - dy * snn, ytf = dx * snn + dy * cn;
+            const float ptf = angle_normalize(rp[2] - sn[2]), utf = rp[3] - sn[3];
+            if (j == 0) {
+                done_m = (fabsf(xtf) > 10.f) || (fabsf(ytf) > 10.f) || (fabsf(ptf) > 3.14159265358979323846f);
+                if (!dn) { nob[0] = xtf; nob[1] = ytf; nob[2] = ptf; nob[3] = utf; nob[4] = sn[4]; nob[5] = sn[5]; }
+            } else if (!dn) {
+                float* d = nob + 6 + 4 * (j - 1);
+                d[0] = xtf; d[1] = ytf; d[2] = ptf; d[3] = utf;
+            }
+        }
+        if (dn) for (int i = 0; i < O; ++i) nob[i] = ob[i];
+        for (int i = 0; i < 6; ++i) io.next_state[(size_t)b * 6 + i] = sn[i];
+        io.next_ref_time[b] = nt;
+    }
+    float rr = dn ? 0.f : r;
+    if (env.shaping) rr = (rr + env.reward_shift) * env.reward_scale;
+    io.reward[b] = rr;
+    io.next_done[b] = (dn || done_m) ? 1.f : 0.f;
+}
+
+hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s) {
+    hipLaunchKernelGGL(env_step_kernel, dim3((B + 127) / 128), dim3(128), 0, s, env, B, io, pdt);
+    return hipGetLastError();
+}

@@ -1,0 +1,212 @@
+// Per-trajectory env-model arithmetic (device), forward and hand-derived adjoints.
+//   pyth_lq            gops/env/env_ocp/resources/lq_base.py:89-141,343-354
+//   pyth_idpendulum    gops/env/env_ocp/env_model/pyth_idpendulum_model.py:31-172,199-216
+//   pyth_veh3dofconti  gops/env/env_ocp/env_model/pyth_veh3dofconti_model.py:25-61,147-203
+#pragma once
+#include "common.h"
+
+// ================================ pyth_lq =====================================================
+// x' = inv_IA (x + dt B u);  r = rs * (rsh - (sum Q x^2 + sum R u^2)) on the CURRENT x.
+__device__ __forceinline__ void lq_forward(const GopsEnv& e, const float* x, const float* u,
+                                           float* xn, float& r) {
+    const int n = e.obs_dim, m = e.act_dim;
+    float tmp[GOPS_MAX_LQ_STATE];
+#pragma unroll
+    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) {
+        if (i < n) {
+            float bu = 0.f;
+            for (int j = 0; j < m; ++j) bu += e.lq_B[i * m + j] * u[j];
+            tmp[i] = bu * e.lq_dt + x[i];
+        }
+    }
+    float rs = 0.f, ra = 0.f;
+#pragma unroll
+    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) {
+        if (i < n) {
+            float acc = 0.f;
+            for (int k = 0; k < n; ++k) acc += e.lq_inv_IA[i * n + k] * tmp[k];
+            xn[i] = acc;
+            rs += x[i] * x[i] * e.lq_Q[i];
+        }
+    }
+    for (int j = 0; j < m; ++j) ra += u[j] * u[j] * e.lq_R[j];
+    r = e.lq_reward_scale * (e.lq_reward_shift - 1.0f * (rs + ra));
+}
+
+// adjoints: gxn (adjoint of x'), gr (adjoint of r) -> gx (accumulated), gu (overwritten)
+__device__ __forceinline__ void lq_backward(const GopsEnv& e, const float* x, const float* u,
+                                            const float* gxn, float gr, float* gx, float* gu) {
+    const int n = e.obs_dim, m = e.act_dim;
+    float gt[GOPS_MAX_LQ_STATE];
+#pragma unroll
+    for (int k = 0; k < GOPS_MAX_LQ_STATE; ++k) {
+        if (k < n) {
+            float acc = 0.f;
+            for (int i = 0; i < n; ++i) acc += e.lq_inv_IA[i * n + k] * gxn[i];
+            gt[k] = acc;
+            gx[k] += acc + gr * e.lq_reward_scale * (-2.f * e.lq_Q[k] * x[k]);
+        }
+    }
+    for (int j = 0; j < m; ++j) {
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) acc += e.lq_B[i * m + j] * gt[i];
+        gu[j] = acc * e.lq_dt + gr * e.lq_reward_scale * (-2.f * e.lq_R[j] * u[j]);
+    }
+}
+
+// ================================ pyth_idpendulum =============================================
+struct IdpConst {   // products of the Python-double constants, rounded once like torch does
+    float a, b, e, f, h, k, gb, ge, l1, l2;
+};
+__device__ __forceinline__ IdpConst idp_const() {
+    const double m = 9.42477796, m1 = 4.1033127, m2 = 4.1033127, l1 = 0.6, l2 = 0.6, g = 9.81;
+    IdpConst c;
+    c.a = (float)(m + m1 + m2);
+    c.b = (float)(l1 * (0.5 * m1 + m2));
+    c.e = (float)(0.5 * m2 * l2);
+    c.f = (float)(l1 * l1 * (0.3333 * m1 + m2));
+    c.h = (float)(0.5 * l1 * l2 * m2);
+    c.k = (float)(0.3333 * l2 * l2 * m2);
+    c.gb = (float)(g * (0.5 * m1 + m2) * l1);
+    c.ge = (float)(g * 0.5 * l2 * m2);
+    c.l1 = (float)l1;
+    c.l2 = (float)l2;
+    return c;
+}
+
+struct IdpSub {     // intermediates of one sub-step that the adjoint re-uses
+    float s1, c1, s2, c2, s12, c12;
+    float inv[6];   // symmetric M^-1: 00 01 02 11 12 22
+    float qdd[3];
+};
+
+__device__ __forceinline__ void idp_substep(const IdpConst& C, const float* s, float u, float tau,
+                                            float* sn, IdpSub& w) {
+    const float th1 = s[1], th2 = s[2], th1d = s[4], th2d = s[5];
+    sincosf(th1, &w.s1, &w.c1);
+    sincosf(th2, &w.s2, &w.c2);
+    sincosf(th1 - th2, &w.s12, &w.c12);
+    const float m00 = C.a, m01 = C.b * w.c1, m02 = C.e * w.c2, m11 = C.f, m12 = C.h * w.c12, m22 = C.k;
+    const float f0 = C.b * (th1d * th1d) * w.s1 + C.e * (th2d * th2d) * w.s2 + u;
+    const float f1 = -C.h * (th2d * th2d) * w.s12 + C.gb * w.s1;
+    const float f2 = C.h * (th1d * th1d) * w.s12 + C.ge * w.s2;
+    const float c00 = m11 * m22 - m12 * m12;
+    const float c01 = m02 * m12 - m01 * m22;
+    const float c02 = m01 * m12 - m02 * m11;
+    const float c11 = m00 * m22 - m02 * m02;
+    const float c12 = m01 * m02 - m00 * m12;
+    const float c22 = m00 * m11 - m01 * m01;
+    const float rdet = 1.f / (m00 * c00 + m01 * c01 + m02 * c02);
+    w.inv[0] = c00 * rdet; w.inv[1] = c01 * rdet; w.inv[2] = c02 * rdet;
+    w.inv[3] = c11 * rdet; w.inv[4] = c12 * rdet; w.inv[5] = c22 * rdet;
+    w.qdd[0] = w.inv[0] * f0 + w.inv[1] * f1 + w.inv[2] * f2;
+    w.qdd[1] = w.inv[1] * f0 + w.inv[3] * f1 + w.inv[4] * f2;
+    w.qdd[2] = w.inv[2] * f0 + w.inv[4] * f1 + w.inv[5] * f2;
+    sn[0] = s[0] + tau * s[3];
+    sn[1] = s[1] + tau * s[4];
+    sn[2] = s[2] + tau * s[5];
+    sn[3] = s[3] + tau * w.qdd[0];
+    sn[4] = s[4] + tau * w.qdd[1];
+    sn[5] = s[5] + tau * w.qdd[2];
+}
+
+// adjoint of one sub-step: g (adjoint of sn, overwritten with adjoint of s), gu accumulated
+__device__ __forceinline__ void idp_substep_bwd(const IdpConst& C, const float* s, float tau,
+                                                const IdpSub& w, float* g, float& gu) {
+    const float th1d = s[4], th2d = s[5];
+    const float q0 = tau * g[3], q1 = tau * g[4], q2 = tau * g[5];       // adjoint of qdd
+    const float fb0 = w.inv[0] * q0 + w.inv[1] * q1 + w.inv[2] * q2;    // adjoint of f = M^-1 q
+    const float fb1 = w.inv[1] * q0 + w.inv[3] * q1 + w.inv[4] * q2;
+    const float fb2 = w.inv[2] * q0 + w.inv[4] * q1 + w.inv[5] * q2;
+    // Mbar_ij = -fb_i qdd_j ; only the cos-dependent entries matter
+    const float cb1 = -C.b * (fb0 * w.qdd[1] + fb1 * w.qdd[0]);
+    const float cb2 = -C.e * (fb0 * w.qdd[2] + fb2 * w.qdd[0]);
+    const float cb12 = -C.h * (fb1 * w.qdd[2] + fb2 * w.qdd[1]);
+    gu += fb0;
+    float th1db = fb0 * C.b * 2.f * th1d * w.s1 + fb2 * C.h * 2.f * th1d * w.s12;
+    float th2db = fb0 * C.e * 2.f * th2d * w.s2 - fb1 * C.h * 2.f * th2d * w.s12;
+    const float sb1 = fb0 * C.b * th1d * th1d + fb1 * C.gb;
+    const float sb2 = fb0 * C.e * th2d * th2d + fb2 * C.ge;
+    const float sb12 = -fb1 * C.h * th2d * th2d + fb2 * C.h * th1d * th1d;
+    const float th1b = -w.s1 * cb1 + w.c1 * sb1 - w.s12 * cb12 + w.c12 * sb12;
+    const float th2b = -w.s2 * cb2 + w.c2 * sb2 + w.s12 * cb12 - w.c12 * sb12;
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    g[1] = g1 + th1b;
+    g[2] = g2 + th2b;
+    g[3] = g[3] + tau * g0;
+    g[4] = g[4] + tau * g1 + th1db;
+    g[5] = g[5] + tau * g2 + th2db;
+}
+
+__device__ __forceinline__ float idp_reward(const float* s, float a) {
+    const float dist = 0.f * (s[0] * s[0]) + 5.f * (s[1] * s[1]) + 10.f * (s[2] * s[2]);
+    const float vel = 0.5f * (s[3] * s[3]) + 0.5f * (s[4] * s[4]) + 1.f * (s[5] * s[5]);
+    return 10.f - dist - vel - 1.f * (a * a);
+}
+
+__device__ __forceinline__ bool idp_done(const IdpConst& C, const float* s) {
+    const float tip_y = C.l1 * cosf(s[1]) + C.l2 * cosf(s[2]);
+    return (tip_y <= 1.0f) || (fabsf(s[0]) >= 15.f);
+}
+
+// ================================ pyth_veh3dofconti ===========================================
+struct VehConst {
+    float m, Iz, dt, c_lk, dt_kf, dt_m, den_v, dt_lfkf, den_w;
+};
+__device__ __forceinline__ VehConst veh_const() {
+    const double k_f = -128915.5, k_r = -85943.6, l_f = 1.06, l_r = 1.85, m = 1412.0, I_z = 1536.7,
+                 dt = 0.1;
+    VehConst c;
+    c.m = (float)m; c.Iz = (float)I_z; c.dt = (float)dt;
+    c.c_lk = (float)(dt * (l_f * k_f - l_r * k_r));
+    c.dt_kf = (float)(dt * k_f);
+    c.dt_m = (float)(dt * m);
+    c.den_v = (float)(dt * (k_f + k_r));
+    c.dt_lfkf = (float)(dt * l_f * k_f);
+    c.den_w = (float)(dt * (l_f * l_f * k_f + l_r * l_r * k_r));
+    return c;
+}
+
+struct VehStep {   // intermediates shared by forward and adjoint
+    float sphi, cphi, Dv, Dw, Nv, Nw;
+};
+
+__device__ __forceinline__ void veh_f_xu(const VehConst& C, const float* s, float steer, float ax,
+                                         float* sn, VehStep& w) {
+    const float x = s[0], y = s[1], phi = s[2], u = s[3], v = s[4], om = s[5];
+    sincosf(phi, &w.sphi, &w.cphi);
+    sn[0] = x + C.dt * (u * w.cphi - v * w.sphi);
+    sn[1] = y + C.dt * (u * w.sphi + v * w.cphi);
+    sn[2] = angle_normalize(phi + C.dt * om);
+    sn[3] = u + C.dt * ax;
+    w.Nv = C.m * v * u + C.c_lk * om - C.dt_kf * steer * u - C.dt_m * (u * u) * om;
+    w.Dv = C.m * u - C.den_v;
+    sn[4] = w.Nv / w.Dv;
+    w.Nw = C.Iz * om * u + C.c_lk * v - C.dt_lfkf * steer * u;
+    w.Dw = C.Iz * u - C.den_w;
+    sn[5] = w.Nw / w.Dw;
+}
+
+// adjoint: lam (adjoint of sn) -> ls (adjoint of s), g_steer, g_ax
+__device__ __forceinline__ void veh_f_xu_bwd(const VehConst& C, const float* s, float steer,
+                                             const VehStep& w, const float* lam, float* ls,
+                                             float& g_steer, float& g_ax) {
+    const float u = s[3], v = s[4], om = s[5];
+    const float lx = lam[0], ly = lam[1], lp = lam[2], lu = lam[3], lv = lam[4], lw = lam[5];
+    const float ivD = 1.f / w.Dv, iwD = 1.f / w.Dw;
+    const float dv_du = (C.m * v - C.dt_kf * steer - 2.f * C.dt_m * u * om) * ivD - w.Nv * C.m * ivD * ivD;
+    const float dw_du = (C.Iz * om - C.dt_lfkf * steer) * iwD - w.Nw * C.Iz * iwD * iwD;
+    ls[0] = lx;
+    ls[1] = ly;
+    ls[2] = lp + lx * C.dt * (-u * w.sphi - v * w.cphi) + ly * C.dt * (u * w.cphi - v * w.sphi);
+    ls[3] = lu + lx * C.dt * w.cphi + ly * C.dt * w.sphi + lv * dv_du + lw * dw_du;
+    ls[4] = -lx * C.dt * w.sphi + ly * C.dt * w.cphi + lv * (C.m * u * ivD) + lw * (C.c_lk * iwD);
+    ls[5] = lp * C.dt + lv * ((C.c_lk - C.dt_m * u * u) * ivD) + lw * (C.Iz * u * iwD);
+    g_steer = lv * (-C.dt_kf * u * ivD) + lw * (-C.dt_lfkf * u * iwD);
+    g_ax = lu * C.dt;
+}
+
+__device__ __forceinline__ float veh_reward(const float* o, float steer, float ax) {
+    return -(0.04f * (o[0] * o[0]) + 0.04f * (o[1] * o[1]) + 0.02f * (o[2] * o[2]) +
+             0.02f * (o[3] * o[3]) + 0.01f * (o[5] * o[5]) + 0.01f * (steer * steer) + 0.01f * (ax * ax));
+}

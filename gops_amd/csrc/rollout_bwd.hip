@@ -1,0 +1,317 @@
+// Backward sweep of the horizon rollout (replaces `loss.backward()` of fhadp.py:108 /
+// infadp.py:151 for the policy path).  Same tiling as the forward kernel: one workgroup owns 16
+// trajectories and walks t = H-1 ... 0 carrying the adjoint of the observation (LDS tile G) and of
+// the env state (registers).  Per step: env-model adjoint -> adjoint of the action -> wrapper /
+// tanh -> head -> hidden-layer deltas on MFMA with the transposed-packed weights.  The deltas are
+// written to the stash; the weight gradients are formed afterwards by the dW GEMM kernels.
+#include "common.h"
+#include "env_models.h"
+
+// delta_y in s_gy[TB][4]  ->  hidden deltas (stashed to stash_d when non-null) and, if want_gx,
+// G[m][n] += (delta_1 W_0)[m][n] for n < ncols.
+__device__ __forceinline__ void mlp_backward(const MlpDev& M, const float* s_gy, float* da, float* db,
+                                             int ldh, float* G, int ldg, int tid,
+                                             float* const* stash_h, float* const* stash_z,
+                                             float* const* stash_d, float* stash_dy, size_t row0,
+                                             int nvalid, bool want_gx, int ncols) {
+    const int lane = tid & 63;
+    const int L = M.nl - 1, A = M.dims[M.nl];
+    const bool gelu = (M.act == GOPS_ACT_GELU);
+    // ---- head: delta_L[m][k] = (sum_a gy[m][a] Wo[a][k]) * act'(z_L[m][k]) on the VALU ----
+    {
+        const int K = M.dims[L];
+        const int hm = tid >> 4, hp = tid & 15;
+        const float* Wo = M.w[L];
+        float gy[GOPS_MAX_ACT];
+#pragma unroll
+        for (int a = 0; a < GOPS_MAX_ACT; ++a) gy[a] = (a < A) ? s_gy[hm * 4 + a] : 0.f;
+        const float* hrow = stash_h[L] + (row0 + hm) * K;
+        const float* zrow = gelu ? stash_z[L] + (row0 + hm) * K : nullptr;
+        for (int k = hp; k < K; k += 16) {
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                if (a < A) acc += gy[a] * Wo[a * K + k];
+            float dv = 0.f;
+            if (hm < nvalid) dv = acc * act_bwd(M.act, hrow[k], gelu ? zrow[k] : 0.f);
+            da[hm * ldh + k] = dv;
+        }
+        if (stash_dy != nullptr && tid < nvalid) {
+            f32x4 v = {s_gy[tid * 4 + 0], s_gy[tid * 4 + 1], s_gy[tid * 4 + 2], s_gy[tid * 4 + 3]};
+#pragma unroll
+            for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                if (a >= A) v[a] = 0.f;
+            *reinterpret_cast<f32x4*>(stash_dy + (row0 + tid) * 4) = v;
+        }
+    }
+    __syncthreads();
+    if (stash_d != nullptr) stash_tile(da, ldh, M.dims[L], stash_d[L], row0, nvalid, tid);
+    float* cur = da;
+    float* out = db;
+    // ---- hidden layers j = L-1 .. 1: delta_j = (delta_{j+1} W_j) * act'(z_j) ----
+    for (int j = L - 1; j >= 1; --j) {
+        const int N = M.dims[j], kch = M.dims[j + 1] >> 4, nt_tot = N >> 4;
+        const float* hbase = stash_h[j] + row0 * N;
+        const float* zbase = gelu ? stash_z[j] + row0 * N : nullptr;
+        gemm_layer(cur, ldh, kch, nt_tot, M.wpt[j], tid, [&](const f32x4& acc, int ntile) {
+            const int n = (ntile << 4) + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = ((lane >> 4) << 2) + r;
+                float dv = 0.f;
+                if (m < nvalid)
+                    dv = acc[r] * act_bwd(M.act, hbase[(size_t)m * N + n], gelu ? zbase[(size_t)m * N + n] : 0.f);
+                out[m * ldh + n] = dv;
+            }
+        });
+        __syncthreads();
+        if (stash_d != nullptr) stash_tile(out, ldh, N, stash_d[j], row0, nvalid, tid);
+        float* tmp = cur; cur = out; out = tmp;
+    }
+    // ---- input adjoint g_x = delta_1 W_0 ----
+    if (want_gx) {
+        const int kch = M.dims[1] >> 4, nt_tot = M.kp[0] >> 4;
+        gemm_layer(cur, ldh, kch, nt_tot, M.wpt[0], tid, [&](const f32x4& acc, int ntile) {
+            const int n = (ntile << 4) + (lane & 15);
+            if (n < ncols) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = ((lane >> 4) << 2) + r;
+                    G[m * ldg + n] += acc[r];
+                }
+            }
+        });
+    }
+}
+
+template <int ENV>
+__global__ __launch_bounds__(NTHREADS) void rollout_bwd_kernel(const RolloutParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * TB;
+    const int nvalid = min(TB, p.B - b0);
+    const int O = p.env.obs_dim, A = p.env.act_dim;
+    const int ldx = p.ldx, ldh = p.ldh;
+    float* G = smem;                    // [TB][ldx] adjoint of obs_{t+1}
+    float* da = G + TB * ldx;           // [TB][ldh]
+    float* db = da + TB * ldh;          // [TB][ldh]
+    float* s_gy = db + TB * ldh;        // [TB][4]
+    float* red = s_gy + TB * 4;         // [4][TB][8]
+
+    for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
+    const float gv = (tid < nvalid) ? p.grad_v[b0 + tid] : 0.f;
+    float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // adjoint of the veh3dof state (tid < TB)
+    const IdpConst IC = idp_const();
+    const VehConst VC = veh_const();
+    const int TL = p.env.pre_horizon + 1 + p.H;
+    const int kp0 = p.pol.kp[0];
+
+    if (p.tail) {
+        if (tid < TB) {
+            const float dH = (tid < nvalid) ? p.st.tail_done[b0 + tid] : 1.f;
+            s_gy[tid * 4 + 0] = gv * ((1.f - dH) * p.gpow[p.H]);
+            s_gy[tid * 4 + 1] = s_gy[tid * 4 + 2] = s_gy[tid * 4 + 3] = 0.f;
+        }
+        __syncthreads();
+        mlp_backward(p.val, s_gy, da, db, ldh, G, ldx, tid, p.st.tail_h, p.st.tail_z, nullptr, nullptr,
+                     (size_t)b0, nvalid, true, O);
+    }
+    __syncthreads();
+
+    for (int t = p.H - 1; t >= 0; --t) {
+        const size_t row0 = (size_t)t * p.B + b0;
+        float g_r = gv * p.gpow[t];                         // adjoint of the shaped reward
+        if (ENV != GOPS_ENV_NONE && p.env.shaping) g_r *= p.env.reward_scale;
+
+        if (ENV == GOPS_ENV_NONE) {
+            if (tid < TB) {
+                s_gy[tid * 4 + 0] = g_r;
+                s_gy[tid * 4 + 1] = s_gy[tid * 4 + 2] = s_gy[tid * 4 + 3] = 0.f;
+            }
+        } else if (ENV == GOPS_ENV_LQ || ENV == GOPS_ENV_IDPENDULUM) {
+            if (tid < TB) {
+                const int m = tid;
+                float th[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, dflag = 1.f;
+                float x[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (m < nvalid) {
+                    const f32x4* er = reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH);
+                    const f32x4 e0 = er[0], e1 = er[1];
+                    th[0] = e0[0]; th[1] = e0[1]; th[2] = e0[2]; th[3] = e0[3];
+                    dflag = e1[0];
+                    const float* xr = p.st.x + (row0 + m) * kp0;
+#pragma unroll
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                        if (i < O) x[i] = xr[i];
+                }
+                float abar[GOPS_MAX_ACT], u[GOPS_MAX_ACT], sc[GOPS_MAX_ACT], gu[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < GOPS_MAX_ACT; ++a) {
+                    sc[a] = (p.env.policy_high[a] - p.env.policy_low[a]) / 2.f;
+                    abar[a] = sc[a] * th[a] + (p.env.policy_high[a] + p.env.policy_low[a]) / 2.f;
+                    u[a] = (a < A) ? wrap_action(p.env, a, abar[a]) : 0.f;
+                }
+                const bool dn = dflag != 0.f;
+                const float g_rm = dn ? 0.f : g_r;
+                float Gin[GOPS_MAX_LQ_STATE], gx[GOPS_MAX_LQ_STATE];
+#pragma unroll
+                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { Gin[i] = (i < O) ? G[m * ldx + i] : 0.f; gx[i] = 0.f; }
+                if (ENV == GOPS_ENV_LQ) {
+                    if (p.env.clip_obs) {
+                        float xn[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rdummy;
+                        lq_forward(p.env, x, u, xn, rdummy);
+#pragma unroll
+                        for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) {
+                            const float pre = dn ? x[i] : xn[i];
+                            if (i < O && !(pre >= p.env.obs_low[i] && pre <= p.env.obs_high[i])) Gin[i] = 0.f;
+                        }
+                    }
+                    float gxn[GOPS_MAX_LQ_STATE];
+#pragma unroll
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { gxn[i] = dn ? 0.f : Gin[i]; gx[i] = dn ? Gin[i] : 0.f; }
+                    lq_backward(p.env, x, u, gxn, g_rm, gx, gu);
+                } else {
+                    // recompute the 5 Euler sub-steps, then walk them backwards
+                    float s[6][6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) s[0][i] = x[i];
+                    const float a = u[0], force = 500.f * a;
+                    IdpSub w;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) idp_substep(IC, s[k], force, 0.002f, s[k + 1], w);
+                    float g[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) g[i] = dn ? 0.f : Gin[i];
+                    g[1] += g_rm * (-10.f * s[5][1]);
+                    g[2] += g_rm * (-20.f * s[5][2]);
+                    g[3] += g_rm * (-1.f * s[5][3]);
+                    g[4] += g_rm * (-1.f * s[5][4]);
+                    g[5] += g_rm * (-2.f * s[5][5]);
+                    float gforce = 0.f;
+#pragma unroll
+                    for (int k = 4; k >= 0; --k) {
+                        float sn_dummy[6];
+                        idp_substep(IC, s[k], force, 0.002f, sn_dummy, w);
+                        idp_substep_bwd(IC, s[k], 0.002f, w, g, gforce);
+                    }
+                    gu[0] = 500.f * gforce + g_rm * (-2.f * a);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) gx[i] = g[i] + (dn ? Gin[i] : 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                    if (i < O) G[m * ldx + i] = gx[i];
+#pragma unroll
+                for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                    s_gy[m * 4 + a] = (a < A) ? wrap_action_bwd(p.env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a]) : 0.f;
+            }
+        } else {   // GOPS_ENV_VEH3DOFCONTI
+            const int m = tid & 15, part = tid >> 4, lane = tid & 63, wave = tid >> 6;
+            const int P = p.env.pre_horizon;
+            float th0 = 0.f, th1 = 0.f, dflag = 1.f;
+            float s[6] = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f};
+            if (m < nvalid) {
+                const f32x4* er = reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH);
+                const f32x4 e0 = er[0], e1 = er[1], e2 = er[2];
+                th0 = e0[0]; th1 = e0[1]; dflag = e1[0];
+                s[0] = e1[1]; s[1] = e1[2]; s[2] = e1[3]; s[3] = e2[0]; s[4] = e2[1]; s[5] = e2[2];
+            }
+            const bool dn = dflag != 0.f;
+            const float sc0 = (p.env.policy_high[0] - p.env.policy_low[0]) / 2.f;
+            const float sc1 = (p.env.policy_high[1] - p.env.policy_low[1]) / 2.f;
+            const float abar0 = sc0 * th0 + (p.env.policy_high[0] + p.env.policy_low[0]) / 2.f;
+            const float abar1 = sc1 * th1 + (p.env.policy_high[1] + p.env.policy_low[1]) / 2.f;
+            const float steer = wrap_action(p.env, 0, abar0), ax = wrap_action(p.env, 1, abar1);
+            float sn[6];
+            VehStep w;
+            veh_f_xu(VC, s, steer, ax, sn, w);
+            float cn, snn;
+            sincosf(-sn[2], &snn, &cn);
+            // partial adjoints of (x', y', phi', u') and of cos/sin(-phi') over this thread's points
+            float px = 0.f, py = 0.f, pphi = 0.f, pu = 0.f, pc = 0.f, ps = 0.f, g4 = 0.f, g5 = 0.f;
+            const f32x4* tbl = reinterpret_cast<const f32x4*>(p.ref_table) + (size_t)(b0 + m) * TL + (t + 1);
+            for (int j = part; j <= P; j += 16) {
+                float* gp = G + m * ldx + (j == 0 ? 0 : 6 + 4 * (j - 1));
+                float gx_ = gp[0], gy_ = gp[1], gph = gp[2], gu_ = gp[3];
+                if (j == 0) { g4 = gp[4]; g5 = gp[5]; }
+                if (dn) {
+                    gx_ = gy_ = gph = gu_ = 0.f; g4 = g5 = 0.f;      // MaskAtDone: adjoint stays on obs_t
+                } else {
+                    gp[0] = gp[1] = gp[2] = gp[3] = 0.f;
+                    if (j == 0) { gp[4] = 0.f; gp[5] = 0.f; }
+                }
+                f32x4 rp = {0.f, 0.f, 0.f, 0.f};
+                if (m < nvalid) rp = tbl[j];
+                const float dx = rp[0] - sn[0], dy = rp[1] - sn[1];
+                px -= gx_ * cn + gy_ * snn;
+                py -= -gx_ * snn + gy_ * cn;
+                pc += gx_ * dx + gy_ * dy;
+                ps += -gx_ * dy + gy_ * dx;
+                pphi -= gph;
+                pu -= gu_;
+            }
+            // reduce over the 16 `part` threads of each trajectory: lanes m+16q in-wave, then 4 waves
+            float v6[6] = {px, py, pphi, pu, pc, ps};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                v6[i] += __shfl_xor(v6[i], 16);
+                v6[i] += __shfl_xor(v6[i], 32);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) red[(wave * TB + m) * 8 + i] = v6[i];
+            }
+            __syncthreads();
+            if (tid < TB) {
+                float tot[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    tot[i] = red[(0 * TB + m) * 8 + i] + red[(1 * TB + m) * 8 + i] + red[(2 * TB + m) * 8 + i] + red[(3 * TB + m) * 8 + i];
+                float lamn[6];
+                lamn[0] = lam[0] + tot[0];
+                lamn[1] = lam[1] + tot[1];
+                lamn[2] = lam[2] + tot[2] + tot[4] * snn - tot[5] * cn;
+                lamn[3] = lam[3] + tot[3];
+                lamn[4] = lam[4] + g4;
+                lamn[5] = lam[5] + g5;
+                float g_steer, g_ax;
+                veh_f_xu_bwd(VC, s, steer, w, lamn, lam, g_steer, g_ax);
+                const float g_rm = dn ? 0.f : g_r;
+                if (m < nvalid) {
+                    const float* xr = p.st.x + (row0 + m) * kp0;
+                    G[m * ldx + 0] += g_rm * (-0.08f * xr[0]);
+                    G[m * ldx + 1] += g_rm * (-0.08f * xr[1]);
+                    G[m * ldx + 2] += g_rm * (-0.04f * xr[2]);
+                    G[m * ldx + 3] += g_rm * (-0.04f * xr[3]);
+                    G[m * ldx + 5] += g_rm * (-0.02f * xr[5]);
+                }
+                g_steer += g_rm * (-0.02f * steer);
+                g_ax += g_rm * (-0.02f * ax);
+                s_gy[m * 4 + 0] = wrap_action_bwd(p.env, 0, abar0, g_steer) * sc0 * (1.f - th0 * th0);
+                s_gy[m * 4 + 1] = wrap_action_bwd(p.env, 1, abar1, g_ax) * sc1 * (1.f - th1 * th1);
+                s_gy[m * 4 + 2] = 0.f;
+                s_gy[m * 4 + 3] = 0.f;
+            }
+        }
+        __syncthreads();
+        mlp_backward(p.pol, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
+                     /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O);
+        __syncthreads();
+    }
+}
+
+size_t rollout_bwd_lds_bytes(int ldx, int ldh) {
+    return sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * 4 + 4 * TB * 8);
+}
+
+hipError_t launch_rollout_bwd(const RolloutParams& p, hipStream_t stream) {
+    const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
+    const size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh);
+    switch (p.env.kind) {
+        case GOPS_ENV_NONE: hipLaunchKernelGGL(rollout_bwd_kernel<GOPS_ENV_NONE>, grid, block, lds, stream, p); break;
+        case GOPS_ENV_LQ: hipLaunchKernelGGL(rollout_bwd_kernel<GOPS_ENV_LQ>, grid, block, lds, stream, p); break;
+        case GOPS_ENV_IDPENDULUM: hipLaunchKernelGGL(rollout_bwd_kernel<GOPS_ENV_IDPENDULUM>, grid, block, lds, stream, p); break;
+        case GOPS_ENV_VEH3DOFCONTI: hipLaunchKernelGGL(rollout_bwd_kernel<GOPS_ENV_VEH3DOFCONTI>, grid, block, lds, stream, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

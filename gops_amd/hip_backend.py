@@ -1,0 +1,320 @@
+"""ctypes binding of libgops_hip.so (C ABI: include/gops_hip.h).
+
+PyTorch is used only for device memory and streams: every call passes raw device pointers of
+caller-owned tensors plus the current HIP stream.  There is NO CPU or eager-PyTorch fallback:
+if the shared library is missing, or a shape is unsupported, the call raises.
+"""
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgops_hip.so")
+
+MAX_LAYERS, MAX_ACT, MAX_LQ, TILE = 5, 4, 6, 16
+ENV_NONE, ENV_LQ, ENV_IDP, ENV_VEH = 0, 1, 2, 3
+ACT_IDS = {"linear": 0, "relu": 1, "elu": 2, "gelu": 3, "selu": 4, "sigmoid": 5, "tanh": 6}
+
+_fp = C.POINTER(C.c_float)
+
+
+class GopsMlp(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("sizes", C.c_int32 * (MAX_LAYERS + 1)),
+                ("hidden_act", C.c_int32), ("reserved", C.c_int32),
+                ("weight", C.c_void_p * MAX_LAYERS), ("bias", C.c_void_p * MAX_LAYERS)]
+
+
+class GopsMlpGrad(C.Structure):
+    _fields_ = [("weight", C.c_void_p * MAX_LAYERS), ("bias", C.c_void_p * MAX_LAYERS)]
+
+
+class GopsEnv(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32),
+                ("pre_horizon", C.c_int32),
+                ("min_action", C.c_float * MAX_ACT), ("max_action", C.c_float * MAX_ACT),
+                ("act_low", C.c_float * MAX_ACT), ("act_high", C.c_float * MAX_ACT),
+                ("policy_low", C.c_float * MAX_ACT), ("policy_high", C.c_float * MAX_ACT),
+                ("clip_obs", C.c_int32), ("obs_low", C.c_float * 8), ("obs_high", C.c_float * 8),
+                ("shaping", C.c_int32), ("reward_scale", C.c_float), ("reward_shift", C.c_float),
+                ("lq_inv_IA", C.c_float * (MAX_LQ * MAX_LQ)), ("lq_B", C.c_float * (MAX_LQ * MAX_ACT)),
+                ("lq_Q", C.c_float * MAX_LQ), ("lq_R", C.c_float * MAX_ACT),
+                ("lq_dt", C.c_float), ("lq_reward_scale", C.c_float), ("lq_reward_shift", C.c_float)]
+
+
+class GopsRolloutDesc(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("horizon", C.c_int32), ("finite_horizon", C.c_int32),
+                ("need_grad", C.c_int32), ("tail_value", C.c_int32), ("reserved", C.c_int32),
+                ("gamma", C.c_double), ("env", GopsEnv), ("policy", GopsMlp), ("value", GopsMlp)]
+
+
+class GopsRolloutIn(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("obs", "done", "state", "ref_points", "path_num", "u_num",
+                                          "ref_time")]
+
+
+class GopsRolloutOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("v_pi", "rewards", "final_obs", "final_done", "final_state")]
+
+
+class GopsStepIO(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("obs", "action", "done", "state", "ref_points", "path_num",
+                                          "u_num", "ref_time", "next_obs", "reward", "next_done",
+                                          "next_state", "next_ref_points", "next_ref_time")]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libgops_hip.so; fails loudly (no fallback) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C gops_amd/csrc`). The HIP rollout has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        l.gops_hip_version.restype = C.c_int
+        l.gops_rollout_workspace_bytes.restype = C.c_size_t
+        l.gops_rollout_workspace_bytes.argtypes = [C.POINTER(GopsRolloutDesc)]
+        l.gops_rollout_forward.restype = C.c_int
+        l.gops_rollout_forward.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn),
+                                           C.POINTER(GopsRolloutOut), C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gops_rollout_backward.restype = C.c_int
+        l.gops_rollout_backward.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn), C.c_void_p,
+                                            C.POINTER(GopsMlpGrad), C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gops_env_step.restype = C.c_int
+        l.gops_env_step.argtypes = [C.POINTER(GopsEnv), C.c_int32, C.POINTER(GopsStepIO), C.c_void_p]
+        l.gops_value_workspace_bytes.restype = C.c_size_t
+        l.gops_value_workspace_bytes.argtypes = [C.POINTER(GopsMlp), C.c_int32]
+        l.gops_value_forward.restype = C.c_int
+        l.gops_value_forward.argtypes = [C.POINTER(GopsMlp), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_void_p]
+        l.gops_value_backward.restype = C.c_int
+        l.gops_value_backward.argtypes = [C.POINTER(GopsMlp), C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.POINTER(GopsMlpGrad), C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gops_profile_enable.argtypes = [C.c_int32]
+        l.gops_profile_reset.argtypes = []
+        l.gops_profile_read.restype = C.c_int
+        l.gops_profile_read.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        _lib = l
+    return _lib
+
+
+EXPORTED_SYMBOLS = ("gops_hip_version", "gops_rollout_workspace_bytes", "gops_rollout_forward",
+                    "gops_rollout_backward", "gops_env_step", "gops_value_workspace_bytes",
+                    "gops_value_forward", "gops_value_backward", "gops_profile_enable",
+                    "gops_profile_reset", "gops_profile_read")
+
+_ERR = {-1: "GOPS_ERR_BAD_ARG", -2: "GOPS_ERR_UNSUPPORTED", -3: "GOPS_ERR_WORKSPACE"}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, 'hipError_t ' + str(rc))}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "need contiguous fp32 device tensor"
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _fill(arr, vals):
+    for i, v in enumerate(vals):
+        arr[i] = float(v)
+
+
+def make_mlp(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], act: str) -> GopsMlp:
+    m = GopsMlp()
+    m.n_layers = len(weights)
+    if not 2 <= len(weights) <= MAX_LAYERS:
+        raise RuntimeError(f"MLP with {len(weights)} Linear layers is outside the HIP path (2..{MAX_LAYERS})")
+    m.sizes[0] = weights[0].shape[1]
+    for j, (w, b) in enumerate(zip(weights, biases)):
+        m.sizes[j + 1] = w.shape[0]
+        m.weight[j] = _ptr(w)
+        m.bias[j] = _ptr(b)
+    m.hidden_act = ACT_IDS[act]
+    m._keep = (list(weights), list(biases))   # the struct holds raw pointers: keep the tensors alive
+    return m
+
+
+def make_mlp_grad(gw: Sequence[torch.Tensor], gb: Sequence[torch.Tensor]) -> GopsMlpGrad:
+    g = GopsMlpGrad()
+    for j, (w, b) in enumerate(zip(gw, gb)):
+        g.weight[j] = _ptr(w)
+        g.bias[j] = _ptr(b)
+    return g
+
+
+def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_action=-1.0, max_action=1.0,
+             policy_low=None, policy_high=None, obs_low=None, obs_high=None, pre_horizon: int = 0,
+             reward_scale: Optional[float] = None, reward_shift: Optional[float] = None,
+             lq: Optional[Dict] = None) -> GopsEnv:
+    """Constants of the wrapped env model (create_env_model.py:86-128) as a C struct."""
+    e = GopsEnv()
+    e.kind, e.obs_dim, e.act_dim, e.pre_horizon = kind, obs_dim, act_dim, pre_horizon
+    A = act_dim
+
+    def bc(v):
+        v = torch.as_tensor(v, dtype=torch.float32).reshape(-1)
+        return (v.expand(A) if v.numel() == 1 else v).tolist()
+
+    _fill(e.min_action, bc(min_action)); _fill(e.max_action, bc(max_action))
+    _fill(e.act_low, bc(act_low)); _fill(e.act_high, bc(act_high))
+    _fill(e.policy_low, bc(-1.0 if policy_low is None else policy_low))
+    _fill(e.policy_high, bc(1.0 if policy_high is None else policy_high))
+    finite = False
+    if obs_low is not None:
+        lo = torch.as_tensor(obs_low, dtype=torch.float32).reshape(-1)
+        hi = torch.as_tensor(obs_high, dtype=torch.float32).reshape(-1)
+        finite = bool(torch.isfinite(lo).any() or torch.isfinite(hi).any())
+        if finite:
+            if obs_dim > 8:
+                raise RuntimeError("finite observation bounds are only supported for obs_dim <= 8 (pyth_lq)")
+            _fill(e.obs_low, lo.tolist()); _fill(e.obs_high, hi.tolist())
+    e.clip_obs = 1 if finite else 0
+    e.shaping = 1 if (reward_scale is not None or reward_shift is not None) else 0
+    e.reward_scale = 1.0 if reward_scale is None else float(reward_scale)
+    e.reward_shift = 0.0 if reward_shift is None else float(reward_shift)
+    if lq is not None:
+        n, m = obs_dim, act_dim
+        _fill(e.lq_inv_IA, torch.as_tensor(lq["inv_IA"], dtype=torch.float32).reshape(n * n).tolist())
+        _fill(e.lq_B, torch.as_tensor(lq["B"], dtype=torch.float32).reshape(n * m).tolist())
+        _fill(e.lq_Q, torch.as_tensor(lq["Q"], dtype=torch.float32).tolist())
+        _fill(e.lq_R, torch.as_tensor(lq["R"], dtype=torch.float32).tolist())
+        e.lq_dt = float(lq["dt"])
+        e.lq_reward_scale = float(lq.get("reward_scale", 1.0))
+        e.lq_reward_shift = float(lq.get("reward_shift", 0.0))
+    return e
+
+
+class Rollout:
+    """One configured horizon rollout (forward + backward) bound to caller-owned tensors.
+
+    The workspace (activation stash, packed weights, reference table, split-K partials) is a
+    single torch uint8 tensor sized by `gops_rollout_workspace_bytes` and reused across calls.
+    """
+
+    def __init__(self, env: GopsEnv, policy: GopsMlp, *, batch: int, horizon: int, gamma: float,
+                 finite_horizon: bool, need_grad: bool = True, value: Optional[GopsMlp] = None,
+                 device: Optional[torch.device] = None):
+        self.desc = GopsRolloutDesc()
+        d = self.desc
+        d.batch, d.horizon, d.finite_horizon = batch, horizon, int(finite_horizon)
+        d.need_grad, d.tail_value, d.gamma = int(need_grad), int(value is not None), float(gamma)
+        d.env, d.policy = env, policy
+        if value is not None:
+            d.value = value
+        self._mlps = (policy, value)
+        nbytes = lib().gops_rollout_workspace_bytes(C.byref(d))
+        if nbytes == 0:
+            raise RuntimeError("gops_rollout_workspace_bytes: descriptor rejected (unsupported shape for the HIP path)")
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._in = GopsRolloutIn()
+        self._keep = None
+
+    def set_policy(self, policy: GopsMlp, value: Optional[GopsMlp] = None):
+        self.desc.policy = policy
+        if value is not None:
+            self.desc.value = value
+        self._mlps = (policy, value if value is not None else self._mlps[1])
+
+    def forward(self, data: Dict[str, torch.Tensor], *, want_rewards=False, want_final=False):
+        d = self.desc
+        B, H, O = d.batch, d.horizon, d.env.obs_dim
+        i = self._in
+        i.obs, i.done = _ptr(data["obs"]), _ptr(data.get("done"))
+        if d.env.kind == ENV_VEH:
+            for k in ("state", "ref_points", "path_num", "u_num", "ref_time"):
+                setattr(i, k, _ptr(data[k]))
+        self._keep = data
+        out = GopsRolloutOut()
+        res = {"v_pi": torch.empty(B, dtype=torch.float32, device=self.device)}
+        out.v_pi = _ptr(res["v_pi"])
+        if want_rewards:
+            res["rewards"] = torch.empty(H, B, dtype=torch.float32, device=self.device)
+            out.rewards = _ptr(res["rewards"])
+        if want_final:
+            res["final_obs"] = torch.empty(B, O, dtype=torch.float32, device=self.device)
+            res["final_done"] = torch.empty(B, dtype=torch.float32, device=self.device)
+            out.final_obs, out.final_done = _ptr(res["final_obs"]), _ptr(res["final_done"])
+            if d.env.kind == ENV_VEH:
+                res["final_state"] = torch.empty(B, 6, dtype=torch.float32, device=self.device)
+                out.final_state = _ptr(res["final_state"])
+        check(lib().gops_rollout_forward(C.byref(d), C.byref(i), C.byref(out), self.workspace.data_ptr(),
+                                         self.workspace.numel(), _stream()), "gops_rollout_forward")
+        return res
+
+    def backward(self, grad_v: torch.Tensor, grad_w: List[torch.Tensor], grad_b: List[torch.Tensor]):
+        g = make_mlp_grad(grad_w, grad_b)
+        check(lib().gops_rollout_backward(C.byref(self.desc), C.byref(self._in), _ptr(grad_v), C.byref(g),
+                                          self.workspace.data_ptr(), self.workspace.numel(), _stream()),
+              "gops_rollout_backward")
+
+
+class ValueNet:
+    """StateValue batch forward/backward on the HIP path (INFADP PEV, infadp.py:167,185)."""
+
+    def __init__(self, value: GopsMlp, batch: int, device: Optional[torch.device] = None):
+        self.mlp, self.batch = value, batch
+        nbytes = lib().gops_value_workspace_bytes(C.byref(value), batch)
+        if nbytes == 0:
+            raise RuntimeError("gops_value_workspace_bytes: unsupported value network for the HIP path")
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def forward(self, obs: torch.Tensor) -> torch.Tensor:
+        v = torch.empty(self.batch, dtype=torch.float32, device=self.device)
+        check(lib().gops_value_forward(C.byref(self.mlp), self.batch, _ptr(obs), _ptr(v),
+                                       self.workspace.data_ptr(), self.workspace.numel(), _stream()),
+              "gops_value_forward")
+        return v
+
+    def backward(self, obs: torch.Tensor, grad_v: torch.Tensor, grad_w, grad_b):
+        g = make_mlp_grad(grad_w, grad_b)
+        check(lib().gops_value_backward(C.byref(self.mlp), self.batch, _ptr(obs), _ptr(grad_v), C.byref(g),
+                                        self.workspace.data_ptr(), self.workspace.numel(), _stream()),
+              "gops_value_backward")
+
+
+def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Tensor]] = None):
+    """One wrapped env-model step on the GPU (gops_env_step)."""
+    B = obs.shape[0]
+    io = GopsStepIO()
+    nobs, rew, ndone = torch.empty_like(obs), torch.empty(B, device=obs.device), torch.empty(B, device=obs.device)
+    io.obs, io.action, io.done = _ptr(obs), _ptr(action), _ptr(done)
+    io.next_obs, io.reward, io.next_done = _ptr(nobs), _ptr(rew), _ptr(ndone)
+    ninfo = {}
+    if env.kind == ENV_VEH:
+        for k in ("state", "ref_points", "path_num", "u_num", "ref_time"):
+            setattr(io, k, _ptr(info[k]))
+        ninfo = dict(state=torch.empty_like(info["state"]), ref_points=torch.empty_like(info["ref_points"]),
+                     ref_time=torch.empty_like(info["ref_time"]), path_num=info["path_num"], u_num=info["u_num"])
+        io.next_state, io.next_ref_points = _ptr(ninfo["state"]), _ptr(ninfo["ref_points"])
+        io.next_ref_time = _ptr(ninfo["ref_time"])
+    check(lib().gops_env_step(C.byref(env), B, C.byref(io), _stream()), "gops_env_step")
+    return nobs, rew, ndone, ninfo
+
+
+def profile_enable(on: bool):
+    lib().gops_profile_enable(int(on))
+
+
+def profile_reset():
+    lib().gops_profile_reset()
+
+
+def profile_read(kernel_id: int):
+    ms, n = C.c_double(0.0), C.c_int64(0)
+    check(lib().gops_profile_read(kernel_id, C.byref(ms), C.byref(n)), "gops_profile_read")
+    return ms.value, n.value

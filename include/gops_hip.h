@@ -1,0 +1,173 @@
+/*
+ * gops_hip.h - C ABI of the MI355X-native GOPS ADP hot path (libgops_hip.so).
+ *
+ * Drop-in boundary for the reference's model-based ADP gradient loop.  Each entry point names
+ * the reference interface it replaces (paths relative to the GOPS tree):
+ *
+ *   gops_rollout_forward   <- the H-step loop  `a = policy(o, t); o,r,d,info = envmodel.forward(...)`
+ *                             of FHADP._compute_loss_policy      (gops/algorithm/fhadp.py:113-125)
+ *                             and INFADP.__compute_loss_v/_policy (gops/algorithm/infadp.py:159-213),
+ *                             i.e. MLP policy eval (gops/apprfunc/mlp.py:73-77,103-111), the wrapper
+ *                             chain (gops/create_pkg/create_env_model.py:104-126) and the env models
+ *                             pyth_lq / pyth_idpendulum / pyth_veh3dofconti
+ *                             (gops/env/env_ocp/resources/lq_base.py:343-354,
+ *                              gops/env/env_ocp/env_model/pyth_idpendulum_model.py:199-216,
+ *                              gops/env/env_ocp/env_model/pyth_veh3dofconti_model.py:91-145).
+ *   gops_rollout_backward  <- `loss.backward()` of the same functions (fhadp.py:108, infadp.py:143,151):
+ *                             fills per-parameter gradients in torch nn.Linear layout.
+ *   gops_env_step          <- one wrapped `env_model.forward(obs, action, done, info)`
+ *                             (gops/env/env_ocp/env_model/pyth_base_model.py:59-67), kept for
+ *                             per-step consumers (gops/sys_simulator/opt_controller.py:240-300).
+ *   gops_value_forward/backward <- `v = self.networks.v(o)` and its backward in INFADP PEV
+ *                             (infadp.py:167,185; StateValue gops/apprfunc/mlp.py:327-329).
+ *
+ * Conventions: every buffer is caller-allocated DEVICE memory (fp32 unless noted); the library
+ * allocates nothing, keeps no global state and is re-entrant.  All work is enqueued on `stream`
+ * (a hipStream_t passed as void*); no call synchronises.  Return value: 0 on success, a
+ * negative GOPS_ERR_* code or a positive hipError_t otherwise; nothing throws across the ABI.
+ */
+#ifndef GOPS_HIP_H
+#define GOPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOPS_HIP_ABI_VERSION 1
+
+#define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
+#define GOPS_MAX_ACT 4      /* action dimensions */
+#define GOPS_MAX_LQ_STATE 6
+#define GOPS_MAX_HORIZON 256
+#define GOPS_TILE 16        /* trajectories per workgroup tile (MFMA M) */
+
+enum { GOPS_OK = 0, GOPS_ERR_BAD_ARG = -1, GOPS_ERR_UNSUPPORTED = -2, GOPS_ERR_WORKSPACE = -3 };
+
+/* env kinds: the three env models named by BASELINE.json + NONE (plain MLP batch evaluation) */
+enum { GOPS_ENV_NONE = 0, GOPS_ENV_LQ = 1, GOPS_ENV_IDPENDULUM = 2, GOPS_ENV_VEH3DOFCONTI = 3 };
+
+/* hidden activations: gops/utils/common_utils.py:26-55 */
+enum { GOPS_ACT_LINEAR = 0, GOPS_ACT_RELU = 1, GOPS_ACT_ELU = 2, GOPS_ACT_GELU = 3,
+       GOPS_ACT_SELU = 4, GOPS_ACT_SIGMOID = 5, GOPS_ACT_TANH = 6 };
+
+/* An MLP in torch nn.Linear layout: layer j has weight [sizes[j+1]][sizes[j]] row-major and
+ * bias [sizes[j+1]].  Hidden widths must be multiples of 16; the input width is arbitrary. */
+typedef struct GopsMlp {
+    int32_t n_layers;                      /* number of Linear layers, 2..GOPS_MAX_LAYERS */
+    int32_t sizes[GOPS_MAX_LAYERS + 1];    /* in, hidden..., out */
+    int32_t hidden_act;                    /* GOPS_ACT_* */
+    int32_t reserved;
+    const float* weight[GOPS_MAX_LAYERS];  /* device pointers */
+    const float* bias[GOPS_MAX_LAYERS];
+} GopsMlp;
+
+/* Gradients of one MLP, same shapes/layout as GopsMlp weight/bias (device, overwritten). */
+typedef struct GopsMlpGrad {
+    float* weight[GOPS_MAX_LAYERS];
+    float* bias[GOPS_MAX_LAYERS];
+} GopsMlpGrad;
+
+/* The wrapped env model: base model constants + the wrapper chain built by create_env_model. */
+typedef struct GopsEnv {
+    int32_t kind;                 /* GOPS_ENV_* */
+    int32_t obs_dim, act_dim;
+    int32_t pre_horizon;          /* veh3dofconti: number of preview points P (obs_dim = 6+4P) */
+    /* ScaleActionModel / ClipActionModel (scale_action.py:75-83, clip_action.py:34-36) */
+    float min_action[GOPS_MAX_ACT], max_action[GOPS_MAX_ACT];
+    float act_low[GOPS_MAX_ACT], act_high[GOPS_MAX_ACT];       /* base-model action bounds */
+    /* tanh squash of the policy head (mlp.py:73-77): act_high_lim / act_low_lim buffers */
+    float policy_low[GOPS_MAX_ACT], policy_high[GOPS_MAX_ACT];
+    /* ClipObservationModel (clip_observation.py:38-40); +-inf = inactive */
+    int32_t clip_obs;             /* 0: all bounds infinite (idpendulum, veh3dofconti) */
+    float obs_low[8], obs_high[8];
+    /* ShapingRewardModel (shaping_reward.py:84-88), applied outside MaskAtDone */
+    int32_t shaping;
+    float reward_scale, reward_shift;
+    /* pyth_lq constants (lq_base.py:39-57): x' = inv_IA (x + dt B u), r = rs*(rsh - (Qx^2+Ru^2)) */
+    float lq_inv_IA[GOPS_MAX_LQ_STATE * GOPS_MAX_LQ_STATE];    /* row-major n x n */
+    float lq_B[GOPS_MAX_LQ_STATE * GOPS_MAX_ACT];              /* row-major n x m */
+    float lq_Q[GOPS_MAX_LQ_STATE], lq_R[GOPS_MAX_ACT];
+    float lq_dt, lq_reward_scale, lq_reward_shift;
+} GopsEnv;
+
+typedef struct GopsRolloutDesc {
+    int32_t batch;            /* B trajectories */
+    int32_t horizon;          /* H = pre_horizon (FHADP) or forward_step (INFADP) */
+    int32_t finite_horizon;   /* 1: FiniteHorizonPolicy, time index t+1 appended to the input */
+    int32_t need_grad;        /* 1: keep the activation stash for gops_rollout_backward */
+    int32_t tail_value;       /* 1: v += (~done_H) gamma^H V(obs_H)   (infadp.py:182-184, 210) */
+    int32_t reserved;
+    double gamma;             /* discount; gamma^t is formed in double then rounded (fhadp.py:120) */
+    GopsEnv env;
+    GopsMlp policy;           /* out width = act_dim */
+    GopsMlp value;            /* used iff tail_value (out width 1): INFADP's v_target */
+} GopsRolloutDesc;
+
+/* Batch inputs (the `data` dict of the algorithms). */
+typedef struct GopsRolloutIn {
+    const float* obs;         /* [B, obs_dim] */
+    const float* done;        /* [B] 0/1 */
+    const float* state;       /* veh3dofconti info["state"]      [B,6]      else NULL */
+    const float* ref_points;  /* veh3dofconti info["ref_points"] [B,P+1,4]  else NULL */
+    const float* path_num;    /* [B] */
+    const float* u_num;       /* [B] */
+    const float* ref_time;    /* [B] */
+} GopsRolloutIn;
+
+typedef struct GopsRolloutOut {
+    float* v_pi;              /* [B] sum_t gamma^t r_t (+ tail); required */
+    float* rewards;           /* [H,B] per-step (masked, shaped) rewards, or NULL */
+    float* final_obs;         /* [B, obs_dim] or NULL */
+    float* final_done;        /* [B] or NULL */
+    float* final_state;       /* veh3dofconti [B,6] or NULL */
+} GopsRolloutOut;
+
+int gops_hip_version(void);
+
+/* Bytes of scratch `workspace` needed by forward(+backward) for this descriptor. */
+size_t gops_rollout_workspace_bytes(const GopsRolloutDesc* desc);
+
+int gops_rollout_forward(const GopsRolloutDesc* desc, const GopsRolloutIn* in,
+                         const GopsRolloutOut* out, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* Back-propagate d(loss)/d(v_pi[b]) = grad_v[b] through the stashed rollout into the policy
+ * parameters (value/target parameters receive no gradient, as in the reference). */
+int gops_rollout_backward(const GopsRolloutDesc* desc, const GopsRolloutIn* in,
+                          const float* grad_v, const GopsMlpGrad* policy_grad,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* One wrapped env-model step.  `action` is the raw (pre-wrapper) action [B, act_dim].  For
+ * veh3dofconti the info tensors are updated into the next_* outputs (may alias the inputs
+ * except ref_points). */
+typedef struct GopsStepIO {
+    const float* obs; const float* action; const float* done;
+    const float* state; const float* ref_points; const float* path_num; const float* u_num;
+    const float* ref_time;
+    float* next_obs; float* reward; float* next_done;
+    float* next_state; float* next_ref_points; float* next_ref_time;
+} GopsStepIO;
+int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream);
+
+/* StateValue batch evaluation v = V(obs) with stash, and its backward into V's parameters. */
+size_t gops_value_workspace_bytes(const GopsMlp* value, int32_t batch);
+int gops_value_forward(const GopsMlp* value, int32_t batch, const float* obs, float* v,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int gops_value_backward(const GopsMlp* value, int32_t batch, const float* obs, const float* grad_v,
+                        const GopsMlpGrad* grad, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* Timing hook for bench.py: average duration in ms of the named internal kernel over the
+ * launches recorded since the last reset (HIP events on the launch stream).  kernel ids:
+ * 0 = forward rollout, 1 = backward sweep, 2 = weight-gradient GEMMs. */
+void gops_profile_enable(int32_t on);
+void gops_profile_reset(void);
+int gops_profile_read(int32_t kernel_id, double* avg_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOPS_HIP_H */

@@ -62,3 +62,32 @@ def reference_init_nets(cfg, seed, obs_dim, act_dim):
             p_.requires_grad_(False)
         nets["v_target"] = vt
     return nets
+
+
+# ---- HIP side: build C-ABI descriptors from the same (oracle-side) constants -------------------
+def hip_env_from_oracle(env, policy_net=None):
+    from gops_amd import hip_backend as hb
+    kind = {"lq": hb.ENV_LQ, "idp": hb.ENV_IDP, "veh": hb.ENV_VEH}[env["kind"]]
+    lq = None
+    if env["kind"] == "lq":
+        c = env["lq"]
+        lq = dict(inv_IA=c["inv_IA"], B=c["B"], Q=c["Q"], R=c["R"], dt=c["dt"],
+                  reward_scale=c["reward_scale"], reward_shift=c["reward_shift"])
+    return hb.make_env(kind, env["obs_dim"], env["act_dim"], act_low=env["act_low"], act_high=env["act_high"],
+                       min_action=env["min_action"], max_action=env["max_action"],
+                       policy_low=None if policy_net is None else policy_net["act_low"],
+                       policy_high=None if policy_net is None else policy_net["act_high"],
+                       obs_low=env["obs_low"], obs_high=env["obs_high"], pre_horizon=env.get("P", 0),
+                       reward_scale=env["reward_scale"] if env["shaping"] else None,
+                       reward_shift=env["reward_shift"] if env["shaping"] else None, lq=lq)
+
+
+def hip_mlp_from_net(net, device):
+    from gops_amd import hip_backend as hb
+    ws = [w.detach().to(device).contiguous() for w in net["w"]]
+    bs = [b.detach().to(device).contiguous() for b in net["b"]]
+    return hb.make_mlp(ws, bs, net["act"]), ws, bs
+
+
+def to_device(data, device):
+    return {k: v.to(device).contiguous() for k, v in data.items()}

@@ -1,0 +1,157 @@
+"""GPU parity: the HIP rollout (through the C ABI) against the oracle and the reference fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_meta, load_golden, rel_l2
+from helpers import (INFO_KEYS, data_from_golden, hip_env_from_oracle, hip_mlp_from_net, nets_from_golden,
+                     oracle_env, reference_init_nets, to_device)
+from oracle import adp_oracle as orc
+
+from gops_amd.utils.synthetic import CONFIGS, act_dim_of, make_batch, obs_dim_of
+
+pytestmark = pytest.mark.gpu
+
+# north_star tolerance: outputs within 1e-4 relative (L2) of the CPU fp32 reference
+TOL = 1e-4
+
+STEP_CASES = ["step_lq_s4a2", "step_lq_s6a3", "step_lq_s2a1_shaped", "step_idp", "step_veh_p10",
+              "step_veh_p30"]
+FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fhadp_idp_selu_shaped",
+               "fhadp_veh_p10_elu", "fhadp_veh_p30_sigmoid"]
+INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("name", STEP_CASES)
+def test_env_step_vs_reference_fixture(name, dev):
+    from gops_amd import hip_backend as hb
+    g = load_golden(name)
+    meta = golden_meta(g)
+    env = hip_env_from_oracle(oracle_env(meta["cfg"], meta["extra"]))
+    data = to_device(data_from_golden(g), dev)
+    obs, done = data["obs"], data["done"]
+    info = {k: data[k] for k in INFO_KEYS if k in data}
+    for s in range(int(g["meta/nsteps"])):
+        a = torch.from_numpy(g[f"s{s}/act"]).to(dev)
+        obs, r, done, ninfo = hb.env_step(env, obs, a, done, info)
+        if ninfo:
+            info = ninfo
+        # single step: the reference's own tolerance, with atol widened to fp32 trig noise
+        np.testing.assert_allclose(obs.cpu().numpy(), g[f"s{s}/obs"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(r.cpu().numpy(), g[f"s{s}/rew"], rtol=1e-5, atol=2e-5)
+        assert np.array_equal(done.cpu().numpy() != 0, g[f"s{s}/done"])
+
+
+def _run_fhadp(env, nets, data, cfg, dev):
+    from gops_amd import hip_backend as hb
+    henv = hip_env_from_oracle(env, nets["policy"])
+    mlp, ws, bs = hip_mlp_from_net(nets["policy"], dev)
+    B = data["obs"].shape[0]
+    ro = hb.Rollout(henv, mlp, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=True)
+    ddev = to_device(data, dev)
+    res = ro.forward(ddev, want_rewards=True, want_final=True)
+    gv = torch.full((B,), -1.0 / B, device=dev)
+    gw, gb = [torch.empty_like(w) for w in ws], [torch.empty_like(b) for b in bs]
+    ro.backward(gv, gw, gb)
+    torch.cuda.synchronize()
+    grads = [t for pair in zip(gw, gb) for t in pair]
+    return res, grads
+
+
+@pytest.mark.parametrize("name", FHADP_CASES)
+def test_fhadp_vs_reference_fixture(name, dev):
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg = meta["cfg"]
+    env = oracle_env(cfg, meta["extra"])
+    nets, _ = nets_from_golden(g, cfg)
+    data = data_from_golden(g)
+    res, grads = _run_fhadp(env, nets, data, cfg, dev)
+    ref = orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+    assert rel_l2(res["v_pi"].cpu(), ref["v_pi"]) < TOL
+    assert rel_l2(res["rewards"].cpu(), ref["rewards"]) < TOL
+    assert rel_l2(res["final_obs"].cpu(), ref["final_obs"]) < TOL
+    assert np.array_equal(res["final_done"].cpu().numpy() != 0, ref["final_done"].numpy())
+    loss = -res["v_pi"].double().mean().item()
+    assert abs(loss - float(g["loss"])) <= TOL * max(1.0, abs(float(g["loss"])))
+    for i, gr in enumerate(grads):
+        assert rel_l2(gr.cpu(), g[f"grad/{i}"]) < TOL, (name, i, rel_l2(gr.cpu(), g[f"grad/{i}"]))
+    flat = torch.cat([x.reshape(-1).cpu() for x in grads])
+    flat_ref = torch.cat([torch.from_numpy(g[f"grad/{i}"]).reshape(-1) for i in range(len(grads))])
+    assert rel_l2(flat, flat_ref) < TOL
+
+
+@pytest.mark.parametrize("name", INFADP_CASES)
+def test_infadp_vs_reference_fixture(name, dev):
+    from gops_amd import hip_backend as hb
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg = meta["cfg"]
+    env = oracle_env(cfg, meta["extra"])
+    nets, _ = nets_from_golden(g, cfg)
+    data = data_from_golden(g)
+    ddev = to_device(data, dev)
+    B = data["obs"].shape[0]
+    henv = hip_env_from_oracle(env, nets["policy"])
+    pol, pw, pb = hip_mlp_from_net(nets["policy"], dev)
+    vt, _, _ = hip_mlp_from_net(nets["v_target"], dev)
+    v, vw, vb = hip_mlp_from_net(nets["v"], dev)
+    # PEV: backup from a no-grad rollout with tail value; V(o) regression through the value path
+    ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=False,
+                    need_grad=False, value=vt)
+    backup = ro.forward(ddev)["v_pi"]
+    vn = hb.ValueNet(v, B)
+    vo = vn.forward(ddev["obs"])
+    loss_v = ((vo - backup) ** 2).mean().item()
+    gw, gb = [torch.empty_like(w) for w in vw], [torch.empty_like(b) for b in vb]
+    vn.backward(ddev["obs"], (2.0 / B) * (vo - backup), gw, gb)
+    torch.cuda.synchronize()
+    assert abs(loss_v - float(g["pev_loss"])) <= TOL * max(1.0, abs(float(g["pev_loss"])))
+    assert abs(vo.mean().item() - float(g["pev_vmean"])) <= TOL
+    k = 0
+    for w_, b_ in zip(gw, gb):
+        for t in (w_, b_):
+            assert rel_l2(t.cpu(), g[f"pev_grad/{k}"]) < TOL, (name, "pev", k)
+            k += 1
+    # PIM: gradient through policy, model and V_target's input
+    ro2 = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=False,
+                     need_grad=True, value=vt)
+    res = ro2.forward(ddev)
+    gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]
+    ro2.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
+    torch.cuda.synchronize()
+    loss_p = -res["v_pi"].double().mean().item()
+    assert abs(loss_p - float(g["pim_loss"])) <= TOL * max(1.0, abs(float(g["pim_loss"])))
+    k = 0
+    for w_, b_ in zip(gw, gb):
+        for t in (w_, b_):
+            assert rel_l2(t.cpu(), g[f"pim_grad/{k}"]) < TOL, (name, "pim", k, rel_l2(t.cpu(), g[f"pim_grad/{k}"]))
+            k += 1
+
+
+@pytest.mark.parametrize("name", ["cfg1_idp_fhadp_b64_h10", "cfg2_idp_fhadp_b4096_h30",
+                                  "target_veh3dof_fhadp_b4096_h30", "cfg4_veh3dof_fhadp_b4096_h50"])
+def test_fhadp_baseline_shapes_vs_reference(name, dev):
+    """BASELINE.json shapes: loss, per-parameter gradient norms and 256 sampled entries per
+    parameter against the reference's values (fixtures hold no inputs: rebuilt from the seed)."""
+    cfg = CONFIGS[name]
+    g = load_golden("big_" + name)
+    data = make_batch(cfg, 0)
+    assert abs(data["obs"].double().sum().item() - float(g["chk/obs_sum"])) < 1e-6
+    nets = reference_init_nets(cfg, 0, obs_dim_of(cfg), act_dim_of(cfg))
+    assert abs(nets["policy"]["w"][0].double().sum().item() - float(g["chk/policy_w0_sum"])) < 1e-9
+    env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10))
+    res, grads = _run_fhadp(env, nets, data, cfg, dev)
+    loss = -res["v_pi"].double().mean().item()
+    assert abs(loss - float(g["loss"])) <= TOL * abs(float(g["loss"]))
+    assert torch.isfinite(res["v_pi"]).all()
+    for i, gr in enumerate(grads):
+        got = gr.reshape(-1).cpu()[torch.from_numpy(g[f"grad/idx{i}"])]
+        assert rel_l2(got, g[f"grad/val{i}"]) < TOL, (name, i, rel_l2(got, g[f"grad/val{i}"]))
+        assert abs(gr.double().norm().item() - g["grad/norms"][i]) <= TOL * g["grad/norms"][i]

@@ -39,6 +39,11 @@ hipError_t launch_pack(const float* W, int N, int K, int Kp, float* wp, float* w
 // rounded separately in fp32, in the reference's order (no FMA contraction): the heading is a
 // 1 ms finite difference whose cancellation noise is part of the reference's result.
 // ---------------------------------------------------------------------------------------------
+// Transcendentals are evaluated in double and rounded once, i.e. correctly rounded in fp32: the CPU
+// reference (Sleef u10) is correctly rounded for almost every argument, so this minimises the
+// number of points where a 1-ulp difference in x(t) is amplified ~1e3x by the finite difference.
+#define SINF_CR(x) ((float)sin((double)(x)))
+#define COSF_CR(x) ((float)cos((double)(x)))
 #define RMUL(a, b) __fmul_rn((a), (b))
 #define RADD(a, b) __fadd_rn((a), (b))
 #define RSUB(a, b) __fsub_rn((a), (b))
@@ -48,7 +53,7 @@ __device__ __forceinline__ float ref_arc(float t, int u_num) {
     if (u_num == 0) {
         const float c1 = (float)(-1.0 / (2.0 * 3.14159265358979323846 / 10.0));
         const float c2 = (float)(1.0 / (2.0 * 3.14159265358979323846 / 10.0));
-        return RADD(RADD(RMUL(c1, cosf(RMUL(W, t))), RMUL(5.0f, t)), c2);
+        return RADD(RADD(RMUL(c1, COSF_CR(RMUL(W, t))), RMUL(5.0f, t)), c2);
     }
     return RMUL(5.0f, t);
 }
@@ -58,7 +63,7 @@ __device__ __forceinline__ void ref_xy(float t, int path, int u_num, float& x, f
     const float s = ref_arc(t, u_num);
     if (path == 0) {
         x = s;
-        y = RMUL(1.5f, sinf(RMUL(W, t)));
+        y = RMUL(1.5f, SINF_CR(RMUL(W, t)));
     } else if (path == 1) {
         x = s;
         if (t <= 5.0f) y = 0.f;
@@ -75,8 +80,8 @@ __device__ __forceinline__ void ref_xy(float t, int path, int u_num, float& x, f
         else y = 0.f;
     } else {
         const float q = s / 100.0f;
-        x = RMUL(100.0f, sinf(q));
-        y = RMUL(100.0f, RSUB(cosf(q), 1.0f));
+        x = RMUL(100.0f, SINF_CR(q));
+        y = RMUL(100.0f, RSUB(COSF_CR(q), 1.0f));
     }
 }
 
@@ -85,8 +90,8 @@ __device__ __forceinline__ f32x4 ref_point(float t, int path, int u_num) {
     float x0, y0, x1, y1;
     ref_xy(t, path, u_num, x0, y0);
     ref_xy(RADD(t, 0.001f), path, u_num, x1, y1);
-    const float phi = atan2f(RSUB(y1, y0), RSUB(x1, x0));
-    const float u = (u_num == 0) ? RADD(sinf(RMUL(W, t)), 5.0f) : 5.0f;
+    const float phi = (float)atan2((double)RSUB(y1, y0), (double)RSUB(x1, x0));
+    const float u = (u_num == 0) ? RADD(SINF_CR(RMUL(W, t)), 5.0f) : 5.0f;
     f32x4 r = {x0, y0, phi, u};
     return r;
 }

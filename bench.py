@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""Benchmark of the GOPS ADP hot path on MI355X.
+
+A "step" is one trainer iteration of the hot path on one batch: FHADP `compute_gradient` (fused
+forward rollout + backward sweep + weight-gradient GEMMs through libgops_hip.so), the gradient
+all-reduce when N > 1, and the Adam update.  Inputs are synthetic and already resident in HBM.
+Metric (BASELINE.json): env-model steps/s = N * B * H * K / wall time, weak scaling (per-GPU batch
+fixed).  Launch for N > 1:  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from gops_amd import hip_backend as hb  # noqa: E402
+from gops_amd.create_pkg.create_alg import create_alg  # noqa: E402
+from gops_amd.trainer.grad_sync import GradAllReducer  # noqa: E402
+from gops_amd.utils.synthetic import CONFIGS, act_dim_of, make_batch, obs_dim_of  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+KERNEL_NAMES = {0: "rollout_fwd_kernel", 1: "rollout_bwd_kernel", 2: "dw_gemm_kernel(+reduce)"}
+
+
+def alg_kwargs(cfg, seed):
+    A = act_dim_of(cfg)
+    kw = dict(algorithm=cfg["alg"], trainer="on_sync_trainer", seed=seed, cnn_shared=False,
+              env_id=cfg["env_id"], obsv_dim=obs_dim_of(cfg), action_dim=A, action_type="continu",
+              action_high_limit=np.ones(A, dtype=np.float32), action_low_limit=-np.ones(A, dtype=np.float32),
+              policy_func_type="MLP",
+              policy_func_name="FiniteHorizonPolicy" if cfg["alg"] == "FHADP" else "DetermPolicy",
+              policy_hidden_sizes=list(cfg["hidden"]), policy_hidden_activation=cfg["act"],
+              policy_act_distribution="default", policy_learning_rate=1e-3, use_gpu=True)
+    if cfg["alg"] == "FHADP":
+        kw["pre_horizon"] = cfg.get("pre_horizon", cfg["horizon"])
+        kw["gamma"] = cfg["gamma"]
+    else:
+        kw.update(value_func_type="MLP", value_func_name="StateValue", value_hidden_sizes=list(cfg["hidden"]),
+                  value_hidden_activation=cfg["act"], value_learning_rate=1e-3)
+        if "pre_horizon" in cfg:
+            kw["pre_horizon"] = cfg["pre_horizon"]
+    if "lq_config" in cfg:
+        kw["lq_config"] = cfg["lq_config"]
+    return kw
+
+
+def mac_per_step(cfg):
+    sizes = [obs_dim_of(cfg) + (1 if cfg["alg"] == "FHADP" else 0)] + list(cfg["hidden"]) + [act_dim_of(cfg)]
+    return sum(a * b for a, b in zip(sizes[:-1], sizes[1:]))
+
+
+def cpu_baseline(cfg, seed):
+    """The oracle (CPU restatement of the reference, pinned to its fixtures) timed on the host
+    cores of this box.  Checker only: nothing it computes is used by the GPU path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import reference_init_nets
+    from oracle import adp_oracle as orc
+    nets = reference_init_nets(cfg, seed, obs_dim_of(cfg), act_dim_of(cfg))
+    env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
+    data = make_batch(cfg, seed)
+    times = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": cfg["batch"] * cfg["horizon"] / best, "unit": "env-model steps/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"full workload batch (B={cfg['batch']}, H={cfg['horizon']}), 1 warm-up + 3 timed "
+                      f"compute_gradient calls, best of 3 ({best * 1e3:.0f} ms)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="target_veh3dof_fhadp_b4096_h30")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = CONFIGS[args.workload]
+    assert cfg["alg"] == "FHADP", "bench.py times the FHADP workloads"
+    torch.manual_seed(0)   # identical random-init weights on every replica
+    alg = create_alg(**alg_kwargs(cfg, 0))
+    alg.networks.to(device)
+    data = {k: v.to(device) for k, v in make_batch(cfg, 1000 + rank).items()}   # per-rank shard
+    reducer = GradAllReducer()
+
+    def step(it):
+        if world == 1:
+            alg.local_update(data, it)
+        else:
+            _, info = alg.get_remote_update_info(data, it)
+            reducer.average_(info)
+            alg.remote_update(info)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        step(it)
+    hb.profile_reset()
+    hb.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        step(args.warmup + it)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    hb.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        B, H = cfg["batch"], cfg["horizon"]
+        steps_total = world * B * H * args.steps
+        kern = {k: hb.profile_read(k) for k in (0, 1, 2)}
+        flops_per_launch = 2.0 * mac_per_step(cfg) * B * H      # each of fwd / dX sweep / dW
+        dom = max(kern, key=lambda k: kern[k][0])
+        dom_ms = kern[dom][0]
+        achieved = flops_per_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "env-model steps/sec (batch x H), FHADP compute_gradient + update",
+            "value": steps_total / elapsed, "unit": "env-model steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded initial states, random-init networks)",
+            "config": {"workload": args.workload, "env_id": cfg["env_id"], "algorithm": cfg["alg"],
+                       "batch_per_gpu": B, "horizon": H, "policy_mlp": [obs_dim_of(cfg) + 1] + list(cfg["hidden"]) + [act_dim_of(cfg)],
+                       "activation": cfg["act"], "parallelism": f"dp{world}"},
+            "rollouts_per_sec": world * B * args.steps / elapsed,
+            "roofline": {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": achieved,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "algorithmic_flops_per_launch": flops_per_launch,
+                         "avg_ms": dom_ms},
+            "kernels_ms": {KERNEL_NAMES[k]: {"avg_ms": kern[k][0], "launches": kern[k][1],
+                                             "tflops": (flops_per_launch / (kern[k][0] * 1e-3) / 1e12) if kern[k][0] > 0 else 0.0}
+                           for k in kern},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, 0)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,96 @@
+"""FHADP - finite-horizon approximate dynamic programming - on the fused HIP rollout.
+
+Same class surface as the reference's gops/algorithm/fhadp.py (ApproxContainer :32-55, FHADP
+:58-125): `loss = -mean_b sum_t gamma^t r_t` over an H-step model rollout with the
+FiniteHorizonPolicy, gradient into `networks.policy` parameters' `.grad`, Adam step.  The Python
+loop `for step in range(H): a = policy(o, step+1); o, r, d, info = envmodel.forward(...)` and its
+autograd replay are ONE forward and ONE backward kernel sweep (gops_rollout_forward/_backward).
+"""
+__all__ = ["FHADP"]
+
+import time
+from typing import Tuple
+
+import torch
+from torch.optim import Adam
+
+from gops_amd import hip_backend as hb
+from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, batch_to_device, cuda_device_of,
+                                     grad_buffers)
+from gops_amd.create_pkg.create_apprfunc import create_apprfunc
+from gops_amd.create_pkg.create_env_model import create_env_model
+from gops_amd.utils.common_utils import get_apprfunc_dict
+from gops_amd.utils.tensorboard_setup import tb_tags
+
+
+class ApproxContainer(ApprBase):
+    """Approximate function container for FHADP: one policy network + Adam (+ lr scheduler)."""
+
+    def __init__(self, *, policy_learning_rate: float, **kwargs):
+        super().__init__(**kwargs)
+        self.policy = create_apprfunc(**get_apprfunc_dict("policy", **kwargs))
+        self.policy_optimizer = Adam(self.policy.parameters(), lr=policy_learning_rate)
+        self.optimizer_dict = {"policy": self.policy_optimizer}
+        self.init_scheduler(**kwargs)
+
+    def create_action_distributions(self, logits):
+        return self.policy.get_act_dist(logits)
+
+
+class FHADP(AlgorithmBase):
+    """:param int pre_horizon: envmodel predict horizon.  :param float gamma: discount factor."""
+
+    def __init__(self, *, pre_horizon: int, gamma: float = 1.0, index: int = 0, **kwargs):
+        super().__init__(index, **kwargs)
+        self.networks = ApproxContainer(**kwargs)
+        self.envmodel = create_env_model(**kwargs, pre_horizon=pre_horizon)
+        self.pre_horizon = pre_horizon
+        self.gamma = gamma
+        self.tb_info = dict()
+        self._rollouts = {}
+
+    @property
+    def adjustable_parameters(self) -> Tuple[str]:
+        return ("pre_horizon", "gamma")
+
+    def _local_update(self, data, iteration: int):
+        self._compute_gradient(data)
+        self.networks.policy_optimizer.step()
+        return self.tb_info
+
+    def get_remote_update_info(self, data, iteration: int):
+        self._compute_gradient(data)
+        return self.tb_info, {"grad": [p._grad for p in self.networks.policy.parameters()]}
+
+    def _remote_update(self, update_info):
+        for p, grad in zip(self.networks.policy.parameters(), update_info["grad"]):
+            p.grad = grad
+        self.networks.policy_optimizer.step()
+
+    # ------------------------------------------------------------------------------------------
+    def _rollout_for(self, batch: int, device) -> hb.Rollout:
+        policy = self.networks.policy
+        key = (batch, self.pre_horizon, float(self.gamma), str(device))
+        ro = self._rollouts.get(key)
+        mlp = policy.hip_mlp()
+        if ro is None:
+            env = self.envmodel.hip_env(policy.act_low_lim.cpu().numpy(), policy.act_high_lim.cpu().numpy())
+            ro = hb.Rollout(env, mlp, batch=batch, horizon=self.pre_horizon, gamma=self.gamma,
+                            finite_horizon=True, need_grad=True, device=device)
+            self._rollouts = {key: ro}   # one live workspace: shapes rarely change between updates
+        else:
+            ro.set_policy(mlp)
+        return ro
+
+    def _compute_gradient(self, data):
+        start_time = time.time()
+        device = cuda_device_of(self.networks)
+        batch = batch_to_device(data, device, ("obs", "done") + _INFO_KEYS)
+        B = batch["obs"].shape[0]
+        ro = self._rollout_for(B, device)
+        v_pi = ro.forward(batch)["v_pi"]
+        loss_policy = -v_pi.mean()
+        gw, gb = grad_buffers(self.networks.policy)
+        ro.backward(torch.full((B,), -1.0 / B, dtype=torch.float32, device=device), gw, gb)
+        self.tb_info[tb_tags["loss_actor"]] = loss_policy.item()   # host sync, as in the reference
+        self.tb_info[tb_tags["alg_time"]] = (time.time() - start_time) * 1000  # ms

@@ -1,0 +1,146 @@
+"""INFADP - infinite-horizon approximate dynamic programming - on the fused HIP rollout.
+
+Same class surface as the reference's gops/algorithm/infadp.py (ApproxContainer :31-64, INFADP
+:67-213): alternating policy evaluation (PEV: regress V(o) onto the n-step model return plus the
+bootstrapped target value, rollout without gradient) and policy improvement (PIM: ascend the
+same quantity through policy, model and the target value's input), Adam + Polyak target update.
+"""
+__all__ = ["INFADP"]
+
+import time
+from copy import deepcopy
+from typing import Tuple
+
+import torch
+from torch.optim import Adam
+
+from gops_amd import hip_backend as hb
+from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, batch_to_device, cuda_device_of,
+                                     grad_buffers)
+from gops_amd.create_pkg.create_apprfunc import create_apprfunc
+from gops_amd.create_pkg.create_env_model import create_env_model
+from gops_amd.utils.common_utils import get_apprfunc_dict
+from gops_amd.utils.tensorboard_setup import tb_tags
+
+
+class ApproxContainer(ApprBase):
+    """Value + policy networks, frozen target copies, one Adam per online network.  The value
+    network is constructed BEFORE the policy (RNG draw order of the reference, infadp.py:41-42)."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        v_args = get_apprfunc_dict("value", **kwargs)
+        policy_args = get_apprfunc_dict("policy", **kwargs)
+        self.v = create_apprfunc(**v_args)
+        self.policy = create_apprfunc(**policy_args)
+        self.v_target = deepcopy(self.v)
+        self.policy_target = deepcopy(self.policy)
+        for p in list(self.v_target.parameters()) + list(self.policy_target.parameters()):
+            p.requires_grad = False
+        self.policy_optimizer = Adam(self.policy.parameters(), lr=kwargs["policy_learning_rate"])
+        self.v_optimizer = Adam(self.v.parameters(), lr=kwargs["value_learning_rate"])
+        self.net_dict = {"v": self.v, "policy": self.policy}
+        self.target_net_dict = {"v": self.v_target, "policy": self.policy_target}
+        self.optimizer_dict = {"v": self.v_optimizer, "policy": self.policy_optimizer}
+
+    def create_action_distributions(self, logits):
+        return self.policy.get_act_dist(logits)
+
+
+class INFADP(AlgorithmBase):
+    """forward_step: model rollout length; gamma; tau: Polyak factor; pev_step / pim_step:
+    alternation period of evaluation and improvement."""
+
+    def __init__(self, index=0, **kwargs):
+        super().__init__(index, **kwargs)
+        self.networks = ApproxContainer(**kwargs)
+        self.envmodel = create_env_model(**kwargs)
+        self.gamma = 0.99
+        self.tau = 0.005
+        self.pev_step = 1
+        self.pim_step = 1
+        self.forward_step = 10
+        self.tb_info = dict()
+        self._cache = {}
+
+    @property
+    def adjustable_parameters(self):
+        return ("gamma", "tau", "pev_step", "pim_step", "forward_step", "reward_scale")
+
+    def local_update(self, data: dict, iteration: int) -> dict:
+        self._update(self._compute_gradient(data, iteration))
+        return self.tb_info
+
+    def get_remote_update_info(self, data: dict, iteration: int) -> Tuple[dict, dict]:
+        update_list = self._compute_gradient(data, iteration)
+        update_info = {name: [p.grad for p in self.networks.net_dict[name].parameters()] for name in update_list}
+        return self.tb_info, update_info
+
+    def remote_update(self, update_info: dict):
+        for net_name, grads in update_info.items():
+            for p, grad in zip(self.networks.net_dict[net_name].parameters(), grads):
+                p.grad = grad
+        self._update(list(update_info.keys()))
+
+    def _update(self, update_list):
+        tau = self.tau
+        for net_name in update_list:
+            self.networks.optimizer_dict[net_name].step()
+        with torch.no_grad():
+            for net_name in update_list:
+                online = list(self.networks.net_dict[net_name].parameters())
+                target = list(self.networks.target_net_dict[net_name].parameters())
+                torch._foreach_mul_(target, 1 - tau)
+                torch._foreach_add_(target, online, alpha=tau)
+
+    # ------------------------------------------------------------------------------------------
+    def _rollout_for(self, batch: int, device, need_grad: bool) -> hb.Rollout:
+        nets = self.networks
+        key = (batch, self.forward_step, float(self.gamma), str(device), need_grad)
+        pol, vt = nets.policy.hip_mlp(), nets.v_target.hip_mlp()
+        ro = self._cache.get(key)
+        if ro is None:
+            env = self.envmodel.hip_env(nets.policy.act_low_lim.cpu().numpy(), nets.policy.act_high_lim.cpu().numpy())
+            ro = hb.Rollout(env, pol, batch=batch, horizon=self.forward_step, gamma=self.gamma,
+                            finite_horizon=False, need_grad=need_grad, value=vt, device=device)
+            self._cache[key] = ro
+        else:
+            ro.set_policy(pol, vt)
+        return ro
+
+    def _value_for(self, batch: int, device) -> hb.ValueNet:
+        key = ("v", batch, str(device))
+        mlp = self.networks.v.hip_mlp()
+        vn = self._cache.get(key)
+        if vn is None:
+            vn = self._cache[key] = hb.ValueNet(mlp, batch, device=device)
+        else:
+            vn.mlp = mlp
+        return vn
+
+    def _compute_gradient(self, data, iteration):
+        start_time = time.time()
+        device = cuda_device_of(self.networks)
+        batch = batch_to_device(data, device, ("obs", "done") + _INFO_KEYS)
+        B = batch["obs"].shape[0]
+        if iteration % (self.pev_step + self.pim_step) < self.pev_step:
+            # PEV: loss_v = mean((V(o) - [sum_t gamma^t r_t + (~d) gamma^n V_target(o_n)])^2)
+            backup = self._rollout_for(B, device, need_grad=False).forward(batch)["v_pi"]
+            vn = self._value_for(B, device)
+            v = vn.forward(batch["obs"])
+            diff = v - backup
+            gw, gb = grad_buffers(self.networks.v)
+            vn.backward(batch["obs"], (2.0 / B) * diff, gw, gb)
+            self.tb_info[tb_tags["loss_critic"]] = (diff * diff).mean().item()
+            self.tb_info[tb_tags["critic_avg_value"]] = v.mean().item()
+            update_list = ["v"]
+        else:
+            # PIM: loss = -mean(sum_t gamma^t r_t + (~d) gamma^n V_target(o_n)), grads into the policy
+            ro = self._rollout_for(B, device, need_grad=True)
+            v_pi = ro.forward(batch)["v_pi"]
+            gw, gb = grad_buffers(self.networks.policy)
+            ro.backward(torch.full((B,), -1.0 / B, dtype=torch.float32, device=device), gw, gb)
+            self.tb_info[tb_tags["loss_actor"]] = (-v_pi.mean()).item()
+            update_list = ["policy"]
+        self.tb_info[tb_tags["alg_time"]] = (time.time() - start_time) * 1000  # ms
+        return update_list

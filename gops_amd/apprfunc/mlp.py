@@ -1,0 +1,92 @@
+"""MLP approximate functions of the ADP path: DetermPolicy, FiniteHorizonPolicy, StateValue.
+
+Module structure, parameter names (`pi.0.weight` ... / `v.0.weight` ...), registered buffers and
+`forward` semantics follow the reference (gops/apprfunc/mlp.py:36-41,50-111,309-329) so that its
+`apprfunc_*.pkl` checkpoints load unchanged.  `forward` is the eager definition used by samplers
+and evaluators for single observations; inside `compute_gradient` the same parameters are read
+in place by the fused HIP rollout (`hip_mlp()`), which never calls `forward`.
+"""
+__all__ = ["DetermPolicy", "FiniteHorizonPolicy", "StateValue"]
+
+import torch
+import torch.nn as nn
+
+from gops_amd.utils.act_distribution import Action_Distribution
+from gops_amd.utils.common_utils import get_activation_func
+
+
+def mlp(sizes, activation, output_activation=nn.Identity):
+    layers = []
+    for j in range(len(sizes) - 1):
+        act = activation if j < len(sizes) - 2 else output_activation
+        layers += [nn.Linear(sizes[j], sizes[j + 1]), act()]
+    return nn.Sequential(*layers)
+
+
+class _HipMlpMixin:
+    """Exports the Linear stack as a C-ABI `GopsMlp` over the live parameter storage."""
+
+    _net_attr = "pi"
+
+    def linear_layers(self):
+        return [m for m in getattr(self, self._net_attr) if isinstance(m, nn.Linear)]
+
+    def hip_mlp(self):
+        from gops_amd import hip_backend as hb
+        if self._output_activation != "linear":
+            raise RuntimeError("the HIP rollout supports a linear output activation only")
+        layers = self.linear_layers()
+        return hb.make_mlp([l.weight.data for l in layers], [l.bias.data for l in layers],
+                           self._hidden_activation)
+
+
+class DetermPolicy(nn.Module, Action_Distribution, _HipMlpMixin):
+    """Deterministic policy: obs -> tanh-squashed action."""
+
+    _time_input = False
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        obs_dim = kwargs["obs_dim"] + (1 if self._time_input else 0)
+        sizes = [obs_dim] + list(kwargs["hidden_sizes"]) + [kwargs["act_dim"]]
+        self._hidden_activation = kwargs["hidden_activation"]
+        self._output_activation = kwargs.get("output_activation", "linear")
+        self.pi = mlp(sizes, get_activation_func(self._hidden_activation),
+                      get_activation_func(self._output_activation))
+        self.register_buffer("act_high_lim", torch.from_numpy(kwargs["act_high_lim"]))
+        self.register_buffer("act_low_lim", torch.from_numpy(kwargs["act_low_lim"]))
+        self.action_distribution_cls = kwargs["action_distribution_cls"]
+
+    def _squash(self, y):
+        return (self.act_high_lim - self.act_low_lim) / 2 * torch.tanh(y) + (self.act_high_lim + self.act_low_lim) / 2
+
+    def forward(self, obs):
+        return self._squash(self.pi(obs))
+
+
+class FiniteHorizonPolicy(DetermPolicy):
+    """Finite-horizon policy: the (un-normalised) virtual time step is one more input column."""
+
+    _time_input = True
+
+    def forward(self, obs, virtual_t=1):
+        t = virtual_t * torch.ones(size=[obs.shape[0], 1], dtype=torch.float32, device=obs.device)
+        return self._squash(self.pi(torch.cat((obs, t), 1)))
+
+
+class StateValue(nn.Module, Action_Distribution, _HipMlpMixin):
+    """State-value function: obs -> scalar."""
+
+    _net_attr = "v"
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self._hidden_activation = kwargs["hidden_activation"]
+        self._output_activation = kwargs.get("output_activation", "linear")
+        self.v = mlp([kwargs["obs_dim"]] + list(kwargs["hidden_sizes"]) + [1],
+                     get_activation_func(self._hidden_activation),
+                     get_activation_func(self._output_activation))
+        self.action_distribution_cls = kwargs["action_distribution_cls"]
+
+    def forward(self, obs):
+        return torch.squeeze(self.v(obs), -1)

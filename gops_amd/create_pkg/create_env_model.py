@@ -1,0 +1,153 @@
+"""create_env_model: string-keyed registry of model-type environments plus the wrapper chain.
+
+Same surface as the reference's gops/create_pkg/create_env_model.py:51-147 (registry filled by
+scanning `env/env_*/env_model/*.py` for `env_model_creator` or the CamelCase class; the same
+keyword arguments select the wrappers).  Where the reference nests one Python object per wrapper
+(ScaleAction -> ClipAction -> ClipObservation -> ShapingReward -> MaskAtDone -> base), here the
+chain is a set of constants on ONE object, because the whole chain is evaluated inside the HIP
+kernels (csrc/common.h wrap_action, csrc/rollout_fwd.hip).
+"""
+import importlib
+import os
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from gops_amd import hip_backend as hb
+from gops_amd.utils.gops_path import env_path, underline2camel
+
+
+@dataclass
+class Spec:
+    env_id: str
+    entry_point: Callable
+    kwargs: dict = field(default_factory=dict)
+
+
+registry: Dict[str, Spec] = {}
+
+
+def register(env_id: str, entry_point: Union[Callable, str], **kwargs):
+    registry[env_id] = Spec(env_id=env_id, entry_point=entry_point, kwargs=kwargs)
+
+
+class WrappedEnvModel:
+    """The wrapped model: base model + ScaleAction/ClipAction/ClipObservation/ShapingReward/
+    MaskAtDone constants.  `forward` is one fused `gops_env_step`; `hip_env()` exports the
+    constants for the fused horizon rollout."""
+
+    def __init__(self, model, *, min_action, max_action, clip_obs: bool,
+                 reward_scale: Optional[float], reward_shift: Optional[float]):
+        self.model = model
+        self.min_action = torch.zeros_like(model.action_lower_bound) + torch.as_tensor(
+            min_action, dtype=torch.float32, device=model.action_lower_bound.device)
+        self.max_action = torch.zeros_like(model.action_upper_bound) + torch.as_tensor(
+            max_action, dtype=torch.float32, device=model.action_upper_bound.device)
+        # like ScaleActionModel, the wrapped model advertises the scaled action range
+        self.action_lower_bound, self.action_upper_bound = self.min_action, self.max_action
+        self.clip_obs = clip_obs
+        self.reward_scale, self.reward_shift = reward_scale, reward_shift
+        self._env_cache = {}
+
+    def __getattr__(self, name):   # obs_dim, dt, obs bounds, get_constraint, ... from the base model
+        return getattr(self.__dict__["model"], name)
+
+    @property
+    def unwrapped(self):
+        return self.model.unwrapped
+
+    def hip_env(self, policy_low=None, policy_high=None) -> hb.GopsEnv:
+        key = (None if policy_low is None else tuple(np.asarray(policy_low, dtype=np.float32).reshape(-1).tolist()),
+               None if policy_high is None else tuple(np.asarray(policy_high, dtype=np.float32).reshape(-1).tolist()))
+        if key not in self._env_cache:
+            m = self.model
+            self._env_cache[key] = hb.make_env(
+                m.hip_kind, m.obs_dim, m.action_dim, act_low=m.action_lower_bound.cpu(),
+                act_high=m.action_upper_bound.cpu(), min_action=self.min_action.cpu(),
+                max_action=self.max_action.cpu(), policy_low=policy_low, policy_high=policy_high,
+                obs_low=m.obs_lower_bound.cpu() if self.clip_obs else None,
+                obs_high=m.obs_upper_bound.cpu() if self.clip_obs else None,
+                pre_horizon=getattr(m, "pre_horizon", 0), reward_scale=self.reward_scale,
+                reward_shift=self.reward_shift, **m.hip_constants())
+        return self._env_cache[key]
+
+    def forward(self, obs: torch.Tensor, action: torch.Tensor, done: torch.Tensor, info: Dict
+                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Dict]:
+        if not obs.is_cuda:
+            raise RuntimeError("env_model.forward runs on the MI355X only (tensors must be on 'cuda'); "
+                               "there is no CPU fallback in gops_amd")
+        f = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+        dev_info = {k: f(info[k]) for k in ("state", "ref_points", "path_num", "u_num", "ref_time")
+                    if isinstance(info, dict) and k in info and info[k] is not None}
+        nobs, rew, ndone, ninfo = hb.env_step(self.hip_env(), f(obs), f(action), f(done), dev_info)
+        if not ninfo:
+            ninfo = {"constraint": None}
+        return nobs, rew, ndone.bool(), ninfo
+
+
+def create_env_model(
+    env_id: str,
+    *,
+    reward_shift: Optional[float] = None,
+    reward_scale: Optional[float] = None,
+    obs_shift: Union[np.ndarray, float, list, None] = None,
+    obs_scale: Union[np.ndarray, float, list, None] = None,
+    clip_obs: bool = True,
+    clip_action: bool = True,
+    mask_at_done: bool = True,
+    repeat_num: Optional[int] = None,
+    sum_reward: bool = True,
+    action_scale: bool = True,
+    min_action: Union[float, int, np.ndarray, list] = -1.0,
+    max_action: Union[float, int, np.ndarray, list] = 1.0,
+    **kwargs,
+) -> object:
+    """Build the model `<env_id>_model` and apply the wrappers selected by the arguments (same
+    arguments, defaults and KeyError/RuntimeError behaviour as the reference)."""
+    env_model_id = env_id + "_model"
+    spec_ = registry.get(env_model_id)
+    if spec_ is None:
+        raise KeyError(f"No registered env with id: {env_model_id}")
+    _kwargs = spec_.kwargs.copy()
+    _kwargs.update(kwargs)
+    _kwargs["device"] = "cuda" if _kwargs.get("use_gpu", False) else "cpu"
+    if not callable(spec_.entry_point):
+        raise RuntimeError(f"{spec_.env_id} registered but entry_point is not specified")
+    env_model = spec_.entry_point(**_kwargs)
+
+    # wrapper options outside the fused kernels' contract are refused, never silently ignored
+    if repeat_num is not None:
+        raise RuntimeError("ActionRepeatModel (repeat_num) is not supported by the HIP env models")
+    if obs_shift is not None or obs_scale is not None:
+        raise RuntimeError("ScaleObservationModel (obs_shift/obs_scale) is not supported by the HIP env models")
+    if not mask_at_done:
+        raise RuntimeError("mask_at_done=False is not supported by the HIP env models")
+    if not action_scale:
+        if not clip_action:
+            raise RuntimeError("action_scale=False with clip_action=False is not supported by the HIP env models")
+        # ClipActionModel alone == scaling from [low, high] onto itself
+        min_action, max_action = env_model.action_lower_bound.cpu().numpy(), env_model.action_upper_bound.cpu().numpy()
+    shaping = reward_scale is not None or reward_shift is not None
+    return WrappedEnvModel(
+        env_model, min_action=min_action, max_action=max_action, clip_obs=clip_obs,
+        reward_scale=(1.0 if reward_scale is None else reward_scale) if shaping else None,
+        reward_shift=(0.0 if reward_shift is None else reward_shift) if shaping else None)
+
+
+# fill the registry: every env/env_*/env_model/<id>.py exporting env_model_creator or <Id>
+for _env_dir in sorted(e for e in os.listdir(env_path) if e.startswith("env_")):
+    _model_dir = os.path.join(env_path, _env_dir, "env_model")
+    if not os.path.exists(_model_dir):
+        continue
+    for _file in sorted(os.listdir(_model_dir)):
+        if _file.endswith(".py") and _file[0] != "_" and "base" not in _file:
+            _id = _file[:-3]
+            _mdl = importlib.import_module(f"gops_amd.env.{_env_dir}.env_model.{_id}")
+            if hasattr(_mdl, "env_model_creator"):
+                register(env_id=_id, entry_point=getattr(_mdl, "env_model_creator"))
+            elif hasattr(_mdl, underline2camel(_id)):
+                register(env_id=_id, entry_point=getattr(_mdl, underline2camel(_id)))
+            else:
+                print(f"env {_id} has no env_model_creator or {underline2camel(_id)} in {_env_dir}")

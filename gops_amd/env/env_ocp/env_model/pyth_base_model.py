@@ -1,0 +1,46 @@
+"""Base class of the model-type environments (contract of the reference's
+gops/env/env_ocp/env_model/pyth_base_model.py:21-85): dimensions, dt, bound tensors on `device`,
+`forward(obs, action, done, info) -> (next_obs, reward, next_done, next_info)`, `.unwrapped`.
+
+Every concrete model here is evaluated on the MI355X: `forward` is one call of `gops_env_step`
+(include/gops_hip.h) and the fused horizon rollout reads the same constants through
+`hip_constants()`.
+"""
+from typing import Callable, Dict, Optional, Sequence, Tuple, Union
+
+import torch
+
+
+class PythBaseModel:
+    hip_kind: int = 0  # GOPS_ENV_* id of the HIP implementation
+
+    def __init__(self, obs_dim: int, action_dim: int, dt: Optional[float] = None,
+                 obs_lower_bound: Optional[Sequence] = None, obs_upper_bound: Optional[Sequence] = None,
+                 action_lower_bound: Optional[Sequence] = None, action_upper_bound: Optional[Sequence] = None,
+                 device: Union[torch.device, str, None] = None):
+        self.obs_dim, self.action_dim, self.dt, self.device = obs_dim, action_dim, dt, device
+
+        def bound(v, n, fill):
+            v = [fill] * n if v is None else v
+            return torch.tensor(v, dtype=torch.float32, device=device)
+
+        self.obs_lower_bound = bound(obs_lower_bound, obs_dim, float("-inf"))
+        self.obs_upper_bound = bound(obs_upper_bound, obs_dim, float("inf"))
+        self.action_lower_bound = bound(action_lower_bound, action_dim, float("-inf"))
+        self.action_upper_bound = bound(action_upper_bound, action_dim, float("inf"))
+
+    # optional hooks with the reference's names (pyth_base_model.py:69-81)
+    get_constraint: Callable = None
+    get_terminal_cost: Callable = None
+
+    def hip_constants(self) -> Dict:
+        """Extra keyword arguments for `hip_backend.make_env` (e.g. the LQ matrices)."""
+        return {}
+
+    def forward(self, obs: torch.Tensor, action: torch.Tensor, done: torch.Tensor, info: Dict
+                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Dict]:
+        raise NotImplementedError
+
+    @property
+    def unwrapped(self):
+        return self

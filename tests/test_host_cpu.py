@@ -1,0 +1,180 @@
+"""CPU-only checks of the host layer: C-ABI library exports, factories/registries, error
+behaviour, state_dict layout and the N>1 gradient exchange (gloo, world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fhadp_kwargs(**over):
+    kw = dict(algorithm="FHADP", trainer="on_serial_trainer", seed=0, env_id="pyth_idpendulum", pre_horizon=10,
+              obsv_dim=6, action_dim=1, action_type="continu", action_high_limit=np.ones(1, np.float32),
+              action_low_limit=-np.ones(1, np.float32), policy_func_type="MLP",
+              policy_func_name="FiniteHorizonPolicy", policy_hidden_sizes=[64, 64],
+              policy_hidden_activation="gelu", policy_act_distribution="default", policy_learning_rate=1e-3,
+              use_gpu=False)
+    kw.update(over)
+    return kw
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/gops_hip.h is exported by the built library."""
+    from gops_amd import hip_backend as hb
+    header = open(os.path.join(ROOT, "include", "gops_hip.h")).read()
+    declared = set(re.findall(r"\b(gops_[a-z_]+)\s*\(", header))
+    assert declared == set(hb.EXPORTED_SYMBOLS)
+    assert os.path.exists(hb.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(hb.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert hb.lib().gops_hip_version() == 1
+
+
+def test_workspace_query_and_rejections_need_no_gpu():
+    from gops_amd import hip_backend as hb
+    d = hb.GopsRolloutDesc()
+    assert hb.lib().gops_rollout_workspace_bytes(ctypes.byref(d)) == 0     # empty descriptor rejected
+    from gops_amd.create_pkg.create_env_model import create_env_model
+    env = create_env_model("pyth_veh3dofconti", pre_horizon=30).hip_env()
+    d.batch, d.horizon, d.finite_horizon, d.need_grad, d.gamma, d.env = 4096, 30, 1, 1, 1.0, env
+    m = hb.GopsMlp()
+    m.n_layers = 3
+    for i, s in enumerate([127, 256, 256, 2]):
+        m.sizes[i] = s
+    for j in range(3):
+        m.weight[j] = m.bias[j] = 1   # non-null placeholders: the size query never dereferences
+    m.hidden_act = hb.ACT_IDS["elu"]
+    d.policy = m
+    nbytes = hb.lib().gops_rollout_workspace_bytes(ctypes.byref(d))
+    stash = 4096 * 30 * 4 * (128 + 2 * 256 + 2 * 256)   # X + H1,H2 + D1,D2
+    assert stash < nbytes < 2 * stash
+    m.sizes[1] = 250                                     # hidden width not a multiple of 16
+    d.policy = m
+    assert hb.lib().gops_rollout_workspace_bytes(ctypes.byref(d)) == 0
+
+
+def test_registries_and_error_behaviour():
+    from gops_amd.create_pkg import create_alg, create_apprfunc, create_env_model, create_trainer
+    assert set(create_alg.registry) == {"FHADP", "INFADP"}
+    assert {"mlp_DetermPolicy", "mlp_FiniteHorizonPolicy", "mlp_StateValue"} <= set(create_apprfunc.registry)
+    assert {"pyth_lq_model", "pyth_idpendulum_model", "pyth_veh3dofconti_model"} <= set(create_env_model.registry)
+    assert {"on_serial_trainer", "on_sync_trainer"} <= set(create_trainer.registry)
+    with pytest.raises(KeyError, match="No registered algorithm with id"):
+        create_alg.create_alg(algorithm="NOPE")
+    with pytest.raises(KeyError, match="No registered env with id"):
+        create_env_model.create_env_model("pyth_nope")
+    with pytest.raises(KeyError, match="No registered apprfunc with id"):
+        create_apprfunc.create_apprfunc(apprfunc="MLP", name="Nope")
+    with pytest.raises(KeyError, match="No registered trainer with id"):
+        create_trainer.create_trainer(None, None, None, None, trainer="nope_trainer")
+    with pytest.raises(RuntimeError):
+        create_env_model.create_env_model("pyth_lq", repeat_num=2)
+
+
+def test_state_dict_layout_and_parameter_api():
+    from gops_amd.create_pkg.create_alg import create_alg
+    alg = create_alg(**_fhadp_kwargs())
+    assert list(alg.state_dict()) == ["policy.act_high_lim", "policy.act_low_lim", "policy.pi.0.weight",
+                                      "policy.pi.0.bias", "policy.pi.2.weight", "policy.pi.2.bias",
+                                      "policy.pi.4.weight", "policy.pi.4.bias"]
+    assert alg.networks.policy.pi[0].weight.shape == (64, 7)       # obs + virtual time column
+    alg.set_parameters({"gamma": 0.9, "pre_horizon": 5})
+    assert alg.get_parameters() == {"pre_horizon": 5, "gamma": 0.9}
+    with pytest.raises(RuntimeError):
+        alg.set_parameters({"tau": 0.1})
+    a = alg.networks.policy(torch.zeros(3, 6), 4)
+    assert a.shape == (3, 1) and a.abs().max() <= 1
+    inf = create_alg(**_fhadp_kwargs(algorithm="INFADP", policy_func_name="DetermPolicy", value_func_type="MLP",
+                                     value_func_name="StateValue", value_hidden_sizes=[64, 64],
+                                     value_hidden_activation="gelu", value_learning_rate=1e-3))
+    keys = list(inf.state_dict())
+    assert keys[0] == "v.v.0.weight" and "v_target.v.4.bias" in keys and "policy_target.pi.0.weight" in keys
+    # lr scheduler wiring like the reference's example scripts
+    sch = create_alg(**_fhadp_kwargs(policy_scheduler={"name": "LinearLR", "params": {
+        "start_factor": 1.0, "end_factor": 0.0, "total_iters": 10}}))
+    assert "policy_scheduler" in sch.networks.scheduler_dict
+
+
+def test_reference_random_init_is_reproduced():
+    """Same seed -> same nn.Linear draws as the reference's FHADP constructor (fixture checksum)."""
+    from conftest import load_golden
+    from gops_amd.create_pkg.create_alg import create_alg
+    g = load_golden("big_cfg1_idp_fhadp_b64_h10")
+    torch.manual_seed(0)
+    alg = create_alg(**_fhadp_kwargs())
+    assert abs(alg.networks.policy.pi[0].weight.double().sum().item() - float(g["chk/policy_w0_sum"])) < 1e-9
+
+
+def test_no_cpu_fallback():
+    from gops_amd.create_pkg.create_alg import create_alg
+    from gops_amd.utils.synthetic import make_batch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    alg = create_alg(**_fhadp_kwargs())
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        alg.local_update(make_batch(dict(env_id="pyth_idpendulum", batch=8), 0), 0)
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from gops_amd.trainer.grad_sync import GradAllReducer, broadcast_parameters
+from gops_amd.trainer.on_sync_trainer import OnSyncTrainer
+dist.init_process_group("gloo")
+r, n = dist.get_rank(), dist.get_world_size()
+
+class FakeAlg:   # same update API as FHADP, CPU arithmetic: grad = mean over the local batch of x
+    def __init__(self):
+        torch.manual_seed(100 + r)   # deliberately different init per rank: trainer must broadcast
+        self.networks = torch.nn.Linear(3, 1, bias=False)
+        self.tb_info = {}
+    def get_remote_update_info(self, data, it):
+        return self.tb_info, {"grad": [data["obs"].mean(0, keepdim=True).clone()]}
+    def remote_update(self, info):
+        with torch.no_grad():
+            self.networks.weight -= 0.5 * info["grad"][0]
+
+class Sampler:
+    networks = None
+    def sample_with_replay_format(self):
+        g = torch.Generator().manual_seed(r)
+        return {"obs": torch.rand(4, 3, generator=g)}, {}
+    def get_total_sample_number(self): return 0
+
+alg = FakeAlg()
+tr = OnSyncTrainer(alg, Sampler(), None, max_iteration=1, log_save_interval=10, apprfunc_save_interval=10,
+                   eval_interval=10, save_folder=None, ini_network_dir=None, use_gpu=False)
+w0 = alg.networks.weight.detach().clone()
+gathered = [torch.zeros_like(w0) for _ in range(n)]
+dist.all_gather(gathered, w0)
+assert all(torch.equal(g, gathered[0]) for g in gathered), "replicas not broadcast from rank 0"
+tr.step()
+batches = [torch.rand(4, 3, generator=torch.Generator().manual_seed(k)) for k in range(n)]
+expect = w0 - 0.5 * torch.cat(batches).mean(0, keepdim=True)   # gradient of the CONCATENATED batch
+assert torch.allclose(alg.networks.weight, expect, atol=1e-7), (alg.networks.weight, expect)
+red = GradAllReducer()
+info = {"policy": [torch.full((5,), float(r)), torch.full((2, 2), 10.0 * r)], "v": [torch.ones(3) * (r + 1)]}
+red.average_(info)
+assert torch.allclose(info["policy"][0], torch.full((5,), (n - 1) / 2))
+assert torch.allclose(info["v"][0], torch.ones(3) * (n + 1) / 2)
+dist.destroy_process_group()
+open(os.path.join(sys.argv[2], f"ok_{r}"), "w").write("ok")
+"""
+
+
+def test_sync_trainer_gradient_exchange_world_size_2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29671", str(script), ROOT, str(tmp_path)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()

@@ -8,6 +8,7 @@ Metric (BASELINE.json): env-model steps/s = N * B * H * K / wall time, weak scal
 fixed).  Launch for N > 1:  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -100,7 +101,8 @@ def main():
     cfg = CONFIGS[args.workload]
     assert cfg["alg"] == "FHADP", "bench.py times the FHADP workloads"
     torch.manual_seed(0)   # identical random-init weights on every replica
-    alg = create_alg(**alg_kwargs(cfg, 0))
+    with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
+        alg = create_alg(**alg_kwargs(cfg, 0))
     alg.networks.to(device)
     data = {k: v.to(device) for k, v in make_batch(cfg, 1000 + rank).items()}   # per-rank shard
     reducer = GradAllReducer()

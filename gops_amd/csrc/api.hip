@@ -1,6 +1,8 @@
 // Host side of the C ABI (include/gops_hip.h): argument checking, workspace carving, launch
 // sequencing.  Nothing here allocates device memory or synchronises the stream.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -8,10 +10,11 @@
 
 #include "common.h"
 
-hipError_t launch_rollout_fwd(const RolloutParams& p, hipStream_t stream);
-hipError_t launch_rollout_bwd(const RolloutParams& p, hipStream_t stream);
-size_t rollout_fwd_lds_bytes(int ldx, int ldh);
-size_t rollout_bwd_lds_bytes(int ldx, int ldh);
+hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);
+hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);
+size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points);
+size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points);
+hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s);
 hipError_t launch_pack(const float* W, int N, int K, int Kp, float* wp, float* wpt, hipStream_t s);
 hipError_t launch_ref_table(int B, int P, int H, const GopsRolloutIn& in, float pdt, float* table, hipStream_t s);
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
@@ -77,7 +80,7 @@ DwPlan plan_dw(int N, int Kp, long long S) {
     const int T = d.big ? 128 : 64;
     const int tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
     const long long chunks = (S + DW_SC_HOST - 1) / DW_SC_HOST;
-    long long splits = (1024 + tiles - 1) / tiles;
+    long long splits = (512 + tiles - 1) / tiles;
     if (splits > chunks) splits = chunks;
     if (splits < 1) splits = 1;
     d.chunks_per_split = (int)((chunks + splits - 1) / splits);
@@ -119,6 +122,7 @@ void carve_packs(Carver& c, MlpDev& d) {
 
 struct Plan {
     RolloutParams p;
+    RolloutParams* dev_params = nullptr;   // device copy read by the rollout kernels
     float* dw_part = nullptr;
     float* dw_part_b = nullptr;
     size_t bytes = 0;
@@ -159,11 +163,13 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         for (int j = 1; j < p.val.nl; ++j) hmax = p.val.dims[j] > hmax ? p.val.dims[j] : hmax;
     p.ldx = kp0 + 4;
     p.ldh = hmax + 4;
-    if (rollout_fwd_lds_bytes(p.ldx, p.ldh) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh) > 160 * 1024)
+    const int ref_pts = (e.kind == GOPS_ENV_VEH3DOFCONTI) ? e.pre_horizon + 1 + desc.horizon : 0;
+    if (rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts) > 160 * 1024)
         return GOPS_ERR_UNSUPPORTED;
     for (int t = 0; t <= p.H; ++t) p.gpow[t] = (float)pow(desc.gamma, (double)t);
 
     Carver c(ws);
+    plan.dev_params = reinterpret_cast<RolloutParams*>(c.take((sizeof(RolloutParams) + 3) / 4));
     carve_packs(c, p.pol);
     if (p.tail) carve_packs(c, p.val);
     const long long S = (long long)p.B * p.H;
@@ -235,8 +241,23 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
                                         const_cast<float*>(p.ref_table), s);
         if (e != hipSuccess) return (int)e;
     }
-    ProfScope scope(0, s);
-    return (int)launch_rollout_fwd(p, s);
+    static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
+    const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
+    if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 8 * sizeof(unsigned long long));
+    p.dbg = dbg ? dbg_buf : nullptr;
+    int ret;
+    {
+        ProfScope scope(0, s);
+        hipError_t ue = launch_upload_params(p, plan.dev_params, s);
+        ret = (ue != hipSuccess) ? (int)ue : (int)launch_rollout_fwd(p, plan.dev_params, s);
+    }
+    if (dbg) {
+        unsigned long long h[8];
+        (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[gops dbg] fwd cycles/step: top+sync %llu | xstash %llu | hidden %llu | head %llu | envstash %llu | env %llu\n",
+                h[0] / p.H, h[1] / p.H, h[2] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H);
+    }
+    return ret;
 }
 
 int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const float* grad_v,
@@ -252,9 +273,20 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     for (int j = 0; j < p.pol.nl; ++j)
         if (grad.weight[j] == nullptr || grad.bias[j] == nullptr) return GOPS_ERR_BAD_ARG;
     hipError_t e;
+    static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
+    const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
+    if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 8 * sizeof(unsigned long long));
+    p.dbg = dbg ? dbg_buf : nullptr;
     {
         ProfScope scope(1, s);
-        if ((e = launch_rollout_bwd(p, s)) != hipSuccess) return (int)e;
+        if ((e = launch_upload_params(p, plan.dev_params, s)) != hipSuccess) return (int)e;
+        if ((e = launch_rollout_bwd(p, plan.dev_params, s)) != hipSuccess) return (int)e;
+    }
+    if (dbg) {
+        unsigned long long h[8];
+        (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[gops dbg] bwd cycles/step: loop-top %llu | env adjoint %llu | mlp backward %llu\n",
+                h[0] / p.H, h[1] / p.H, h[2] / p.H);
     }
     ProfScope scope(2, s);
     const long long S = (long long)p.B * p.H;

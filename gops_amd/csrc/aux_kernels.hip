@@ -34,6 +34,20 @@ hipError_t launch_pack(const float* W, int N, int K, int Kp, float* wp, float* w
     return hipGetLastError();
 }
 
+// Copies the by-value parameter block into device memory (stream ordered, no host staging): the
+// rollout kernels then read it with uniform scalar loads instead of a per-lane scratch copy.
+__global__ void upload_params_kernel(const RolloutParams p, RolloutParams* dst) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(&p);
+    unsigned* d = reinterpret_cast<unsigned*>(dst);
+    for (unsigned i = threadIdx.x; i < sizeof(RolloutParams) / 4; i += blockDim.x) d[i] = src[i];
+}
+
+hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s) {
+    static_assert(sizeof(RolloutParams) % 4 == 0, "parameter block must be dword sized");
+    hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, s, p, dst);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Reference trajectories of pyth_veh3dofconti (ref_traj_model.py:26-232).  Every operation is
 // rounded separately in fp32, in the reference's order (no FMA contraction): the heading is a
@@ -264,22 +278,38 @@ hipError_t launch_dw_out(const float* dy, const float* h, int K, int A, long lon
     return hipGetLastError();
 }
 
-// out[r][c] = sum_split part[split][r][c]   for c < cols (row stride `ld` inside a split)
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int splits, int rows, int cols,
-                                       int ld, float* __restrict__ out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * cols) return;
-    const int r = idx / cols, c = idx - r * cols;
-    const size_t stride = (size_t)rows * ld;
-    const float* p = part + (size_t)r * ld + c;
-    float acc = 0.f;
-    for (int s = 0; s < splits; ++s) acc += p[s * stride];
-    out[idx] = acc;
+// out[r][c] = sum_split part[split][r][c]   for c < cols (row stride `ld` inside a split).
+// Block = 64 outputs x 4 split lanes; each lane sums every 4th split with independent loads in
+// flight, then the 4 lanes are combined through LDS (fixed order -> deterministic).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits,
+                                                              int rows, int cols, int ld,
+                                                              float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;
+    const bool valid = idx < rows * cols;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    if (valid) {
+        const int r = idx / cols, c = idx - r * cols;
+        const size_t stride = (size_t)rows * ld;
+        const float* p = part + (size_t)r * ld + c;
+        int s = sl;
+        for (; s + 12 < splits; s += 16) {
+            acc0 += p[(size_t)s * stride];
+            acc1 += p[(size_t)(s + 4) * stride];
+            acc2 += p[(size_t)(s + 8) * stride];
+            acc3 += p[(size_t)(s + 12) * stride];
+        }
+        for (; s < splits; s += 4) acc0 += p[(size_t)s * stride];
+    }
+    red[sl][o] = (acc0 + acc1) + (acc2 + acc3);
+    __syncthreads();
+    if (sl == 0 && valid) out[idx] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
 }
 
 hipError_t launch_reduce(const float* part, int splits, int rows, int cols, int ld, float* out, hipStream_t s) {
     const int total = rows * cols;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, splits,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 63) / 64), dim3(256), 0, s, part, splits,
                        rows, cols, ld, out);
     return hipGetLastError();
 }

@@ -8,7 +8,7 @@
 #define TB GOPS_TILE      // trajectories per workgroup tile = MFMA M
 #define NTHREADS 256      // 4 wavefronts of 64
 #define DW_SC_HOST 32     // samples per staged chunk of the dW GEMM (== DW_SC in aux_kernels.hip)
-#define DW_OUT_SPLITS 1024  // sample splits of the output-layer weight gradient
+#define DW_OUT_SPLITS 256   // sample splits of the output-layer weight gradient
 #define ENV_STASH 16      // floats of per-(t,b) env stash: [0..3] abar, [4] done_t, [5..10] state_t
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -47,39 +47,70 @@ struct RolloutParams {
     GopsRolloutOut out;
     const float* grad_v;              // backward only
     const float* ref_table;           // veh: [B][P+1+H][4]
+    unsigned long long* dbg;          // debug: per-phase cycle counters of block 0 (GOPS_DBG_TIMING)
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double
 };
+
+// per-phase cycle accounting of block 0 / thread 0 (debug builds of the timing knob only)
+#define DBG_TICK(i)                                                            \
+    if (dbg_on) {                                                              \
+        const long long now_ = clock64();                                      \
+        dbg_acc[i] += now_ - dbg_last;                                         \
+        dbg_last = now_;                                                       \
+    }
 
 // ---- activations ---------------------------------------------------------------------------
 #define SELU_SCALE 1.0507009873554804934193349852946f
 #define SELU_ALPHA 1.6732632423543772848170429916717f
 
-__device__ __forceinline__ float act_fwd(int kind, float z) {
-    switch (kind) {
-        case GOPS_ACT_RELU: return fmaxf(z, 0.f);
-        case GOPS_ACT_ELU: return z > 0.f ? z : expm1f(z);
-        case GOPS_ACT_GELU: return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
-        case GOPS_ACT_SELU: return SELU_SCALE * (z > 0.f ? z : SELU_ALPHA * expm1f(z));
-        case GOPS_ACT_SIGMOID: return 1.f / (1.f + expf(-z));
-        case GOPS_ACT_TANH: return tanhf(z);
-        default: return z;
-    }
+// exp(z) - 1 for z <= 0 without libm's branchy expm1f: Taylor series where the subtraction would
+// cancel (|z| < 0.25, truncation < 2e-9 relative), hardware exp elsewhere (abs. error ~1e-7).
+__device__ __forceinline__ float expm1_neg(float z) {
+    const float p = z * (1.f + z * (0.5f + z * (1.6666667e-1f + z * (4.1666668e-2f + z * (8.3333338e-3f +
+                    z * (1.3888889e-3f + z * 1.9841270e-4f))))));
+    const float e = __expf(z) - 1.f;
+    return z > -0.25f ? p : e;
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd_t(float z) {
+    if (ACT == GOPS_ACT_RELU) return fmaxf(z, 0.f);
+    if (ACT == GOPS_ACT_ELU) return z > 0.f ? z : expm1_neg(z);
+    if (ACT == GOPS_ACT_GELU) return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
+    if (ACT == GOPS_ACT_SELU) return SELU_SCALE * (z > 0.f ? z : SELU_ALPHA * expm1_neg(z));
+    if (ACT == GOPS_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
+    if (ACT == GOPS_ACT_TANH) return tanhf(z);
+    return z;
 }
 
 // derivative act'(z); `h` is the stashed activation act(z), `z` only valid for GELU
-__device__ __forceinline__ float act_bwd(int kind, float h, float z) {
+template <int ACT>
+__device__ __forceinline__ float act_bwd_t(float h, float z) {
+    if (ACT == GOPS_ACT_RELU) return h > 0.f ? 1.f : 0.f;
+    if (ACT == GOPS_ACT_ELU) return h > 0.f ? 1.f : h + 1.f;
+    if (ACT == GOPS_ACT_GELU) {
+        const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+        return cdf + z * pdf;
+    }
+    if (ACT == GOPS_ACT_SELU) return h > 0.f ? SELU_SCALE : h + SELU_SCALE * SELU_ALPHA;
+    if (ACT == GOPS_ACT_SIGMOID) return h * (1.f - h);
+    if (ACT == GOPS_ACT_TANH) return 1.f - h * h;
+    return 1.f;
+}
+
+// Run `body.template operator()<ACT>()` for the runtime activation id: the switch is taken once per
+// layer, the per-element loops inside are branch-free.
+template <class F>
+__device__ __forceinline__ void act_dispatch(int kind, F&& body) {
     switch (kind) {
-        case GOPS_ACT_RELU: return h > 0.f ? 1.f : 0.f;
-        case GOPS_ACT_ELU: return h > 0.f ? 1.f : h + 1.f;
-        case GOPS_ACT_GELU: {
-            const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
-            const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
-            return cdf + z * pdf;
-        }
-        case GOPS_ACT_SELU: return h > 0.f ? SELU_SCALE : h + SELU_SCALE * SELU_ALPHA;
-        case GOPS_ACT_SIGMOID: return h * (1.f - h);
-        case GOPS_ACT_TANH: return 1.f - h * h;
-        default: return 1.f;
+        case GOPS_ACT_RELU: body.template operator()<GOPS_ACT_RELU>(); break;
+        case GOPS_ACT_ELU: body.template operator()<GOPS_ACT_ELU>(); break;
+        case GOPS_ACT_GELU: body.template operator()<GOPS_ACT_GELU>(); break;
+        case GOPS_ACT_SELU: body.template operator()<GOPS_ACT_SELU>(); break;
+        case GOPS_ACT_SIGMOID: body.template operator()<GOPS_ACT_SIGMOID>(); break;
+        case GOPS_ACT_TANH: body.template operator()<GOPS_ACT_TANH>(); break;
+        default: body.template operator()<GOPS_ACT_LINEAR>(); break;
     }
 }
 
@@ -108,7 +139,14 @@ __device__ __forceinline__ float wrap_action_bwd(const GopsEnv& e, int i, float 
 // ((x + pi) mod 2pi) - pi with Python/torch remainder semantics (gops/utils/math_utils.py:8-11)
 __device__ __forceinline__ float angle_normalize(float x) {
     const float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f;
-    float r = fmodf(x + pi, two_pi);
+    const float y = x + pi;
+    float r;
+    // fmodf(y, 2pi) is exact; so are these shortcuts on their ranges (Sterbenz), which cover every
+    // angle the env models produce in practice - the libm loop is only the fallback.
+    if (y >= 0.f && y < two_pi) r = y;
+    else if (y >= two_pi && y < 2.f * two_pi) r = y - two_pi;
+    else if (y < 0.f && y > -two_pi) r = y;
+    else r = fmodf(y, two_pi);
     if (r < 0.f) r += two_pi;
     return r - pi;
 }
@@ -143,8 +181,8 @@ __device__ __forceinline__ void mfma_gemm(const float* __restrict__ A, int lda, 
 }
 
 // One dense layer on the tile: out tiles are dealt to the 4 waves in contiguous groups, each wave
-// walks its group 4 / 2 / 1 MFMA n-tiles at a time and hands every finished 16x16 accumulator
-// (rows 4*(lane>>4)+r, column 16*ntile + (lane&15)) to `epi(acc, ntile)`.
+// walks its group 4 / 2 / 1 MFMA n-tiles at a time and hands the finished 16x16 accumulators
+// (tile nt0+q: rows 4*(lane>>4)+r, column 16*(nt0+q) + (lane&15)) to `epi(acc, count, nt0)`.
 template <class Epi>
 __device__ __forceinline__ void gemm_layer(const float* A, int lda, int kch, int nt_tot,
                                            const f32x4* Wp, int tid, Epi&& epi) {
@@ -157,33 +195,98 @@ __device__ __forceinline__ void gemm_layer(const float* A, int lda, int kch, int
         if (left >= 4) {
             f32x4 acc[4] = {};
             mfma_gemm<4>(A, lda, kch, Wp, nt, lane, acc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) epi(acc[q], nt + q);
+            epi(acc, 4, nt);
             nt += 4;
         } else if (left >= 2) {
-            f32x4 acc[2] = {};
-            mfma_gemm<2>(A, lda, kch, Wp, nt, lane, acc);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) epi(acc[q], nt + q);
+            f32x4 acc[4] = {};
+            mfma_gemm<2>(A, lda, kch, Wp, nt, lane, reinterpret_cast<f32x4(&)[2]>(acc));
+            epi(acc, 2, nt);
             nt += 2;
         } else {
-            f32x4 acc[1] = {};
-            mfma_gemm<1>(A, lda, kch, Wp, nt, lane, acc);
-            epi(acc[0], nt);
+            f32x4 acc[4] = {};
+            mfma_gemm<1>(A, lda, kch, Wp, nt, lane, reinterpret_cast<f32x4(&)[1]>(acc));
+            epi(acc, 1, nt);
             nt += 1;
         }
     }
+}
+
+// ---- register-stationary weights ---------------------------------------------------------------
+// With one workgroup per CU (B = 4096 -> 256 tiles) each wave owns a whole SIMD's 512-entry
+// register file, 512 KiB per CU: more than LDS (160 KiB) and enough to keep a wave's slice of a
+// 256-wide layer (KCH x NT dwordx4 fragments = 4*KCH*NT registers) resident for all H steps, so
+// the weights are read from HBM/L2 once per launch instead of once per timestep.  hipcc places the
+// fragments in AGPRs and feeds them to v_mfma directly (gfx950 unified VGPR/AGPR file).
+template <int KCH, int NT>
+struct StatW {
+    f32x4 w[KCH * NT];
+    __device__ __forceinline__ void load(const f32x4* __restrict__ Wp, int nt_tot, int tid) {
+        const int lane = tid & 63, nt0 = (tid >> 6) * NT;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                w[c * NT + j] = (nt0 + j < nt_tot) ? Wp[((size_t)(nt0 + j) * KCH + c) * 64 + lane] : z;
+            }
+    }
+};
+struct NoW {};   // placeholder for a streamed layer
+
+template <int KCH, int NT, class Epi>
+__device__ __forceinline__ void gemm_layer_stat(const float* A, int lda, const StatW<KCH, NT>& W,
+                                                int nt_tot, int tid, Epi&& epi) {
+    const int lane = tid & 63, nt0 = (tid >> 6) * NT;
+    if (nt0 >= nt_tot) return;
+    const float* arow = A + (lane & 15) * lda + 4 * (lane >> 4);
+    f32x4 acc[NT] = {};
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], W.w[c * NT + j][i], acc[j], 0, 0, 0);
+    }
+    f32x4 out[4] = {};
+#pragma unroll
+    for (int q = 0; q < NT; ++q) out[q] = acc[q];
+    epi(out, min(NT, nt_tot - nt0), nt0);
 }
 
 // Copy a [TB][ncols] LDS tile (leading dim ld) to global rows g[(row0+m)*ncols ...], coalesced.
 __device__ __forceinline__ void stash_tile(const float* lds, int ld, int ncols, float* g, size_t row0,
                                            int nrows_valid, int tid) {
     const int vec_per_row = ncols >> 2;   // ncols % 4 == 0
+    if ((vec_per_row & (vec_per_row - 1)) == 0) {   // power of two: shifts instead of a division
+        const int sh = 31 - __builtin_clz(vec_per_row);
+        for (int idx = tid; idx < TB * vec_per_row; idx += NTHREADS) {
+            const int m = idx >> sh, c4 = idx & (vec_per_row - 1);
+            if (m < nrows_valid) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(lds + m * ld + 4 * c4);
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g + (row0 + m) * ncols + 4 * c4));
+            }
+        }
+        return;
+    }
     for (int idx = tid; idx < TB * vec_per_row; idx += NTHREADS) {
         const int m = idx / vec_per_row, c4 = idx - m * vec_per_row;
         if (m < nrows_valid) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(lds + m * ld + 4 * c4);
-            *reinterpret_cast<f32x4*>(g + (row0 + m) * ncols + 4 * c4) = v;
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g + (row0 + m) * ncols + 4 * c4));
         }
     }
+}
+
+// Launch with up to 160 KiB of dynamic LDS (the default cap is 64 KiB): the attribute is set once
+// per kernel instantiation.
+template <class K, class... Args>
+inline void launch_with_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
 }

@@ -4,13 +4,17 @@
 // the env state (registers).  Per step: env-model adjoint -> adjoint of the action -> wrapper /
 // tanh -> head -> hidden-layer deltas on MFMA with the transposed-packed weights.  The deltas are
 // written to the stash; the weight gradients are formed afterwards by the dW GEMM kernels.
+#include <type_traits>
+
 #include "common.h"
 #include "env_models.h"
 
 // delta_y in s_gy[TB][4]  ->  hidden deltas (stashed to stash_d when non-null) and, if want_gx,
 // G[m][n] += (delta_1 W_0)[m][n] for n < ncols.
-__device__ __forceinline__ void mlp_backward(const MlpDev& M, const float* s_gy, float* da, float* db,
-                                             int ldh, float* G, int ldg, int tid,
+template <class W0T, class W1T>
+__device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, const W1T& WT1,
+                                             const float* Wo, int ldw, const float* s_gy, float* da,
+                                             float* db, int ldh, float* G, int ldg, int tid,
                                              float* const* stash_h, float* const* stash_z,
                                              float* const* stash_d, float* stash_dy, size_t row0,
                                              int nvalid, bool want_gx, int ncols) {
@@ -21,21 +25,40 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const float* s_gy,
     {
         const int K = M.dims[L];
         const int hm = tid >> 4, hp = tid & 15;
-        const float* Wo = M.w[L];
         float gy[GOPS_MAX_ACT];
 #pragma unroll
         for (int a = 0; a < GOPS_MAX_ACT; ++a) gy[a] = (a < A) ? s_gy[hm * 4 + a] : 0.f;
         const float* hrow = stash_h[L] + (row0 + hm) * K;
         const float* zrow = gelu ? stash_z[L] + (row0 + hm) * K : nullptr;
-        for (int k = hp; k < K; k += 16) {
-            float acc = 0.f;
+        act_dispatch(M.act, [&]<int ACT>() {
+            if ((K & 63) == 0 && (ldw & 3) == 0) {
+#pragma unroll 4
+                for (int k = 4 * hp; k < K; k += 64) {
+                    f32x4 hv = {0.f, 0.f, 0.f, 0.f}, zv = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
+                    if (hm < nvalid) {
+                        hv = *reinterpret_cast<const f32x4*>(hrow + k);
+                        if (ACT == GOPS_ACT_GELU) zv = *reinterpret_cast<const f32x4*>(zrow + k);
+                    }
 #pragma unroll
-            for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                if (a < A) acc += gy[a] * Wo[a * K + k];
-            float dv = 0.f;
-            if (hm < nvalid) dv = acc * act_bwd(M.act, hrow[k], gelu ? zrow[k] : 0.f);
-            da[hm * ldh + k] = dv;
-        }
+                    for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                        if (a < A) acc += gy[a] * *reinterpret_cast<const f32x4*>(Wo + a * ldw + k);
+                    f32x4 dv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[e] = (hm < nvalid) ? acc[e] * act_bwd_t<ACT>(hv[e], zv[e]) : 0.f;
+                    *reinterpret_cast<f32x4*>(da + hm * ldh + k) = dv;
+                }
+            } else {
+                for (int k = hp; k < K; k += 16) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                        if (a < A) acc += gy[a] * Wo[a * ldw + k];
+                    float dv = 0.f;
+                    if (hm < nvalid) dv = acc * act_bwd_t<ACT>(hrow[k], ACT == GOPS_ACT_GELU ? zrow[k] : 0.f);
+                    da[hm * ldh + k] = dv;
+                }
+            }
+        });
         if (stash_dy != nullptr && tid < nvalid) {
             f32x4 v = {s_gy[tid * 4 + 0], s_gy[tid * 4 + 1], s_gy[tid * 4 + 2], s_gy[tid * 4 + 3]};
 #pragma unroll
@@ -53,17 +76,35 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const float* s_gy,
         const int N = M.dims[j], kch = M.dims[j + 1] >> 4, nt_tot = N >> 4;
         const float* hbase = stash_h[j] + row0 * N;
         const float* zbase = gelu ? stash_z[j] + row0 * N : nullptr;
-        gemm_layer(cur, ldh, kch, nt_tot, M.wpt[j], tid, [&](const f32x4& acc, int ntile) {
-            const int n = (ntile << 4) + (lane & 15);
+        auto epi = [&](const f32x4 (&acc)[4], int cnt, int nt0) {
+            act_dispatch(M.act, [&]<int ACT>() {
+                float hv[4][4], zv[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = ((lane >> 4) << 2) + r;
-                float dv = 0.f;
-                if (m < nvalid)
-                    dv = acc[r] * act_bwd(M.act, hbase[(size_t)m * N + n], gelu ? zbase[(size_t)m * N + n] : 0.f);
-                out[m * ldh + n] = dv;
-            }
-        });
+                for (int q = 0; q < 4; ++q)    // issue every stash load before the math
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = ((nt0 + q) << 4) + (lane & 15), m = ((lane >> 4) << 2) + r;
+                        const bool ok = q < cnt && m < nvalid;
+                        hv[q][r] = ok ? hbase[(size_t)m * N + n] : 0.f;
+                        zv[q][r] = (ok && ACT == GOPS_ACT_GELU) ? zbase[(size_t)m * N + n] : 0.f;
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < cnt) {
+                        const int n = ((nt0 + q) << 4) + (lane & 15);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = ((lane >> 4) << 2) + r;
+                            out[m * ldh + n] = (m < nvalid) ? acc[q][r] * act_bwd_t<ACT>(hv[q][r], zv[q][r]) : 0.f;
+                        }
+                    }
+            });
+        };
+        bool done = false;
+        if constexpr (!std::is_same<W1T, NoW>::value) {
+            if (j == 1) { gemm_layer_stat(cur, ldh, WT1, nt_tot, tid, epi); done = true; }
+        }
+        if (!done) gemm_layer(cur, ldh, kch, nt_tot, M.wpt[j], tid, epi);
         __syncthreads();
         if (stash_d != nullptr) stash_tile(out, ldh, N, stash_d[j], row0, nvalid, tid);
         float* tmp = cur; cur = out; out = tmp;
@@ -71,22 +112,31 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const float* s_gy,
     // ---- input adjoint g_x = delta_1 W_0 ----
     if (want_gx) {
         const int kch = M.dims[1] >> 4, nt_tot = M.kp[0] >> 4;
-        gemm_layer(cur, ldh, kch, nt_tot, M.wpt[0], tid, [&](const f32x4& acc, int ntile) {
-            const int n = (ntile << 4) + (lane & 15);
-            if (n < ncols) {
+        auto epi = [&](const f32x4 (&acc)[4], int cnt, int nt0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = ((lane >> 4) << 2) + r;
-                    G[m * ldg + n] += acc[r];
+            for (int q = 0; q < 4; ++q) {
+                const int n = ((nt0 + q) << 4) + (lane & 15);
+                if (q < cnt && n < ncols) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = ((lane >> 4) << 2) + r;
+                        G[m * ldg + n] += acc[q][r];
+                    }
                 }
             }
-        });
+        };
+        if constexpr (!std::is_same<W0T, NoW>::value) gemm_layer_stat(cur, ldh, WT0, nt_tot, tid, epi);
+        else gemm_layer(cur, ldh, kch, nt_tot, M.wpt[0], tid, epi);
     }
 }
 
-template <int ENV>
-__global__ __launch_bounds__(NTHREADS) void rollout_bwd_kernel(const RolloutParams p) {
+// SK0 / SK1 as in the forward kernel: here the stationary fragments are the TRANSPOSED packings
+// (delta_2 -> delta_1 through W_1: 16 chunks x 4 tiles; delta_1 -> g_x through W_0: 16 chunks x
+// ceil(SK0/4) tiles per wave).
+template <int ENV, int SK0, int SK1>
+__global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RolloutParams& p = *pp;
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * TB;
     const int nvalid = min(TB, p.B - b0);
@@ -97,6 +147,8 @@ __global__ __launch_bounds__(NTHREADS) void rollout_bwd_kernel(const RolloutPara
     float* db = da + TB * ldh;          // [TB][ldh]
     float* s_gy = db + TB * ldh;        // [TB][4]
     float* red = s_gy + TB * 4;         // [4][TB][8]
+    float* s_wo = red + 4 * TB * 8;     // [4][ldh] head weights
+    f32x4* s_ref = reinterpret_cast<f32x4*>(s_wo + 4 * ldh);   // veh: [TB][TL]
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
     const float gv = (tid < nvalid) ? p.grad_v[b0 + tid] : 0.f;
@@ -105,6 +157,25 @@ __global__ __launch_bounds__(NTHREADS) void rollout_bwd_kernel(const RolloutPara
     const VehConst VC = veh_const();
     const int TL = p.env.pre_horizon + 1 + p.H;
     const int kp0 = p.pol.kp[0];
+    {
+        const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
+        for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
+            const int a = idx / K, k = idx - a * K;
+            s_wo[a * ldh + k] = p.pol.w[Lh][idx];
+        }
+        if (ENV == GOPS_ENV_VEH3DOFCONTI) {
+            const f32x4* tbl = reinterpret_cast<const f32x4*>(p.ref_table) + (size_t)b0 * TL;
+            for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                s_ref[idx] = (idx < nvalid * TL) ? tbl[idx] : z;
+            }
+        }
+    }
+    constexpr int PT0 = (SK0 + 3) / 4;   // n-tiles of the input adjoint per wave
+    typename std::conditional<(SK0 > 0), StatW<16, (PT0 > 0 ? PT0 : 1)>, NoW>::type WT0;
+    typename std::conditional<(SK1 > 0), StatW<16, 4>, NoW>::type WT1;
+    if constexpr (SK0 > 0) WT0.load(p.pol.wpt[0], kp0 >> 4, tid);
+    if constexpr (SK1 > 0) WT1.load(p.pol.wpt[1], p.pol.dims[1] >> 4, tid);
 
     if (p.tail) {
         if (tid < TB) {
@@ -113,13 +184,17 @@ __global__ __launch_bounds__(NTHREADS) void rollout_bwd_kernel(const RolloutPara
             s_gy[tid * 4 + 1] = s_gy[tid * 4 + 2] = s_gy[tid * 4 + 3] = 0.f;
         }
         __syncthreads();
-        mlp_backward(p.val, s_gy, da, db, ldh, G, ldx, tid, p.st.tail_h, p.st.tail_z, nullptr, nullptr,
+        mlp_backward(p.val, NoW{}, NoW{}, p.val.w[p.val.nl - 1], p.val.dims[p.val.nl - 1], s_gy, da, db, ldh, G, ldx,
+                     tid, p.st.tail_h, p.st.tail_z, nullptr, nullptr,
                      (size_t)b0, nvalid, true, O);
     }
     __syncthreads();
 
+    const bool dbg_on = (p.dbg != nullptr) && blockIdx.x == 0 && tid == 0;
+    long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_last = dbg_on ? clock64() : 0;
     for (int t = p.H - 1; t >= 0; --t) {
         const size_t row0 = (size_t)t * p.B + b0;
+        DBG_TICK(0)
         float g_r = gv * p.gpow[t];                         // adjoint of the shaped reward
         if (ENV != GOPS_ENV_NONE && p.env.shaping) g_r *= p.env.reward_scale;
 
@@ -228,7 +303,7 @@ __global__ __launch_bounds__(NTHREADS) void rollout_bwd_kernel(const RolloutPara
             sincosf(-sn[2], &snn, &cn);
             // partial adjoints of (x', y', phi', u') and of cos/sin(-phi') over this thread's points
             float px = 0.f, py = 0.f, pphi = 0.f, pu = 0.f, pc = 0.f, ps = 0.f, g4 = 0.f, g5 = 0.f;
-            const f32x4* tbl = reinterpret_cast<const f32x4*>(p.ref_table) + (size_t)(b0 + m) * TL + (t + 1);
+            const f32x4* tbl = s_ref + m * TL + (t + 1);
             for (int j = part; j <= P; j += 16) {
                 float* gp = G + m * ldx + (j == 0 ? 0 : 6 + 4 * (j - 1));
                 float gx_ = gp[0], gy_ = gp[1], gph = gp[2], gu_ = gp[3];
@@ -239,8 +314,7 @@ __global__ __launch_bounds__(NTHREADS) void rollout_bwd_kernel(const RolloutPara
                     gp[0] = gp[1] = gp[2] = gp[3] = 0.f;
                     if (j == 0) { gp[4] = 0.f; gp[5] = 0.f; }
                 }
-                f32x4 rp = {0.f, 0.f, 0.f, 0.f};
-                if (m < nvalid) rp = tbl[j];
+                const f32x4 rp = tbl[j];
                 const float dx = rp[0] - sn[0], dy = rp[1] - sn[1];
                 px -= gx_ * cn + gy_ * snn;
                 py -= -gx_ * snn + gy_ * cn;
@@ -293,24 +367,44 @@ __global__ __launch_bounds__(NTHREADS) void rollout_bwd_kernel(const RolloutPara
             }
         }
         __syncthreads();
-        mlp_backward(p.pol, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
+        DBG_TICK(1)
+        mlp_backward(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
                      /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O);
         __syncthreads();
+        DBG_TICK(2)
     }
+    if (dbg_on)
+        for (int i = 0; i < 8; ++i) p.dbg[i] = (unsigned long long)dbg_acc[i];
 }
 
-size_t rollout_bwd_lds_bytes(int ldx, int ldh) {
-    return sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * 4 + 4 * TB * 8);
+size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points) {
+    return sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * 4 + 4 * TB * 8 + 4 * ldh + 4 * TB * ref_points);
 }
 
-hipError_t launch_rollout_bwd(const RolloutParams& p, hipStream_t stream) {
+void rollout_variant(const RolloutParams& p, int sk[2]);
+
+#define LAUNCH_BWD(ENV, A, B) launch_with_lds(rollout_bwd_kernel<ENV, A, B>, grid, block, lds, stream, dp)
+
+hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    const size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh);
+    const size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H : 0);
+    int sk[2];
+    rollout_variant(p, sk);
+    const int key = sk[0] * 100 + sk[1];
     switch (p.env.kind) {
-        case GOPS_ENV_NONE: hipLaunchKernelGGL(rollout_bwd_kernel<GOPS_ENV_NONE>, grid, block, lds, stream, p); break;
-        case GOPS_ENV_LQ: hipLaunchKernelGGL(rollout_bwd_kernel<GOPS_ENV_LQ>, grid, block, lds, stream, p); break;
-        case GOPS_ENV_IDPENDULUM: hipLaunchKernelGGL(rollout_bwd_kernel<GOPS_ENV_IDPENDULUM>, grid, block, lds, stream, p); break;
-        case GOPS_ENV_VEH3DOFCONTI: hipLaunchKernelGGL(rollout_bwd_kernel<GOPS_ENV_VEH3DOFCONTI>, grid, block, lds, stream, p); break;
+        case GOPS_ENV_NONE: LAUNCH_BWD(GOPS_ENV_NONE, 0, 0); break;
+        case GOPS_ENV_LQ:
+            if (key == 116) LAUNCH_BWD(GOPS_ENV_LQ, 1, 16); else LAUNCH_BWD(GOPS_ENV_LQ, 0, 0);
+            break;
+        case GOPS_ENV_IDPENDULUM:
+            if (key == 116) LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 1, 16); else LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 0, 0);
+            break;
+        case GOPS_ENV_VEH3DOFCONTI:
+            if (key == 816) LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 8, 16);
+            else if (key == 316) LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 3, 16);
+            else if (key == 16) LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 0, 16);
+            else LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 0, 0);
+            break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -3,14 +3,22 @@
 // v_mfma_f32_16x16x4_f32 with the activations staged in LDS and the weights streamed from L2 in
 // MFMA-fragment order), tanh head + wrapper chain, env model step, masked/shaped reward into the
 // discounted return.  Replaces the Python loop of fhadp.py:117-120 / infadp.py:171-180,198-208.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 #include "env_models.h"
 
 // Hidden layers of `M` applied to the LDS tile `in` (TB x kp[0], leading dim ld_in).  Returns the
 // LDS buffer that holds the last hidden activation.  When stash_h is non-null the activations
-// (and GELU pre-activations) of the tile are written to stash_h[j] + row0 * dims[j].
-__device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const float* in, int ld_in,
-                                                     float* ha, float* hb, int ldh, int tid,
+// (and GELU pre-activations) of the tile are written to stash_h[j] + row0 * dims[j].  Layers 0 / 1
+// use the register-stationary fragments W0 / W1 when those are StatW, else stream from L2.
+template <class W0T, class W1T>
+__device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T& W0, const W1T& W1,
+                                                     const float* in, int ld_in, float* ha, float* hb,
+                                                     int ldh, int tid, const float* s_bias,
                                                      float* const* stash_h, float* const* stash_z,
                                                      size_t row0, int nvalid) {
     const int lane = tid & 63;
@@ -20,20 +28,35 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const floa
     float* out = ha;
     for (int j = 0; j < L; ++j) {
         const int N = M.dims[j + 1], kch = M.kp[j] >> 4, nt_tot = N >> 4;
-        const float* bias = M.b[j];
+        const float* bias = (s_bias != nullptr) ? s_bias + j * ldh : M.b[j];   // LDS copy or global
         const bool save_z = (stash_z != nullptr) && (M.act == GOPS_ACT_GELU);
         float* zrow = save_z ? stash_z[j + 1] + row0 * N : nullptr;
-        gemm_layer(cur, ldc, kch, nt_tot, M.wp[j], tid, [&](const f32x4& acc, int ntile) {
-            const int n = (ntile << 4) + (lane & 15);
-            const float bn = bias[n];
+        auto epi = [&](const f32x4 (&acc)[4], int cnt, int nt0) {
+            act_dispatch(M.act, [&]<int ACT>() {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = ((lane >> 4) << 2) + r;
-                const float z = acc[r] + bn;
-                out[m * ldh + n] = act_fwd(M.act, z);
-                if (save_z && m < nvalid) zrow[(size_t)m * N + n] = z;
-            }
-        });
+                for (int q = 0; q < 4; ++q) {
+                    if (q < cnt) {
+                        const int n = ((nt0 + q) << 4) + (lane & 15);
+                        const float bn = bias[n];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = ((lane >> 4) << 2) + r;
+                            const float z = acc[q][r] + bn;
+                            out[m * ldh + n] = act_fwd_t<ACT>(z);
+                            if (save_z && m < nvalid) zrow[(size_t)m * N + n] = z;
+                        }
+                    }
+                }
+            });
+        };
+        bool done = false;
+        if constexpr (!std::is_same<W0T, NoW>::value) {
+            if (j == 0) { gemm_layer_stat(cur, ldc, W0, nt_tot, tid, epi); done = true; }
+        }
+        if constexpr (!std::is_same<W1T, NoW>::value) {
+            if (j == 1) { gemm_layer_stat(cur, ldc, W1, nt_tot, tid, epi); done = true; }
+        }
+        if (!done) gemm_layer(cur, ldc, kch, nt_tot, M.wp[j], tid, epi);
         __syncthreads();
         if (stash_h != nullptr) stash_tile(out, ldh, N, stash_h[j + 1], row0, nvalid, tid);
         cur = out;
@@ -44,19 +67,31 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const floa
 }
 
 // Output layer (width A <= 4) on the VALU: thread (hm = tid>>4, hp = tid&15) strides over k.
-// Result y[a] valid in the lanes with hp == 0.
-__device__ __forceinline__ void mlp_head(const MlpDev& M, const float* hcur, int ldh, int tid,
-                                         float (&y)[GOPS_MAX_ACT]) {
-    const int L = M.nl - 1, K = M.dims[L], A = M.dims[M.nl];
+// Wo is [A][ldw] (an LDS copy made once per launch, or the global weight with ldw = K); the
+// result y[a] is valid in the lanes with hp == 0.
+__device__ __forceinline__ void mlp_head(const float* Wo, int ldw, const float* bo, int K, int A,
+                                         const float* hcur, int ldh, int tid, float (&y)[GOPS_MAX_ACT]) {
     const int hm = tid >> 4, hp = tid & 15;
-    const float* Wo = M.w[L];
 #pragma unroll
     for (int a = 0; a < GOPS_MAX_ACT; ++a) y[a] = 0.f;
-    for (int k = hp; k < K; k += 16) {
-        const float hv = hcur[hm * ldh + k];
+    if ((K & 63) == 0 && (ldw & 3) == 0) {   // 16-byte LDS reads, conflict-free within a 16-lane group
+#pragma unroll 4
+        for (int k = 4 * hp; k < K; k += 64) {
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(hcur + hm * ldh + k);
 #pragma unroll
-        for (int a = 0; a < GOPS_MAX_ACT; ++a)
-            if (a < A) y[a] += hv * Wo[a * K + k];
+            for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                if (a < A) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(Wo + a * ldw + k);
+                    y[a] += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+                }
+        }
+    } else {
+        for (int k = hp; k < K; k += 16) {
+            const float hv = hcur[hm * ldh + k];
+#pragma unroll
+            for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                if (a < A) y[a] += hv * Wo[a * ldw + k];
+        }
     }
 #pragma unroll
     for (int a = 0; a < GOPS_MAX_ACT; ++a) {
@@ -64,13 +99,16 @@ __device__ __forceinline__ void mlp_head(const MlpDev& M, const float* hcur, int
         y[a] += __shfl_xor(y[a], 2);
         y[a] += __shfl_xor(y[a], 4);
         y[a] += __shfl_xor(y[a], 8);
-        if (a < A) y[a] += M.b[L][a];
+        if (a < A) y[a] += bo[a];
     }
 }
 
-template <int ENV>
-__global__ __launch_bounds__(NTHREADS) void rollout_fwd_kernel(const RolloutParams p) {
+// SK0 / SK1: k-chunks (16 inputs each) of hidden layers 0 / 1 when their weights are register-
+// stationary (the layer must then be 256 wide), 0 = streamed.
+template <int ENV, int SK0, int SK1>
+__global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RolloutParams& p = *pp;   // parameters live in device memory: uniform scalar loads
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * TB;
     const int nvalid = min(TB, p.B - b0);
@@ -83,6 +121,28 @@ __global__ __launch_bounds__(NTHREADS) void rollout_fwd_kernel(const RolloutPara
     float* s_act = s_state + TB * 8;        // [TB][4] wrapped action
     float* s_th = s_act + TB * 4;           // [TB][4] tanh(head) (ENV_NONE: raw head output)
     float* s_done = s_th + TB * 4;          // [TB]
+    float* s_bo = s_done + TB;              // [4]  head bias
+    float* s_wo = s_bo + TB;                // [4][ldh] head weights (16-float gap keeps 16 B alignment)
+    float* s_bias = s_wo + 4 * ldh;         // [GOPS_MAX_LAYERS-1][ldh] hidden-layer biases
+    f32x4* s_ref = reinterpret_cast<f32x4*>(s_bias + (GOPS_MAX_LAYERS - 1) * ldh);   // veh: [TB][TL]
+    const int TL = p.env.pre_horizon + 1 + p.H;   // reference-table points per trajectory
+    {   // one-time staging of everything the H-step loop would otherwise re-fetch from L2
+        const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
+        for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
+            const int a = idx / K, k = idx - a * K;
+            s_wo[a * ldh + k] = p.pol.w[Lh][idx];
+        }
+        if (tid < Ao) s_bo[tid] = p.pol.b[Lh][tid];
+        for (int j = 0; j < Lh; ++j)
+            for (int n = tid; n < p.pol.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = p.pol.b[j][n];
+        if (ENV == GOPS_ENV_VEH3DOFCONTI) {
+            const f32x4* tbl = reinterpret_cast<const f32x4*>(p.ref_table) + (size_t)b0 * TL;
+            for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                s_ref[idx] = (idx < nvalid * TL) ? tbl[idx] : z;
+            }
+        }
+    }
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) {
         const int m = idx / ldx, c = idx - m * ldx;
@@ -95,22 +155,30 @@ __global__ __launch_bounds__(NTHREADS) void rollout_fwd_kernel(const RolloutPara
             s_state[m * 8 + c] = (m < nvalid) ? p.in.state[(size_t)(b0 + m) * 6 + c] : (c == 3 ? 1.f : 0.f);
         }
     }
+    typename std::conditional<(SK0 > 0), StatW<(SK0 > 0 ? SK0 : 1), 4>, NoW>::type W0;
+    typename std::conditional<(SK1 > 0), StatW<(SK1 > 0 ? SK1 : 1), 4>, NoW>::type W1;
+    if constexpr (SK0 > 0) W0.load(p.pol.wp[0], p.pol.dims[1] >> 4, tid);
+    if constexpr (SK1 > 0) W1.load(p.pol.wp[1], p.pol.dims[2] >> 4, tid);
     float v_acc = 0.f;
     const IdpConst IC = idp_const();
     const VehConst VC = veh_const();
-    const int TL = p.env.pre_horizon + 1 + p.H;   // reference-table points per trajectory
 
+    const bool dbg_on = (p.dbg != nullptr) && blockIdx.x == 0 && tid == 0;
+    long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_last = dbg_on ? clock64() : 0;
     for (int t = 0; t < p.H; ++t) {
         if (p.fh && tid < TB) xs[tid * ldx + O] = (float)(t + 1);
         __syncthreads();
+        DBG_TICK(0)
         const size_t row0 = (size_t)t * p.B + b0;
         if (p.need_grad) stash_tile(xs, ldx, p.pol.kp[0], p.st.x, row0, nvalid, tid);
-        float* hcur = mlp_hidden_forward(p.pol, xs, ldx, ha, hb, ldh, tid,
+        DBG_TICK(1)
+        float* hcur = mlp_hidden_forward(p.pol, W0, W1, xs, ldx, ha, hb, ldh, tid, s_bias,
                                          p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
                                          row0, nvalid);
+        DBG_TICK(2)
         {
             float y[GOPS_MAX_ACT];
-            mlp_head(p.pol, hcur, ldh, tid, y);
+            mlp_head(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ldh, tid, y);
             if ((tid & 15) == 0) {
                 const int hm = tid >> 4;
 #pragma unroll
@@ -130,6 +198,7 @@ __global__ __launch_bounds__(NTHREADS) void rollout_fwd_kernel(const RolloutPara
             }
         }
         __syncthreads();
+        DBG_TICK(3)
         if (p.need_grad && tid < nvalid) {   // env stash row: tanh outputs, done_t, state_t
             float* er = p.st.env + (row0 + tid) * ENV_STASH;
             f32x4 e0 = {s_th[tid * 4 + 0], s_th[tid * 4 + 1], s_th[tid * 4 + 2], s_th[tid * 4 + 3]};
@@ -140,6 +209,7 @@ __global__ __launch_bounds__(NTHREADS) void rollout_fwd_kernel(const RolloutPara
             reinterpret_cast<f32x4*>(er)[2] = e2;
         }
 
+        DBG_TICK(4)
         // ---------------- env model step + MaskAtDone / ShapingReward / ClipObservation ---------
         float r = 0.f;          // raw model reward (threads tid < TB)
         bool done_m = false;    // done flag from the base model
@@ -205,10 +275,9 @@ __global__ __launch_bounds__(NTHREADS) void rollout_fwd_kernel(const RolloutPara
             __syncthreads();   // every read of the old obs / state is done
             float cn, snn;
             sincosf(-sn[2], &snn, &cn);
-            const f32x4* tbl = reinterpret_cast<const f32x4*>(p.ref_table) + (size_t)(b0 + m) * TL + (t + 1);
+            const f32x4* tbl = s_ref + m * TL + (t + 1);
             for (int j = part; j <= P; j += 16) {
-                f32x4 rp = {0.f, 0.f, 0.f, 0.f};
-                if (m < nvalid) rp = tbl[j];
+                const f32x4 rp = tbl[j];
                 const float dx = rp[0] - sn[0], dy = rp[1] - sn[1];
                 const float xtf = dx * cn - dy * snn;
                 const float ytf = dx * snn + dy * cn;
@@ -239,17 +308,23 @@ __global__ __launch_bounds__(NTHREADS) void rollout_fwd_kernel(const RolloutPara
             if (p.out.rewards != nullptr && tid < nvalid) p.out.rewards[(size_t)t * p.B + b0 + tid] = rr;
             if (done_m) s_done[tid] = 1.f;
         }
+        DBG_TICK(5)
     }
     __syncthreads();
+    if (dbg_on)
+        for (int i = 0; i < 8; ++i) p.dbg[i] = (unsigned long long)dbg_acc[i];
 
     if (p.tail) {   // v += (~done_H) * gamma^H * V_target(obs_H)   (infadp.py:182-184, 210)
         if (p.fh && tid < TB) xs[tid * ldx + O] = 0.f;
         __syncthreads();
-        float* hcur = mlp_hidden_forward(p.val, xs, ldx, ha, hb, ldh, tid,
+        float* hcur = mlp_hidden_forward(p.val, NoW{}, NoW{}, xs, ldx, ha, hb, ldh, tid, nullptr,
                                          p.need_grad ? p.st.tail_h : nullptr,
                                          p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, nvalid);
         float y[GOPS_MAX_ACT];
-        mlp_head(p.val, hcur, ldh, tid, y);
+        {
+            const int Lv = p.val.nl - 1;
+            mlp_head(p.val.w[Lv], p.val.dims[Lv], p.val.b[Lv], p.val.dims[Lv], 1, hcur, ldh, tid, y);
+        }
         if ((tid & 15) == 0) s_th[(tid >> 4) * 4] = y[0];
         __syncthreads();
         if (tid < TB) v_acc += ((1.f - s_done[tid]) * p.gpow[p.H]) * s_th[tid * 4];
@@ -272,18 +347,54 @@ __global__ __launch_bounds__(NTHREADS) void rollout_fwd_kernel(const RolloutPara
     }
 }
 
-size_t rollout_fwd_lds_bytes(int ldx, int ldh) {
-    return sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * (8 + 4 + 4 + 1));
+size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points) {
+    return sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * (8 + 4 + 4 + 1 + 1) + (4 + GOPS_MAX_LAYERS - 1) * ldh +
+                                    4 * TB * ref_points);
 }
 
-hipError_t launch_rollout_fwd(const RolloutParams& p, hipStream_t stream) {
+// Picks the register-stationary variant when the policy is (kp0 in {16,48,128}) -> 256 -> 256 ...,
+// else the fully streamed kernel.  sk[0] / sk[1] receive the chosen chunk counts (0 = streamed).
+void rollout_variant(const RolloutParams& p, int sk[2]) {
+    sk[0] = sk[1] = 0;
+    const MlpDev& M = p.pol;
+    if (M.nl - 1 < 2 || M.dims[1] != 256 || M.dims[2] != 256 || p.env.kind == GOPS_ENV_NONE) return;
+    sk[1] = 16;
+    const int k0 = M.kp[0] >> 4;
+    if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && (k0 == 3 || k0 == 8)) sk[0] = k0;
+    if ((p.env.kind == GOPS_ENV_LQ || p.env.kind == GOPS_ENV_IDPENDULUM) && k0 == 1) sk[0] = 1;
+    // tuning knob (benchmarks only): GOPS_SK="0,0" forces the streamed kernels, "0,16" layer 1 only
+    if (const char* e = getenv("GOPS_SK")) {
+        int a = -1, b = -1;
+        if (sscanf(e, "%d,%d", &a, &b) == 2) {
+            if (a == 0) sk[0] = 0;
+            if (b == 0) sk[0] = sk[1] = 0;
+        }
+    }
+}
+
+#define LAUNCH_FWD(ENV, A, B) launch_with_lds(rollout_fwd_kernel<ENV, A, B>, grid, block, lds, stream, dp)
+
+// `p` is the host copy (for shape dispatch), `dp` the device copy the kernel reads.
+hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh);
+    const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H : 0);
+    int sk[2];
+    rollout_variant(p, sk);
+    const int key = sk[0] * 100 + sk[1];
     switch (p.env.kind) {
-        case GOPS_ENV_NONE: hipLaunchKernelGGL(rollout_fwd_kernel<GOPS_ENV_NONE>, grid, block, lds, stream, p); break;
-        case GOPS_ENV_LQ: hipLaunchKernelGGL(rollout_fwd_kernel<GOPS_ENV_LQ>, grid, block, lds, stream, p); break;
-        case GOPS_ENV_IDPENDULUM: hipLaunchKernelGGL(rollout_fwd_kernel<GOPS_ENV_IDPENDULUM>, grid, block, lds, stream, p); break;
-        case GOPS_ENV_VEH3DOFCONTI: hipLaunchKernelGGL(rollout_fwd_kernel<GOPS_ENV_VEH3DOFCONTI>, grid, block, lds, stream, p); break;
+        case GOPS_ENV_NONE: LAUNCH_FWD(GOPS_ENV_NONE, 0, 0); break;
+        case GOPS_ENV_LQ:
+            if (key == 116) LAUNCH_FWD(GOPS_ENV_LQ, 1, 16); else LAUNCH_FWD(GOPS_ENV_LQ, 0, 0);
+            break;
+        case GOPS_ENV_IDPENDULUM:
+            if (key == 116) LAUNCH_FWD(GOPS_ENV_IDPENDULUM, 1, 16); else LAUNCH_FWD(GOPS_ENV_IDPENDULUM, 0, 0);
+            break;
+        case GOPS_ENV_VEH3DOFCONTI:
+            if (key == 816) LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 8, 16);
+            else if (key == 316) LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 3, 16);
+            else if (key == 16) LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 0, 16);
+            else LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 0, 0);
+            break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

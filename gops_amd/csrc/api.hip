@@ -243,7 +243,7 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
     }
     static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
     const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
-    if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 8 * sizeof(unsigned long long));
+    if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
     p.dbg = dbg ? dbg_buf : nullptr;
     int ret;
     {
@@ -252,10 +252,12 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
         ret = (ue != hipSuccess) ? (int)ue : (int)launch_rollout_fwd(p, plan.dev_params, s);
     }
     if (dbg) {
-        unsigned long long h[8];
+        unsigned long long h[16];
         (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[gops dbg] fwd cycles/step: top+sync %llu | xstash %llu | hidden %llu | head %llu | envstash %llu | env %llu\n",
-                h[0] / p.H, h[1] / p.H, h[2] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H);
+        fprintf(stderr, "[gops dbg] fwd cycles/step: top+sync %llu | xstash %llu | hidden-rest %llu | head %llu | envstash %llu | env %llu"
+                " || L0 epi %llu sync %llu stash %llu | L1 epi %llu sync %llu stash %llu | gemm(L0+L1) %llu\n",
+                h[0] / p.H, h[1] / p.H, h[2] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H, h[8] / p.H, h[9] / p.H,
+                h[10] / p.H, h[11] / p.H, h[12] / p.H, h[13] / p.H, h[14] / p.H);
     }
     return ret;
 }
@@ -275,7 +277,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     hipError_t e;
     static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
     const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
-    if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 8 * sizeof(unsigned long long));
+    if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
     p.dbg = dbg ? dbg_buf : nullptr;
     {
         ProfScope scope(1, s);
@@ -283,7 +285,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
         if ((e = launch_rollout_bwd(p, plan.dev_params, s)) != hipSuccess) return (int)e;
     }
     if (dbg) {
-        unsigned long long h[8];
+        unsigned long long h[16];
         (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
         fprintf(stderr, "[gops dbg] bwd cycles/step: loop-top %llu | env adjoint %llu | mlp backward %llu\n",
                 h[0] / p.H, h[1] / p.H, h[2] / p.H);

@@ -251,23 +251,46 @@ hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long lo
 }
 
 // Output layer (width A <= 4) on the VALU: part[split][a][k] = sum_s dy[s][a] * h[s][k].
+// Thread = (4 columns, sample lane): 16-byte coalesced reads of h, four sample lanes per block
+// combined through LDS in a fixed order.
 __global__ __launch_bounds__(NTHREADS) void dw_out_kernel(const float* __restrict__ dy,
                                                           const float* __restrict__ h, int K, int A,
                                                           long long S, long long per_split,
                                                           float* __restrict__ part, float* __restrict__ part_b) {
-    const int split = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) f32x4 red[4][GOPS_MAX_ACT][64];
+    __shared__ float redb[4][GOPS_MAX_ACT];
+    const int split = blockIdx.x, c = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const long long s0 = split * per_split, s1 = min(S, s0 + per_split);
-    for (int k = threadIdx.x; k < K; k += NTHREADS) {
-        float acc[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, accb[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
-        for (long long s = s0; s < s1; ++s) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + s * 4);
-            const float hv = h[s * K + k];
+    const int npass = ((K >> 2) + 63) / 64;   // uniform trip count: every lane reaches the barriers
+    for (int pass = 0; pass < npass; ++pass) {
+        const int k4 = c + 64 * pass;
+        const bool col_ok = k4 < (K >> 2);
+        f32x4 acc[GOPS_MAX_ACT] = {};
+        float accb[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
+        if (col_ok) {
+#pragma unroll 4
+            for (long long sidx = s0 + sl; sidx < s1; sidx += 4) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dy + sidx * 4);
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(h + sidx * K + 4 * k4);
 #pragma unroll
-            for (int a = 0; a < GOPS_MAX_ACT; ++a) { acc[a] += g[a] * hv; accb[a] += g[a]; }
+                for (int a = 0; a < GOPS_MAX_ACT; ++a) { acc[a] += g[a] * hv; accb[a] += g[a]; }
+            }
         }
-        for (int a = 0; a < A; ++a) part[((size_t)split * A + a) * K + k] = acc[a];
-        if (k == 0)
-            for (int a = 0; a < A; ++a) part_b[(size_t)split * A + a] = accb[a];
+#pragma unroll
+        for (int a = 0; a < GOPS_MAX_ACT; ++a) red[sl][a][c] = acc[a];
+        if (c == 0 && k4 == 0)
+            for (int a = 0; a < GOPS_MAX_ACT; ++a) redb[sl][a] = accb[a];
+        __syncthreads();
+        if (sl == 0 && col_ok) {
+            for (int a = 0; a < A; ++a) {
+                const f32x4 t = (red[0][a][c] + red[1][a][c]) + (red[2][a][c] + red[3][a][c]);
+                *reinterpret_cast<f32x4*>(part + ((size_t)split * A + a) * K + 4 * k4) = t;
+            }
+            if (k4 == 0)
+                for (int a = 0; a < A; ++a)
+                    part_b[(size_t)split * A + a] = (redb[0][a] + redb[1][a]) + (redb[2][a] + redb[3][a]);
+        }
+        __syncthreads();
     }
 }
 
@@ -354,6 +377,7 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         float s[6], sn[6], o6[6];
         for (int i = 0; i < 6; ++i) { s[i] = io.state[(size_t)b * 6 + i]; o6[i] = ob[i]; }
         VehStep w;
+        sincosf(s[2], &w.sphi, &w.cphi);
         veh_f_xu(VC, s, u[0], u[1], sn, w);
         r = veh_reward(o6, u[0], u[1]);
         const float nt = RADD(io.ref_time[b], 0.1f);

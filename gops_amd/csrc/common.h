@@ -8,7 +8,7 @@
 #define TB GOPS_TILE      // trajectories per workgroup tile = MFMA M
 #define NTHREADS 256      // 4 wavefronts of 64
 #define DW_SC_HOST 32     // samples per staged chunk of the dW GEMM (== DW_SC in aux_kernels.hip)
-#define DW_OUT_SPLITS 256   // sample splits of the output-layer weight gradient
+#define DW_OUT_SPLITS 1024  // sample splits of the output-layer weight gradient
 #define ENV_STASH 16      // floats of per-(t,b) env stash: [0..3] abar, [4] done_t, [5..10] state_t
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -52,32 +52,37 @@ struct RolloutParams {
 };
 
 // per-phase cycle accounting of block 0 / thread 0 (debug builds of the timing knob only)
-#define DBG_TICK(i)                                                            \
-    if (dbg_on) {                                                              \
-        const long long now_ = clock64();                                      \
-        dbg_acc[i] += now_ - dbg_last;                                         \
-        dbg_last = now_;                                                       \
+struct DbgClock {
+    bool on;
+    long long acc[16], last;
+    __device__ __forceinline__ void init(bool enable) {
+        on = enable;
+        for (int i = 0; i < 16; ++i) acc[i] = 0;
+        last = enable ? clock64() : 0;
     }
+    __device__ __forceinline__ void tick(int i) {
+        if (on) {
+            const long long now = clock64();
+            acc[i] += now - last;
+            last = now;
+        }
+    }
+};
+#define DBG_TICK(i) dbg.tick(i);
 
 // ---- activations ---------------------------------------------------------------------------
 #define SELU_SCALE 1.0507009873554804934193349852946f
 #define SELU_ALPHA 1.6732632423543772848170429916717f
 
-// exp(z) - 1 for z <= 0 without libm's branchy expm1f: Taylor series where the subtraction would
-// cancel (|z| < 0.25, truncation < 2e-9 relative), hardware exp elsewhere (abs. error ~1e-7).
-__device__ __forceinline__ float expm1_neg(float z) {
-    const float p = z * (1.f + z * (0.5f + z * (1.6666667e-1f + z * (4.1666668e-2f + z * (8.3333338e-3f +
-                    z * (1.3888889e-3f + z * 1.9841270e-4f))))));
-    const float e = __expf(z) - 1.f;
-    return z > -0.25f ? p : e;
-}
-
+// ELU / SELU negative branch: exp(min(z,0)) - 1 on the hardware exponential (v_exp_f32, ~1 ulp of a
+// value <= 1, i.e. absolute error <= 1.2e-7 - fp32 round-off class, far inside the 1e-4 parity
+// bar) and written as max(z,0) + (e - 1) so that no lane diverges: for z > 0, e == 1 exactly.
 template <int ACT>
 __device__ __forceinline__ float act_fwd_t(float z) {
     if (ACT == GOPS_ACT_RELU) return fmaxf(z, 0.f);
-    if (ACT == GOPS_ACT_ELU) return z > 0.f ? z : expm1_neg(z);
+    if (ACT == GOPS_ACT_ELU) return fmaxf(z, 0.f) + (__expf(fminf(z, 0.f)) - 1.f);
     if (ACT == GOPS_ACT_GELU) return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
-    if (ACT == GOPS_ACT_SELU) return SELU_SCALE * (z > 0.f ? z : SELU_ALPHA * expm1_neg(z));
+    if (ACT == GOPS_ACT_SELU) return SELU_SCALE * (fmaxf(z, 0.f) + SELU_ALPHA * (__expf(fminf(z, 0.f)) - 1.f));
     if (ACT == GOPS_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
     if (ACT == GOPS_ACT_TANH) return tanhf(z);
     return z;
@@ -151,6 +156,20 @@ __device__ __forceinline__ float angle_normalize(float x) {
     return r - pi;
 }
 
+// Sum over each aligned group of 16 lanes, result in every lane: four DPP adds (quad_perm x2,
+// row_half_mirror, row_mirror) - no LDS crossbar round trips like __shfl_xor.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);   // row_half_mirror
+    v += dpp_f<0x140>(v);   // row_mirror
+    return v;
+}
+
 // ---- MFMA tile GEMM: acc[j] (16 x 16 tile nt0+j) += A[16 x 16*kchunks] * Wp ------------------
 // A lives in LDS row-major with leading dimension lda (floats, lda % 4 == 0); lane l supplies
 // A[m = l&15][16c + 4*(l>>4) + i] to the i-th v_mfma_f32_16x16x4_f32 of chunk c, and the packed
@@ -182,7 +201,7 @@ __device__ __forceinline__ void mfma_gemm(const float* __restrict__ A, int lda, 
 
 // One dense layer on the tile: out tiles are dealt to the 4 waves in contiguous groups, each wave
 // walks its group 4 / 2 / 1 MFMA n-tiles at a time and hands the finished 16x16 accumulators
-// (tile nt0+q: rows 4*(lane>>4)+r, column 16*(nt0+q) + (lane&15)) to `epi(acc, count, nt0)`.
+// (tile nt0+q: rows 4*(lane>>4)+r, column 16*(nt0+q) + (lane&15)) to `epi.operator()<COUNT>(acc, nt0)`.
 template <class Epi>
 __device__ __forceinline__ void gemm_layer(const float* A, int lda, int kch, int nt_tot,
                                            const f32x4* Wp, int tid, Epi&& epi) {
@@ -195,17 +214,17 @@ __device__ __forceinline__ void gemm_layer(const float* A, int lda, int kch, int
         if (left >= 4) {
             f32x4 acc[4] = {};
             mfma_gemm<4>(A, lda, kch, Wp, nt, lane, acc);
-            epi(acc, 4, nt);
+            epi.template operator()<4>(acc, nt);
             nt += 4;
         } else if (left >= 2) {
             f32x4 acc[4] = {};
             mfma_gemm<2>(A, lda, kch, Wp, nt, lane, reinterpret_cast<f32x4(&)[2]>(acc));
-            epi(acc, 2, nt);
+            epi.template operator()<2>(acc, nt);
             nt += 2;
         } else {
             f32x4 acc[4] = {};
             mfma_gemm<1>(A, lda, kch, Wp, nt, lane, reinterpret_cast<f32x4(&)[1]>(acc));
-            epi(acc, 1, nt);
+            epi.template operator()<1>(acc, nt);
             nt += 1;
         }
     }
@@ -252,7 +271,7 @@ __device__ __forceinline__ void gemm_layer_stat(const float* A, int lda, const S
     f32x4 out[4] = {};
 #pragma unroll
     for (int q = 0; q < NT; ++q) out[q] = acc[q];
-    epi(out, min(NT, nt_tot - nt0), nt0);
+    epi.template operator()<NT>(out, nt0);   // stationary layers: nt_tot is a multiple of NT (or < 4 with NT = 1)
 }
 
 // Copy a [TB][ncols] LDS tile (leading dim ld) to global rows g[(row0+m)*ncols ...], coalesced.
@@ -261,6 +280,7 @@ __device__ __forceinline__ void stash_tile(const float* lds, int ld, int ncols, 
     const int vec_per_row = ncols >> 2;   // ncols % 4 == 0
     if ((vec_per_row & (vec_per_row - 1)) == 0) {   // power of two: shifts instead of a division
         const int sh = 31 - __builtin_clz(vec_per_row);
+#pragma unroll 4
         for (int idx = tid; idx < TB * vec_per_row; idx += NTHREADS) {
             const int m = idx >> sh, c4 = idx & (vec_per_row - 1);
             if (m < nrows_valid) {

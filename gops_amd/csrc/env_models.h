@@ -173,8 +173,8 @@ struct VehStep {   // intermediates shared by forward and adjoint
 
 __device__ __forceinline__ void veh_f_xu(const VehConst& C, const float* s, float steer, float ax,
                                          float* sn, VehStep& w) {
+    // w.sphi / w.cphi = sin / cos of s[2], supplied by the caller (carried across rollout steps)
     const float x = s[0], y = s[1], phi = s[2], u = s[3], v = s[4], om = s[5];
-    sincosf(phi, &w.sphi, &w.cphi);
     sn[0] = x + C.dt * (u * w.cphi - v * w.sphi);
     sn[1] = y + C.dt * (u * w.sphi + v * w.cphi);
     sn[2] = angle_normalize(phi + C.dt * om);

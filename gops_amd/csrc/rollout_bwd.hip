@@ -76,28 +76,27 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
         const int N = M.dims[j], kch = M.dims[j + 1] >> 4, nt_tot = N >> 4;
         const float* hbase = stash_h[j] + row0 * N;
         const float* zbase = gelu ? stash_z[j] + row0 * N : nullptr;
-        auto epi = [&](const f32x4 (&acc)[4], int cnt, int nt0) {
+        auto epi = [&]<int CNT>(const f32x4 (&acc)[4], int nt0) {
             act_dispatch(M.act, [&]<int ACT>() {
-                float hv[4][4], zv[4][4];
+                float hv[CNT][4], zv[CNT][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)    // issue every stash load before the math
+                for (int q = 0; q < CNT; ++q)    // issue every stash load before the math
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int n = ((nt0 + q) << 4) + (lane & 15), m = ((lane >> 4) << 2) + r;
-                        const bool ok = q < cnt && m < nvalid;
+                        const bool ok = m < nvalid;
                         hv[q][r] = ok ? hbase[(size_t)m * N + n] : 0.f;
                         zv[q][r] = (ok && ACT == GOPS_ACT_GELU) ? zbase[(size_t)m * N + n] : 0.f;
                     }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q < cnt) {
-                        const int n = ((nt0 + q) << 4) + (lane & 15);
+                for (int q = 0; q < CNT; ++q) {
+                    const int n = ((nt0 + q) << 4) + (lane & 15);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int m = ((lane >> 4) << 2) + r;
-                            out[m * ldh + n] = (m < nvalid) ? acc[q][r] * act_bwd_t<ACT>(hv[q][r], zv[q][r]) : 0.f;
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = ((lane >> 4) << 2) + r;
+                        out[m * ldh + n] = (m < nvalid) ? acc[q][r] * act_bwd_t<ACT>(hv[q][r], zv[q][r]) : 0.f;
                     }
+                }
             });
         };
         bool done = false;
@@ -112,11 +111,11 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
     // ---- input adjoint g_x = delta_1 W_0 ----
     if (want_gx) {
         const int kch = M.dims[1] >> 4, nt_tot = M.kp[0] >> 4;
-        auto epi = [&](const f32x4 (&acc)[4], int cnt, int nt0) {
+        auto epi = [&]<int CNT>(const f32x4 (&acc)[4], int nt0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < CNT; ++q) {
                 const int n = ((nt0 + q) << 4) + (lane & 15);
-                if (q < cnt && n < ncols) {
+                if (n < ncols) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int m = ((lane >> 4) << 2) + r;
@@ -141,7 +140,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
     const int b0 = blockIdx.x * TB;
     const int nvalid = min(TB, p.B - b0);
     const int O = p.env.obs_dim, A = p.env.act_dim;
-    const int ldx = p.ldx, ldh = p.ldh;
+    const int ldx = (SK0 > 0) ? 16 * SK0 + 4 : p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* G = smem;                    // [TB][ldx] adjoint of obs_{t+1}
     float* da = G + TB * ldx;           // [TB][ldh]
     float* db = da + TB * ldh;          // [TB][ldh]
@@ -190,8 +189,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
     }
     __syncthreads();
 
-    const bool dbg_on = (p.dbg != nullptr) && blockIdx.x == 0 && tid == 0;
-    long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_last = dbg_on ? clock64() : 0;
+    DbgClock dbg;
+    dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
     for (int t = p.H - 1; t >= 0; --t) {
         const size_t row0 = (size_t)t * p.B + b0;
         DBG_TICK(0)
@@ -298,9 +297,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
             const float steer = wrap_action(p.env, 0, abar0), ax = wrap_action(p.env, 1, abar1);
             float sn[6];
             VehStep w;
+            sincosf(s[2], &w.sphi, &w.cphi);
             veh_f_xu(VC, s, steer, ax, sn, w);
             float cn, snn;
-            sincosf(-sn[2], &snn, &cn);
+            sincosf(sn[2], &snn, &cn);
+            snn = -snn;   // cos(-phi') = cos(phi'), sin(-phi') = -sin(phi')
             // partial adjoints of (x', y', phi', u') and of cos/sin(-phi') over this thread's points
             float px = 0.f, py = 0.f, pphi = 0.f, pu = 0.f, pc = 0.f, ps = 0.f, g4 = 0.f, g5 = 0.f;
             const f32x4* tbl = s_ref + m * TL + (t + 1);
@@ -373,8 +374,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
         __syncthreads();
         DBG_TICK(2)
     }
-    if (dbg_on)
-        for (int i = 0; i < 8; ++i) p.dbg[i] = (unsigned long long)dbg_acc[i];
+    if (dbg.on)
+        for (int i = 0; i < 16; ++i) p.dbg[i] = (unsigned long long)dbg.acc[i];
 }
 
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points) {

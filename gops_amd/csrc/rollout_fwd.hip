@@ -20,7 +20,7 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
                                                      const float* in, int ld_in, float* ha, float* hb,
                                                      int ldh, int tid, const float* s_bias,
                                                      float* const* stash_h, float* const* stash_z,
-                                                     size_t row0, int nvalid) {
+                                                     size_t row0, int nvalid, DbgClock& dbg) {
     const int lane = tid & 63;
     const int L = M.nl - 1;
     const float* cur = in;
@@ -28,23 +28,24 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
     float* out = ha;
     for (int j = 0; j < L; ++j) {
         const int N = M.dims[j + 1], kch = M.kp[j] >> 4, nt_tot = N >> 4;
-        const float* bias = (s_bias != nullptr) ? s_bias + j * ldh : M.b[j];   // LDS copy or global
+        const float* bias = s_bias + j * ldh;   // LDS copy of the layer's bias
         const bool save_z = (stash_z != nullptr) && (M.act == GOPS_ACT_GELU);
         float* zrow = save_z ? stash_z[j + 1] + row0 * N : nullptr;
-        auto epi = [&](const f32x4 (&acc)[4], int cnt, int nt0) {
+        auto epi = [&]<int CNT>(const f32x4 (&acc)[4], int nt0) {
+            DBG_TICK(14)
             act_dispatch(M.act, [&]<int ACT>() {
+                float bn[CNT];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (q < cnt) {
-                        const int n = ((nt0 + q) << 4) + (lane & 15);
-                        const float bn = bias[n];
+                for (int q = 0; q < CNT; ++q) bn[q] = bias[((nt0 + q) << 4) + (lane & 15)];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int m = ((lane >> 4) << 2) + r;
-                            const float z = acc[q][r] + bn;
-                            out[m * ldh + n] = act_fwd_t<ACT>(z);
-                            if (save_z && m < nvalid) zrow[(size_t)m * N + n] = z;
-                        }
+                for (int q = 0; q < CNT; ++q) {
+                    const int n = ((nt0 + q) << 4) + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = ((lane >> 4) << 2) + r;
+                        const float z = acc[q][r] + bn[q];
+                        out[m * ldh + n] = act_fwd_t<ACT>(z);
+                        if (ACT == GOPS_ACT_GELU && save_z && m < nvalid) zrow[(size_t)m * N + n] = z;
                     }
                 }
             });
@@ -57,8 +58,11 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
             if (j == 1) { gemm_layer_stat(cur, ldc, W1, nt_tot, tid, epi); done = true; }
         }
         if (!done) gemm_layer(cur, ldc, kch, nt_tot, M.wp[j], tid, epi);
+        DBG_TICK(8 + 3 * (j & 1))
         __syncthreads();
+        DBG_TICK(9 + 3 * (j & 1))
         if (stash_h != nullptr) stash_tile(out, ldh, N, stash_h[j + 1], row0, nvalid, tid);
+        DBG_TICK(10 + 3 * (j & 1))
         cur = out;
         ldc = ldh;
         out = (out == ha) ? hb : ha;
@@ -95,10 +99,7 @@ __device__ __forceinline__ void mlp_head(const float* Wo, int ldw, const float* 
     }
 #pragma unroll
     for (int a = 0; a < GOPS_MAX_ACT; ++a) {
-        y[a] += __shfl_xor(y[a], 1);
-        y[a] += __shfl_xor(y[a], 2);
-        y[a] += __shfl_xor(y[a], 4);
-        y[a] += __shfl_xor(y[a], 8);
+        y[a] = row16_sum(y[a]);
         if (a < A) y[a] += bo[a];
     }
 }
@@ -113,7 +114,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
     const int b0 = blockIdx.x * TB;
     const int nvalid = min(TB, p.B - b0);
     const int O = p.env.obs_dim, A = p.env.act_dim;
-    const int ldx = p.ldx, ldh = p.ldh;
+    // leading dimensions are compile-time constants in the register-stationary variants
+    const int ldx = (SK0 > 0) ? 16 * SK0 + 4 : p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* xs = smem;                       // [TB][ldx]  current observation (+ time column)
     float* ha = xs + TB * ldx;              // [TB][ldh]
     float* hb = ha + TB * ldh;              // [TB][ldh]
@@ -160,11 +162,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
     if constexpr (SK0 > 0) W0.load(p.pol.wp[0], p.pol.dims[1] >> 4, tid);
     if constexpr (SK1 > 0) W1.load(p.pol.wp[1], p.pol.dims[2] >> 4, tid);
     float v_acc = 0.f;
+    float veh_s = 0.f, veh_c = 1.f;   // sin/cos of the current heading, carried across steps
     const IdpConst IC = idp_const();
     const VehConst VC = veh_const();
 
-    const bool dbg_on = (p.dbg != nullptr) && blockIdx.x == 0 && tid == 0;
-    long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_last = dbg_on ? clock64() : 0;
+    DbgClock dbg;
+    dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
+    __syncthreads();
+    if (ENV == GOPS_ENV_VEH3DOFCONTI) sincosf(s_state[(tid & 15) * 8 + 2], &veh_s, &veh_c);
     for (int t = 0; t < p.H; ++t) {
         if (p.fh && tid < TB) xs[tid * ldx + O] = (float)(t + 1);
         __syncthreads();
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
         DBG_TICK(1)
         float* hcur = mlp_hidden_forward(p.pol, W0, W1, xs, ldx, ha, hb, ldh, tid, s_bias,
                                          p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
-                                         row0, nvalid);
+                                         row0, nvalid, dbg);
         DBG_TICK(2)
         {
             float y[GOPS_MAX_ACT];
@@ -265,6 +270,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
             const float steer = s_act[m * 4 + 0], ax = s_act[m * 4 + 1];
             const float dflag = s_done[m];
             VehStep w;
+            w.sphi = veh_s; w.cphi = veh_c;
             veh_f_xu(VC, s, steer, ax, sn, w);
             if (part == 0) {
                 float o[6];
@@ -273,8 +279,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
                 r = veh_reward(o, steer, ax);
             }
             __syncthreads();   // every read of the old obs / state is done
-            float cn, snn;
-            sincosf(-sn[2], &snn, &cn);
+            sincosf(sn[2], &veh_s, &veh_c);                 // also next step's f_xu heading terms
+            const float cn = veh_c, snn = -veh_s;           // cos(-phi'), sin(-phi')
             const f32x4* tbl = s_ref + m * TL + (t + 1);
             for (int j = part; j <= P; j += 16) {
                 const f32x4 rp = tbl[j];
@@ -311,15 +317,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
         DBG_TICK(5)
     }
     __syncthreads();
-    if (dbg_on)
-        for (int i = 0; i < 8; ++i) p.dbg[i] = (unsigned long long)dbg_acc[i];
+    if (dbg.on)
+        for (int i = 0; i < 16; ++i) p.dbg[i] = (unsigned long long)dbg.acc[i];
 
     if (p.tail) {   // v += (~done_H) * gamma^H * V_target(obs_H)   (infadp.py:182-184, 210)
         if (p.fh && tid < TB) xs[tid * ldx + O] = 0.f;
+        for (int j = 0; j < p.val.nl - 1; ++j)   // the policy biases are no longer needed
+            for (int n = tid; n < p.val.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = p.val.b[j][n];
         __syncthreads();
-        float* hcur = mlp_hidden_forward(p.val, NoW{}, NoW{}, xs, ldx, ha, hb, ldh, tid, nullptr,
+        float* hcur = mlp_hidden_forward(p.val, NoW{}, NoW{}, xs, ldx, ha, hb, ldh, tid, s_bias,
                                          p.need_grad ? p.st.tail_h : nullptr,
-                                         p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, nvalid);
+                                         p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, nvalid, dbg);
         float y[GOPS_MAX_ACT];
         {
             const int Lv = p.val.nl - 1;
@@ -357,11 +365,13 @@ size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points) {
 void rollout_variant(const RolloutParams& p, int sk[2]) {
     sk[0] = sk[1] = 0;
     const MlpDev& M = p.pol;
-    if (M.nl - 1 < 2 || M.dims[1] != 256 || M.dims[2] != 256 || p.env.kind == GOPS_ENV_NONE) return;
+    if (M.nl - 1 < 2 || M.dims[1] != 256 || M.dims[2] != 256 || p.env.kind == GOPS_ENV_NONE || p.ldh != 260) return;
     sk[1] = 16;
     const int k0 = M.kp[0] >> 4;
-    if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && (k0 == 3 || k0 == 8)) sk[0] = k0;
-    if ((p.env.kind == GOPS_ENV_LQ || p.env.kind == GOPS_ENV_IDPENDULUM) && k0 == 1) sk[0] = 1;
+    if (p.ldx == M.kp[0] + 4) {
+        if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && (k0 == 3 || k0 == 8)) sk[0] = k0;
+        if ((p.env.kind == GOPS_ENV_LQ || p.env.kind == GOPS_ENV_IDPENDULUM) && k0 == 1) sk[0] = 1;
+    }
     // tuning knob (benchmarks only): GOPS_SK="0,0" forces the streamed kernels, "0,16" layer 1 only
     if (const char* e = getenv("GOPS_SK")) {
         int a = -1, b = -1;

@@ -66,16 +66,26 @@ def cpu_baseline(cfg, seed):
     nets = reference_init_nets(cfg, seed, obs_dim_of(cfg), act_dim_of(cfg))
     env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
     data = make_batch(cfg, seed)
-    times = []
-    for i in range(4):
-        t0 = time.perf_counter()
-        orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
-        times.append(time.perf_counter() - t0)
-    best = min(times[1:])
+    # The reference pins 4 intra-op threads for serial trainers (gops/utils/init_args.py:31-35); the
+    # many tiny ATen ops of this loop scale poorly, so try a few counts and report the fastest.
+    ncpu = os.cpu_count() or 4
+    results = {}
+    for nthreads in sorted({4, min(16, ncpu), min(64, ncpu)}):
+        torch.set_num_threads(nthreads)
+        times = []
+        for i in range(3):
+            t0 = time.perf_counter()
+            orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+            times.append(time.perf_counter() - t0)
+        results[nthreads] = min(times[1:])
+    best_threads = min(results, key=results.get)
+    best = results[best_threads]
     return {"value": cfg["batch"] * cfg["horizon"] / best, "unit": "env-model steps/s",
-            "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"full workload batch (B={cfg['batch']}, H={cfg['horizon']}), 1 warm-up + 3 timed "
-                      f"compute_gradient calls, best of 3 ({best * 1e3:.0f} ms)"}
+            "cores": best_threads, "kind": "port",
+            "sample": f"full workload batch (B={cfg['batch']}, H={cfg['horizon']}); per thread count 1 warm-up + 2 "
+                      f"timed compute_gradient calls (fwd+bwd), best call; "
+                      + ", ".join(f"{n} threads: {t * 1e3:.0f} ms" for n, t in results.items())
+                      + f"; host has {ncpu} logical CPUs"}
 
 
 def main():

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Turn a gpurun_out/<round>/ directory (bench JSON, rocprofv3 --stats CSV, separate --pmc passes)
+into the committed summary under profiles/.  Usage: python tools/summarize_profile.py gpurun_out/r1 r01"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "stats", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+bench = json.loads(open(os.path.join(src, f"bench_{tag}.json")).read().strip().splitlines()[-1])
+json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
+
+pmc = {}
+for d in sorted(os.listdir(src)):
+    f = os.path.join(src, d, "p_counter_collection.csv")
+    if not d.startswith("pmc_") or not os.path.exists(f):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        if any(x in k for x in ("rollout", "dw_gemm", "dw_out", "reduce_partials")):
+            pmc.setdefault(k, {}).update({c: sum(x) / len(x) for c, x in v.items()})
+json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_per_launch.json"), "w"), indent=1)
+
+stats = {r["Name"].split("(")[0]: r for r in csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv")))}
+lines = [f"# Profile summary {tag} (MI355X, workload {bench['config']['workload']})", "",
+         f"bench.py: {bench['value'] / 1e6:.1f} M env-model steps/s, {bench['ms_per_step']:.3f} ms/step; "
+         f"CPU baseline ({bench.get('cpu_baseline', {}).get('kind', '-')}, "
+         f"{bench.get('cpu_baseline', {}).get('cores', '-')} threads): "
+         f"{bench.get('cpu_baseline', {}).get('value', 0) / 1e3:.1f} k steps/s", "",
+         "Per-launch averages: duration from `rocprofv3 --kernel-trace --stats`, counters from separate "
+         "`--pmc` passes (FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; "
+         "FETCH/WRITE_SIZE are in KiB).", "",
+         "| kernel | avg us (rocprof) | MFMA busy % | HBM read MB (corrected) | HBM write MB | L2 hit % | waves parked % |",
+         "|---|---|---|---|---|---|---|"]
+for k, c in pmc.items():
+    st = next((v for n, v in stats.items() if n.strip('"') == k), None)
+    avg_us = float(st["AverageNs"]) / 1e3 if st else float("nan")
+    gui = c.get("GRBM_GUI_ACTIVE", 0) / 8.0   # summed over 8 XCDs
+    mfma = 100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * gui) if gui else float("nan")
+    rd = 2.0 * c.get("FETCH_SIZE", 0) * 1024 / 1e6
+    wr = c.get("WRITE_SIZE", 0) * 1024 / 1e6
+    hit = 100.0 * c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))
+    park = 100.0 * c.get("SQ_WAIT_ANY", 0) / max(1.0, c.get("SQ_WAVE_CYCLES", 0))
+    lines.append(f"| `{k}` | {avg_us:.1f} | {mfma:.1f} | {rd:.1f} | {wr:.1f} | {hit:.0f} | {park:.0f} |")
+lines += ["", "bench.py HIP-event timings of the same kernels (ms): " +
+          ", ".join(f"{k}: {v['avg_ms']:.3f}" for k, v in bench["kernels_ms"].items()), ""]
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
+print("\n".join(lines))

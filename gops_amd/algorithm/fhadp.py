@@ -12,7 +12,7 @@ import time
 from typing import Tuple
 
 import torch
-from torch.optim import Adam
+from gops_amd.utils.common_utils import make_adam
 
 from gops_amd import hip_backend as hb
 from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, batch_to_device, cuda_device_of,
@@ -29,7 +29,7 @@ class ApproxContainer(ApprBase):
     def __init__(self, *, policy_learning_rate: float, **kwargs):
         super().__init__(**kwargs)
         self.policy = create_apprfunc(**get_apprfunc_dict("policy", **kwargs))
-        self.policy_optimizer = Adam(self.policy.parameters(), lr=policy_learning_rate)
+        self.policy_optimizer = make_adam(self.policy.parameters(), lr=policy_learning_rate)
         self.optimizer_dict = {"policy": self.policy_optimizer}
         self.init_scheduler(**kwargs)
 

@@ -12,7 +12,7 @@ from copy import deepcopy
 from typing import Tuple
 
 import torch
-from torch.optim import Adam
+from gops_amd.utils.common_utils import make_adam
 
 from gops_amd import hip_backend as hb
 from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, batch_to_device, cuda_device_of,
@@ -37,8 +37,8 @@ class ApproxContainer(ApprBase):
         self.policy_target = deepcopy(self.policy)
         for p in list(self.v_target.parameters()) + list(self.policy_target.parameters()):
             p.requires_grad = False
-        self.policy_optimizer = Adam(self.policy.parameters(), lr=kwargs["policy_learning_rate"])
-        self.v_optimizer = Adam(self.v.parameters(), lr=kwargs["value_learning_rate"])
+        self.policy_optimizer = make_adam(self.policy.parameters(), lr=kwargs["policy_learning_rate"])
+        self.v_optimizer = make_adam(self.v.parameters(), lr=kwargs["value_learning_rate"])
         self.net_dict = {"v": self.v, "policy": self.policy}
         self.target_net_dict = {"v": self.v_target, "policy": self.policy_target}
         self.optimizer_dict = {"v": self.v_optimizer, "policy": self.policy_optimizer}

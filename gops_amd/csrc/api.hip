@@ -21,7 +21,8 @@ hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long lo
                           int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s);
 hipError_t launch_dw_out(const float* dy, const float* h, int K, int A, long long S, int splits,
                          float* part, float* part_b, hipStream_t s);
-hipError_t launch_reduce(const float* part, int splits, int rows, int cols, int ld, float* out, hipStream_t s);
+void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, int cols, int ld, float* out);
+hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s);
 hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s);
 
 namespace {
@@ -123,8 +124,8 @@ void carve_packs(Carver& c, MlpDev& d) {
 struct Plan {
     RolloutParams p;
     RolloutParams* dev_params = nullptr;   // device copy read by the rollout kernels
-    float* dw_part = nullptr;
-    float* dw_part_b = nullptr;
+    float* dw_part[GOPS_MAX_LAYERS] = {};     // split-K partial slabs, one region per Linear layer
+    float* dw_part_b[GOPS_MAX_LAYERS] = {};
     size_t bytes = 0;
 };
 
@@ -161,6 +162,8 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     for (int j = 1; j < p.pol.nl; ++j) hmax = p.pol.dims[j] > hmax ? p.pol.dims[j] : hmax;
     if (p.tail)
         for (int j = 1; j < p.val.nl; ++j) hmax = p.val.dims[j] > hmax ? p.val.dims[j] : hmax;
+    p.touch_mode = 2;
+    if (const char* tm = getenv("GOPS_TOUCH")) p.touch_mode = atoi(tm);   // tuning knob
     p.ldx = kp0 + 4;
     p.ldh = hmax + 4;
     const int ref_pts = (e.kind == GOPS_ENV_VEH3DOFCONTI) ? e.pre_horizon + 1 + desc.horizon : 0;
@@ -172,7 +175,8 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     plan.dev_params = reinterpret_cast<RolloutParams*>(c.take((sizeof(RolloutParams) + 3) / 4));
     carve_packs(c, p.pol);
     if (p.tail) carve_packs(c, p.val);
-    const long long S = (long long)p.B * p.H;
+    // stash rows: every tile stores all 16 rows of every step (tile-major order)
+    const long long S = (long long)((p.B + TB - 1) / TB) * TB * p.H;
     if (e.kind == GOPS_ENV_VEH3DOFCONTI) p.ref_table = c.take((size_t)p.B * (e.pre_horizon + 1 + p.H) * 4);
     if (p.need_grad) {
         const bool gelu = p.pol.act == GOPS_ACT_GELU;
@@ -191,20 +195,16 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
             }
         }
         p.st.tail_done = c.take((size_t)p.B);
-        // scratch for split-K partials of the weight-gradient GEMMs (largest layer)
-        size_t part = 0, part_b = 0;
+        // split-K partial slabs of the weight-gradient GEMMs: one region per layer so that all
+        // partial sums can be reduced by a single launch at the end
         for (int j = 0; j < p.pol.nl - 1; ++j) {
             const DwPlan d = plan_dw(p.pol.dims[j + 1], p.pol.kp[j], S);
-            const size_t n = (size_t)d.splits * p.pol.dims[j + 1] * p.pol.kp[j];
-            part = n > part ? n : part;
-            const size_t nb = (size_t)d.splits * p.pol.dims[j + 1];
-            part_b = nb > part_b ? nb : part_b;
+            plan.dw_part[j] = c.take((size_t)d.splits * p.pol.dims[j + 1] * p.pol.kp[j]);
+            plan.dw_part_b[j] = c.take((size_t)d.splits * p.pol.dims[j + 1]);
         }
-        const size_t nout = (size_t)DW_OUT_SPLITS * GOPS_MAX_ACT * p.pol.dims[p.pol.nl - 1];
-        part = nout > part ? nout : part;
-        part_b = (size_t)DW_OUT_SPLITS * GOPS_MAX_ACT > part_b ? (size_t)DW_OUT_SPLITS * GOPS_MAX_ACT : part_b;
-        plan.dw_part = c.take(part);
-        plan.dw_part_b = c.take(part_b);
+        const int Lh = p.pol.nl - 1;
+        plan.dw_part[Lh] = c.take((size_t)DW_OUT_SPLITS * GOPS_MAX_ACT * p.pol.dims[Lh]);
+        plan.dw_part_b[Lh] = c.take((size_t)DW_OUT_SPLITS * GOPS_MAX_ACT);
     }
     plan.bytes = c.off + kAlign;
     return GOPS_OK;
@@ -287,29 +287,34 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     if (dbg) {
         unsigned long long h[16];
         (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[gops dbg] bwd cycles/step: loop-top %llu | env adjoint %llu | mlp backward %llu\n",
-                h[0] / p.H, h[1] / p.H, h[2] / p.H);
+        fprintf(stderr, "[gops dbg] bwd cycles/step: touch %llu | env(points %llu, reduce+sync %llu, finish %llu) | head-bwd %llu sync %llu stash %llu | "
+                "gemm1+epi %llu sync %llu stash %llu | gemm0+epi %llu | end sync %llu\n",
+                h[0] / p.H, h[10] / p.H, h[11] / p.H, h[1] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H, h[6] / p.H, h[7] / p.H,
+                h[8] / p.H, h[9] / p.H, h[2] / p.H);
     }
     ProfScope scope(2, s);
-    const long long S = (long long)p.B * p.H;
+    const long long S = (long long)((p.B + TB - 1) / TB) * TB * p.H;
     const int L = p.pol.nl - 1;
+    ReduceJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
     for (int j = 0; j < L; ++j) {   // dW_j = D_{j+1}^T * (j == 0 ? X : H_j)
         const int N = p.pol.dims[j + 1], Kp = p.pol.kp[j], K = p.pol.dims[j];
         const DwPlan d = plan_dw(N, Kp, S);
         const float* X = (j == 0) ? p.st.x : p.st.h[j];
-        if ((e = launch_dw_gemm(p.st.d[j + 1], N, X, Kp, S, d.splits, d.chunks_per_split, plan.dw_part,
-                                plan.dw_part_b, d.big, s)) != hipSuccess) return (int)e;
-        if ((e = launch_reduce(plan.dw_part, d.splits, N, K, Kp, grad.weight[j], s)) != hipSuccess) return (int)e;
-        if ((e = launch_reduce(plan.dw_part_b, d.splits, 1, N, N, grad.bias[j], s)) != hipSuccess) return (int)e;
+        if ((e = launch_dw_gemm(p.st.d[j + 1], N, X, Kp, S, d.splits, d.chunks_per_split, plan.dw_part[j],
+                                plan.dw_part_b[j], d.big, s)) != hipSuccess) return (int)e;
+        reduce_jobs_add(jobs, plan.dw_part[j], d.splits, N, K, Kp, grad.weight[j]);
+        reduce_jobs_add(jobs, plan.dw_part_b[j], d.splits, 1, N, N, grad.bias[j]);
     }
     {
         const int K = p.pol.dims[L], A = p.pol.dims[p.pol.nl];
         long long splits = DW_OUT_SPLITS;
         if (splits > S) splits = S;
-        if ((e = launch_dw_out(p.st.dy, p.st.h[L], K, A, S, (int)splits, plan.dw_part, plan.dw_part_b, s)) != hipSuccess) return (int)e;
-        if ((e = launch_reduce(plan.dw_part, (int)splits, A, K, K, grad.weight[L], s)) != hipSuccess) return (int)e;
-        if ((e = launch_reduce(plan.dw_part_b, (int)splits, 1, A, A, grad.bias[L], s)) != hipSuccess) return (int)e;
+        if ((e = launch_dw_out(p.st.dy, p.st.h[L], K, A, S, (int)splits, plan.dw_part[L], plan.dw_part_b[L], s)) != hipSuccess) return (int)e;
+        reduce_jobs_add(jobs, plan.dw_part[L], (int)splits, A, K, K, grad.weight[L]);
+        reduce_jobs_add(jobs, plan.dw_part_b[L], (int)splits, 1, A, A, grad.bias[L]);
     }
+    if ((e = launch_reduce(jobs, s)) != hipSuccess) return (int)e;
     return GOPS_OK;
 }
 

@@ -153,7 +153,7 @@ hipError_t launch_ref_table(int B, int P, int H, const GopsRolloutIn& in, float 
 template <int R>
 __global__ __launch_bounds__(NTHREADS) void dw_gemm_kernel(const float* __restrict__ D, int N,
                                                            const float* __restrict__ X, int Kp,
-                                                           long long S, int chunks_per_split,
+                                                           long long S, int splits, int chunks_per_split,
                                                            float* __restrict__ part,
                                                            float* __restrict__ part_b) {
     constexpr int T = 32 * R;          // tile edge
@@ -162,10 +162,15 @@ __global__ __launch_bounds__(NTHREADS) void dw_gemm_kernel(const float* __restri
     __shared__ __attribute__((aligned(16))) float Ds[DW_SC * LD];
     __shared__ __attribute__((aligned(16))) float Xs[DW_SC * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_k = (Kp + T - 1) / T;
-    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+    const int tiles_k = (Kp + T - 1) / T, tiles = tiles_k * ((N + T - 1) / T);
+    // XCD-aware order: workgroup b runs on XCD b % 8.  All output tiles of one sample split read the
+    // same D / X chunks, so they get the same XCD and adjacent slots: the second reader of a chunk
+    // hits that XCD's L2 instead of HBM.
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tile = local % tiles, split = (local / tiles) * 8 + xcd;
+    if (split >= splits) return;
+    const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
     const int n0 = tile_n * T, k0 = tile_k * T;
-    const int split = blockIdx.y;
     const long long s_begin = (long long)split * chunks_per_split * DW_SC;
     const int wn = wave >> 1, wk = wave & 1;
 
@@ -240,12 +245,12 @@ hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long lo
                           int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s) {
     if (big) {
         const int T = 128, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
-        hipLaunchKernelGGL(dw_gemm_kernel<4>, dim3(tiles, splits), dim3(NTHREADS), 0, s, D, N, X, Kp, S,
-                           chunks_per_split, part, part_b);
+        hipLaunchKernelGGL(dw_gemm_kernel<4>, dim3(tiles * ((splits + 7) / 8) * 8), dim3(NTHREADS), 0, s, D, N, X, Kp, S,
+                           splits, chunks_per_split, part, part_b);
     } else {
         const int T = 64, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
-        hipLaunchKernelGGL(dw_gemm_kernel<2>, dim3(tiles, splits), dim3(NTHREADS), 0, s, D, N, X, Kp, S,
-                           chunks_per_split, part, part_b);
+        hipLaunchKernelGGL(dw_gemm_kernel<2>, dim3(tiles * ((splits + 7) / 8) * 8), dim3(NTHREADS), 0, s, D, N, X, Kp, S,
+                           splits, chunks_per_split, part, part_b);
     }
     return hipGetLastError();
 }
@@ -301,15 +306,18 @@ hipError_t launch_dw_out(const float* dy, const float* h, int K, int A, long lon
     return hipGetLastError();
 }
 
-// out[r][c] = sum_split part[split][r][c]   for c < cols (row stride `ld` inside a split).
-// Block = 64 outputs x 4 split lanes; each lane sums every 4th split with independent loads in
-// flight, then the 4 lanes are combined through LDS (fixed order -> deterministic).
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits,
-                                                              int rows, int cols, int ld,
-                                                              float* __restrict__ out) {
+// out[r][c] = sum_split part[split][r][c]   for c < cols (row stride `ld` inside a split), for every
+// job of the table in ONE launch.  Block = 64 outputs x 4 split lanes; each lane sums every 4th split
+// with independent loads in flight, then the 4 lanes are combined through LDS (fixed order ->
+// deterministic).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs jobs) {
     __shared__ float red[4][64];
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.block0[j + 1]) ++j;
+    const float* __restrict__ part = jobs.part[j];
+    const int splits = jobs.splits[j], rows = jobs.rows[j], cols = jobs.cols[j], ld = jobs.ld[j];
     const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o;
+    const int idx = (blockIdx.x - jobs.block0[j]) * 64 + o;
     const bool valid = idx < rows * cols;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     if (valid) {
@@ -327,13 +335,20 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
     red[sl][o] = (acc0 + acc1) + (acc2 + acc3);
     __syncthreads();
-    if (sl == 0 && valid) out[idx] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    if (sl == 0 && valid) jobs.out[j][idx] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
 }
 
-hipError_t launch_reduce(const float* part, int splits, int rows, int cols, int ld, float* out, hipStream_t s) {
-    const int total = rows * cols;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 63) / 64), dim3(256), 0, s, part, splits,
-                       rows, cols, ld, out);
+void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, int cols, int ld, float* out) {
+    const int i = jobs.n++;
+    jobs.part[i] = part; jobs.out[i] = out;
+    jobs.splits[i] = splits; jobs.rows[i] = rows; jobs.cols[i] = cols; jobs.ld[i] = ld;
+    if (i == 0) jobs.block0[0] = 0;
+    jobs.block0[i + 1] = jobs.block0[i] + (rows * cols + 63) / 64;
+}
+
+hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s) {
+    if (jobs.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(jobs.block0[jobs.n]), dim3(256), 0, s, jobs);
     return hipGetLastError();
 }
 

@@ -13,6 +13,15 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Pointers that reach the kernels through the parameter block are generic to the compiler, and
+// generic accesses become FLAT instructions, which count on lgkmcnt as well as vmcnt: every LDS wait
+// would then also wait for the pending stash stores.  gptr() re-types them as global (addrspace 1).
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ GLOBAL_AS T* gptr(T* p) { return (GLOBAL_AS T*)p; }
+template <class T> __device__ __forceinline__ const GLOBAL_AS T* gptr(const T* p) { return (const GLOBAL_AS T*)p; }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const GLOBAL_AS float* p) { return *(const GLOBAL_AS f32x4*)p; }
+
 // ---- device-side descriptors (passed by value as kernel arguments) -------------------------
 struct MlpDev {
     int nl;                       // Linear layers
@@ -40,6 +49,7 @@ struct StashDev {
 struct RolloutParams {
     int B, H, fh, need_grad, tail;
     int ldx, ldh;                     // LDS leading dims: input tile / hidden tiles (floats)
+    int touch_mode;                   // backward L2 warm-up: 0 off, 1 all at the step top, 2 spread over the step
     GopsEnv env;
     MlpDev pol, val;
     StashDev st;
@@ -52,6 +62,7 @@ struct RolloutParams {
 };
 
 // per-phase cycle accounting of block 0 / thread 0 (debug builds of the timing knob only)
+#ifdef GOPS_DBG_BUILD   // make -C gops_amd/csrc DBG=1 : in-kernel phase timing (costs ~32 VGPRs)
 struct DbgClock {
     bool on;
     long long acc[16], last;
@@ -67,8 +78,28 @@ struct DbgClock {
             last = now;
         }
     }
+    __device__ __forceinline__ void dump(unsigned long long* out) const {
+        if (on)
+            for (int i = 0; i < 16; ++i) gptr(out)[i] = (unsigned long long)acc[i];
+    }
 };
+#else
+struct DbgClock {
+    __device__ __forceinline__ void init(bool) {}
+    __device__ __forceinline__ void tick(int) {}
+    __device__ __forceinline__ void dump(unsigned long long*) const {}
+};
+#endif
 #define DBG_TICK(i) dbg.tick(i);
+
+// Batched split-K reductions: job i sums `splits` partial slabs [rows][ld] into out[rows][cols].
+struct ReduceJobs {
+    int n;
+    int block0[2 * GOPS_MAX_LAYERS + 1];   // first block of each job; block0[n] = total
+    const float* part[2 * GOPS_MAX_LAYERS];
+    float* out[2 * GOPS_MAX_LAYERS];
+    int splits[2 * GOPS_MAX_LAYERS], rows[2 * GOPS_MAX_LAYERS], cols[2 * GOPS_MAX_LAYERS], ld[2 * GOPS_MAX_LAYERS];
+};
 
 // ---- activations ---------------------------------------------------------------------------
 #define SELU_SCALE 1.0507009873554804934193349852946f
@@ -174,29 +205,55 @@ __device__ __forceinline__ float row16_sum(float v) {
 // A lives in LDS row-major with leading dimension lda (floats, lda % 4 == 0); lane l supplies
 // A[m = l&15][16c + 4*(l>>4) + i] to the i-th v_mfma_f32_16x16x4_f32 of chunk c, and the packed
 // operand holds the matching B values so that one dwordx4 load per lane feeds four MFMAs.
+// Streamed B operand: PF chunks of fragments are kept in flight ahead of the MFMAs (L2 latency is
+// 500+ cycles under load).  prime() may be called well before run() to hide the first fetch.
+template <int NT>
+struct StreamB {
+    static constexpr int PF = (NT >= 4) ? 1 : 4;
+    f32x4 ring[PF][NT];
+    const GLOBAL_AS f32x4* wbase;
+    __device__ __forceinline__ void prime(const f32x4* Wp, int kchunks, int nt0, int lane, int c_begin) {
+        wbase = gptr(Wp) + (size_t)nt0 * kchunks * 64 + lane;
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const int cd = (c_begin + d < kchunks) ? c_begin + d : kchunks - 1;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ring[d][j] = wbase[((size_t)j * kchunks + cd) * 64];
+        }
+    }
+    __device__ __forceinline__ void run(const float* A, int lda, int kchunks, int lane, f32x4 (&acc)[NT], int c_begin) {
+        const float* arow = A + (lane & 15) * lda + 4 * (lane >> 4);
+        for (int c0 = c_begin; c0 < kchunks; c0 += PF) {
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                const int c = c0 + d;
+                if (c < kchunks) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * c);
+                    f32x4 bcur[NT];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bcur[j] = ring[d][j];
+                    const int cn = (c + PF < kchunks) ? c + PF : kchunks - 1;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) ring[d][j] = wbase[((size_t)j * kchunks + cn) * 64];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bcur[j][i], acc[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+};
+
 template <int NT>
 __device__ __forceinline__ void mfma_gemm(const float* __restrict__ A, int lda, int kchunks,
                                           const f32x4* __restrict__ Wp, int nt0, int lane,
                                           f32x4 (&acc)[NT]) {
-    const float* arow = A + (lane & 15) * lda + 4 * (lane >> 4);
-    const f32x4* wbase = Wp + (size_t)nt0 * kchunks * 64 + lane;
-    f32x4 bcur[NT], bnxt[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bcur[j] = wbase[(size_t)j * kchunks * 64];
-    for (int c = 0; c < kchunks; ++c) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * c);
-        const int cn = (c + 1 < kchunks) ? c + 1 : c;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bnxt[j] = wbase[((size_t)j * kchunks + cn) * 64];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bcur[j][i], acc[j], 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bcur[j] = bnxt[j];
-    }
+    StreamB<NT> sb;
+    sb.prime(Wp, kchunks, nt0, lane, 0);
+    sb.run(A, lda, kchunks, lane, acc, 0);
 }
 
 // One dense layer on the tile: out tiles are dealt to the 4 waves in contiguous groups, each wave
@@ -239,26 +296,31 @@ __device__ __forceinline__ void gemm_layer(const float* A, int lda, int kch, int
 template <int KCH, int NT>
 struct StatW {
     f32x4 w[KCH * NT];
-    __device__ __forceinline__ void load(const f32x4* __restrict__ Wp, int nt_tot, int tid) {
+    __device__ __forceinline__ void load(const f32x4* __restrict__ Wp, int nt_tot, int tid, int kch_total = KCH) {
         const int lane = tid & 63, nt0 = (tid >> 6) * NT;
 #pragma unroll
         for (int c = 0; c < KCH; ++c)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                w[c * NT + j] = (nt0 + j < nt_tot) ? Wp[((size_t)(nt0 + j) * KCH + c) * 64 + lane] : z;
+                w[c * NT + j] = (nt0 + j < nt_tot) ? gptr(Wp)[((size_t)(nt0 + j) * kch_total + c) * 64 + lane] : z;
             }
     }
 };
 struct NoW {};   // placeholder for a streamed layer
 
+// K-chunks 0..KCH-1 come from the stationary fragments, chunks KCH..kch_total-1 (if any) are
+// streamed from the packed weights like mfma_gemm does.
 template <int KCH, int NT, class Epi>
 __device__ __forceinline__ void gemm_layer_stat(const float* A, int lda, const StatW<KCH, NT>& W,
-                                                int nt_tot, int tid, Epi&& epi) {
+                                                int nt_tot, int tid, Epi&& epi, int kch_total = KCH,
+                                                const f32x4* Wp = nullptr) {
     const int lane = tid & 63, nt0 = (tid >> 6) * NT;
     if (nt0 >= nt_tot) return;
     const float* arow = A + (lane & 15) * lda + 4 * (lane >> 4);
     f32x4 acc[NT] = {};
+    StreamB<NT> sb;
+    if (kch_total > KCH) sb.prime(Wp, kch_total, nt0, lane, KCH);   // fetched behind the stationary MFMAs
 #pragma unroll
     for (int c = 0; c < KCH; ++c) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * c);
@@ -268,10 +330,40 @@ __device__ __forceinline__ void gemm_layer_stat(const float* A, int lda, const S
             for (int j = 0; j < NT; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], W.w[c * NT + j][i], acc[j], 0, 0, 0);
     }
+    if (kch_total > KCH) sb.run(A, lda, kch_total, lane, acc, KCH);
     f32x4 out[4] = {};
 #pragma unroll
     for (int q = 0; q < NT; ++q) out[q] = acc[q];
     epi.template operator()<NT>(out, nt0);   // stationary layers: nt_tot is a multiple of NT (or < 4 with NT = 1)
+}
+
+// L2 warm-up of the stash tiles the NEXT backward step will read.  Plain loads whose values are
+// consumed one step later (XOR into a sink), so the compiler's s_waitcnt for them lands after a whole
+// step of work: the lines travel HBM -> L2 in the background and the real reads hit L2.  (Inline-asm
+// loads are not an option: hipcc drains vmcnt(0) - i.e. every pending stash store - before each asm.)
+#define TOUCH_SLOTS 4
+// One warm-up line per (thread, slot): line g of the concatenation [H_1 .. H_L (Z_1 .. Z_L if GELU),
+// env rows, first line of each X row] of the tile at stash row `prow`.  Fully unrolled over constant
+// layer indices - nothing here may live in (scratch) memory.
+__device__ __forceinline__ unsigned touch_fetch(const MlpDev& M, const StashDev& st, size_t prow, int g) {
+    const int Lh = M.nl - 1;
+    const bool gelu = M.act == GOPS_ACT_GELU;
+#pragma unroll
+    for (int j = 1; j < GOPS_MAX_LAYERS; ++j) {
+        if (j <= Lh) {
+            const int n = M.dims[j], nl = TB * n / 32;
+            if (g >= 0 && g < nl) return *gptr(reinterpret_cast<const unsigned*>(st.h[j] + prow * n) + g * 32);
+            g -= nl;
+            if (gelu) {
+                if (g >= 0 && g < nl) return *gptr(reinterpret_cast<const unsigned*>(st.z[j] + prow * n) + g * 32);
+                g -= nl;
+            }
+        }
+    }
+    if (g >= 0 && g < TB * ENV_STASH / 32) return *gptr(reinterpret_cast<const unsigned*>(st.env + prow * ENV_STASH) + g * 32);
+    g -= TB * ENV_STASH / 32;
+    if (g >= 0 && g < TB) return *gptr(reinterpret_cast<const unsigned*>(st.x + (prow + g) * M.kp[0]));
+    return 0u;
 }
 
 // Copy a [TB][ncols] LDS tile (leading dim ld) to global rows g[(row0+m)*ncols ...], coalesced.
@@ -285,7 +377,7 @@ __device__ __forceinline__ void stash_tile(const float* lds, int ld, int ncols, 
             const int m = idx >> sh, c4 = idx & (vec_per_row - 1);
             if (m < nrows_valid) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(lds + m * ld + 4 * c4);
-                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g + (row0 + m) * ncols + 4 * c4));
+                __builtin_nontemporal_store(v, gptr(reinterpret_cast<f32x4*>(g + (row0 + m) * ncols + 4 * c4)));
             }
         }
         return;
@@ -294,7 +386,7 @@ __device__ __forceinline__ void stash_tile(const float* lds, int ld, int ncols, 
         const int m = idx / vec_per_row, c4 = idx - m * vec_per_row;
         if (m < nrows_valid) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(lds + m * ld + 4 * c4);
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g + (row0 + m) * ncols + 4 * c4));
+            __builtin_nontemporal_store(v, gptr(reinterpret_cast<f32x4*>(g + (row0 + m) * ncols + 4 * c4)));
         }
     }
 }

@@ -11,13 +11,13 @@
 
 // delta_y in s_gy[TB][4]  ->  hidden deltas (stashed to stash_d when non-null) and, if want_gx,
 // G[m][n] += (delta_1 W_0)[m][n] for n < ncols.
-template <class W0T, class W1T>
+template <class W0T, class W1T, class WP>
 __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, const W1T& WT1,
-                                             const float* Wo, int ldw, const float* s_gy, float* da,
+                                             WP Wo, int ldw, const float* s_gy, float* da,
                                              float* db, int ldh, float* G, int ldg, int tid,
                                              float* const* stash_h, float* const* stash_z,
                                              float* const* stash_d, float* stash_dy, size_t row0,
-                                             int nvalid, bool want_gx, int ncols) {
+                                             int nvalid, bool want_gx, int ncols, DbgClock& dbg) {
     const int lane = tid & 63;
     const int L = M.nl - 1, A = M.dims[M.nl];
     const bool gelu = (M.act == GOPS_ACT_GELU);
@@ -28,23 +28,20 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
         float gy[GOPS_MAX_ACT];
 #pragma unroll
         for (int a = 0; a < GOPS_MAX_ACT; ++a) gy[a] = (a < A) ? s_gy[hm * 4 + a] : 0.f;
-        const float* hrow = stash_h[L] + (row0 + hm) * K;
-        const float* zrow = gelu ? stash_z[L] + (row0 + hm) * K : nullptr;
+        const GLOBAL_AS float* hrow = gptr(stash_h[L] + (row0 + hm) * K);
+        const GLOBAL_AS float* zrow = gptr(gelu ? stash_z[L] + (row0 + hm) * K : stash_h[L]);
         act_dispatch(M.act, [&]<int ACT>() {
             if ((K & 63) == 0 && (ldw & 3) == 0) {
 #pragma unroll 4
                 for (int k = 4 * hp; k < K; k += 64) {
-                    f32x4 hv = {0.f, 0.f, 0.f, 0.f}, zv = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
-                    if (hm < nvalid) {
-                        hv = *reinterpret_cast<const f32x4*>(hrow + k);
-                        if (ACT == GOPS_ACT_GELU) zv = *reinterpret_cast<const f32x4*>(zrow + k);
-                    }
+                    f32x4 hv = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
+                    if (hm < nvalid) hv = ld4((ACT == GOPS_ACT_GELU ? zrow : hrow) + k);
 #pragma unroll
                     for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                        if (a < A) acc += gy[a] * *reinterpret_cast<const f32x4*>(Wo + a * ldw + k);
+                        if (a < A) acc += gy[a] * ld4(Wo + a * ldw + k);
                     f32x4 dv;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dv[e] = (hm < nvalid) ? acc[e] * act_bwd_t<ACT>(hv[e], zv[e]) : 0.f;
+                    for (int e = 0; e < 4; ++e) dv[e] = (hm < nvalid) ? acc[e] * act_bwd_t<ACT>(hv[e], hv[e]) : 0.f;
                     *reinterpret_cast<f32x4*>(da + hm * ldh + k) = dv;
                 }
             } else {
@@ -54,39 +51,44 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
                     for (int a = 0; a < GOPS_MAX_ACT; ++a)
                         if (a < A) acc += gy[a] * Wo[a * ldw + k];
                     float dv = 0.f;
-                    if (hm < nvalid) dv = acc * act_bwd_t<ACT>(hrow[k], ACT == GOPS_ACT_GELU ? zrow[k] : 0.f);
+                    if (hm < nvalid) {
+                        const float v = (ACT == GOPS_ACT_GELU ? zrow : hrow)[k];
+                        dv = acc * act_bwd_t<ACT>(v, v);
+                    }
                     da[hm * ldh + k] = dv;
                 }
             }
         });
-        if (stash_dy != nullptr && tid < nvalid) {
+        if (stash_dy != nullptr && tid < TB) {
             f32x4 v = {s_gy[tid * 4 + 0], s_gy[tid * 4 + 1], s_gy[tid * 4 + 2], s_gy[tid * 4 + 3]};
 #pragma unroll
             for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                if (a >= A) v[a] = 0.f;
-            *reinterpret_cast<f32x4*>(stash_dy + (row0 + tid) * 4) = v;
+                if (a >= A || tid >= nvalid) v[a] = 0.f;
+            *gptr(reinterpret_cast<f32x4*>(stash_dy + (row0 + tid) * 4)) = v;
         }
     }
+    DBG_TICK(3)
     __syncthreads();
-    if (stash_d != nullptr) stash_tile(da, ldh, M.dims[L], stash_d[L], row0, nvalid, tid);
+    DBG_TICK(4)
+    if (stash_d != nullptr) stash_tile(da, ldh, M.dims[L], stash_d[L], row0, TB, tid);
+    DBG_TICK(5)
     float* cur = da;
     float* out = db;
     // ---- hidden layers j = L-1 .. 1: delta_j = (delta_{j+1} W_j) * act'(z_j) ----
     for (int j = L - 1; j >= 1; --j) {
         const int N = M.dims[j], kch = M.dims[j + 1] >> 4, nt_tot = N >> 4;
-        const float* hbase = stash_h[j] + row0 * N;
-        const float* zbase = gelu ? stash_z[j] + row0 * N : nullptr;
+        const GLOBAL_AS float* hbase = gptr(stash_h[j] + row0 * N);
+        const GLOBAL_AS float* zbase = gptr(gelu ? stash_z[j] + row0 * N : stash_h[j]);
         auto epi = [&]<int CNT>(const f32x4 (&acc)[4], int nt0) {
             act_dispatch(M.act, [&]<int ACT>() {
-                float hv[CNT][4], zv[CNT][4];
+                float hv[CNT][4];
 #pragma unroll
                 for (int q = 0; q < CNT; ++q)    // issue every stash load before the math
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int n = ((nt0 + q) << 4) + (lane & 15), m = ((lane >> 4) << 2) + r;
-                        const bool ok = m < nvalid;
-                        hv[q][r] = ok ? hbase[(size_t)m * N + n] : 0.f;
-                        zv[q][r] = (ok && ACT == GOPS_ACT_GELU) ? zbase[(size_t)m * N + n] : 0.f;
+                        // GELU's derivative needs z, every other activation's needs h
+                        hv[q][r] = (m < nvalid) ? (ACT == GOPS_ACT_GELU ? zbase : hbase)[(size_t)m * N + n] : 0.f;
                     }
 #pragma unroll
                 for (int q = 0; q < CNT; ++q) {
@@ -94,7 +96,7 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int m = ((lane >> 4) << 2) + r;
-                        out[m * ldh + n] = (m < nvalid) ? acc[q][r] * act_bwd_t<ACT>(hv[q][r], zv[q][r]) : 0.f;
+                        out[m * ldh + n] = (m < nvalid) ? acc[q][r] * act_bwd_t<ACT>(hv[q][r], hv[q][r]) : 0.f;
                     }
                 }
             });
@@ -104,8 +106,11 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
             if (j == 1) { gemm_layer_stat(cur, ldh, WT1, nt_tot, tid, epi); done = true; }
         }
         if (!done) gemm_layer(cur, ldh, kch, nt_tot, M.wpt[j], tid, epi);
+        DBG_TICK(6)
         __syncthreads();
-        if (stash_d != nullptr) stash_tile(out, ldh, N, stash_d[j], row0, nvalid, tid);
+        DBG_TICK(7)
+        if (stash_d != nullptr) stash_tile(out, ldh, N, stash_d[j], row0, TB, tid);
+        DBG_TICK(8)
         float* tmp = cur; cur = out; out = tmp;
     }
     // ---- input adjoint g_x = delta_1 W_0 ----
@@ -124,15 +129,16 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
                 }
             }
         };
-        if constexpr (!std::is_same<W0T, NoW>::value) gemm_layer_stat(cur, ldh, WT0, nt_tot, tid, epi);
+        if constexpr (!std::is_same<W0T, NoW>::value) gemm_layer_stat(cur, ldh, WT0, nt_tot, tid, epi, kch, M.wpt[0]);
         else gemm_layer(cur, ldh, kch, nt_tot, M.wpt[0], tid, epi);
+        DBG_TICK(9)
     }
 }
 
 // SK0 / SK1 as in the forward kernel: here the stationary fragments are the TRANSPOSED packings
-// (delta_2 -> delta_1 through W_1: 16 chunks x 4 tiles; delta_1 -> g_x through W_0: 16 chunks x
-// ceil(SK0/4) tiles per wave).
-template <int ENV, int SK0, int SK1>
+// (delta_2 -> delta_1 through W_1: 16 chunks x 4 tiles).  SK0 here = number of the 16 K-chunks of
+// delta_1 -> g_x (through W_0^T, PT0 n-tiles per wave) that stay in registers; the rest streams.
+template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1>
 __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
     const int b0 = blockIdx.x * TB;
     const int nvalid = min(TB, p.B - b0);
     const int O = p.env.obs_dim, A = p.env.act_dim;
-    const int ldx = (SK0 > 0) ? 16 * SK0 + 4 : p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
+    const int ldx = p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* G = smem;                    // [TB][ldx] adjoint of obs_{t+1}
     float* da = G + TB * ldx;           // [TB][ldh]
     float* db = da + TB * ldh;          // [TB][ldh]
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
     f32x4* s_ref = reinterpret_cast<f32x4*>(s_wo + 4 * ldh);   // veh: [TB][TL]
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
-    const float gv = (tid < nvalid) ? p.grad_v[b0 + tid] : 0.f;
+    const float gv = (tid < nvalid) ? gptr(p.grad_v)[b0 + tid] : 0.f;
     float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // adjoint of the veh3dof state (tid < TB)
     const IdpConst IC = idp_const();
     const VehConst VC = veh_const();
@@ -160,39 +166,47 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
         for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
             const int a = idx / K, k = idx - a * K;
-            s_wo[a * ldh + k] = p.pol.w[Lh][idx];
+            s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
         }
         if (ENV == GOPS_ENV_VEH3DOFCONTI) {
-            const f32x4* tbl = reinterpret_cast<const f32x4*>(p.ref_table) + (size_t)b0 * TL;
+            const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
             for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 s_ref[idx] = (idx < nvalid * TL) ? tbl[idx] : z;
             }
         }
     }
-    constexpr int PT0 = (SK0 + 3) / 4;   // n-tiles of the input adjoint per wave
-    typename std::conditional<(SK0 > 0), StatW<16, (PT0 > 0 ? PT0 : 1)>, NoW>::type WT0;
+    typename std::conditional<(SK0 > 0), StatW<(SK0 > 0 ? SK0 : 1), PT0>, NoW>::type WT0;
     typename std::conditional<(SK1 > 0), StatW<16, 4>, NoW>::type WT1;
-    if constexpr (SK0 > 0) WT0.load(p.pol.wpt[0], kp0 >> 4, tid);
+    if constexpr (SK0 > 0) WT0.load(p.pol.wpt[0], kp0 >> 4, tid, p.pol.dims[1] >> 4);
     if constexpr (SK1 > 0) WT1.load(p.pol.wpt[1], p.pol.dims[1] >> 4, tid);
 
-    if (p.tail) {
+    DbgClock dbg;
+    dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
+    if (TAIL) {
         if (tid < TB) {
-            const float dH = (tid < nvalid) ? p.st.tail_done[b0 + tid] : 1.f;
+            const float dH = (tid < nvalid) ? gptr(p.st.tail_done)[b0 + tid] : 1.f;
             s_gy[tid * 4 + 0] = gv * ((1.f - dH) * p.gpow[p.H]);
             s_gy[tid * 4 + 1] = s_gy[tid * 4 + 2] = s_gy[tid * 4 + 3] = 0.f;
         }
         __syncthreads();
-        mlp_backward(p.val, NoW{}, NoW{}, p.val.w[p.val.nl - 1], p.val.dims[p.val.nl - 1], s_gy, da, db, ldh, G, ldx,
+        mlp_backward(p.val, NoW{}, NoW{}, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, da, db, ldh, G, ldx,
                      tid, p.st.tail_h, p.st.tail_z, nullptr, nullptr,
-                     (size_t)b0, nvalid, true, O);
+                     (size_t)b0, nvalid, true, O, dbg);
     }
     __syncthreads();
 
-    DbgClock dbg;
-    dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
+    unsigned l2_sink = 0, l2_pf[TOUCH_SLOTS] = {0u, 0u, 0u, 0u};
     for (int t = p.H - 1; t >= 0; --t) {
-        const size_t row0 = (size_t)t * p.B + b0;
+        const size_t row0 = ((size_t)blockIdx.x * p.H + t) * TB;   // tile-major stash rows
+        const size_t prow = row0 - TB;
+        const int tmode = (t > 0) ? p.touch_mode : 0;
+        if (tmode == 1) {   // start fetching what step t-1 will read (written long ago by the forward kernel)
+#pragma unroll
+            for (int q = 0; q < TOUCH_SLOTS; ++q) l2_pf[q] = touch_fetch(p.pol, p.st, prow, tid + NTHREADS * q);
+        } else if (tmode == 2) {
+            l2_pf[0] = touch_fetch(p.pol, p.st, prow, tid);
+        }
         DBG_TICK(0)
         float g_r = gv * p.gpow[t];                         // adjoint of the shaped reward
         if (ENV != GOPS_ENV_NONE && p.env.shaping) g_r *= p.env.reward_scale;
@@ -208,11 +222,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
                 float th[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, dflag = 1.f;
                 float x[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (m < nvalid) {
-                    const f32x4* er = reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH);
+                    const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
                     const f32x4 e0 = er[0], e1 = er[1];
                     th[0] = e0[0]; th[1] = e0[1]; th[2] = e0[2]; th[3] = e0[3];
                     dflag = e1[0];
-                    const float* xr = p.st.x + (row0 + m) * kp0;
+                    const GLOBAL_AS float* xr = gptr(p.st.x + (row0 + m) * kp0);
 #pragma unroll
                     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
                         if (i < O) x[i] = xr[i];
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
             float th0 = 0.f, th1 = 0.f, dflag = 1.f;
             float s[6] = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f};
             if (m < nvalid) {
-                const f32x4* er = reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH);
+                const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
                 const f32x4 e0 = er[0], e1 = er[1], e2 = er[2];
                 th0 = e0[0]; th1 = e0[1]; dflag = e1[0];
                 s[0] = e1[1]; s[1] = e1[2]; s[2] = e1[3]; s[3] = e2[0]; s[4] = e2[1]; s[5] = e2[2];
@@ -324,6 +338,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
                 pphi -= gph;
                 pu -= gu_;
             }
+            DBG_TICK(10)
             // reduce over the 16 `part` threads of each trajectory: lanes m+16q in-wave, then 4 waves
             float v6[6] = {px, py, pphi, pu, pc, ps};
 #pragma unroll
@@ -336,6 +351,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
                 for (int i = 0; i < 6; ++i) red[(wave * TB + m) * 8 + i] = v6[i];
             }
             __syncthreads();
+            DBG_TICK(11)
             if (tid < TB) {
                 float tot[6];
 #pragma unroll
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
                 veh_f_xu_bwd(VC, s, steer, w, lamn, lam, g_steer, g_ax);
                 const float g_rm = dn ? 0.f : g_r;
                 if (m < nvalid) {
-                    const float* xr = p.st.x + (row0 + m) * kp0;
+                    const GLOBAL_AS float* xr = gptr(p.st.x + (row0 + m) * kp0);
                     G[m * ldx + 0] += g_rm * (-0.08f * xr[0]);
                     G[m * ldx + 1] += g_rm * (-0.08f * xr[1]);
                     G[m * ldx + 2] += g_rm * (-0.04f * xr[2]);
@@ -368,41 +384,55 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
             }
         }
         __syncthreads();
+        if (tmode == 2) l2_pf[1] = touch_fetch(p.pol, p.st, prow, tid + NTHREADS);
         DBG_TICK(1)
         mlp_backward(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
-                     /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O);
+                     /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg);
+        // retire this step's warm-up loads inside the same iteration: the compiler can then count the
+        // memory operations issued since (exact vmcnt) instead of draining everything at the back-edge
+#pragma unroll
+        for (int q = 0; q < TOUCH_SLOTS; ++q) l2_sink ^= l2_pf[q];
         __syncthreads();
         DBG_TICK(2)
     }
-    if (dbg.on)
-        for (int i = 0; i < 16; ++i) p.dbg[i] = (unsigned long long)dbg.acc[i];
+    if (l2_sink == 0x9e3779b9u && p.dbg != nullptr) gptr(p.dbg)[15] = l2_sink;   // keeps the warm-up loads alive
+    dbg.dump(p.dbg);
 }
 
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points) {
     return sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * 4 + 4 * TB * 8 + 4 * ldh + 4 * TB * ref_points);
 }
 
-void rollout_variant(const RolloutParams& p, int sk[2]);
+void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
 
-#define LAUNCH_BWD(ENV, A, B) launch_with_lds(rollout_bwd_kernel<ENV, A, B>, grid, block, lds, stream, dp)
+#define LAUNCH_BWD(ENV, A, B)                                                                            \
+    do {                                                                                                 \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, A, B, true>, grid, block, lds, stream, dp);   \
+        else launch_with_lds(rollout_bwd_kernel<ENV, A, B, false>, grid, block, lds, stream, dp);         \
+    } while (0)
+
+#define LAUNCH_BWD2(ENV, A, B, PT)                                                                          \
+    do {                                                                                                    \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, A, B, true, PT>, grid, block, lds, stream, dp);  \
+        else launch_with_lds(rollout_bwd_kernel<ENV, A, B, false, PT>, grid, block, lds, stream, dp);        \
+    } while (0)
 
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
     const size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H : 0);
     int sk[2];
-    rollout_variant(p, sk);
+    rollout_variant(p, sk, true);
     const int key = sk[0] * 100 + sk[1];
     switch (p.env.kind) {
         case GOPS_ENV_NONE: LAUNCH_BWD(GOPS_ENV_NONE, 0, 0); break;
         case GOPS_ENV_LQ:
-            if (key == 116) LAUNCH_BWD(GOPS_ENV_LQ, 1, 16); else LAUNCH_BWD(GOPS_ENV_LQ, 0, 0);
+            if (key == 1616) LAUNCH_BWD(GOPS_ENV_LQ, 16, 16); else LAUNCH_BWD(GOPS_ENV_LQ, 0, 0);
             break;
         case GOPS_ENV_IDPENDULUM:
-            if (key == 116) LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 1, 16); else LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 0, 0);
+            LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 0, 0);
             break;
         case GOPS_ENV_VEH3DOFCONTI:
-            if (key == 816) LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 8, 16);
-            else if (key == 316) LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 3, 16);
+            if (key == 816) LAUNCH_BWD2(GOPS_ENV_VEH3DOFCONTI, 8, 16, 2);
             else if (key == 16) LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 0, 16);
             else LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 0, 0);
             break;

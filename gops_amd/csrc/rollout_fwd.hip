@@ -20,7 +20,7 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
                                                      const float* in, int ld_in, float* ha, float* hb,
                                                      int ldh, int tid, const float* s_bias,
                                                      float* const* stash_h, float* const* stash_z,
-                                                     size_t row0, int nvalid, DbgClock& dbg) {
+                                                     size_t row0, int nvalid, int stash_rows, DbgClock& dbg) {
     const int lane = tid & 63;
     const int L = M.nl - 1;
     const float* cur = in;
@@ -45,14 +45,14 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
                         const int m = ((lane >> 4) << 2) + r;
                         const float z = acc[q][r] + bn[q];
                         out[m * ldh + n] = act_fwd_t<ACT>(z);
-                        if (ACT == GOPS_ACT_GELU && save_z && m < nvalid) zrow[(size_t)m * N + n] = z;
+                        if (ACT == GOPS_ACT_GELU && save_z && m < nvalid) gptr(zrow)[(size_t)m * N + n] = z;
                     }
                 }
             });
         };
         bool done = false;
         if constexpr (!std::is_same<W0T, NoW>::value) {
-            if (j == 0) { gemm_layer_stat(cur, ldc, W0, nt_tot, tid, epi); done = true; }
+            if (j == 0) { gemm_layer_stat(cur, ldc, W0, nt_tot, tid, epi, kch, M.wp[0]); done = true; }
         }
         if constexpr (!std::is_same<W1T, NoW>::value) {
             if (j == 1) { gemm_layer_stat(cur, ldc, W1, nt_tot, tid, epi); done = true; }
@@ -61,7 +61,7 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
         DBG_TICK(8 + 3 * (j & 1))
         __syncthreads();
         DBG_TICK(9 + 3 * (j & 1))
-        if (stash_h != nullptr) stash_tile(out, ldh, N, stash_h[j + 1], row0, nvalid, tid);
+        if (stash_h != nullptr) stash_tile(out, ldh, N, stash_h[j + 1], row0, stash_rows, tid);
         DBG_TICK(10 + 3 * (j & 1))
         cur = out;
         ldc = ldh;
@@ -73,8 +73,9 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
 // Output layer (width A <= 4) on the VALU: thread (hm = tid>>4, hp = tid&15) strides over k.
 // Wo is [A][ldw] (an LDS copy made once per launch, or the global weight with ldw = K); the
 // result y[a] is valid in the lanes with hp == 0.
-__device__ __forceinline__ void mlp_head(const float* Wo, int ldw, const float* bo, int K, int A,
-                                         const float* hcur, int ldh, int tid, float (&y)[GOPS_MAX_ACT]) {
+template <class WP, class BP>
+__device__ __forceinline__ void mlp_head(WP Wo, int ldw, BP bo, int K, int A, const float* hcur, int ldh,
+                                         int tid, float (&y)[GOPS_MAX_ACT]) {
     const int hm = tid >> 4, hp = tid & 15;
 #pragma unroll
     for (int a = 0; a < GOPS_MAX_ACT; ++a) y[a] = 0.f;
@@ -85,7 +86,7 @@ __device__ __forceinline__ void mlp_head(const float* Wo, int ldw, const float* 
 #pragma unroll
             for (int a = 0; a < GOPS_MAX_ACT; ++a)
                 if (a < A) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(Wo + a * ldw + k);
+                    const f32x4 wv = ld4(Wo + a * ldw + k);
                     y[a] += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
                 }
         }
@@ -106,7 +107,9 @@ __device__ __forceinline__ void mlp_head(const float* Wo, int ldw, const float* 
 
 // SK0 / SK1: k-chunks (16 inputs each) of hidden layers 0 / 1 when their weights are register-
 // stationary (the layer must then be 256 wide), 0 = streamed.
-template <int ENV, int SK0, int SK1>
+// TAIL: the INFADP terminal value V_target(obs_H) is evaluated after the loop (compiled out for FHADP so
+// that its streamed-GEMM registers do not add to the pressure of the stationary variants).
+template <int ENV, int SK0, int SK1, bool TAIL>
 __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;   // parameters live in device memory: uniform scalar loads
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
     const int nvalid = min(TB, p.B - b0);
     const int O = p.env.obs_dim, A = p.env.act_dim;
     // leading dimensions are compile-time constants in the register-stationary variants
-    const int ldx = (SK0 > 0) ? 16 * SK0 + 4 : p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
+    const int ldx = p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* xs = smem;                       // [TB][ldx]  current observation (+ time column)
     float* ha = xs + TB * ldx;              // [TB][ldh]
     float* hb = ha + TB * ldh;              // [TB][ldh]
@@ -132,13 +135,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
         for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
             const int a = idx / K, k = idx - a * K;
-            s_wo[a * ldh + k] = p.pol.w[Lh][idx];
+            s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
         }
-        if (tid < Ao) s_bo[tid] = p.pol.b[Lh][tid];
+        if (tid < Ao) s_bo[tid] = gptr(p.pol.b[Lh])[tid];
         for (int j = 0; j < Lh; ++j)
-            for (int n = tid; n < p.pol.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = p.pol.b[j][n];
+            for (int n = tid; n < p.pol.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = gptr(p.pol.b[j])[n];
         if (ENV == GOPS_ENV_VEH3DOFCONTI) {
-            const f32x4* tbl = reinterpret_cast<const f32x4*>(p.ref_table) + (size_t)b0 * TL;
+            const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
             for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 s_ref[idx] = (idx < nvalid * TL) ? tbl[idx] : z;
@@ -148,18 +151,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) {
         const int m = idx / ldx, c = idx - m * ldx;
-        xs[idx] = (c < O && m < nvalid) ? p.in.obs[(size_t)(b0 + m) * O + c] : 0.f;
+        xs[idx] = (c < O && m < nvalid) ? gptr(p.in.obs)[(size_t)(b0 + m) * O + c] : 0.f;
     }
-    if (tid < TB) s_done[tid] = (tid < nvalid && p.in.done != nullptr && p.in.done[b0 + tid] != 0.f) ? 1.f : 0.f;
+    if (tid < TB) s_done[tid] = (tid < nvalid && p.in.done != nullptr && gptr(p.in.done)[b0 + tid] != 0.f) ? 1.f : 0.f;
     if (ENV == GOPS_ENV_VEH3DOFCONTI) {
         if (tid < TB * 6) {
             const int m = tid / 6, c = tid - m * 6;
-            s_state[m * 8 + c] = (m < nvalid) ? p.in.state[(size_t)(b0 + m) * 6 + c] : (c == 3 ? 1.f : 0.f);
+            s_state[m * 8 + c] = (m < nvalid) ? gptr(p.in.state)[(size_t)(b0 + m) * 6 + c] : (c == 3 ? 1.f : 0.f);
         }
     }
     typename std::conditional<(SK0 > 0), StatW<(SK0 > 0 ? SK0 : 1), 4>, NoW>::type W0;
     typename std::conditional<(SK1 > 0), StatW<(SK1 > 0 ? SK1 : 1), 4>, NoW>::type W1;
-    if constexpr (SK0 > 0) W0.load(p.pol.wp[0], p.pol.dims[1] >> 4, tid);
+    if constexpr (SK0 > 0) W0.load(p.pol.wp[0], p.pol.dims[1] >> 4, tid, p.pol.kp[0] >> 4);
     if constexpr (SK1 > 0) W1.load(p.pol.wp[1], p.pol.dims[2] >> 4, tid);
     float v_acc = 0.f;
     float veh_s = 0.f, veh_c = 1.f;   // sin/cos of the current heading, carried across steps
@@ -174,12 +177,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
         if (p.fh && tid < TB) xs[tid * ldx + O] = (float)(t + 1);
         __syncthreads();
         DBG_TICK(0)
-        const size_t row0 = (size_t)t * p.B + b0;
-        if (p.need_grad) stash_tile(xs, ldx, p.pol.kp[0], p.st.x, row0, nvalid, tid);
+        const size_t row0 = ((size_t)blockIdx.x * p.H + t) * TB;   // tile-major stash: a tile's rows are contiguous over t
+        if (p.need_grad) stash_tile(xs, ldx, p.pol.kp[0], p.st.x, row0, TB, tid);
         DBG_TICK(1)
         float* hcur = mlp_hidden_forward(p.pol, W0, W1, xs, ldx, ha, hb, ldh, tid, s_bias,
                                          p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
-                                         row0, nvalid, dbg);
+                                         row0, nvalid, TB, dbg);
         DBG_TICK(2)
         {
             float y[GOPS_MAX_ACT];
@@ -204,14 +207,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
         }
         __syncthreads();
         DBG_TICK(3)
-        if (p.need_grad && tid < nvalid) {   // env stash row: tanh outputs, done_t, state_t
-            float* er = p.st.env + (row0 + tid) * ENV_STASH;
+        if (p.need_grad && tid < TB) {   // env stash row: tanh outputs, done_t, state_t
+            GLOBAL_AS f32x4* er = gptr(reinterpret_cast<f32x4*>(p.st.env + (row0 + tid) * ENV_STASH));
             f32x4 e0 = {s_th[tid * 4 + 0], s_th[tid * 4 + 1], s_th[tid * 4 + 2], s_th[tid * 4 + 3]};
             f32x4 e1 = {s_done[tid], s_state[tid * 8 + 0], s_state[tid * 8 + 1], s_state[tid * 8 + 2]};
             f32x4 e2 = {s_state[tid * 8 + 3], s_state[tid * 8 + 4], s_state[tid * 8 + 5], 0.f};
-            reinterpret_cast<f32x4*>(er)[0] = e0;
-            reinterpret_cast<f32x4*>(er)[1] = e1;
-            reinterpret_cast<f32x4*>(er)[2] = e2;
+            er[0] = e0;
+            er[1] = e1;
+            er[2] = e2;
         }
 
         DBG_TICK(4)
@@ -311,27 +314,26 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
             float rr = (d != 0.f) ? 0.f : r;
             if (ENV != GOPS_ENV_NONE && p.env.shaping) rr = (rr + p.env.reward_shift) * p.env.reward_scale;
             v_acc += rr * p.gpow[t];
-            if (p.out.rewards != nullptr && tid < nvalid) p.out.rewards[(size_t)t * p.B + b0 + tid] = rr;
+            if (p.out.rewards != nullptr && tid < nvalid) gptr(p.out.rewards)[(size_t)t * p.B + b0 + tid] = rr;
             if (done_m) s_done[tid] = 1.f;
         }
         DBG_TICK(5)
     }
     __syncthreads();
-    if (dbg.on)
-        for (int i = 0; i < 16; ++i) p.dbg[i] = (unsigned long long)dbg.acc[i];
+    dbg.dump(p.dbg);
 
-    if (p.tail) {   // v += (~done_H) * gamma^H * V_target(obs_H)   (infadp.py:182-184, 210)
+    if (TAIL) {   // v += (~done_H) * gamma^H * V_target(obs_H)   (infadp.py:182-184, 210)
         if (p.fh && tid < TB) xs[tid * ldx + O] = 0.f;
         for (int j = 0; j < p.val.nl - 1; ++j)   // the policy biases are no longer needed
-            for (int n = tid; n < p.val.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = p.val.b[j][n];
+            for (int n = tid; n < p.val.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = gptr(p.val.b[j])[n];
         __syncthreads();
         float* hcur = mlp_hidden_forward(p.val, NoW{}, NoW{}, xs, ldx, ha, hb, ldh, tid, s_bias,
                                          p.need_grad ? p.st.tail_h : nullptr,
-                                         p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, nvalid, dbg);
+                                         p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, nvalid, nvalid, dbg);
         float y[GOPS_MAX_ACT];
         {
             const int Lv = p.val.nl - 1;
-            mlp_head(p.val.w[Lv], p.val.dims[Lv], p.val.b[Lv], p.val.dims[Lv], 1, hcur, ldh, tid, y);
+            mlp_head(gptr(p.val.w[Lv]), p.val.dims[Lv], gptr(p.val.b[Lv]), p.val.dims[Lv], 1, hcur, ldh, tid, y);
         }
         if ((tid & 15) == 0) s_th[(tid >> 4) * 4] = y[0];
         __syncthreads();
@@ -339,19 +341,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
     }
 
     if (tid < nvalid) {
-        p.out.v_pi[b0 + tid] = v_acc;
-        if (p.out.final_done != nullptr) p.out.final_done[b0 + tid] = s_done[tid];
-        if (p.need_grad && p.st.tail_done != nullptr) p.st.tail_done[b0 + tid] = s_done[tid];
+        gptr(p.out.v_pi)[b0 + tid] = v_acc;
+        if (p.out.final_done != nullptr) gptr(p.out.final_done)[b0 + tid] = s_done[tid];
+        if (p.need_grad && p.st.tail_done != nullptr) gptr(p.st.tail_done)[b0 + tid] = s_done[tid];
     }
     if (p.out.final_obs != nullptr) {
         for (int idx = tid; idx < TB * O; idx += NTHREADS) {
             const int m = idx / O, c = idx - m * O;
-            if (m < nvalid) p.out.final_obs[(size_t)(b0 + m) * O + c] = xs[m * ldx + c];
+            if (m < nvalid) gptr(p.out.final_obs)[(size_t)(b0 + m) * O + c] = xs[m * ldx + c];
         }
     }
     if (ENV == GOPS_ENV_VEH3DOFCONTI && p.out.final_state != nullptr && tid < TB * 6) {
         const int m = tid / 6, c = tid - m * 6;
-        if (m < nvalid) p.out.final_state[(size_t)(b0 + m) * 6 + c] = s_state[m * 8 + c];
+        if (m < nvalid) gptr(p.out.final_state)[(size_t)(b0 + m) * 6 + c] = s_state[m * 8 + c];
     }
 }
 
@@ -362,16 +364,25 @@ size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points) {
 
 // Picks the register-stationary variant when the policy is (kp0 in {16,48,128}) -> 256 -> 256 ...,
 // else the fully streamed kernel.  sk[0] / sk[1] receive the chosen chunk counts (0 = streamed).
-void rollout_variant(const RolloutParams& p, int sk[2]) {
+void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
     sk[0] = sk[1] = 0;
     const MlpDev& M = p.pol;
     if (M.nl - 1 < 2 || M.dims[1] != 256 || M.dims[2] != 256 || p.env.kind == GOPS_ENV_NONE || p.ldh != 260) return;
     sk[1] = 16;
     const int k0 = M.kp[0] >> 4;
     if (p.ldx == M.kp[0] + 4) {
-        if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && (k0 == 3 || k0 == 8)) sk[0] = k0;
+        // veh3dofconti: 3 chunks (P = 10) fully stationary; from 6 chunks up, the first 6 stay in
+        // registers and the rest streams (P = 30: 6 + 2, P = 50: 6 + 7)
+        if (p.env.kind == GOPS_ENV_VEH3DOFCONTI) sk[0] = (k0 == 3) ? 3 : (k0 >= 6 ? 6 : 0);
         if ((p.env.kind == GOPS_ENV_LQ || p.env.kind == GOPS_ENV_IDPENDULUM) && k0 == 1) sk[0] = 1;
     }
+    // The backward sweep's VALU phases need more than the 128 VGPRs left beside 384 weight registers:
+    // it keeps only the 256-register layer-1 fragments (all in AGPRs) and streams layer 0.
+    // Backward: sk[0] counts stationary K-chunks (of 16) of the delta_1 -> g_x GEMM.  kp0 = 128: half
+    // of them (2 n-tiles per wave); kp0 = 16 (lq): all 16 (1 tile, wave 0); anything else streams.
+    if (backward) sk[0] = (sk[1] == 16 && M.kp[0] == 128) ? 8 : ((sk[1] == 16 && M.kp[0] == 16 && p.env.kind == GOPS_ENV_LQ) ? 16 : 0);
+    // the idpendulum adjoint (5 recomputed Euler sub-steps) is even hungrier: fully streamed there
+    if (backward && p.env.kind == GOPS_ENV_IDPENDULUM) sk[0] = sk[1] = 0;
     // tuning knob (benchmarks only): GOPS_SK="0,0" forces the streamed kernels, "0,16" layer 1 only
     if (const char* e = getenv("GOPS_SK")) {
         int a = -1, b = -1;
@@ -382,14 +393,18 @@ void rollout_variant(const RolloutParams& p, int sk[2]) {
     }
 }
 
-#define LAUNCH_FWD(ENV, A, B) launch_with_lds(rollout_fwd_kernel<ENV, A, B>, grid, block, lds, stream, dp)
+#define LAUNCH_FWD(ENV, A, B)                                                                            \
+    do {                                                                                                 \
+        if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, A, B, true>, grid, block, lds, stream, dp);   \
+        else launch_with_lds(rollout_fwd_kernel<ENV, A, B, false>, grid, block, lds, stream, dp);         \
+    } while (0)
 
 // `p` is the host copy (for shape dispatch), `dp` the device copy the kernel reads.
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
     const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H : 0);
     int sk[2];
-    rollout_variant(p, sk);
+    rollout_variant(p, sk, false);
     const int key = sk[0] * 100 + sk[1];
     switch (p.env.kind) {
         case GOPS_ENV_NONE: LAUNCH_FWD(GOPS_ENV_NONE, 0, 0); break;
@@ -400,7 +415,7 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
             if (key == 116) LAUNCH_FWD(GOPS_ENV_IDPENDULUM, 1, 16); else LAUNCH_FWD(GOPS_ENV_IDPENDULUM, 0, 0);
             break;
         case GOPS_ENV_VEH3DOFCONTI:
-            if (key == 816) LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 8, 16);
+            if (key == 616) LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 6, 16);
             else if (key == 316) LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 3, 16);
             else if (key == 16) LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 0, 16);
             else LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 0, 0);

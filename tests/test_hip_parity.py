@@ -165,3 +165,85 @@ def test_fhadp_baseline_shapes_vs_reference(name, dev):
         got = gr.reshape(-1).cpu()[torch.from_numpy(g[f"grad/idx{i}"])]
         assert rel_l2(got, g[f"grad/val{i}"]) < TOL, (name, i, rel_l2(got, g[f"grad/val{i}"]))
         assert abs(gr.double().norm().item() - g["grad/norms"][i]) <= TOL * g["grad/norms"][i]
+
+
+@pytest.mark.parametrize("name", ["cfg3_veh3dof_infadp_b8192", "cfg5_lq_infadp_b65536"])
+def test_infadp_baseline_shapes_vs_reference(name, dev):
+    """INFADP at the BASELINE.json shapes (cfg3: veh3dof B=8192 MLP 256^3; cfg5: lq s4a2 B=65536):
+    PEV and PIM losses, gradient norms and sampled entries against the reference's values."""
+    from gops_amd import hip_backend as hb
+    cfg = CONFIGS[name]
+    g = load_golden("big_" + name)
+    data = make_batch(cfg, 0)
+    assert abs(data["obs"].double().sum().item() - float(g["chk/obs_sum"])) < 1e-6
+    nets = reference_init_nets(cfg, 0, obs_dim_of(cfg), act_dim_of(cfg))
+    assert abs(nets["policy"]["w"][0].double().sum().item() - float(g["chk/policy_w0_sum"])) < 1e-9
+    assert abs(nets["v_target"]["w"][0].double().sum().item() - float(g["chk/vt_w0_sum"])) < 1e-6
+    env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
+    henv = hip_env_from_oracle(env, nets["policy"])
+    ddev = to_device(data, dev)
+    B = cfg["batch"]
+    pol, pw, pb = hip_mlp_from_net(nets["policy"], dev)
+    vt, _, _ = hip_mlp_from_net(nets["v_target"], dev)
+    v, vw, vb = hip_mlp_from_net(nets["v"], dev)
+
+    def check(prefix, grads, loss, ref_loss):
+        assert abs(loss - ref_loss) <= TOL * max(1.0, abs(ref_loss)), (prefix, loss, ref_loss)
+        for i, gr in enumerate(grads):
+            got = gr.reshape(-1).cpu()[torch.from_numpy(g[f"{prefix}idx{i}"])]
+            assert rel_l2(got, g[f"{prefix}val{i}"]) < TOL, (name, prefix, i, rel_l2(got, g[f"{prefix}val{i}"]))
+            assert abs(gr.double().norm().item() - g[prefix + "norms"][i]) <= TOL * g[prefix + "norms"][i]
+
+    ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=False,
+                    need_grad=False, value=vt)
+    backup = ro.forward(ddev)["v_pi"]
+    vn = hb.ValueNet(v, B)
+    vo = vn.forward(ddev["obs"])
+    gw, gb = [torch.empty_like(w) for w in vw], [torch.empty_like(b) for b in vb]
+    vn.backward(ddev["obs"], (2.0 / B) * (vo - backup), gw, gb)
+    torch.cuda.synchronize()
+    check("pev_grad/", [t for pair in zip(gw, gb) for t in pair], ((vo - backup).double() ** 2).mean().item(),
+          float(g["pev_loss"]))
+    del ro, vn
+    ro2 = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=False,
+                     need_grad=True, value=vt)
+    res = ro2.forward(ddev)
+    gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]
+    ro2.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
+    torch.cuda.synchronize()
+    check("pim_grad/", [t for pair in zip(gw, gb) for t in pair], -res["v_pi"].double().mean().item(),
+          float(g["pim_loss"]))
+
+
+@pytest.mark.parametrize("batch", [1, 15, 17, 100])
+def test_ragged_batches_match_oracle(batch, dev):
+    """Batch sizes that do not fill the 16-trajectory tiles (edge rows masked in every kernel)."""
+    cfg = dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=batch, horizon=6, pre_horizon=10,
+               hidden=(64, 64), act="tanh", gamma=0.9)
+    data = make_batch(cfg, 11)
+    nets = reference_init_nets(cfg, 11, obs_dim_of(cfg), act_dim_of(cfg))
+    env = orc.make_env(cfg["env_id"], pre_horizon=10)
+    res, grads = _run_fhadp(env, nets, data, cfg, dev)
+    ref = orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+    assert rel_l2(res["v_pi"].cpu(), ref["v_pi"]) < TOL
+    for gr, want in zip(grads, ref["grads"]):
+        assert rel_l2(gr.cpu(), want) < TOL
+
+
+def test_horizon_one_and_all_done(dev):
+    """H = 1 and a batch whose trajectories are all done on entry (zero return, zero gradient)."""
+    cfg = dict(alg="FHADP", env_id="pyth_idpendulum", batch=32, horizon=1, hidden=(64, 64), act="relu", gamma=1.0)
+    data = make_batch(cfg, 5)
+    nets = reference_init_nets(cfg, 5, 6, 1)
+    env = orc.make_env("pyth_idpendulum")
+    res, grads = _run_fhadp(env, nets, data, cfg, dev)
+    ref = orc.fhadp_gradient(env, nets["policy"], data, 1, 1.0)
+    assert rel_l2(res["v_pi"].cpu(), ref["v_pi"]) < TOL
+    for gr, want in zip(grads, ref["grads"]):
+        assert rel_l2(gr.cpu(), want) < TOL
+    data["done"][:] = 1.0
+    cfg["horizon"] = 7
+    res, grads = _run_fhadp(env, nets, data, cfg, dev)
+    assert float(res["v_pi"].abs().max()) == 0.0
+    assert all(float(gr.abs().max()) == 0.0 for gr in grads)
+    assert np.array_equal(res["final_obs"].cpu().numpy(), data["obs"].numpy())

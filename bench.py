@@ -88,6 +88,22 @@ def cpu_baseline(cfg, seed):
                       + f"; host has {ncpu} logical CPUs"}
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC pass
+    (profiles/rNN_pmc_per_launch.json, made by tools/summarize_profile.py from separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md, both counters are KiB).  None when no profile is committed."""
+    pdir = os.path.join(ROOT, "profiles")
+    files = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_per_launch.json")) if os.path.isdir(pdir) else []
+    if not files:
+        return None
+    pmc = json.load(open(os.path.join(pdir, files[-1])))
+    for name, c in pmc.items():
+        if kernel_key in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return {"bytes": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "source": "profiles/" + files[-1]}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,7 +182,7 @@ def main():
             "rollouts_per_sec": world * B * args.steps / elapsed,
             "roofline": {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "algorithmic_flops_per_launch": flops_per_launch,
+                         "traffic": pmc_traffic(KERNEL_NAMES[dom].split("(")[0]), "algorithmic_flops_per_launch": flops_per_launch,
                          "avg_ms": dom_ms},
             "kernels_ms": {KERNEL_NAMES[k]: {"avg_ms": kern[k][0], "launches": kern[k][1],
                                              "tflops": (flops_per_launch / (kern[k][0] * 1e-3) / 1e12) if kern[k][0] > 0 else 0.0}

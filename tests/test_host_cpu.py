@@ -178,3 +178,27 @@ def test_sync_trainer_gradient_exchange_world_size_2(tmp_path):
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/gops"), reason="needs the GOPS tree (build container only)")
+def test_overlay_routes_hot_path_modules_only(tmp_path):
+    """`gops.<hot path>` -> gops_amd, the rest of GOPS untouched (run in a subprocess: it edits sys.modules)."""
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import _ref_import; _ref_import.install()            # gym / tensorboard stubs + reference on sys.path
+import gops_amd.overlay as ov; ov.install()
+from gops.create_pkg.create_alg import create_alg
+from gops.create_pkg.create_env_model import create_env_model
+import gops.algorithm.fhadp as f, gops.apprfunc.mlp as m
+assert create_alg.__module__ == "gops_amd.create_pkg.create_alg"
+assert f.FHADP.__module__ == "gops_amd.algorithm.fhadp" and m.StateValue.__module__ == "gops_amd.apprfunc.mlp"
+import gops.trainer.buffer.replay_buffer as rb, gops.utils.common_utils as cu   # still the reference's own
+assert rb.__file__.startswith("/root/reference") and cu.__file__.startswith("/root/reference")
+import numpy as np
+buf = rb.ReplayBuffer(index=0, obsv_dim=6, action_dim=1, buffer_max_size=64, seed=0, additional_info={},
+                      trainer="off_serial_trainer")
+print("overlay ok")
+""" % (ROOT, os.path.join(ROOT, "tests", "golden"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "overlay ok" in out.stdout, out.stdout + out.stderr

@@ -117,19 +117,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # (== local_rank on a node with >= N GPUs)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        # RCCL ("nccl") is the product path; GOPS_BENCH_BACKEND=gloo only exists to exercise this
+        # script's multi-rank logic on a single-GPU box (ranks then share the device)
+        backend = os.environ.get("GOPS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     cfg = CONFIGS[args.workload]
-    assert cfg["alg"] == "FHADP", "bench.py times the FHADP workloads"
     torch.manual_seed(0)   # identical random-init weights on every replica
     with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
         alg = create_alg(**alg_kwargs(cfg, 0))
     alg.networks.to(device)
+    if cfg["alg"] == "INFADP":   # cfg3 / cfg5: one step = one local_update, PEV and PIM alternate
+        alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]
     data = {k: v.to(device) for k, v in make_batch(cfg, 1000 + rank).items()}   # per-rank shard
     reducer = GradAllReducer()
 
@@ -177,7 +185,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded initial states, random-init networks)",
             "config": {"workload": args.workload, "env_id": cfg["env_id"], "algorithm": cfg["alg"],
-                       "batch_per_gpu": B, "horizon": H, "policy_mlp": [obs_dim_of(cfg) + 1] + list(cfg["hidden"]) + [act_dim_of(cfg)],
+                       "batch_per_gpu": B, "horizon": H, "policy_mlp": [obs_dim_of(cfg) + (1 if cfg["alg"] == "FHADP" else 0)] + list(cfg["hidden"]) + [act_dim_of(cfg)],
                        "activation": cfg["act"], "parallelism": f"dp{world}"},
             "rollouts_per_sec": world * B * args.steps / elapsed,
             "roofline": {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": achieved,
@@ -188,7 +196,7 @@ def main():
                                              "tflops": (flops_per_launch / (kern[k][0] * 1e-3) / 1e12) if kern[k][0] > 0 else 0.0}
                            for k in kern},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and cfg["alg"] == "FHADP":
             out["cpu_baseline"] = cpu_baseline(cfg, 0)
         print(json.dumps(out))
     if world > 1:

@@ -367,6 +367,16 @@ size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points) {
 void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
     sk[0] = sk[1] = 0;
     const MlpDev& M = p.pol;
+    // Register-stationary weights pin one workgroup per CU.  That is the right trade only while there
+    // is at most one tile per CU (B <= 16 * #CUs = 4096 on MI355X); with more tiles the streamed
+    // kernels win because 2-3 workgroups per CU overlap each other's MFMA and VALU phases.
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    if ((p.B + TB - 1) / TB > n_cu && getenv("GOPS_SK") == nullptr) return;
     if (M.nl - 1 < 2 || M.dims[1] != 256 || M.dims[2] != 256 || p.env.kind == GOPS_ENV_NONE || p.ldh != 260) return;
     sk[1] = 16;
     const int k0 = M.kp[0] >> 4;

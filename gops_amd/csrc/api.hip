@@ -166,7 +166,8 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     if (const char* tm = getenv("GOPS_TOUCH")) p.touch_mode = atoi(tm);   // tuning knob
     p.ldx = kp0 + 4;
     p.ldh = hmax + 4;
-    const int ref_pts = (e.kind == GOPS_ENV_VEH3DOFCONTI) ? e.pre_horizon + 1 + desc.horizon : 0;
+    const int ref_pts = (e.kind == GOPS_ENV_VEH3DOFCONTI) ? e.pre_horizon + 1 + desc.horizon
+                                                          : (e.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
     if (rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts) > 160 * 1024)
         return GOPS_ERR_UNSUPPORTED;
     for (int t = 0; t <= p.H; ++t) p.gpow[t] = (float)pow(desc.gamma, (double)t);

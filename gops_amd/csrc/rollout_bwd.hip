@@ -154,6 +154,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
     float* red = s_gy + TB * 4;         // [4][TB][8]
     float* s_wo = red + 4 * TB * 8;     // [4][ldh] head weights
     f32x4* s_ref = reinterpret_cast<f32x4*>(s_wo + 4 * ldh);   // veh: [TB][TL]
+    float* s_idp = reinterpret_cast<float*>(s_ref);             // idpendulum: [TB][5][24] sub-step parking
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
     const float gv = (tid < nvalid) ? gptr(p.grad_v)[b0 + tid] : 0.f;
@@ -258,28 +259,50 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
                     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { gxn[i] = dn ? 0.f : Gin[i]; gx[i] = dn ? Gin[i] : 0.f; }
                     lq_backward(p.env, x, u, gxn, g_rm, gx, gu);
                 } else {
-                    // recompute the 5 Euler sub-steps, then walk them backwards
-                    float s[6][6];
+                    // Recompute the 5 Euler sub-steps once, parking each sub-step's input state and
+                    // intermediates (M^-1, qdd, sin/cos) in LDS; then walk them backwards from there.
+                    float* park = s_idp + m * (5 * 24);
+                    float sc_[6], sn_[6];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) s[0][i] = x[i];
+                    for (int i = 0; i < 6; ++i) sc_[i] = x[i];
                     const float a = u[0], force = 500.f * a;
-                    IdpSub w;
+#pragma unroll 1
+                    for (int k = 0; k < 5; ++k) {
+                        IdpSub w;
+                        idp_substep(IC, sc_, force, 0.002f, sn_, w);
+                        float* pk = park + k * 24;
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) idp_substep(IC, s[k], force, 0.002f, s[k + 1], w);
+                        for (int i = 0; i < 6; ++i) pk[i] = sc_[i];
+                        pk[6] = w.s1; pk[7] = w.c1; pk[8] = w.s2; pk[9] = w.c2; pk[10] = w.s12; pk[11] = w.c12;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) pk[12 + i] = w.inv[i];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) pk[18 + i] = w.qdd[i];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) sc_[i] = sn_[i];
+                    }
                     float g[6];
 #pragma unroll
                     for (int i = 0; i < 6; ++i) g[i] = dn ? 0.f : Gin[i];
-                    g[1] += g_rm * (-10.f * s[5][1]);
-                    g[2] += g_rm * (-20.f * s[5][2]);
-                    g[3] += g_rm * (-1.f * s[5][3]);
-                    g[4] += g_rm * (-1.f * s[5][4]);
-                    g[5] += g_rm * (-2.f * s[5][5]);
+                    g[1] += g_rm * (-10.f * sc_[1]);
+                    g[2] += g_rm * (-20.f * sc_[2]);
+                    g[3] += g_rm * (-1.f * sc_[3]);
+                    g[4] += g_rm * (-1.f * sc_[4]);
+                    g[5] += g_rm * (-2.f * sc_[5]);
                     float gforce = 0.f;
-#pragma unroll
+#pragma unroll 1
                     for (int k = 4; k >= 0; --k) {
-                        float sn_dummy[6];
-                        idp_substep(IC, s[k], force, 0.002f, sn_dummy, w);
-                        idp_substep_bwd(IC, s[k], 0.002f, w, g, gforce);
+                        const float* pk = park + k * 24;
+                        IdpSub w;
+                        float sk[6];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) sk[i] = pk[i];
+                        w.s1 = pk[6]; w.c1 = pk[7]; w.s2 = pk[8]; w.c2 = pk[9]; w.s12 = pk[10]; w.c12 = pk[11];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) w.inv[i] = pk[12 + i];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) w.qdd[i] = pk[18 + i];
+                        idp_substep_bwd(IC, sk, 0.002f, w, g, gforce);
                     }
                     gu[0] = 500.f * gforce + g_rm * (-2.f * a);
 #pragma unroll
@@ -399,6 +422,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
     dbg.dump(p.dbg);
 }
 
+// ref_points: reference-table points per trajectory (veh3dofconti), 30 (= 5 x 24 / 4) for the
+// idpendulum sub-step parking area, else 0
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points) {
     return sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * 4 + 4 * TB * 8 + 4 * ldh + 4 * TB * ref_points);
 }
@@ -419,7 +444,8 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
 
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    const size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H : 0);
+    const size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H
+                                                             : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0));
     int sk[2];
     rollout_variant(p, sk, true);
     const int key = sk[0] * 100 + sk[1];
@@ -429,7 +455,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
             if (key == 1616) LAUNCH_BWD(GOPS_ENV_LQ, 16, 16); else LAUNCH_BWD(GOPS_ENV_LQ, 0, 0);
             break;
         case GOPS_ENV_IDPENDULUM:
-            LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 0, 0);
+            if (key == 1616) LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 16, 16); else LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 0, 0);
             break;
         case GOPS_ENV_VEH3DOFCONTI:
             if (key == 816) LAUNCH_BWD2(GOPS_ENV_VEH3DOFCONTI, 8, 16, 2);

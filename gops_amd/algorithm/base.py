@@ -95,8 +95,11 @@ def batch_to_device(data: Dict[str, torch.Tensor], device, keys) -> Dict[str, to
     from on-policy samplers are widened here, like the replay buffer does: replay_buffer.py:105)."""
     out = {}
     for k in keys:
-        if k in data and data[k] is not None:
-            out[k] = data[k].to(device=device, dtype=torch.float32, non_blocking=True).contiguous()
+        v = data.get(k)
+        if v is not None:
+            if v.dtype is not torch.float32 or v.device != device or not v.is_contiguous():
+                v = v.to(device=device, dtype=torch.float32, non_blocking=True).contiguous()
+            out[k] = v
     return out
 
 

@@ -54,8 +54,10 @@ class FHADP(AlgorithmBase):
         return ("pre_horizon", "gamma")
 
     def _local_update(self, data, iteration: int):
-        self._compute_gradient(data)
+        # queue the Adam kernel behind the backward pass BEFORE the host blocks on the loss scalar
+        loss = self._compute_gradient(data, sync=False)
         self.networks.policy_optimizer.step()
+        self._log(loss)
         return self.tb_info
 
     def get_remote_update_info(self, data, iteration: int):
@@ -82,15 +84,27 @@ class FHADP(AlgorithmBase):
             ro.set_policy(mlp)
         return ro
 
-    def _compute_gradient(self, data):
-        start_time = time.time()
+    def _log(self, loss_policy):   # loss_policy holds mean(v_pi); the loss is its negative
+        self.tb_info[tb_tags["loss_actor"]] = -loss_policy.item()   # host sync, as in the reference
+        self.tb_info[tb_tags["alg_time"]] = (time.time() - self._t0) * 1000  # ms
+
+    def _compute_gradient(self, data, sync=True):
+        self._t0 = time.time()
         device = cuda_device_of(self.networks)
         batch = batch_to_device(data, device, ("obs", "done") + _INFO_KEYS)
         B = batch["obs"].shape[0]
         ro = self._rollout_for(B, device)
         v_pi = ro.forward(batch)["v_pi"]
-        loss_policy = -v_pi.mean()
+        loss_policy = v_pi.mean()   # negated on the host when logged (saves a kernel)
         gw, gb = grad_buffers(self.networks.policy)
-        ro.backward(torch.full((B,), -1.0 / B, dtype=torch.float32, device=device), gw, gb)
-        self.tb_info[tb_tags["loss_actor"]] = loss_policy.item()   # host sync, as in the reference
-        self.tb_info[tb_tags["alg_time"]] = (time.time() - start_time) * 1000  # ms
+        ro.backward(self._grad_v(B, device), gw, gb)
+        if sync:
+            self._log(loss_policy)
+        return loss_policy
+
+    def _grad_v(self, B, device):
+        """d(-mean v_pi)/d v_pi = -1/B for every trajectory (cached: it only depends on B)."""
+        gv = getattr(self, "_gv", None)
+        if gv is None or gv.shape[0] != B or gv.device != device:
+            gv = self._gv = torch.full((B,), -1.0 / B, dtype=torch.float32, device=device)
+        return gv

@@ -29,15 +29,26 @@ class _HipMlpMixin:
     _net_attr = "pi"
 
     def linear_layers(self):
-        return [m for m in getattr(self, self._net_attr) if isinstance(m, nn.Linear)]
+        layers = getattr(self, "_linear_cache", None)
+        if layers is None:
+            layers = [m for m in getattr(self, self._net_attr) if isinstance(m, nn.Linear)]
+            object.__setattr__(self, "_linear_cache", layers)
+        return layers
 
     def hip_mlp(self):
         from gops_amd import hip_backend as hb
         if self._output_activation != "linear":
             raise RuntimeError("the HIP rollout supports a linear output activation only")
         layers = self.linear_layers()
-        return hb.make_mlp([l.weight.data for l in layers], [l.bias.data for l in layers],
-                           self._hidden_activation)
+        # the struct only holds raw pointers: rebuild it when the storage moved (.to(device), load)
+        key = tuple(l.weight.data_ptr() for l in layers) + tuple(l.bias.data_ptr() for l in layers)
+        cached = getattr(self, "_hip_mlp_cache", None)
+        if cached is None or cached[0] != key:
+            mlp = hb.make_mlp([l.weight.data for l in layers], [l.bias.data for l in layers],
+                              self._hidden_activation)
+            object.__setattr__(self, "_hip_mlp_cache", (key, mlp))
+            return mlp
+        return cached[1]
 
 
 class DetermPolicy(nn.Module, Action_Distribution, _HipMlpMixin):

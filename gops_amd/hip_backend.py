@@ -224,8 +224,9 @@ class Rollout:
         self._keep = None
 
     def set_policy(self, policy: GopsMlp, value: Optional[GopsMlp] = None):
-        self.desc.policy = policy
-        if value is not None:
+        if policy is not self._mlps[0]:
+            self.desc.policy = policy
+        if value is not None and value is not self._mlps[1]:
             self.desc.value = value
         self._mlps = (policy, value if value is not None else self._mlps[1])
 
@@ -233,11 +234,12 @@ class Rollout:
         d = self.desc
         B, H, O = d.batch, d.horizon, d.env.obs_dim
         i = self._in
-        i.obs, i.done = _ptr(data["obs"]), _ptr(data.get("done"))
-        if d.env.kind == ENV_VEH:
-            for k in ("state", "ref_points", "path_num", "u_num", "ref_time"):
-                setattr(i, k, _ptr(data[k]))
-        self._keep = data
+        if self._keep is not data:   # same batch dict object as last call: pointers already bound
+            i.obs, i.done = _ptr(data["obs"]), _ptr(data.get("done"))
+            if d.env.kind == ENV_VEH:
+                for k in ("state", "ref_points", "path_num", "u_num", "ref_time"):
+                    setattr(i, k, _ptr(data[k]))
+            self._keep = data
         out = GopsRolloutOut()
         res = {"v_pi": torch.empty(B, dtype=torch.float32, device=self.device)}
         out.v_pi = _ptr(res["v_pi"])

@@ -212,18 +212,26 @@ __global__ __launch_bounds__(NTHREADS) void dw_gemm_kernel(const float* __restri
         }
         const float* dbase = Ds + (lane >> 4) * LD + wn * 16 * R + (lane & 15);
         const float* xbase = Xs + (lane >> 4) * LD + wk * 16 * R + (lane & 15);
+        // fragment loads run one k-step ahead of the MFMAs that consume them (LDS latency hidden)
+        float a[2][R], b[2][R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) { a[0][i] = dbase[16 * i]; b[0][i] = xbase[16 * i]; }
 #pragma unroll
         for (int kk = 0; kk < DW_SC / 4; ++kk) {
-            float a[R], b[R];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < DW_SC / 4) {
 #pragma unroll
-            for (int i = 0; i < R; ++i) a[i] = dbase[kk * 4 * LD + 16 * i];
-#pragma unroll
-            for (int j = 0; j < R; ++j) b[j] = xbase[kk * 4 * LD + 16 * j];
+                for (int i = 0; i < R; ++i) {
+                    a[nxt][i] = dbase[(kk + 1) * 4 * LD + 16 * i];
+                    b[nxt][i] = xbase[(kk + 1) * 4 * LD + 16 * i];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs (hipcc would sink it to its use)
 #pragma unroll
             for (int i = 0; i < R; ++i)
 #pragma unroll
                 for (int j = 0; j < R; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
         }
     }
     float* pbase = part + (size_t)split * N * Kp;

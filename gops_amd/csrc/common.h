@@ -321,14 +321,19 @@ __device__ __forceinline__ void gemm_layer_stat(const float* A, int lda, const S
     f32x4 acc[NT] = {};
     StreamB<NT> sb;
     if (kch_total > KCH) sb.prime(Wp, kch_total, nt0, lane, KCH);   // fetched behind the stationary MFMAs
+    f32x4 a_cur = *reinterpret_cast<const f32x4*>(arow);
 #pragma unroll
     for (int c = 0; c < KCH; ++c) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * c);
+        // the next chunk's A fragment is fetched from LDS while this chunk's MFMAs run
+        f32x4 a_nxt = a_cur;
+        if (c + 1 < KCH) a_nxt = *reinterpret_cast<const f32x4*>(arow + 16 * (c + 1));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], W.w[c * NT + j][i], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], W.w[c * NT + j][i], acc[j], 0, 0, 0);
+        a_cur = a_nxt;
     }
     if (kch_total > KCH) sb.run(A, lda, kch_total, lane, acc, KCH);
     f32x4 out[4] = {};

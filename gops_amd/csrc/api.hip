@@ -15,8 +15,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
 size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points);
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points);
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s);
-hipError_t launch_pack(const float* W, int N, int K, int Kp, float* wp, float* wpt, hipStream_t s);
-hipError_t launch_ref_table(int B, int P, int H, const GopsRolloutIn& in, float pdt, float* table, hipStream_t s);
+hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s);
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
                           int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s);
 hipError_t launch_dw_out(const float* dy, const float* h, int K, int A, long long S, int splits,
@@ -24,6 +23,8 @@ hipError_t launch_dw_out(const float* dy, const float* h, int K, int A, long lon
 void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, int cols, int ld, float* out);
 hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s);
 hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s);
+hipError_t launch_adam(const GopsAdamTensors& T, float step_size, float omb1, float beta2, float omb2,
+                       float bc2_sqrt, float eps, hipStream_t s);
 
 namespace {
 
@@ -211,16 +212,6 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     return GOPS_OK;
 }
 
-int pack_all(const MlpDev& d, hipStream_t s) {
-    for (int j = 0; j < d.nl - 1; ++j) {
-        hipError_t e = launch_pack(d.w[j], d.dims[j + 1], d.dims[j], d.kp[j],
-                                   const_cast<float*>(reinterpret_cast<const float*>(d.wp[j])),
-                                   const_cast<float*>(reinterpret_cast<const float*>(d.wpt[j])), s);
-        if (e != hipSuccess) return (int)e;
-    }
-    return GOPS_OK;
-}
-
 float pdt_of(const GopsEnv& e) { return (float)((double)e.pre_horizon * 0.1); }
 
 int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const GopsRolloutOut& out,
@@ -235,22 +226,17 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
     RolloutParams& p = plan.p;
     p.in = in;
     p.out = out;
-    if ((rc = pack_all(p.pol, s)) != GOPS_OK) return rc;
-    if (p.tail && (rc = pack_all(p.val, s)) != GOPS_OK) return rc;
-    if (desc.env.kind == GOPS_ENV_VEH3DOFCONTI) {
-        hipError_t e = launch_ref_table(p.B, desc.env.pre_horizon, p.H, in, pdt_of(desc.env),
-                                        const_cast<float*>(p.ref_table), s);
-        if (e != hipSuccess) return (int)e;
-    }
     static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
     const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
     if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
     p.dbg = dbg ? dbg_buf : nullptr;
+    // parameter block upload + weight packing + reference table: one launch
+    hipError_t ue = launch_prologue(p, plan.dev_params, desc.env.pre_horizon, pdt_of(desc.env), s);
+    if (ue != hipSuccess) return (int)ue;
     int ret;
     {
         ProfScope scope(0, s);
-        hipError_t ue = launch_upload_params(p, plan.dev_params, s);
-        ret = (ue != hipSuccess) ? (int)ue : (int)launch_rollout_fwd(p, plan.dev_params, s);
+        ret = (int)launch_rollout_fwd(p, plan.dev_params, s);
     }
     if (dbg) {
         unsigned long long h[16];
@@ -280,9 +266,9 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
     if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
     p.dbg = dbg ? dbg_buf : nullptr;
+    if ((e = launch_upload_params(p, plan.dev_params, s)) != hipSuccess) return (int)e;
     {
         ProfScope scope(1, s);
-        if ((e = launch_upload_params(p, plan.dev_params, s)) != hipSuccess) return (int)e;
         if ((e = launch_rollout_bwd(p, plan.dev_params, s)) != hipSuccess) return (int)e;
     }
     if (dbg) {
@@ -398,6 +384,18 @@ int gops_value_backward(const GopsMlp* value, int32_t batch, const float* obs, c
     memset(&in, 0, sizeof(in));
     in.obs = obs;
     return run_backward(d, in, grad_v, *grad, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int gops_adam_step(const GopsAdamTensors* tensors, double lr, double beta1, double beta2, double eps,
+                   int64_t step, void* stream) {
+    if (!tensors || tensors->n < 1 || tensors->n > GOPS_ADAM_MAX_TENSORS || step < 1) return GOPS_ERR_BAD_ARG;
+    for (int i = 0; i < tensors->n; ++i)
+        if (!tensors->param[i] || !tensors->grad[i] || !tensors->exp_avg[i] || !tensors->exp_avg_sq[i] ||
+            tensors->numel[i] < 1) return GOPS_ERR_BAD_ARG;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    return (int)launch_adam(*tensors, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                            (float)sqrt(bc2), (float)eps,
+                            static_cast<hipStream_t>(stream));
 }
 
 void gops_profile_enable(int32_t on) {

@@ -11,9 +11,8 @@
 // (zero where the input index is in the padding), so that lane `lane` fetches with one dwordx4 the
 // B operands of four consecutive v_mfma_f32_16x16x4_f32.
 // ---------------------------------------------------------------------------------------------
-__global__ void pack_weights_kernel(const float* __restrict__ W, int N, int K, int Kp,
-                                    float* __restrict__ wp, float* __restrict__ wpt) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_element(const float* __restrict__ W, int N, int K, int Kp,
+                                             float* __restrict__ wp, float* __restrict__ wpt, int e) {
     if (e >= N * Kp) return;
     const int i = e & 3, lane = (e >> 2) & 63, blk = e >> 8;
     {   // forward: n tiles over N, chunks over Kp
@@ -28,11 +27,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, int N, int K, i
     }
 }
 
-hipError_t launch_pack(const float* W, int N, int K, int Kp, float* wp, float* wpt, hipStream_t s) {
-    const int total = N * Kp;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, W, N, K, Kp, wp, wpt);
-    return hipGetLastError();
-}
 
 // Copies the by-value parameter block into device memory (stream ordered, no host staging): the
 // rollout kernels then read it with uniform scalar loads instead of a per-lane scratch copy.
@@ -112,11 +106,12 @@ __device__ __forceinline__ f32x4 ref_point(float t, int path, int u_num) {
 
 // table[b][i] : i <= P copies info["ref_points"][b][i]; i = P + s (s >= 1) is the point the model
 // appends at rollout step s-1: evaluated at (t0 + s*dt accumulated in fp32) + P*dt.
-__global__ void ref_table_kernel(int B, int P, int H, const float* __restrict__ ref_points,
-                                 const float* __restrict__ path_num, const float* __restrict__ u_num,
-                                 const float* __restrict__ ref_time, float pdt, float* __restrict__ table) {
+__device__ __forceinline__ void ref_table_element(int B, int P, int H, const float* __restrict__ ref_points,
+                                                  const float* __restrict__ path_num,
+                                                  const float* __restrict__ u_num,
+                                                  const float* __restrict__ ref_time, float pdt,
+                                                  float* __restrict__ table, int idx) {
     const int TL = P + 1 + H;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * TL) return;
     const int b = idx / TL, i = idx - b * TL;
     f32x4 v;
@@ -134,11 +129,47 @@ __global__ void ref_table_kernel(int B, int P, int H, const float* __restrict__ 
     reinterpret_cast<f32x4*>(table)[idx] = v;
 }
 
-hipError_t launch_ref_table(int B, int P, int H, const GopsRolloutIn& in, float pdt, float* table,
-                            hipStream_t s) {
-    const int total = B * (P + 1 + H);
-    hipLaunchKernelGGL(ref_table_kernel, dim3((total + 255) / 256), dim3(256), 0, s, B, P, H,
-                       in.ref_points, in.path_num, in.u_num, in.ref_time, pdt, table);
+// ---------------------------------------------------------------------------------------------
+// Forward prologue, ONE launch: block 0 uploads the parameter block, the next blocks pack the
+// hidden-layer weights of the policy (and of the tail value net), the rest fill the reference table.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int pack_blocks(const MlpDev& d) {
+    int nb = 0;
+    for (int j = 0; j < d.nl - 1; ++j) nb += (d.dims[j + 1] * d.kp[j] + 255) / 256;
+    return nb;
+}
+
+__global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, RolloutParams* dst, int P, float pdt) {
+    int b = blockIdx.x;
+    if (b == 0) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(&p);
+        unsigned* d = reinterpret_cast<unsigned*>(dst);
+        for (unsigned i = threadIdx.x; i < sizeof(RolloutParams) / 4; i += blockDim.x) d[i] = src[i];
+        return;
+    }
+    b -= 1;
+    for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
+        const MlpDev& d = m ? p.val : p.pol;
+        for (int j = 0; j < d.nl - 1; ++j) {
+            const int nb = (d.dims[j + 1] * d.kp[j] + 255) / 256;
+            if (b < nb) {
+                pack_element(d.w[j], d.dims[j + 1], d.dims[j], d.kp[j],
+                             const_cast<float*>(reinterpret_cast<const float*>(d.wp[j])),
+                             const_cast<float*>(reinterpret_cast<const float*>(d.wpt[j])), b * 256 + threadIdx.x);
+                return;
+            }
+            b -= nb;
+        }
+    }
+    if (p.env.kind == GOPS_ENV_VEH3DOFCONTI)
+        ref_table_element(p.B, P, p.H, p.in.ref_points, p.in.path_num, p.in.u_num, p.in.ref_time, pdt,
+                          const_cast<float*>(p.ref_table), b * 256 + threadIdx.x);
+}
+
+hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s) {
+    int nb = 1 + pack_blocks(p.pol) + (p.tail ? pack_blocks(p.val) : 0);
+    if (p.env.kind == GOPS_ENV_VEH3DOFCONTI) nb += (p.B * (P + 1 + p.H) + 255) / 256;
+    hipLaunchKernelGGL(prologue_kernel, dim3(nb), dim3(256), 0, s, p, dst, P, pdt);
     return hipGetLastError();
 }
 
@@ -357,6 +388,38 @@ void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, 
 hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s) {
     if (jobs.n == 0) return hipSuccess;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(jobs.block0[jobs.n]), dim3(256), 0, s, jobs);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam over a table of tensors, one launch.  Same update as torch.optim.Adam (foreach path):
+//   m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(const GopsAdamTensors T, float step_size, float omb1,
+                                                   float beta2, float omb2, float bc2_sqrt, float eps) {
+    const int t = blockIdx.y;
+    const long long n = T.numel[t];
+    float* __restrict__ p = T.param[t];
+    const float* __restrict__ g = T.grad[t];
+    float* __restrict__ m = T.exp_avg[t];
+    float* __restrict__ v = T.exp_avg_sq[t];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * omb1;   // omb = 1 - beta, formed in double by the host
+        const float vi = v[i] * beta2 + omb2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+
+hipError_t launch_adam(const GopsAdamTensors& T, float step_size, float omb1, float beta2, float omb2,
+                       float bc2_sqrt, float eps, hipStream_t s) {
+    long long nmax = 1;
+    for (int i = 0; i < T.n; ++i) nmax = T.numel[i] > nmax ? T.numel[i] : nmax;
+    int bx = (int)((nmax + 255) / 256);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(adam_kernel, dim3(bx, T.n), dim3(256), 0, s, T, step_size, omb1, beta2, omb2, bc2_sqrt, eps);
     return hipGetLastError();
 }
 

@@ -58,6 +58,15 @@ class GopsRolloutOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("v_pi", "rewards", "final_obs", "final_done", "final_state")]
 
 
+ADAM_MAX = 16
+
+
+class GopsAdamTensors(C.Structure):
+    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("numel", C.c_int64 * ADAM_MAX),
+                ("param", C.c_void_p * ADAM_MAX), ("grad", C.c_void_p * ADAM_MAX),
+                ("exp_avg", C.c_void_p * ADAM_MAX), ("exp_avg_sq", C.c_void_p * ADAM_MAX)]
+
+
 class GopsStepIO(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "action", "done", "state", "ref_points", "path_num",
                                           "u_num", "ref_time", "next_obs", "reward", "next_done",
@@ -95,6 +104,9 @@ def lib() -> C.CDLL:
         l.gops_value_backward.restype = C.c_int
         l.gops_value_backward.argtypes = [C.POINTER(GopsMlp), C.c_int32, C.c_void_p, C.c_void_p,
                                           C.POINTER(GopsMlpGrad), C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gops_adam_step.restype = C.c_int
+        l.gops_adam_step.argtypes = [C.POINTER(GopsAdamTensors), C.c_double, C.c_double, C.c_double, C.c_double,
+                                     C.c_int64, C.c_void_p]
         l.gops_profile_enable.argtypes = [C.c_int32]
         l.gops_profile_reset.argtypes = []
         l.gops_profile_read.restype = C.c_int
@@ -105,7 +117,7 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = ("gops_hip_version", "gops_rollout_workspace_bytes", "gops_rollout_forward",
                     "gops_rollout_backward", "gops_env_step", "gops_value_workspace_bytes",
-                    "gops_value_forward", "gops_value_backward", "gops_profile_enable",
+                    "gops_value_forward", "gops_value_backward", "gops_adam_step", "gops_profile_enable",
                     "gops_profile_reset", "gops_profile_read")
 
 _ERR = {-1: "GOPS_ERR_BAD_ARG", -2: "GOPS_ERR_UNSUPPORTED", -3: "GOPS_ERR_WORKSPACE"}
@@ -306,6 +318,47 @@ def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Ten
         io.next_ref_time = _ptr(ninfo["ref_time"])
     check(lib().gops_env_step(C.byref(env), B, C.byref(io), _stream()), "gops_env_step")
     return nobs, rew, ndone, ninfo
+
+
+class HipAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (default hyper-parameters' semantics) whose `step()` is ONE HIP launch over all
+    parameters (`gops_adam_step`).  Same `param_groups` / `state` layout as torch's Adam (`step`,
+    `exp_avg`, `exp_avg_sq`), so lr schedulers and optimizer checkpoints are interchangeable.
+    Parameters must be fp32 CUDA tensors when `step()` is called."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            steps = set()
+            for p in ps:
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                elif st["exp_avg"].device != p.device:   # parameters were moved after the state was made
+                    st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].to(p.device), st["exp_avg_sq"].to(p.device)
+                st["step"] = int(st["step"]) + 1
+                steps.add(st["step"])
+            assert len(steps) == 1, "parameters of one group must share the step count"
+            step = steps.pop()
+            for i0 in range(0, len(ps), ADAM_MAX):
+                chunk = ps[i0:i0 + ADAM_MAX]
+                t = GopsAdamTensors()
+                t.n = len(chunk)
+                for i, p in enumerate(chunk):
+                    st = self.state[p]
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    t.numel[i], t.param[i], t.grad[i] = p.numel(), _ptr(p.data), _ptr(g)
+                    t.exp_avg[i], t.exp_avg_sq[i] = _ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"])
+                b1, b2 = group["betas"]
+                check(lib().gops_adam_step(C.byref(t), float(group["lr"]), b1, b2, group["eps"], step, _stream()), "gops_adam_step")
 
 
 def profile_enable(on: bool):

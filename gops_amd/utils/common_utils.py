@@ -49,12 +49,10 @@ def get_apprfunc_dict(key: str, **kwargs):
 
 
 def make_adam(params, lr: float):
-    """torch.optim.Adam with the reference's defaults (gops/algorithm/fhadp.py:45-47), as ONE fused
-    kernel per step on the GPU instead of the foreach implementation's seven launches."""
-    try:
-        return torch.optim.Adam(params, lr=lr, fused=True)
-    except (RuntimeError, TypeError):   # torch build without the fused kernel for these tensors
-        return torch.optim.Adam(params, lr=lr)
+    """Adam with the reference's defaults (gops/algorithm/fhadp.py:45-47): one HIP launch per step
+    (`gops_adam_step`) instead of torch's multi-kernel foreach implementation."""
+    from gops_amd.hip_backend import HipAdam
+    return HipAdam(params, lr=lr)
 
 
 def seed_everything(seed: Optional[int] = None) -> int:

@@ -160,6 +160,23 @@ int gops_value_backward(const GopsMlp* value, int32_t batch, const float* obs, c
                         const GopsMlpGrad* grad, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* One Adam step (torch.optim.Adam defaults semantics: no weight decay, no amsgrad) over up to
+ * GOPS_ADAM_MAX_TENSORS parameter tensors in ONE launch - replaces `self.networks.policy_optimizer.step()`
+ * (gops/algorithm/fhadp.py:89, gops/algorithm/infadp.py:124).  `step` is the 1-based step count used
+ * for the bias corrections; exp_avg / exp_avg_sq are updated in place. */
+#define GOPS_ADAM_MAX_TENSORS 16
+typedef struct GopsAdamTensors {
+    int32_t n;
+    int32_t reserved;
+    int64_t numel[GOPS_ADAM_MAX_TENSORS];
+    float* param[GOPS_ADAM_MAX_TENSORS];
+    const float* grad[GOPS_ADAM_MAX_TENSORS];
+    float* exp_avg[GOPS_ADAM_MAX_TENSORS];
+    float* exp_avg_sq[GOPS_ADAM_MAX_TENSORS];
+} GopsAdamTensors;
+int gops_adam_step(const GopsAdamTensors* tensors, double lr, double beta1, double beta2, double eps,
+                   int64_t step, void* stream);
+
 /* Timing hook for bench.py: average duration in ms of the named internal kernel over the
  * launches recorded since the last reset (HIP events on the launch stream).  kernel ids:
  * 0 = forward rollout, 1 = backward sweep, 2 = weight-gradient GEMMs. */

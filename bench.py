@@ -156,14 +156,21 @@ def main():
 
     for it in range(args.warmup):
         step(it)
-    hb.profile_reset()
-    hb.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):
         step(args.warmup + it)
     barrier()
     elapsed = time.perf_counter() - t0
+    # Per-kernel durations (roofline): HIP events around each launch on the launch stream.  Events
+    # cannot be read back from inside a replayed graph, so the same steps are issued once more as
+    # plain launches (same kernels, same batch, same stream) right after the timed region.
+    os.environ["GOPS_HIP_GRAPH"] = "0"
+    hb.profile_reset()
+    hb.profile_enable(True)
+    for it in range(min(args.steps, 100)):
+        step(args.warmup + args.steps + it)
+    barrier()
     hb.profile_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)

@@ -17,6 +17,7 @@ from gops_amd.utils.common_utils import make_adam
 from gops_amd import hip_backend as hb
 from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, batch_to_device, cuda_device_of,
                                      grad_buffers)
+from gops_amd.utils.hip_graph import StepGraphCache
 from gops_amd.create_pkg.create_apprfunc import create_apprfunc
 from gops_amd.create_pkg.create_env_model import create_env_model
 from gops_amd.utils.common_utils import get_apprfunc_dict
@@ -48,20 +49,36 @@ class FHADP(AlgorithmBase):
         self.gamma = gamma
         self.tb_info = dict()
         self._rollouts = {}
+        self._update_graph, self._grad_graph = StepGraphCache(), StepGraphCache()
 
     @property
     def adjustable_parameters(self) -> Tuple[str]:
         return ("pre_horizon", "gamma")
 
     def _local_update(self, data, iteration: int):
-        # queue the Adam kernel behind the backward pass BEFORE the host blocks on the loss scalar
-        loss = self._compute_gradient(data, sync=False)
-        self.networks.policy_optimizer.step()
+        # gradient + Adam as one captured HIP graph (eager for the first calls, see utils/hip_graph.py); the
+        # Adam kernel is queued behind the backward pass BEFORE the host blocks on the loss scalar
+        self._t0 = time.time()
+        batch = self._device_batch(data)
+        opt = self.networks.policy_optimizer
+
+        def update(b):
+            loss = self._gradient_kernels(b)
+            opt.step()
+            return loss
+
+        loss = self._update_graph.run(self._signature(batch), batch, update,
+                                      before_replay=opt.sync_hyper, on_replay=opt.advance,
+                                      work=batch["obs"].shape[0] * self.pre_horizon)
         self._log(loss)
         return self.tb_info
 
     def get_remote_update_info(self, data, iteration: int):
-        self._compute_gradient(data)
+        self._t0 = time.time()
+        batch = self._device_batch(data)
+        loss = self._grad_graph.run(self._signature(batch), batch, self._gradient_kernels,
+                                   work=batch["obs"].shape[0] * self.pre_horizon)
+        self._log(loss)
         return self.tb_info, {"grad": [p._grad for p in self.networks.policy.parameters()]}
 
     def _remote_update(self, update_info):
@@ -88,16 +105,28 @@ class FHADP(AlgorithmBase):
         self.tb_info[tb_tags["loss_actor"]] = -loss_policy.item()   # host sync, as in the reference
         self.tb_info[tb_tags["alg_time"]] = (time.time() - self._t0) * 1000  # ms
 
-    def _compute_gradient(self, data, sync=True):
-        self._t0 = time.time()
-        device = cuda_device_of(self.networks)
-        batch = batch_to_device(data, device, ("obs", "done") + _INFO_KEYS)
-        B = batch["obs"].shape[0]
+    def _device_batch(self, data):
+        return batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
+
+    def _signature(self, batch):
+        """What a captured graph is specialised on: shapes, rollout settings, parameter / gradient storage."""
+        return (tuple((k, tuple(v.shape)) for k, v in batch.items()), self.pre_horizon, float(self.gamma),
+                tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr())
+                      for p in self.networks.policy.parameters()))
+
+    def _gradient_kernels(self, batch):
+        """Enqueue forward rollout, loss and backward sweep; returns mean(v_pi) (device scalar)."""
+        B, device = batch["obs"].shape[0], batch["obs"].device
         ro = self._rollout_for(B, device)
         v_pi = ro.forward(batch)["v_pi"]
         loss_policy = v_pi.mean()   # negated on the host when logged (saves a kernel)
         gw, gb = grad_buffers(self.networks.policy)
         ro.backward(self._grad_v(B, device), gw, gb)
+        return loss_policy
+
+    def _compute_gradient(self, data, sync=True):
+        self._t0 = time.time()
+        loss_policy = self._gradient_kernels(self._device_batch(data))
         if sync:
             self._log(loss_policy)
         return loss_policy

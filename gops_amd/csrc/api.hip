@@ -23,8 +23,8 @@ hipError_t launch_dw_out(const float* dy, const float* h, int K, int A, long lon
 void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, int cols, int ld, float* out);
 hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s);
 hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s);
-hipError_t launch_adam(const GopsAdamTensors& T, float step_size, float omb1, float beta2, float omb2,
-                       float bc2_sqrt, float eps, hipStream_t s);
+hipError_t launch_adam(const GopsAdamTensors& T, GopsAdamState* st, double beta1, double beta2, float eps,
+                       hipStream_t s);
 
 namespace {
 
@@ -386,16 +386,13 @@ int gops_value_backward(const GopsMlp* value, int32_t batch, const float* obs, c
     return run_backward(d, in, grad_v, *grad, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
-int gops_adam_step(const GopsAdamTensors* tensors, double lr, double beta1, double beta2, double eps,
-                   int64_t step, void* stream) {
-    if (!tensors || tensors->n < 1 || tensors->n > GOPS_ADAM_MAX_TENSORS || step < 1) return GOPS_ERR_BAD_ARG;
+int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, double beta1, double beta2,
+                   double eps, void* stream) {
+    if (!tensors || !state_dev || tensors->n < 1 || tensors->n > GOPS_ADAM_MAX_TENSORS) return GOPS_ERR_BAD_ARG;
     for (int i = 0; i < tensors->n; ++i)
         if (!tensors->param[i] || !tensors->grad[i] || !tensors->exp_avg[i] || !tensors->exp_avg_sq[i] ||
             tensors->numel[i] < 1) return GOPS_ERR_BAD_ARG;
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    return (int)launch_adam(*tensors, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                            (float)sqrt(bc2), (float)eps,
-                            static_cast<hipStream_t>(stream));
+    return (int)launch_adam(*tensors, state_dev, beta1, beta2, (float)eps, static_cast<hipStream_t>(stream));
 }
 
 void gops_profile_enable(int32_t on) {

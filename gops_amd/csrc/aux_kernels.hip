@@ -394,32 +394,50 @@ hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // Adam over a table of tensors, one launch.  Same update as torch.optim.Adam (foreach path):
 //   m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// lr and the step count are read from device memory (graph-replayable); the scalar factors are
+// formed in double like torch's host code, then rounded to fp32.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adam_kernel(const GopsAdamTensors T, float step_size, float omb1,
-                                                   float beta2, float omb2, float bc2_sqrt, float eps) {
-    const int t = blockIdx.y;
-    const long long n = T.numel[t];
-    float* __restrict__ p = T.param[t];
-    const float* __restrict__ g = T.grad[t];
-    float* __restrict__ m = T.exp_avg[t];
-    float* __restrict__ v = T.exp_avg_sq[t];
+__global__ __launch_bounds__(256) void adam_kernel(const GopsAdamTensors T, GopsAdamState* st, double beta1,
+                                                   double beta2, float eps) {
+    const double b1p = st->beta1_pow * beta1, b2p = st->beta2_pow * beta2;   // beta^t, t = step + 1
+    const float step_size = (float)(st->lr / (1.0 - b1p)), bc2_sqrt = (float)sqrt(1.0 - b2p);
+    const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2), b2 = (float)beta2;
+    const int ti = blockIdx.y;
+    const long long n = T.numel[ti];
+    float* __restrict__ p = T.param[ti];
+    const float* __restrict__ g = T.grad[ti];
+    float* __restrict__ m = T.exp_avg[ti];
+    float* __restrict__ v = T.exp_avg_sq[ti];
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i];
-        const float mi = m[i] + (gi - m[i]) * omb1;   // omb = 1 - beta, formed in double by the host
-        const float vi = v[i] * beta2 + omb2 * gi * gi;
+        const float mi = m[i] + (gi - m[i]) * omb1;
+        const float vi = v[i] * b2 + omb2 * gi * gi;
         m[i] = mi;
         v[i] = vi;
         p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
     }
+    // every block has read st->step before it takes a ticket; the last one publishes step + 1
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned total = gridDim.x * gridDim.y;
+        if (atomicAdd(&st->ticket, 1u) == total - 1) {
+            st->ticket = 0;
+            st->step += 1;
+            st->beta1_pow = b1p;
+            st->beta2_pow = b2p;
+            __threadfence();
+        }
+    }
 }
 
-hipError_t launch_adam(const GopsAdamTensors& T, float step_size, float omb1, float beta2, float omb2,
-                       float bc2_sqrt, float eps, hipStream_t s) {
+hipError_t launch_adam(const GopsAdamTensors& T, GopsAdamState* st, double beta1, double beta2, float eps,
+                       hipStream_t s) {
     long long nmax = 1;
     for (int i = 0; i < T.n; ++i) nmax = T.numel[i] > nmax ? T.numel[i] : nmax;
     int bx = (int)((nmax + 255) / 256);
-    if (bx > 256) bx = 256;
-    hipLaunchKernelGGL(adam_kernel, dim3(bx, T.n), dim3(256), 0, s, T, step_size, omb1, beta2, omb2, bc2_sqrt, eps);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(adam_kernel, dim3(bx, T.n), dim3(256), 0, s, T, st, beta1, beta2, eps);
     return hipGetLastError();
 }
 

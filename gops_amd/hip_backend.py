@@ -105,8 +105,8 @@ def lib() -> C.CDLL:
         l.gops_value_backward.argtypes = [C.POINTER(GopsMlp), C.c_int32, C.c_void_p, C.c_void_p,
                                           C.POINTER(GopsMlpGrad), C.c_void_p, C.c_size_t, C.c_void_p]
         l.gops_adam_step.restype = C.c_int
-        l.gops_adam_step.argtypes = [C.POINTER(GopsAdamTensors), C.c_double, C.c_double, C.c_double, C.c_double,
-                                     C.c_int64, C.c_void_p]
+        l.gops_adam_step.argtypes = [C.POINTER(GopsAdamTensors), C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                     C.c_void_p]
         l.gops_profile_enable.argtypes = [C.c_int32]
         l.gops_profile_reset.argtypes = []
         l.gops_profile_read.restype = C.c_int
@@ -322,43 +322,100 @@ def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Ten
 
 class HipAdam(torch.optim.Optimizer):
     """torch.optim.Adam (default hyper-parameters' semantics) whose `step()` is ONE HIP launch over all
-    parameters (`gops_adam_step`).  Same `param_groups` / `state` layout as torch's Adam (`step`,
-    `exp_avg`, `exp_avg_sq`), so lr schedulers and optimizer checkpoints are interchangeable.
-    Parameters must be fp32 CUDA tensors when `step()` is called."""
+    parameters of a group (`gops_adam_step`).  Same `param_groups` / `state` layout as torch's Adam
+    (`step`, `exp_avg`, `exp_avg_sq`), so lr schedulers and optimizer checkpoints are interchangeable.
+    The learning rate and step count the kernel uses live in device memory, which makes `step()`
+    capturable in a HIP graph: a graph owner calls `sync_hyper()` before and `advance()` after each
+    replay.  Parameters must be fp32 CUDA tensors when `step()` is called."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._dev = {}   # group index -> {"state": GopsAdamState device tensors (5 x 8 bytes) per chunk, "lr", "step"}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._dev = {}   # device mirrors are rebuilt from the loaded host state
+
+    def _prepare(self, gi, group):
+        ps = [p for p in group["params"] if p.grad is not None]
+        if not ps:
+            return None, None
+        steps = set()
+        for p in ps:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p)
+                st["exp_avg_sq"] = torch.zeros_like(p)
+            elif st["exp_avg"].device != p.device:   # parameters were moved after the state was made
+                st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].to(p.device), st["exp_avg_sq"].to(p.device)
+            steps.add(int(st["step"]))
+        assert len(steps) == 1, "parameters of one group must share the step count"
+        step = steps.pop()
+        nchunk = (len(ps) + ADAM_MAX - 1) // ADAM_MAX
+        dev = self._dev.get(gi)
+        if dev is None or len(dev["state"]) != nchunk or dev["state"][0].device != ps[0].device:
+            dev = self._dev[gi] = {"state": [torch.zeros(5, dtype=torch.int64, device=ps[0].device)
+                                             for _ in range(nchunk)], "lr": None, "step": None}
+        if dev["step"] != step:       # first use, after load_state_dict, or an external edit of state
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("HipAdam: device step count out of date while capturing a graph")
+            b1, b2 = group["betas"]
+            for t in dev["state"]:   # GopsAdamState: lr, step, beta1^step, beta2^step, ticket
+                t[1] = step
+                t.view(torch.float64)[2] = float(b1) ** step
+                t.view(torch.float64)[3] = float(b2) ** step
+                t[4] = 0
+            dev["step"] = step
+        self._sync_lr(dev, group)
+        return ps, dev
+
+    @staticmethod
+    def _sync_lr(dev, group):
+        lr = float(group["lr"])
+        if dev["lr"] != lr:
+            for t in dev["state"]:
+                t.view(torch.float64)[0] = lr
+            dev["lr"] = lr
+
+    def sync_hyper(self):
+        """Push a changed `lr` (schedulers) to the device copies; call before replaying a graph."""
+        for gi, group in enumerate(self.param_groups):
+            if gi in self._dev:
+                self._sync_lr(self._dev[gi], group)
+
+    def advance(self, n: int = 1):
+        """Account for `n` graph replays of `step()` in the host-side step counters."""
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p in self.state and len(self.state[p]):
+                    self.state[p]["step"] = int(self.state[p]["step"]) + n
+            if gi in self._dev and self._dev[gi]["step"] is not None:
+                self._dev[gi]["step"] += n
 
     @torch.no_grad()
     def step(self, closure=None):
-        for group in self.param_groups:
-            ps = [p for p in group["params"] if p.grad is not None]
-            if not ps:
+        for gi, group in enumerate(self.param_groups):
+            ps, dev = self._prepare(gi, group)
+            if ps is None:
                 continue
-            steps = set()
-            for p in ps:
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p)
-                    st["exp_avg_sq"] = torch.zeros_like(p)
-                elif st["exp_avg"].device != p.device:   # parameters were moved after the state was made
-                    st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].to(p.device), st["exp_avg_sq"].to(p.device)
-                st["step"] = int(st["step"]) + 1
-                steps.add(st["step"])
-            assert len(steps) == 1, "parameters of one group must share the step count"
-            step = steps.pop()
-            for i0 in range(0, len(ps), ADAM_MAX):
+            b1, b2 = group["betas"]
+            for ci, i0 in enumerate(range(0, len(ps), ADAM_MAX)):
                 chunk = ps[i0:i0 + ADAM_MAX]
                 t = GopsAdamTensors()
                 t.n = len(chunk)
+                keep = []
                 for i, p in enumerate(chunk):
                     st = self.state[p]
                     g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    keep.append(g)
                     t.numel[i], t.param[i], t.grad[i] = p.numel(), _ptr(p.data), _ptr(g)
                     t.exp_avg[i], t.exp_avg_sq[i] = _ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"])
-                b1, b2 = group["betas"]
-                check(lib().gops_adam_step(C.byref(t), float(group["lr"]), b1, b2, group["eps"], step, _stream()), "gops_adam_step")
+                check(lib().gops_adam_step(C.byref(t), dev["state"][ci].data_ptr(), b1, b2, group["eps"], _stream()),
+                      "gops_adam_step")
+            for p in ps:
+                self.state[p]["step"] = int(self.state[p]["step"]) + 1
+            dev["step"] += 1
 
 
 def profile_enable(on: bool):

@@ -36,8 +36,7 @@ class GradAllReducer:
         flat = _flatten_dense_tensors(tensors)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.div_(n)
-        for dst, src in zip(tensors, _unflatten_dense_tensors(flat, tensors)):
-            dst.copy_(src)
+        torch._foreach_copy_(tensors, list(_unflatten_dense_tensors(flat, tensors)))
         return update_info
 
     def mean_scalar(self, value: float, device) -> float:

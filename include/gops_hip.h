@@ -162,8 +162,11 @@ int gops_value_backward(const GopsMlp* value, int32_t batch, const float* obs, c
 
 /* One Adam step (torch.optim.Adam defaults semantics: no weight decay, no amsgrad) over up to
  * GOPS_ADAM_MAX_TENSORS parameter tensors in ONE launch - replaces `self.networks.policy_optimizer.step()`
- * (gops/algorithm/fhadp.py:89, gops/algorithm/infadp.py:124).  `step` is the 1-based step count used
- * for the bias corrections; exp_avg / exp_avg_sq are updated in place. */
+ * (gops/algorithm/fhadp.py:89, gops/algorithm/infadp.py:124).  The learning rate and the step count
+ * live in DEVICE memory (`GopsAdamState`, caller-owned; initialise step = updates done so far,
+ * beta1_pow = beta1^step, beta2_pow = beta2^step, ticket = 0): the kernel uses t = step + 1 for the
+ * bias corrections and its last block stores the advanced state, so the call can be captured in a
+ * HIP graph and replayed.  exp_avg / exp_avg_sq are updated in place. */
 #define GOPS_ADAM_MAX_TENSORS 16
 typedef struct GopsAdamTensors {
     int32_t n;
@@ -174,8 +177,15 @@ typedef struct GopsAdamTensors {
     float* exp_avg[GOPS_ADAM_MAX_TENSORS];
     float* exp_avg_sq[GOPS_ADAM_MAX_TENSORS];
 } GopsAdamTensors;
-int gops_adam_step(const GopsAdamTensors* tensors, double lr, double beta1, double beta2, double eps,
-                   int64_t step, void* stream);
+typedef struct GopsAdamState {   /* 40 bytes of device memory */
+    double lr;
+    int64_t step;
+    double beta1_pow, beta2_pow;
+    uint32_t ticket;
+    uint32_t reserved;
+} GopsAdamState;
+int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, double beta1, double beta2,
+                   double eps, void* stream);
 
 /* Timing hook for bench.py: average duration in ms of the named internal kernel over the
  * launches recorded since the last reset (HIP events on the launch stream).  kernel ids:

@@ -57,7 +57,7 @@ def mac_per_step(cfg):
     return sum(a * b for a, b in zip(sizes[:-1], sizes[1:]))
 
 
-def cpu_baseline(cfg, seed):
+def cpu_baseline(cfg, seed, eager_gpu=False):
     """The oracle (CPU restatement of the reference, pinned to its fixtures) timed on the host
     cores of this box.  Checker only: nothing it computes is used by the GPU path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -80,7 +80,28 @@ def cpu_baseline(cfg, seed):
         results[nthreads] = min(times[1:])
     best_threads = min(results, key=results.get)
     best = results[best_threads]
-    return {"value": cfg["batch"] * cfg["horizon"] / best, "unit": "env-model steps/s",
+    eager = None
+    if eager_gpu:   # the same restatement as plain PyTorch-ROCm eager ops on the GPU ("no-kernel" baseline)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        src = nets["policy"]
+        pol = dict(src, w=[w.detach().to(dev).requires_grad_(True) for w in src["w"]],
+                   b=[b.detach().to(dev).requires_grad_(True) for b in src["b"]],
+                   act_high=src["act_high"].to(dev), act_low=src["act_low"].to(dev))
+        ddata = {k: v.to(dev) for k, v in data.items()}
+        def on_dev(x):
+            if torch.is_tensor(x):
+                return x.to(dev)
+            return {k: on_dev(v) for k, v in x.items()} if isinstance(x, dict) else x
+        denv = on_dev(env)
+        times = []
+        for i in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            orc.fhadp_gradient(denv, pol, ddata, cfg["horizon"], cfg["gamma"])
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        eager = cfg["batch"] * cfg["horizon"] / min(times[1:])
+    return {"eager_gpu_steps_per_s": eager, "value": cfg["batch"] * cfg["horizon"] / best, "unit": "env-model steps/s",
             "cores": best_threads, "kind": "port",
             "sample": f"full workload batch (B={cfg['batch']}, H={cfg['horizon']}); per thread count 1 warm-up + 2 "
                       f"timed compute_gradient calls (fwd+bwd), best call; "
@@ -111,6 +132,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="target_veh3dof_fhadp_b4096_h30")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager-gpu-baseline", action="store_true",
+                    help="also time the oracle restatement as PyTorch eager ops on the GPU (reported inside cpu_baseline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -204,7 +227,7 @@ def main():
                            for k in kern},
         }
         if world == 1 and not args.no_cpu_baseline and cfg["alg"] == "FHADP":
-            out["cpu_baseline"] = cpu_baseline(cfg, 0)
+            out["cpu_baseline"] = cpu_baseline(cfg, 0, args.eager_gpu_baseline)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -79,6 +79,16 @@ def sample_idx(n, k, seed):
     return np.random.RandomState(seed).choice(n, size=min(k, n), replace=False)
 
 
+def model_consts(model):
+    """Constants the reference derives at construction with LAPACK (`torch.linalg.pinv` in fp32,
+    lq_base.py:55-57): their last bits depend on the host CPU, so the fixtures carry the values the
+    recorded outputs were computed with."""
+    dyn = getattr(model.unwrapped, "dynamics", None)
+    if dyn is not None and hasattr(dyn, "inv_IA"):
+        return {"const/lq_inv_IA": dyn.inv_IA.detach().numpy().copy()}
+    return {}
+
+
 def save(name, **arrays):
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
@@ -128,6 +138,7 @@ def golden_steps():
                 out[f"s{s}/state"] = info["state"].numpy().copy()
                 out[f"s{s}/ref_last"] = info["ref_points"][:, -1].numpy().copy()
         out["meta/nsteps"] = nsteps
+        out.update(model_consts(model))
         out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra=extra))
         save(name, **out)
 
@@ -183,6 +194,7 @@ def golden_small():
         data["done"][-3:] = 1.0  # already-done rows in the batch
         out = {"in/" + k: v.numpy().copy() for k, v in data.items()}
         out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra=extra, seed=seed))
+        out.update(model_consts(alg.envmodel))
         if cfg["alg"] == "FHADP":
             out.update(sd_to_np(alg.networks.state_dict()))
             alg._compute_gradient(data)
@@ -214,6 +226,7 @@ def golden_big():
         alg = build_alg(cfg, seed)
         data = make_batch(cfg, seed)
         out = {"chk/obs_sum": data["obs"].double().sum().item()}
+        out.update(model_consts(alg.envmodel))
         params0 = [p.detach().clone() for p in alg.networks.policy.parameters()]
         out["chk/policy_w0_sum"] = params0[0].double().sum().item()
         out["chk/policy_wlast_sum"] = params0[-2].double().sum().item()
@@ -242,8 +255,65 @@ def golden_big():
         save("big_" + name, **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 4. the reference's shipped TRAINED checkpoints (results/<ALG>/<run>/apprfunc/*.pkl): saturating
+#    policies, long horizons, non-unit action limits - same arrays as the small cases.
+# ------------------------------------------------------------------------------------------
+REF_ROOT = "/root/reference"
+TRAINED = {
+    "fhadp_trained_idp_h80": ("FHADP/idpendulum", "apprfunc_54000_opt.pkl", dict(batch=96)),
+    "fhadp_trained_lqs3a1_h80": ("FHADP/lqs3a1", "apprfunc_5400_opt.pkl", dict(batch=80)),
+    "infadp_trained_lqs4a2": ("INFADP/lqs4a2_mlp", "apprfunc_6000.pkl", dict(batch=128, horizon=10)),
+    "infadp_trained_idp": ("INFADP/idpendulum", "apprfunc_90000_opt.pkl", dict(batch=96, horizon=10)),
+}
+
+
+def golden_trained():
+    for name, (run, ckpt, over) in TRAINED.items():
+        rc = json.load(open(os.path.join(REF_ROOT, "results", run, "config.json")))
+        cfg = dict(alg=rc["algorithm"], env_id=rc["env_id"], hidden=tuple(rc["policy_hidden_sizes"]),
+                   act=rc["policy_hidden_activation"], batch=over["batch"],
+                   horizon=over.get("horizon", rc.get("pre_horizon")),
+                   gamma=1.0 if rc["algorithm"] == "FHADP" else 0.99)
+        if "lq_config" in rc:
+            cfg["lq_config"] = rc["lq_config"]
+        if rc["algorithm"] == "FHADP":
+            cfg["pre_horizon"] = rc["pre_horizon"]
+        extra = {k: rc[k] for k in ("reward_scale", "reward_shift") if rc.get(k) is not None}
+        lim = dict(action_high_limit=np.array(rc["action_high_limit"], dtype=np.float32),
+                   action_low_limit=np.array(rc["action_low_limit"], dtype=np.float32))
+        seed = zlib.crc32(name.encode()) % 1000
+        alg = build_alg(cfg, seed, **extra, **lim)
+        sd = torch.load(os.path.join(REF_ROOT, "results", run, "apprfunc", ckpt), map_location="cpu")
+        alg.networks.load_state_dict(sd)
+        data = make_batch(cfg, seed)
+        data["done"][-2:] = 1.0
+        out = {"in/" + k: v.numpy().copy() for k, v in data.items()}
+        out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra=extra, seed=seed, checkpoint=f"results/{run}/apprfunc/{ckpt}"))
+        out.update(sd_to_np(alg.networks.state_dict()))
+        out.update(model_consts(alg.envmodel))
+        if cfg["alg"] == "FHADP":
+            alg._compute_gradient(data)
+            for i, gr in enumerate(grads_of(alg.networks.policy)):
+                out[f"grad/{i}"] = gr.numpy()
+            out["loss"] = alg.tb_info["Loss/Actor loss-RL iter"]
+        else:
+            _, info = alg.get_remote_update_info(data, 0)  # PEV
+            for i, gr in enumerate(info["v"]):
+                out[f"pev_grad/{i}"] = gr.detach().numpy().copy()
+            out["pev_loss"] = alg.tb_info["Loss/Critic loss-RL iter"]
+            out["pev_vmean"] = alg.tb_info["Train/Critic avg value-RL iter"]
+            _, info = alg.get_remote_update_info(data, 1)  # PIM
+            for i, gr in enumerate(info["policy"]):
+                out[f"pim_grad/{i}"] = gr.detach().numpy().copy()
+            out["pim_loss"] = alg.tb_info["Loss/Actor loss-RL iter"]
+        save(name, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained"]
+    if "trained" in which:
+        golden_trained()
     if "steps" in which:
         golden_steps()
     if "small" in which:

@@ -7,10 +7,16 @@ from oracle import adp_oracle as orc
 INFO_KEYS = ("state", "ref_points", "path_num", "u_num", "ref_time")
 
 
-def oracle_env(cfg, extra):
-    return orc.make_env(cfg["env_id"], lq_config=cfg.get("lq_config", "s4a2"),
-                        pre_horizon=cfg.get("pre_horizon", 10),
-                        reward_scale=extra.get("reward_scale"), reward_shift=extra.get("reward_shift"))
+def oracle_env(cfg, extra, golden=None):
+    """Oracle env for a fixture's config.  `golden`: the fixture - constants the reference derived
+    with LAPACK when the fixture was recorded (fp32 `pinv`, whose last bits are host dependent and
+    get amplified by long unstable LQ horizons) are taken from it instead of being recomputed."""
+    env = orc.make_env(cfg["env_id"], lq_config=cfg.get("lq_config", "s4a2"),
+                       pre_horizon=cfg.get("pre_horizon", 10),
+                       reward_scale=extra.get("reward_scale"), reward_shift=extra.get("reward_shift"))
+    if golden is not None and "const/lq_inv_IA" in golden:
+        env["lq"]["inv_IA"] = torch.from_numpy(np.array(golden["const/lq_inv_IA"]))
+    return env
 
 
 def data_from_golden(g, prefix="in/"):
@@ -91,3 +97,41 @@ def hip_mlp_from_net(net, device):
 
 def to_device(data, device):
     return {k: v.to(device).contiguous() for k, v in data.items()}
+
+
+def as_f64(x):
+    """Deep copy of an oracle env / net / data structure in float64."""
+    if torch.is_tensor(x):
+        return x.detach().double() if x.is_floating_point() else x
+    if isinstance(x, dict):
+        return {k: as_f64(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [as_f64(v) for v in x]
+    return x
+
+
+def fhadp_gradient_f64(env, net, data, horizon, gamma):
+    """The oracle's FHADP gradient evaluated in float64: the value both fp32 evaluations (the
+    reference's and the HIP path's) approximate.  Used to size the fp32 noise floor of a case."""
+    n64 = as_f64(net)
+    n64["w"] = [w.requires_grad_(True) for w in n64["w"]]
+    n64["b"] = [b.requires_grad_(True) for b in n64["b"]]
+    return orc.fhadp_gradient(as_f64(env), n64, as_f64(data), horizon, gamma)
+
+
+def fp32_noise_floor(env, net, data, horizon, gamma, ref64_flat, trials=8):
+    """How far fp32 evaluations of one FHADP gradient scatter around its float64 value: the oracle
+    (fp32) is re-run with every weight moved by at most one ulp; returns the largest rel-L2 distance
+    to `ref64_flat` (1e-7-ish for well-conditioned cases, up to 5e-4 for the trained LQ H=80 case,
+    whose clipped, unstable closed loop amplifies last-bit differences)."""
+    gen = torch.Generator().manual_seed(0)
+    worst = 0.0
+    for _ in range(trials):
+        pert = dict(net)
+        pert["w"] = [(w.detach() * (1 + (torch.rand(w.shape, generator=gen) - 0.5) * 1.2e-7)).requires_grad_(True)
+                     for w in net["w"]]
+        pert["b"] = [b.detach().clone().requires_grad_(True) for b in net["b"]]
+        grads = orc.fhadp_gradient(env, pert, data, horizon, gamma)["grads"]
+        flat = torch.cat([x.reshape(-1) for x in grads]).double()
+        worst = max(worst, float((flat - ref64_flat).norm() / ref64_flat.norm()))
+    return worst

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from conftest import golden_meta, load_golden, rel_l2
-from helpers import (INFO_KEYS, data_from_golden, hip_env_from_oracle, hip_mlp_from_net, nets_from_golden,
+from helpers import (fhadp_gradient_f64, fp32_noise_floor, INFO_KEYS, data_from_golden, hip_env_from_oracle, hip_mlp_from_net, nets_from_golden,
                      oracle_env, reference_init_nets, to_device)
 from oracle import adp_oracle as orc
 
@@ -18,8 +18,11 @@ TOL = 1e-4
 STEP_CASES = ["step_lq_s4a2", "step_lq_s6a3", "step_lq_s2a1_shaped", "step_idp", "step_veh_p10",
               "step_veh_p30"]
 FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fhadp_idp_selu_shaped",
-               "fhadp_veh_p10_elu", "fhadp_veh_p30_sigmoid"]
-INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu"]
+               "fhadp_veh_p10_elu", "fhadp_veh_p30_sigmoid",
+               # the reference's shipped trained checkpoints (saturating policies, H = 80, limits != +-1)
+               "fhadp_trained_idp_h80", "fhadp_trained_lqs3a1_h80"]
+INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu",
+                "infadp_trained_lqs4a2", "infadp_trained_idp"]
 
 
 @pytest.fixture(scope="module")
@@ -33,7 +36,7 @@ def test_env_step_vs_reference_fixture(name, dev):
     from gops_amd import hip_backend as hb
     g = load_golden(name)
     meta = golden_meta(g)
-    env = hip_env_from_oracle(oracle_env(meta["cfg"], meta["extra"]))
+    env = hip_env_from_oracle(oracle_env(meta["cfg"], meta["extra"], g))
     data = to_device(data_from_golden(g), dev)
     obs, done = data["obs"], data["done"]
     info = {k: data[k] for k in INFO_KEYS if k in data}
@@ -79,7 +82,7 @@ def test_fhadp_vs_reference_fixture(name, dev):
     g = load_golden(name)
     meta = golden_meta(g)
     cfg = meta["cfg"]
-    env = oracle_env(cfg, meta["extra"])
+    env = oracle_env(cfg, meta["extra"], g)
     nets, _ = nets_from_golden(g, cfg)
     data = data_from_golden(g)
     res, grads = _run_fhadp(env, nets, data, cfg, dev)
@@ -90,11 +93,27 @@ def test_fhadp_vs_reference_fixture(name, dev):
     assert np.array_equal(res["final_done"].cpu().numpy() != 0, ref["final_done"].numpy())
     loss = -res["v_pi"].double().mean().item()
     assert abs(loss - float(g["loss"])) <= TOL * max(1.0, abs(float(g["loss"])))
-    for i, gr in enumerate(grads):
-        assert rel_l2(gr.cpu(), g[f"grad/{i}"]) < TOL, (name, i, rel_l2(gr.cpu(), g[f"grad/{i}"]))
+    # Gradients: 1e-4 against the reference's fp32 output, per parameter and over the flat vector.
+    # One fixture (trained LQ policy, H = 80: clipped, unstable closed loop) is so ill-conditioned that
+    # fp32 evaluations of the SAME function scatter by more than that - moving every weight by one ulp
+    # moves the reference's own gradient by up to 4e-4.  There the bar is the float64 value: the HIP
+    # result must lie within 4x the scatter of fp32 oracle evaluations around it (one trajectory of that
+    # batch carries nearly all of the error: |dL/dtheta| = 1.7e6 for a return of -5.9e3; on it the
+    # reference's fp32 gradient is itself 0.3 % off the float64 value).
     flat = torch.cat([x.reshape(-1).cpu() for x in grads])
     flat_ref = torch.cat([torch.from_numpy(g[f"grad/{i}"]).reshape(-1) for i in range(len(grads))])
-    assert rel_l2(flat, flat_ref) < TOL
+    err = rel_l2(flat, flat_ref)
+    worst = max(rel_l2(gr.cpu(), g[f"grad/{i}"]) for i, gr in enumerate(grads))
+    if worst >= TOL:
+        ref64 = fhadp_gradient_f64(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])["grads"]
+        flat64 = torch.cat([x.reshape(-1) for x in ref64])
+        floor = fp32_noise_floor(env, nets["policy"], data, cfg["horizon"], cfg["gamma"], flat64)
+        err64 = rel_l2(flat.double(), flat64)
+        print(f"{name}: ill-conditioned; rel-L2 to float64: HIP {err64:.2e}, reference fp32 "
+              f"{rel_l2(flat_ref.double(), flat64):.2e}, fp32 scatter (1-ulp weight moves) {floor:.2e}")
+        assert floor > TOL / 3 and err64 <= 4.0 * floor, (name, err, err64, floor)
+    else:
+        assert err < TOL, (name, err)
 
 
 @pytest.mark.parametrize("name", INFADP_CASES)
@@ -103,7 +122,7 @@ def test_infadp_vs_reference_fixture(name, dev):
     g = load_golden(name)
     meta = golden_meta(g)
     cfg = meta["cfg"]
-    env = oracle_env(cfg, meta["extra"])
+    env = oracle_env(cfg, meta["extra"], g)
     nets, _ = nets_from_golden(g, cfg)
     data = data_from_golden(g)
     ddev = to_device(data, dev)
@@ -179,7 +198,7 @@ def test_infadp_baseline_shapes_vs_reference(name, dev):
     nets = reference_init_nets(cfg, 0, obs_dim_of(cfg), act_dim_of(cfg))
     assert abs(nets["policy"]["w"][0].double().sum().item() - float(g["chk/policy_w0_sum"])) < 1e-9
     assert abs(nets["v_target"]["w"][0].double().sum().item() - float(g["chk/vt_w0_sum"])) < 1e-6
-    env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
+    env = oracle_env(cfg, {}, g)
     henv = hip_env_from_oracle(env, nets["policy"])
     ddev = to_device(data, dev)
     B = cfg["batch"]

@@ -12,15 +12,18 @@ from gops_amd.utils.synthetic import CONFIGS, act_dim_of, make_batch, obs_dim_of
 STEP_CASES = ["step_lq_s4a2", "step_lq_s6a3", "step_lq_s2a1_shaped", "step_idp", "step_veh_p10",
               "step_veh_p30"]
 FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fhadp_idp_selu_shaped",
-               "fhadp_veh_p10_elu", "fhadp_veh_p30_sigmoid"]
-INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu"]
+               "fhadp_veh_p10_elu", "fhadp_veh_p30_sigmoid",
+               # the reference's shipped trained checkpoints (saturating policies, H = 80, limits != +-1)
+               "fhadp_trained_idp_h80", "fhadp_trained_lqs3a1_h80"]
+INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu",
+                "infadp_trained_lqs4a2", "infadp_trained_idp"]
 
 
 @pytest.mark.parametrize("name", STEP_CASES)
 def test_env_step_matches_reference(name):
     g = load_golden(name)
     meta = golden_meta(g)
-    env = oracle_env(meta["cfg"], meta["extra"])
+    env = oracle_env(meta["cfg"], meta["extra"], g)
     data = data_from_golden(g)
     obs, done = data["obs"], data["done"]
     info = {k: data[k] for k in INFO_KEYS if k in data}
@@ -42,7 +45,7 @@ def test_fhadp_gradient_matches_reference(name):
     g = load_golden(name)
     meta = golden_meta(g)
     cfg = meta["cfg"]
-    env = oracle_env(cfg, meta["extra"])
+    env = oracle_env(cfg, meta["extra"], g)
     nets, _ = nets_from_golden(g, cfg)
     data = data_from_golden(g)
     out = orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
@@ -56,7 +59,7 @@ def test_infadp_gradients_match_reference(name):
     g = load_golden(name)
     meta = golden_meta(g)
     cfg = meta["cfg"]
-    env = oracle_env(cfg, meta["extra"])
+    env = oracle_env(cfg, meta["extra"], g)
     nets, _ = nets_from_golden(g, cfg)
     data = data_from_golden(g)
     pev = orc.infadp_pev_gradient(env, nets["policy"], nets["v"], nets["v_target"], data,

@@ -280,9 +280,191 @@ __global__ __launch_bounds__(NTHREADS) void dw_gemm_kernel(const float* __restri
     if (part_b != nullptr && tile_k == 0 && tid < T && n0 + tid < N) part_b[(size_t)split * N + n0 + tid] = bsum;
 }
 
+// ---------------------------------------------------------------------------------------------
+// dW GEMM on the bf16 matrix cores with fp32 results ("bf16x3"): every fp32 operand a is split
+// EXACTLY into three bf16 planes a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1),
+// a3 = bf16(a - a1 - a2): 3 x 8 significant bits cover the 24 of fp32) and the product a*b is
+// accumulated in fp32 from the six plane products a1b1, a1b2, a2b1, a1b3, a2b2, a3b1; the three
+// dropped ones are below 2^-25 |ab|, i.e. under fp32 rounding.  v_mfma_f32_16x16x32_bf16 runs ~15x
+// the fp32 MFMA rate, so six of them are ~2.5x faster than the fp32 instruction for the same 32-deep
+// block and the GEMM becomes HBM-bound (it reads each stash tile once).
+//
+// Tile 128 x 128 outputs per workgroup, 2 x 2 waves of 64 x 64.  The contraction runs over samples,
+// which are the ROWS of both operands in memory, so the staging transposes: a thread loads 4 rows x
+// 4 columns (dwordx4, coalesced), splits, and writes plane fragments [g = s/8][col][8 samples] with
+// ds_write_b64; a lane's MFMA fragment (8 consecutive samples of one column) is then one ds_read_b128.
+// The 16-byte units are XOR-swizzled over the column index so that both directions are conflict-free.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (__bf16)lo;   // v_cvt_pk_bf16_f32: round to nearest even
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// (a, b) -> three packed bf16 pairs; a == sum of the low halves, b == sum of the high halves, exactly.
+__device__ __forceinline__ void split3(float a, float b, unsigned (&pl)[3]) {
+    pl[0] = pack_bf16(a, b);
+    const float ra = a - __uint_as_float(pl[0] << 16), rb = b - __uint_as_float(pl[0] & 0xffff0000u);
+    pl[1] = pack_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(pl[1] << 16), sb = rb - __uint_as_float(pl[1] & 0xffff0000u);
+    pl[2] = pack_bf16(sa, sb);
+}
+
+#define DWB_T 128                      // tile edge
+#define DWB_PLANE (4 * DWB_T * 8)      // halfs per plane: [4 g][128 cols][8 samples]
+
+#ifdef GOPS_DBG_BUILD
+#define GT(i) { if (tid == 0 && blockIdx.x == 0) { long long now = clock64(); tacc[i] += now - tlast; tlast = now; } }
+#else
+#define GT(i)
+#endif
+
+__global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_bf16x3_kernel(const float* __restrict__ D, int N,
+                                                                      const float* __restrict__ X, int Kp,
+                                                                      long long S, int splits, int chunks_per_split,
+                                                                      float* __restrict__ part,
+                                                                      float* __restrict__ part_b) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[3 * DWB_PLANE];   // D^T planes
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[3 * DWB_PLANE];   // X planes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_k = (Kp + DWB_T - 1) / DWB_T, tiles = tiles_k * ((N + DWB_T - 1) / DWB_T);
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;   // same XCD-aware order as dw_gemm_kernel
+    const int tile = local % tiles, split = (local / tiles) * 8 + xcd;
+    if (split >= splits) return;
+    const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
+    const int n0 = tile_n * DWB_T, k0 = tile_k * DWB_T;
+    const long long s_begin = (long long)split * chunks_per_split * DW_SC;
+    const int wn = wave >> 1, wk = wave & 1;
+#ifdef GOPS_DBG_BUILD
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
+
+    // Staging item of this thread: columns 4*c4 .. 4*c4+3, samples 4*s4 .. 4*s4+3 of the chunk.  Lane
+    // bits -> (s4 bit 0, c4 bits 0, 2, 3, 1, 4): the 16 lanes of a ds_write_b64 group then hit 16
+    // distinct 8-byte slots mod 128 B (conflict-free), and one load instruction still covers two full
+    // 512-byte rows.
+    const int c4 = ((lane >> 1) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 2) & 3) << 2) | ((lane >> 5) << 4);
+    const int s4 = (lane & 1) | (wave << 1);
+    int wofs[4];   // LDS half-offset of column 4*c4 + i: 16-byte unit index swizzled with column bits 4..5
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = 4 * c4 + i, nsw = n ^ ((n >> 4) & 3);
+        wofs[i] = (((s4 >> 1) * DWB_T + nsw) << 3) + ((s4 & 1) << 2);
+    }
+    const bool want_bias = part_b != nullptr && tile_k == 0;
+
+    f32x4 acc[4][4] = {};
+    f32x4 dreg[4], xreg[4];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    auto gload = [&](long long s0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long srow = s0 + 4 * s4 + r;
+            const int n = n0 + 4 * c4, k = k0 + 4 * c4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            dreg[r] = (srow < S && n < N) ? *reinterpret_cast<const f32x4*>(D + srow * N + n) : z;
+            xreg[r] = (srow < S && k < Kp) ? *reinterpret_cast<const f32x4*>(X + srow * Kp + k) : z;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned p01[3], p23[3];
+            split3(dreg[0][i], dreg[1][i], p01);
+            split3(dreg[2][i], dreg[3][i], p23);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<uint2*>(As + pl * DWB_PLANE + wofs[i]) = make_uint2(p01[pl], p23[pl]);
+            split3(xreg[0][i], xreg[1][i], p01);
+            split3(xreg[2][i], xreg[3][i], p23);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<uint2*>(Bs + pl * DWB_PLANE + wofs[i]) = make_uint2(p01[pl], p23[pl]);
+            if (want_bias) bsum[i] += (dreg[0][i] + dreg[1][i]) + (dreg[2][i] + dreg[3][i]);
+        }
+    };
+    // fragment (8 consecutive samples of tile-local column `col`) of this lane: g = lane >> 4
+    auto frag = [&](const __bf16* base, int pl, int col) {
+        const int nsw = col ^ ((col >> 4) & 3);
+        return *reinterpret_cast<const bf16x8*>(base + pl * DWB_PLANE + ((((lane >> 4) * DWB_T) + nsw) << 3));
+    };
+
+    gload(s_begin);
+    for (int c = 0; c < chunks_per_split; ++c) {
+        GT(0)
+        __syncthreads();
+        GT(1)
+        lstore();
+        GT(2)
+        __syncthreads();
+        GT(3)
+        if (c + 1 < chunks_per_split) gload(s_begin + (long long)(c + 1) * DW_SC);
+        bf16x8 b[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[j][pl] = frag(Bs, pl, wk * 64 + 16 * j + (lane & 15));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = frag(As, pl, wn * 64 + 16 * i + (lane & 15));
+            // six plane products, smallest terms first; consecutive MFMAs go to different accumulators
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+        }
+        GT(4)
+    }
+#ifdef GOPS_DBG_BUILD
+    if (tid == 0 && blockIdx.x == 0)
+        printf("[dw dbg] per chunk: loop-top->sync1 %lld | sync1 %lld | lstore(+load wait) %lld | sync2 %lld | frags+mfma %lld  (chunks %d)\n",
+               tacc[0] / chunks_per_split, tacc[1] / chunks_per_split, tacc[2] / chunks_per_split,
+               tacc[3] / chunks_per_split, tacc[4] / chunks_per_split, chunks_per_split);
+#endif
+    float* pbase = part + (size_t)split * N * Kp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + wk * 64 + 16 * j + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + 16 * i + 4 * (lane >> 4) + r;
+                if (n < N && k < Kp) pbase[(size_t)n * Kp + k] = acc[i][j][r];
+            }
+        }
+    if (want_bias) {   // column sums of D: 8 sample groups per column, combined in a fixed order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(As);   // [8][128]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[s4 * DWB_T + 4 * c4 + i] = bsum[i];
+        __syncthreads();
+        if (tid < DWB_T && n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += red[q * DWB_T + tid];
+            part_b[(size_t)split * N + n0 + tid] = t;
+        }
+    }
+}
+
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
                           int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s) {
-    if (big) {
+    static const bool force_f32 = getenv("GOPS_DW_F32") != nullptr;   // A/B knob: fp32 MFMA GEMM
+    if (big && !force_f32 && (N & 3) == 0 && (Kp & 3) == 0) {
+        const int T = DWB_T, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
+        hipLaunchKernelGGL(dw_gemm_bf16x3_kernel, dim3(tiles * ((splits + 7) / 8) * 8), dim3(NTHREADS), 0, s, D, N, X,
+                           Kp, S, splits, chunks_per_split, part, part_b);
+    } else if (big) {
         const int T = 128, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
         hipLaunchKernelGGL(dw_gemm_kernel<4>, dim3(tiles * ((splits + 7) / 8) * 8), dim3(NTHREADS), 0, s, D, N, X, Kp, S,
                            splits, chunks_per_split, part, part_b);

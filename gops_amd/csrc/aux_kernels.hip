@@ -598,17 +598,16 @@ __global__ __launch_bounds__(256) void adam_kernel(const GopsAdamTensors T, Gops
         v[i] = vi;
         p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
     }
-    // every block has read st->step before it takes a ticket; the last one publishes step + 1
+    // Every block has read the state (its values feed the arithmetic above) before it takes a ticket;
+    // the last one publishes the advanced state.  No fence: the next reader is a later kernel.
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
         const unsigned total = gridDim.x * gridDim.y;
         if (atomicAdd(&st->ticket, 1u) == total - 1) {
             st->ticket = 0;
             st->step += 1;
             st->beta1_pow = b1p;
             st->beta2_pow = b2p;
-            __threadfence();
         }
     }
 }
@@ -617,7 +616,7 @@ hipError_t launch_adam(const GopsAdamTensors& T, GopsAdamState* st, double beta1
                        hipStream_t s) {
     long long nmax = 1;
     for (int i = 0; i < T.n; ++i) nmax = T.numel[i] > nmax ? T.numel[i] : nmax;
-    int bx = (int)((nmax + 255) / 256);
+    int bx = (int)((nmax + 1023) / 1024);   // >= 4 elements per thread of the largest tensor
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(adam_kernel, dim3(bx, T.n), dim3(256), 0, s, T, st, beta1, beta2, eps);
     return hipGetLastError();

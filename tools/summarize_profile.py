@@ -26,7 +26,18 @@ for d in sorted(os.listdir(src)):
     for k, v in agg.items():
         if any(x in k for x in ("rollout", "dw_gemm", "dw_out", "reduce_partials")):
             pmc.setdefault(k, {}).update({c: sum(x) / len(x) for c, x in v.items()})
-json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_per_launch.json"), "w"), indent=1)
+# A pass that timed out on the box (FETCH_SIZE / WRITE_SIZE did in the second r01 collection) leaves
+# its counters missing: kernels that have not changed since the previous committed collection keep
+# those values, flagged by "carried_over".
+prev_path = os.path.join(dst, f"{tag}_pmc_per_launch.json")
+if os.path.exists(prev_path):
+    prev = json.load(open(prev_path))
+    for k, c in pmc.items():
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            if name not in c and name in prev.get(k, {}):
+                c[name] = prev[k][name]
+                c["carried_over"] = sorted(set(c.get("carried_over", []) + [name]))
+json.dump(pmc, open(prev_path, "w"), indent=1)
 
 stats = {r["Name"].split("(")[0]: r for r in csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv")))}
 lines = [f"# Profile summary {tag} (MI355X, workload {bench['config']['workload']})", "",
@@ -44,11 +55,15 @@ for k, c in pmc.items():
     avg_us = float(st["AverageNs"]) / 1e3 if st else float("nan")
     gui = c.get("GRBM_GUI_ACTIVE", 0) / 8.0   # summed over 8 XCDs
     mfma = 100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * gui) if gui else float("nan")
-    rd = 2.0 * c.get("FETCH_SIZE", 0) * 1024 / 1e6
-    wr = c.get("WRITE_SIZE", 0) * 1024 / 1e6
+    # read bytes: FETCH_SIZE (KiB, doubled on gfx950), else the L2's HBM-side read requests x 128 B
+    # (the two agree to 0.1 % where both were collected)
+    rd = 2.0 * c["FETCH_SIZE"] * 1024 / 1e6 if "FETCH_SIZE" in c else c.get("TCC_EA0_RDREQ_sum", 0) * 128 / 1e6
+    wr = c.get("WRITE_SIZE", float("nan")) * 1024 / 1e6
     hit = 100.0 * c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))
     park = 100.0 * c.get("SQ_WAIT_ANY", 0) / max(1.0, c.get("SQ_WAVE_CYCLES", 0))
-    lines.append(f"| `{k}` | {avg_us:.1f} | {mfma:.1f} | {rd:.1f} | {wr:.1f} | {hit:.0f} | {park:.0f} |")
+    wr_s = "n/a" if wr != wr else f"{wr:.1f}"
+    note = " (memory counters carried over from the previous collection)" if c.get("carried_over") else ""
+    lines.append(f"| `{k}`{note} | {avg_us:.1f} | {mfma:.1f} | {rd:.1f} | {wr_s} | {hit:.0f} | {park:.0f} |")
 lines += ["", "bench.py HIP-event timings of the same kernels (ms): " +
           ", ".join(f"{k}: {v['avg_ms']:.3f}" for k, v in bench["kernels_ms"].items()), ""]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))

@@ -115,11 +115,22 @@ def cuda_device_of(networks) -> torch.device:
 
 
 def grad_buffers(module):
-    """Per-Linear-layer (weight grads, bias grads): existing .grad tensors or fresh zeros."""
+    """Per-Linear-layer (weight grads, bias grads).  The `.grad` tensors of one network are views into
+    ONE flat buffer (allocated here on first use, in `parameters()` order), so that the data-parallel
+    trainer can all-reduce a network's gradient in place without flattening / copying back
+    (`trainer/grad_sync.py`).  Gradients installed from outside (`remote_update`) are kept as they are."""
+    params = list(module.parameters())
+    flat = getattr(module, "_flat_grad", None)
+    if any(p.grad is None or not p.grad.is_contiguous() for p in params):
+        total = sum(p.numel() for p in params)
+        flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+        off = 0
+        for p in params:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        module._flat_grad = flat
     gw, gb = [], []
     for layer in module.linear_layers():
-        for p, dst in ((layer.weight, gw), (layer.bias, gb)):
-            if p.grad is None or not p.grad.is_contiguous():
-                p.grad = torch.zeros_like(p.data)
-            dst.append(p.grad)
+        gw.append(layer.weight.grad)
+        gb.append(layer.bias.grad)
     return gw, gb

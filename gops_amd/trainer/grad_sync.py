@@ -22,6 +22,24 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def _as_one_buffer(tensors: List[torch.Tensor]):
+    """The 1-D tensor that `tensors` tile back to back (the algorithms allocate a network's gradients
+    that way, `algorithm/base.py:grad_buffers`), or None if they are separate allocations."""
+    if not tensors or not all(t.is_contiguous() for t in tensors):
+        return None
+    first = tensors[0]
+    esz = first.element_size()
+    ptr = first.data_ptr()
+    for t in tensors:
+        if t.dtype != first.dtype or t.device != first.device or t.data_ptr() != ptr:
+            return None
+        if t.untyped_storage().data_ptr() != first.untyped_storage().data_ptr():
+            return None
+        ptr += t.numel() * esz
+    total = sum(t.numel() for t in tensors)
+    return torch.as_strided(first, (total,), (1,), first.storage_offset())
+
+
 class GradAllReducer:
     """In-place mean of `update_info` (dict: name -> list of gradient tensors) over all ranks."""
 
@@ -33,10 +51,17 @@ class GradAllReducer:
         if n == 1:
             return update_info
         tensors = [g for name in sorted(update_info) for g in update_info[name]]
-        flat = _flatten_dense_tensors(tensors)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.div_(n)
-        torch._foreach_copy_(tensors, list(_unflatten_dense_tensors(flat, tensors)))
+        flat = _as_one_buffer(tensors)
+        in_place = flat is not None
+        if not in_place:
+            flat = _flatten_dense_tensors(tensors)
+        if dist.get_backend(self.group) == "nccl":     # RCCL averages inside the collective
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(n)
+        if not in_place:
+            torch._foreach_copy_(tensors, list(_unflatten_dense_tensors(flat, tensors)))
         return update_info
 
     def mean_scalar(self, value: float, device) -> float:

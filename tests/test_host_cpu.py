@@ -164,6 +164,24 @@ info = {"policy": [torch.full((5,), float(r)), torch.full((2, 2), 10.0 * r)], "v
 red.average_(info)
 assert torch.allclose(info["policy"][0], torch.full((5,), (n - 1) / 2))
 assert torch.allclose(info["v"][0], torch.ones(3) * (n + 1) / 2)
+# a network's gradients as allocated by the algorithms: views into one flat buffer, reduced in place
+from gops_amd.algorithm.base import grad_buffers
+from gops_amd.apprfunc.mlp import StateValue
+from gops_amd.trainer.grad_sync import _as_one_buffer
+net = StateValue(obs_dim=3, hidden_sizes=[16, 16], hidden_activation="relu", output_activation="linear",
+                 action_distribution_cls=None)
+gw, gb = grad_buffers(net)
+grads = [p.grad for p in net.parameters()]
+flat = _as_one_buffer(grads)
+assert flat is not None and flat.data_ptr() == net._flat_grad.data_ptr() and flat.numel() == net._flat_grad.numel()
+for i, g in enumerate(grads):
+    g.fill_(float(r * 10 + i))
+ptrs = [g.data_ptr() for g in grads]
+red.average_({"v": grads})
+assert [g.data_ptr() for g in grads] == ptrs
+for i, g in enumerate(grads):
+    assert torch.allclose(g, torch.full_like(g, 10 * (n - 1) / 2 + i))
+assert _as_one_buffer([grads[0], grads[2]]) is None   # a gap between the pieces: not one buffer
 dist.destroy_process_group()
 open(os.path.join(sys.argv[2], f"ok_{r}"), "w").write("ok")
 """

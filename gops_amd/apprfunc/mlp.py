@@ -1,4 +1,5 @@
-"""MLP approximate functions of the ADP path: DetermPolicy, FiniteHorizonPolicy, StateValue.
+"""MLP approximate functions of the ADP path: DetermPolicy, FiniteHorizonPolicy,
+FiniteHorizonFullPolicy, StateValue.
 
 Module structure, parameter names (`pi.0.weight` ... / `v.0.weight` ...), registered buffers and
 `forward` semantics follow the reference (gops/apprfunc/mlp.py:36-41,50-111,309-329) so that its
@@ -6,7 +7,7 @@ Module structure, parameter names (`pi.0.weight` ... / `v.0.weight` ...), regist
 and evaluators for single observations; inside `compute_gradient` the same parameters are read
 in place by the fused HIP rollout (`hip_mlp()`), which never calls `forward`.
 """
-__all__ = ["DetermPolicy", "FiniteHorizonPolicy", "StateValue"]
+__all__ = ["DetermPolicy", "FiniteHorizonPolicy", "FiniteHorizonFullPolicy", "StateValue"]
 
 import torch
 import torch.nn as nn
@@ -83,6 +84,37 @@ class FiniteHorizonPolicy(DetermPolicy):
     def forward(self, obs, virtual_t=1):
         t = virtual_t * torch.ones(size=[obs.shape[0], 1], dtype=torch.float32, device=obs.device)
         return self._squash(self.pi(torch.cat((obs, t), 1)))
+
+
+class FiniteHorizonFullPolicy(nn.Module, Action_Distribution, _HipMlpMixin):
+    """Finite-horizon policy that emits the whole action sequence from one evaluation at obs_0
+    (reference gops/apprfunc/mlp.py:114-145): output width = act_dim * pre_horizon.  This single MLP
+    evaluation is a plain library GEMM chain (rocBLAS through torch); FHADP2's HIP rollout consumes
+    `pre_tanh(obs)` and returns its gradient."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.act_dim = kwargs["act_dim"]
+        self.pre_horizon = kwargs["pre_horizon"]
+        sizes = [kwargs["obs_dim"]] + list(kwargs["hidden_sizes"]) + [self.act_dim * self.pre_horizon]
+        self._hidden_activation = kwargs["hidden_activation"]
+        self._output_activation = kwargs.get("output_activation", "linear")
+        self.pi = mlp(sizes, get_activation_func(self._hidden_activation),
+                      get_activation_func(self._output_activation))
+        self.register_buffer("act_high_lim", torch.from_numpy(kwargs["act_high_lim"]).float())
+        self.register_buffer("act_low_lim", torch.from_numpy(kwargs["act_low_lim"]).float())
+        self.action_distribution_cls = kwargs["action_distribution_cls"]
+
+    def pre_tanh(self, obs):
+        """[B, pre_horizon, act_dim] head outputs before the tanh squash."""
+        return self.pi(obs).reshape(obs.shape[0], self.pre_horizon, self.act_dim)
+
+    def forward_all_policy(self, obs):
+        y = self.pre_tanh(obs)
+        return (self.act_high_lim - self.act_low_lim) / 2 * torch.tanh(y) + (self.act_high_lim + self.act_low_lim) / 2
+
+    def forward(self, obs):
+        return self.forward_all_policy(obs)[:, 0, :]
 
 
 class StateValue(nn.Module, Action_Distribution, _HipMlpMixin):

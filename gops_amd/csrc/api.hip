@@ -127,6 +127,8 @@ struct Plan {
     RolloutParams* dev_params = nullptr;   // device copy read by the rollout kernels
     float* dw_part[GOPS_MAX_LAYERS] = {};     // split-K partial slabs, one region per Linear layer
     float* dw_part_b[GOPS_MAX_LAYERS] = {};
+    float* dummy = nullptr;                   // open loop: stand-in policy weights
+    size_t dummy_floats = 0;
     size_t bytes = 0;
 };
 
@@ -139,8 +141,12 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     if (e.kind < GOPS_ENV_NONE || e.kind > GOPS_ENV_VEH3DOFCONTI) return GOPS_ERR_BAD_ARG;
     if (e.obs_dim < 1) return GOPS_ERR_BAD_ARG;
     const int pol_out = (e.kind == GOPS_ENV_NONE) ? 1 : e.act_dim;
-    int rc = check_mlp(desc.policy, e.obs_dim + (desc.finite_horizon ? 1 : 0), pol_out);
-    if (rc != GOPS_OK) return rc;
+    int rc = GOPS_OK;
+    if (desc.open_loop) {   // no policy inside the rollout (FHADP2)
+        if (e.kind == GOPS_ENV_NONE || desc.tail_value || desc.finite_horizon) return GOPS_ERR_BAD_ARG;
+    } else if ((rc = check_mlp(desc.policy, e.obs_dim + (desc.finite_horizon ? 1 : 0), pol_out)) != GOPS_OK) {
+        return rc;
+    }
     if (desc.tail_value && (rc = check_mlp(desc.value, e.obs_dim, 1)) != GOPS_OK) return rc;
     if (e.kind == GOPS_ENV_NONE && (desc.horizon != 1 || desc.tail_value || desc.finite_horizon)) return GOPS_ERR_BAD_ARG;
     if (e.kind == GOPS_ENV_LQ && (e.obs_dim > GOPS_MAX_LQ_STATE || e.act_dim > GOPS_MAX_ACT)) return GOPS_ERR_UNSUPPORTED;
@@ -156,7 +162,20 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     p.need_grad = desc.need_grad ? 1 : 0;
     p.tail = desc.tail_value ? 1 : 0;
     p.env = e;
-    fill_mlp(p.pol, desc.policy);
+    p.open_loop = desc.open_loop ? 1 : 0;
+    if (p.open_loop) {
+        // The kernels keep their tile / stash bookkeeping in terms of a policy: give them the
+        // smallest one (obs -> 16 -> act, weights zeroed in the workspace); its layers are never
+        // evaluated, only the observation stash (env adjoints read it) is live.
+        GopsMlp dummy;
+        memset(&dummy, 0, sizeof(dummy));
+        dummy.n_layers = 2;
+        dummy.sizes[0] = e.obs_dim; dummy.sizes[1] = 16; dummy.sizes[2] = e.act_dim;
+        dummy.hidden_act = GOPS_ACT_RELU;
+        fill_mlp(p.pol, dummy);
+    } else {
+        fill_mlp(p.pol, desc.policy);
+    }
     if (p.tail) fill_mlp(p.val, desc.value);
     int kp0 = p.pol.kp[0], hmax = 16;
     if (p.tail && p.val.kp[0] > kp0) kp0 = p.val.kp[0];
@@ -175,6 +194,13 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
 
     Carver c(ws);
     plan.dev_params = reinterpret_cast<RolloutParams*>(c.take((sizeof(RolloutParams) + 3) / 4));
+    if (p.open_loop) {   // zeroed stand-in weights (run_forward clears them)
+        plan.dummy_floats = (size_t)16 * p.pol.dims[0] + 16 + (size_t)p.pol.dims[2] * 16 + p.pol.dims[2];
+        float* z = c.take(plan.dummy_floats);
+        plan.dummy = z;
+        p.pol.w[0] = z; p.pol.b[0] = z + (size_t)16 * p.pol.dims[0];
+        p.pol.w[1] = p.pol.b[0] + 16; p.pol.b[1] = p.pol.w[1] + (size_t)p.pol.dims[2] * 16;
+    }
     carve_packs(c, p.pol);
     if (p.tail) carve_packs(c, p.val);
     // stash rows: every tile stores all 16 rows of every step (tile-major order)
@@ -226,6 +252,11 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
     RolloutParams& p = plan.p;
     p.in = in;
     p.out = out;
+    if (p.open_loop) {
+        if (in.head_pre == nullptr) return GOPS_ERR_BAD_ARG;
+        hipError_t me = hipMemsetAsync(plan.dummy, 0, plan.dummy_floats * sizeof(float), s);
+        if (me != hipSuccess) return (int)me;
+    }
     static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
     const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
     if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
@@ -250,7 +281,7 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
 }
 
 int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const float* grad_v,
-                 const GopsMlpGrad& grad, void* ws, size_t ws_bytes, hipStream_t s) {
+                 const GopsMlpGrad& grad, float* g_head_pre, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!desc.need_grad || grad_v == nullptr) return GOPS_ERR_BAD_ARG;
     Plan plan;
     int rc = build_plan(desc, ws, plan);
@@ -259,8 +290,12 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     RolloutParams& p = plan.p;
     p.in = in;
     p.grad_v = grad_v;
-    for (int j = 0; j < p.pol.nl; ++j)
-        if (grad.weight[j] == nullptr || grad.bias[j] == nullptr) return GOPS_ERR_BAD_ARG;
+    p.g_head_pre = g_head_pre;
+    if (p.open_loop != (g_head_pre != nullptr ? 1 : 0)) return GOPS_ERR_BAD_ARG;
+    if (p.open_loop && in.head_pre == nullptr) return GOPS_ERR_BAD_ARG;
+    if (!p.open_loop)
+        for (int j = 0; j < p.pol.nl; ++j)
+            if (grad.weight[j] == nullptr || grad.bias[j] == nullptr) return GOPS_ERR_BAD_ARG;
     hipError_t e;
     static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
     const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
@@ -279,6 +314,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
                 h[0] / p.H, h[10] / p.H, h[11] / p.H, h[1] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H, h[6] / p.H, h[7] / p.H,
                 h[8] / p.H, h[9] / p.H, h[2] / p.H);
     }
+    if (p.open_loop) return GOPS_OK;   // no parameters behind the rollout: the head adjoint is the result
     ProfScope scope(2, s);
     const long long S = (long long)((p.B + TB - 1) / TB) * TB * p.H;
     const int L = p.pol.nl - 1;
@@ -342,7 +378,16 @@ int gops_rollout_backward(const GopsRolloutDesc* desc, const GopsRolloutIn* in, 
                           const GopsMlpGrad* policy_grad, void* workspace, size_t workspace_bytes,
                           void* stream) {
     if (!desc || !in || !policy_grad) return GOPS_ERR_BAD_ARG;
-    return run_backward(*desc, *in, grad_v, *policy_grad, workspace, workspace_bytes,
+    return run_backward(*desc, *in, grad_v, *policy_grad, nullptr, workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream));
+}
+
+int gops_rollout_backward_open_loop(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const float* grad_v,
+                                    float* grad_head_pre, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!desc || !in || !grad_head_pre || !desc->open_loop) return GOPS_ERR_BAD_ARG;
+    GopsMlpGrad none;
+    memset(&none, 0, sizeof(none));
+    return run_backward(*desc, *in, grad_v, none, grad_head_pre, workspace, workspace_bytes,
                         static_cast<hipStream_t>(stream));
 }
 
@@ -383,7 +428,7 @@ int gops_value_backward(const GopsMlp* value, int32_t batch, const float* obs, c
     GopsRolloutIn in;
     memset(&in, 0, sizeof(in));
     in.obs = obs;
-    return run_backward(d, in, grad_v, *grad, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return run_backward(d, in, grad_v, *grad, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, double beta1, double beta2,

@@ -56,6 +56,8 @@ struct RolloutParams {
     GopsRolloutIn in;
     GopsRolloutOut out;
     const float* grad_v;              // backward only
+    int open_loop;                    // 1: head outputs come from in.head_pre, the MLP phases are skipped
+    float* g_head_pre;                // open-loop backward: d(loss)/d(head_pre) [B][H][A]
     const float* ref_table;           // veh: [B][P+1+H][4]
     unsigned long long* dbg;          // debug: per-phase cycle counters of block 0 (GOPS_DBG_TIMING)
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double

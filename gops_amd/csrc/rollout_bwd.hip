@@ -409,8 +409,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
         __syncthreads();
         if (tmode == 2) l2_pf[1] = touch_fetch(p.pol, p.st, prow, tid + NTHREADS);
         DBG_TICK(1)
-        mlp_backward(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
-                     /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg);
+        if (!p.open_loop) {
+            mlp_backward(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
+                         nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg);
+        } else if (tid < nvalid) {   // open loop: the head adjoint IS the result; no policy input adjoint
+            GLOBAL_AS float* gp = gptr(p.g_head_pre) + ((size_t)(b0 + tid) * p.H + t) * A;
+#pragma unroll
+            for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                if (a < A) gp[a] = s_gy[tid * 4 + a];
+        }
         // retire this step's warm-up loads inside the same iteration: the compiler can then count the
         // memory operations issued since (exact vmcnt) instead of draining everything at the back-edge
 #pragma unroll

@@ -180,13 +180,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
         const size_t row0 = ((size_t)blockIdx.x * p.H + t) * TB;   // tile-major stash: a tile's rows are contiguous over t
         if (p.need_grad) stash_tile(xs, ldx, p.pol.kp[0], p.st.x, row0, TB, tid);
         DBG_TICK(1)
-        float* hcur = mlp_hidden_forward(p.pol, W0, W1, xs, ldx, ha, hb, ldh, tid, s_bias,
-                                         p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
-                                         row0, nvalid, TB, dbg);
-        DBG_TICK(2)
         {
-            float y[GOPS_MAX_ACT];
-            mlp_head(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ldh, tid, y);
+            float y[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
+            if (!p.open_loop) {
+                float* hcur = mlp_hidden_forward(p.pol, W0, W1, xs, ldx, ha, hb, ldh, tid, s_bias,
+                                                 p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
+                                                 row0, nvalid, TB, dbg);
+                DBG_TICK(2)
+                mlp_head(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ldh, tid, y);
+            } else if ((tid & 15) == 0 && (tid >> 4) < nvalid) {
+                // open loop (FHADP2): the action sequence was emitted by one MLP evaluation outside
+                const GLOBAL_AS float* hp = gptr(p.in.head_pre) + ((size_t)(b0 + (tid >> 4)) * p.H + t) * A;
+#pragma unroll
+                for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                    if (a < A) y[a] = hp[a];
+            }
             if ((tid & 15) == 0) {
                 const int hm = tid >> 4;
 #pragma unroll

@@ -45,13 +45,13 @@ class GopsEnv(C.Structure):
 
 class GopsRolloutDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("horizon", C.c_int32), ("finite_horizon", C.c_int32),
-                ("need_grad", C.c_int32), ("tail_value", C.c_int32), ("reserved", C.c_int32),
+                ("need_grad", C.c_int32), ("tail_value", C.c_int32), ("open_loop", C.c_int32),
                 ("gamma", C.c_double), ("env", GopsEnv), ("policy", GopsMlp), ("value", GopsMlp)]
 
 
 class GopsRolloutIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "done", "state", "ref_points", "path_num", "u_num",
-                                          "ref_time")]
+                                          "ref_time", "head_pre")]
 
 
 class GopsRolloutOut(C.Structure):
@@ -91,6 +91,9 @@ def lib() -> C.CDLL:
         l.gops_rollout_forward.restype = C.c_int
         l.gops_rollout_forward.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn),
                                            C.POINTER(GopsRolloutOut), C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gops_rollout_backward_open_loop.restype = C.c_int
+        l.gops_rollout_backward_open_loop.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn), C.c_void_p,
+                                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         l.gops_rollout_backward.restype = C.c_int
         l.gops_rollout_backward.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn), C.c_void_p,
                                             C.POINTER(GopsMlpGrad), C.c_void_p, C.c_size_t, C.c_void_p]
@@ -116,7 +119,7 @@ def lib() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = ("gops_hip_version", "gops_rollout_workspace_bytes", "gops_rollout_forward",
-                    "gops_rollout_backward", "gops_env_step", "gops_value_workspace_bytes",
+                    "gops_rollout_backward", "gops_rollout_backward_open_loop", "gops_env_step", "gops_value_workspace_bytes",
                     "gops_value_forward", "gops_value_backward", "gops_adam_step", "gops_profile_enable",
                     "gops_profile_reset", "gops_profile_read")
 
@@ -216,14 +219,19 @@ class Rollout:
     single torch uint8 tensor sized by `gops_rollout_workspace_bytes` and reused across calls.
     """
 
-    def __init__(self, env: GopsEnv, policy: GopsMlp, *, batch: int, horizon: int, gamma: float,
+    def __init__(self, env: GopsEnv, policy: Optional[GopsMlp], *, batch: int, horizon: int, gamma: float,
                  finite_horizon: bool, need_grad: bool = True, value: Optional[GopsMlp] = None,
                  device: Optional[torch.device] = None):
+        """`policy=None` selects the open-loop mode: `forward(data, head_pre=...)` takes the pre-tanh
+        policy-head outputs of all steps [B, H, act_dim] and `backward_open_loop` returns their gradient."""
         self.desc = GopsRolloutDesc()
         d = self.desc
         d.batch, d.horizon, d.finite_horizon = batch, horizon, int(finite_horizon)
         d.need_grad, d.tail_value, d.gamma = int(need_grad), int(value is not None), float(gamma)
-        d.env, d.policy = env, policy
+        d.env = env
+        d.open_loop = int(policy is None)
+        if policy is not None:
+            d.policy = policy
         if value is not None:
             d.value = value
         self._mlps = (policy, value)
@@ -242,10 +250,15 @@ class Rollout:
             self.desc.value = value
         self._mlps = (policy, value if value is not None else self._mlps[1])
 
-    def forward(self, data: Dict[str, torch.Tensor], *, want_rewards=False, want_final=False):
+    def forward(self, data: Dict[str, torch.Tensor], *, want_rewards=False, want_final=False,
+                head_pre: Optional[torch.Tensor] = None):
         d = self.desc
         B, H, O = d.batch, d.horizon, d.env.obs_dim
         i = self._in
+        if d.open_loop:
+            assert head_pre is not None and tuple(head_pre.shape) == (B, H, d.env.act_dim)
+            i.head_pre = _ptr(head_pre)
+            self._head_pre = head_pre
         if self._keep is not data:   # same batch dict object as last call: pointers already bound
             i.obs, i.done = _ptr(data["obs"]), _ptr(data.get("done"))
             if d.env.kind == ENV_VEH:
@@ -274,6 +287,16 @@ class Rollout:
         check(lib().gops_rollout_backward(C.byref(self.desc), C.byref(self._in), _ptr(grad_v), C.byref(g),
                                           self.workspace.data_ptr(), self.workspace.numel(), _stream()),
               "gops_rollout_backward")
+
+
+    def backward_open_loop(self, grad_v: torch.Tensor) -> torch.Tensor:
+        """d(loss)/d(head_pre) [B, H, act_dim] of the last open-loop forward."""
+        d = self.desc
+        g = torch.empty(d.batch, d.horizon, d.env.act_dim, dtype=torch.float32, device=self.device)
+        check(lib().gops_rollout_backward_open_loop(C.byref(d), C.byref(self._in), _ptr(grad_v), _ptr(g),
+                                                    self.workspace.data_ptr(), self.workspace.numel(), _stream()),
+              "gops_rollout_backward_open_loop")
+        return g
 
 
 class ValueNet:

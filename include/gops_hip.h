@@ -15,6 +15,8 @@
  *                              gops/env/env_ocp/env_model/pyth_veh3dofconti_model.py:91-145).
  *   gops_rollout_backward  <- `loss.backward()` of the same functions (fhadp.py:108, infadp.py:143,151):
  *                             fills per-parameter gradients in torch nn.Linear layout.
+ *   gops_rollout_backward_open_loop <- `loss.backward()` of FHADP2 (gops/algorithm/fhadp2.py:89) down to
+ *                             the action sequence emitted by the single policy evaluation.
  *   gops_env_step          <- one wrapped `env_model.forward(obs, action, done, info)`
  *                             (gops/env/env_ocp/env_model/pyth_base_model.py:59-67), kept for
  *                             per-step consumers (gops/sys_simulator/opt_controller.py:240-300).
@@ -36,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GOPS_HIP_ABI_VERSION 1
+#define GOPS_HIP_ABI_VERSION 2
 
 #define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
 #define GOPS_MAX_ACT 4      /* action dimensions */
@@ -99,7 +101,9 @@ typedef struct GopsRolloutDesc {
     int32_t finite_horizon;   /* 1: FiniteHorizonPolicy, time index t+1 appended to the input */
     int32_t need_grad;        /* 1: keep the activation stash for gops_rollout_backward */
     int32_t tail_value;       /* 1: v += (~done_H) gamma^H V(obs_H)   (infadp.py:182-184, 210) */
-    int32_t reserved;
+    int32_t open_loop;        /* 1: no policy evaluation inside the rollout - the pre-tanh head outputs of
+                                 every step come from GopsRolloutIn.head_pre (FHADP2: one MLP evaluation
+                                 emits all H actions, gops/algorithm/fhadp2.py:100-121); `policy` is ignored */
     double gamma;             /* discount; gamma^t is formed in double then rounded (fhadp.py:120) */
     GopsEnv env;
     GopsMlp policy;           /* out width = act_dim */
@@ -115,6 +119,7 @@ typedef struct GopsRolloutIn {
     const float* path_num;    /* [B] */
     const float* u_num;       /* [B] */
     const float* ref_time;    /* [B] */
+    const float* head_pre;    /* open_loop only: [B, H, act_dim] policy-head outputs BEFORE the tanh squash */
 } GopsRolloutIn;
 
 typedef struct GopsRolloutOut {
@@ -139,6 +144,13 @@ int gops_rollout_forward(const GopsRolloutDesc* desc, const GopsRolloutIn* in,
 int gops_rollout_backward(const GopsRolloutDesc* desc, const GopsRolloutIn* in,
                           const float* grad_v, const GopsMlpGrad* policy_grad,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Open-loop counterpart of gops_rollout_backward: d(loss)/d(head_pre) [B, H, act_dim] of a forward
+ * run with desc->open_loop = 1 (the caller back-propagates it through its single MLP evaluation -
+ * FiniteHorizonFullPolicy.forward_all_policy, gops/apprfunc/mlp.py:140-145). */
+int gops_rollout_backward_open_loop(const GopsRolloutDesc* desc, const GopsRolloutIn* in,
+                                    const float* grad_v, float* grad_head_pre,
+                                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* One wrapped env-model step.  `action` is the raw (pre-wrapper) action [B, act_dim].  For
  * veh3dofconti the info tensors are updated into the next_* outputs (may alias the inputs

@@ -23,6 +23,7 @@ import _ref_import  # noqa: E402
 _ref_import.install()
 
 from gops.algorithm.fhadp import FHADP  # noqa: E402
+from gops.algorithm.fhadp2 import FHADP2  # noqa: E402
 from gops.algorithm.infadp import INFADP  # noqa: E402
 from gops.create_pkg.create_env_model import create_env_model  # noqa: E402
 
@@ -50,6 +51,8 @@ def alg_kwargs(cfg, seed, **extra):
         kw["pre_horizon"] = cfg.get("pre_horizon", cfg["horizon"])
     if "lq_config" in cfg:
         kw["lq_config"] = cfg["lq_config"]
+    if cfg["alg"] == "FHADP2":
+        kw["policy_func_name"] = "FiniteHorizonFullPolicy"
     kw.update(extra)
     return kw
 
@@ -63,6 +66,9 @@ def build_alg(cfg, seed, **extra):
     kw = alg_kwargs(cfg, seed, **extra)
     if cfg["alg"] == "FHADP":
         alg = FHADP(**kw)
+        alg.gamma = cfg.get("gamma", 1.0)
+    elif cfg["alg"] == "FHADP2":
+        alg = FHADP2(**kw)
         alg.gamma = cfg.get("gamma", 1.0)
     else:
         alg = INFADP(**kw)
@@ -310,8 +316,48 @@ def golden_trained():
         save(name, **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 5. FHADP2 (open-loop action sequence from one FiniteHorizonFullPolicy evaluation)
+# ------------------------------------------------------------------------------------------
+FHADP2_CASES = {
+    "fhadp2_lq_s4a2_tanh": (dict(alg="FHADP2", env_id="pyth_lq", lq_config="s4a2", batch=40, horizon=12,
+                                 pre_horizon=12, hidden=(64, 64), act="tanh", gamma=0.97), {}),
+    "fhadp2_idp_gelu": (dict(alg="FHADP2", env_id="pyth_idpendulum", batch=48, horizon=20, pre_horizon=20,
+                             hidden=(64, 64), act="gelu", gamma=1.0), dict(reward_scale=1)),
+    "fhadp2_veh_p10_elu": (dict(alg="FHADP2", env_id="pyth_veh3dofconti", batch=48, horizon=10, pre_horizon=10,
+                                hidden=(128, 128), act="elu", gamma=1.0), {}),
+}
+
+
+def golden_fhadp2():
+    for name, (cfg, extra) in FHADP2_CASES.items():
+        seed = zlib.crc32(name.encode()) % 1000
+        alg = build_alg(cfg, seed, **extra)
+        data = make_batch(cfg, seed)
+        if "idp" in name:
+            data["obs"][:5, 1] = 0.9
+            data["obs2"] = data["obs"].clone()
+        if cfg["env_id"] == "pyth_veh3dofconti":
+            data["state"][:3, 1] += 9.3
+            from gops_amd.utils.synthetic import veh_obs_f32
+            data["obs"] = torch.from_numpy(veh_obs_f32(data["state"].numpy(), data["ref_points"].numpy()))
+            data["obs2"] = data["obs"].clone()
+        data["done"][-3:] = 1.0
+        out = {"in/" + k: v.numpy().copy() for k, v in data.items()}
+        out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra=extra, seed=seed))
+        out.update(model_consts(alg.envmodel))
+        out.update(sd_to_np(alg.networks.state_dict()))
+        _, info = alg.get_remote_update_info(data, 0)
+        for i, gr in enumerate(info["grad"]):
+            out[f"grad/{i}"] = gr.detach().numpy().copy()
+        out["loss"] = alg.tb_info["Loss/Actor loss-RL iter"]
+        save(name, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2"]
+    if "fhadp2" in which:
+        golden_fhadp2()
     if "trained" in which:
         golden_trained()
     if "steps" in which:

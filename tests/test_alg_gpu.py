@@ -176,3 +176,28 @@ def test_graph_replay_matches_eager_updates(monkeypatch):
         assert torch.equal(a, b)
     st = algs[0].networks.policy_optimizer.state_dict()["state"]
     assert all(int(v["step"]) == 8 for v in st.values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["fhadp2_idp_gelu", "fhadp2_veh_p10_elu"])
+def test_fhadp2_class_matches_reference(name):
+    """gops_amd FHADP2 (create_alg surface) loaded with the reference's weights reproduces its loss and
+    per-parameter gradients, then takes an Adam step."""
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg = meta["cfg"]
+    kw = _kwargs(cfg, meta["extra"], meta["seed"])
+    kw.update(algorithm="FHADP2", policy_func_name="FiniteHorizonFullPolicy")
+    alg = create_alg(**kw)
+    alg.gamma = cfg["gamma"]
+    sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("sd/")}
+    alg.load_state_dict(sd)
+    alg.networks.to("cuda")
+    data = data_from_golden(g)
+    tb, info = alg.get_remote_update_info(data, 0)
+    assert abs(tb["Loss/Actor loss-RL iter"] - float(g["loss"])) <= 1e-4 * max(1.0, abs(float(g["loss"])))
+    for i, gr in enumerate(info["grad"]):
+        assert rel_l2(gr.cpu(), g[f"grad/{i}"]) < 1e-4, (name, i)
+    before = [p.detach().clone() for p in alg.networks.policy.parameters()]
+    alg.local_update(data, 1)
+    assert any(not torch.equal(a, b) for a, b in zip(before, alg.networks.policy.parameters()))

@@ -266,3 +266,40 @@ def test_horizon_one_and_all_done(dev):
     assert float(res["v_pi"].abs().max()) == 0.0
     assert all(float(gr.abs().max()) == 0.0 for gr in grads)
     assert np.array_equal(res["final_obs"].cpu().numpy(), data["obs"].numpy())
+
+
+FHADP2_CASES = ["fhadp2_lq_s4a2_tanh", "fhadp2_idp_gelu", "fhadp2_veh_p10_elu"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FHADP2_CASES)
+def test_open_loop_rollout_vs_reference_fixture(name, dev):
+    """FHADP2's open-loop mode through the C ABI: head outputs of all steps in, v_pi / rewards out,
+    gradient w.r.t. the head outputs back; chained through the MLP with torch it must reproduce the
+    reference's parameter gradients."""
+    from gops_amd import hip_backend as hb
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg = meta["cfg"]
+    env = oracle_env(cfg, meta["extra"], g)
+    nets, _ = nets_from_golden(g, cfg)
+    data = data_from_golden(g)
+    ref = orc.fhadp2_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+    B, H = data["obs"].shape[0], cfg["horizon"]
+    net = nets["policy"]
+    ws = [w.detach().to(dev).requires_grad_(True) for w in net["w"]]
+    bs = [b.detach().to(dev).requires_grad_(True) for b in net["b"]]
+    dnet = dict(net, w=ws, b=bs)
+    ddev = to_device(data, dev)
+    pre = orc.mlp_forward(dnet["w"], dnet["b"], ddev["obs"], net["act"]).reshape(B, H, -1)
+    ro = hb.Rollout(hip_env_from_oracle(env, net), None, batch=B, horizon=H, gamma=cfg["gamma"], finite_horizon=False)
+    res = ro.forward(ddev, want_rewards=True, want_final=True, head_pre=pre.detach().contiguous())
+    gpre = ro.backward_open_loop(torch.full((B,), -1.0 / B, device=dev))
+    torch.cuda.synchronize()
+    assert rel_l2(res["v_pi"].cpu(), ref["v_pi"]) < TOL
+    assert rel_l2(res["rewards"].cpu(), ref["rewards"]) < TOL
+    assert rel_l2(res["final_obs"].cpu(), ref["final_obs"]) < TOL
+    assert np.array_equal(res["final_done"].cpu().numpy() != 0, ref["final_done"].numpy())
+    grads = torch.autograd.grad(pre, [p for pair in zip(ws, bs) for p in pair], grad_outputs=gpre)
+    for i, gr in enumerate(grads):
+        assert rel_l2(gr.cpu(), g[f"grad/{i}"]) < TOL, (name, i, rel_l2(gr.cpu(), g[f"grad/{i}"]))

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hb.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hb.lib().gops_hip_version() == 1
+    assert hb.lib().gops_hip_version() == 2
 
 
 def test_workspace_query_and_rejections_need_no_gpu():
@@ -62,7 +62,7 @@ def test_workspace_query_and_rejections_need_no_gpu():
 
 def test_registries_and_error_behaviour():
     from gops_amd.create_pkg import create_alg, create_apprfunc, create_env_model, create_trainer
-    assert set(create_alg.registry) == {"FHADP", "INFADP"}
+    assert set(create_alg.registry) == {"FHADP", "FHADP2", "INFADP"}
     assert {"mlp_DetermPolicy", "mlp_FiniteHorizonPolicy", "mlp_StateValue"} <= set(create_apprfunc.registry)
     assert {"pyth_lq_model", "pyth_idpendulum_model", "pyth_veh3dofconti_model"} <= set(create_env_model.registry)
     assert {"on_serial_trainer", "on_sync_trainer"} <= set(create_trainer.registry)

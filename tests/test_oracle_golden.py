@@ -92,3 +92,21 @@ def test_baseline_shape_fixture_reproducible_from_seed(name):
         got = gr.reshape(-1)[torch.from_numpy(g[f"grad/idx{i}"])]
         assert rel_l2(got, g[f"grad/val{i}"]) < 1e-5
         assert abs(gr.double().norm().item() - g["grad/norms"][i]) < 1e-5 * g["grad/norms"][i]
+
+
+FHADP2_CASES = ["fhadp2_lq_s4a2_tanh", "fhadp2_idp_gelu", "fhadp2_veh_p10_elu"]
+
+
+@pytest.mark.parametrize("name", FHADP2_CASES)
+def test_fhadp2_gradient_matches_reference(name):
+    """Open-loop FHADP2 (one FiniteHorizonFullPolicy evaluation emits all H actions) vs the reference."""
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg = meta["cfg"]
+    env = oracle_env(cfg, meta["extra"], g)
+    nets, _ = nets_from_golden(g, cfg)
+    data = data_from_golden(g)
+    out = orc.fhadp2_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+    assert abs(out["loss"].item() - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
+    for i, gr in enumerate(out["grads"]):
+        assert rel_l2(gr, g[f"grad/{i}"]) < 1e-5, (name, i)

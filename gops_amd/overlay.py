@@ -19,8 +19,10 @@ OVERLAY = {
     "gops.create_pkg.create_apprfunc": "gops_amd.create_pkg.create_apprfunc",
     "gops.create_pkg.create_env_model": "gops_amd.create_pkg.create_env_model",
     "gops.create_pkg.create_trainer": "gops_amd.create_pkg.create_trainer",
+    "gops.create_pkg.create_buffer": "gops_amd.create_pkg.create_buffer",
     "gops.algorithm.base": "gops_amd.algorithm.base",
     "gops.algorithm.fhadp": "gops_amd.algorithm.fhadp",
+    "gops.algorithm.fhadp2": "gops_amd.algorithm.fhadp2",
     "gops.algorithm.infadp": "gops_amd.algorithm.infadp",
     "gops.apprfunc.mlp": "gops_amd.apprfunc.mlp",
     "gops.env.env_ocp.env_model.pyth_base_model": "gops_amd.env.env_ocp.env_model.pyth_base_model",
@@ -29,6 +31,8 @@ OVERLAY = {
     "gops.env.env_ocp.env_model.pyth_veh3dofconti_model": "gops_amd.env.env_ocp.env_model.pyth_veh3dofconti_model",
     "gops.trainer.on_serial_trainer": "gops_amd.trainer.on_serial_trainer",
     "gops.trainer.on_sync_trainer": "gops_amd.trainer.on_sync_trainer",
+    "gops.trainer.off_serial_trainer": "gops_amd.trainer.off_serial_trainer",
+    "gops.trainer.buffer.replay_buffer": "gops_amd.trainer.buffer.replay_buffer",
 }
 
 

@@ -1,0 +1,62 @@
+"""Serial off-policy trainer: sample -> buffer -> replay batch -> alg.local_update -> log / save / eval.
+
+Constructor signature, kwargs keys, warm-up (`buffer_warm_size`), `sample_interval`, checkpoint naming
+and TensorBoard tags follow the reference's gops/trainer/off_serial_trainer.py:30-188 - the trainer
+every shipped FHADP / INFADP example script defaults to.  MI355X differences: the replay buffer is
+device resident (`gops_amd/trainer/buffer/replay_buffer.py`), so the sampled batch is already in HBM
+(the reference copies it over PCIe every step, :91-93); the networks stay on the GPU (the sampler gets
+a CPU copy of the weights only when it samples, instead of the whole container bouncing with
+ModuleOnDevice, :81); the evaluator runs in-process (no Ray).
+"""
+import copy
+import time
+
+from gops_amd.trainer.on_serial_trainer import OnSerialTrainer
+
+__all__ = ["OffSerialTrainer"]
+
+
+class OffSerialTrainer(OnSerialTrainer):
+    def __init__(self, alg, sampler, buffer, evaluator, **kwargs):
+        super().__init__(alg, sampler, evaluator, **kwargs)
+        self.buffer = buffer
+        self._host_networks = None
+        if kwargs.get("buffer_name") == "prioritized_replay_buffer":
+            raise NotImplementedError("prioritized replay is outside the MI355X ADP path (FHADP / INFADP use uniform replay)")
+        self.replay_batch_size = kwargs["replay_batch_size"]
+        self.sample_interval = kwargs.get("sample_interval", 1)
+        while self.buffer.size < kwargs["buffer_warm_size"]:   # pre sampling
+            samples, _ = self._sampler_samples()
+            self.buffer.add_batch(samples)
+        self.start_time = time.time()
+
+    def _sampler_samples(self):
+        """The reference's samplers step numpy envs with the policy on the CPU: they get their own host
+        copy of the container, refreshed from the learner's weights before each sampling call (a 0.4 MB
+        device-to-host copy); the learner's parameters never move, so every pointer the HIP path has
+        cached stays valid."""
+        if getattr(self.sampler, "on_device", False):
+            return self.sampler.sample()
+        if next(self.networks.parameters()).is_cuda:
+            if self._host_networks is None:
+                self._host_networks = copy.deepcopy(self.networks).to("cpu")
+                self.sampler.networks = self._host_networks
+            self._host_networks.load_state_dict(self.networks.state_dict())
+        return self.sampler.sample()
+
+    def step(self):
+        if self.iteration % self.sample_interval == 0:
+            samples, sampler_tb = self._sampler_samples()
+            self.buffer.add_batch(samples)
+            self.sampler_tb_dict.add_average(sampler_tb)
+        replay_samples = self.buffer.sample_batch(self.replay_batch_size)
+        self.networks.train()
+        alg_tb_dict = self.alg.local_update(replay_samples, self.iteration)
+        self.networks.eval()
+        self._after_update(alg_tb_dict)
+
+    def _evaluate(self):
+        super()._evaluate()
+        if self.writer is not None:
+            from gops_amd.utils.tensorboard_setup import tb_tags
+            self.writer.add_scalar(tb_tags["Buffer RAM of RL iteration"], self.buffer.__get_RAM__(), self.iteration)

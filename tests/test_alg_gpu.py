@@ -201,3 +201,63 @@ def test_fhadp2_class_matches_reference(name):
     before = [p.detach().clone() for p in alg.networks.policy.parameters()]
     alg.local_update(data, 1)
     assert any(not torch.equal(a, b) for a, b in zip(before, alg.networks.policy.parameters()))
+
+
+@pytest.mark.gpu
+def test_off_serial_trainer_with_device_replay_buffer(tmp_path):
+    """off_serial_trainer + HBM-resident replay buffer + FHADP on the GPU: replay batches are sampled
+    on the device (never on the host), a numpy-side sampler gets a host copy of the weights, and the
+    veh3dof tracking return improves."""
+    from gops_amd.create_pkg.create_buffer import create_buffer
+    from gops_amd.create_pkg.create_trainer import create_trainer
+    from gops_amd.utils.synthetic import make_batch
+    cfg = dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=2048, horizon=10, pre_horizon=10, hidden=(64, 64),
+               act="elu", gamma=1.0)
+    torch.manual_seed(0)
+    kw = _kwargs(cfg, {}, 0)
+    info_spec = {"state": {"shape": (6,), "dtype": np.float32}, "ref_points": {"shape": (11, 4), "dtype": np.float32},
+                 "path_num": {"shape": (), "dtype": np.float32}, "u_num": {"shape": (), "dtype": np.float32},
+                 "ref_time": {"shape": (), "dtype": np.float32}}
+    kw.update(trainer="off_serial_trainer", buffer_name="replay_buffer", buffer_max_size=4096, buffer_warm_size=2048,
+              replay_batch_size=256, sample_interval=4, additional_info=info_spec, max_iteration=50,
+              log_save_interval=1000, apprfunc_save_interval=1000, eval_interval=10 ** 9, save_folder=str(tmp_path),
+              ini_network_dir=None)
+    alg = create_alg(**kw)
+    alg.networks.to("cuda")
+    buf = create_buffer(**kw)
+    assert buf.device.type == "cuda"
+
+    class HostSampler:   # stands in for the reference's numpy-env sampler: uses `networks` on the CPU
+        networks = None
+        calls = 0
+
+        def sample(self):
+            HostSampler.calls += 1
+            data = make_batch(dict(cfg, batch=64), 300 + HostSampler.calls)
+            with torch.no_grad():
+                act = self.networks.policy(data["obs"], 1)          # CPU forward of the host copy
+            assert act.device.type == "cpu"
+            out = []
+            for i in range(64):
+                info = {k: data[k][i].numpy() for k in info_spec}
+                out.append((data["obs"][i].numpy(), act[i].numpy(), 0.0, False, info, data["obs"][i].numpy(), info, 0.0))
+            return out, {"Time/Sampler time [ms]-RL iter": 0.0}
+
+        def get_total_sample_number(self):
+            return 64 * HostSampler.calls
+
+    trainer = create_trainer(alg, HostSampler(), buf, None, **kw)
+    assert len(buf) >= 2048
+    p0 = next(alg.networks.policy.parameters()).data_ptr()
+    losses = []
+    for _ in range(50):
+        trainer.step()
+        trainer.iteration += 1
+        losses.append(alg.tb_info["Loss/Actor loss-RL iter"])
+    assert next(alg.networks.policy.parameters()).data_ptr() == p0 and next(alg.networks.parameters()).is_cuda
+    batch = buf.sample_batch(8)
+    assert all(v.is_cuda and v.dtype == torch.float32 for v in batch.values())
+    assert np.mean(losses[-10:]) < np.mean(losses[:10])
+    # the sampler's host copy follows the learner
+    host_w = next(trainer._host_networks.policy.parameters())
+    assert not host_w.is_cuda

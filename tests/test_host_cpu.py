@@ -211,12 +211,99 @@ from gops.create_pkg.create_env_model import create_env_model
 import gops.algorithm.fhadp as f, gops.apprfunc.mlp as m
 assert create_alg.__module__ == "gops_amd.create_pkg.create_alg"
 assert f.FHADP.__module__ == "gops_amd.algorithm.fhadp" and m.StateValue.__module__ == "gops_amd.apprfunc.mlp"
-import gops.trainer.buffer.replay_buffer as rb, gops.utils.common_utils as cu   # still the reference's own
-assert rb.__file__.startswith("/root/reference") and cu.__file__.startswith("/root/reference")
+import gops.trainer.buffer.replay_buffer as rb, gops.utils.common_utils as cu, gops.trainer.sampler.off_sampler as smp
+assert rb.ReplayBuffer.__module__ == "gops_amd.trainer.buffer.replay_buffer"      # device-resident buffer
+assert cu.__file__.startswith("/root/reference") and smp.__file__.startswith("/root/reference")   # the reference's own
 import numpy as np
 buf = rb.ReplayBuffer(index=0, obsv_dim=6, action_dim=1, buffer_max_size=64, seed=0, additional_info={},
-                      trainer="off_serial_trainer")
+                      trainer="off_serial_trainer", buffer_device="cpu")
 print("overlay ok")
 """ % (ROOT, os.path.join(ROOT, "tests", "golden"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "overlay ok" in out.stdout, out.stdout + out.stderr
+
+
+def _buffer_kwargs(**over):
+    kw = dict(trainer="off_serial_trainer", seed=3, obsv_dim=5, action_dim=2, buffer_max_size=10,
+              buffer_name="replay_buffer", buffer_device="cpu",
+              additional_info={"state": {"shape": (3,), "dtype": np.float32}, "ref_time": {"shape": (), "dtype": np.float32}})
+    kw.update(over)
+    return kw
+
+
+def _transition(i):
+    info = {"state": np.full(3, i, np.float32), "ref_time": np.float32(i)}
+    nxt = {"state": np.full(3, i + 0.5, np.float32), "ref_time": np.float32(i + 0.5)}
+    return (np.full(5, i, np.float32), np.full(2, -i, np.float32), float(i), bool(i % 2), info,
+            np.full(5, i + 1, np.float32), nxt, np.float32(0.1 * i))
+
+
+def test_replay_buffer_interface_and_ring_semantics():
+    """Same keys / dtypes / ring behaviour as the reference buffer (replay_buffer.py:27-108)."""
+    from gops_amd.create_pkg.create_buffer import create_buffer, registry
+    assert "replay_buffer" in registry
+    assert create_buffer(**_buffer_kwargs(trainer="on_serial_trainer")) is None
+    with pytest.raises(KeyError, match="No registered buffer with id: nope"):
+        create_buffer(**_buffer_kwargs(buffer_name="nope"))
+    buf = create_buffer(**_buffer_kwargs())
+    buf.add_batch([_transition(i) for i in range(7)])
+    assert len(buf) == 7 and buf.ptr == 7
+    buf.store(*_transition(7))
+    buf.add_batch([_transition(i) for i in range(8, 13)])        # wraps: rows 0..2 now hold 10, 11, 12
+    assert len(buf) == 10 and buf.ptr == 3
+    assert buf.buf["rew"].tolist() == [10, 11, 12, 3, 4, 5, 6, 7, 8, 9]
+    batch = buf.sample_batch(64)
+    assert set(batch) == {"obs", "obs2", "act", "rew", "done", "logp", "state", "next_state", "ref_time", "next_ref_time"}
+    assert all(v.dtype == torch.float32 and v.shape[0] == 64 for v in batch.values())
+    assert batch["state"].shape == (64, 3) and batch["ref_time"].shape == (64,)
+    # rows stay consistent across keys, and every live row can be drawn
+    assert torch.equal(batch["obs"][:, 0], batch["rew"]) and torch.equal(batch["next_state"][:, 0], batch["rew"] + 0.5)
+    assert torch.equal(batch["done"], (batch["rew"] % 2 == 1).float())
+    assert set(batch["rew"].tolist()) <= set(range(3, 13)) and len(set(batch["rew"].tolist())) >= 8
+    again = create_buffer(**_buffer_kwargs())
+    again.add_batch([_transition(i) for i in range(8)])
+    again.add_batch([_transition(i) for i in range(8, 13)])
+    assert torch.equal(again.sample_batch(64)["rew"], batch["rew"])   # seeded index stream
+    again.add_tensors({"obs": torch.ones(2, 5), "rew": torch.tensor([100.0, 101.0])})
+    assert again.buf["rew"][3:5].tolist() == [100.0, 101.0] and again.buf["obs"][3].tolist() == [1.0] * 5
+    assert buf.__get_RAM__() > 0
+
+
+def test_off_serial_trainer_loop(tmp_path):
+    """warm-up, sample_interval, replay batch into alg.local_update, checkpoints - reference
+    off_serial_trainer.py:30-165 semantics with a CPU stand-in algorithm."""
+    from gops_amd.create_pkg.create_buffer import create_buffer
+    from gops_amd.create_pkg.create_trainer import create_trainer
+
+    class Alg:
+        def __init__(self):
+            self.networks = torch.nn.Linear(5, 2)
+            self.seen = []
+
+        def local_update(self, data, it):
+            self.seen.append((it, data["obs"].shape[0], float(data["rew"].max())))
+            return {"Loss/Actor loss-RL iter": 0.0}
+
+    class Sampler:
+        networks = None
+        calls = 0
+
+        def sample(self):
+            base = 4 * Sampler.calls
+            Sampler.calls += 1
+            return [_transition(base + i) for i in range(4)], {"Time/Sampler time [ms]-RL iter": 1.0}
+
+        def get_total_sample_number(self):
+            return 4 * Sampler.calls
+
+    alg, buf = Alg(), create_buffer(**_buffer_kwargs(buffer_max_size=100))
+    tr = create_trainer(alg, Sampler(), buf, None, trainer="off_serial_trainer", buffer_name="replay_buffer",
+                        replay_batch_size=16, buffer_warm_size=10, sample_interval=2, max_iteration=5,
+                        log_save_interval=100, apprfunc_save_interval=4, eval_interval=100,
+                        save_folder=str(tmp_path), ini_network_dir=None, use_gpu=False)
+    assert len(buf) == 12 and Sampler.calls == 3             # warm-up: 3 sampler calls reach >= 10
+    tr.train()
+    assert Sampler.calls == 3 + 3                            # iterations 0, 2, 4 sample
+    assert [s[:2] for s in alg.seen] == [(i, 16) for i in range(5)]
+    assert len(buf) == 24
+    assert {"apprfunc_0.pkl", "apprfunc_4.pkl", "apprfunc_5.pkl"} <= set(os.listdir(tmp_path / "apprfunc"))

@@ -27,7 +27,7 @@ class OffSerialTrainer(OnSerialTrainer):
         self.sample_interval = kwargs.get("sample_interval", 1)
         while self.buffer.size < kwargs["buffer_warm_size"]:   # pre sampling
             samples, _ = self._sampler_samples()
-            self.buffer.add_batch(samples)
+            self._store(samples)
         self.start_time = time.time()
 
     def _sampler_samples(self):
@@ -44,10 +44,18 @@ class OffSerialTrainer(OnSerialTrainer):
             self._host_networks.load_state_dict(self.networks.state_dict())
         return self.sampler.sample()
 
+    def _store(self, samples):
+        """Lists of Experience tuples (reference samplers) or a dict of batched device tensors
+        (`DeviceEnvSampler`)."""
+        if isinstance(samples, dict):
+            self.buffer.add_tensors(samples)
+        else:
+            self.buffer.add_batch(samples)
+
     def step(self):
         if self.iteration % self.sample_interval == 0:
             samples, sampler_tb = self._sampler_samples()
-            self.buffer.add_batch(samples)
+            self._store(samples)
             self.sampler_tb_dict.add_average(sampler_tb)
         replay_samples = self.buffer.sample_batch(self.replay_batch_size)
         self.networks.train()

@@ -1,0 +1,112 @@
+"""Closed-loop batched sampling on the GPU.
+
+The reference's samplers step numpy data environments one env and one step at a time on the CPU
+(gops/trainer/sampler/base.py:101-187) - the bottleneck once the learner runs on the MI355X (SURVEY
+section 8(f) rank 3).  For the OCP tasks of this path the data environment and the env model share their
+dynamics, reward and termination (reference tests/env_gen_ocp/test_consistency.py), so N environment
+instances are advanced together by the wrapped env-model step kernel (`gops_env_step`):
+
+    act = policy(obs)            # N x obs_dim through the policy MLP (library GEMMs), on the device
+    obs2, rew, done, info2 = gops_env_step(obs, act, done=0, info)
+    finished or timed-out instances are re-seeded from a device pool of reset states
+
+`sample()` returns replay-format DEVICE tensors (`obs, act, rew, done, obs2, logp` + info / next_info
+keys) for `ReplayBuffer.add_tensors`; nothing crosses PCIe in steady state.  Reset states come from the
+data envs' reset distributions (`gops_amd.utils.synthetic.make_batch`), generated on the host in pools of
+`pool_factor x n_envs` and uploaded once per pool.
+"""
+import time
+
+import numpy as np
+import torch
+
+from gops_amd import hip_backend as hb
+from gops_amd.utils.synthetic import make_batch
+from gops_amd.utils.tensorboard_setup import tb_tags
+
+_INFO = ("state", "ref_points", "path_num", "u_num", "ref_time")
+
+
+class DeviceEnvSampler:
+    on_device = True   # trainers: do not move the networks to the CPU around sample()
+
+    def __init__(self, cfg: dict, env_model, *, n_envs: int, steps_per_sample: int = 1, max_episode_steps: int = 200,
+                 seed: int = 0, device="cuda", pool_factor: int = 8, noise_std: float = 0.0):
+        """cfg: workload dict as in `gops_amd.utils.synthetic.CONFIGS` (env_id, pre_horizon, lq_config);
+        env_model: the wrapped model from `create_env_model` (its constants drive the step kernel)."""
+        self.cfg, self.env_model = dict(cfg), env_model
+        self.n, self.steps, self.max_steps = n_envs, steps_per_sample, max_episode_steps
+        self.device = torch.device(device)
+        self.seed, self.pool_factor, self.noise_std = seed, pool_factor, noise_std
+        self.networks = None
+        self.total = 0
+        self._pool, self._pool_pos, self._pools_made = None, 0, 0
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(seed)
+        self._henv = None
+        first = self._draw(self.n)
+        self.obs = first["obs"]
+        self.info = {k: first[k] for k in _INFO if k in first}
+        self.t = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+
+    # ---- reset pool ---------------------------------------------------------------------------
+    def _draw(self, k: int):
+        """k fresh initial conditions (device tensors) from the pool; refills the pool when it runs dry."""
+        size = self.pool_factor * self.n
+        if self._pool is None or self._pool_pos + k > size:
+            host = make_batch(self.cfg, self.seed + 7919 * self._pools_made, batch=size)
+            self._pool = {key: v.to(self.device) for key, v in host.items() if key == "obs" or key in _INFO}
+            self._pool_pos, self._pools_made = 0, self._pools_made + 1
+        sl = slice(self._pool_pos, self._pool_pos + k)
+        self._pool_pos += k
+        return {key: v[sl].clone() for key, v in self._pool.items()}
+
+    def _hip_env(self):
+        if self._henv is None:
+            pol = self.networks.policy
+            self._henv = self.env_model.hip_env(pol.act_low_lim.cpu().numpy(), pol.act_high_lim.cpu().numpy())
+        return self._henv
+
+    # ---- sampling -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample(self):
+        """Advance all N environments `steps_per_sample` steps; returns (dict of [N*steps, ...] device
+        tensors in replay format, tb dict)."""
+        t0 = time.time()
+        policy = self.networks.policy
+        zeros = torch.zeros(self.n, device=self.device)
+        chunks = []
+        for _ in range(self.steps):
+            obs, info = self.obs, self.info
+            act = policy(obs)
+            if self.noise_std > 0.0:
+                act = act + self.noise_std * torch.randn(act.shape, generator=self._gen, device=self.device)
+            obs2, rew, done, info2 = hb.env_step(self._hip_env(), obs, act.contiguous(), zeros, info)
+            row = dict(obs=obs, act=act, rew=rew, done=done, obs2=obs2, logp=zeros)
+            for k in info:
+                row[k], row["next_" + k] = info[k], info2[k]
+            chunks.append(row)
+            # episode bookkeeping: terminated or timed-out instances restart from a fresh reset state
+            self.t += 1
+            over = (done != 0) | (self.t >= self.max_steps)
+            n_over = int(over.sum().item())
+            self.obs, self.info = obs2, dict(info2)
+            if n_over:
+                fresh = self._draw(n_over)
+                idx = over.nonzero(as_tuple=True)[0]
+                self.obs = self.obs.index_copy(0, idx, fresh["obs"])
+                for k in self.info:
+                    self.info[k] = self.info[k].index_copy(0, idx, fresh[k])
+                self.t.index_fill_(0, idx, 0)
+        batch = {k: torch.cat([c[k] for c in chunks]) for k in chunks[0]} if len(chunks) > 1 else chunks[0]
+        self.total += self.n * self.steps
+        return batch, {tb_tags["sampler_time"]: (time.time() - t0) * 1000}
+
+    def sample_with_replay_format(self):
+        return self.sample()
+
+    def get_total_sample_number(self):
+        return self.total
+
+    def load_state_dict(self, state_dict):
+        pass

@@ -261,3 +261,53 @@ def test_off_serial_trainer_with_device_replay_buffer(tmp_path):
     # the sampler's host copy follows the learner
     host_w = next(trainer._host_networks.policy.parameters())
     assert not host_w.is_cuda
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["pyth_idpendulum", "pyth_veh3dofconti"])
+def test_device_env_sampler_closed_loop(env_id, tmp_path):
+    """N environments stepped together on the GPU by gops_env_step: every stored transition equals the
+    oracle's wrapped model step of (obs, act), episodes restart on termination / time-out, and the
+    batches flow into the device replay buffer through the off-policy trainer."""
+    from helpers import oracle_env
+    from oracle import adp_oracle as orc
+    from gops_amd.create_pkg.create_buffer import create_buffer
+    from gops_amd.create_pkg.create_trainer import create_trainer
+    from gops_amd.trainer.sampler.device_env_sampler import DeviceEnvSampler
+    cfg = dict(alg="FHADP", env_id=env_id, batch=128, horizon=10, pre_horizon=10, hidden=(64, 64), act="gelu", gamma=1.0)
+    torch.manual_seed(1)
+    kw = _kwargs(cfg, {}, 1)
+    alg = create_alg(**kw)
+    alg.networks.to("cuda")
+    smp = DeviceEnvSampler(cfg, alg.envmodel, n_envs=96, steps_per_sample=6, max_episode_steps=4, seed=11)
+    smp.networks = alg.networks
+    batch, _ = smp.sample()
+    n = 96 * 6
+    assert all(v.is_cuda and v.shape[0] == n for v in batch.values())
+    env = oracle_env(cfg, {})
+    info = {k: batch[k].cpu() for k in ("state", "ref_points", "path_num", "u_num", "ref_time") if k in batch}
+    o2, r, d, ninfo = orc.env_forward(env, batch["obs"].cpu(), batch["act"].cpu(), torch.zeros(n), info)
+    assert rel_l2(batch["obs2"].cpu(), o2) < 1e-4 and rel_l2(batch["rew"].cpu(), r) < 1e-4
+    assert np.array_equal(batch["done"].cpu().numpy() != 0, d.numpy())
+    if env_id == "pyth_veh3dofconti":
+        assert rel_l2(batch["next_state"].cpu(), ninfo["state"]) < 1e-4
+        assert rel_l2(batch["next_ref_time"].cpu(), ninfo["ref_time"]) < 1e-6
+    # time-outs after 4 steps: step 4 of every instance starts from a fresh reset state, not from obs2 of step 3
+    obs_s = batch["obs"].view(6, 96, -1)
+    obs2_s = batch["obs2"].view(6, 96, -1)
+    assert torch.equal(obs_s[1], obs2_s[0]) or (batch["done"].view(6, 96)[0] != 0).any()
+    assert not torch.equal(obs_s[4], obs2_s[3])
+    assert smp.get_total_sample_number() == n
+    # into the replay buffer through the trainer
+    info_spec = {k: {"shape": tuple(v.shape[1:]), "dtype": np.float32} for k, v in info.items()}
+    kw.update(trainer="off_serial_trainer", buffer_name="replay_buffer", buffer_max_size=4096, buffer_warm_size=1000,
+              replay_batch_size=128, sample_interval=1, additional_info=info_spec, max_iteration=5,
+              log_save_interval=1000, apprfunc_save_interval=1000, eval_interval=10 ** 9, save_folder=str(tmp_path),
+              ini_network_dir=None)
+    buf = create_buffer(**kw)
+    trainer = create_trainer(alg, smp, buf, None, **kw)
+    assert len(buf) >= 1000
+    for _ in range(5):
+        trainer.step()
+        trainer.iteration += 1
+    assert len(buf) >= 1000 + 5 * n and np.isfinite(alg.tb_info["Loss/Actor loss-RL iter"])

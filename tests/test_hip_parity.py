@@ -303,3 +303,42 @@ def test_open_loop_rollout_vs_reference_fixture(name, dev):
     grads = torch.autograd.grad(pre, [p for pair in zip(ws, bs) for p in pair], grad_outputs=gpre)
     for i, gr in enumerate(grads):
         assert rel_l2(gr.cpu(), g[f"grad/{i}"]) < TOL, (name, i, rel_l2(gr.cpu(), g[f"grad/{i}"]))
+
+
+def _sweep_cases():
+    """Seeded random shapes off the BASELINE grid: 1-4 hidden layers of any multiple-of-16 width, every
+    activation, every env (all LQ configs), ragged batches, horizons 1..40, discount < 1."""
+    rng = np.random.RandomState(2024)
+    acts = ["relu", "elu", "gelu", "selu", "sigmoid", "tanh", "linear"]
+    envs = [("pyth_idpendulum", {}), ("pyth_veh3dofconti", {})] + [("pyth_lq", {"lq_config": c}) for c in
+                                                                    ("s2a1", "s3a1", "s4a2", "s5a1", "s6a3")]
+    cases = []
+    for i in range(28):
+        env_id, extra = envs[i % len(envs)]
+        layers = int(rng.randint(1, 5))
+        hidden = tuple(int(16 * rng.randint(1, 13)) for _ in range(layers))
+        cfg = dict(alg="FHADP", env_id=env_id, batch=int(rng.randint(1, 150)), horizon=int(rng.randint(1, 41)),
+                   hidden=hidden, act=acts[i % len(acts)], gamma=float(rng.choice([1.0, 0.99, 0.9])), **extra)
+        if env_id == "pyth_veh3dofconti":
+            cfg["pre_horizon"] = int(rng.choice([5, 10, 17, 30]))
+        cases.append(cfg)
+    return cases
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", _sweep_cases(), ids=lambda c: f"{c['env_id'][5:]}-{c.get('lq_config', '')}-B{c['batch']}-H{c['horizon']}-"
+                                                            f"{'x'.join(map(str, c['hidden']))}-{c['act']}")
+def test_shape_sweep_matches_oracle(cfg, dev):
+    seed = cfg["batch"] * 131 + cfg["horizon"]
+    data = make_batch(cfg, seed)
+    data["done"][::7] = 1.0
+    nets = reference_init_nets(cfg, seed, obs_dim_of(cfg), act_dim_of(cfg))
+    env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
+    res, grads = _run_fhadp(env, nets, data, cfg, dev)
+    ref = orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+    assert rel_l2(res["v_pi"].cpu(), ref["v_pi"]) < TOL
+    assert rel_l2(res["rewards"].cpu(), ref["rewards"]) < TOL
+    assert np.array_equal(res["final_done"].cpu().numpy() != 0, ref["final_done"].numpy())
+    flat = torch.cat([x.reshape(-1).cpu() for x in grads])
+    flat_ref = torch.cat([x.reshape(-1) for x in ref["grads"]])
+    assert rel_l2(flat, flat_ref) < TOL, rel_l2(flat, flat_ref)

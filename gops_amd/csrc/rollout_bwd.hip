@@ -9,15 +9,25 @@
 #include "common.h"
 #include "env_models.h"
 
+// LDS floats of the per-tile buffers (everything except the optional staged tiles at the end).
+__host__ __device__ inline int bwd_lds_floats(int ldx, int ldh, int ref_points) {
+    return TB * ldx + 2 * TB * ldh + TB * 4 + 4 * TB * 8 + 4 * ldh + 4 * TB * ref_points;
+}
+
 // delta_y in s_gy[TB][4]  ->  hidden deltas (stashed to stash_d when non-null) and, if want_gx,
 // G[m][n] += (delta_1 W_0)[m][n] for n < ncols.
-template <class W0T, class W1T, class WP>
+template <bool STAGED, class W0T, class W1T, class WP, class Hook>
 __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, const W1T& WT1,
                                              WP Wo, int ldw, const float* s_gy, float* da,
                                              float* db, int ldh, float* G, int ldg, int tid,
                                              float* const* stash_h, float* const* stash_z,
                                              float* const* stash_d, float* stash_dy, size_t row0,
-                                             int nvalid, bool want_gx, int ncols, DbgClock& dbg) {
+                                             int nvalid, bool want_gx, int ncols, DbgClock& dbg,
+                                             Hook&& after_head, const float* stage_head = nullptr,
+                                             const float* stage_h1 = nullptr) {
+    // stage_head / stage_h1: LDS copies (direct global->LDS loads issued at the top of the step) of the
+    // tiles the head / the layer-1 epilogue take act' from: [TB][K] row-major, and [wave][TB][64]
+    // (each wave's own 64 columns) - each wave reads only what its own lanes fetched.
     const int lane = tid & 63;
     const int L = M.nl - 1, A = M.dims[M.nl];
     const bool gelu = (M.act == GOPS_ACT_GELU);
@@ -35,7 +45,8 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
 #pragma unroll 4
                 for (int k = 4 * hp; k < K; k += 64) {
                     f32x4 hv = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
-                    if (hm < nvalid) hv = ld4((ACT == GOPS_ACT_GELU ? zrow : hrow) + k);
+                    if constexpr (STAGED) hv = *reinterpret_cast<const f32x4*>(stage_head + hm * K + k);
+                    else if (hm < nvalid) hv = ld4((ACT == GOPS_ACT_GELU ? zrow : hrow) + k);
 #pragma unroll
                     for (int a = 0; a < GOPS_MAX_ACT; ++a)
                         if (a < A) acc += gy[a] * ld4(Wo + a * ldw + k);
@@ -71,6 +82,7 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
     __syncthreads();
     DBG_TICK(4)
     if (stash_d != nullptr) stash_tile(da, ldh, M.dims[L], stash_d[L], row0, TB, tid);
+    after_head();   // long stretch without dependent global loads ahead: the caller's prefetches go here
     DBG_TICK(5)
     float* cur = da;
     float* out = db;
@@ -88,7 +100,8 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
                     for (int r = 0; r < 4; ++r) {
                         const int n = ((nt0 + q) << 4) + (lane & 15), m = ((lane >> 4) << 2) + r;
                         // GELU's derivative needs z, every other activation's needs h
-                        hv[q][r] = (m < nvalid) ? (ACT == GOPS_ACT_GELU ? zbase : hbase)[(size_t)m * N + n] : 0.f;
+                        if constexpr (STAGED) hv[q][r] = stage_h1[(tid >> 6) * (TB * 64) + m * 64 + (n & 63)];   // j == 1 only
+                        else hv[q][r] = (m < nvalid) ? (ACT == GOPS_ACT_GELU ? zbase : hbase)[(size_t)m * N + n] : 0.f;
                     }
 #pragma unroll
                 for (int q = 0; q < CNT; ++q) {
@@ -155,6 +168,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
     float* s_wo = red + 4 * TB * 8;     // [4][ldh] head weights
     f32x4* s_ref = reinterpret_cast<f32x4*>(s_wo + 4 * ldh);   // veh: [TB][TL]
     float* s_idp = reinterpret_cast<float*>(s_ref);             // idpendulum: [TB][5][24] sub-step parking
+    // One-workgroup-per-CU variants: LDS copies of this step's H_2 / H_1 (Z for GELU) tiles, [2][TB][256]
+    constexpr bool STAGE = (SK1 > 0);   // (those variants are only selected for obs-256-256-act policies)
+    float* s_stage = smem + bwd_lds_floats(ldx, ldh, ENV == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H
+                                                                             : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0));
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
     const float gv = (tid < nvalid) ? gptr(p.grad_v)[b0 + tid] : 0.f;
@@ -191,9 +208,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
             s_gy[tid * 4 + 1] = s_gy[tid * 4 + 2] = s_gy[tid * 4 + 3] = 0.f;
         }
         __syncthreads();
-        mlp_backward(p.val, NoW{}, NoW{}, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, da, db, ldh, G, ldx,
+        mlp_backward<false>(p.val, NoW{}, NoW{}, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, da, db, ldh, G, ldx,
                      tid, p.st.tail_h, p.st.tail_z, nullptr, nullptr,
-                     (size_t)b0, nvalid, true, O, dbg);
+                     (size_t)b0, nvalid, true, O, dbg, [] {});
     }
     __syncthreads();
 
@@ -201,13 +218,36 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
     for (int t = p.H - 1; t >= 0; --t) {
         const size_t row0 = ((size_t)blockIdx.x * p.H + t) * TB;   // tile-major stash rows
         const size_t prow = row0 - TB;
-        const int tmode = (t > 0) ? p.touch_mode : 0;
-        if (tmode == 1) {   // start fetching what step t-1 will read (written long ago by the forward kernel)
+        if constexpr (STAGE) {
+            // Direct global->LDS loads (no VGPRs) of the tiles the head and the layer-1 epilogue need
+            // act' from; they land behind the env adjoint.  Each wave fetches exactly the part its own
+            // lanes read later: rows 4w..4w+3 of H_2 (1 KiB = one row per instruction) and columns
+            // 64w..64w+63 of H_1 (4 rows x 64 columns per instruction).
+            typedef __attribute__((address_space(3))) void* lds_ptr;
+            const bool gelu_s = p.pol.act == GOPS_ACT_GELU;
+            const float* src2 = (gelu_s ? p.st.z[2] : p.st.h[2]) + row0 * 256;
+            const float* src1 = (gelu_s ? p.st.z[1] : p.st.h[1]) + row0 * 256;
+            const int ln = tid & 63, wv = tid >> 6;
 #pragma unroll
-            for (int q = 0; q < TOUCH_SLOTS; ++q) l2_pf[q] = touch_fetch(p.pol, p.st, prow, tid + NTHREADS * q);
-        } else if (tmode == 2) {
-            l2_pf[0] = touch_fetch(p.pol, p.st, prow, tid);
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_global_load_lds(gptr(src2 + (4 * wv + q) * 256 + 4 * ln),
+                                                 (lds_ptr)(s_stage + (4 * wv + q) * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gptr(src1 + (4 * q + (ln >> 4)) * 256 + 64 * wv + 4 * (ln & 15)),
+                                                 (lds_ptr)(s_stage + TB * 256 + wv * (TB * 64) + q * 256), 16, 0, 0);
+            }
         }
+        // (the staged variants fetch their tiles straight into LDS and measured faster without it)
+        const int tmode = (t > 0 && !STAGE) ? p.touch_mode : 0;
+        // L2 warm-up of what step t-1 will read (written long ago by the forward kernel): HBM-latency
+        // loads whose values are only XOR-ed into a sink at the end of the step.  Loads return in order,
+        // so they are issued where no latency-critical load follows for thousands of cycles - right
+        // after the head, ahead of the hidden-layer GEMMs - never in front of the env-row / act' loads.
+        auto warm_up = [&]() {
+            if (tmode != 0) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) l2_pf[q] = touch_fetch(p.pol, p.st, prow, tid + NTHREADS * q);
+            }
+        };
         DBG_TICK(0)
         float g_r = gv * p.gpow[t];                         // adjoint of the shaped reward
         if (ENV != GOPS_ENV_NONE && p.env.shaping) g_r *= p.env.reward_scale;
@@ -407,11 +447,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
             }
         }
         __syncthreads();
-        if (tmode == 2) l2_pf[1] = touch_fetch(p.pol, p.st, prow, tid + NTHREADS);
         DBG_TICK(1)
         if (!p.open_loop) {
-            mlp_backward(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
-                         nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg);
+            if constexpr (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staged tiles have landed
+            mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
+                         nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up, s_stage, s_stage + TB * 256);
         } else if (tid < nvalid) {   // open loop: the head adjoint IS the result; no policy input adjoint
             GLOBAL_AS float* gp = gptr(p.g_head_pre) + ((size_t)(b0 + tid) * p.H + t) * A;
 #pragma unroll
@@ -432,7 +472,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
 // ref_points: reference-table points per trajectory (veh3dofconti), 30 (= 5 x 24 / 4) for the
 // idpendulum sub-step parking area, else 0
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points) {
-    return sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * 4 + 4 * TB * 8 + 4 * ldh + 4 * TB * ref_points);
+    return sizeof(float) * (size_t)bwd_lds_floats(ldx, ldh, ref_points);
 }
 
 void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
@@ -451,10 +491,11 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
 
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    const size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H
-                                                             : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0));
+    size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H
+                                                       : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0));
     int sk[2];
     rollout_variant(p, sk, true);
+    if (sk[1] > 0) lds += sizeof(float) * 2 * TB * 256;   // staged H_2 / H_1 tiles of the one-workgroup-per-CU variants
     const int key = sk[0] * 100 + sk[1];
     switch (p.env.kind) {
         case GOPS_ENV_NONE: LAUNCH_BWD(GOPS_ENV_NONE, 0, 0); break;

@@ -373,6 +373,23 @@ __device__ __forceinline__ unsigned touch_fetch(const MlpDev& M, const StashDev&
     return 0u;
 }
 
+// Asynchronous 16-byte-per-lane copy global -> LDS (global_load_lds_dwordx4): lane i's 16 bytes land at
+// LDS address `lds_base` + 16 i (wave-uniform base in M0), no VGPR holds the data, completion is
+// counted by vmcnt.  Issued as inline asm on purpose: the builtin makes hipcc wait vmcnt(0) before the
+// next LDS read that MAY alias the destination - i.e. within a few dozen instructions - which turns the
+// prefetch into a blocking load.  The caller owns the ordering: `s_waitcnt vmcnt(0)` + barrier before
+// anyone reads the destination.  (An asm-issued VMEM op only makes the compiler's own counted waits
+// more conservative, never unsafe: vmcnt retires in order.)
+__device__ __forceinline__ void async_copy16_to_lds(const float* gsrc, const float* lds_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gptr(gsrc)), "s"(m0v)
+                 : "memory");
+}
+
 // Copy a [TB][ncols] LDS tile (leading dim ld) to global rows g[(row0+m)*ncols ...], coalesced.
 __device__ __forceinline__ void stash_tile(const float* lds, int ld, int ncols, float* g, size_t row0,
                                            int nrows_valid, int tid) {

@@ -214,28 +214,45 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
     }
     __syncthreads();
 
+    // One-workgroup-per-CU variants: everything step tt reads from the stash - the H_2 / H_1 tiles the
+    // head and the layer-1 epilogue take act' from (Z for GELU), the env rows and the first 8 columns of
+    // the observation rows - is fetched straight into LDS (global_load_lds: no VGPRs) ONE STEP AHEAD, into
+    // the half of the staging area selected by the step's parity.  For the tiles each wave fetches
+    // exactly what its own lanes read later: rows 4w..4w+3 of H_2 (one 1-KiB row per instruction) and
+    // columns 64w..64w+63 of H_1 (4 rows x 64 columns per instruction); the small rows are fetched by
+    // waves 0 / 1 and read by everyone after the end-of-step barrier (which drains the loads).
+    constexpr int STAGE_FLOATS = 2 * TB * 256 + TB * ENV_STASH + TB * 8;
+    auto stage_step = [&](int tt) {
+        const size_t r0 = ((size_t)blockIdx.x * p.H + tt) * TB;
+        const float* dst = s_stage + (tt & 1) * STAGE_FLOATS;
+        const bool gelu_s = p.pol.act == GOPS_ACT_GELU;
+        const float* src2 = (gelu_s ? p.st.z[2] : p.st.h[2]) + r0 * 256;
+        const float* src1 = (gelu_s ? p.st.z[1] : p.st.h[1]) + r0 * 256;
+        const int ln = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            async_copy16_to_lds(src2 + (4 * wv + q) * 256 + 4 * ln, dst + (4 * wv + q) * 256);
+            async_copy16_to_lds(src1 + (4 * q + (ln >> 4)) * 256 + 64 * wv + 4 * (ln & 15),
+                                dst + TB * 256 + wv * (TB * 64) + q * 256);
+        }
+        if (wv == 0)        // env rows: 16 x 64 B, contiguous
+            async_copy16_to_lds(p.st.env + r0 * ENV_STASH + 4 * ln, dst + 2 * TB * 256);
+        if (wv == 1 && ln < 2 * TB)   // first 8 floats of every observation row
+            async_copy16_to_lds(p.st.x + (r0 + (ln >> 1)) * kp0 + 4 * (ln & 1), dst + 2 * TB * 256 + TB * ENV_STASH);
+    };
+    if constexpr (STAGE) {
+        stage_step(p.H - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
     unsigned l2_sink = 0, l2_pf[TOUCH_SLOTS] = {0u, 0u, 0u, 0u};
     for (int t = p.H - 1; t >= 0; --t) {
         const size_t row0 = ((size_t)blockIdx.x * p.H + t) * TB;   // tile-major stash rows
         const size_t prow = row0 - TB;
-        if constexpr (STAGE) {
-            // Direct global->LDS loads (no VGPRs) of the tiles the head and the layer-1 epilogue need
-            // act' from; they land behind the env adjoint.  Each wave fetches exactly the part its own
-            // lanes read later: rows 4w..4w+3 of H_2 (1 KiB = one row per instruction) and columns
-            // 64w..64w+63 of H_1 (4 rows x 64 columns per instruction).
-            typedef __attribute__((address_space(3))) void* lds_ptr;
-            const bool gelu_s = p.pol.act == GOPS_ACT_GELU;
-            const float* src2 = (gelu_s ? p.st.z[2] : p.st.h[2]) + row0 * 256;
-            const float* src1 = (gelu_s ? p.st.z[1] : p.st.h[1]) + row0 * 256;
-            const int ln = tid & 63, wv = tid >> 6;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                __builtin_amdgcn_global_load_lds(gptr(src2 + (4 * wv + q) * 256 + 4 * ln),
-                                                 (lds_ptr)(s_stage + (4 * wv + q) * 256), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(gptr(src1 + (4 * q + (ln >> 4)) * 256 + 64 * wv + 4 * (ln & 15)),
-                                                 (lds_ptr)(s_stage + TB * 256 + wv * (TB * 64) + q * 256), 16, 0, 0);
-            }
-        }
+        const float* st_cur = s_stage + (t & 1) * STAGE_FLOATS;       // this step's staged data (STAGE only)
+        const float* st_env = st_cur + 2 * TB * 256;
+        const float* st_x = st_env + TB * ENV_STASH;
         // (the staged variants fetch their tiles straight into LDS and measured faster without it)
         const int tmode = (t > 0 && !STAGE) ? p.touch_mode : 0;
         // L2 warm-up of what step t-1 will read (written long ago by the forward kernel): HBM-latency
@@ -251,6 +268,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
         DBG_TICK(0)
         float g_r = gv * p.gpow[t];                         // adjoint of the shaped reward
         if (ENV != GOPS_ENV_NONE && p.env.shaping) g_r *= p.env.reward_scale;
+        if constexpr (STAGE) {
+            // Next step's tiles travel HBM -> LDS during this whole step.  Issued AFTER the first use of a
+            // loaded value in the iteration (g_r above): hipcc drains vmcnt(0) there on every trip, and the
+            // copies must not be outstanding at that point.
+            if (t > 0) stage_step(t - 1);
+        }
 
         if (ENV == GOPS_ENV_NONE) {
             if (tid < TB) {
@@ -263,14 +286,23 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
                 float th[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, dflag = 1.f;
                 float x[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (m < nvalid) {
-                    const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
-                    const f32x4 e0 = er[0], e1 = er[1];
+                    f32x4 e0, e1;
+                    if constexpr (STAGE) {
+                        const f32x4* er = reinterpret_cast<const f32x4*>(st_env + m * ENV_STASH);
+                        e0 = er[0]; e1 = er[1];
+#pragma unroll
+                        for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                            if (i < O) x[i] = st_x[m * 8 + i];
+                    } else {
+                        const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
+                        e0 = er[0]; e1 = er[1];
+                        const GLOBAL_AS float* xr = gptr(p.st.x + (row0 + m) * kp0);
+#pragma unroll
+                        for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                            if (i < O) x[i] = xr[i];
+                    }
                     th[0] = e0[0]; th[1] = e0[1]; th[2] = e0[2]; th[3] = e0[3];
                     dflag = e1[0];
-                    const GLOBAL_AS float* xr = gptr(p.st.x + (row0 + m) * kp0);
-#pragma unroll
-                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                        if (i < O) x[i] = xr[i];
                 }
                 float abar[GOPS_MAX_ACT], u[GOPS_MAX_ACT], sc[GOPS_MAX_ACT], gu[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -361,8 +393,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
             float th0 = 0.f, th1 = 0.f, dflag = 1.f;
             float s[6] = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f};
             if (m < nvalid) {
-                const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
-                const f32x4 e0 = er[0], e1 = er[1], e2 = er[2];
+                f32x4 e0, e1, e2;
+                if constexpr (STAGE) {
+                    const f32x4* er = reinterpret_cast<const f32x4*>(st_env + m * ENV_STASH);
+                    e0 = er[0]; e1 = er[1]; e2 = er[2];
+                } else {
+                    const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
+                    e0 = er[0]; e1 = er[1]; e2 = er[2];
+                }
                 th0 = e0[0]; th1 = e0[1]; dflag = e1[0];
                 s[0] = e1[1]; s[1] = e1[2]; s[2] = e1[3]; s[3] = e2[0]; s[4] = e2[1]; s[5] = e2[2];
             }
@@ -431,7 +469,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
                 veh_f_xu_bwd(VC, s, steer, w, lamn, lam, g_steer, g_ax);
                 const float g_rm = dn ? 0.f : g_r;
                 if (m < nvalid) {
-                    const GLOBAL_AS float* xr = gptr(p.st.x + (row0 + m) * kp0);
+                    float xr[6];
+                    if constexpr (STAGE) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) xr[i] = st_x[m * 8 + i];
+                    } else {
+                        const GLOBAL_AS float* xg = gptr(p.st.x + (row0 + m) * kp0);
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) xr[i] = xg[i];
+                    }
                     G[m * ldx + 0] += g_rm * (-0.08f * xr[0]);
                     G[m * ldx + 1] += g_rm * (-0.08f * xr[1]);
                     G[m * ldx + 2] += g_rm * (-0.04f * xr[2]);
@@ -449,9 +495,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
         __syncthreads();
         DBG_TICK(1)
         if (!p.open_loop) {
-            if constexpr (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staged tiles have landed
             mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
-                         nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up, s_stage, s_stage + TB * 256);
+                         nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up, st_cur, st_cur + TB * 256);
         } else if (tid < nvalid) {   // open loop: the head adjoint IS the result; no policy input adjoint
             GLOBAL_AS float* gp = gptr(p.g_head_pre) + ((size_t)(b0 + tid) * p.H + t) * A;
 #pragma unroll
@@ -462,6 +507,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
         // memory operations issued since (exact vmcnt) instead of draining everything at the back-edge
 #pragma unroll
         for (int q = 0; q < TOUCH_SLOTS; ++q) l2_sink ^= l2_pf[q];
+        if constexpr (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next step's staged data has landed
         __syncthreads();
         DBG_TICK(2)
     }
@@ -495,7 +541,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
                                                        : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0));
     int sk[2];
     rollout_variant(p, sk, true);
-    if (sk[1] > 0) lds += sizeof(float) * 2 * TB * 256;   // staged H_2 / H_1 tiles of the one-workgroup-per-CU variants
+    if (sk[1] > 0) lds += sizeof(float) * 2 * (2 * TB * 256 + TB * ENV_STASH + TB * 8);   // two staging halves
     const int key = sk[0] * 100 + sk[1];
     switch (p.env.kind) {
         case GOPS_ENV_NONE: LAUNCH_BWD(GOPS_ENV_NONE, 0, 0); break;

@@ -552,7 +552,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
             if (key == 1616) LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 16, 16); else LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 0, 0);
             break;
         case GOPS_ENV_VEH3DOFCONTI:
-            if (key == 816) LAUNCH_BWD2(GOPS_ENV_VEH3DOFCONTI, 8, 16, 2);
+            if (key == 1216) LAUNCH_BWD2(GOPS_ENV_VEH3DOFCONTI, 12, 16, 2);
             else if (key == 16) LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 0, 16);
             else LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 0, 0);
             break;

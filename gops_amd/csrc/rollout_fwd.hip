@@ -396,11 +396,11 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
     }
     // The backward sweep's VALU phases need more than the 128 VGPRs left beside 384 weight registers:
     // it keeps only the 256-register layer-1 fragments (all in AGPRs) and streams layer 0.
-    // Backward: sk[0] counts stationary K-chunks (of 16) of the delta_1 -> g_x GEMM.  kp0 = 128: half
-    // of them (2 n-tiles per wave); kp0 = 16 (lq): all 16 (1 tile, wave 0); anything else streams.
+    // Backward: sk[0] counts stationary K-chunks (of 16) of the delta_1 -> g_x GEMM.  kp0 = 128: 12 of
+    // them (2 n-tiles per wave; 14 spills); kp0 = 16 (lq): all 16 (1 tile, wave 0); anything else streams.
     // The backward's stationary variants also stage this step's H_2 / H_1 tiles in LDS: exactly two hidden layers.
     if (backward && M.nl != 3) { sk[0] = sk[1] = 0; return; }
-    if (backward) sk[0] = (sk[1] == 16 && M.kp[0] == 128) ? 8 : ((sk[1] == 16 && M.kp[0] == 16) ? 16 : 0);
+    if (backward) sk[0] = (sk[1] == 16 && M.kp[0] == 128) ? 12 : ((sk[1] == 16 && M.kp[0] == 16) ? 16 : 0);
     // tuning knob (benchmarks only): GOPS_SK="0,0" forces the streamed kernels, "0,16" layer 1 only
     if (const char* e = getenv("GOPS_SK")) {
         int a = -1, b = -1;

@@ -392,14 +392,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
             const int P = p.env.pre_horizon;
             float th0 = 0.f, th1 = 0.f, dflag = 1.f;
             float s[6] = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f};
+            f32x4 e3 = {0.f, 1.f, 0.f, 1.f};   // sin / cos of the heading before and after the step (forward's values)
             if (m < nvalid) {
                 f32x4 e0, e1, e2;
                 if constexpr (STAGE) {
                     const f32x4* er = reinterpret_cast<const f32x4*>(st_env + m * ENV_STASH);
-                    e0 = er[0]; e1 = er[1]; e2 = er[2];
+                    e0 = er[0]; e1 = er[1]; e2 = er[2]; e3 = er[3];
                 } else {
                     const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
-                    e0 = er[0]; e1 = er[1]; e2 = er[2];
+                    e0 = er[0]; e1 = er[1]; e2 = er[2]; e3 = er[3];
                 }
                 th0 = e0[0]; th1 = e0[1]; dflag = e1[0];
                 s[0] = e1[1]; s[1] = e1[2]; s[2] = e1[3]; s[3] = e2[0]; s[4] = e2[1]; s[5] = e2[2];
@@ -412,11 +413,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
             const float steer = wrap_action(p.env, 0, abar0), ax = wrap_action(p.env, 1, abar1);
             float sn[6];
             VehStep w;
-            sincosf(s[2], &w.sphi, &w.cphi);
+            w.sphi = e3[0]; w.cphi = e3[1];
             veh_f_xu(VC, s, steer, ax, sn, w);
-            float cn, snn;
-            sincosf(sn[2], &snn, &cn);
-            snn = -snn;   // cos(-phi') = cos(phi'), sin(-phi') = -sin(phi')
+            const float cn = e3[3], snn = -e3[2];   // cos(-phi') = cos(phi'), sin(-phi') = -sin(phi')
             // partial adjoints of (x', y', phi', u') and of cos/sin(-phi') over this thread's points
             float px = 0.f, py = 0.f, pphi = 0.f, pu = 0.f, pc = 0.f, ps = 0.f, g4 = 0.f, g5 = 0.f;
             const f32x4* tbl = s_ref + m * TL + (t + 1);

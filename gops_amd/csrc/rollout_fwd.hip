@@ -290,7 +290,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
                 r = veh_reward(o, steer, ax);
             }
             __syncthreads();   // every read of the old obs / state is done
+            const float s_old = veh_s, c_old = veh_c;
             sincosf(sn[2], &veh_s, &veh_c);                 // also next step's f_xu heading terms
+            if (p.need_grad && tid < TB) {   // 4th quad of the env stash row: the backward sweep reuses both sin / cos pairs
+                const f32x4 e3 = {s_old, c_old, veh_s, veh_c};
+                gptr(reinterpret_cast<f32x4*>(p.st.env + (row0 + tid) * ENV_STASH))[3] = e3;
+            }
             const float cn = veh_c, snn = -veh_s;           // cos(-phi'), sin(-phi')
             const f32x4* tbl = s_ref + m * TL + (t + 1);
             for (int j = part; j <= P; j += 16) {

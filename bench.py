@@ -120,8 +120,11 @@ def pmc_traffic(kernel_key):
         return None
     pmc = json.load(open(os.path.join(pdir, files[-1])))
     for name, c in pmc.items():
-        if kernel_key in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return {"bytes": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "source": "profiles/" + files[-1]}
+        if kernel_key in name and "WRITE_SIZE" in c and ("FETCH_SIZE" in c or "TCC_EA0_RDREQ_sum" in c):
+            # reads: FETCH_SIZE (KiB, x2 on gfx950) or, where that pass was unavailable, the L2's HBM-side read
+            # requests x 128 B (the two agree to 0.1 % where both were collected)
+            rd = 2.0 * c["FETCH_SIZE"] * 1024.0 if "FETCH_SIZE" in c else c["TCC_EA0_RDREQ_sum"] * 128.0
+            return {"bytes": rd + c["WRITE_SIZE"] * 1024.0, "source": "profiles/" + files[-1]}
     return None
 
 

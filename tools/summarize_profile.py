@@ -33,9 +33,13 @@ prev_path = os.path.join(dst, f"{tag}_pmc_per_launch.json")
 if os.path.exists(prev_path):
     prev = json.load(open(prev_path))
     for k, c in pmc.items():
+        # same kernel, or the same kernel template under other (tuning) arguments
+        old = prev.get(k) or next((v for pk, v in prev.items() if pk.split("<")[0] == k.split("<")[0]), {})
         for name in ("FETCH_SIZE", "WRITE_SIZE"):
-            if name not in c and name in prev.get(k, {}):
-                c[name] = prev[k][name]
+            if name not in c and name in old:
+                if name == "FETCH_SIZE" and "TCC_EA0_RDREQ_sum" in c:
+                    continue   # a current read figure exists (L2's HBM-side read requests x 128 B)
+                c[name] = old[name]
                 c["carried_over"] = sorted(set(c.get("carried_over", []) + [name]))
 json.dump(pmc, open(prev_path, "w"), indent=1)
 

@@ -1,5 +1,7 @@
+"""Three updates of the target workload (veh3dof FHADP, B=4096, H=30) - the driver for the in-kernel phase
+counters:  make -C gops_amd/csrc -B DBG=1 && GOPS_DBG_TIMING=1 python tools/dbg_run.py   (stderr shows cycles / step)."""
 import sys, torch, contextlib
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from bench import alg_kwargs
 from gops_amd.create_pkg.create_alg import create_alg
 from gops_amd.utils.synthetic import CONFIGS, make_batch

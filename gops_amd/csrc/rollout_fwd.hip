@@ -31,6 +31,10 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
         const float* bias = s_bias + j * ldh;   // LDS copy of the layer's bias
         const bool save_z = (stash_z != nullptr) && (M.act == GOPS_ACT_GELU);
         float* zrow = save_z ? stash_z[j + 1] + row0 * N : nullptr;
+        // The activation tile goes to the stash straight from the epilogue registers (fire-and-forget
+        // 64-byte row segments; a wave's four n-tiles make 256 contiguous bytes per row) instead of a
+        // separate LDS -> register -> global pass after the barrier.
+        float* hrow = (stash_h != nullptr) ? stash_h[j + 1] + row0 * N : nullptr;
         auto epi = [&]<int CNT>(const f32x4 (&acc)[4], int nt0) {
             DBG_TICK(14)
             act_dispatch(M.act, [&]<int ACT>() {
@@ -44,7 +48,9 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
                     for (int r = 0; r < 4; ++r) {
                         const int m = ((lane >> 4) << 2) + r;
                         const float z = acc[q][r] + bn[q];
-                        out[m * ldh + n] = act_fwd_t<ACT>(z);
+                        const float h = act_fwd_t<ACT>(z);
+                        out[m * ldh + n] = h;
+                        if (hrow != nullptr && m < stash_rows) __builtin_nontemporal_store(h, gptr(hrow) + (size_t)m * N + n);
                         if (ACT == GOPS_ACT_GELU && save_z && m < nvalid) gptr(zrow)[(size_t)m * N + n] = z;
                     }
                 }
@@ -61,7 +67,6 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
         DBG_TICK(8 + 3 * (j & 1))
         __syncthreads();
         DBG_TICK(9 + 3 * (j & 1))
-        if (stash_h != nullptr) stash_tile(out, ldh, N, stash_h[j + 1], row0, stash_rows, tid);
         DBG_TICK(10 + 3 * (j & 1))
         cur = out;
         ldc = ldh;

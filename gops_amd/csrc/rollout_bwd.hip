@@ -54,6 +54,9 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dv[e] = (hm < nvalid) ? acc[e] * act_bwd_t<ACT>(hv[e], hv[e]) : 0.f;
                     *reinterpret_cast<f32x4*>(da + hm * ldh + k) = dv;
+                    // the delta tile goes to the stash from the registers that produced it
+                    if (stash_d != nullptr)
+                        __builtin_nontemporal_store(dv, gptr(reinterpret_cast<f32x4*>(stash_d[L] + (row0 + hm) * K + k)));
                 }
             } else {
                 for (int k = hp; k < K; k += 16) {
@@ -67,6 +70,7 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
                         dv = acc * act_bwd_t<ACT>(v, v);
                     }
                     da[hm * ldh + k] = dv;
+                    if (stash_d != nullptr) gptr(stash_d[L])[(row0 + hm) * K + k] = dv;
                 }
             }
         });
@@ -81,7 +85,6 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
     DBG_TICK(3)
     __syncthreads();
     DBG_TICK(4)
-    if (stash_d != nullptr) stash_tile(da, ldh, M.dims[L], stash_d[L], row0, TB, tid);
     after_head();   // long stretch without dependent global loads ahead: the caller's prefetches go here
     DBG_TICK(5)
     float* cur = da;

@@ -342,3 +342,50 @@ def test_shape_sweep_matches_oracle(cfg, dev):
     flat = torch.cat([x.reshape(-1).cpu() for x in grads])
     flat_ref = torch.cat([x.reshape(-1) for x in ref["grads"]])
     assert rel_l2(flat, flat_ref) < TOL, rel_l2(flat, flat_ref)
+
+
+_STATIONARY = [  # 256-256 policies on <= 256 tiles: the register-stationary / LDS-staged kernel variants of every env
+    dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=200, horizon=12, hidden=(256, 256), act="gelu", gamma=0.99),
+    dict(alg="FHADP", env_id="pyth_lq", lq_config="s6a3", batch=77, horizon=9, hidden=(256, 256), act="tanh", gamma=1.0),
+    dict(alg="FHADP", env_id="pyth_idpendulum", batch=130, horizon=14, hidden=(256, 256), act="elu", gamma=1.0),
+    dict(alg="FHADP", env_id="pyth_veh3dofconti", pre_horizon=10, batch=90, horizon=10, hidden=(256, 256), act="relu", gamma=0.97),
+    dict(alg="FHADP", env_id="pyth_veh3dofconti", pre_horizon=30, batch=40, horizon=1, hidden=(256, 256), act="gelu", gamma=1.0),
+    dict(alg="INFADP", env_id="pyth_veh3dofconti", pre_horizon=10, batch=64, horizon=6, hidden=(256, 256), act="elu", gamma=0.99),
+    dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=100, horizon=7, hidden=(256, 256), act="relu", gamma=0.99),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", _STATIONARY, ids=lambda c: f"{c['alg']}-{c['env_id'][5:]}-{c.get('lq_config', c.get('pre_horizon', ''))}-{c['act']}")
+def test_stationary_staged_variants_match_oracle(cfg, dev):
+    """Small batches of 256-256 policies select the one-workgroup-per-CU kernels (weights in registers,
+    backward stash tiles copied to LDS one step ahead) for every env, closed loop and with INFADP's tail value."""
+    from gops_amd import hip_backend as hb
+    seed = 17 + cfg["batch"]
+    data = make_batch(cfg, seed)
+    data["done"][::5] = 1.0
+    nets = reference_init_nets(cfg, seed, obs_dim_of(cfg), act_dim_of(cfg))
+    env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
+    if cfg["alg"] == "FHADP":
+        res, grads = _run_fhadp(env, nets, data, cfg, dev)
+        ref = orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+        assert rel_l2(res["rewards"].cpu(), ref["rewards"]) < TOL
+    else:
+        B = cfg["batch"]
+        ddev = to_device(data, dev)
+        pol, pw, pb = hip_mlp_from_net(nets["policy"], dev)
+        vt, _, _ = hip_mlp_from_net(nets["v_target"], dev)
+        ro = hb.Rollout(hip_env_from_oracle(env, nets["policy"]), pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"],
+                        finite_horizon=False, need_grad=True, value=vt)
+        res = ro.forward(ddev)
+        gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]
+        ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
+        torch.cuda.synchronize()
+        grads = [t for pair in zip(gw, gb) for t in pair]
+        ref = orc.infadp_pim_gradient(env, nets["policy"], nets["v_target"], data, cfg["horizon"], cfg["gamma"])
+        assert abs(-res["v_pi"].double().mean().item() - ref["loss"].item()) <= TOL * max(1.0, abs(ref["loss"].item()))
+    if "v_pi" in ref:
+        assert rel_l2(res["v_pi"].cpu(), ref["v_pi"]) < TOL
+    flat = torch.cat([x.reshape(-1).cpu() for x in grads])
+    flat_ref = torch.cat([x.reshape(-1) for x in ref["grads"]])
+    assert rel_l2(flat, flat_ref) < TOL, rel_l2(flat, flat_ref)

@@ -259,12 +259,11 @@ class Rollout:
             assert head_pre is not None and tuple(head_pre.shape) == (B, H, d.env.act_dim)
             i.head_pre = _ptr(head_pre)
             self._head_pre = head_pre
-        if self._keep is not data:   # same batch dict object as last call: pointers already bound
-            i.obs, i.done = _ptr(data["obs"]), _ptr(data.get("done"))
-            if d.env.kind == ENV_VEH:
-                for k in ("state", "ref_points", "path_num", "u_num", "ref_time"):
-                    setattr(i, k, _ptr(data[k]))
-            self._keep = data
+        i.obs, i.done = _ptr(data["obs"]), _ptr(data.get("done"))
+        if d.env.kind == ENV_VEH:
+            for k in ("state", "ref_points", "path_num", "u_num", "ref_time"):
+                setattr(i, k, _ptr(data[k]))
+        self._keep = dict(data)   # the kernels (and a later backward) read these tensors: keep them alive
         out = GopsRolloutOut()
         res = {"v_pi": torch.empty(B, dtype=torch.float32, device=self.device)}
         out.v_pi = _ptr(res["v_pi"])

@@ -55,11 +55,8 @@ class GradAllReducer:
         in_place = flat is not None
         if not in_place:
             flat = _flatten_dense_tensors(tensors)
-        if dist.get_backend(self.group) == "nccl":     # RCCL averages inside the collective
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.div_(n)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)   # SUM + scale: valid on every backend / RCCL build
+        flat.div_(n)
         if not in_place:
             torch._foreach_copy_(tensors, list(_unflatten_dense_tensors(flat, tensors)))
         return update_info

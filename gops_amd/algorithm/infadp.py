@@ -17,6 +17,7 @@ from gops_amd.utils.common_utils import make_adam
 from gops_amd import hip_backend as hb
 from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, batch_to_device, cuda_device_of,
                                      grad_buffers)
+from gops_amd.utils.hip_graph import StepGraphCache
 from gops_amd.create_pkg.create_apprfunc import create_apprfunc
 from gops_amd.create_pkg.create_env_model import create_env_model
 from gops_amd.utils.common_utils import get_apprfunc_dict
@@ -62,13 +63,29 @@ class INFADP(AlgorithmBase):
         self.forward_step = 10
         self.tb_info = dict()
         self._cache = {}
+        self._graphs = {}
 
     @property
     def adjustable_parameters(self):
         return ("gamma", "tau", "pev_step", "pim_step", "forward_step", "reward_scale")
 
     def local_update(self, data: dict, iteration: int) -> dict:
-        self._update(self._compute_gradient(data, iteration))
+        # gradient + Adam + Polyak of the iteration's mode as one HIP graph when the update is launch-bound
+        # (replay batches of the shipped examples are 64-256 samples); eager kernels otherwise
+        start_time = time.time()
+        batch = batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
+        mode = self._mode(iteration)
+        opt = self.networks.optimizer_dict[mode]
+
+        def update(b):
+            scalars = self._gradient_kernels(mode, b)
+            self._update([mode])
+            return scalars
+
+        cache = self._graphs.setdefault(mode, StepGraphCache())
+        scalars = cache.run(self._signature(mode, batch), batch, update, before_replay=opt.sync_hyper,
+                            on_replay=opt.advance, work=batch["obs"].shape[0] * self.forward_step)
+        self._log(mode, scalars, start_time)
         return self.tb_info
 
     def get_remote_update_info(self, data: dict, iteration: int) -> Tuple[dict, dict]:
@@ -118,12 +135,14 @@ class INFADP(AlgorithmBase):
             vn.mlp = mlp
         return vn
 
-    def _compute_gradient(self, data, iteration):
-        start_time = time.time()
-        device = cuda_device_of(self.networks)
-        batch = batch_to_device(data, device, ("obs", "done") + _INFO_KEYS)
-        B = batch["obs"].shape[0]
-        if iteration % (self.pev_step + self.pim_step) < self.pev_step:
+    def _mode(self, iteration) -> str:
+        return "v" if iteration % (self.pev_step + self.pim_step) < self.pev_step else "policy"
+
+    def _gradient_kernels(self, mode: str, batch) -> torch.Tensor:
+        """Enqueue one policy-evaluation ("v") or policy-improvement ("policy") gradient; returns the
+        device scalars the log needs ([loss_v, mean V] / [loss_policy]) without synchronising."""
+        B, device = batch["obs"].shape[0], batch["obs"].device
+        if mode == "v":
             # PEV: loss_v = mean((V(o) - [sum_t gamma^t r_t + (~d) gamma^n V_target(o_n)])^2)
             backup = self._rollout_for(B, device, need_grad=False).forward(batch)["v_pi"]
             vn = self._value_for(B, device)
@@ -131,16 +150,38 @@ class INFADP(AlgorithmBase):
             diff = v - backup
             gw, gb = grad_buffers(self.networks.v)
             vn.backward(batch["obs"], (2.0 / B) * diff, gw, gb)
-            self.tb_info[tb_tags["loss_critic"]] = (diff * diff).mean().item()
-            self.tb_info[tb_tags["critic_avg_value"]] = v.mean().item()
-            update_list = ["v"]
+            return torch.stack(((diff * diff).mean(), v.mean()))
+        # PIM: loss = -mean(sum_t gamma^t r_t + (~d) gamma^n V_target(o_n)), grads into the policy
+        ro = self._rollout_for(B, device, need_grad=True)
+        v_pi = ro.forward(batch)["v_pi"]
+        gw, gb = grad_buffers(self.networks.policy)
+        ro.backward(self._grad_v(B, device), gw, gb)
+        return (-v_pi.mean()).reshape(1)
+
+    def _grad_v(self, B, device):
+        gv = getattr(self, "_gv", None)
+        if gv is None or gv.shape[0] != B or gv.device != device:
+            gv = self._gv = torch.full((B,), -1.0 / B, dtype=torch.float32, device=device)
+        return gv
+
+    def _log(self, mode: str, scalars: torch.Tensor, start_time: float):
+        vals = scalars.tolist()   # host sync, as in the reference
+        if mode == "v":
+            self.tb_info[tb_tags["loss_critic"]], self.tb_info[tb_tags["critic_avg_value"]] = vals
         else:
-            # PIM: loss = -mean(sum_t gamma^t r_t + (~d) gamma^n V_target(o_n)), grads into the policy
-            ro = self._rollout_for(B, device, need_grad=True)
-            v_pi = ro.forward(batch)["v_pi"]
-            gw, gb = grad_buffers(self.networks.policy)
-            ro.backward(torch.full((B,), -1.0 / B, dtype=torch.float32, device=device), gw, gb)
-            self.tb_info[tb_tags["loss_actor"]] = (-v_pi.mean()).item()
-            update_list = ["policy"]
+            self.tb_info[tb_tags["loss_actor"]] = vals[0]
         self.tb_info[tb_tags["alg_time"]] = (time.time() - start_time) * 1000  # ms
-        return update_list
+
+    def _compute_gradient(self, data, iteration):
+        start_time = time.time()
+        batch = batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
+        mode = self._mode(iteration)
+        self._log(mode, self._gradient_kernels(mode, batch), start_time)
+        return [mode]
+
+    def _signature(self, mode, batch):
+        nets = self.networks
+        mods = (nets.v, nets.v_target, nets.policy) if mode == "v" else (nets.policy, nets.policy_target, nets.v_target)
+        return (mode, tuple((k, tuple(v.shape)) for k, v in batch.items()), self.forward_step, float(self.gamma),
+                float(self.tau), tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr())
+                                       for m in mods for p in m.parameters()))

@@ -311,3 +311,31 @@ def test_device_env_sampler_closed_loop(env_id, tmp_path):
         trainer.step()
         trainer.iteration += 1
     assert len(buf) >= 1000 + 5 * n and np.isfinite(alg.tb_info["Loss/Actor loss-RL iter"])
+
+
+@pytest.mark.gpu
+def test_infadp_graph_replay_matches_eager_updates(monkeypatch):
+    """INFADP's PEV and PIM updates (gradient + Adam + Polyak) captured as HIP graphs replay exactly
+    the eager updates: two learners stay bit-identical over alternating iterations and fresh batches."""
+    from gops_amd.utils.synthetic import make_batch
+    cfg = dict(alg="INFADP", env_id="pyth_idpendulum", batch=96, horizon=8, hidden=(64, 64), act="gelu", gamma=0.99)
+    algs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GOPS_HIP_GRAPH", flag)
+        torch.manual_seed(9)
+        alg = create_alg(**_kwargs(cfg, {}, 9))
+        alg.forward_step = cfg["horizon"]
+        alg.networks.to("cuda")
+        algs.append(alg)
+    for it in range(12):
+        data = {k: v.cuda() for k, v in make_batch(cfg, 70 + it).items()}
+        infos = []
+        for alg, flag in zip(algs, ("1", "0")):
+            monkeypatch.setenv("GOPS_HIP_GRAPH", flag)
+            infos.append(dict(alg.local_update(data, it)))
+        strip = lambda d: {k: v for k, v in d.items() if "time" not in k.lower()}
+        assert strip(infos[0]) == strip(infos[1])
+    assert all(c.graph is not None for c in algs[0]._graphs.values()) and len(algs[0]._graphs) == 2
+    assert all(c.graph is None for c in algs[1]._graphs.values())
+    for a, b in zip(algs[0].networks.parameters(), algs[1].networks.parameters()):
+        assert torch.equal(a, b)

@@ -7,30 +7,21 @@ keyword arguments select the wrappers).  Where the reference nests one Python ob
 chain is a set of constants on ONE object, because the whole chain is evaluated inside the HIP
 kernels (csrc/common.h wrap_action, csrc/rollout_fwd.hip).
 """
-import importlib
 import os
-from dataclasses import dataclass, field
 from typing import Callable, Dict, Optional, Tuple, Union
 
 import numpy as np
 import torch
 
 from gops_amd import hip_backend as hb
+from gops_amd.create_pkg._registry import Registry
 from gops_amd.utils.gops_path import env_path, underline2camel
 
-
-@dataclass
-class Spec:
-    env_id: str
-    entry_point: Callable
-    kwargs: dict = field(default_factory=dict)
-
-
-registry: Dict[str, Spec] = {}
+registry = Registry("env")
 
 
 def register(env_id: str, entry_point: Union[Callable, str], **kwargs):
-    registry[env_id] = Spec(env_id=env_id, entry_point=entry_point, kwargs=kwargs)
+    registry.add(env_id, entry_point, kwargs, env_id=env_id)
 
 
 class WrappedEnvModel:
@@ -106,16 +97,7 @@ def create_env_model(
 ) -> object:
     """Build the model `<env_id>_model` and apply the wrappers selected by the arguments (same
     arguments, defaults and KeyError/RuntimeError behaviour as the reference)."""
-    env_model_id = env_id + "_model"
-    spec_ = registry.get(env_model_id)
-    if spec_ is None:
-        raise KeyError(f"No registered env with id: {env_model_id}")
-    _kwargs = spec_.kwargs.copy()
-    _kwargs.update(kwargs)
-    _kwargs["device"] = "cuda" if _kwargs.get("use_gpu", False) else "cpu"
-    if not callable(spec_.entry_point):
-        raise RuntimeError(f"{spec_.env_id} registered but entry_point is not specified")
-    env_model = spec_.entry_point(**_kwargs)
+    env_model = registry.build(env_id + "_model", **kwargs, device="cuda" if kwargs.get("use_gpu", False) else "cpu")
 
     # wrapper options outside the fused kernels' contract are refused, never silently ignored
     if repeat_num is not None:
@@ -136,18 +118,17 @@ def create_env_model(
         reward_shift=(0.0 if reward_shift is None else reward_shift) if shaping else None)
 
 
-# fill the registry: every env/env_*/env_model/<id>.py exporting env_model_creator or <Id>
+# fill the registry: every env/env_*/env_model/<id>.py exporting env_model_creator or the CamelCase class
+def _model_entries(stem, module):
+    ctor = getattr(module, "env_model_creator", None) or getattr(module, underline2camel(stem), None)
+    if ctor is None:
+        print(f"env {stem} has no env_model_creator or {underline2camel(stem)}")
+        return
+    yield stem, ctor, dict(env_id=stem)
+
+
 for _env_dir in sorted(e for e in os.listdir(env_path) if e.startswith("env_")):
     _model_dir = os.path.join(env_path, _env_dir, "env_model")
-    if not os.path.exists(_model_dir):
-        continue
-    for _file in sorted(os.listdir(_model_dir)):
-        if _file.endswith(".py") and _file[0] != "_" and "base" not in _file:
-            _id = _file[:-3]
-            _mdl = importlib.import_module(f"gops_amd.env.{_env_dir}.env_model.{_id}")
-            if hasattr(_mdl, "env_model_creator"):
-                register(env_id=_id, entry_point=getattr(_mdl, "env_model_creator"))
-            elif hasattr(_mdl, underline2camel(_id)):
-                register(env_id=_id, entry_point=getattr(_mdl, underline2camel(_id)))
-            else:
-                print(f"env {_id} has no env_model_creator or {underline2camel(_id)} in {_env_dir}")
+    if os.path.isdir(_model_dir):
+        registry.scan(_model_dir, f"gops_amd.env.{_env_dir}.env_model", _model_entries,
+                      keep=lambda stem: "base" not in stem)

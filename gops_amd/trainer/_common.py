@@ -1,0 +1,98 @@
+"""What every trainer of this package does around an update: running means of the sampler's log values,
+periodic TensorBoard logging, checkpoints (`apprfunc/apprfunc_{it}.pkl`, best-so-far `*_opt.pkl`) and
+in-process evaluation.  File names, intervals and tags follow the reference trainers
+(gops/trainer/on_serial_trainer.py:30-152, off_serial_trainer.py:30-188); the networks live on the GPU
+for the whole run and the evaluator is called directly (no Ray actor)."""
+import os
+import time
+from math import inf
+
+import torch
+
+from gops_amd.utils.tensorboard_setup import add_scalars, make_writer, tb_tags
+
+
+class RunningMean:
+    """Running mean of the sampler's tb dicts between two log points."""
+
+    def __init__(self):
+        self.data, self.n = {}, 0
+
+    def add_average(self, d: dict):
+        self.n += 1
+        for k, v in d.items():
+            self.data[k] = self.data.get(k, 0.0) + (v - self.data.get(k, 0.0)) / self.n
+
+    def pop(self) -> dict:
+        out, self.data, self.n = self.data, {}, 0
+        return out
+
+
+class TrainerBase:
+    def __init__(self, alg, sampler, evaluator, **kwargs):
+        self.alg, self.sampler, self.evaluator = alg, sampler, evaluator
+        self.networks = self.alg.networks
+        if self.sampler is not None:
+            self.sampler.networks = self.networks
+        if kwargs.get("ini_network_dir") is not None:
+            self.networks.load_state_dict(torch.load(kwargs["ini_network_dir"]))
+        self.max_iteration = kwargs.get("max_iteration")
+        self.log_save_interval = kwargs["log_save_interval"]
+        self.apprfunc_save_interval = kwargs["apprfunc_save_interval"]
+        self.eval_interval = kwargs["eval_interval"]
+        self.save_folder = kwargs["save_folder"]
+        self.use_gpu = kwargs.get("use_gpu", True)
+        self.best_tar = -inf
+        self.iteration = 0
+        self.last_eval_iteration = 0
+        self.writer = make_writer(self.save_folder) if self.save_folder else None
+        add_scalars({tb_tags["alg_time"]: 0, tb_tags["sampler_time"]: 0}, self.writer, 0)
+        self.sampler_tb_dict = RunningMean()
+        self.start_time = time.time()
+
+    # ---- one iteration = subclass `step()`, then this -------------------------------------------
+    def _after_update(self, alg_tb_dict):
+        if self.iteration % self.log_save_interval == 0:
+            print("Iter = ", self.iteration)
+            add_scalars(alg_tb_dict, self.writer, step=self.iteration)
+            add_scalars(self.sampler_tb_dict.pop(), self.writer, step=self.iteration)
+        if self.iteration % self.apprfunc_save_interval == 0:
+            self.save_apprfunc()
+        if self.evaluator is not None and self.iteration - self.last_eval_iteration >= self.eval_interval:
+            self._evaluate()
+
+    def _apprfunc_dir(self):
+        folder = os.path.join(self.save_folder, "apprfunc")
+        os.makedirs(folder, exist_ok=True)
+        return folder
+
+    def _evaluate(self):
+        self.evaluator.load_state_dict({k: v.cpu() for k, v in self.networks.state_dict().items()})
+        total_avg_return = self.evaluator.run_evaluation(self.iteration)
+        self.last_eval_iteration = self.iteration
+        if total_avg_return >= self.best_tar and self.iteration >= self.max_iteration / 5:
+            self.best_tar = total_avg_return
+            print("Best return = {}!".format(str(self.best_tar)))
+            folder = self._apprfunc_dir()
+            for filename in os.listdir(folder):
+                if filename.endswith("_opt.pkl"):
+                    os.remove(os.path.join(folder, filename))
+            torch.save(self.networks.state_dict(), os.path.join(folder, "apprfunc_{}_opt.pkl".format(self.iteration)))
+        if self.writer is not None:
+            self.writer.add_scalar(tb_tags["TAR of RL iteration"], total_avg_return, self.iteration)
+            self.writer.add_scalar(tb_tags["TAR of total time"], total_avg_return, int(time.time() - self.start_time))
+            self.writer.add_scalar(tb_tags["TAR of collected samples"], total_avg_return,
+                                   self.sampler.get_total_sample_number())
+
+    def train(self):
+        while self.iteration < self.max_iteration:
+            self.step()
+            self.iteration += 1
+        self.save_apprfunc()
+        if self.writer is not None:
+            self.writer.flush()
+
+    def save_apprfunc(self):
+        if self.save_folder:
+            torch.save(self.networks.state_dict(),
+                       os.path.join(self._apprfunc_dir(), "apprfunc_{}.pkl".format(self.iteration)))

@@ -11,12 +11,12 @@ ModuleOnDevice, :81); the evaluator runs in-process (no Ray).
 import copy
 import time
 
-from gops_amd.trainer.on_serial_trainer import OnSerialTrainer
+from gops_amd.trainer._common import TrainerBase
 
 __all__ = ["OffSerialTrainer"]
 
 
-class OffSerialTrainer(OnSerialTrainer):
+class OffSerialTrainer(TrainerBase):
     def __init__(self, alg, sampler, buffer, evaluator, **kwargs):
         super().__init__(alg, sampler, evaluator, **kwargs)
         self.buffer = buffer

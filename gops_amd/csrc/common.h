@@ -155,6 +155,34 @@ __device__ __forceinline__ void act_dispatch(int kind, F&& body) {
 // ---- wrapper chain on the action (ScaleActionModel -> ClipActionModel) -----------------------
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
+// Per-action constants staged in LDS ([GOPS_MAX_ACT][8]: sc, of, min_action, max_action, act_low,
+// act_high) so that lane `a` of a 16-lane group can squash + wrap action `a` with a lane-dependent index
+// (the parameter block is only addressable with wave-uniform indices): all actions of a trajectory are
+// then processed in parallel lanes instead of one after the other.
+struct ActC {
+    float sc, of, min_action, max_action, act_low, act_high;   // abar = sc * tanh(y) + of, then the wrapper chain
+};
+__device__ __forceinline__ void stage_act_const(const GopsEnv& e, float* s_ac, int tid) {
+    if (tid < GOPS_MAX_ACT) {
+        float* c = s_ac + tid * 8;
+        c[0] = (e.policy_high[tid] - e.policy_low[tid]) / 2.f;
+        c[1] = (e.policy_high[tid] + e.policy_low[tid]) / 2.f;
+        c[2] = e.min_action[tid]; c[3] = e.max_action[tid];
+        c[4] = e.act_low[tid]; c[5] = e.act_high[tid];
+        c[6] = c[7] = 0.f;
+    }
+}
+__device__ __forceinline__ ActC act_const(const float* s_ac, int a) {
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(s_ac + a * 8), c1 = *reinterpret_cast<const f32x4*>(s_ac + a * 8 + 4);
+    return ActC{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1]};
+}
+__device__ __forceinline__ float wrap_action(const ActC& e, float abar) {   // same arithmetic as the GopsEnv form below
+    const float a1 = clampf(abar, e.min_action, e.max_action);
+    const float a2 = e.act_low + (e.act_high - e.act_low) * ((a1 - e.min_action) / (e.max_action - e.min_action));
+    const float a3 = clampf(a2, e.act_low, e.act_high);
+    return clampf(a3, e.act_low, e.act_high);
+}
+
 __device__ __forceinline__ float wrap_action(const GopsEnv& e, int i, float abar) {
     const float a1 = clampf(abar, e.min_action[i], e.max_action[i]);
     const float a2 = e.act_low[i] + (e.act_high[i] - e.act_low[i]) *

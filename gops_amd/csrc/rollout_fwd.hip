@@ -132,7 +132,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
     float* s_th = s_act + TB * 4;           // [TB][4] tanh(head) (ENV_NONE: raw head output)
     float* s_done = s_th + TB * 4;          // [TB]
     float* s_bo = s_done + TB;              // [4]  head bias
-    float* s_wo = s_bo + TB;                // [4][ldh] head weights (16-float gap keeps 16 B alignment)
+    float* s_ac = s_bo + TB;                // [4][8] per-action constants (stage_act_const)
+    float* s_wo = s_ac + 2 * TB;            // [4][ldh] head weights
     float* s_bias = s_wo + 4 * ldh;         // [GOPS_MAX_LAYERS-1][ldh] hidden-layer biases
     f32x4* s_ref = reinterpret_cast<f32x4*>(s_bias + (GOPS_MAX_LAYERS - 1) * ldh);   // veh: [TB][TL]
     const int TL = p.env.pre_horizon + 1 + p.H;   // reference-table points per trajectory
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
             s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
         }
         if (tid < Ao) s_bo[tid] = gptr(p.pol.b[Lh])[tid];
+        stage_act_const(p.env, s_ac, tid);
         for (int j = 0; j < Lh; ++j)
             for (int n = tid; n < p.pol.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = gptr(p.pol.b[j])[n];
         if (ENV == GOPS_ENV_VEH3DOFCONTI) {
@@ -193,27 +195,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
                                                  row0, nvalid, TB, dbg);
                 DBG_TICK(2)
                 mlp_head(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ldh, tid, y);
-            } else if ((tid & 15) == 0 && (tid >> 4) < nvalid) {
-                // open loop (FHADP2): the action sequence was emitted by one MLP evaluation outside
-                const GLOBAL_AS float* hp = gptr(p.in.head_pre) + ((size_t)(b0 + (tid >> 4)) * p.H + t) * A;
-#pragma unroll
-                for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                    if (a < A) y[a] = hp[a];
             }
-            if ((tid & 15) == 0) {
-                const int hm = tid >> 4;
-#pragma unroll
-                for (int a = 0; a < GOPS_MAX_ACT; ++a) {
-                    if (a < A) {
-                        if (ENV == GOPS_ENV_NONE) {
-                            s_th[hm * 4 + a] = y[a];
-                        } else {
-                            const float th = tanhf(y[a]);
-                            const float sc = (p.env.policy_high[a] - p.env.policy_low[a]) / 2.f;
-                            const float of = (p.env.policy_high[a] + p.env.policy_low[a]) / 2.f;
-                            s_th[hm * 4 + a] = th;
-                            s_act[hm * 4 + a] = wrap_action(p.env, a, sc * th + of);
-                        }
+            {   // lane a of each 16-lane trajectory group squashes and wraps action a (row16_sum left y in every lane)
+                const int hm = tid >> 4, la = tid & 15;
+                float ya = (la == 0) ? y[0] : (la == 1) ? y[1] : (la == 2) ? y[2] : y[3];
+                if (p.open_loop && la < A && hm < nvalid)   // FHADP2: the sequence was emitted by one MLP evaluation outside
+                    ya = gptr(p.in.head_pre)[((size_t)(b0 + hm) * p.H + t) * A + la];
+                if (la < A) {
+                    if (ENV == GOPS_ENV_NONE) {
+                        s_th[hm * 4 + la] = ya;
+                    } else {
+                        const ActC c = act_const(s_ac, la);
+                        const float th = tanhf(ya);
+                        s_th[hm * 4 + la] = th;
+                        s_act[hm * 4 + la] = wrap_action(c, c.sc * th + c.of);
                     }
                 }
             }
@@ -376,7 +371,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
 }
 
 size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points) {
-    return sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * (8 + 4 + 4 + 1 + 1) + (4 + GOPS_MAX_LAYERS - 1) * ldh +
+    return sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * (8 + 4 + 4 + 1 + 1 + 2) + (4 + GOPS_MAX_LAYERS - 1) * ldh +
                                     4 * TB * ref_points);
 }
 

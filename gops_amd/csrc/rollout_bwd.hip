@@ -393,7 +393,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
         } else {   // GOPS_ENV_VEH3DOFCONTI
             const int m = tid & 15, part = tid >> 4, lane = tid & 63, wave = tid >> 6;
             const int P = p.env.pre_horizon;
-            float th0 = 0.f, th1 = 0.f, dflag = 1.f;
+            float th0 = 0.f, th1 = 0.f, dflag = 1.f, st_steer = 0.f, st_ax = 0.f;
             float s[6] = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f};
             f32x4 e3 = {0.f, 1.f, 0.f, 1.f};   // sin / cos of the heading before and after the step (forward's values)
             if (m < nvalid) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
                     const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
                     e0 = er[0]; e1 = er[1]; e2 = er[2]; e3 = er[3];
                 }
-                th0 = e0[0]; th1 = e0[1]; dflag = e1[0];
+                th0 = e0[0]; th1 = e0[1]; st_steer = e0[2]; st_ax = e0[3]; dflag = e1[0];
                 s[0] = e1[1]; s[1] = e1[2]; s[2] = e1[3]; s[3] = e2[0]; s[4] = e2[1]; s[5] = e2[2];
             }
             const bool dn = dflag != 0.f;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
             const float sc1 = (p.env.policy_high[1] - p.env.policy_low[1]) / 2.f;
             const float abar0 = sc0 * th0 + (p.env.policy_high[0] + p.env.policy_low[0]) / 2.f;
             const float abar1 = sc1 * th1 + (p.env.policy_high[1] + p.env.policy_low[1]) / 2.f;
-            const float steer = wrap_action(p.env, 0, abar0), ax = wrap_action(p.env, 1, abar1);
+            const float steer = st_steer, ax = st_ax;   // = wrap_action(abar0 / abar1), stashed by the forward kernel
             float sn[6];
             VehStep w;
             w.sphi = e3[0]; w.cphi = e3[1];

@@ -218,6 +218,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
         if (p.need_grad && tid < TB) {   // env stash row: tanh outputs, done_t, state_t
             GLOBAL_AS f32x4* er = gptr(reinterpret_cast<f32x4*>(p.st.env + (row0 + tid) * ENV_STASH));
             f32x4 e0 = {s_th[tid * 4 + 0], s_th[tid * 4 + 1], s_th[tid * 4 + 2], s_th[tid * 4 + 3]};
+            if (ENV == GOPS_ENV_VEH3DOFCONTI) {   // two actions: the free slots carry the wrapped (steer, a_x) for the backward sweep
+                e0[2] = s_act[tid * 4 + 0];
+                e0[3] = s_act[tid * 4 + 1];
+            }
             f32x4 e1 = {s_done[tid], s_state[tid * 8 + 0], s_state[tid * 8 + 1], s_state[tid * 8 + 2]};
             f32x4 e2 = {s_state[tid * 8 + 3], s_state[tid * 8 + 4], s_state[tid * 8 + 5], 0.f};
             er[0] = e0;

@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="target_veh3dof_fhadp_b4096_h30")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16"],
+                    help="arithmetic of the MLP contractions: fp32 (exact, parity path) or fp16 (half-precision MFMA, BASELINE cfg5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager-gpu-baseline", action="store_true",
                     help="also time the oracle restatement as PyTorch eager ops on the GPU (reported inside cpu_baseline)")
@@ -160,7 +162,7 @@ def main():
     cfg = CONFIGS[args.workload]
     torch.manual_seed(0)   # identical random-init weights on every replica
     with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
-        alg = create_alg(**alg_kwargs(cfg, 0))
+        alg = create_alg(**alg_kwargs(cfg, 0), mlp_dtype=args.dtype)
     alg.networks.to(device)
     if cfg["alg"] == "INFADP":   # cfg3 / cfg5: one step = one local_update, PEV and PIM alternate
         alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]

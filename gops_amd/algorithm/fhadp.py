@@ -47,6 +47,8 @@ class FHADP(AlgorithmBase):
         self.envmodel = create_env_model(**kwargs, pre_horizon=pre_horizon)
         self.pre_horizon = pre_horizon
         self.gamma = gamma
+        # arithmetic of the MLP contractions: "fp32" (exact, the 1e-4 parity path) or "fp16" (half-precision MFMA)
+        self.mlp_dtype = kwargs.get("mlp_dtype", "fp32")
         self.tb_info = dict()
         self._rollouts = {}
         self._update_graph, self._grad_graph = StepGraphCache(), StepGraphCache()
@@ -89,13 +91,13 @@ class FHADP(AlgorithmBase):
     # ------------------------------------------------------------------------------------------
     def _rollout_for(self, batch: int, device) -> hb.Rollout:
         policy = self.networks.policy
-        key = (batch, self.pre_horizon, float(self.gamma), str(device))
+        key = (batch, self.pre_horizon, float(self.gamma), str(device), hb.dtype_id(self.mlp_dtype))
         ro = self._rollouts.get(key)
         mlp = policy.hip_mlp()
         if ro is None:
             env = self.envmodel.hip_env(policy.act_low_lim.cpu().numpy(), policy.act_high_lim.cpu().numpy())
             ro = hb.Rollout(env, mlp, batch=batch, horizon=self.pre_horizon, gamma=self.gamma,
-                            finite_horizon=True, need_grad=True, device=device)
+                            finite_horizon=True, need_grad=True, device=device, dtype=self.mlp_dtype)
             self._rollouts = {key: ro}   # one live workspace: shapes rarely change between updates
         else:
             ro.set_policy(mlp)

@@ -61,6 +61,9 @@ class INFADP(AlgorithmBase):
         self.pev_step = 1
         self.pim_step = 1
         self.forward_step = 10
+        # arithmetic of the MLP contractions: "fp32" (exact, the 1e-4 parity path) or "fp16" (half-precision
+        # MFMA, BASELINE.json configs[4])
+        self.mlp_dtype = kwargs.get("mlp_dtype", "fp32")
         self.tb_info = dict()
         self._cache = {}
         self._graphs = {}
@@ -113,21 +116,21 @@ class INFADP(AlgorithmBase):
     # ------------------------------------------------------------------------------------------
     def _rollout_for(self, batch: int, device, need_grad: bool) -> hb.Rollout:
         nets = self.networks
-        key = (batch, self.forward_step, float(self.gamma), str(device), need_grad)
+        key = (batch, self.forward_step, float(self.gamma), str(device), need_grad, hb.dtype_id(self.mlp_dtype))
         pol, vt = nets.policy.hip_mlp(), nets.v_target.hip_mlp()
         ro = self._cache.get(key)
         if ro is None:
             env = self.envmodel.hip_env(nets.policy.act_low_lim.cpu().numpy(), nets.policy.act_high_lim.cpu().numpy())
             ro = hb.Rollout(env, pol, batch=batch, horizon=self.forward_step, gamma=self.gamma,
-                            finite_horizon=False, need_grad=need_grad, value=vt, device=device)
+                            finite_horizon=False, need_grad=need_grad, value=vt, device=device, dtype=self.mlp_dtype)
             self._cache[key] = ro
         else:
             ro.set_policy(pol, vt)
         return ro
 
     def _value_for(self, batch: int, device) -> hb.ValueNet:
-        key = ("v", batch, str(device))
-        mlp = self.networks.v.hip_mlp()
+        key = ("v", batch, str(device), hb.dtype_id(self.mlp_dtype))
+        mlp = self.networks.v.hip_mlp(self.mlp_dtype)
         vn = self._cache.get(key)
         if vn is None:
             vn = self._cache[key] = hb.ValueNet(mlp, batch, device=device)

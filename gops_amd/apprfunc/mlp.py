@@ -9,6 +9,8 @@ in place by the fused HIP rollout (`hip_mlp()`), which never calls `forward`.
 """
 __all__ = ["DetermPolicy", "FiniteHorizonPolicy", "FiniteHorizonFullPolicy", "StateValue"]
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -24,6 +26,11 @@ def mlp(sizes, activation, output_activation=nn.Identity):
     return nn.Sequential(*layers)
 
 
+# ctypes structs (raw device pointers) cannot be pickled / deep-copied, and trainers deep-copy the
+# networks for host-side samplers: the C-ABI views live OUTSIDE the modules, keyed weakly by module.
+_HIP_CACHE = weakref.WeakKeyDictionary()
+
+
 class _HipMlpMixin:
     """Exports the Linear stack as a C-ABI `GopsMlp` over the live parameter storage."""
 
@@ -36,18 +43,18 @@ class _HipMlpMixin:
             object.__setattr__(self, "_linear_cache", layers)
         return layers
 
-    def hip_mlp(self):
+    def hip_mlp(self, dtype=None):
         from gops_amd import hip_backend as hb
         if self._output_activation != "linear":
             raise RuntimeError("the HIP rollout supports a linear output activation only")
         layers = self.linear_layers()
         # the struct only holds raw pointers: rebuild it when the storage moved (.to(device), load)
-        key = tuple(l.weight.data_ptr() for l in layers) + tuple(l.bias.data_ptr() for l in layers)
-        cached = getattr(self, "_hip_mlp_cache", None)
+        key = tuple(l.weight.data_ptr() for l in layers) + tuple(l.bias.data_ptr() for l in layers) + (hb.dtype_id(dtype),)
+        cached = _HIP_CACHE.get(self)
         if cached is None or cached[0] != key:
             mlp = hb.make_mlp([l.weight.data for l in layers], [l.bias.data for l in layers],
-                              self._hidden_activation)
-            object.__setattr__(self, "_hip_mlp_cache", (key, mlp))
+                              self._hidden_activation, dtype)
+            _HIP_CACHE[self] = (key, mlp)
             return mlp
         return cached[1]
 

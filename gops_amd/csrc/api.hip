@@ -12,13 +12,15 @@
 
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);
-size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points);
+size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16);
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points);
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s);
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s);
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
                           int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s);
-hipError_t launch_dw_out(const float* dy, const float* h, int K, int A, long long S, int splits,
+hipError_t launch_dw_gemm_f16(const void* D, int N, const void* X, int Kp, long long S, int splits,
+                              int chunks_per_split, float* part, float* part_b, hipStream_t s);
+hipError_t launch_dw_out(const float* dy, const float* h, bool h_is_half, int K, int A, long long S, int splits,
                          float* part, float* part_b, hipStream_t s);
 void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, int cols, int ld, float* out);
 hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s);
@@ -26,9 +28,21 @@ hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, floa
 hipError_t launch_adam(const GopsAdamTensors& T, GopsAdamState* st, double beta1, double beta2, float eps,
                        hipStream_t s);
 
+// One hipFuncSetAttribute per kernel (common.h: launch_with_lds).
+bool lds_attr_needed(const void* kernel) {
+    static std::mutex mu;
+    static std::vector<const void*> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const void* k : seen)
+        if (k == kernel) return false;
+    seen.push_back(kernel);
+    return true;
+}
+
 namespace {
 
 inline int pad16(int x) { return (x + 15) & ~15; }
+inline int pad32(int x) { return (x + 31) & ~31; }
 constexpr size_t kAlign = 256;   // bytes
 
 // ---- opt-in kernel timing (bench.py) ---------------------------------------------------------
@@ -76,12 +90,13 @@ struct DwPlan {
     bool big;
 };
 
-DwPlan plan_dw(int N, int Kp, long long S) {
+DwPlan plan_dw(int N, int Kp, long long S, bool f16 = false) {
     DwPlan d;
-    d.big = (N >= 128 && Kp >= 128);
+    d.big = f16 || (N >= 128 && Kp >= 128);   // the half-precision GEMM has one tile size (128) and 64-sample chunks
     const int T = d.big ? 128 : 64;
     const int tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
-    const long long chunks = (S + DW_SC_HOST - 1) / DW_SC_HOST;
+    const int sc = f16 ? 64 : DW_SC_HOST;
+    const long long chunks = (S + sc - 1) / sc;
     long long splits = (512 + tiles - 1) / tiles;
     if (splits > chunks) splits = chunks;
     if (splits < 1) splits = 1;
@@ -90,12 +105,12 @@ DwPlan plan_dw(int N, int Kp, long long S) {
     return d;
 }
 
-int check_mlp(const GopsMlp& m, int in_dim, int out_dim) {
+int check_mlp(const GopsMlp& m, int in_dim, int out_dim, bool f16) {
     if (m.n_layers < 2 || m.n_layers > GOPS_MAX_LAYERS) return GOPS_ERR_UNSUPPORTED;
     if (m.sizes[0] != in_dim || m.sizes[m.n_layers] != out_dim) return GOPS_ERR_BAD_ARG;
     if (out_dim < 1 || out_dim > GOPS_MAX_ACT) return GOPS_ERR_UNSUPPORTED;
     for (int j = 1; j < m.n_layers; ++j)
-        if (m.sizes[j] < 16 || (m.sizes[j] & 15)) return GOPS_ERR_UNSUPPORTED;
+        if (m.sizes[j] < 16 || (m.sizes[j] & (f16 ? 63 : 15))) return GOPS_ERR_UNSUPPORTED;
     if (m.hidden_act < GOPS_ACT_LINEAR || m.hidden_act > GOPS_ACT_TANH) return GOPS_ERR_BAD_ARG;
     for (int j = 0; j < m.n_layers; ++j)
         if (m.weight[j] == nullptr || m.bias[j] == nullptr) return GOPS_ERR_BAD_ARG;
@@ -109,13 +124,20 @@ void fill_mlp(MlpDev& d, const GopsMlp& m) {
     for (int j = 0; j <= m.n_layers; ++j) d.dims[j] = m.sizes[j];
     for (int j = 0; j < m.n_layers; ++j) {
         d.kp[j] = pad16(m.sizes[j]);
+        d.kp32[j] = pad32(m.sizes[j]);
         d.w[j] = m.weight[j];
         d.b[j] = m.bias[j];
     }
 }
 
-void carve_packs(Carver& c, MlpDev& d) {
+void carve_packs(Carver& c, MlpDev& d, bool f16) {
     for (int j = 0; j < d.nl - 1; ++j) {
+        if (f16) {   // half fragments: N x kp32 elements each (2 per float)
+            const size_t n = ((size_t)d.dims[j + 1] * d.kp32[j] + 1) / 2;
+            d.wph[j] = reinterpret_cast<const f16x8*>(c.take(n));
+            d.wpth[j] = reinterpret_cast<const f16x8*>(c.take(n));
+            continue;
+        }
         const size_t n = (size_t)d.dims[j + 1] * d.kp[j];
         d.wp[j] = reinterpret_cast<const f32x4*>(c.take(n));
         d.wpt[j] = reinterpret_cast<const f32x4*>(c.take(n));
@@ -141,13 +163,15 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     if (e.kind < GOPS_ENV_NONE || e.kind > GOPS_ENV_VEH3DOFCONTI) return GOPS_ERR_BAD_ARG;
     if (e.obs_dim < 1) return GOPS_ERR_BAD_ARG;
     const int pol_out = (e.kind == GOPS_ENV_NONE) ? 1 : e.act_dim;
+    if (desc.dtype != GOPS_DTYPE_F32 && desc.dtype != GOPS_DTYPE_F16) return GOPS_ERR_BAD_ARG;
+    const bool f16 = desc.dtype == GOPS_DTYPE_F16;
     int rc = GOPS_OK;
     if (desc.open_loop) {   // no policy inside the rollout (FHADP2)
-        if (e.kind == GOPS_ENV_NONE || desc.tail_value || desc.finite_horizon) return GOPS_ERR_BAD_ARG;
-    } else if ((rc = check_mlp(desc.policy, e.obs_dim + (desc.finite_horizon ? 1 : 0), pol_out)) != GOPS_OK) {
+        if (e.kind == GOPS_ENV_NONE || desc.tail_value || desc.finite_horizon || f16) return GOPS_ERR_BAD_ARG;
+    } else if ((rc = check_mlp(desc.policy, e.obs_dim + (desc.finite_horizon ? 1 : 0), pol_out, f16)) != GOPS_OK) {
         return rc;
     }
-    if (desc.tail_value && (rc = check_mlp(desc.value, e.obs_dim, 1)) != GOPS_OK) return rc;
+    if (desc.tail_value && (rc = check_mlp(desc.value, e.obs_dim, 1, f16)) != GOPS_OK) return rc;
     if (e.kind == GOPS_ENV_NONE && (desc.horizon != 1 || desc.tail_value || desc.finite_horizon)) return GOPS_ERR_BAD_ARG;
     if (e.kind == GOPS_ENV_LQ && (e.obs_dim > GOPS_MAX_LQ_STATE || e.act_dim > GOPS_MAX_ACT)) return GOPS_ERR_UNSUPPORTED;
     if (e.kind == GOPS_ENV_IDPENDULUM && (e.obs_dim != 6 || e.act_dim != 1 || e.clip_obs)) return GOPS_ERR_BAD_ARG;
@@ -163,6 +187,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     p.tail = desc.tail_value ? 1 : 0;
     p.env = e;
     p.open_loop = desc.open_loop ? 1 : 0;
+    p.f16 = f16 ? 1 : 0;
     if (p.open_loop) {
         // The kernels keep their tile / stash bookkeeping in terms of a policy: give them the
         // smallest one (obs -> 16 -> act, weights zeroed in the workspace); its layers are never
@@ -188,7 +213,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     p.ldh = hmax + 4;
     const int ref_pts = (e.kind == GOPS_ENV_VEH3DOFCONTI) ? e.pre_horizon + 1 + desc.horizon
                                                           : (e.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
-    if (rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts) > 160 * 1024)
+    if (rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts) > 160 * 1024)
         return GOPS_ERR_UNSUPPORTED;
     for (int t = 0; t <= p.H; ++t) p.gpow[t] = (float)pow(desc.gamma, (double)t);
 
@@ -201,33 +226,37 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         p.pol.w[0] = z; p.pol.b[0] = z + (size_t)16 * p.pol.dims[0];
         p.pol.w[1] = p.pol.b[0] + 16; p.pol.b[1] = p.pol.w[1] + (size_t)p.pol.dims[2] * 16;
     }
-    carve_packs(c, p.pol);
-    if (p.tail) carve_packs(c, p.val);
+    carve_packs(c, p.pol, f16);
+    if (p.tail) carve_packs(c, p.val, f16);
+    if (f16) p.gscale = c.take(4);
     // stash rows: every tile stores all 16 rows of every step (tile-major order)
     const long long S = (long long)((p.B + TB - 1) / TB) * TB * p.H;
     if (e.kind == GOPS_ENV_VEH3DOFCONTI) p.ref_table = c.take((size_t)p.B * (e.pre_horizon + 1 + p.H) * 4);
     if (p.need_grad) {
         const bool gelu = p.pol.act == GOPS_ACT_GELU;
-        p.st.x = c.take((size_t)S * p.pol.kp[0]);
+        const size_t el = f16 ? 2 : 1;   // stash elements per float of workspace (half: 2)
+        p.st.x = c.take(((size_t)S * (f16 ? p.pol.kp32[0] : p.pol.kp[0]) + el - 1) / el);
+        if (f16) p.st.xf = c.take((size_t)S * 8);
         for (int j = 1; j < p.pol.nl; ++j) {
-            p.st.h[j] = c.take((size_t)S * p.pol.dims[j]);
-            p.st.d[j] = c.take((size_t)S * p.pol.dims[j]);
-            if (gelu) p.st.z[j] = c.take((size_t)S * p.pol.dims[j]);
+            p.st.h[j] = c.take(((size_t)S * p.pol.dims[j] + el - 1) / el);
+            p.st.d[j] = c.take(((size_t)S * p.pol.dims[j] + el - 1) / el);
+            if (gelu) p.st.z[j] = c.take(((size_t)S * p.pol.dims[j] + el - 1) / el);
         }
         p.st.dy = c.take((size_t)S * 4);
         p.st.env = c.take((size_t)S * ENV_STASH);
         if (p.tail) {
             for (int j = 1; j < p.val.nl; ++j) {
-                p.st.tail_h[j] = c.take((size_t)p.B * p.val.dims[j]);
-                if (p.val.act == GOPS_ACT_GELU) p.st.tail_z[j] = c.take((size_t)p.B * p.val.dims[j]);
+                p.st.tail_h[j] = c.take(((size_t)p.B * p.val.dims[j] + el - 1) / el);
+                if (p.val.act == GOPS_ACT_GELU) p.st.tail_z[j] = c.take(((size_t)p.B * p.val.dims[j] + el - 1) / el);
             }
         }
         p.st.tail_done = c.take((size_t)p.B);
         // split-K partial slabs of the weight-gradient GEMMs: one region per layer so that all
         // partial sums can be reduced by a single launch at the end
         for (int j = 0; j < p.pol.nl - 1; ++j) {
-            const DwPlan d = plan_dw(p.pol.dims[j + 1], p.pol.kp[j], S);
-            plan.dw_part[j] = c.take((size_t)d.splits * p.pol.dims[j + 1] * p.pol.kp[j]);
+            const int Kp = f16 ? p.pol.kp32[j] : p.pol.kp[j];
+            const DwPlan d = plan_dw(p.pol.dims[j + 1], Kp, S, f16);
+            plan.dw_part[j] = c.take((size_t)d.splits * p.pol.dims[j + 1] * Kp);
             plan.dw_part_b[j] = c.take((size_t)d.splits * p.pol.dims[j + 1]);
         }
         const int Lh = p.pol.nl - 1;
@@ -320,10 +349,15 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     const int L = p.pol.nl - 1;
     ReduceJobs jobs;
     memset(&jobs, 0, sizeof(jobs));
+    if (p.f16) jobs.unscale = p.gscale + 1;   // the sweep ran on gradients scaled by gscale[0]
     for (int j = 0; j < L; ++j) {   // dW_j = D_{j+1}^T * (j == 0 ? X : H_j)
-        const int N = p.pol.dims[j + 1], Kp = p.pol.kp[j], K = p.pol.dims[j];
-        const DwPlan d = plan_dw(N, Kp, S);
+        const int N = p.pol.dims[j + 1], Kp = p.f16 ? p.pol.kp32[j] : p.pol.kp[j], K = p.pol.dims[j];
+        const DwPlan d = plan_dw(N, Kp, S, p.f16 != 0);
         const float* X = (j == 0) ? p.st.x : p.st.h[j];
+        if (p.f16) {
+            if ((e = launch_dw_gemm_f16(p.st.d[j + 1], N, X, Kp, S, d.splits, d.chunks_per_split, plan.dw_part[j],
+                                        plan.dw_part_b[j], s)) != hipSuccess) return (int)e;
+        } else
         if ((e = launch_dw_gemm(p.st.d[j + 1], N, X, Kp, S, d.splits, d.chunks_per_split, plan.dw_part[j],
                                 plan.dw_part_b[j], d.big, s)) != hipSuccess) return (int)e;
         reduce_jobs_add(jobs, plan.dw_part[j], d.splits, N, K, Kp, grad.weight[j]);
@@ -333,7 +367,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
         const int K = p.pol.dims[L], A = p.pol.dims[p.pol.nl];
         long long splits = DW_OUT_SPLITS;
         if (splits > S) splits = S;
-        if ((e = launch_dw_out(p.st.dy, p.st.h[L], K, A, S, (int)splits, plan.dw_part[L], plan.dw_part_b[L], s)) != hipSuccess) return (int)e;
+        if ((e = launch_dw_out(p.st.dy, p.st.h[L], p.f16 != 0, K, A, S, (int)splits, plan.dw_part[L], plan.dw_part_b[L], s)) != hipSuccess) return (int)e;
         reduce_jobs_add(jobs, plan.dw_part[L], (int)splits, A, K, K, grad.weight[L]);
         reduce_jobs_add(jobs, plan.dw_part_b[L], (int)splits, 1, A, A, grad.bias[L]);
     }
@@ -352,6 +386,7 @@ GopsRolloutDesc value_desc(const GopsMlp& value, int batch) {
     d.env.obs_dim = value.sizes[0];
     d.env.act_dim = 1;
     d.policy = value;
+    d.dtype = value.dtype;
     return d;
 }
 

@@ -27,13 +27,67 @@ __device__ __forceinline__ void pack_element(const float* __restrict__ W, int N,
     }
 }
 
+// Half-precision packings (rollout_f16.h: the weights are the A operand of v_mfma_f32_16x16x32_f16, 8 halfs
+// per lane).  Element e = ((blk * 64 + lane) * 8 + i8):
+//   wph[j]  (forward)   blk = (4q + jt) * kch + c, kch = kp32 / 32:  W[64q + 16(r>>2) + 4jt + (r&3)][32c + 8(lane>>4) + i8], r = lane & 15
+//   wpth[j] (backward, j >= 1) same with roles swapped: rows = inputs of the layer (quads over dims[j]),
+//           chunks over its outputs:  W[32c + 8(lane>>4) + i8][64q + 16(r>>2) + 4jt + (r&3)]
+//   wpth[0] (backward, input adjoint) plain 16-row tiles over the 16-padded inputs:  W[32c + 8(lane>>4) + i8][16nt + r]
+__device__ __forceinline__ void pack_element_h(const float* __restrict__ W, int N, int K, int Kp16, int Kp32, int layer,
+                                               _Float16* __restrict__ wph, _Float16* __restrict__ wpth, int e) {
+    const int i8 = e & 7, lane = (e >> 3) & 63, blk = e >> 9, r = lane & 15, kg = lane >> 4;
+    if (e < N * Kp32) {   // forward
+        const int kch = Kp32 >> 5, c = blk % kch, t = blk / kch, jt = t & 3, q = t >> 2;
+        const int n = 64 * q + 16 * (r >> 2) + 4 * jt + (r & 3), k = 32 * c + 8 * kg + i8;
+        wph[e] = (_Float16)((k < K) ? W[(size_t)n * K + k] : 0.f);
+    }
+    const int kchN = N >> 5;   // outputs are a multiple of 64
+    if (layer >= 1) {
+        if (e < N * K) {      // K = width of the previous hidden layer, a multiple of 64
+            const int c = blk % kchN, t = blk / kchN, jt = t & 3, q = t >> 2;
+            const int kin = 64 * q + 16 * (r >> 2) + 4 * jt + (r & 3), nout = 32 * c + 8 * kg + i8;
+            wpth[e] = (_Float16)W[(size_t)nout * K + kin];
+        }
+    } else if (e < N * Kp16) {
+        const int c = blk % kchN, nt = blk / kchN;
+        const int kin = 16 * nt + r, nout = 32 * c + 8 * kg + i8;
+        wpth[e] = (_Float16)((kin < K) ? W[(size_t)nout * K + kin] : 0.f);
+    }
+}
 
 // Copies the by-value parameter block into device memory (stream ordered, no host staging): the
 // rollout kernels then read it with uniform scalar loads instead of a per-lane scratch copy.
+// F16 launches: the same block also scans grad_v for max|g| and publishes the power-of-two scale s that
+// brings it to 2^-4 (deltas then sit mid-range in half: ~2^10 of headroom above, normals down to 2^-10 of
+// the largest), as {s, 1/s} in p.gscale.  max|g| == 0 or non-finite -> s = 1.
 __global__ void upload_params_kernel(const RolloutParams p, RolloutParams* dst) {
     const unsigned* src = reinterpret_cast<const unsigned*>(&p);
     unsigned* d = reinterpret_cast<unsigned*>(dst);
     for (unsigned i = threadIdx.x; i < sizeof(RolloutParams) / 4; i += blockDim.x) d[i] = src[i];
+    if (p.f16 && p.gscale != nullptr && p.grad_v != nullptr) {
+        __shared__ float red[256];
+        float mx = 0.f;
+        for (int i = threadIdx.x; i < p.B; i += blockDim.x) mx = fmaxf(mx, fabsf(p.grad_v[i]));
+        red[threadIdx.x] = mx;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float m = red[0];
+            float sc = 1.f;
+            if (m > 0.f && m < 3.0e38f) {
+                int ex;
+                (void)frexpf(m, &ex);          // m = f * 2^ex, f in [0.5, 1)
+                int sh = -4 - ex + 1;          // 2^sh * m in [2^-4, 2^-3)
+                sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+                sc = ldexpf(1.f, sh);
+            }
+            p.gscale[0] = sc;
+            p.gscale[1] = 1.f / sc;
+        }
+    }
 }
 
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s) {
@@ -138,6 +192,9 @@ __host__ __device__ inline int pack_blocks(const MlpDev& d) {
     for (int j = 0; j < d.nl - 1; ++j) nb += (d.dims[j + 1] * d.kp[j] + 255) / 256;
     return nb;
 }
+__host__ __device__ inline int pack_blocks_h(const MlpDev& d, int j) {   // covers wph[j] (N x kp32) and wpth[j]
+    return (d.dims[j + 1] * d.kp32[j] + 255) / 256;
+}
 
 __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, RolloutParams* dst, int P, float pdt) {
     int b = blockIdx.x;
@@ -151,6 +208,17 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
     for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
         const MlpDev& d = m ? p.val : p.pol;
         for (int j = 0; j < d.nl - 1; ++j) {
+            if (p.f16) {
+                const int nb = pack_blocks_h(d, j);
+                if (b < nb) {
+                    pack_element_h(d.w[j], d.dims[j + 1], d.dims[j], d.kp[j], d.kp32[j], j,
+                                   const_cast<_Float16*>(reinterpret_cast<const _Float16*>(d.wph[j])),
+                                   const_cast<_Float16*>(reinterpret_cast<const _Float16*>(d.wpth[j])), b * 256 + threadIdx.x);
+                    return;
+                }
+                b -= nb;
+                continue;
+            }
             const int nb = (d.dims[j + 1] * d.kp[j] + 255) / 256;
             if (b < nb) {
                 pack_element(d.w[j], d.dims[j + 1], d.dims[j], d.kp[j],
@@ -167,7 +235,12 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
 }
 
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s) {
-    int nb = 1 + pack_blocks(p.pol) + (p.tail ? pack_blocks(p.val) : 0);
+    int nb = 1;
+    for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
+        const MlpDev& d = m ? p.val : p.pol;
+        if (!p.f16) { nb += pack_blocks(d); continue; }
+        for (int j = 0; j < d.nl - 1; ++j) nb += pack_blocks_h(d, j);
+    }
     if (p.env.kind == GOPS_ENV_VEH3DOFCONTI) nb += (p.B * (P + 1 + p.H) + 255) / 256;
     hipLaunchKernelGGL(prologue_kernel, dim3(nb), dim3(256), 0, s, p, dst, P, pdt);
     return hipGetLastError();
@@ -476,11 +549,160 @@ hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long lo
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// dW GEMM, half-precision operands (GOPS_DTYPE_F16):  part[split][n][k] = sum_s D[s][n] * X[s][k] with D, X
+// row-major _Float16 stash tiles, fp32 accumulation on v_mfma_f32_16x16x32_f16.  Same decomposition as the
+// bf16x3 kernel (128 x 128 outputs per workgroup, 2 x 2 waves of 64 x 64, split-K over samples, XCD-aware
+// block order); a chunk is 64 samples = two MFMA K-steps.  The contraction index (samples) is the ROW
+// index of both operands in memory, so the staging transposes: a thread loads 4 rows x 8 columns (one
+// dwordx4 per row, 256-byte coalesced rows), regroups them with v_perm_b32 into 8 columns x 4 samples and
+// writes [g = s/8][column][8 samples] fragments (ds_write_b64); a lane's MFMA fragment is one ds_read_b128.
+// 16-byte units are XOR-swizzled (column ^ (column >> 3 & 7)) so that both directions are conflict-free.
+// ---------------------------------------------------------------------------------------------
+#define DWH_SC 64                       // samples per staged chunk
+#define DWH_T 128                       // tile edge
+#define DWH_PLANE (8 * DWH_T * 8)       // halfs per operand: [8 g][128 cols][8 samples]
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_f16_kernel(const _Float16* __restrict__ D, int N,
+                                                                   const _Float16* __restrict__ X, int Kp,
+                                                                   long long S, int splits, int chunks_per_split,
+                                                                   float* __restrict__ part,
+                                                                   float* __restrict__ part_b) {
+    __shared__ __attribute__((aligned(16))) _Float16 As[DWH_PLANE];   // D^T
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[DWH_PLANE];   // X
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_k = (Kp + DWH_T - 1) / DWH_T, tiles = tiles_k * ((N + DWH_T - 1) / DWH_T);
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;   // same XCD-aware order as dw_gemm_kernel
+    const int tile = local % tiles, split = (local / tiles) * 8 + xcd;
+    if (split >= splits) return;
+    const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
+    const int n0 = tile_n * DWH_T, k0 = tile_k * DWH_T;
+    const long long s_begin = (long long)split * chunks_per_split * DWH_SC;
+    const int wn = wave >> 1, wk = wave & 1;
+
+    // Staging item of this thread: columns 8*c8 .. +7, samples 4*s4 .. +3 of the chunk.  Lane bits ->
+    // (s4 bit 0, c8 bits 0..2, c8 bit 3, s4 bit 1), wave -> s4 bits 2..3: one load instruction covers four
+    // full 256-byte rows, and the 16 lanes of a ds_write_b64 group hit 16 distinct 8-byte slots.
+    const int c8 = ((lane >> 1) & 7) | (((lane >> 4) & 1) << 3);
+    const int s4 = (lane & 1) | (((lane >> 5) & 1) << 1) | (wave << 2);
+    int wofs[8];   // LDS half-offset of column 8*c8 + i
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = 8 * c8 + i, nsw = n ^ ((n >> 3) & 7);
+        wofs[i] = (((s4 >> 1) * DWH_T + nsw) << 3) + ((s4 & 1) << 2);
+    }
+    const bool want_bias = part_b != nullptr && tile_k == 0;
+
+    f32x4 acc[4][4] = {};
+    u32x4 dreg[4], xreg[4];
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    auto gload = [&](long long s0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long srow = s0 + 4 * s4 + r;
+            const int n = n0 + 8 * c8, k = k0 + 8 * c8;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            dreg[r] = (srow < S && n < N) ? *reinterpret_cast<const u32x4*>(D + srow * N + n) : z;
+            xreg[r] = (srow < S && k < Kp) ? *reinterpret_cast<const u32x4*>(X + srow * Kp + k) : z;
+        }
+    };
+    // 4 rows x 8 halfs -> for each column pair (2w, 2w+1): samples 0..3 as two dwords each
+    auto lstore = [&]<bool SUM>(const u32x4& q0, const u32x4& q1, const u32x4& q2, const u32x4& q3, _Float16* base) {
+        #pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned r0w = q0[w], r1w = q1[w], r2w = q2[w], r3w = q3[w];
+            // (low halfs of rows 0,1), (rows 2,3) = column 2w; (high halfs) = column 2w+1  (hipcc folds these to v_perm_b32)
+            const unsigned lo01 = (r0w & 0xffffu) | (r1w << 16), lo23 = (r2w & 0xffffu) | (r3w << 16);
+            const unsigned hi01 = (r0w >> 16) | (r1w & 0xffff0000u), hi23 = (r2w >> 16) | (r3w & 0xffff0000u);
+            { const u32x2 v = {lo01, lo23}; *reinterpret_cast<u32x2*>(base + wofs[2 * w]) = v; }
+            { const u32x2 v = {hi01, hi23}; *reinterpret_cast<u32x2*>(base + wofs[2 * w + 1]) = v; }
+            if (SUM && want_bias) {
+                const f16x2 a0 = __builtin_bit_cast(f16x2, lo01), a1 = __builtin_bit_cast(f16x2, lo23);
+                const f16x2 b0 = __builtin_bit_cast(f16x2, hi01), b1 = __builtin_bit_cast(f16x2, hi23);
+                bsum[2 * w] += ((float)a0[0] + (float)a0[1]) + ((float)a1[0] + (float)a1[1]);
+                bsum[2 * w + 1] += ((float)b0[0] + (float)b0[1]) + ((float)b1[0] + (float)b1[1]);
+            }
+        }
+    };
+    // fragment (8 consecutive samples of tile-local column `col`) of this lane in K-step ks
+    auto frag = [&](const _Float16* base, int ks, int col) {
+        const int nsw = col ^ ((col >> 3) & 7);
+        return *reinterpret_cast<const f16x8*>(base + (((4 * ks + (lane >> 4)) * DWH_T + nsw) << 3));
+    };
+
+    gload(s_begin);
+    for (int c = 0; c < chunks_per_split; ++c) {
+        __syncthreads();
+        lstore.template operator()<true>(dreg[0], dreg[1], dreg[2], dreg[3], As);
+        lstore.template operator()<false>(xreg[0], xreg[1], xreg[2], xreg[3], Bs);
+        __syncthreads();
+        if (c + 1 < chunks_per_split) gload(s_begin + (long long)(c + 1) * DWH_SC);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = frag(Bs, ks, wk * 64 + 16 * j + (lane & 15));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f16x8 a = frag(As, ks, wn * 64 + 16 * i + (lane & 15));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    float* pbase = part + (size_t)split * N * Kp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + wk * 64 + 16 * j + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + 16 * i + 4 * (lane >> 4) + r;
+                if (n < N && k < Kp) pbase[(size_t)n * Kp + k] = acc[i][j][r];
+            }
+        }
+    if (want_bias) {   // column sums of D: 16 sample groups per column, combined in a fixed order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(As);   // [16][128] floats = 8 KiB of the 16 KiB plane
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[s4 * DWH_T + 8 * c8 + i] = bsum[i];
+        __syncthreads();
+        if (tid < DWH_T && n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += red[q * DWH_T + tid];
+            part_b[(size_t)split * N + n0 + tid] = t;
+        }
+    }
+}
+
+hipError_t launch_dw_gemm_f16(const void* D, int N, const void* X, int Kp, long long S, int splits,
+                              int chunks_per_split, float* part, float* part_b, hipStream_t s) {
+    const int tiles = ((N + DWH_T - 1) / DWH_T) * ((Kp + DWH_T - 1) / DWH_T);
+    hipLaunchKernelGGL(dw_gemm_f16_kernel, dim3(tiles * ((splits + 7) / 8) * 8), dim3(NTHREADS), 0, s,
+                       static_cast<const _Float16*>(D), N, static_cast<const _Float16*>(X), Kp, S, splits, chunks_per_split,
+                       part, part_b);
+    return hipGetLastError();
+}
+
 // Output layer (width A <= 4) on the VALU: part[split][a][k] = sum_s dy[s][a] * h[s][k].
 // Thread = (4 columns, sample lane): 16-byte coalesced reads of h, four sample lanes per block
 // combined through LDS in a fixed order.
+__device__ __forceinline__ f32x4 ld4_as_f32(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4_as_f32(const _Float16* p) {
+    const f16x4 v = *reinterpret_cast<const f16x4*>(p);
+    const f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+template <class HT>   // float, or _Float16 for GOPS_DTYPE_F16 (dy stays fp32)
 __global__ __launch_bounds__(NTHREADS) void dw_out_kernel(const float* __restrict__ dy,
-                                                          const float* __restrict__ h, int K, int A,
+                                                          const HT* __restrict__ h, int K, int A,
                                                           long long S, long long per_split,
                                                           float* __restrict__ part, float* __restrict__ part_b) {
     __shared__ __attribute__((aligned(16))) f32x4 red[4][GOPS_MAX_ACT][64];
@@ -497,7 +719,7 @@ __global__ __launch_bounds__(NTHREADS) void dw_out_kernel(const float* __restric
 #pragma unroll 4
             for (long long sidx = s0 + sl; sidx < s1; sidx += 4) {
                 const f32x4 g = *reinterpret_cast<const f32x4*>(dy + sidx * 4);
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(h + sidx * K + 4 * k4);
+                const f32x4 hv = ld4_as_f32(h + sidx * K + 4 * k4);
 #pragma unroll
                 for (int a = 0; a < GOPS_MAX_ACT; ++a) { acc[a] += g[a] * hv; accb[a] += g[a]; }
             }
@@ -520,10 +742,14 @@ __global__ __launch_bounds__(NTHREADS) void dw_out_kernel(const float* __restric
     }
 }
 
-hipError_t launch_dw_out(const float* dy, const float* h, int K, int A, long long S, int splits,
+hipError_t launch_dw_out(const float* dy, const float* h, bool h_is_half, int K, int A, long long S, int splits,
                          float* part, float* part_b, hipStream_t s) {
     const long long per = (S + splits - 1) / splits;
-    hipLaunchKernelGGL(dw_out_kernel, dim3(splits), dim3(NTHREADS), 0, s, dy, h, K, A, S, per, part, part_b);
+    if (h_is_half)
+        hipLaunchKernelGGL(dw_out_kernel<_Float16>, dim3(splits), dim3(NTHREADS), 0, s, dy, reinterpret_cast<const _Float16*>(h),
+                           K, A, S, per, part, part_b);
+    else
+        hipLaunchKernelGGL(dw_out_kernel<float>, dim3(splits), dim3(NTHREADS), 0, s, dy, h, K, A, S, per, part, part_b);
     return hipGetLastError();
 }
 
@@ -556,7 +782,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
     }
     red[sl][o] = (acc0 + acc1) + (acc2 + acc3);
     __syncthreads();
-    if (sl == 0 && valid) jobs.out[j][idx] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    if (sl == 0 && valid) {
+        float t = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+        if (jobs.unscale != nullptr) t *= *jobs.unscale;   // power of two: exact
+        jobs.out[j][idx] = t;
+    }
 }
 
 void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, int cols, int ld, float* out) {

@@ -12,6 +12,9 @@
 #define ENV_STASH 16      // floats of per-(t,b) env stash: [0..3] abar, [4] done_t, [5..10] state_t, [12..15] veh3dof: sin, cos of the heading before / after the step
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));   // one A / B fragment of v_mfma_f32_16x16x32_f16
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // Pointers that reach the kernels through the parameter block are generic to the compiler, and
 // generic accesses become FLAT instructions, which count on lgkmcnt as well as vmcnt: every LDS wait
@@ -32,6 +35,10 @@ struct MlpDev {
     const float* b[GOPS_MAX_LAYERS];
     const f32x4* wp[GOPS_MAX_LAYERS];   // forward MFMA-fragment packing of layer j (hidden layers)
     const f32x4* wpt[GOPS_MAX_LAYERS];  // backward (transposed operand) packing of layer j
+    // GOPS_DTYPE_F16: half-precision fragment packings (rollout_f16.h) and the input width padded to 32
+    int kp32[GOPS_MAX_LAYERS];
+    const f16x8* wph[GOPS_MAX_LAYERS];
+    const f16x8* wpth[GOPS_MAX_LAYERS];
 };
 
 struct StashDev {
@@ -44,6 +51,9 @@ struct StashDev {
     float* tail_h[GOPS_MAX_LAYERS];   // [B][dims[j]] hidden activations of the tail value net
     float* tail_z[GOPS_MAX_LAYERS];
     float* tail_done;                 // [B] done flag after the last step
+    // GOPS_DTYPE_F16: x / h / z / d / tail_h / tail_z hold _Float16 elements (x rows are kp32[0] wide, z holds
+    // act'(z) instead of z), and the first 8 observation columns are kept in fp32 for the env adjoints:
+    float* xf;                        // [S][8]
 };
 
 struct RolloutParams {
@@ -60,6 +70,8 @@ struct RolloutParams {
     float* g_head_pre;                // open-loop backward: d(loss)/d(head_pre) [B][H][A]
     const float* ref_table;           // veh: [B][P+1+H][4]
     unsigned long long* dbg;          // debug: per-phase cycle counters of block 0 (GOPS_DBG_TIMING)
+    int f16;                          // 1: GOPS_DTYPE_F16
+    float* gscale;                    // f16 backward: {s, 1/s}, s = power of two that brings max|grad_v| to 2^-4
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double
 };
 
@@ -101,6 +113,7 @@ struct ReduceJobs {
     const float* part[2 * GOPS_MAX_LAYERS];
     float* out[2 * GOPS_MAX_LAYERS];
     int splits[2 * GOPS_MAX_LAYERS], rows[2 * GOPS_MAX_LAYERS], cols[2 * GOPS_MAX_LAYERS], ld[2 * GOPS_MAX_LAYERS];
+    const float* unscale;                  // f16: device pointer to 1/s (see RolloutParams::gscale), else null
 };
 
 // ---- activations ---------------------------------------------------------------------------
@@ -443,14 +456,13 @@ __device__ __forceinline__ void stash_tile(const float* lds, int ld, int ncols, 
     }
 }
 
-// Launch with up to 160 KiB of dynamic LDS (the default cap is 64 KiB): the attribute is set once
-// per kernel instantiation.
+// Launch with up to 160 KiB of dynamic LDS (the default cap is 64 KiB).  The attribute belongs to a
+// kernel, and every template instantiation is its own kernel: the "already raised" flag is keyed on the
+// kernel's address (a function-local static would be shared by all instantiations of one signature).
+bool lds_attr_needed(const void* kernel);   // api.hip: true the first time it sees `kernel`
 template <class K, class... Args>
 inline void launch_with_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
-    static bool raised = false;
-    if (!raised) {
+    if (lds_attr_needed(reinterpret_cast<const void*>(kernel)))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised = true;
-    }
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
 }

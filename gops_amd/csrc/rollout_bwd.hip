@@ -8,6 +8,7 @@
 
 #include "common.h"
 #include "env_models.h"
+#include "rollout_f16.h"
 
 // LDS floats of the per-tile buffers (everything except the optional staged tiles at the end).
 __host__ __device__ inline int bwd_lds_floats(int ldx, int ldh, int ref_points) {
@@ -154,7 +155,10 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
 // SK0 / SK1 as in the forward kernel: here the stationary fragments are the TRANSPOSED packings
 // (delta_2 -> delta_1 through W_1: 16 chunks x 4 tiles).  SK0 here = number of the 16 K-chunks of
 // delta_1 -> g_x (through W_0^T, PT0 n-tiles per wave) that stay in registers; the rest streams.
-template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1>
+// F16: GOPS_DTYPE_F16 - deltas and act' operands are half, the contractions run on
+// v_mfma_f32_16x16x32_f16 (rollout_f16.h), and every adjoint carries the launch's power-of-two scale
+// (gscale[0]) that the reduce kernel takes out of the parameter gradients again.
+template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false>
 __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;
@@ -177,7 +181,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
                                                                              : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0));
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
-    const float gv = (tid < nvalid) ? gptr(p.grad_v)[b0 + tid] : 0.f;
+    float gv = (tid < nvalid) ? gptr(p.grad_v)[b0 + tid] : 0.f;
+    if constexpr (F16) gv *= gptr(p.gscale)[0];
+    const int ld16 = (p.ldh - 4) + 8;                 // F16: leading dimension (halfs) of the delta tiles
+    const float* xrows = F16 ? p.st.xf : p.st.x;      // fp32 observation columns the env adjoints read
+    const int xld = F16 ? 8 : p.pol.kp[0];
     float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // adjoint of the veh3dof state (tid < TB)
     const IdpConst IC = idp_const();
     const VehConst VC = veh_const();
@@ -211,6 +219,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
             s_gy[tid * 4 + 1] = s_gy[tid * 4 + 2] = s_gy[tid * 4 + 3] = 0.f;
         }
         __syncthreads();
+        if constexpr (F16)
+            mlp_backward_h(p.val, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, reinterpret_cast<_Float16*>(da),
+                           reinterpret_cast<_Float16*>(db), ld16, G, ldx, tid, p.st.tail_h, p.st.tail_z, nullptr, nullptr,
+                           (size_t)b0, nvalid, true, O, [] {});
+        else
         mlp_backward<false>(p.val, NoW{}, NoW{}, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, da, db, ldh, G, ldx,
                      tid, p.st.tail_h, p.st.tail_z, nullptr, nullptr,
                      (size_t)b0, nvalid, true, O, dbg, [] {});
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
         const float* st_env = st_cur + 2 * TB * 256;
         const float* st_x = st_env + TB * ENV_STASH;
         // (the staged variants fetch their tiles straight into LDS and measured faster without it)
-        const int tmode = (t > 0 && !STAGE) ? p.touch_mode : 0;
+        const int tmode = (t > 0 && !STAGE && !F16) ? p.touch_mode : 0;
         // L2 warm-up of what step t-1 will read (written long ago by the forward kernel): HBM-latency
         // loads whose values are only XOR-ed into a sink at the end of the step.  Loads return in order,
         // so they are issued where no latency-critical load follows for thousands of cycles - right
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
                     } else {
                         const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
                         e0 = er[0]; e1 = er[1];
-                        const GLOBAL_AS float* xr = gptr(p.st.x + (row0 + m) * kp0);
+                        const GLOBAL_AS float* xr = gptr(xrows + (row0 + m) * xld);
 #pragma unroll
                         for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
                             if (i < O) x[i] = xr[i];
@@ -476,7 +489,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
 #pragma unroll
                         for (int i = 0; i < 6; ++i) xr[i] = st_x[m * 8 + i];
                     } else {
-                        const GLOBAL_AS float* xg = gptr(p.st.x + (row0 + m) * kp0);
+                        const GLOBAL_AS float* xg = gptr(xrows + (row0 + m) * xld);
 #pragma unroll
                         for (int i = 0; i < 6; ++i) xr[i] = xg[i];
                     }
@@ -497,6 +510,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
         __syncthreads();
         DBG_TICK(1)
         if (!p.open_loop) {
+            if constexpr (F16)
+                mlp_backward_h(p.pol, s_wo, ldh, s_gy, reinterpret_cast<_Float16*>(da), reinterpret_cast<_Float16*>(db), ld16, G, ldx,
+                               tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, [] {});
+            else
             mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
                          nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up, st_cur, st_cur + TB * 256);
         } else if (tid < nvalid) {   // open loop: the head adjoint IS the result; no policy input adjoint
@@ -531,6 +548,12 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
         else launch_with_lds(rollout_bwd_kernel<ENV, A, B, false>, grid, block, lds, stream, dp);         \
     } while (0)
 
+#define LAUNCH_BWD_H(ENV)                                                                                       \
+    do {                                                                                                        \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, true>, grid, block, lds, stream, dp); \
+        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, true>, grid, block, lds, stream, dp);       \
+    } while (0)
+
 #define LAUNCH_BWD2(ENV, A, B, PT)                                                                          \
     do {                                                                                                    \
         if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, A, B, true, PT>, grid, block, lds, stream, dp);  \
@@ -545,6 +568,16 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
     rollout_variant(p, sk, true);
     if (sk[1] > 0) lds += sizeof(float) * 2 * (2 * TB * 256 + TB * ENV_STASH + TB * 8);   // two staging halves
     const int key = sk[0] * 100 + sk[1];
+    if (p.f16) {
+        switch (p.env.kind) {
+            case GOPS_ENV_NONE: LAUNCH_BWD_H(GOPS_ENV_NONE); break;
+            case GOPS_ENV_LQ: LAUNCH_BWD_H(GOPS_ENV_LQ); break;
+            case GOPS_ENV_IDPENDULUM: LAUNCH_BWD_H(GOPS_ENV_IDPENDULUM); break;
+            case GOPS_ENV_VEH3DOFCONTI: LAUNCH_BWD_H(GOPS_ENV_VEH3DOFCONTI); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (p.env.kind) {
         case GOPS_ENV_NONE: LAUNCH_BWD(GOPS_ENV_NONE, 0, 0); break;
         case GOPS_ENV_LQ:

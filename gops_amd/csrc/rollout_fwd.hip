@@ -10,6 +10,7 @@
 
 #include "common.h"
 #include "env_models.h"
+#include "rollout_f16.h"
 
 // Hidden layers of `M` applied to the LDS tile `in` (TB x kp[0], leading dim ld_in).  Returns the
 // LDS buffer that holds the last hidden activation.  When stash_h is non-null the activations
@@ -114,7 +115,9 @@ __device__ __forceinline__ void mlp_head(WP Wo, int ldw, BP bo, int K, int A, co
 // stationary (the layer must then be 256 wide), 0 = streamed.
 // TAIL: the INFADP terminal value V_target(obs_H) is evaluated after the loop (compiled out for FHADP so
 // that its streamed-GEMM registers do not add to the pressure of the stationary variants).
-template <int ENV, int SK0, int SK1, bool TAIL>
+// F16: GOPS_DTYPE_F16 - the hidden layers run on v_mfma_f32_16x16x32_f16 (rollout_f16.h) and the
+// activation stash is half precision; everything else in the step is the same fp32 code.
+template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false>
 __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;   // parameters live in device memory: uniform scalar loads
@@ -137,6 +140,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
     float* s_bias = s_wo + 4 * ldh;         // [GOPS_MAX_LAYERS-1][ldh] hidden-layer biases
     f32x4* s_ref = reinterpret_cast<f32x4*>(s_bias + (GOPS_MAX_LAYERS - 1) * ldh);   // veh: [TB][TL]
     const int TL = p.env.pre_horizon + 1 + p.H;   // reference-table points per trajectory
+    // F16: half copy of the policy / value input tile, [TB][ldx16], behind the reference-table region
+    _Float16* x16 = reinterpret_cast<_Float16*>(s_ref + (ENV == GOPS_ENV_VEH3DOFCONTI ? TB * TL : 0));
+    const int ldx16 = (((p.ldx - 4) + 31) & ~31) + 8, ld16 = (p.ldh - 4) + 8;
     {   // one-time staging of everything the H-step loop would otherwise re-fetch from L2
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
         for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
@@ -185,16 +191,35 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
         __syncthreads();
         DBG_TICK(0)
         const size_t row0 = ((size_t)blockIdx.x * p.H + t) * TB;   // tile-major stash: a tile's rows are contiguous over t
-        if (p.need_grad) stash_tile(xs, ldx, p.pol.kp[0], p.st.x, row0, TB, tid);
+        if constexpr (F16) {
+            // half copy of the input tile (LDS, and the stash rows the weight-gradient GEMM reads); the env
+            // adjoints get the first 8 observation columns in fp32
+            convert_x_h(xs, ldx, p.pol.kp[0], p.pol.kp32[0], x16, ldx16,
+                        p.need_grad ? reinterpret_cast<_Float16*>(p.st.x) : nullptr, row0, tid);
+            if (p.need_grad && tid < 2 * TB)
+                *gptr(reinterpret_cast<f32x4*>(p.st.xf + (row0 + (tid >> 1)) * 8 + 4 * (tid & 1))) =
+                    *reinterpret_cast<const f32x4*>(xs + (tid >> 1) * ldx + 4 * (tid & 1));
+            __syncthreads();
+        } else {
+            if (p.need_grad) stash_tile(xs, ldx, p.pol.kp[0], p.st.x, row0, TB, tid);
+        }
         DBG_TICK(1)
         {
             float y[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
             if (!p.open_loop) {
-                float* hcur = mlp_hidden_forward(p.pol, W0, W1, xs, ldx, ha, hb, ldh, tid, s_bias,
-                                                 p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
-                                                 row0, nvalid, TB, dbg);
-                DBG_TICK(2)
-                mlp_head(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ldh, tid, y);
+                if constexpr (F16) {
+                    const _Float16* hcur = mlp_hidden_forward_h(p.pol, x16, ldx16, reinterpret_cast<_Float16*>(ha),
+                                                                reinterpret_cast<_Float16*>(hb), ld16, tid, s_bias, ldh,
+                                                                p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
+                                                                row0, TB);
+                    mlp_head_h(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ld16, tid, y);
+                } else {
+                    float* hcur = mlp_hidden_forward(p.pol, W0, W1, xs, ldx, ha, hb, ldh, tid, s_bias,
+                                                     p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
+                                                     row0, nvalid, TB, dbg);
+                    DBG_TICK(2)
+                    mlp_head(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ldh, tid, y);
+                }
             }
             {   // lane a of each 16-lane trajectory group squashes and wraps action a (row16_sum left y in every lane)
                 const int hm = tid >> 4, la = tid & 15;
@@ -344,12 +369,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
         for (int j = 0; j < p.val.nl - 1; ++j)   // the policy biases are no longer needed
             for (int n = tid; n < p.val.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = gptr(p.val.b[j])[n];
         __syncthreads();
-        float* hcur = mlp_hidden_forward(p.val, NoW{}, NoW{}, xs, ldx, ha, hb, ldh, tid, s_bias,
-                                         p.need_grad ? p.st.tail_h : nullptr,
-                                         p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, nvalid, nvalid, dbg);
         float y[GOPS_MAX_ACT];
-        {
-            const int Lv = p.val.nl - 1;
+        const int Lv = p.val.nl - 1;
+        if constexpr (F16) {
+            convert_x_h(xs, ldx, p.val.kp[0], p.val.kp32[0], x16, ldx16, nullptr, 0, tid);
+            __syncthreads();
+            const _Float16* hcur = mlp_hidden_forward_h(p.val, x16, ldx16, reinterpret_cast<_Float16*>(ha),
+                                                        reinterpret_cast<_Float16*>(hb), ld16, tid, s_bias, ldh,
+                                                        p.need_grad ? p.st.tail_h : nullptr,
+                                                        p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, nvalid);
+            mlp_head_h(gptr(p.val.w[Lv]), p.val.dims[Lv], gptr(p.val.b[Lv]), p.val.dims[Lv], 1, hcur, ld16, tid, y);
+        } else {
+            float* hcur = mlp_hidden_forward(p.val, NoW{}, NoW{}, xs, ldx, ha, hb, ldh, tid, s_bias,
+                                             p.need_grad ? p.st.tail_h : nullptr,
+                                             p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, nvalid, nvalid, dbg);
             mlp_head(gptr(p.val.w[Lv]), p.val.dims[Lv], gptr(p.val.b[Lv]), p.val.dims[Lv], 1, hcur, ldh, tid, y);
         }
         if ((tid & 15) == 0) s_th[(tid >> 4) * 4] = y[0];
@@ -374,9 +407,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_fwd_kernel(const RolloutP
     }
 }
 
-size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points) {
-    return sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * (8 + 4 + 4 + 1 + 1 + 2) + (4 + GOPS_MAX_LAYERS - 1) * ldh +
-                                    4 * TB * ref_points);
+size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16) {
+    size_t b = sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * (8 + 4 + 4 + 1 + 1 + 2) + (4 + GOPS_MAX_LAYERS - 1) * ldh +
+                                        4 * TB * ref_points);
+    if (f16) b += sizeof(_Float16) * (size_t)TB * ((((ldx - 4) + 31) & ~31) + 8);   // x16
+    return b;
 }
 
 // Picks the register-stationary variant when the policy is (kp0 in {16,48,128}) -> 256 -> 256 ...,
@@ -384,6 +419,7 @@ size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points) {
 void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
     sk[0] = sk[1] = 0;
     const MlpDev& M = p.pol;
+    if (p.f16) return;   // the half-precision path streams its (half as large) weights from L2
     // Register-stationary weights pin one workgroup per CU.  That is the right trade only while there
     // is at most one tile per CU (B <= 16 * #CUs = 4096 on MI355X); with more tiles the streamed
     // kernels win because 2-3 workgroups per CU overlap each other's MFMA and VALU phases.
@@ -425,14 +461,29 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
         if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, A, B, true>, grid, block, lds, stream, dp);   \
         else launch_with_lds(rollout_fwd_kernel<ENV, A, B, false>, grid, block, lds, stream, dp);         \
     } while (0)
+#define LAUNCH_FWD_H(ENV)                                                                                          \
+    do {                                                                                                           \
+        if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, true, true>, grid, block, lds, stream, dp);       \
+        else launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, false, true>, grid, block, lds, stream, dp);             \
+    } while (0)
 
 // `p` is the host copy (for shape dispatch), `dp` the device copy the kernel reads.
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H : 0);
+    const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H : 0, p.f16 != 0);
     int sk[2];
     rollout_variant(p, sk, false);
     const int key = sk[0] * 100 + sk[1];
+    if (p.f16) {
+        switch (p.env.kind) {
+            case GOPS_ENV_NONE: LAUNCH_FWD_H(GOPS_ENV_NONE); break;
+            case GOPS_ENV_LQ: LAUNCH_FWD_H(GOPS_ENV_LQ); break;
+            case GOPS_ENV_IDPENDULUM: LAUNCH_FWD_H(GOPS_ENV_IDPENDULUM); break;
+            case GOPS_ENV_VEH3DOFCONTI: LAUNCH_FWD_H(GOPS_ENV_VEH3DOFCONTI); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (p.env.kind) {
         case GOPS_ENV_NONE: LAUNCH_FWD(GOPS_ENV_NONE, 0, 0); break;
         case GOPS_ENV_LQ:

@@ -16,13 +16,24 @@ LIB_PATH = os.path.join(_HERE, "libgops_hip.so")
 MAX_LAYERS, MAX_ACT, MAX_LQ, TILE = 5, 4, 6, 16
 ENV_NONE, ENV_LQ, ENV_IDP, ENV_VEH = 0, 1, 2, 3
 ACT_IDS = {"linear": 0, "relu": 1, "elu": 2, "gelu": 3, "selu": 4, "sigmoid": 5, "tanh": 6}
+DTYPE_IDS = {"fp32": 0, "f32": 0, "float32": 0, "fp16": 1, "f16": 1, "float16": 1, "half": 1}
+
+
+def dtype_id(name) -> int:
+    """GOPS_DTYPE_* of an `mlp_dtype` setting ("fp32" default; "fp16" = half-precision MFMA contractions)."""
+    if name is None:
+        return 0
+    try:
+        return DTYPE_IDS[str(name).lower()]
+    except KeyError:
+        raise RuntimeError(f"unknown mlp_dtype {name!r}: expected 'fp32' or 'fp16'") from None
 
 _fp = C.POINTER(C.c_float)
 
 
 class GopsMlp(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("sizes", C.c_int32 * (MAX_LAYERS + 1)),
-                ("hidden_act", C.c_int32), ("reserved", C.c_int32),
+                ("hidden_act", C.c_int32), ("dtype", C.c_int32),
                 ("weight", C.c_void_p * MAX_LAYERS), ("bias", C.c_void_p * MAX_LAYERS)]
 
 
@@ -46,7 +57,7 @@ class GopsEnv(C.Structure):
 class GopsRolloutDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("horizon", C.c_int32), ("finite_horizon", C.c_int32),
                 ("need_grad", C.c_int32), ("tail_value", C.c_int32), ("open_loop", C.c_int32),
-                ("gamma", C.c_double), ("env", GopsEnv), ("policy", GopsMlp), ("value", GopsMlp)]
+                ("dtype", C.c_int32), ("reserved", C.c_int32), ("gamma", C.c_double), ("env", GopsEnv), ("policy", GopsMlp), ("value", GopsMlp)]
 
 
 class GopsRolloutIn(C.Structure):
@@ -147,8 +158,10 @@ def _fill(arr, vals):
         arr[i] = float(v)
 
 
-def make_mlp(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], act: str) -> GopsMlp:
+def make_mlp(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], act: str, dtype=None) -> GopsMlp:
+    """`dtype` ("fp32" / "fp16") only matters for `ValueNet`; a `Rollout` takes its own `dtype` for all nets."""
     m = GopsMlp()
+    m.dtype = dtype_id(dtype)
     m.n_layers = len(weights)
     if not 2 <= len(weights) <= MAX_LAYERS:
         raise RuntimeError(f"MLP with {len(weights)} Linear layers is outside the HIP path (2..{MAX_LAYERS})")
@@ -221,11 +234,13 @@ class Rollout:
 
     def __init__(self, env: GopsEnv, policy: Optional[GopsMlp], *, batch: int, horizon: int, gamma: float,
                  finite_horizon: bool, need_grad: bool = True, value: Optional[GopsMlp] = None,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, dtype=None):
         """`policy=None` selects the open-loop mode: `forward(data, head_pre=...)` takes the pre-tanh
-        policy-head outputs of all steps [B, H, act_dim] and `backward_open_loop` returns their gradient."""
+        policy-head outputs of all steps [B, H, act_dim] and `backward_open_loop` returns their gradient.
+        `dtype`: "fp32" (default, exact fp32 MFMA) or "fp16" (half-precision MFMA contractions and stash)."""
         self.desc = GopsRolloutDesc()
         d = self.desc
+        d.dtype = dtype_id(dtype)
         d.batch, d.horizon, d.finite_horizon = batch, horizon, int(finite_horizon)
         d.need_grad, d.tail_value, d.gamma = int(need_grad), int(value is not None), float(gamma)
         d.env = env
@@ -244,6 +259,7 @@ class Rollout:
         self._keep = None
 
     def set_policy(self, policy: GopsMlp, value: Optional[GopsMlp] = None):
+        """Rebind the networks (their storage moved, or a new GopsMlp was built for them)."""
         if policy is not self._mlps[0]:
             self.desc.policy = policy
         if value is not None and value is not self._mlps[1]:

@@ -24,7 +24,10 @@
  *                             (infadp.py:167,185; StateValue gops/apprfunc/mlp.py:327-329).
  *
  * Conventions: every buffer is caller-allocated DEVICE memory (fp32 unless noted); the library
- * allocates nothing, keeps no global state and is re-entrant.  All work is enqueued on `stream`
+ * allocates no device memory on the data path and keeps no per-call state, so calls on different
+ * workspaces are re-entrant.  Process-wide state is limited to: the opt-in timing hook
+ * (gops_profile_*: HIP events, mutex-guarded), the cached CU count of the device, a one-time
+ * hipFuncSetAttribute per kernel, and - debug builds only - one counter buffer.  All work is enqueued on `stream`
  * (a hipStream_t passed as void*); no call synchronises.  Return value: 0 on success, a
  * negative GOPS_ERR_* code or a positive hipError_t otherwise; nothing throws across the ABI.
  */
@@ -38,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GOPS_HIP_ABI_VERSION 2
+#define GOPS_HIP_ABI_VERSION 3
 
 #define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
 #define GOPS_MAX_ACT 4      /* action dimensions */
@@ -55,13 +58,25 @@ enum { GOPS_ENV_NONE = 0, GOPS_ENV_LQ = 1, GOPS_ENV_IDPENDULUM = 2, GOPS_ENV_VEH
 enum { GOPS_ACT_LINEAR = 0, GOPS_ACT_RELU = 1, GOPS_ACT_ELU = 2, GOPS_ACT_GELU = 3,
        GOPS_ACT_SELU = 4, GOPS_ACT_SIGMOID = 5, GOPS_ACT_TANH = 6 };
 
+/* Arithmetic of the MLP contractions (BASELINE.json configs[4]: "fp16 MFMA MLP path").
+ *   GOPS_DTYPE_F32: v_mfma_f32_16x16x4_f32, exact fp32 (the 1e-4 parity path, default).
+ *   GOPS_DTYPE_F16: weights, hidden activations and deltas rounded to IEEE half, products accumulated
+ *                   in fp32 by v_mfma_f32_16x16x32_f16; the activation stash is half (2 bytes/element).
+ *                   Env model, wrapper chain, rewards, returns, observation / state adjoints, policy
+ *                   head and every result stay fp32.  The backward pass runs on gradients scaled by a
+ *                   power of two chosen from max|grad_v| on the device (deltas stay inside half's
+ *                   range) and un-scales the parameter gradients; tolerance: DESIGN.md section 2. */
+enum { GOPS_DTYPE_F32 = 0, GOPS_DTYPE_F16 = 1 };
+
 /* An MLP in torch nn.Linear layout: layer j has weight [sizes[j+1]][sizes[j]] row-major and
- * bias [sizes[j+1]].  Hidden widths must be multiples of 16; the input width is arbitrary. */
+ * bias [sizes[j+1]].  Hidden widths must be multiples of 16 (64 with GOPS_DTYPE_F16); the input width is arbitrary.
+ * Weights and biases are always fp32 in memory; the F16 path rounds them when it packs them. */
 typedef struct GopsMlp {
     int32_t n_layers;                      /* number of Linear layers, 2..GOPS_MAX_LAYERS */
     int32_t sizes[GOPS_MAX_LAYERS + 1];    /* in, hidden..., out */
     int32_t hidden_act;                    /* GOPS_ACT_* */
-    int32_t reserved;
+    int32_t dtype;                         /* GOPS_DTYPE_*: read by gops_value_forward / _backward only
+                                              (a rollout takes GopsRolloutDesc.dtype for all its nets) */
     const float* weight[GOPS_MAX_LAYERS];  /* device pointers */
     const float* bias[GOPS_MAX_LAYERS];
 } GopsMlp;
@@ -104,6 +119,9 @@ typedef struct GopsRolloutDesc {
     int32_t open_loop;        /* 1: no policy evaluation inside the rollout - the pre-tanh head outputs of
                                  every step come from GopsRolloutIn.head_pre (FHADP2: one MLP evaluation
                                  emits all H actions, gops/algorithm/fhadp2.py:100-121); `policy` is ignored */
+    int32_t dtype;            /* GOPS_DTYPE_F32 (default) or GOPS_DTYPE_F16: arithmetic of the MLP contractions
+                                 (hidden widths must then be multiples of 64) */
+    int32_t reserved;
     double gamma;             /* discount; gamma^t is formed in double then rounded (fhadp.py:120) */
     GopsEnv env;
     GopsMlp policy;           /* out width = act_dim */

@@ -1,15 +1,26 @@
-"""Three updates of the target workload (veh3dof FHADP, B=4096, H=30) - the driver for the in-kernel phase
-counters:  make -C gops_amd/csrc -B DBG=1 && GOPS_DBG_TIMING=1 python tools/dbg_run.py   (stderr shows cycles / step)."""
-import sys, torch, contextlib
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
-from bench import alg_kwargs
-from gops_amd.create_pkg.create_alg import create_alg
-from gops_amd.utils.synthetic import CONFIGS, make_batch
-cfg = CONFIGS["target_veh3dof_fhadp_b4096_h30"]
+"""Three updates of one workload - the driver for the in-kernel phase counters:
+    make -C gops_amd/csrc -B DBG=1 && GOPS_DBG_TIMING=1 python tools/dbg_run.py [workload] [fp32|fp16]
+(stderr shows cycles / step of block 0; default: the target workload veh3dof FHADP B=4096 H=30, fp32)."""
+import contextlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import alg_kwargs  # noqa: E402
+from gops_amd.create_pkg.create_alg import create_alg  # noqa: E402
+from gops_amd.utils.synthetic import CONFIGS, make_batch  # noqa: E402
+
+workload = sys.argv[1] if len(sys.argv) > 1 else "target_veh3dof_fhadp_b4096_h30"
+dtype = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+cfg = CONFIGS[workload]
 with contextlib.redirect_stdout(sys.stderr):
-    alg = create_alg(**alg_kwargs(cfg, 0))
+    alg = create_alg(**alg_kwargs(cfg, 0), mlp_dtype=dtype)
 alg.networks.to("cuda")
+if cfg["alg"] == "INFADP":
+    alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]
 data = {k: v.cuda() for k, v in make_batch(cfg, 1000).items()}
-for it in range(3):
+for it in range(4):
     alg.local_update(data, it)
 torch.cuda.synchronize()

@@ -58,8 +58,9 @@ __device__ __forceinline__ void pack_element_h(const float* __restrict__ W, int 
 // Copies the by-value parameter block into device memory (stream ordered, no host staging): the
 // rollout kernels then read it with uniform scalar loads instead of a per-lane scratch copy.
 // F16 launches: the same block also scans grad_v for max|g| and publishes the power-of-two scale s that
-// brings it to 2^-4 (deltas then sit mid-range in half: ~2^10 of headroom above, normals down to 2^-10 of
-// the largest), as {s, 1/s} in p.gscale.  max|g| == 0 or non-finite -> s = 1.
+// brings it into [1, 2) (deltas then sit mid-range in half: 2^15 of headroom above - conversions saturate
+// instead of overflowing - and normals down to 2^-14 of it), as {s, 1/s} in p.gscale.  max|g| == 0 or
+// non-finite -> s = 1.
 __global__ void upload_params_kernel(const RolloutParams p, RolloutParams* dst) {
     const unsigned* src = reinterpret_cast<const unsigned*>(&p);
     unsigned* d = reinterpret_cast<unsigned*>(dst);
@@ -80,7 +81,7 @@ __global__ void upload_params_kernel(const RolloutParams p, RolloutParams* dst) 
             if (m > 0.f && m < 3.0e38f) {
                 int ex;
                 (void)frexpf(m, &ex);          // m = f * 2^ex, f in [0.5, 1)
-                int sh = -4 - ex + 1;          // 2^sh * m in [2^-4, 2^-3)
+                int sh = 1 - ex;               // 2^sh * m in [1, 2)
                 sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
                 sc = ldexpf(1.f, sh);
             }

@@ -71,7 +71,7 @@ struct RolloutParams {
     const float* ref_table;           // veh: [B][P+1+H][4]
     unsigned long long* dbg;          // debug: per-phase cycle counters of block 0 (GOPS_DBG_TIMING)
     int f16;                          // 1: GOPS_DTYPE_F16
-    float* gscale;                    // f16 backward: {s, 1/s}, s = power of two that brings max|grad_v| to 2^-4
+    float* gscale;                    // f16 backward: {s, 1/s}, s = power of two that brings max|grad_v| into [1, 2)
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double
 };
 

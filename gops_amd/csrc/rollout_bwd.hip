@@ -158,8 +158,10 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
 // F16: GOPS_DTYPE_F16 - deltas and act' operands are half, the contractions run on
 // v_mfma_f32_16x16x32_f16 (rollout_f16.h), and every adjoint carries the launch's power-of-two scale
 // (gscale[0]) that the reduce kernel takes out of the parameter gradients again.
-template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false>
-__global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
+// SH (F16 only): 16-row tiles of W_0^T per wave when W_1^T and W_0^T are register-stationary in half
+// precision (StatWhT), 0 = streamed.
+template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, int SH = 0>
+__global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;
     const int tid = threadIdx.x;
@@ -209,6 +211,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
     typename std::conditional<(SK1 > 0), StatW<16, 4>, NoW>::type WT1;
     if constexpr (SK0 > 0) WT0.load(p.pol.wpt[0], kp0 >> 4, tid, p.pol.dims[1] >> 4);
     if constexpr (SK1 > 0) WT1.load(p.pol.wpt[1], p.pol.dims[1] >> 4, tid);
+    typename std::conditional<(SH > 0), StatWhT<(SH > 0 ? SH : 1)>, NoWh>::type WHT;
+    if constexpr (SH > 0) WHT.load(p.pol, tid);
 
     DbgClock dbg;
     dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
         }
         __syncthreads();
         if constexpr (F16)
-            mlp_backward_h(p.val, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, reinterpret_cast<_Float16*>(da),
+            mlp_backward_h(p.val, NoWh{}, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, reinterpret_cast<_Float16*>(da),
                            reinterpret_cast<_Float16*>(db), ld16, G, ldx, tid, p.st.tail_h, p.st.tail_z, nullptr, nullptr,
                            (size_t)b0, nvalid, true, O, [] {});
         else
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void rollout_bwd_kernel(const RolloutP
         DBG_TICK(1)
         if (!p.open_loop) {
             if constexpr (F16)
-                mlp_backward_h(p.pol, s_wo, ldh, s_gy, reinterpret_cast<_Float16*>(da), reinterpret_cast<_Float16*>(db), ld16, G, ldx,
+                mlp_backward_h(p.pol, WHT, s_wo, ldh, s_gy, reinterpret_cast<_Float16*>(da), reinterpret_cast<_Float16*>(db), ld16, G, ldx,
                                tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, [] {});
             else
             mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
@@ -548,11 +552,12 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
         else launch_with_lds(rollout_bwd_kernel<ENV, A, B, false>, grid, block, lds, stream, dp);         \
     } while (0)
 
-#define LAUNCH_BWD_H(ENV)                                                                                       \
-    do {                                                                                                        \
-        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, true>, grid, block, lds, stream, dp); \
-        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, true>, grid, block, lds, stream, dp);       \
+#define LAUNCH_BWD_H(ENV, SH)                                                                                       \
+    do {                                                                                                            \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, true, SH>, grid, block, lds, stream, dp); \
+        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, true, SH>, grid, block, lds, stream, dp);       \
     } while (0)
+int rollout_variant_h(const RolloutParams& p);
 
 #define LAUNCH_BWD2(ENV, A, B, PT)                                                                          \
     do {                                                                                                    \
@@ -569,11 +574,17 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
     if (sk[1] > 0) lds += sizeof(float) * 2 * (2 * TB * 256 + TB * ENV_STASH + TB * 8);   // two staging halves
     const int key = sk[0] * 100 + sk[1];
     if (p.f16) {
+        // stationary W_1^T / W_0^T fragments: 1 tile of W_0^T per wave for <= 64 inputs, 2 for <= 128
+        const int sh = rollout_variant_h(p) == 0 ? 0 : ((p.pol.kp[0] >> 4) <= 4 ? 1 : 2);
         switch (p.env.kind) {
-            case GOPS_ENV_NONE: LAUNCH_BWD_H(GOPS_ENV_NONE); break;
-            case GOPS_ENV_LQ: LAUNCH_BWD_H(GOPS_ENV_LQ); break;
-            case GOPS_ENV_IDPENDULUM: LAUNCH_BWD_H(GOPS_ENV_IDPENDULUM); break;
-            case GOPS_ENV_VEH3DOFCONTI: LAUNCH_BWD_H(GOPS_ENV_VEH3DOFCONTI); break;
+            case GOPS_ENV_NONE: if (sh == 1) LAUNCH_BWD_H(GOPS_ENV_NONE, 1); else LAUNCH_BWD_H(GOPS_ENV_NONE, 0); break;
+            case GOPS_ENV_LQ: if (sh == 1) LAUNCH_BWD_H(GOPS_ENV_LQ, 1); else LAUNCH_BWD_H(GOPS_ENV_LQ, 0); break;
+            case GOPS_ENV_IDPENDULUM: if (sh == 1) LAUNCH_BWD_H(GOPS_ENV_IDPENDULUM, 1); else LAUNCH_BWD_H(GOPS_ENV_IDPENDULUM, 0); break;
+            case GOPS_ENV_VEH3DOFCONTI:
+                if (sh == 1) LAUNCH_BWD_H(GOPS_ENV_VEH3DOFCONTI, 1);
+                else if (sh == 2) LAUNCH_BWD_H(GOPS_ENV_VEH3DOFCONTI, 2);
+                else LAUNCH_BWD_H(GOPS_ENV_VEH3DOFCONTI, 0);
+                break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

@@ -11,7 +11,8 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgops_hip.so")
+# GOPS_HIP_LIB: another build of the same library (the phase-counter build `make -C gops_amd/csrc dbg`)
+LIB_PATH = os.environ.get("GOPS_HIP_LIB") or os.path.join(_HERE, "libgops_hip.so")
 
 MAX_LAYERS, MAX_ACT, MAX_LQ, TILE = 5, 4, 6, 16
 ENV_NONE, ENV_LQ, ENV_IDP, ENV_VEH = 0, 1, 2, 3

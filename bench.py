@@ -26,8 +26,12 @@ from gops_amd.create_pkg.create_alg import create_alg  # noqa: E402
 from gops_amd.trainer.grad_sync import GradAllReducer  # noqa: E402
 from gops_amd.utils.synthetic import CONFIGS, act_dim_of, make_batch, obs_dim_of  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
-KERNEL_NAMES = {0: "rollout_fwd_kernel", 1: "rollout_bwd_kernel", 2: "dw_gemm_kernel(+reduce)"}
+# MI355X peaks (MI355X_MICROARCH.md): dense fp32 matrix = fp32 vector rate; dense fp16/bf16 MFMA; HBM3E spec
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}
+HBM_PEAK_GBS = 8000.0
+KERNEL_NAMES = {0: "rollout_fwd_kernel", 1: "rollout_bwd_kernel", 2: "dw_gemm_kernel(+reduce)",
+                3: "value_fwd (rollout_fwd_kernel<ENV_NONE>)", 4: "value_bwd (rollout_bwd_kernel<ENV_NONE>)",
+                5: "value_dw_gemm(+reduce)"}
 
 
 def alg_kwargs(cfg, seed):
@@ -52,20 +56,46 @@ def alg_kwargs(cfg, seed):
     return kw
 
 
-def mac_per_step(cfg):
-    sizes = [obs_dim_of(cfg) + (1 if cfg["alg"] == "FHADP" else 0)] + list(cfg["hidden"]) + [act_dim_of(cfg)]
+def mlp_sizes(cfg, net="policy"):
+    if net == "value":
+        return [obs_dim_of(cfg)] + list(cfg["hidden"]) + [1]
+    return [obs_dim_of(cfg) + (1 if cfg["alg"] == "FHADP" else 0)] + list(cfg["hidden"]) + [act_dim_of(cfg)]
+
+
+def mac_per_step(cfg, net="policy"):
+    sizes = mlp_sizes(cfg, net)
     return sum(a * b for a, b in zip(sizes[:-1], sizes[1:]))
 
 
-def cpu_baseline(cfg, seed, eager_gpu=False):
+def bytes_per_step(cfg, dtype):
+    """the activation stash written once and read once = 2 * sizeof * (in + sum(hidden) + A)."""
+    sizes = mlp_sizes(cfg)
+    return 2 * (2 if dtype == "f16" else 4) * sum(sizes)
+
+
+CPU_SAMPLE_MAX_BATCH = 8192   # bounded sample: larger batches are timed on this many trajectories
+
+
+def cpu_baseline(cfg, seed, workload, eager_gpu=False):
     """The oracle (CPU restatement of the reference, pinned to its fixtures) timed on the host
     cores of this box.  Checker only: nothing it computes is used by the GPU path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import reference_init_nets
     from oracle import adp_oracle as orc
+    B = min(cfg["batch"], CPU_SAMPLE_MAX_BATCH)
+    cfg = dict(cfg, batch=B)
     nets = reference_init_nets(cfg, seed, obs_dim_of(cfg), act_dim_of(cfg))
     env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
     data = make_batch(cfg, seed)
+    if cfg["alg"] == "FHADP":
+        def one(e=env, n=nets, d=data):
+            orc.fhadp_gradient(e, n["policy"], d, cfg["horizon"], cfg["gamma"])
+        calls_per_unit = 1
+    else:   # INFADP: one PEV + one PIM gradient = two bench steps
+        def one(e=env, n=nets, d=data):
+            orc.infadp_pev_gradient(e, n["policy"], n["v"], n["v_target"], d, cfg["horizon"], cfg["gamma"])
+            orc.infadp_pim_gradient(e, n["policy"], n["v_target"], d, cfg["horizon"], cfg["gamma"])
+        calls_per_unit = 2
     # The reference pins 4 intra-op threads for serial trainers (gops/utils/init_args.py:31-35); the
     # many tiny ATen ops of this loop scale poorly, so try a few counts and report the fastest.
     ncpu = os.cpu_count() or 4
@@ -75,13 +105,13 @@ def cpu_baseline(cfg, seed, eager_gpu=False):
         times = []
         for i in range(3):
             t0 = time.perf_counter()
-            orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
-            times.append(time.perf_counter() - t0)
+            one()
+            times.append((time.perf_counter() - t0) / calls_per_unit)
         results[nthreads] = min(times[1:])
     best_threads = min(results, key=results.get)
     best = results[best_threads]
     eager = None
-    if eager_gpu:   # the same restatement as plain PyTorch-ROCm eager ops on the GPU ("no-kernel" baseline)
+    if eager_gpu and cfg["alg"] == "FHADP":   # the same restatement as plain PyTorch-ROCm eager ops on the GPU ("no-kernel" baseline)
         dev = torch.device("cuda", torch.cuda.current_device())
         src = nets["policy"]
         pol = dict(src, w=[w.detach().to(dev).requires_grad_(True) for w in src["w"]],
@@ -100,32 +130,55 @@ def cpu_baseline(cfg, seed, eager_gpu=False):
             orc.fhadp_gradient(denv, pol, ddata, cfg["horizon"], cfg["gamma"])
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
-        eager = cfg["batch"] * cfg["horizon"] / min(times[1:])
-    return {"eager_gpu_steps_per_s": eager, "value": cfg["batch"] * cfg["horizon"] / best, "unit": "env-model steps/s",
-            "cores": best_threads, "kind": "port",
-            "sample": f"full workload batch (B={cfg['batch']}, H={cfg['horizon']}); per thread count 1 warm-up + 2 "
-                      f"timed compute_gradient calls (fwd+bwd), best call; "
-                      + ", ".join(f"{n} threads: {t * 1e3:.0f} ms" for n, t in results.items())
-                      + f"; host has {ncpu} logical CPUs"}
+        eager = B * cfg["horizon"] / min(times[1:])
+    out = {"eager_gpu_steps_per_s": eager, "value": B * cfg["horizon"] / best, "unit": "env-model steps/s",
+           "cores": best_threads, "kind": "port",
+           "sample": f"{B} of the workload's {CONFIGS[workload]['batch']} trajectories x H={cfg['horizon']}; per thread count 1 warm-up + 2 "
+                     f"timed gradient evaluations (fwd+bwd{', PEV and PIM averaged' if calls_per_unit == 2 else ''}), best; "
+                     + ", ".join(f"{n} threads: {t * 1e3:.0f} ms" for n, t in results.items())
+                     + f"; host has {ncpu} logical CPUs"}
+    # the port is faster than the reference classes it restates (no deepcopy(data), no per-key info clones, no
+    # torch.equal host checks): profiles/cpu_port_calibration.json (tools/calibrate_cpu_port.py, build container)
+    # holds the measured ratio on identical cores
+    cal_path = os.path.join(ROOT, "profiles", "cpu_port_calibration.json")
+    if os.path.exists(cal_path):
+        cal = json.load(open(cal_path))
+        rec = cal.get("workloads", {}).get(workload)
+        if rec is not None:
+            out["calibration"] = {"reference_over_port_time_ratio": rec["ratio_ref_over_port"],
+                                  "estimated_reference_value": out["value"] / rec["ratio_ref_over_port"],
+                                  "measured_on": f"{cal['cpu']} ({cal['logical_cpus']} logical CPUs)",
+                                  "source": "profiles/cpu_port_calibration.json"}
+    return out
 
 
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC pass
-    (profiles/rNN_pmc_per_launch.json, made by tools/summarize_profile.py from separate
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs; FETCH_SIZE doubled per
-    MI355X_MICROARCH.md, both counters are KiB).  None when no profile is committed."""
+def pmc_profile(workload, dtype):
+    """Per-launch PMC counters of this workload from the newest committed profile
+    (profiles/rNN_<workload>[_f16]_pmc_per_launch.json, made by tools/summarize_profile.py from separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes).  None when no profile of THIS workload and
+    dtype is committed (another workload's counters are never substituted)."""
     pdir = os.path.join(ROOT, "profiles")
-    files = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_per_launch.json")) if os.path.isdir(pdir) else []
+    tag = workload + ("_f16" if dtype == "f16" else "") + "_pmc_per_launch.json"
+    files = sorted(f for f in os.listdir(pdir) if f.endswith("_" + tag)) if os.path.isdir(pdir) else []
     if not files:
+        return None, None
+    return json.load(open(os.path.join(pdir, files[-1]))), "profiles/" + files[-1]
+
+
+def kernel_bytes(c):
+    """HBM bytes of one launch from its counters: FETCH_SIZE (KiB; doubled on gfx950, MI355X_MICROARCH.md) +
+    WRITE_SIZE (KiB)."""
+    if c is None or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         return None
-    pmc = json.load(open(os.path.join(pdir, files[-1])))
-    for name, c in pmc.items():
-        if kernel_key in name and "WRITE_SIZE" in c and ("FETCH_SIZE" in c or "TCC_EA0_RDREQ_sum" in c):
-            # reads: FETCH_SIZE (KiB, x2 on gfx950) or, where that pass was unavailable, the L2's HBM-side read
-            # requests x 128 B (the two agree to 0.1 % where both were collected)
-            rd = 2.0 * c["FETCH_SIZE"] * 1024.0 if "FETCH_SIZE" in c else c["TCC_EA0_RDREQ_sum"] * 128.0
-            return {"bytes": rd + c["WRITE_SIZE"] * 1024.0, "source": "profiles/" + files[-1]}
-    return None
+    return 2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0
+
+
+def pmc_traffic(pmc, source, kernel_key):
+    if pmc is None:
+        return None
+    # several instantiations can share the name (the value net runs the ENV_NONE one): the rollout's is the largest
+    hits = [kernel_bytes(c) for name, c in pmc.items() if kernel_key in name and kernel_bytes(c) is not None]
+    return {"bytes": max(hits), "source": source} if hits else None
 
 
 def main():
@@ -173,8 +226,8 @@ def main():
         if world == 1:
             alg.local_update(data, it)
         else:
-            _, info = alg.get_remote_update_info(data, it)
-            reducer.average_(info)
+            _, info = alg.get_remote_update_info(data, it)   # no host sync: the loss stays on the device
+            reducer.average_(info, defer_scale=True)         # one flat SUM all-reduce; 1/N applied inside the Adam kernel
             alg.remote_update(info)
 
     def barrier():
@@ -207,32 +260,65 @@ def main():
 
     if rank == 0:
         B, H = cfg["batch"], cfg["horizon"]
+        dt = "f16" if args.dtype == "fp16" else "f32"
         steps_total = world * B * H * args.steps
-        kern = {k: hb.profile_read(k) for k in (0, 1, 2)}
-        flops_per_launch = 2.0 * mac_per_step(cfg) * B * H      # each of fwd / dX sweep / dW
-        dom = max(kern, key=lambda k: kern[k][0])
+        value = steps_total / elapsed
+        kern = {k: hb.profile_read(k) for k in range(6)}
+        # algorithmic work of ONE launch of each rollout kernel: 2 MAC per sample-step for each of
+        # forward / input-adjoint sweep / weight gradients; INFADP's forward and sweep also carry the tail value net
+        tail = cfg["alg"] == "INFADP"
+        flops = {0: 2.0 * (mac_per_step(cfg) * B * H + (mac_per_step(cfg, "value") * B if tail else 0)),
+                 2: 2.0 * mac_per_step(cfg) * B * H}
+        flops[1] = flops[0]
+        flops.update({3: 2.0 * mac_per_step(cfg, "value") * B, 4: 2.0 * mac_per_step(cfg, "value") * B,
+                      5: 2.0 * mac_per_step(cfg, "value") * B})
+        bps = bytes_per_step(cfg, dt)
+        alg_bytes = {0: 0.5 * bps * B * H, 1: 0.5 * bps * B * H, 2: 0.5 * bps * B * H}   # stash written once / read once / read once
+        dom = max((0, 1, 2), key=lambda k: kern[k][0])
         dom_ms = kern[dom][0]
-        achieved = flops_per_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        pmc, pmc_src = pmc_profile(args.workload, dt)
+        peak_tf = MFMA_PEAK_TFLOPS[dt]
+        if dt == "f32":   # exact-fp32 MFMA: arithmetic intensity 115 FLOP/B >> machine balance -> the matrix pipe binds
+            achieved = flops[dom] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+            roofline = {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": peak_tf,
+                        "unit": "TFLOP/s", "frac": achieved / peak_tf,
+                        "traffic": pmc_traffic(pmc, pmc_src, KERNEL_NAMES[dom].split("(")[0]),
+                        "algorithmic_flops_per_launch": flops[dom], "avg_ms": dom_ms}
+        else:             # half-precision MFMA is 16x faster: the stash traffic binds
+            achieved = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            roofline = {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": pmc_traffic(pmc, pmc_src, KERNEL_NAMES[dom].split("(")[0]),
+                        "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_ms": dom_ms}
+        # whole-update fractions of both roofs (SURVEY 8d asks for both next to each other)
+        per_step_flops = 6.0 * mac_per_step(cfg)
+        hbm_measured = None
+        if pmc is not None:   # counter bytes of every kernel of one update / the update's time
+            tot = [kernel_bytes(c) * c.get("launches_per_update", 1.0) for c in pmc.values() if kernel_bytes(c) is not None]
+            if tot:
+                hbm_measured = sum(tot) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
+        alg_name = cfg["alg"]
         out = {
-            "metric": "env-model steps/sec (batch x H), FHADP compute_gradient + update",
-            "value": steps_total / elapsed, "unit": "env-model steps/s", "n_gpus": world,
+            "metric": f"env-model steps/sec (batch x H), {alg_name} compute_gradient + update",
+            "value": value, "unit": "env-model steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt,
             "data": "synthetic (seeded initial states, random-init networks)",
-            "config": {"workload": args.workload, "env_id": cfg["env_id"], "algorithm": cfg["alg"],
-                       "batch_per_gpu": B, "horizon": H, "policy_mlp": [obs_dim_of(cfg) + (1 if cfg["alg"] == "FHADP" else 0)] + list(cfg["hidden"]) + [act_dim_of(cfg)],
+            "config": {"workload": args.workload, "env_id": cfg["env_id"], "algorithm": alg_name,
+                       "batch_per_gpu": B, "horizon": H, "policy_mlp": mlp_sizes(cfg),
                        "activation": cfg["act"], "parallelism": f"dp{world}"},
             "rollouts_per_sec": world * B * args.steps / elapsed,
-            "roofline": {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": achieved,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(KERNEL_NAMES[dom].split("(")[0]), "algorithmic_flops_per_launch": flops_per_launch,
-                         "avg_ms": dom_ms},
+            "roofline": roofline,
+            "flops_fraction": value / world * per_step_flops / (peak_tf * 1e12),
+            "alg_hbm_fraction": value / world * bps / (HBM_PEAK_GBS * 1e9),
+            "hbm_fraction": hbm_measured,
+            "hbm_fraction_source": pmc_src if hbm_measured is not None else None,
             "kernels_ms": {KERNEL_NAMES[k]: {"avg_ms": kern[k][0], "launches": kern[k][1],
-                                             "tflops": (flops_per_launch / (kern[k][0] * 1e-3) / 1e12) if kern[k][0] > 0 else 0.0}
-                           for k in kern},
+                                             "tflops": (flops[k] / (kern[k][0] * 1e-3) / 1e12) if kern[k][0] > 0 else 0.0}
+                           for k in kern if kern[k][1] > 0},
         }
-        if world == 1 and not args.no_cpu_baseline and cfg["alg"] == "FHADP":
-            out["cpu_baseline"] = cpu_baseline(cfg, 0, args.eager_gpu_baseline)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, 0, args.workload, args.eager_gpu_baseline)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

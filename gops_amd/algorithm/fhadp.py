@@ -71,22 +71,30 @@ class FHADP(AlgorithmBase):
 
         loss = self._update_graph.run(self._signature(batch), batch, update,
                                       before_replay=opt.sync_hyper, on_replay=opt.advance,
-                                      work=batch["obs"].shape[0] * self.pre_horizon)
+                                      work=batch["obs"].shape[0] * self.pre_horizon,
+                                      on_capture_fail=opt.resync_device_state)
         self._log(loss)
         return self.tb_info
 
+    accepts_grad_scale = True   # remote_update honours update_info["_grad_scale"] (trainer/grad_sync.py)
+
     def get_remote_update_info(self, data, iteration: int):
+        # Data-parallel path: NO host sync here - the gradient all-reduce is queued right behind the backward
+        # sweep.  The loss stays a device scalar in tb_info (`add_scalars` reads it at log time).
         self._t0 = time.time()
         batch = self._device_batch(data)
         loss = self._grad_graph.run(self._signature(batch), batch, self._gradient_kernels,
                                    work=batch["obs"].shape[0] * self.pre_horizon)
-        self._log(loss)
+        self.tb_info[tb_tags["loss_actor"]] = -loss          # 0-dim device tensor
+        self.tb_info[tb_tags["alg_time"]] = (time.time() - self._t0) * 1000   # ms of host enqueue time
         return self.tb_info, {"grad": [p._grad for p in self.networks.policy.parameters()]}
 
     def _remote_update(self, update_info):
         for p, grad in zip(self.networks.policy.parameters(), update_info["grad"]):
             p.grad = grad
-        self.networks.policy_optimizer.step()
+        opt = self.networks.policy_optimizer
+        opt.grad_scale = float(update_info.get("_grad_scale", 1.0))
+        opt.step()
 
     # ------------------------------------------------------------------------------------------
     def _rollout_for(self, batch: int, device) -> hb.Rollout:
@@ -114,7 +122,11 @@ class FHADP(AlgorithmBase):
         """What a captured graph is specialised on: shapes, rollout settings, parameter / gradient storage."""
         return (tuple((k, tuple(v.shape)) for k, v in batch.items()), self.pre_horizon, float(self.gamma),
                 tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr())
-                      for p in self.networks.policy.parameters()))
+                      for p in self.networks.policy.parameters()),
+                # everything else a captured kernel chain holds raw pointers to: Adam moments / device state
+                # (replaced by optimizer.load_state_dict) and the rollout workspace (replaced when the shape changes)
+                self.networks.policy_optimizer.storage_signature(),
+                tuple(ro.workspace.data_ptr() for ro in self._rollouts.values()))
 
     def _gradient_kernels(self, batch):
         """Enqueue forward rollout, loss and backward sweep; returns mean(v_pi) (device scalar)."""

@@ -87,20 +87,35 @@ class INFADP(AlgorithmBase):
 
         cache = self._graphs.setdefault(mode, StepGraphCache())
         scalars = cache.run(self._signature(mode, batch), batch, update, before_replay=opt.sync_hyper,
-                            on_replay=opt.advance, work=batch["obs"].shape[0] * self.forward_step)
+                            on_replay=opt.advance, work=batch["obs"].shape[0] * self.forward_step,
+                            on_capture_fail=opt.resync_device_state)
         self._log(mode, scalars, start_time)
         return self.tb_info
 
+    accepts_grad_scale = True   # remote_update honours update_info["_grad_scale"] (trainer/grad_sync.py)
+
     def get_remote_update_info(self, data: dict, iteration: int) -> Tuple[dict, dict]:
-        update_list = self._compute_gradient(data, iteration)
-        update_info = {name: [p.grad for p in self.networks.net_dict[name].parameters()] for name in update_list}
+        # Data-parallel path: no host sync between the backward sweep and the gradient all-reduce - the loss
+        # scalars stay on the device in tb_info and are read at log time.
+        start_time = time.time()
+        batch = batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
+        mode = self._mode(iteration)
+        scalars = self._gradient_kernels(mode, batch)
+        if mode == "v":
+            self.tb_info[tb_tags["loss_critic"]], self.tb_info[tb_tags["critic_avg_value"]] = scalars[0], scalars[1]
+        else:
+            self.tb_info[tb_tags["loss_actor"]] = scalars[0]
+        self.tb_info[tb_tags["alg_time"]] = (time.time() - start_time) * 1000  # ms of host enqueue time
+        update_info = {mode: [p.grad for p in self.networks.net_dict[mode].parameters()]}
         return self.tb_info, update_info
 
     def remote_update(self, update_info: dict):
-        for net_name, grads in update_info.items():
-            for p, grad in zip(self.networks.net_dict[net_name].parameters(), grads):
+        names = [k for k in update_info if not k.startswith("_")]
+        for net_name in names:
+            for p, grad in zip(self.networks.net_dict[net_name].parameters(), update_info[net_name]):
                 p.grad = grad
-        self._update(list(update_info.keys()))
+            self.networks.optimizer_dict[net_name].grad_scale = float(update_info.get("_grad_scale", 1.0))
+        self._update(names)
 
     def _update(self, update_list):
         tau = self.tau
@@ -187,4 +202,6 @@ class INFADP(AlgorithmBase):
         mods = (nets.v, nets.v_target, nets.policy) if mode == "v" else (nets.policy, nets.policy_target, nets.v_target)
         return (mode, tuple((k, tuple(v.shape)) for k, v in batch.items()), self.forward_step, float(self.gamma),
                 float(self.tau), tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr())
-                                       for m in mods for p in m.parameters()))
+                                       for m in mods for p in m.parameters()),
+                nets.optimizer_dict[mode].storage_signature(),   # Adam moments / device state, workspaces: raw pointers
+                tuple(sorted(obj.workspace.data_ptr() for obj in self._cache.values())))

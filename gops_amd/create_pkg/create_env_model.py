@@ -106,6 +106,9 @@ def create_env_model(
         raise RuntimeError("ScaleObservationModel (obs_shift/obs_scale) is not supported by the HIP env models")
     if not mask_at_done:
         raise RuntimeError("mask_at_done=False is not supported by the HIP env models")
+    # action_scale=True with clip_action=False needs no flag: ScaleActionModel already ends with
+    # clip(., action_lower_bound, action_upper_bound) (scale_action.py:75-83) and ClipActionModel applies that same
+    # clamp once more (clip_action.py:34-36) - idempotent, so the kernels' chain is exact for both settings.
     if not action_scale:
         if not clip_action:
             raise RuntimeError("action_scale=False with clip_action=False is not supported by the HIP env models")

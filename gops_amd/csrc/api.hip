@@ -49,7 +49,7 @@ constexpr size_t kAlign = 256;   // bytes
 struct ProfState {
     std::mutex mu;
     bool on = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[6];   // 0-2: rollout fwd / bwd / dW; 3-5: the same for plain MLP batches (value net)
 } g_prof;
 
 struct ProfScope {
@@ -295,7 +295,7 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
     if (ue != hipSuccess) return (int)ue;
     int ret;
     {
-        ProfScope scope(0, s);
+        ProfScope scope(desc.env.kind == GOPS_ENV_NONE ? 3 : 0, s);
         ret = (int)launch_rollout_fwd(p, plan.dev_params, s);
     }
     if (dbg) {
@@ -332,7 +332,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     p.dbg = dbg ? dbg_buf : nullptr;
     if ((e = launch_upload_params(p, plan.dev_params, s)) != hipSuccess) return (int)e;
     {
-        ProfScope scope(1, s);
+        ProfScope scope(desc.env.kind == GOPS_ENV_NONE ? 4 : 1, s);
         if ((e = launch_rollout_bwd(p, plan.dev_params, s)) != hipSuccess) return (int)e;
     }
     if (dbg) {
@@ -344,12 +344,12 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
                 h[8] / p.H, h[9] / p.H, h[2] / p.H);
     }
     if (p.open_loop) return GOPS_OK;   // no parameters behind the rollout: the head adjoint is the result
-    ProfScope scope(2, s);
+    ProfScope scope(desc.env.kind == GOPS_ENV_NONE ? 5 : 2, s);
     const long long S = (long long)((p.B + TB - 1) / TB) * TB * p.H;
     const int L = p.pol.nl - 1;
     ReduceJobs jobs;
     memset(&jobs, 0, sizeof(jobs));
-    if (p.f16) jobs.unscale = p.gscale + 1;   // the sweep ran on gradients scaled by gscale[0]
+    if (p.f16) jobs.unscale = p.gscale;   // the sweep ran on gradients scaled by f16_grad_scale(max|grad_v|)
     for (int j = 0; j < L; ++j) {   // dW_j = D_{j+1}^T * (j == 0 ? X : H_j)
         const int N = p.pol.dims[j + 1], Kp = p.f16 ? p.pol.kp32[j] : p.pol.kp[j], K = p.pol.dims[j];
         const DwPlan d = plan_dw(N, Kp, S, p.f16 != 0);
@@ -492,7 +492,7 @@ void gops_profile_reset(void) {
 }
 
 int gops_profile_read(int32_t kernel_id, double* avg_ms, int64_t* launches) {
-    if (kernel_id < 0 || kernel_id > 2 || !avg_ms || !launches) return GOPS_ERR_BAD_ARG;
+    if (kernel_id < 0 || kernel_id > 5 || !avg_ms || !launches) return GOPS_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     double tot = 0.0;
     int64_t n = 0;

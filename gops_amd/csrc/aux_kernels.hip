@@ -57,43 +57,34 @@ __device__ __forceinline__ void pack_element_h(const float* __restrict__ W, int 
 
 // Copies the by-value parameter block into device memory (stream ordered, no host staging): the
 // rollout kernels then read it with uniform scalar loads instead of a per-lane scratch copy.
-// F16 launches: the same block also scans grad_v for max|g| and publishes the power-of-two scale s that
-// brings it into [1, 2) (deltas then sit mid-range in half: 2^15 of headroom above - conversions saturate
-// instead of overflowing - and normals down to 2^-14 of it), as {s, 1/s} in p.gscale.  max|g| == 0 or
-// non-finite -> s = 1.
-__global__ void upload_params_kernel(const RolloutParams p, RolloutParams* dst) {
-    const unsigned* src = reinterpret_cast<const unsigned*>(&p);
-    unsigned* d = reinterpret_cast<unsigned*>(dst);
-    for (unsigned i = threadIdx.x; i < sizeof(RolloutParams) / 4; i += blockDim.x) d[i] = src[i];
+// F16 launches: every block also folds its slice of grad_v into max|g| (atomicMax on the bit pattern - for
+// non-negative floats the unsigned order is the numeric order) in p.gscale[0], which the forward prologue
+// zeroed.  The sweep and the reduce kernel derive the power-of-two scale from it (f16_grad_scale, common.h).
+__global__ __launch_bounds__(256) void upload_params_kernel(const RolloutParams p, RolloutParams* dst) {
+    if (blockIdx.x == 0) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(&p);
+        unsigned* d = reinterpret_cast<unsigned*>(dst);
+        for (unsigned i = threadIdx.x; i < sizeof(RolloutParams) / 4; i += blockDim.x) d[i] = src[i];
+    }
     if (p.f16 && p.gscale != nullptr && p.grad_v != nullptr) {
         __shared__ float red[256];
         float mx = 0.f;
-        for (int i = threadIdx.x; i < p.B; i += blockDim.x) mx = fmaxf(mx, fabsf(p.grad_v[i]));
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.B; i += gridDim.x * blockDim.x) mx = fmaxf(mx, fabsf(p.grad_v[i]));
         red[threadIdx.x] = mx;
         __syncthreads();
         for (int w = 128; w > 0; w >>= 1) {
             if ((int)threadIdx.x < w) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            const float m = red[0];
-            float sc = 1.f;
-            if (m > 0.f && m < 3.0e38f) {
-                int ex;
-                (void)frexpf(m, &ex);          // m = f * 2^ex, f in [0.5, 1)
-                int sh = 1 - ex;               // 2^sh * m in [1, 2)
-                sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
-                sc = ldexpf(1.f, sh);
-            }
-            p.gscale[0] = sc;
-            p.gscale[1] = 1.f / sc;
-        }
+        if (threadIdx.x == 0 && red[0] < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(p.gscale), __float_as_uint(red[0]));
     }
 }
 
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s) {
     static_assert(sizeof(RolloutParams) % 4 == 0, "parameter block must be dword sized");
-    hipLaunchKernelGGL(upload_params_kernel, dim3(1), dim3(256), 0, s, p, dst);
+    int nb = 1;
+    if (p.f16) { nb = (p.B + 4095) / 4096; nb = nb < 1 ? 1 : (nb > 128 ? 128 : nb); }   // >= 16 elements per thread
+    hipLaunchKernelGGL(upload_params_kernel, dim3(nb), dim3(256), 0, s, p, dst);
     return hipGetLastError();
 }
 
@@ -203,6 +194,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
         const unsigned* src = reinterpret_cast<const unsigned*>(&p);
         unsigned* d = reinterpret_cast<unsigned*>(dst);
         for (unsigned i = threadIdx.x; i < sizeof(RolloutParams) / 4; i += blockDim.x) d[i] = src[i];
+        if (p.f16 && p.gscale != nullptr && threadIdx.x == 0) p.gscale[0] = 0.f;   // max|grad_v| of the coming backward
         return;
     }
     b -= 1;
@@ -785,7 +777,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
     __syncthreads();
     if (sl == 0 && valid) {
         float t = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
-        if (jobs.unscale != nullptr) t *= *jobs.unscale;   // power of two: exact
+        if (jobs.unscale != nullptr) t *= 1.f / f16_grad_scale(*jobs.unscale);   // power of two: exact
         jobs.out[j][idx] = t;
     }
 }
@@ -815,6 +807,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const GopsAdamTensors T, Gops
     const double b1p = st->beta1_pow * beta1, b2p = st->beta2_pow * beta2;   // beta^t, t = step + 1
     const float step_size = (float)(st->lr / (1.0 - b1p)), bc2_sqrt = (float)sqrt(1.0 - b2p);
     const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2), b2 = (float)beta2;
+    const float gsc = (float)st->grad_scale;   // 1/N of the data-parallel mean (1 otherwise)
     const int ti = blockIdx.y;
     const long long n = T.numel[ti];
     float* __restrict__ p = T.param[ti];
@@ -822,7 +815,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const GopsAdamTensors T, Gops
     float* __restrict__ m = T.exp_avg[ti];
     float* __restrict__ v = T.exp_avg_sq[ti];
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float gi = g[i];
+        const float gi = g[i] * gsc;
         const float mi = m[i] + (gi - m[i]) * omb1;
         const float vi = v[i] * b2 + omb2 * gi * gi;
         m[i] = mi;

@@ -71,7 +71,7 @@ struct RolloutParams {
     const float* ref_table;           // veh: [B][P+1+H][4]
     unsigned long long* dbg;          // debug: per-phase cycle counters of block 0 (GOPS_DBG_TIMING)
     int f16;                          // 1: GOPS_DTYPE_F16
-    float* gscale;                    // f16 backward: {s, 1/s}, s = power of two that brings max|grad_v| into [1, 2)
+    float* gscale;                    // f16 backward: gscale[0] = max|grad_v| of the launch (upload_params_kernel)
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double
 };
 
@@ -113,8 +113,20 @@ struct ReduceJobs {
     const float* part[2 * GOPS_MAX_LAYERS];
     float* out[2 * GOPS_MAX_LAYERS];
     int splits[2 * GOPS_MAX_LAYERS], rows[2 * GOPS_MAX_LAYERS], cols[2 * GOPS_MAX_LAYERS], ld[2 * GOPS_MAX_LAYERS];
-    const float* unscale;                  // f16: device pointer to 1/s (see RolloutParams::gscale), else null
+    const float* unscale;                  // f16: device pointer to max|grad_v| (RolloutParams::gscale), else null
 };
+
+// GOPS_DTYPE_F16 backward: the power of two s that brings max|grad_v| = m into [1, 2).  The whole sweep runs
+// on s * grad_v (half deltas then sit mid-range: 2^15 of headroom above - conversions saturate - and normals
+// down to 2^-14 of the largest) and the reduce kernel multiplies the parameter gradients by 1/s (exact).
+__device__ __forceinline__ float f16_grad_scale(float m) {
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 1.f;
+    int ex;
+    (void)frexpf(m, &ex);          // m = f * 2^ex, f in [0.5, 1)
+    int sh = 1 - ex;
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    return ldexpf(1.f, sh);
+}
 
 // ---- activations ---------------------------------------------------------------------------
 #define SELU_SCALE 1.0507009873554804934193349852946f

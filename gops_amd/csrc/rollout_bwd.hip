@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
     float gv = (tid < nvalid) ? gptr(p.grad_v)[b0 + tid] : 0.f;
-    if constexpr (F16) gv *= gptr(p.gscale)[0];
+    if constexpr (F16) gv *= f16_grad_scale(gptr(p.gscale)[0]);
     const int ld16 = (p.ldh - 4) + 8;                 // F16: leading dimension (halfs) of the delta tiles
     const float* xrows = F16 ? p.st.xf : p.st.x;      // fp32 observation columns the env adjoints read
     const int xld = F16 ? 8 : p.pol.kp[0];

@@ -369,7 +369,10 @@ class HipAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        self._dev = {}   # group index -> {"state": GopsAdamState device tensors (5 x 8 bytes) per chunk, "lr", "step"}
+        self._dev = {}   # group index -> {"state": GopsAdamState device tensors (6 x 8 bytes) per chunk, "lr", "step"}
+        # factor applied to every gradient element inside the kernel: 1/N after a SUM all-reduce over N replicas
+        # (trainer/grad_sync.py) - the mean costs no separate pass over the gradients
+        self.grad_scale = 1.0
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -394,8 +397,8 @@ class HipAdam(torch.optim.Optimizer):
         nchunk = (len(ps) + ADAM_MAX - 1) // ADAM_MAX
         dev = self._dev.get(gi)
         if dev is None or len(dev["state"]) != nchunk or dev["state"][0].device != ps[0].device:
-            dev = self._dev[gi] = {"state": [torch.zeros(5, dtype=torch.int64, device=ps[0].device)
-                                             for _ in range(nchunk)], "lr": None, "step": None}
+            dev = self._dev[gi] = {"state": [torch.zeros(6, dtype=torch.int64, device=ps[0].device)
+                                             for _ in range(nchunk)], "lr": None, "step": None, "gs": None}
         if dev["step"] != step:       # first use, after load_state_dict, or an external edit of state
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("HipAdam: device step count out of date while capturing a graph")
@@ -409,19 +412,43 @@ class HipAdam(torch.optim.Optimizer):
         self._sync_lr(dev, group)
         return ps, dev
 
-    @staticmethod
-    def _sync_lr(dev, group):
+    def _sync_lr(self, dev, group):
         lr = float(group["lr"])
         if dev["lr"] != lr:
             for t in dev["state"]:
                 t.view(torch.float64)[0] = lr
             dev["lr"] = lr
+        gs = float(self.grad_scale)
+        if dev.get("gs") != gs:
+            for t in dev["state"]:
+                t.view(torch.float64)[5] = gs
+            dev["gs"] = gs
 
     def sync_hyper(self):
         """Push a changed `lr` (schedulers) to the device copies; call before replaying a graph."""
         for gi, group in enumerate(self.param_groups):
             if gi in self._dev:
                 self._sync_lr(self._dev[gi], group)
+
+    def storage_signature(self):
+        """Device addresses a captured `step()` has baked in besides parameters and gradients: the Adam moments
+        and the device-resident hyper-parameter blocks.  `load_state_dict` (new moment tensors, `_dev` dropped)
+        changes it, which makes graph owners re-capture instead of replaying into freed memory."""
+        sig = []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                st = self.state.get(p, {})
+                if len(st):
+                    sig.append((st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
+            if gi in self._dev:
+                sig.append(tuple(t.data_ptr() for t in self._dev[gi]["state"]))
+        return tuple(sig)
+
+    def resync_device_state(self):
+        """Forget the device mirrors of (lr, step, beta powers): the next `step()` re-pushes them from the host
+        state.  Used after an aborted graph capture, whose host-side step bookkeeping ran without the kernel."""
+        for dev in self._dev.values():
+            dev["step"] = dev["lr"] = dev["gs"] = None
 
     def advance(self, n: int = 1):
         """Account for `n` graph replays of `step()` in the host-side step counters."""

@@ -3,6 +3,7 @@ periodic TensorBoard logging, checkpoints (`apprfunc/apprfunc_{it}.pkl`, best-so
 in-process evaluation.  File names, intervals and tags follow the reference trainers
 (gops/trainer/on_serial_trainer.py:30-152, off_serial_trainer.py:30-188); the networks live on the GPU
 for the whole run and the evaluator is called directly (no Ray actor)."""
+import copy
 import os
 import time
 from math import inf
@@ -28,14 +29,31 @@ class RunningMean:
         return out
 
 
+def call_maybe_remote(obj, name, *args):
+    """`obj.name(*args)`, or `ray.get(obj.name.remote(*args))` when `obj` is a Ray actor handle: GOPS's
+    `create_evaluator` returns `ray.remote(Evaluator).remote(...)` (gops/create_pkg/create_evaluator.py),
+    whose methods cannot be called directly."""
+    method = getattr(obj, name)
+    if hasattr(method, "remote"):
+        import ray
+        return ray.get(method.remote(*args))
+    return method(*args)
+
+
 class TrainerBase:
     def __init__(self, alg, sampler, evaluator, **kwargs):
         self.alg, self.sampler, self.evaluator = alg, sampler, evaluator
         self.networks = self.alg.networks
-        if self.sampler is not None:
-            self.sampler.networks = self.networks
         if kwargs.get("ini_network_dir") is not None:
             self.networks.load_state_dict(torch.load(kwargs["ini_network_dir"]))
+        # The learner's networks live on the MI355X from construction on (the algorithms have no CPU path): every
+        # pointer the HIP path caches stays valid, and device samplers see device weights from the first call.
+        if torch.cuda.is_available() and not next(self.networks.parameters()).is_cuda:
+            self.networks.to(torch.device("cuda", torch.cuda.current_device()))
+        self._host_networks = None
+        if self.sampler is not None:
+            self.sampler.networks = self.networks
+            self._refresh_sampler_networks()
         self.max_iteration = kwargs.get("max_iteration")
         self.log_save_interval = kwargs["log_save_interval"]
         self.apprfunc_save_interval = kwargs["apprfunc_save_interval"]
@@ -49,6 +67,19 @@ class TrainerBase:
         add_scalars({tb_tags["alg_time"]: 0, tb_tags["sampler_time"]: 0}, self.writer, 0)
         self.sampler_tb_dict = RunningMean()
         self.start_time = time.time()
+
+    def _refresh_sampler_networks(self):
+        """Samplers that step numpy envs with the policy on the CPU (the reference's, INTEGRATION.md option A') get
+        their own host copy of the container, refreshed from the learner's weights before each sampling call (a
+        0.4 MB device-to-host copy); the learner's parameters never move.  Device samplers (`on_device`) share the
+        learner's container."""
+        if self.sampler is None or getattr(self.sampler, "on_device", False):
+            return
+        if next(self.networks.parameters()).is_cuda:
+            if self._host_networks is None:
+                self._host_networks = copy.deepcopy(self.networks).to("cpu")
+                self.sampler.networks = self._host_networks
+            self._host_networks.load_state_dict(self.networks.state_dict())
 
     # ---- one iteration = subclass `step()`, then this -------------------------------------------
     def _after_update(self, alg_tb_dict):
@@ -67,8 +98,8 @@ class TrainerBase:
         return folder
 
     def _evaluate(self):
-        self.evaluator.load_state_dict({k: v.cpu() for k, v in self.networks.state_dict().items()})
-        total_avg_return = self.evaluator.run_evaluation(self.iteration)
+        call_maybe_remote(self.evaluator, "load_state_dict", {k: v.cpu() for k, v in self.networks.state_dict().items()})
+        total_avg_return = call_maybe_remote(self.evaluator, "run_evaluation", self.iteration)
         self.last_eval_iteration = self.iteration
         if total_avg_return >= self.best_tar and self.iteration >= self.max_iteration / 5:
             self.best_tar = total_avg_return

@@ -46,17 +46,24 @@ class GradAllReducer:
     def __init__(self, group=None):
         self.group = group
 
-    def average_(self, update_info: Dict[str, List[torch.Tensor]]) -> Dict[str, List[torch.Tensor]]:
+    def average_(self, update_info: Dict[str, List[torch.Tensor]], defer_scale: bool = False) -> Dict[str, List[torch.Tensor]]:
+        """`defer_scale`: leave the SUM in the buffers and hand the 1/N to the consumer as
+        `update_info["_grad_scale"]` - the HIP Adam kernel multiplies it in as it reads the gradients
+        (`hip_backend.HipAdam.grad_scale`), which saves the elementwise launch between the collective and
+        the optimizer step.  Entries whose name starts with "_" are not gradients and are left alone."""
         n = world_size()
         if n == 1:
             return update_info
-        tensors = [g for name in sorted(update_info) for g in update_info[name]]
+        tensors = [g for name in sorted(update_info) if not name.startswith("_") for g in update_info[name]]
         flat = _as_one_buffer(tensors)
         in_place = flat is not None
         if not in_place:
             flat = _flatten_dense_tensors(tensors)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)   # SUM + scale: valid on every backend / RCCL build
-        flat.div_(n)
+        if defer_scale:
+            update_info["_grad_scale"] = 1.0 / n
+        else:
+            flat.div_(n)
         if not in_place:
             torch._foreach_copy_(tensors, list(_unflatten_dense_tensors(flat, tensors)))
         return update_info

@@ -8,7 +8,6 @@ device resident (`gops_amd/trainer/buffer/replay_buffer.py`), so the sampled bat
 a CPU copy of the weights only when it samples, instead of the whole container bouncing with
 ModuleOnDevice, :81); the evaluator runs in-process (no Ray).
 """
-import copy
 import time
 
 from gops_amd.trainer._common import TrainerBase
@@ -20,7 +19,6 @@ class OffSerialTrainer(TrainerBase):
     def __init__(self, alg, sampler, buffer, evaluator, **kwargs):
         super().__init__(alg, sampler, evaluator, **kwargs)
         self.buffer = buffer
-        self._host_networks = None
         if kwargs.get("buffer_name") == "prioritized_replay_buffer":
             raise NotImplementedError("prioritized replay is outside the MI355X ADP path (FHADP / INFADP use uniform replay)")
         self.replay_batch_size = kwargs["replay_batch_size"]
@@ -31,17 +29,7 @@ class OffSerialTrainer(TrainerBase):
         self.start_time = time.time()
 
     def _sampler_samples(self):
-        """The reference's samplers step numpy envs with the policy on the CPU: they get their own host
-        copy of the container, refreshed from the learner's weights before each sampling call (a 0.4 MB
-        device-to-host copy); the learner's parameters never move, so every pointer the HIP path has
-        cached stays valid."""
-        if getattr(self.sampler, "on_device", False):
-            return self.sampler.sample()
-        if next(self.networks.parameters()).is_cuda:
-            if self._host_networks is None:
-                self._host_networks = copy.deepcopy(self.networks).to("cpu")
-                self.sampler.networks = self._host_networks
-            self._host_networks.load_state_dict(self.networks.state_dict())
+        self._refresh_sampler_networks()   # host samplers: fresh CPU copy of the weights (TrainerBase)
         return self.sampler.sample()
 
     def _store(self, samples):

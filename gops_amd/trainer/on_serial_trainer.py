@@ -7,6 +7,7 @@ __all__ = ["OnSerialTrainer"]
 
 class OnSerialTrainer(TrainerBase):
     def _sample(self):
+        self._refresh_sampler_networks()   # host samplers: fresh CPU copy of the weights (TrainerBase)
         samples, sampler_tb = self.sampler.sample_with_replay_format()
         self.sampler_tb_dict.add_average(sampler_tb)
         return samples

@@ -38,8 +38,10 @@ class OnSyncTrainer(OnSerialTrainer):
     def step(self):
         samples = self._sample()
         self.networks.train()
+        # no host sync between the backward sweep and the collective: the algorithms leave their loss scalars on the
+        # device (read at log time), and the 1/N is folded into the Adam kernel when the algorithm supports it
         alg_tb_dict, update_info = self.alg.get_remote_update_info(samples, self.iteration)
-        self.reducer.average_(update_info)
+        self.reducer.average_(update_info, defer_scale=getattr(self.alg, "accepts_grad_scale", False))
         self.alg.remote_update(update_info)
         self.networks.eval()
         self._after_update(alg_tb_dict)

@@ -63,11 +63,12 @@ class StepGraphCache:
         self.graph = None
         self.failed = False
 
-    def run(self, signature, batch, eager_fn, on_replay=None, before_replay=None, work=0):
+    def run(self, signature, batch, eager_fn, on_replay=None, before_replay=None, work=0, on_capture_fail=None):
         """Returns fn's output: eagerly for the first calls, by graph replay afterwards.
         `before_replay()` runs ahead of every replay (push changed hyper-parameters to the device),
         `on_replay()` after it (host-side bookkeeping the eager function would have done); `work` is
-        the step's size (batch x horizon) for the "auto" policy."""
+        the step's size (batch x horizon) for the "auto" policy; `on_capture_fail()` runs when a capture
+        attempt raised (host-side bookkeeping done during the aborted capture must be re-synchronised)."""
         if not graphs_enabled(work) or self.failed:
             return eager_fn(batch)
         if signature != self.sig:
@@ -84,6 +85,8 @@ class StepGraphCache:
                 warnings.warn(f"HIP graph capture failed ({exc}); continuing with eager launches")
                 self.failed, self.graph = True, None
                 torch.cuda.synchronize()
+                if on_capture_fail is not None:
+                    on_capture_fail()
                 return eager_fn(batch)
             return self.graph(batch)   # host bookkeeping for this step was done during capture
         if before_replay is not None:

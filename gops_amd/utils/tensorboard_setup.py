@@ -21,10 +21,12 @@ tb_tags = {
 
 
 def add_scalars(tb_info: dict, writer, step: int):
+    """Values may be 0-dim device tensors (the data-parallel path leaves its losses on the GPU so that no
+    host sync sits between the backward pass and the gradient all-reduce): they are read here, at log time."""
     if writer is None:
         return
     for key, value in tb_info.items():
-        writer.add_scalar(key, value, step)
+        writer.add_scalar(key, float(value), step)
 
 
 def make_writer(log_dir: str):

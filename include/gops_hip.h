@@ -196,7 +196,9 @@ int gops_value_backward(const GopsMlp* value, int32_t batch, const float* obs, c
  * live in DEVICE memory (`GopsAdamState`, caller-owned; initialise step = updates done so far,
  * beta1_pow = beta1^step, beta2_pow = beta2^step, ticket = 0): the kernel uses t = step + 1 for the
  * bias corrections and its last block stores the advanced state, so the call can be captured in a
- * HIP graph and replayed.  exp_avg / exp_avg_sq are updated in place. */
+ * HIP graph and replayed.  exp_avg / exp_avg_sq are updated in place.  Every gradient element is
+ * multiplied by `grad_scale` as it is read (1/N after a SUM all-reduce over N data-parallel replicas:
+ * the averaging costs no extra pass over the gradient buffer; set it to 1 otherwise). */
 #define GOPS_ADAM_MAX_TENSORS 16
 typedef struct GopsAdamTensors {
     int32_t n;
@@ -207,19 +209,21 @@ typedef struct GopsAdamTensors {
     float* exp_avg[GOPS_ADAM_MAX_TENSORS];
     float* exp_avg_sq[GOPS_ADAM_MAX_TENSORS];
 } GopsAdamTensors;
-typedef struct GopsAdamState {   /* 40 bytes of device memory */
+typedef struct GopsAdamState {   /* 48 bytes of device memory */
     double lr;
     int64_t step;
     double beta1_pow, beta2_pow;
     uint32_t ticket;
     uint32_t reserved;
+    double grad_scale;
 } GopsAdamState;
 int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, double beta1, double beta2,
                    double eps, void* stream);
 
 /* Timing hook for bench.py: average duration in ms of the named internal kernel over the
  * launches recorded since the last reset (HIP events on the launch stream).  kernel ids:
- * 0 = forward rollout, 1 = backward sweep, 2 = weight-gradient GEMMs. */
+ * 0 = forward rollout, 1 = backward sweep, 2 = weight-gradient GEMMs (+ reduce) of gops_rollout_*;
+ * 3, 4, 5 = the same three of gops_value_forward / _backward (plain MLP batches, INFADP's V(o)). */
 void gops_profile_enable(int32_t on);
 void gops_profile_reset(void);
 int gops_profile_read(int32_t kernel_id, double* avg_ms, int64_t* launches);

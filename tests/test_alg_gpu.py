@@ -52,7 +52,7 @@ def test_fhadp_class_matches_reference(name):
     alg.gamma = cfg["gamma"]
     data = data_from_golden(g)            # CPU batch, like a replay-buffer sample
     tb, info = alg.get_remote_update_info(data, 0)
-    assert abs(tb["Loss/Actor loss-RL iter"] - float(g["loss"])) <= TOL * max(1.0, abs(float(g["loss"])))
+    assert abs(float(tb["Loss/Actor loss-RL iter"]) - float(g["loss"])) <= TOL * max(1.0, abs(float(g["loss"])))
     assert "Time/Algorithm time [ms]-RL iter" in tb
     for i, gr in enumerate(info["grad"]):
         assert rel_l2(gr.cpu(), g[f"grad/{i}"]) < TOL
@@ -71,12 +71,12 @@ def test_infadp_class_matches_reference(name):
     data = data_from_golden(g)
     tb, info = alg.get_remote_update_info(data, 0)       # PEV
     assert list(info) == ["v"]
-    assert abs(tb["Loss/Critic loss-RL iter"] - float(g["pev_loss"])) <= TOL * max(1.0, abs(float(g["pev_loss"])))
+    assert abs(float(tb["Loss/Critic loss-RL iter"]) - float(g["pev_loss"])) <= TOL * max(1.0, abs(float(g["pev_loss"])))
     for i, gr in enumerate(info["v"]):
         assert rel_l2(gr.cpu(), g[f"pev_grad/{i}"]) < TOL
     tb, info = alg.get_remote_update_info(data, 1)       # PIM
     assert list(info) == ["policy"]
-    assert abs(tb["Loss/Actor loss-RL iter"] - float(g["pim_loss"])) <= TOL * max(1.0, abs(float(g["pim_loss"])))
+    assert abs(float(tb["Loss/Actor loss-RL iter"]) - float(g["pim_loss"])) <= TOL * max(1.0, abs(float(g["pim_loss"])))
     for i, gr in enumerate(info["policy"]):
         assert rel_l2(gr.cpu(), g[f"pim_grad/{i}"]) < TOL
     # local_update applies Adam + Polyak to the updated net only
@@ -195,7 +195,7 @@ def test_fhadp2_class_matches_reference(name):
     alg.networks.to("cuda")
     data = data_from_golden(g)
     tb, info = alg.get_remote_update_info(data, 0)
-    assert abs(tb["Loss/Actor loss-RL iter"] - float(g["loss"])) <= 1e-4 * max(1.0, abs(float(g["loss"])))
+    assert abs(float(tb["Loss/Actor loss-RL iter"]) - float(g["loss"])) <= 1e-4 * max(1.0, abs(float(g["loss"])))
     for i, gr in enumerate(info["grad"]):
         assert rel_l2(gr.cpu(), g[f"grad/{i}"]) < 1e-4, (name, i)
     before = [p.detach().clone() for p in alg.networks.policy.parameters()]
@@ -222,8 +222,7 @@ def test_off_serial_trainer_with_device_replay_buffer(tmp_path):
               replay_batch_size=256, sample_interval=4, additional_info=info_spec, max_iteration=50,
               log_save_interval=1000, apprfunc_save_interval=1000, eval_interval=10 ** 9, save_folder=str(tmp_path),
               ini_network_dir=None)
-    alg = create_alg(**kw)
-    alg.networks.to("cuda")
+    alg = create_alg(**kw)   # networks start on the CPU, as create_alg leaves them: the trainer moves them once
     buf = create_buffer(**kw)
     assert buf.device.type == "cuda"
 
@@ -247,7 +246,7 @@ def test_off_serial_trainer_with_device_replay_buffer(tmp_path):
             return 64 * HostSampler.calls
 
     trainer = create_trainer(alg, HostSampler(), buf, None, **kw)
-    assert len(buf) >= 2048
+    assert len(buf) >= 2048 and next(alg.networks.parameters()).is_cuda
     p0 = next(alg.networks.policy.parameters()).data_ptr()
     losses = []
     for _ in range(50):
@@ -258,9 +257,11 @@ def test_off_serial_trainer_with_device_replay_buffer(tmp_path):
     batch = buf.sample_batch(8)
     assert all(v.is_cuda and v.dtype == torch.float32 for v in batch.values())
     assert np.mean(losses[-10:]) < np.mean(losses[:10])
-    # the sampler's host copy follows the learner
+    # the sampler's host copy follows the learner (deep copy taken AFTER the HIP path cached its C-ABI views of the
+    # learner's modules - those views live outside the modules and are not copied)
     host_w = next(trainer._host_networks.policy.parameters())
     assert not host_w.is_cuda
+    assert torch.equal(host_w, next(alg.networks.policy.parameters()).cpu()) or trainer.iteration % kw["sample_interval"] != 1
 
 
 @pytest.mark.gpu

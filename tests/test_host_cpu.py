@@ -307,3 +307,104 @@ def test_off_serial_trainer_loop(tmp_path):
     assert [s[:2] for s in alg.seen] == [(i, 16) for i in range(5)]
     assert len(buf) == 24
     assert {"apprfunc_0.pkl", "apprfunc_4.pkl", "apprfunc_5.pkl"} <= set(os.listdir(tmp_path / "apprfunc"))
+
+
+class _SyncTrap:
+    """Stands for a device scalar: any attempt to read it on the host (a stream sync on a GPU) raises."""
+
+    def __neg__(self):
+        return self
+
+    def __getitem__(self, i):
+        return self
+
+    def _boom(self, *a, **k):
+        raise AssertionError("host read of a device scalar between the backward pass and the all-reduce")
+
+    item = tolist = __float__ = __int__ = cpu = _boom
+
+
+def test_remote_update_path_has_no_host_sync_before_the_collective(monkeypatch):
+    """`get_remote_update_info` must queue the gradient kernels and return WITHOUT reading the
+    loss back (`.item()` blocks the host until the backward sweep has drained, serialising the all-reduce
+    behind it); the scalars stay lazy in tb_info and the 1/N goes to the Adam kernel as `_grad_scale`."""
+    from gops_amd.create_pkg.create_alg import create_alg
+    from gops_amd.trainer.grad_sync import GradAllReducer
+    from gops_amd.utils.tensorboard_setup import tb_tags
+    alg = create_alg(**_fhadp_kwargs())
+    monkeypatch.setattr(alg, "_device_batch", lambda d: d)
+    monkeypatch.setattr(alg._grad_graph, "run", lambda *a, **k: _SyncTrap())
+    monkeypatch.setattr(alg, "_log", lambda *a, **k: (_ for _ in ()).throw(AssertionError("_log syncs the host")))
+    tb, info = alg.get_remote_update_info({"obs": torch.zeros(4, 6), "done": torch.zeros(4)}, 0)
+    assert isinstance(tb[tb_tags["loss_actor"]], _SyncTrap) and list(info) == ["grad"]
+    with pytest.raises(AssertionError):
+        float(tb[tb_tags["loss_actor"]])
+    # single process: the reducer leaves everything alone; N ranks would add "_grad_scale" = 1/N
+    assert GradAllReducer().average_(info, defer_scale=True) is info and "_grad_scale" not in info
+    assert getattr(alg, "accepts_grad_scale", False)
+
+    kw = _fhadp_kwargs()
+    kw.update(algorithm="INFADP", policy_func_name="DetermPolicy", value_func_type="MLP", value_func_name="StateValue",
+              value_hidden_sizes=[64, 64], value_hidden_activation="gelu", value_learning_rate=1e-3)
+    kw.pop("pre_horizon", None)
+    inf = create_alg(**kw)
+    import gops_amd.algorithm.infadp as infadp_mod
+    monkeypatch.setattr(infadp_mod, "batch_to_device", lambda d, dev, keys: d)
+    monkeypatch.setattr(infadp_mod, "cuda_device_of", lambda nets: torch.device("cpu"))
+    monkeypatch.setattr(inf, "_gradient_kernels", lambda mode, b: _SyncTrap())
+    monkeypatch.setattr(inf, "_log", lambda *a, **k: (_ for _ in ()).throw(AssertionError("_log syncs the host")))
+    for it, name in ((0, "v"), (1, "policy")):
+        tb, info = inf.get_remote_update_info({"obs": torch.zeros(4, 6)}, it)
+        assert list(info) == [name]
+
+
+def test_networks_with_cached_abi_views_deepcopy():
+    """the ctypes `GopsMlp` views (raw device pointers) used to live in the modules' __dict__ and
+    made `copy.deepcopy(networks)` - what the trainers do for host-side samplers - raise.  They now live in a weak
+    side table keyed by module."""
+    import copy
+    from gops_amd import hip_backend as hb
+    from gops_amd.apprfunc import mlp as mlp_mod
+    from gops_amd.create_pkg.create_alg import create_alg
+    alg = create_alg(**_fhadp_kwargs())
+    pol = alg.networks.policy
+    view = hb.GopsMlp()
+    view.weight[0] = 0x1000   # a struct with pointer fields: not picklable, not deep-copyable
+    mlp_mod._HIP_CACHE[pol] = (("stale",), view)
+    with pytest.raises(ValueError):
+        copy.deepcopy(view)
+    twin = copy.deepcopy(alg.networks)
+    assert twin.policy is not pol and twin.policy not in mlp_mod._HIP_CACHE
+    assert all(torch.equal(a, b) for a, b in zip(twin.state_dict().values(), alg.networks.state_dict().values()))
+    assert not any(k.startswith("_hip") for k in vars(pol))
+
+
+def test_trainer_calls_ray_actor_evaluators_through_remote(monkeypatch, tmp_path):
+    """GOPS's create_evaluator returns a Ray actor handle; its methods are `.remote()` calls."""
+    import types
+    from gops_amd.trainer import _common
+
+    class _Method:
+        def __init__(self, fn):
+            self.fn = fn
+
+        def __call__(self, *a):
+            raise TypeError("Actor methods cannot be called directly")
+
+        def remote(self, *a):
+            return ("ref", self.fn(*a))
+
+    class _Actor:
+        loaded = None
+
+        def __init__(self):
+            self.load_state_dict = _Method(lambda sd: setattr(_Actor, "loaded", sorted(sd)))
+            self.run_evaluation = _Method(lambda it: 12.5 + it)
+
+    monkeypatch.setitem(sys.modules, "ray", types.SimpleNamespace(get=lambda ref: ref[1]))
+    assert _common.call_maybe_remote(_Actor(), "run_evaluation", 3) == 15.5
+
+    class _Plain:
+        def run_evaluation(self, it):
+            return float(it)
+    assert _common.call_maybe_remote(_Plain(), "run_evaluation", 4) == 4.0

@@ -25,10 +25,10 @@ OVERLAY = {
     "gops.algorithm.fhadp2": "gops_amd.algorithm.fhadp2",
     "gops.algorithm.infadp": "gops_amd.algorithm.infadp",
     "gops.apprfunc.mlp": "gops_amd.apprfunc.mlp",
-    "gops.env.env_ocp.env_model.pyth_base_model": "gops_amd.env.env_ocp.env_model.pyth_base_model",
-    "gops.env.env_ocp.env_model.pyth_lq_model": "gops_amd.env.env_ocp.env_model.pyth_lq_model",
-    "gops.env.env_ocp.env_model.pyth_idpendulum_model": "gops_amd.env.env_ocp.env_model.pyth_idpendulum_model",
-    "gops.env.env_ocp.env_model.pyth_veh3dofconti_model": "gops_amd.env.env_ocp.env_model.pyth_veh3dofconti_model",
+    # NOT overlaid: gops.env.env_ocp.env_model.pyth_*_model.  The reference's DATA envs import helpers from those
+    # modules (`from ...env_model.pyth_idpendulum_model import Dynamics`, pyth_idpendulum.py:20), and nothing on the
+    # hot path imports them by name: `create_env_model` (overlaid above) builds this package's models from its own
+    # registry.
     "gops.trainer.on_serial_trainer": "gops_amd.trainer.on_serial_trainer",
     "gops.trainer.on_sync_trainer": "gops_amd.trainer.on_sync_trainer",
     "gops.trainer.off_serial_trainer": "gops_amd.trainer.off_serial_trainer",

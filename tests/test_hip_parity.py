@@ -21,6 +21,11 @@ FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fh
                "fhadp_veh_p10_elu", "fhadp_veh_p30_sigmoid",
                # the reference's shipped trained checkpoints (saturating policies, H = 80, limits != +-1)
                "fhadp_trained_idp_h80", "fhadp_trained_lqs3a1_h80"]
+# One shipped checkpoint (trained LQ s3a1 policy, H = 80: clipped, unstable closed loop; ONE trajectory of the batch,
+# |dL/dtheta| = 1.7e6 for a return of -5.9e3, carries the error) is ill-conditioned beyond the 1e-4 bar: moving every
+# weight by one ulp moves the REFERENCE's own fp32 gradient by 1e-4 .. 5e-4 (helpers.fp32_noise_floor), and the reference
+# itself is 3e-4 from the float64 value.  Measured HIP distance to float64: 7e-4; bound = 1.5x that.
+ILL_CONDITIONED = {"fhadp_trained_lqs3a1_h80": 1.1e-3}
 INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu",
                 "infadp_trained_lqs4a2", "infadp_trained_idp"]
 
@@ -47,13 +52,22 @@ def test_env_step_vs_reference_fixture(name, dev):
             info = ninfo
         got_o, got_r = obs.cpu().numpy(), r.cpu().numpy()
         if meta["cfg"]["env_id"] == "pyth_veh3dofconti":
-            # The reference derives each appended reference heading from a 1 ms finite difference in
-            # fp32 (ref_traj_model.py:144-148): one ulp of x(t) (a libm-level difference in cos)
-            # moves that heading by up to ~1e-3 rad.  Bound the outliers, hold the rest to the
-            # reference's own tolerance and the whole observation to the 1e-4 norm-wise bar.
+            # The reference derives each APPENDED reference heading from a 1 ms finite difference in fp32
+            # (ref_traj_model.py:144-148): wherever its vectorised sin / cos (Sleef u10, <= 1 ulp, not always the
+            # correctly rounded value the kernel produces) is one ulp off, the heading moves by up to ~1e-3 rad.
+            # Measured on MI355X: 2-4 % of the appended headings differ by more than 2e-5,
+            # at most 1.25e-3 rad; an affected point stays in the preview window for P steps, so the share of
+            # affected observation elements grows to 0.9 % (P = 10) / 0.25 % (P = 30) after the fixture's 6 steps.
+            # Everything that does not depend on an appended heading is held to the reference's own tolerance.
             bad = ~np.isclose(got_o, g[f"s{s}/obs"], rtol=1e-5, atol=2e-5)
-            assert bad.mean() < 0.01 and np.abs(got_o - g[f"s{s}/obs"]).max() < 5e-3
+            assert bad.mean() < 0.012 and np.abs(got_o - g[f"s{s}/obs"]).max() < 2e-3
+            assert not bad[:, [0, 1, 3, 4, 5]].any() or s > 0     # first step: no appended point has reached slot 0 .. P-1
             assert rel_l2(got_o, g[f"s{s}/obs"]) < TOL
+            np.testing.assert_allclose(ninfo["state"].cpu().numpy(), g[f"s{s}/state"], rtol=1e-5, atol=1e-5)
+            last, want = ninfo["ref_points"][:, -1].cpu().numpy(), g[f"s{s}/ref_last"]
+            np.testing.assert_allclose(last[:, [0, 1, 3]], want[:, [0, 1, 3]], rtol=1e-5, atol=2e-5)   # x, y, u of the new point
+            dphi = np.abs(last[:, 2] - want[:, 2])
+            assert dphi.max() < 2e-3 and (dphi > 2e-5).mean() < 0.06
         else:
             # single step: the reference's own tolerance (tests/env_gen_ocp/test_consistency.py:93-98)
             np.testing.assert_allclose(got_o, g[f"s{s}/obs"], rtol=1e-5, atol=2e-5)
@@ -93,27 +107,26 @@ def test_fhadp_vs_reference_fixture(name, dev):
     assert np.array_equal(res["final_done"].cpu().numpy() != 0, ref["final_done"].numpy())
     loss = -res["v_pi"].double().mean().item()
     assert abs(loss - float(g["loss"])) <= TOL * max(1.0, abs(float(g["loss"])))
-    # Gradients: 1e-4 against the reference's fp32 output, per parameter and over the flat vector.
-    # One fixture (trained LQ policy, H = 80: clipped, unstable closed loop) is so ill-conditioned that
-    # fp32 evaluations of the SAME function scatter by more than that - moving every weight by one ulp
-    # moves the reference's own gradient by up to 4e-4.  There the bar is the float64 value: the HIP
-    # result must lie within 4x the scatter of fp32 oracle evaluations around it (one trajectory of that
-    # batch carries nearly all of the error: |dL/dtheta| = 1.7e6 for a return of -5.9e3; on it the
-    # reference's fp32 gradient is itself 0.3 % off the float64 value).
+    # Gradients: 1e-4 against the reference's fp32 output, per parameter and over the flat vector - for every
+    # fixture but ONE, listed in ILL_CONDITIONED with its measured numbers.
     flat = torch.cat([x.reshape(-1).cpu() for x in grads])
     flat_ref = torch.cat([torch.from_numpy(g[f"grad/{i}"]).reshape(-1) for i in range(len(grads))])
     err = rel_l2(flat, flat_ref)
     worst = max(rel_l2(gr.cpu(), g[f"grad/{i}"]) for i, gr in enumerate(grads))
-    if worst >= TOL:
+    if name in ILL_CONDITIONED:
+        # the bar is the float64 value of the same function: the HIP result must be as close to it as fp32
+        # evaluations of the reference scatter around it
+        bound64 = ILL_CONDITIONED[name]
         ref64 = fhadp_gradient_f64(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])["grads"]
         flat64 = torch.cat([x.reshape(-1) for x in ref64])
         floor = fp32_noise_floor(env, nets["policy"], data, cfg["horizon"], cfg["gamma"], flat64)
         err64 = rel_l2(flat.double(), flat64)
-        print(f"{name}: ill-conditioned; rel-L2 to float64: HIP {err64:.2e}, reference fp32 "
-              f"{rel_l2(flat_ref.double(), flat64):.2e}, fp32 scatter (1-ulp weight moves) {floor:.2e}")
-        assert floor > TOL / 3 and err64 <= 4.0 * floor, (name, err, err64, floor)
+        print(f"{name}: rel-L2 to float64: HIP {err64:.2e}, reference fp32 {rel_l2(flat_ref.double(), flat64):.2e}, "
+              f"fp32 scatter of the reference under 1-ulp weight moves {floor:.2e}")
+        assert floor > TOL, (name, "no longer ill-conditioned: drop the exemption", floor)
+        assert err64 <= bound64, (name, err, err64, floor)
     else:
-        assert err < TOL, (name, err)
+        assert err < TOL and worst < TOL, (name, err, worst)
 
 
 @pytest.mark.parametrize("name", INFADP_CASES)

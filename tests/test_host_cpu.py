@@ -408,3 +408,79 @@ def test_trainer_calls_ray_actor_evaluators_through_remote(monkeypatch, tmp_path
         def run_evaluation(self, it):
             return float(it)
     assert _common.call_maybe_remote(_Plain(), "run_evaluation", 4) == 4.0
+
+
+_PLUMBING = r"""
+import os, sys, types, runpy
+ROOT, SCRIPT, SAVE = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import _ref_import; _ref_import.install()            # gym / tensorboard stubs + /root/reference on sys.path
+import numpy as np
+for _old, _new in (("float_", np.float64), ("int_", np.int64), ("bool8", np.bool_)):   # the reference targets numpy 1.x
+    if not hasattr(np, _old):
+        setattr(np, _old, _new)
+
+# ---- a minimal in-process `ray`: actor handles whose methods are `.remote()` calls --------------------
+class _Method:
+    def __init__(self, fn): self._fn = fn
+    def __call__(self, *a, **k): raise TypeError("Actor methods cannot be called directly")
+    def remote(self, *a, **k): return self._fn(*a, **k)
+class _Handle:
+    def __init__(self, obj): object.__setattr__(self, "_obj", obj)
+    def __getattr__(self, name): return _Method(getattr(self._obj, name))
+def _remote(*dargs, **dkw):
+    def wrap(cls):
+        return types.SimpleNamespace(remote=lambda *a, **k: _Handle(cls(*a, **k)))
+    return wrap(dargs[0]) if len(dargs) == 1 and callable(dargs[0]) and not dkw else wrap
+sys.modules["ray"] = types.SimpleNamespace(init=lambda *a, **k: None, remote=_remote, get=lambda x: x, put=lambda x: x,
+                                           shutdown=lambda: None, is_initialized=lambda: True)
+
+import gops_amd.overlay as ov; ov.install()           # gops.<hot path> -> gops_amd
+import gops.utils.plot_evaluation as pe; pe.plot_all = lambda *a, **k: None
+import gops.utils.tensorboard_setup as ts             # no tensorboard package in this image: post-processing helpers off
+ts.start_tensorboard = ts.save_tb_to_csv = lambda *a, **k: None
+import gops_amd.trainer._common as tc
+seen = {}
+def train_one(self):                                   # the script calls trainer.train(): one step is enough here
+    seen["trainer"] = type(self).__module__ + "." + type(self).__name__
+    seen["alg"] = type(self.alg).__module__
+    seen["buffer"] = type(self.buffer).__module__ if getattr(self, "buffer", None) is not None else None
+    seen["sampler"] = type(self.sampler).__module__
+    seen["evaluator"] = type(self.evaluator).__name__
+    seen["warm"] = len(self.buffer) if getattr(self, "buffer", None) is not None else None
+    try:
+        self.step()
+        seen["step"] = "ran"
+    except RuntimeError as e:
+        seen["step"] = str(e)
+tc.TrainerBase.train = train_one
+sys.argv = [SCRIPT, "--save_folder", SAVE, "--max_iteration", "2", "--buffer_warm_size", "128", "--sample_batch_size", "64"]
+runpy.run_path(SCRIPT, run_name="__main__")
+import torch
+assert seen["trainer"] == "gops_amd.trainer.off_serial_trainer.OffSerialTrainer", seen
+assert seen["alg"].startswith("gops_amd.algorithm."), seen
+assert seen["buffer"] == "gops_amd.trainer.buffer.replay_buffer", seen
+assert seen["sampler"].startswith("gops.trainer.sampler"), seen          # the reference's own numpy-env sampler
+assert seen["evaluator"] == "_Handle" and seen["warm"] >= 128, seen
+if not torch.cuda.is_available():
+    assert "no CPU path" in seen["step"], seen                              # the ONLY thing missing without a GPU
+else:
+    assert seen["step"] == "ran", seen
+print("plumbing ok", seen["alg"])
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/gops"), reason="needs the GOPS tree (build container only)")
+@pytest.mark.parametrize("script", ["example_train/fhadp/fhadp_mlp_idpendulum_serial.py",
+                                    "example_train/fhadp/fhadp_mlp_veh3dofconti_serial.py",
+                                    "example_train/infadp/infadp_mlp_lqs4a2_offserial.py"])
+def test_example_scripts_run_unchanged_through_the_overlay(script, tmp_path):
+    """BASELINE configs[0] plumbing: the reference's UNMODIFIED example scripts (their own argparse block, create_env,
+    init_args, create_sampler, create_evaluator - a Ray actor handle, here from an in-process stub) executed with
+    `gops_amd.overlay` installed: create_alg / create_buffer / create_trainer resolve to this package, the trainer
+    warms its buffer from the reference's numpy-env sampler, and the first update fails only for want of a GPU."""
+    worker = tmp_path / "plumbing.py"
+    worker.write_text(_PLUMBING)
+    out = subprocess.run([sys.executable, str(worker), ROOT, os.path.join("/root/reference", script), str(tmp_path / "run")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "plumbing ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]

@@ -49,19 +49,22 @@ class WrappedEnvModel:
     def unwrapped(self):
         return self.model.unwrapped
 
-    def hip_env(self, policy_low=None, policy_high=None) -> hb.GopsEnv:
+    def hip_env(self, policy_low=None, policy_high=None, data_env: bool = False) -> hb.GopsEnv:
+        """C-ABI constants of the wrapped model.  `data_env=True`: the variant whose `gops_env_step` reproduces the DATA
+        environment's step (termination tests, -100 terminal penalty; `sampler/device_env_sampler.py`)."""
         key = (None if policy_low is None else tuple(np.asarray(policy_low, dtype=np.float32).reshape(-1).tolist()),
-               None if policy_high is None else tuple(np.asarray(policy_high, dtype=np.float32).reshape(-1).tolist()))
+               None if policy_high is None else tuple(np.asarray(policy_high, dtype=np.float32).reshape(-1).tolist()),
+               bool(data_env))
         if key not in self._env_cache:
             m = self.model
             self._env_cache[key] = hb.make_env(
                 m.hip_kind, m.obs_dim, m.action_dim, act_low=m.action_lower_bound.cpu(),
                 act_high=m.action_upper_bound.cpu(), min_action=self.min_action.cpu(),
                 max_action=self.max_action.cpu(), policy_low=policy_low, policy_high=policy_high,
-                obs_low=m.obs_lower_bound.cpu() if self.clip_obs else None,
-                obs_high=m.obs_upper_bound.cpu() if self.clip_obs else None,
+                obs_low=m.obs_lower_bound.cpu() if (self.clip_obs or data_env) else None,
+                obs_high=m.obs_upper_bound.cpu() if (self.clip_obs or data_env) else None,
                 pre_horizon=getattr(m, "pre_horizon", 0), reward_scale=self.reward_scale,
-                reward_shift=self.reward_shift, **m.hip_constants())
+                reward_shift=self.reward_shift, data_env=data_env, **m.hip_constants())
         return self._env_cache[key]
 
     def forward(self, obs: torch.Tensor, action: torch.Tensor, done: torch.Tensor, info: Dict

@@ -161,7 +161,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     const GopsEnv& e = desc.env;
     if (desc.batch < 1 || desc.horizon < 1 || desc.horizon > GOPS_MAX_HORIZON) return GOPS_ERR_BAD_ARG;
     if (e.kind < GOPS_ENV_NONE || e.kind > GOPS_ENV_VEH3DOFCONTI) return GOPS_ERR_BAD_ARG;
-    if (e.obs_dim < 1) return GOPS_ERR_BAD_ARG;
+    if (e.obs_dim < 1 || e.data_env) return GOPS_ERR_BAD_ARG;   // data-env semantics exist for gops_env_step only
     const int pol_out = (e.kind == GOPS_ENV_NONE) ? 1 : e.act_dim;
     if (desc.dtype != GOPS_DTYPE_F32 && desc.dtype != GOPS_DTYPE_F16) return GOPS_ERR_BAD_ARG;
     const bool f16 = desc.dtype == GOPS_DTYPE_F16;

@@ -853,9 +853,10 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int O = env.obs_dim, A = env.act_dim;
+    const bool data = env.data_env != 0;   // the DATA environment's step (include/gops_hip.h: GopsEnv.data_env)
     float u[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
     for (int a = 0; a < A; ++a) u[a] = wrap_action(env, a, io.action[(size_t)b * A + a]);
-    const bool dn = io.done != nullptr && io.done[b] != 0.f;
+    const bool dn = !data && io.done != nullptr && io.done[b] != 0.f;
     float r = 0.f;
     bool done_m = false;
     const float* ob = io.obs + (size_t)b * O;
@@ -866,9 +867,12 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         lq_forward(env, x, u, xn, r);
         for (int i = 0; i < O; ++i) {
             const float v = dn ? x[i] : xn[i];
-            nob[i] = env.clip_obs ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
+            nob[i] = (env.clip_obs && !data) ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
+            // data env (lq_base.py:224-231, 236-239): done when the NEXT state leaves the state bounds
+            if (data && env.clip_obs && (xn[i] > env.obs_high[i] || xn[i] < env.obs_low[i])) done_m = true;   // clip_obs: bounds are finite
         }
-    } else if (env.kind == GOPS_ENV_IDPENDULUM) {
+        if (data && done_m) r -= 100.f;
+    } else if (env.kind == GOPS_ENV_IDPENDULUM) {   // data env == model (pyth_idpendulum.py:71-87 calls the model's Dynamics)
         const IdpConst IC = idp_const();
         float s[6], sn[6], s0[6];
         for (int i = 0; i < 6; ++i) s0[i] = s[i] = ob[i];
@@ -904,13 +908,17 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
             const float xtf = dx * cn - dy * snn, ytf = dx * snn + dy * cn;
             const float ptf = angle_normalize(rp[2] - sn[2]), utf = rp[3] - sn[3];
             if (j == 0) {
-                done_m = (fabsf(xtf) > 10.f) || (fabsf(ytf) > 10.f) || (fabsf(ptf) > 3.14159265358979323846f);
+                if (data)   // pyth_veh3dofconti.py:263-271: world-frame offsets to the first reference point, 5 / 2 / pi
+                    done_m = (fabsf(dx) > 5.f) || (fabsf(dy) > 2.f) || (fabsf(ptf) > 3.14159265358979323846f);
+                else
+                    done_m = (fabsf(xtf) > 10.f) || (fabsf(ytf) > 10.f) || (fabsf(ptf) > 3.14159265358979323846f);
                 if (!dn) { nob[0] = xtf; nob[1] = ytf; nob[2] = ptf; nob[3] = utf; nob[4] = sn[4]; nob[5] = sn[5]; }
             } else if (!dn) {
                 float* d = nob + 6 + 4 * (j - 1);
                 d[0] = xtf; d[1] = ytf; d[2] = ptf; d[3] = utf;
             }
         }
+        if (data && done_m) r -= 100.f;   // :224-226
         if (dn) for (int i = 0; i < O; ++i) nob[i] = ob[i];
         for (int i = 0; i < 6; ++i) io.next_state[(size_t)b * 6 + i] = sn[i];
         io.next_ref_time[b] = nt;

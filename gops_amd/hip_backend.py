@@ -52,7 +52,8 @@ class GopsEnv(C.Structure):
                 ("shaping", C.c_int32), ("reward_scale", C.c_float), ("reward_shift", C.c_float),
                 ("lq_inv_IA", C.c_float * (MAX_LQ * MAX_LQ)), ("lq_B", C.c_float * (MAX_LQ * MAX_ACT)),
                 ("lq_Q", C.c_float * MAX_LQ), ("lq_R", C.c_float * MAX_ACT),
-                ("lq_dt", C.c_float), ("lq_reward_scale", C.c_float), ("lq_reward_shift", C.c_float)]
+                ("lq_dt", C.c_float), ("lq_reward_scale", C.c_float), ("lq_reward_shift", C.c_float),
+                ("data_env", C.c_int32)]
 
 
 class GopsRolloutDesc(C.Structure):
@@ -187,9 +188,12 @@ def make_mlp_grad(gw: Sequence[torch.Tensor], gb: Sequence[torch.Tensor]) -> Gop
 def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_action=-1.0, max_action=1.0,
              policy_low=None, policy_high=None, obs_low=None, obs_high=None, pre_horizon: int = 0,
              reward_scale: Optional[float] = None, reward_shift: Optional[float] = None,
-             lq: Optional[Dict] = None) -> GopsEnv:
-    """Constants of the wrapped env model (create_env_model.py:86-128) as a C struct."""
+             lq: Optional[Dict] = None, data_env: bool = False) -> GopsEnv:
+    """Constants of the wrapped env model (create_env_model.py:86-128) as a C struct.  `data_env=True` (for
+    `env_step` only): the DATA environment's termination tests / terminal penalty instead of the model's; obs_low /
+    obs_high are then the data env's state bounds (pyth_lq) and are NOT applied as a clip."""
     e = GopsEnv()
+    e.data_env = int(bool(data_env))
     e.kind, e.obs_dim, e.act_dim, e.pre_horizon = kind, obs_dim, act_dim, pre_horizon
     A = act_dim
 

@@ -32,6 +32,7 @@ OVERLAY = {
     "gops.trainer.on_serial_trainer": "gops_amd.trainer.on_serial_trainer",
     "gops.trainer.on_sync_trainer": "gops_amd.trainer.on_sync_trainer",
     "gops.trainer.off_serial_trainer": "gops_amd.trainer.off_serial_trainer",
+    "gops.trainer.off_sync_trainer": "gops_amd.trainer.off_sync_trainer",
     "gops.trainer.buffer.replay_buffer": "gops_amd.trainer.buffer.replay_buffer",
 }
 

@@ -2,9 +2,13 @@
 
 The reference's samplers step numpy data environments one env and one step at a time on the CPU
 (gops/trainer/sampler/base.py:101-187) - the bottleneck once the learner runs on the MI355X (SURVEY
-section 8(f) rank 3).  For the OCP tasks of this path the data environment and the env model share their
-dynamics, reward and termination (reference tests/env_gen_ocp/test_consistency.py), so N environment
-instances are advanced together by the wrapped env-model step kernel (`gops_env_step`):
+section 8(f) rank 3).  The data environments of this path share their dynamics and stage reward with the env
+models but NOT their termination rules or terminal reward (pyth_veh3dofconti.py:224-226,263-271: -100 at done,
+world-frame |dx| > 5, |dy| > 2 against the model's ego-frame 10 / 10; lq_base.py:224-239: done when the state leaves
+its bounds, -100, no clipping; pyth_idpendulum.py:71-87 is identical to its model).  `env_step="data"` (default)
+selects those data-env semantics in the step kernel (`GopsEnv.data_env`, checked against transitions recorded from the
+reference's numpy envs: tests/golden/dataenv_*.npz); `env_step="model"` steps the env model instead.  N environment
+instances are advanced together by `gops_env_step`:
 
     act = policy(obs)            # N x obs_dim through the policy MLP (library GEMMs), on the device
     obs2, rew, done, info2 = gops_env_step(obs, act, done=0, info)
@@ -31,13 +35,16 @@ class DeviceEnvSampler:
     on_device = True   # trainers: do not move the networks to the CPU around sample()
 
     def __init__(self, cfg: dict, env_model, *, n_envs: int, steps_per_sample: int = 1, max_episode_steps: int = 200,
-                 seed: int = 0, device="cuda", pool_factor: int = 8, noise_std: float = 0.0):
+                 seed: int = 0, device="cuda", pool_factor: int = 8, noise_std: float = 0.0, env_step: str = "data"):
         """cfg: workload dict as in `gops_amd.utils.synthetic.CONFIGS` (env_id, pre_horizon, lq_config);
         env_model: the wrapped model from `create_env_model` (its constants drive the step kernel)."""
         self.cfg, self.env_model = dict(cfg), env_model
         self.n, self.steps, self.max_steps = n_envs, steps_per_sample, max_episode_steps
         self.device = torch.device(device)
         self.seed, self.pool_factor, self.noise_std = seed, pool_factor, noise_std
+        if env_step not in ("data", "model"):
+            raise ValueError("env_step must be 'data' (the data environment's step) or 'model' (the env model's)")
+        self.data_env = env_step == "data"
         self.networks = None
         self.total = 0
         self._pool, self._pool_pos, self._pools_made = None, 0, 0
@@ -64,7 +71,8 @@ class DeviceEnvSampler:
     def _hip_env(self):
         if self._henv is None:
             pol = self.networks.policy
-            self._henv = self.env_model.hip_env(pol.act_low_lim.cpu().numpy(), pol.act_high_lim.cpu().numpy())
+            self._henv = self.env_model.hip_env(pol.act_low_lim.cpu().numpy(), pol.act_high_lim.cpu().numpy(),
+                                                data_env=self.data_env)
         return self._henv
 
     # ---- sampling -----------------------------------------------------------------------------

@@ -108,6 +108,13 @@ typedef struct GopsEnv {
     float lq_B[GOPS_MAX_LQ_STATE * GOPS_MAX_ACT];              /* row-major n x m */
     float lq_Q[GOPS_MAX_LQ_STATE], lq_R[GOPS_MAX_ACT];
     float lq_dt, lq_reward_scale, lq_reward_shift;
+    /* gops_env_step only (rollouts reject it): 1 = the step of the DATA environment the reference's samplers drive
+     * (gops/env/env_ocp/pyth_veh3dofconti.py:195-271, resources/lq_base.py:209-231, pyth_idpendulum.py:71-87) instead
+     * of the env MODEL's: same dynamics and stage reward, but the data env's termination tests (veh3dofconti: world-frame
+     * |x - x_ref| > 5, |y - y_ref| > 2, |dphi| > pi; lq: next state outside the state bounds), a -100 terminal penalty
+     * (veh3dofconti, lq), no observation clipping and no MaskAtDone (an episode that is done gets reset by the caller:
+     * the `done` input is ignored). */
+    int32_t data_env;
 } GopsEnv;
 
 typedef struct GopsRolloutDesc {

@@ -354,8 +354,82 @@ def golden_fhadp2():
         save(name, **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 6. DATA-environment transitions (the numpy envs the reference's samplers step: create_env + its wrappers)
+#    and the reference ReplayBuffer run on them - the semantics DeviceEnvSampler / the device ReplayBuffer
+#    reproduce (terminal penalty -100, data-env termination tests, no observation clipping)
+# ------------------------------------------------------------------------------------------
+DATA_ENV_CASES = {
+    "dataenv_veh_p10": dict(env_id="pyth_veh3dofconti", pre_horizon=10),
+    "dataenv_lq_s4a2": dict(env_id="pyth_lq", lq_config="s4a2"),
+    "dataenv_idp": dict(env_id="pyth_idpendulum"),
+    "dataenv_lq_s2a1_shaped": dict(env_id="pyth_lq", lq_config="s2a1", reward_scale=0.5, reward_shift=1.0),
+}
+
+
+def golden_data_envs():
+    from gops.create_pkg.create_env import create_env
+    from gops.trainer.buffer.replay_buffer import ReplayBuffer as RefBuffer
+    for _old, _new in (("float_", np.float64), ("int_", np.int64), ("bool8", np.bool_)):   # reference targets numpy 1.x
+        if not hasattr(np, _old):
+            setattr(np, _old, _new)
+    for name, cfg in DATA_ENV_CASES.items():
+        env = create_env(**cfg)
+        rng = np.random.RandomState(zlib.crc32(name.encode()) % 10000)
+        rows = []
+        info_keys = ("state", "ref_points", "path_num", "u_num", "ref_time")
+        episodes, n_done = 0, 0
+        while len(rows) < 400:
+            episodes += 1
+            env.seed(int(rng.randint(1 << 30)))
+            ret = env.reset()
+            obs, info = ret if isinstance(ret, tuple) else (ret, getattr(env, "info", {}))
+            if not info:
+                info = getattr(env.unwrapped, "info", {}) or {}
+            # half of the episodes use violent actions so that terminations (and the -100) are in the fixture
+            amp = 1.3 if episodes % 2 else 0.4
+            for t in range(40):
+                act = rng.uniform(-amp, amp, size=env.action_space.shape).astype(np.float32)
+                cur_info = {k: np.array(info[k], dtype=np.float32).copy() for k in info_keys if k in info}
+                step = env.step(act)
+                obs2, rew, done, info2 = step[0], step[1], step[2], step[-1]
+                rows.append(dict(obs=np.array(obs, np.float32), act=act, rew=np.float32(rew), done=np.float32(done),
+                                 obs2=np.array(obs2, np.float32),
+                                 **{"info_" + k: v for k, v in cur_info.items()},
+                                 **{"next_" + k: np.array(info2[k], dtype=np.float32) for k in cur_info}))
+                obs, info = obs2, info2
+                if done:
+                    n_done += 1
+                    break
+        out = {"t/" + k: np.stack([r[k] for r in rows]) for k in rows[0]}
+        print(name, "transitions", len(rows), "episodes", episodes, "terminations", n_done)
+        out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra={k: cfg[k] for k in ("reward_scale", "reward_shift") if k in cfg}))
+        model = create_env_model(**cfg)
+        out.update(model_consts(model))
+        # the reference ReplayBuffer fed with the first 150 transitions (capacity 100: wraps), then two sampled batches
+        add_info = {}
+        for k in rows[0]:
+            if k.startswith("info_"):
+                add_info[k[5:]] = {"shape": rows[0][k].shape, "dtype": np.float32}
+        bkw = dict(trainer="off_serial_trainer", seed=5, obsv_dim=rows[0]["obs"].shape[0], action_dim=rows[0]["act"].shape[0],
+                   buffer_max_size=100, additional_info=add_info)
+        buf = RefBuffer(index=0, **bkw)
+        for r in rows[:150]:
+            info = {k[5:]: r[k] for k in r if k.startswith("info_")}
+            nxt = {k[5:]: r[k] for k in r if k.startswith("next_")}
+            buf.store(r["obs"], r["act"], float(r["rew"]), bool(r["done"]), info, r["obs2"], nxt, 0.25)
+        out["buf/size"], out["buf/ptr"] = buf.size, buf.ptr
+        for k, v in buf.buf.items():
+            out["buf/store/" + k] = np.asarray(v)
+        out["meta/buffer_kwargs"] = json.dumps({k: (v if k != "additional_info" else {kk: {"shape": list(vv["shape"])} for kk, vv in v.items()})
+                                                for k, v in bkw.items()})
+        save(name, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv"]
+    if "dataenv" in which:
+        golden_data_envs()
     if "fhadp2" in which:
         golden_fhadp2()
     if "trained" in which:

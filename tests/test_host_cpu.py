@@ -182,6 +182,46 @@ assert [g.data_ptr() for g in grads] == ptrs
 for i, g in enumerate(grads):
     assert torch.allclose(g, torch.full_like(g, 10 * (n - 1) / 2 + i))
 assert _as_one_buffer([grads[0], grads[2]]) is None   # a gap between the pieces: not one buffer
+# ---- off-policy variant: every rank owns a sampler + replay buffer, gradients of the replay batches are averaged ----
+from gops_amd.trainer.off_sync_trainer import OffSyncTrainer
+from gops_amd.trainer.buffer.replay_buffer import ReplayBuffer
+import numpy as np
+
+class OffSampler:
+    networks = None
+    def sample(self):
+        g = np.random.RandomState(50 + r)
+        return [(g.rand(3).astype(np.float32), np.zeros(1, np.float32), 0.0, False, {}, g.rand(3).astype(np.float32), {}, 0.0)
+                for _ in range(8)], {}
+    def get_total_sample_number(self): return 0
+
+class ScaledAlg(FakeAlg):   # honours the deferred 1/N like the HIP Adam kernel does
+    accepts_grad_scale = True
+    def remote_update(self, info):
+        with torch.no_grad():
+            self.networks.weight -= 0.5 * info["grad"][0] * info.get("_grad_scale", 1.0)
+
+alg2 = ScaledAlg()
+buf = ReplayBuffer(index=r, trainer="off_sync_trainer", seed=9, obsv_dim=3, action_dim=1, buffer_max_size=64,
+                   additional_info={}, buffer_device="cpu")
+tr2 = OffSyncTrainer(alg2, OffSampler(), buf, None, max_iteration=1, log_save_interval=10, apprfunc_save_interval=10,
+                     eval_interval=10, save_folder=None, ini_network_dir=None, use_gpu=False, buffer_warm_size=16,
+                     replay_batch_size=8, sample_interval=1)
+w0 = alg2.networks.weight.detach().clone()
+gathered = [torch.zeros_like(w0) for _ in range(n)]
+dist.all_gather(gathered, w0)
+assert all(torch.equal(g, gathered[0]) for g in gathered), "off_sync replicas not broadcast from rank 0"
+seen = {}
+orig = alg2.get_remote_update_info
+def spy(data, it):
+    seen["mean"] = data["obs"].mean(0, keepdim=True).clone()
+    return orig(data, it)
+alg2.get_remote_update_info = spy
+tr2.step()
+means = [torch.zeros_like(seen["mean"]) for _ in range(n)]
+dist.all_gather(means, seen["mean"])
+expect = w0 - 0.5 * torch.stack(means).mean(0)      # mean over ranks of the per-rank replay-batch gradients
+assert torch.allclose(alg2.networks.weight, expect, atol=1e-7), (alg2.networks.weight, expect)
 dist.destroy_process_group()
 open(os.path.join(sys.argv[2], f"ok_{r}"), "w").write("ok")
 """
@@ -484,3 +524,45 @@ def test_example_scripts_run_unchanged_through_the_overlay(script, tmp_path):
     out = subprocess.run([sys.executable, str(worker), ROOT, os.path.join("/root/reference", script), str(tmp_path / "run")],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "plumbing ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("name", ["dataenv_veh_p10", "dataenv_lq_s4a2"])
+def test_replay_buffer_matches_reference_buffer_side_by_side(name):
+    """The reference's ReplayBuffer (gops/trainer/buffer/replay_buffer.py) was fed 150 recorded transitions at capacity
+    100 by tests/golden/make_golden.py (ring wrap included) and its arrays stored in the fixture; this package's buffer,
+    fed the same transitions through `add_batch` (sampler tuples) and through `add_tensors` (batched device insert),
+    must hold exactly the same rows, pointer and size, and sample float32 rows of them."""
+    import json
+    from gops_amd.trainer.buffer.replay_buffer import ReplayBuffer
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    kw = json.loads(str(g["meta/buffer_kwargs"]))
+    kw["additional_info"] = {k: {"shape": tuple(v["shape"]), "dtype": np.float32} for k, v in kw["additional_info"].items()}
+    t = {k[2:]: g[k] for k in g if k.startswith("t/")}
+    info_keys = list(kw["additional_info"])
+    rows = []
+    for i in range(150):
+        info = {k: t["info_" + k][i] for k in info_keys}
+        nxt = {k: t["next_" + k][i] for k in info_keys}
+        rows.append((t["obs"][i], t["act"][i], float(t["rew"][i]), bool(t["done"][i]), info, t["obs2"][i], nxt, 0.25))
+    a = ReplayBuffer(index=0, buffer_device="cpu", **kw)
+    for lo in range(0, 150, 7):            # sampler-sized chunks
+        a.add_batch(rows[lo:lo + 7])
+    b = ReplayBuffer(index=0, buffer_device="cpu", **kw)
+    for lo in range(0, 150, 32):           # batched tensor insert (DeviceEnvSampler path)
+        sl = slice(lo, min(lo + 32, 150))
+        batch = dict(obs=torch.from_numpy(t["obs"][sl]), act=torch.from_numpy(t["act"][sl]), rew=torch.from_numpy(t["rew"][sl]),
+                     done=torch.from_numpy(t["done"][sl]), obs2=torch.from_numpy(t["obs2"][sl]),
+                     logp=torch.full((sl.stop - sl.start,), 0.25))
+        for k in info_keys:
+            batch[k], batch["next_" + k] = torch.from_numpy(t["info_" + k][sl]), torch.from_numpy(t["next_" + k][sl])
+        b.add_tensors(batch)
+    for buf in (a, b):
+        assert buf.size == int(g["buf/size"]) and buf.ptr == int(g["buf/ptr"]) and len(buf) == 100
+        assert sorted(buf.buf) == sorted(k[len("buf/store/"):] for k in g if k.startswith("buf/store/"))
+        for k, v in buf.buf.items():
+            assert np.array_equal(v.numpy(), g["buf/store/" + k].astype(np.float32)), k
+    s = a.sample_batch(16)
+    assert set(s) == set(a.buf) and all(v.dtype == torch.float32 and v.shape[0] == 16 for v in s.values())
+    stored = {tuple(r.tolist()) for r in a.buf["obs"]}
+    assert all(tuple(r.tolist()) in stored for r in s["obs"])

@@ -110,3 +110,47 @@ def test_fhadp2_gradient_matches_reference(name):
     assert abs(out["loss"].item() - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
     for i, gr in enumerate(out["grads"]):
         assert rel_l2(gr, g[f"grad/{i}"]) < 1e-5, (name, i)
+
+
+DATA_ENV_CASES = ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped"]
+
+
+def _dataenv_inputs(g):
+    t = {k[2:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("t/")}
+    info = {k[5:]: v for k, v in t.items() if k.startswith("info_")}
+    return t, info
+
+
+def check_data_env_transitions(got_obs2, got_rew, got_done, got_info, t, veh):
+    """Shared by the oracle (CPU) and the HIP (GPU) data-env tests.  The numpy data env evaluates the appended
+    reference heading in float64 (ref_traj_data), the torch model - and everything restating it - in fp32 with a
+    1 ms finite difference (ref_traj_model.py:144-148): that heading (and the one observation element made of it)
+    may differ by the fp32 finite-difference noise, everything else matches to the reference's own 1e-5."""
+    want_o, got_o = t["obs2"].numpy(), np.asarray(got_obs2)
+    assert np.array_equal(np.asarray(got_done) != 0, t["done"].numpy() != 0)
+    np.testing.assert_allclose(np.asarray(got_rew), t["rew"].numpy(), rtol=2e-5, atol=2e-4)
+    if not veh:
+        np.testing.assert_allclose(got_o, want_o, rtol=1e-5, atol=2e-5)
+        return
+    keep = np.ones(want_o.shape[1], dtype=bool)
+    keep[-2] = False     # dphi of the appended (last) reference point
+    np.testing.assert_allclose(got_o[:, keep], want_o[:, keep], rtol=1e-5, atol=5e-5)
+    assert np.abs(got_o[:, -2] - want_o[:, -2]).max() < 5e-3
+    np.testing.assert_allclose(np.asarray(got_info["state"]), t["next_state"].numpy(), rtol=1e-5, atol=2e-5)
+    rp, want_rp = np.asarray(got_info["ref_points"]), t["next_ref_points"].numpy()
+    np.testing.assert_allclose(rp[:, :, [0, 1, 3]], want_rp[:, :, [0, 1, 3]], rtol=1e-5, atol=5e-5)
+    np.testing.assert_allclose(rp[:, :-1, 2], want_rp[:, :-1, 2], rtol=1e-5, atol=2e-5)
+    assert np.abs(rp[:, -1, 2] - want_rp[:, -1, 2]).max() < 5e-3
+
+
+@pytest.mark.parametrize("name", DATA_ENV_CASES)
+def test_data_env_step_matches_reference_numpy_envs(name):
+    """oracle.data_env_forward against transitions recorded from the reference's numpy data envs (create_env + its
+    wrappers, random actions incl. out-of-range ones, episodes that terminate: -100 and the data-env done tests)."""
+    g = load_golden(name)
+    meta = golden_meta(g)
+    env = oracle_env(meta["cfg"], meta["extra"], g)
+    t, info = _dataenv_inputs(g)
+    assert t["done"].sum() > 0 or "shaped" in name
+    nobs, r, done, ninfo = orc.data_env_forward(env, t["obs"], t["act"], info)
+    check_data_env_transitions(nobs, r, done, ninfo, t, env["kind"] == "veh")

@@ -87,7 +87,7 @@ class AlgorithmBase(metaclass=ABCMeta):
 
 
 # ---- helpers shared by the HIP-backed algorithms ---------------------------------------------
-_INFO_KEYS = ("state", "ref_points", "path_num", "u_num", "ref_time")
+_INFO_KEYS = ("state", "ref_points", "path_num", "u_num", "ref_time", "surr_state")
 
 
 def batch_to_device(data: Dict[str, torch.Tensor], device, keys) -> Dict[str, torch.Tensor]:

@@ -85,7 +85,7 @@ class FHADP(AlgorithmBase):
         batch = self._device_batch(data)
         loss = self._grad_graph.run(self._signature(batch), batch, self._gradient_kernels,
                                    work=batch["obs"].shape[0] * self.pre_horizon)
-        self.tb_info[tb_tags["loss_actor"]] = -loss          # 0-dim device tensor
+        self._fill_tb(loss, lazy=True)                       # device scalars, read at log time
         self.tb_info[tb_tags["alg_time"]] = (time.time() - self._t0) * 1000   # ms of host enqueue time
         return self.tb_info, {"grad": [p._grad for p in self.networks.policy.parameters()]}
 
@@ -111,16 +111,25 @@ class FHADP(AlgorithmBase):
             ro.set_policy(mlp)
         return ro
 
-    def _log(self, loss_policy):   # loss_policy holds mean(v_pi); the loss is its negative
-        self.tb_info[tb_tags["loss_actor"]] = -loss_policy.item()   # host sync, as in the reference
+    def _fill_tb(self, out, lazy=False):
+        """`out` is what `_gradient_kernels` returned - here mean(v_pi), whose negative is the loss.  lazy: leave
+        device tensors in tb_info (no host sync); else read them back (`.item()`, as the reference does)."""
+        self.tb_info[tb_tags["loss_actor"]] = -out if lazy else -out.item()
+
+    def _log(self, out):
+        self._fill_tb(out)   # host sync, as in the reference
         self.tb_info[tb_tags["alg_time"]] = (time.time() - self._t0) * 1000  # ms
 
     def _device_batch(self, data):
         return batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
 
+    def _extra_signature(self):
+        """Host-side values a subclass bakes into the captured kernels' inputs (penalty coefficients ...)."""
+        return ()
+
     def _signature(self, batch):
         """What a captured graph is specialised on: shapes, rollout settings, parameter / gradient storage."""
-        return (tuple((k, tuple(v.shape)) for k, v in batch.items()), self.pre_horizon, float(self.gamma),
+        return (tuple((k, tuple(v.shape)) for k, v in batch.items()), self.pre_horizon, float(self.gamma), self._extra_signature(),
                 tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr())
                       for p in self.networks.policy.parameters()),
                 # everything else a captured kernel chain holds raw pointers to: Adam moments / device state

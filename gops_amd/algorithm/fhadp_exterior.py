@@ -1,0 +1,86 @@
+"""FHADPExterior - FHADP with an exterior (quadratic) penalty on the model's constraint outputs.
+
+Same surface as the reference's gops/algorithm/fhadp_exterior.py:19-78:
+    loss = -mean_b sum_t gamma^t r_t  +  penalty * mean_b sum_t gamma^t sum_k max(c_tk, 0)^2
+with `penalty` multiplied by `penalty_increase` every `penalty_delay` updates up to `max_penalty`.  The rollout kernel
+of the constrained veh3dofconti models (GOPS_ENV_VEH3DOF_SURR) returns the discounted constraint sums next to v_pi and
+its backward sweep takes d(loss)/d(sums) per trajectory - here penalty / B on the quadratic sum."""
+__all__ = ["FHADPExterior"]
+
+from typing import Tuple
+
+import torch
+
+from gops_amd.algorithm.base import grad_buffers
+from gops_amd.algorithm.fhadp import ApproxContainer, FHADP   # noqa: F401  (ApproxContainer: create_alg looks it up here)
+from gops_amd.utils.tensorboard_setup import tb_tags
+
+
+class ConstrainedFHADP(FHADP):
+    """Shared by the Exterior / Interior / Lagrangian variants: forward rollout with constraint sums, per-trajectory
+    weights of those sums, backward sweep, device scalars for the log."""
+
+    LOG_KEYS: Tuple[str, ...] = ()
+
+    def _constraint_terms(self, v_pi, cs, B):
+        """-> (grad_constraint [3, B], stacked device scalars in LOG_KEYS order)."""
+        raise NotImplementedError
+
+    def _after_gradient(self):
+        """Host-side schedule step (penalty / multiplier), once per computed gradient like the reference."""
+
+    def _gradient_kernels(self, batch):
+        if "surr_state" not in batch:
+            raise RuntimeError(f"{type(self).__name__} needs a model with constraint outputs "
+                               "(pyth_veh3dofconti_surrcstr / _detour): batch has no 'surr_state'")
+        B, device = batch["obs"].shape[0], batch["obs"].device
+        ro = self._rollout_for(B, device)
+        res = ro.forward(batch)
+        gc, scalars = self._constraint_terms(res["v_pi"], res["constraint_sums"], B)
+        gw, gb = grad_buffers(self.networks.policy)
+        ro.backward(self._grad_v(B, device), gw, gb, grad_constraint=gc)
+        if not torch.cuda.is_current_stream_capturing():
+            self._after_gradient()
+        return scalars
+
+    def _fill_tb(self, out, lazy=False):
+        vals = out if lazy else out.tolist()
+        for k, v in zip(self.LOG_KEYS, vals):
+            self.tb_info[k] = v
+        self._fill_host_tb()
+
+    def _fill_host_tb(self):
+        pass
+
+
+class FHADPExterior(ConstrainedFHADP):
+    LOG_KEYS = (tb_tags["loss_actor"], tb_tags["loss_actor_reward"], tb_tags["loss_actor_constraint"])
+
+    def __init__(self, *, pre_horizon: int, gamma: float = 1.0, penalty: float = 1.0, penalty_increase: float = 1.1,
+                 penalty_delay: float = 100, max_penalty: float = 1e3, index: int = 0, **kwargs):
+        super().__init__(pre_horizon=pre_horizon, gamma=gamma, index=index, **kwargs)
+        self.penalty, self.penalty_increase = penalty, penalty_increase
+        self.penalty_delay, self.max_penalty = penalty_delay, max_penalty
+        self.update_step = 0
+
+    @property
+    def adjustable_parameters(self) -> Tuple[str]:
+        return (*super().adjustable_parameters, "penalty", "penalty_increase", "penalty_delay")
+
+    def _extra_signature(self):
+        return (float(self.penalty),)
+
+    def _constraint_terms(self, v_pi, cs, B):
+        loss_reward, loss_constraint = -v_pi.mean(), cs[0].mean()
+        gc = torch.zeros(3, B, dtype=torch.float32, device=v_pi.device)
+        gc[0] = self.penalty / B
+        self._penalty_used = self.penalty
+        return gc, torch.stack((loss_reward + self.penalty * loss_constraint, loss_reward, loss_constraint))
+
+    def _after_gradient(self):   # fhadp_exterior.py:68-70
+        self.update_step += 1
+        if self.update_step % self.penalty_delay == 0:
+            self.penalty = min(self.penalty * self.penalty_increase, self.max_penalty)
+
+    def _fill_host_tb(self):
+        self.tb_info["Loss/Penalty coefficient-RL iter"] = self.penalty

@@ -160,7 +160,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     memset(&p, 0, sizeof(p));
     const GopsEnv& e = desc.env;
     if (desc.batch < 1 || desc.horizon < 1 || desc.horizon > GOPS_MAX_HORIZON) return GOPS_ERR_BAD_ARG;
-    if (e.kind < GOPS_ENV_NONE || e.kind > GOPS_ENV_VEH3DOFCONTI) return GOPS_ERR_BAD_ARG;
+    if (e.kind < GOPS_ENV_NONE || e.kind > GOPS_ENV_VEH3DOF_SURR) return GOPS_ERR_BAD_ARG;
     if (e.obs_dim < 1 || e.data_env) return GOPS_ERR_BAD_ARG;   // data-env semantics exist for gops_env_step only
     const int pol_out = (e.kind == GOPS_ENV_NONE) ? 1 : e.act_dim;
     if (desc.dtype != GOPS_DTYPE_F32 && desc.dtype != GOPS_DTYPE_F16) return GOPS_ERR_BAD_ARG;
@@ -177,6 +177,11 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     if (e.kind == GOPS_ENV_IDPENDULUM && (e.obs_dim != 6 || e.act_dim != 1 || e.clip_obs)) return GOPS_ERR_BAD_ARG;
     if (e.kind == GOPS_ENV_VEH3DOFCONTI &&
         (e.act_dim != 2 || e.pre_horizon < 1 || e.obs_dim != 6 + 4 * e.pre_horizon || e.clip_obs))
+        return GOPS_ERR_BAD_ARG;
+    if (e.kind == GOPS_ENV_VEH3DOF_SURR &&
+        (e.act_dim != 2 || e.pre_horizon < 1 || e.n_surr < 1 || e.n_surr > GOPS_MAX_SURR ||
+         (e.n_constraint != 1 && e.n_constraint != 3) || e.obs_dim != 6 + 4 * e.pre_horizon + 4 * e.n_surr || e.clip_obs ||
+         desc.open_loop || desc.dtype != GOPS_DTYPE_F32))
         return GOPS_ERR_BAD_ARG;
     if (e.clip_obs && e.obs_dim > 8) return GOPS_ERR_UNSUPPORTED;
 
@@ -211,7 +216,8 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     if (const char* tm = getenv("GOPS_TOUCH")) p.touch_mode = atoi(tm);   // tuning knob
     p.ldx = kp0 + 4;
     p.ldh = hmax + 4;
-    const int ref_pts = (e.kind == GOPS_ENV_VEH3DOFCONTI) ? e.pre_horizon + 1 + desc.horizon
+    const bool veh = e.kind == GOPS_ENV_VEH3DOFCONTI || e.kind == GOPS_ENV_VEH3DOF_SURR;
+    const int ref_pts = veh ? e.pre_horizon + 1 + desc.horizon
                                                           : (e.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
     if (rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts) > 160 * 1024)
         return GOPS_ERR_UNSUPPORTED;
@@ -231,7 +237,9 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     if (f16) p.gscale = c.take(4);
     // stash rows: every tile stores all 16 rows of every step (tile-major order)
     const long long S = (long long)((p.B + TB - 1) / TB) * TB * p.H;
-    if (e.kind == GOPS_ENV_VEH3DOFCONTI) p.ref_table = c.take((size_t)p.B * (e.pre_horizon + 1 + p.H) * 4);
+    if (veh) p.ref_table = c.take((size_t)p.B * (e.pre_horizon + 1 + p.H) * 4);
+    if (e.kind == GOPS_ENV_VEH3DOF_SURR)
+        p.surr_table = reinterpret_cast<const f32x4*>(c.take((size_t)p.B * (p.H + 1) * e.n_surr * 4));
     if (p.need_grad) {
         const bool gelu = p.pol.act == GOPS_ACT_GELU;
         const size_t el = f16 ? 2 : 1;   // stash elements per float of workspace (half: 2)
@@ -276,8 +284,9 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
     if (rc != GOPS_OK) return rc;
     if (ws == nullptr || ws_bytes < plan.bytes) return GOPS_ERR_WORKSPACE;
     if (in.obs == nullptr || out.v_pi == nullptr) return GOPS_ERR_BAD_ARG;
-    if (desc.env.kind == GOPS_ENV_VEH3DOFCONTI &&
+    if ((desc.env.kind == GOPS_ENV_VEH3DOFCONTI || desc.env.kind == GOPS_ENV_VEH3DOF_SURR) &&
         (!in.state || !in.ref_points || !in.path_num || !in.u_num || !in.ref_time)) return GOPS_ERR_BAD_ARG;
+    if (desc.env.kind == GOPS_ENV_VEH3DOF_SURR && !in.surr_state) return GOPS_ERR_BAD_ARG;
     RolloutParams& p = plan.p;
     p.in = in;
     p.out = out;
@@ -428,9 +437,12 @@ int gops_rollout_backward_open_loop(const GopsRolloutDesc* desc, const GopsRollo
 
 int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream) {
     if (!env || !io || batch < 1) return GOPS_ERR_BAD_ARG;
-    if (env->kind < GOPS_ENV_LQ || env->kind > GOPS_ENV_VEH3DOFCONTI) return GOPS_ERR_BAD_ARG;
+    if (env->kind < GOPS_ENV_LQ || env->kind > GOPS_ENV_VEH3DOF_SURR) return GOPS_ERR_BAD_ARG;
     if (!io->obs || !io->action || !io->next_obs || !io->reward || !io->next_done) return GOPS_ERR_BAD_ARG;
-    if (env->kind == GOPS_ENV_VEH3DOFCONTI &&
+    if (env->kind == GOPS_ENV_VEH3DOF_SURR &&
+        (env->data_env || env->n_surr < 1 || env->n_surr > GOPS_MAX_SURR || (env->n_constraint != 1 && env->n_constraint != 3) ||
+         !io->surr_state || !io->next_surr_state || !io->constraint)) return GOPS_ERR_BAD_ARG;
+    if ((env->kind == GOPS_ENV_VEH3DOFCONTI || env->kind == GOPS_ENV_VEH3DOF_SURR) &&
         (!io->state || !io->ref_points || !io->path_num || !io->u_num || !io->ref_time ||
          !io->next_state || !io->next_ref_points || !io->next_ref_time)) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_LQ && env->obs_dim > GOPS_MAX_LQ_STATE) return GOPS_ERR_UNSUPPORTED;

@@ -222,9 +222,31 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
             b -= nb;
         }
     }
-    if (p.env.kind == GOPS_ENV_VEH3DOFCONTI)
-        ref_table_element(p.B, P, p.H, p.in.ref_points, p.in.path_num, p.in.u_num, p.in.ref_time, pdt,
-                          const_cast<float*>(p.ref_table), b * 256 + threadIdx.x);
+    if (p.env.kind == GOPS_ENV_VEH3DOFCONTI || p.env.kind == GOPS_ENV_VEH3DOF_SURR) {
+        const int nrt = (p.B * (P + 1 + p.H) + 255) / 256;
+        if (b < nrt) {
+            ref_table_element(p.B, P, p.H, p.in.ref_points, p.in.path_num, p.in.u_num, p.in.ref_time, pdt,
+                              const_cast<float*>(p.ref_table), b * 256 + threadIdx.x);
+            return;
+        }
+        b -= nrt;
+    }
+    if (p.env.kind == GOPS_ENV_VEH3DOF_SURR) {
+        // surrounding vehicles move independently of the policy: their (x, y, phi, u) after t = 0 .. H steps, one
+        // thread per (trajectory, vehicle)
+        const int ns = p.env.n_surr, idx = b * 256 + threadIdx.x;
+        if (idx < p.B * ns) {
+            const int bb = idx / ns, i = idx - bb * ns;
+            const float* s5 = p.in.surr_state + ((size_t)bb * ns + i) * 5;
+            f32x4 cur = {s5[0], s5[1], s5[2], s5[3]};
+            const float delta = s5[4];
+            f32x4* tab = const_cast<f32x4*>(p.surr_table) + (size_t)bb * (p.H + 1) * ns + i;
+            for (int t = 0; t <= p.H; ++t) {
+                tab[(size_t)t * ns] = cur;
+                cur = surr_next(cur, delta);
+            }
+        }
+    }
 }
 
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s) {
@@ -234,7 +256,8 @@ hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, fl
         if (!p.f16) { nb += pack_blocks(d); continue; }
         for (int j = 0; j < d.nl - 1; ++j) nb += pack_blocks_h(d, j);
     }
-    if (p.env.kind == GOPS_ENV_VEH3DOFCONTI) nb += (p.B * (P + 1 + p.H) + 255) / 256;
+    if (p.env.kind == GOPS_ENV_VEH3DOFCONTI || p.env.kind == GOPS_ENV_VEH3DOF_SURR) nb += (p.B * (P + 1 + p.H) + 255) / 256;
+    if (p.env.kind == GOPS_ENV_VEH3DOF_SURR) nb += (p.B * p.env.n_surr + 255) / 256;
     hipLaunchKernelGGL(prologue_kernel, dim3(nb), dim3(256), 0, s, p, dst, P, pdt);
     return hipGetLastError();
 }
@@ -884,7 +907,8 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         r = idp_reward(s, u[0]);
         done_m = idp_done(IC, s);
         for (int i = 0; i < 6; ++i) nob[i] = dn ? s0[i] : s[i];
-    } else if (env.kind == GOPS_ENV_VEH3DOFCONTI) {
+    } else if (env.kind == GOPS_ENV_VEH3DOFCONTI || env.kind == GOPS_ENV_VEH3DOF_SURR) {
+        const bool surr = env.kind == GOPS_ENV_VEH3DOF_SURR;
         const VehConst VC = veh_const();
         const int P = env.pre_horizon;
         float s[6], sn[6], o6[6];
@@ -892,7 +916,7 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         VehStep w;
         sincosf(s[2], &w.sphi, &w.cphi);
         veh_f_xu(VC, s, u[0], u[1], sn, w);
-        r = veh_reward(o6, u[0], u[1]);
+        r = surr ? veh_reward_w(env.reward_w, o6, u[0], u[1]) : veh_reward(o6, u[0], u[1]);
         const float nt = RADD(io.ref_time[b], 0.1f);
         const float pn = io.path_num[b], un = io.u_num[b];
         const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : 3;
@@ -919,6 +943,25 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
             }
         }
         if (data && done_m) r -= 100.f;   // :224-226
+        if (surr) {   // pyth_veh3dofconti_surrcstr_model.py:84-95: surrounding vehicles step, relative obs, constraint (unmasked)
+            f32x4 pts[GOPS_MAX_SURR];
+            for (int i = 0; i < env.n_surr; ++i) {
+                const float* s5 = io.surr_state + ((size_t)b * env.n_surr + i) * 5;
+                const f32x4 cur = {s5[0], s5[1], s5[2], s5[3]};
+                pts[i] = surr_next(cur, s5[4]);
+                float* d5 = io.next_surr_state + ((size_t)b * env.n_surr + i) * 5;
+                d5[0] = pts[i][0]; d5[1] = pts[i][1]; d5[2] = pts[i][2]; d5[3] = pts[i][3]; d5[4] = s5[4];
+                if (!dn) {
+                    float* d = nob + 6 + 4 * P + 4 * i;
+                    d[0] = pts[i][0] - sn[0]; d[1] = pts[i][1] - sn[1]; d[2] = pts[i][2] - sn[2]; d[3] = pts[i][3] - sn[3];
+                }
+            }
+            SurrCstr sc;
+            float sp, cp;
+            sincosf(sn[2], &sp, &cp);
+            surr_constraint<false>(env, sn[0], sn[1], sp, cp, pts, sc);
+            for (int k = 0; k < env.n_constraint; ++k) io.constraint[(size_t)b * env.n_constraint + k] = sc.c[k];
+        }
         if (dn) for (int i = 0; i < O; ++i) nob[i] = ob[i];
         for (int i = 0; i < 6; ++i) io.next_state[(size_t)b * 6 + i] = sn[i];
         io.next_ref_time[b] = nt;

@@ -69,6 +69,7 @@ struct RolloutParams {
     int open_loop;                    // 1: head outputs come from in.head_pre, the MLP phases are skipped
     float* g_head_pre;                // open-loop backward: d(loss)/d(head_pre) [B][H][A]
     const float* ref_table;           // veh: [B][P+1+H][4]
+    const f32x4* surr_table;          // GOPS_ENV_VEH3DOF_SURR: [B][H+1][n_surr] (x, y, phi, u) of every surrounding vehicle after t steps
     unsigned long long* dbg;          // debug: per-phase cycle counters of block 0 (GOPS_DBG_TIMING)
     int f16;                          // 1: GOPS_DTYPE_F16
     float* gscale;                    // f16 backward: gscale[0] = max|grad_v| of the launch (upload_params_kernel)

@@ -210,3 +210,67 @@ __device__ __forceinline__ float veh_reward(const float* o, float steer, float a
     return -(0.04f * (o[0] * o[0]) + 0.04f * (o[1] * o[1]) + 0.02f * (o[2] * o[2]) +
              0.02f * (o[3] * o[3]) + 0.01f * (o[5] * o[5]) + 0.01f * (steer * steer) + 0.01f * (ax * ax));
 }
+
+// ================================ veh3dofconti + surrounding vehicles ==========================
+// pyth_veh3dofconti_surrcstr_model.py:28-39 (SurrVehicleModel), :98-148 (get_constraint);
+// pyth_veh3dofconti_detour_model.py:115-151 (road-boundary terms), :153-173 (reward weights).
+__device__ __forceinline__ f32x4 surr_next(const f32x4& p, float delta) {   // (x, y, phi, u); delta, u constant
+    float s, c;
+    sincosf(p[2], &s, &c);
+    f32x4 n;
+    n[0] = p[0] + p[3] * c * 0.1f;
+    n[1] = p[1] + p[3] * s * 0.1f;
+    n[2] = angle_normalize(p[2] + p[3] * tanf(delta) / 3.0f * 0.1f);
+    n[3] = p[3];
+    return n;
+}
+
+struct SurrCstr {   // constraint values and their derivatives w.r.t. the ego pose (x, y, phi)
+    float c[GOPS_MAX_CONSTRAINT];
+    float dx[GOPS_MAX_CONSTRAINT], dy[GOPS_MAX_CONSTRAINT], dphi[GOPS_MAX_CONSTRAINT];
+};
+
+// `surr`: the n_surr (x, y, phi, u) points of the SAME time as the ego pose (x, y, phi).
+template <bool WANT_GRAD>
+__device__ __forceinline__ void surr_constraint(const GopsEnv& e, float x, float y, float sphi, float cphi,
+                                                const f32x4* surr, SurrCstr& o) {
+    const float d = (e.veh_length - e.veh_width) / 2.f;
+    const float r = 0.70710678118654752440f * e.veh_width;
+    const float ex[2] = {x + d * cphi, x - d * cphi}, ey[2] = {y + d * sphi, y - d * sphi};
+    float best = 3.402823466e+38f, bvx = 0.f, bvy = 0.f, bsign = 1.f;
+    for (int k = 0; k < e.n_surr; ++k) {
+        float ss, sc;
+        sincosf(surr[k][2], &ss, &sc);
+        const float sx[2] = {surr[k][0] + d * sc, surr[k][0] - d * sc}, sy[2] = {surr[k][1] + d * ss, surr[k][1] - d * ss};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float vx = ex[i] - sx[j], vy = ey[i] - sy[j];
+                const float dist = sqrtf(vx * vx + vy * vy);
+                if (dist < best) { best = dist; bvx = vx; bvy = vy; bsign = i == 0 ? 1.f : -1.f; }
+            }
+    }
+    o.c[0] = 2.f * r - best;
+    if (WANT_GRAD) {
+        const float inv = best > 0.f ? 1.f / best : 0.f;
+        o.dx[0] = -bvx * inv;
+        o.dy[0] = -bvy * inv;
+        o.dphi[0] = -(bvx * (-bsign * d * sphi) + bvy * (bsign * d * cphi)) * inv;
+    }
+    if (e.n_constraint >= 3) {   // detour: road boundaries on the circles' y extent
+        const int iu = ey[0] >= ey[1] ? 0 : 1;            // max over the two circles of (y_i + r - upper)
+        o.c[1] = ey[iu] + r - e.road_upper;
+        const int il = ey[0] <= ey[1] ? 0 : 1;            // max over the two circles of (lower - (y_i - r))
+        o.c[2] = e.road_lower - (ey[il] - r);
+        if (WANT_GRAD) {
+            o.dx[1] = 0.f; o.dy[1] = 1.f; o.dphi[1] = (iu == 0 ? 1.f : -1.f) * d * cphi;
+            o.dx[2] = 0.f; o.dy[2] = -1.f; o.dphi[2] = -(il == 0 ? 1.f : -1.f) * d * cphi;
+        }
+    }
+}
+
+__device__ __forceinline__ float veh_reward_w(const float* w, const float* o, float steer, float ax) {
+    return -(w[0] * (o[0] * o[0]) + w[1] * (o[1] * o[1]) + w[2] * (o[2] * o[2]) + w[3] * (o[3] * o[3]) +
+             w[4] * (o[5] * o[5]) + w[5] * (steer * steer) + w[6] * (ax * ax));
+}

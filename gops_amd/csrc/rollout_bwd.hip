@@ -168,6 +168,8 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel
     const int b0 = blockIdx.x * TB;
     const int nvalid = min(TB, p.B - b0);
     const int O = p.env.obs_dim, A = p.env.act_dim;
+    constexpr bool SURR = (ENV == GOPS_ENV_VEH3DOF_SURR);   // veh3dofconti + surrounding vehicles + constraint outputs
+    constexpr bool VEH = (ENV == GOPS_ENV_VEH3DOFCONTI) || SURR;
     const int ldx = p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* G = smem;                    // [TB][ldx] adjoint of obs_{t+1}
     float* da = G + TB * ldx;           // [TB][ldh]
@@ -179,12 +181,17 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel
     float* s_idp = reinterpret_cast<float*>(s_ref);             // idpendulum: [TB][5][24] sub-step parking
     // One-workgroup-per-CU variants: LDS copies of this step's H_2 / H_1 (Z for GELU) tiles, [2][TB][256]
     constexpr bool STAGE = (SK1 > 0);   // (those variants are only selected for obs-256-256-act policies)
-    float* s_stage = smem + bwd_lds_floats(ldx, ldh, ENV == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H
+    float* s_stage = smem + bwd_lds_floats(ldx, ldh, VEH ? p.env.pre_horizon + 1 + p.H
                                                                              : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0));
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
     float gv = (tid < nvalid) ? gptr(p.grad_v)[b0 + tid] : 0.f;
     if constexpr (F16) gv *= f16_grad_scale(gptr(p.gscale)[0]);
+    float gc_ext = 0.f, gc_lin = 0.f, gc_int = 0.f;   // SURR: d(loss)/d(constraint sums) of trajectory tid
+    if (SURR && tid < nvalid && p.in.grad_constraint != nullptr) {
+        const GLOBAL_AS float* gcp = gptr(p.in.grad_constraint) + b0 + tid;
+        gc_ext = gcp[0]; gc_lin = gcp[(size_t)p.B]; gc_int = gcp[(size_t)2 * p.B];
+    }
     const int ld16 = (p.ldh - 4) + 8;                 // F16: leading dimension (halfs) of the delta tiles
     const float* xrows = F16 ? p.st.xf : p.st.x;      // fp32 observation columns the env adjoints read
     const int xld = F16 ? 8 : p.pol.kp[0];
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel
             const int a = idx / K, k = idx - a * K;
             s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
         }
-        if (ENV == GOPS_ENV_VEH3DOFCONTI) {
+        if (VEH) {
             const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
             for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -484,6 +491,40 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel
                 lamn[3] = lam[3] + tot[3];
                 lamn[4] = lam[4] + g4;
                 lamn[5] = lam[5] + g5;
+                if constexpr (SURR) {
+                    if (m < nvalid) {
+                        const int ns = p.env.n_surr;
+                        const GLOBAL_AS f32x4* sp = gptr(p.surr_table) + ((size_t)(b0 + m) * (p.H + 1) + (t + 1)) * ns;
+                        f32x4 pts[GOPS_MAX_SURR];
+#pragma unroll
+                        for (int i = 0; i < GOPS_MAX_SURR; ++i) {
+                            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                            pts[i] = (i < ns) ? sp[i] : z;
+                        }
+                        // adjoint of the (unmasked) constraint sums w.r.t. the new ego pose
+                        SurrCstr sc;
+                        surr_constraint<true>(p.env, sn[0], sn[1], e3[2], e3[3], pts, sc);
+                        for (int k = 0; k < p.env.n_constraint; ++k) {
+                            const float c = sc.c[k];
+                            float gck = gc_ext * 2.f * fmaxf(c, 0.f) + (c > 0.f ? gc_lin : 0.f);
+                            if (c < 0.f) gck += gc_int * (-1.f / (-c + 1e-8f));
+                            gck *= p.gpow[t];
+                            lamn[0] += gck * sc.dx[k];
+                            lamn[1] += gck * sc.dy[k];
+                            lamn[2] += gck * sc.dphi[k];
+                        }
+                        // observation columns (x, y, phi, u)_surr - (x, y, phi, u)_ego: MaskAtDone keeps the adjoint on obs_t
+                        if (!dn) {
+#pragma unroll
+                            for (int i = 0; i < GOPS_MAX_SURR; ++i)
+                                if (i < ns) {
+                                    float* gp = G + m * ldx + 6 + 4 * P + 4 * i;
+                                    lamn[0] -= gp[0]; lamn[1] -= gp[1]; lamn[2] -= gp[2]; lamn[3] -= gp[3];
+                                    gp[0] = gp[1] = gp[2] = gp[3] = 0.f;
+                                }
+                        }
+                    }
+                }
                 float g_steer, g_ax;
                 veh_f_xu_bwd(VC, s, steer, w, lamn, lam, g_steer, g_ax);
                 const float g_rm = dn ? 0.f : g_r;
@@ -497,14 +538,23 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel
 #pragma unroll
                         for (int i = 0; i < 6; ++i) xr[i] = xg[i];
                     }
-                    G[m * ldx + 0] += g_rm * (-0.08f * xr[0]);
-                    G[m * ldx + 1] += g_rm * (-0.08f * xr[1]);
-                    G[m * ldx + 2] += g_rm * (-0.04f * xr[2]);
-                    G[m * ldx + 3] += g_rm * (-0.04f * xr[3]);
-                    G[m * ldx + 5] += g_rm * (-0.02f * xr[5]);
+                    if constexpr (SURR) {
+                        const float* rw = p.env.reward_w;
+                        G[m * ldx + 0] += g_rm * (-2.f * rw[0] * xr[0]);
+                        G[m * ldx + 1] += g_rm * (-2.f * rw[1] * xr[1]);
+                        G[m * ldx + 2] += g_rm * (-2.f * rw[2] * xr[2]);
+                        G[m * ldx + 3] += g_rm * (-2.f * rw[3] * xr[3]);
+                        G[m * ldx + 5] += g_rm * (-2.f * rw[4] * xr[5]);
+                    } else {
+                        G[m * ldx + 0] += g_rm * (-0.08f * xr[0]);
+                        G[m * ldx + 1] += g_rm * (-0.08f * xr[1]);
+                        G[m * ldx + 2] += g_rm * (-0.04f * xr[2]);
+                        G[m * ldx + 3] += g_rm * (-0.04f * xr[3]);
+                        G[m * ldx + 5] += g_rm * (-0.02f * xr[5]);
+                    }
                 }
-                g_steer += g_rm * (-0.02f * steer);
-                g_ax += g_rm * (-0.02f * ax);
+                g_steer += g_rm * ((SURR ? -2.f * p.env.reward_w[5] : -0.02f) * steer);
+                g_ax += g_rm * ((SURR ? -2.f * p.env.reward_w[6] : -0.02f) * ax);
                 s_gy[m * 4 + 0] = wrap_action_bwd(p.env, 0, abar0, g_steer) * sc0 * (1.f - th0 * th0);
                 s_gy[m * 4 + 1] = wrap_action_bwd(p.env, 1, abar1, g_ax) * sc1 * (1.f - th1 * th1);
                 s_gy[m * 4 + 2] = 0.f;
@@ -567,7 +617,7 @@ int rollout_variant_h(const RolloutParams& p);
 
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H
+    size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, (p.env.kind == GOPS_ENV_VEH3DOFCONTI || p.env.kind == GOPS_ENV_VEH3DOF_SURR) ? p.env.pre_horizon + 1 + p.H
                                                        : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0));
     int sk[2];
     rollout_variant(p, sk, true);
@@ -602,6 +652,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
             else if (key == 16) LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 0, 16);
             else LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 0, 0);
             break;
+        case GOPS_ENV_VEH3DOF_SURR: LAUNCH_BWD(GOPS_ENV_VEH3DOF_SURR, 0, 0); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

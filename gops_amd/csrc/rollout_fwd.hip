@@ -127,6 +127,8 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
     const int b0 = blockIdx.x * TB;
     const int nvalid = min(TB, p.B - b0);
     const int O = p.env.obs_dim, A = p.env.act_dim;
+    constexpr bool SURR = (ENV == GOPS_ENV_VEH3DOF_SURR);   // veh3dofconti + surrounding vehicles + constraint outputs
+    constexpr bool VEH = (ENV == GOPS_ENV_VEH3DOFCONTI) || SURR;
     // leading dimensions are compile-time constants in the register-stationary variants
     const int ldx = p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* xs = smem;                       // [TB][ldx]  current observation (+ time column)
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
     f32x4* s_ref = reinterpret_cast<f32x4*>(s_bias + (GOPS_MAX_LAYERS - 1) * ldh);   // veh: [TB][TL]
     const int TL = p.env.pre_horizon + 1 + p.H;   // reference-table points per trajectory
     // F16: half copy of the policy / value input tile, [TB][ldx16], behind the reference-table region
-    _Float16* x16 = reinterpret_cast<_Float16*>(s_ref + (ENV == GOPS_ENV_VEH3DOFCONTI ? TB * TL : 0));
+    _Float16* x16 = reinterpret_cast<_Float16*>(s_ref + (VEH ? TB * TL : 0));
     const int ldx16 = (((p.ldx - 4) + 31) & ~31) + 8, ld16 = (p.ldh - 4) + 8;
     {   // one-time staging of everything the H-step loop would otherwise re-fetch from L2
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
         stage_act_const(p.env, s_ac, tid);
         for (int j = 0; j < Lh; ++j)
             for (int n = tid; n < p.pol.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = gptr(p.pol.b[j])[n];
-        if (ENV == GOPS_ENV_VEH3DOFCONTI) {
+        if (VEH) {
             const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
             for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
         xs[idx] = (c < O && m < nvalid) ? gptr(p.in.obs)[(size_t)(b0 + m) * O + c] : 0.f;
     }
     if (tid < TB) s_done[tid] = (tid < nvalid && p.in.done != nullptr && gptr(p.in.done)[b0 + tid] != 0.f) ? 1.f : 0.f;
-    if (ENV == GOPS_ENV_VEH3DOFCONTI) {
+    if (VEH) {
         if (tid < TB * 6) {
             const int m = tid / 6, c = tid - m * 6;
             s_state[m * 8 + c] = (m < nvalid) ? gptr(p.in.state)[(size_t)(b0 + m) * 6 + c] : (c == 3 ? 1.f : 0.f);
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
     typename std::conditional<(SH > 0), StatWh<(SH > 0 ? SH : 1)>, NoWh>::type WH;
     if constexpr (SH > 0) WH.load(p.pol, tid);
     float v_acc = 0.f;
+    float c_ext = 0.f, c_lin = 0.f, c_int = 0.f, c_feas = 1.f;   // SURR: discounted constraint sums of trajectory tid (tid < TB)
     float veh_s = 0.f, veh_c = 1.f;   // sin/cos of the current heading, carried across steps
     const IdpConst IC = idp_const();
     const VehConst VC = veh_const();
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
     DbgClock dbg;
     dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
     __syncthreads();
-    if (ENV == GOPS_ENV_VEH3DOFCONTI) sincosf(s_state[(tid & 15) * 8 + 2], &veh_s, &veh_c);
+    if (VEH) sincosf(s_state[(tid & 15) * 8 + 2], &veh_s, &veh_c);
     for (int t = 0; t < p.H; ++t) {
         if (p.fh && tid < TB) xs[tid * ldx + O] = (float)(t + 1);
         __syncthreads();
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
         if (p.need_grad && tid < TB) {   // env stash row: tanh outputs, done_t, state_t
             GLOBAL_AS f32x4* er = gptr(reinterpret_cast<f32x4*>(p.st.env + (row0 + tid) * ENV_STASH));
             f32x4 e0 = {s_th[tid * 4 + 0], s_th[tid * 4 + 1], s_th[tid * 4 + 2], s_th[tid * 4 + 3]};
-            if (ENV == GOPS_ENV_VEH3DOFCONTI) {   // two actions: the free slots carry the wrapped (steer, a_x) for the backward sweep
+            if (VEH) {   // two actions: the free slots carry the wrapped (steer, a_x) for the backward sweep
                 e0[2] = s_act[tid * 4 + 0];
                 e0[3] = s_act[tid * 4 + 1];
             }
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
                 float o[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) o[i] = xs[m * ldx + i];
-                r = veh_reward(o, steer, ax);
+                r = SURR ? veh_reward_w(p.env.reward_w, o, steer, ax) : veh_reward(o, steer, ax);
             }
             __syncthreads();   // every read of the old obs / state is done
             const float s_old = veh_s, c_old = veh_c;
@@ -354,6 +357,43 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
             if (part == 0) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) s_state[m * 8 + i] = sn[i];
+            }
+            if constexpr (SURR) {
+                // surrounding vehicles at the new time: observation columns (x, y, phi, u)_surr - (x, y, phi, u)_ego and
+                // the constraint on the new ego pose; info["constraint"] is NOT masked at done (the algorithms sum it
+                // for every trajectory), the observation is
+                if (part == 0 && m < nvalid) {
+                    const int ns = p.env.n_surr;
+                    const GLOBAL_AS f32x4* sp = gptr(p.surr_table) + ((size_t)(b0 + m) * (p.H + 1) + (t + 1)) * ns;
+                    f32x4 pts[GOPS_MAX_SURR];
+#pragma unroll
+                    for (int i = 0; i < GOPS_MAX_SURR; ++i) {
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        pts[i] = (i < ns) ? sp[i] : z;
+                    }
+                    if (dflag == 0.f) {
+#pragma unroll
+                        for (int i = 0; i < GOPS_MAX_SURR; ++i)
+                            if (i < ns) {
+                                float* dst = xs + m * ldx + 6 + 4 * P + 4 * i;
+                                dst[0] = pts[i][0] - sn[0]; dst[1] = pts[i][1] - sn[1];
+                                dst[2] = pts[i][2] - sn[2]; dst[3] = pts[i][3] - sn[3];
+                            }
+                    }
+                    SurrCstr sc;
+                    surr_constraint<false>(p.env, sn[0], sn[1], veh_s, veh_c, pts, sc);
+                    float e2 = 0.f, e1 = 0.f, lg = 0.f;
+                    for (int k = 0; k < p.env.n_constraint; ++k) {
+                        const float cp = fmaxf(sc.c[k], 0.f), cm = fminf(sc.c[k], 0.f);
+                        e2 += cp * cp;
+                        e1 += cp;
+                        lg += logf(-cm + 1e-8f);
+                        if (!(sc.c[k] < 0.f)) c_feas = 0.f;
+                    }
+                    c_ext += e2 * p.gpow[t];
+                    c_lin += e1 * p.gpow[t];
+                    c_int += lg * p.gpow[t];
+                }
             }
         }
         if (tid < TB) {
@@ -395,6 +435,10 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
         if (tid < TB) v_acc += ((1.f - s_done[tid]) * p.gpow[p.H]) * s_th[tid * 4];
     }
 
+    if (SURR && tid < nvalid && p.out.constraint_sums != nullptr) {
+        GLOBAL_AS float* cs = gptr(p.out.constraint_sums) + b0 + tid;
+        cs[0] = c_ext; cs[(size_t)p.B] = c_lin; cs[(size_t)2 * p.B] = c_int; cs[(size_t)3 * p.B] = c_feas;
+    }
     if (tid < nvalid) {
         gptr(p.out.v_pi)[b0 + tid] = v_acc;
         if (p.out.final_done != nullptr) gptr(p.out.final_done)[b0 + tid] = s_done[tid];
@@ -406,7 +450,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
             if (m < nvalid) gptr(p.out.final_obs)[(size_t)(b0 + m) * O + c] = xs[m * ldx + c];
         }
     }
-    if (ENV == GOPS_ENV_VEH3DOFCONTI && p.out.final_state != nullptr && tid < TB * 6) {
+    if (VEH && p.out.final_state != nullptr && tid < TB * 6) {
         const int m = tid / 6, c = tid - m * 6;
         if (m < nvalid) gptr(p.out.final_state)[(size_t)(b0 + m) * 6 + c] = s_state[m * 8 + c];
     }
@@ -425,6 +469,7 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
     sk[0] = sk[1] = 0;
     const MlpDev& M = p.pol;
     if (p.f16) return;   // the half-precision path streams its (half as large) weights from L2
+    if (p.env.kind == GOPS_ENV_VEH3DOF_SURR) return;   // constrained models: streamed kernels only
     // Register-stationary weights pin one workgroup per CU.  That is the right trade only while there
     // is at most one tile per CU (B <= 16 * #CUs = 4096 on MI355X); with more tiles the streamed
     // kernels win because 2-3 workgroups per CU overlap each other's MFMA and VALU phases.
@@ -485,7 +530,7 @@ int rollout_variant_h(const RolloutParams& p) {
 // `p` is the host copy (for shape dispatch), `dp` the device copy the kernel reads.
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_VEH3DOFCONTI ? p.env.pre_horizon + 1 + p.H : 0, p.f16 != 0);
+    const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, (p.env.kind == GOPS_ENV_VEH3DOFCONTI || p.env.kind == GOPS_ENV_VEH3DOF_SURR) ? p.env.pre_horizon + 1 + p.H : 0, p.f16 != 0);
     int sk[2];
     rollout_variant(p, sk, false);
     const int key = sk[0] * 100 + sk[1];
@@ -515,6 +560,7 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
             else if (key == 16) LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 0, 16);
             else LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 0, 0);
             break;
+        case GOPS_ENV_VEH3DOF_SURR: LAUNCH_FWD(GOPS_ENV_VEH3DOF_SURR, 0, 0); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

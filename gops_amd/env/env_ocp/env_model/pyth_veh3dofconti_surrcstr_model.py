@@ -1,0 +1,45 @@
+"""pyth_veh3dofconti_surrcstr model: veh3dofconti tracking next to `surr_veh_num` surrounding vehicles; info carries
+`surr_state` [n, 5] (x, y, phi, u, delta), the observation appends (x, y, phi, u)_surr - (x, y, phi, u)_ego per vehicle
+and `info["constraint"]` = 2 r - min circle distance (bicircle collision model).  Reference:
+gops/env/env_ocp/env_model/pyth_veh3dofconti_surrcstr_model.py:28-148 - the model behind FHADPExterior / Interior /
+Lagrangian.  Arithmetic in csrc/env_models.h (surr_next, surr_constraint) inside the GOPS_ENV_VEH3DOF_SURR kernels."""
+from typing import Dict, Optional, Union
+
+import numpy as np
+import torch
+
+from gops_amd import hip_backend as hb
+from gops_amd.env.env_ocp.env_model.pyth_base_model import PythBaseModel
+
+# stage-reward weights of pyth_veh3dofconti (pyth_veh3dofconti_model.py:161-177): dx^2, dy^2, dphi^2, du^2, omega^2, steer^2, a_x^2
+TRACKING_WEIGHTS = (0.04, 0.04, 0.02, 0.02, 0.01, 0.01, 0.01)
+
+
+class Veh3dofcontiSurrCstrModel(PythBaseModel):
+    hip_kind = hb.ENV_VEH_SURR
+    n_constraint = 1
+    reward_weights = TRACKING_WEIGHTS
+    road_upper, road_lower = 0.0, 0.0
+
+    def __init__(self, pre_horizon: int = 10, device: Union[torch.device, str, None] = None,
+                 path_para: Optional[Dict[str, Dict]] = None, u_para: Optional[Dict[str, Dict]] = None,
+                 surr_veh_num: int = 4, veh_length: float = 4.8, veh_width: float = 2.0, **kwargs):
+        if path_para is not None or u_para is not None:
+            raise RuntimeError("custom path_para/u_para are not supported by the HIP reference-trajectory "
+                               "kernel (it implements the default parameter set)")
+        if not 1 <= surr_veh_num <= hb.MAX_SURR:
+            raise RuntimeError(f"surr_veh_num must be 1..{hb.MAX_SURR} for the HIP env models")
+        self.pre_horizon, self.surr_veh_num = pre_horizon, surr_veh_num
+        self.veh_length, self.veh_width = veh_length, veh_width
+        super().__init__(obs_dim=6 + 4 * pre_horizon + 4 * surr_veh_num, action_dim=2, dt=0.1,
+                         action_lower_bound=[-np.pi / 6, -3], action_upper_bound=[np.pi / 6, 3], device=device)
+
+    def hip_constants(self) -> Dict:
+        return dict(surr=dict(n_surr=self.surr_veh_num, n_constraint=self.n_constraint, veh_length=self.veh_length,
+                              veh_width=self.veh_width, road_upper=self.road_upper, road_lower=self.road_lower,
+                              reward_w=self.reward_weights))
+
+
+def env_model_creator(**kwargs):
+    """make env model `pyth_veh3dofconti_surrcstr`"""
+    return Veh3dofcontiSurrCstrModel(**kwargs)

@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOPS_HIP_LIB") or os.path.join(_HERE, "libgops_hip.so")
 
 MAX_LAYERS, MAX_ACT, MAX_LQ, TILE = 5, 4, 6, 16
-ENV_NONE, ENV_LQ, ENV_IDP, ENV_VEH = 0, 1, 2, 3
+ENV_NONE, ENV_LQ, ENV_IDP, ENV_VEH, ENV_VEH_SURR = 0, 1, 2, 3, 4
+MAX_SURR = 4
 ACT_IDS = {"linear": 0, "relu": 1, "elu": 2, "gelu": 3, "selu": 4, "sigmoid": 5, "tanh": 6}
 DTYPE_IDS = {"fp32": 0, "f32": 0, "float32": 0, "fp16": 1, "f16": 1, "float16": 1, "half": 1}
 
@@ -53,6 +54,8 @@ class GopsEnv(C.Structure):
                 ("lq_inv_IA", C.c_float * (MAX_LQ * MAX_LQ)), ("lq_B", C.c_float * (MAX_LQ * MAX_ACT)),
                 ("lq_Q", C.c_float * MAX_LQ), ("lq_R", C.c_float * MAX_ACT),
                 ("lq_dt", C.c_float), ("lq_reward_scale", C.c_float), ("lq_reward_shift", C.c_float),
+                ("n_surr", C.c_int32), ("n_constraint", C.c_int32), ("veh_length", C.c_float), ("veh_width", C.c_float),
+                ("road_upper", C.c_float), ("road_lower", C.c_float), ("reward_w", C.c_float * 7),
                 ("data_env", C.c_int32)]
 
 
@@ -64,11 +67,11 @@ class GopsRolloutDesc(C.Structure):
 
 class GopsRolloutIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "done", "state", "ref_points", "path_num", "u_num",
-                                          "ref_time", "head_pre")]
+                                          "ref_time", "head_pre", "surr_state", "grad_constraint")]
 
 
 class GopsRolloutOut(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("v_pi", "rewards", "final_obs", "final_done", "final_state")]
+    _fields_ = [(k, C.c_void_p) for k in ("v_pi", "rewards", "final_obs", "final_done", "final_state", "constraint_sums")]
 
 
 ADAM_MAX = 16
@@ -83,7 +86,8 @@ class GopsAdamTensors(C.Structure):
 class GopsStepIO(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "action", "done", "state", "ref_points", "path_num",
                                           "u_num", "ref_time", "next_obs", "reward", "next_done",
-                                          "next_state", "next_ref_points", "next_ref_time")]
+                                          "next_state", "next_ref_points", "next_ref_time",
+                                          "surr_state", "next_surr_state", "constraint")]
 
 
 _lib = None
@@ -188,12 +192,17 @@ def make_mlp_grad(gw: Sequence[torch.Tensor], gb: Sequence[torch.Tensor]) -> Gop
 def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_action=-1.0, max_action=1.0,
              policy_low=None, policy_high=None, obs_low=None, obs_high=None, pre_horizon: int = 0,
              reward_scale: Optional[float] = None, reward_shift: Optional[float] = None,
-             lq: Optional[Dict] = None, data_env: bool = False) -> GopsEnv:
+             lq: Optional[Dict] = None, data_env: bool = False, surr: Optional[Dict] = None) -> GopsEnv:
     """Constants of the wrapped env model (create_env_model.py:86-128) as a C struct.  `data_env=True` (for
     `env_step` only): the DATA environment's termination tests / terminal penalty instead of the model's; obs_low /
     obs_high are then the data env's state bounds (pyth_lq) and are NOT applied as a clip."""
     e = GopsEnv()
     e.data_env = int(bool(data_env))
+    if surr is not None:   # ENV_VEH_SURR: surrounding vehicles, constraint geometry, reward weights
+        e.n_surr, e.n_constraint = int(surr["n_surr"]), int(surr["n_constraint"])
+        e.veh_length, e.veh_width = float(surr["veh_length"]), float(surr["veh_width"])
+        e.road_upper, e.road_lower = float(surr.get("road_upper", 0.0)), float(surr.get("road_lower", 0.0))
+        _fill(e.reward_w, surr["reward_w"])
     e.kind, e.obs_dim, e.act_dim, e.pre_horizon = kind, obs_dim, act_dim, pre_horizon
     A = act_dim
 
@@ -281,9 +290,11 @@ class Rollout:
             i.head_pre = _ptr(head_pre)
             self._head_pre = head_pre
         i.obs, i.done = _ptr(data["obs"]), _ptr(data.get("done"))
-        if d.env.kind == ENV_VEH:
+        if d.env.kind in (ENV_VEH, ENV_VEH_SURR):
             for k in ("state", "ref_points", "path_num", "u_num", "ref_time"):
                 setattr(i, k, _ptr(data[k]))
+        if d.env.kind == ENV_VEH_SURR:
+            i.surr_state = _ptr(data["surr_state"])
         self._keep = dict(data)   # the kernels (and a later backward) read these tensors: keep them alive
         out = GopsRolloutOut()
         res = {"v_pi": torch.empty(B, dtype=torch.float32, device=self.device)}
@@ -295,15 +306,22 @@ class Rollout:
             res["final_obs"] = torch.empty(B, O, dtype=torch.float32, device=self.device)
             res["final_done"] = torch.empty(B, dtype=torch.float32, device=self.device)
             out.final_obs, out.final_done = _ptr(res["final_obs"]), _ptr(res["final_done"])
-            if d.env.kind == ENV_VEH:
+            if d.env.kind in (ENV_VEH, ENV_VEH_SURR):
                 res["final_state"] = torch.empty(B, 6, dtype=torch.float32, device=self.device)
                 out.final_state = _ptr(res["final_state"])
+        if d.env.kind == ENV_VEH_SURR:   # [4, B]: sum c+^2, sum c+, sum log(-c- + eps), feasible  (discounted, unmasked)
+            res["constraint_sums"] = torch.empty(4, B, dtype=torch.float32, device=self.device)
+            out.constraint_sums = _ptr(res["constraint_sums"])
         check(lib().gops_rollout_forward(C.byref(d), C.byref(i), C.byref(out), self.workspace.data_ptr(),
                                          self.workspace.numel(), _stream()), "gops_rollout_forward")
         return res
 
-    def backward(self, grad_v: torch.Tensor, grad_w: List[torch.Tensor], grad_b: List[torch.Tensor]):
+    def backward(self, grad_v: torch.Tensor, grad_w: List[torch.Tensor], grad_b: List[torch.Tensor],
+                 grad_constraint: Optional[torch.Tensor] = None):
+        """`grad_constraint` (ENV_VEH_SURR): d(loss)/d(constraint_sums rows 0..2), [3, B]."""
         g = make_mlp_grad(grad_w, grad_b)
+        self._in.grad_constraint = _ptr(grad_constraint)
+        self._grad_c = grad_constraint
         check(lib().gops_rollout_backward(C.byref(self.desc), C.byref(self._in), _ptr(grad_v), C.byref(g),
                                           self.workspace.data_ptr(), self.workspace.numel(), _stream()),
               "gops_rollout_backward")
@@ -352,13 +370,18 @@ def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Ten
     io.obs, io.action, io.done = _ptr(obs), _ptr(action), _ptr(done)
     io.next_obs, io.reward, io.next_done = _ptr(nobs), _ptr(rew), _ptr(ndone)
     ninfo = {}
-    if env.kind == ENV_VEH:
+    if env.kind in (ENV_VEH, ENV_VEH_SURR):
         for k in ("state", "ref_points", "path_num", "u_num", "ref_time"):
             setattr(io, k, _ptr(info[k]))
         ninfo = dict(state=torch.empty_like(info["state"]), ref_points=torch.empty_like(info["ref_points"]),
                      ref_time=torch.empty_like(info["ref_time"]), path_num=info["path_num"], u_num=info["u_num"])
         io.next_state, io.next_ref_points = _ptr(ninfo["state"]), _ptr(ninfo["ref_points"])
         io.next_ref_time = _ptr(ninfo["ref_time"])
+    if env.kind == ENV_VEH_SURR:
+        ninfo["surr_state"] = torch.empty_like(info["surr_state"])
+        ninfo["constraint"] = torch.empty(B, env.n_constraint, dtype=torch.float32, device=obs.device)
+        io.surr_state, io.next_surr_state = _ptr(info["surr_state"]), _ptr(ninfo["surr_state"])
+        io.constraint = _ptr(ninfo["constraint"])
     check(lib().gops_env_step(C.byref(env), B, C.byref(io), _stream()), "gops_env_step")
     return nobs, rew, ndone, ninfo
 

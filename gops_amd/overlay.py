@@ -23,6 +23,9 @@ OVERLAY = {
     "gops.algorithm.base": "gops_amd.algorithm.base",
     "gops.algorithm.fhadp": "gops_amd.algorithm.fhadp",
     "gops.algorithm.fhadp2": "gops_amd.algorithm.fhadp2",
+    "gops.algorithm.fhadp_exterior": "gops_amd.algorithm.fhadp_exterior",
+    "gops.algorithm.fhadp_interior": "gops_amd.algorithm.fhadp_interior",
+    "gops.algorithm.fhadp_lagrangian": "gops_amd.algorithm.fhadp_lagrangian",
     "gops.algorithm.infadp": "gops_amd.algorithm.infadp",
     "gops.apprfunc.mlp": "gops_amd.apprfunc.mlp",
     # NOT overlaid: gops.env.env_ocp.env_model.pyth_*_model.  The reference's DATA envs import helpers from those

@@ -105,13 +105,22 @@ def obs_dim_of(cfg: Dict) -> int:
         return 6
     if cfg["env_id"] == "pyth_veh3dofconti":
         return 6 + 4 * cfg["pre_horizon"]
+    if cfg["env_id"] in _SURR_ENVS:
+        return 6 + 4 * cfg["pre_horizon"] + 4 * n_surr_of(cfg)
     return len(_LQ_INIT[cfg.get("lq_config", "s4a2")][0])
+
+
+_SURR_ENVS = {"pyth_veh3dofconti_surrcstr": 4, "pyth_veh3dofconti_detour": 1}   # env id -> default surr_veh_num
+
+
+def n_surr_of(cfg: Dict) -> int:
+    return cfg.get("surr_veh_num", _SURR_ENVS[cfg["env_id"]])
 
 
 def act_dim_of(cfg: Dict) -> int:
     if cfg["env_id"] == "pyth_idpendulum":
         return 1
-    if cfg["env_id"] == "pyth_veh3dofconti":
+    if cfg["env_id"] == "pyth_veh3dofconti" or cfg["env_id"] in _SURR_ENVS:
         return 2
     return _LQ_ACT_DIM[cfg.get("lq_config", "s4a2")]
 
@@ -128,7 +137,7 @@ def make_batch(cfg: Dict, seed: int, batch: int = None) -> Dict[str, torch.Tenso
     elif env_id == "pyth_lq":
         mean, std = (np.array(v, dtype=np.float32) for v in _LQ_INIT[cfg.get("lq_config", "s4a2")])
         out["obs"] = rng.uniform(mean - 3 * std, mean + 3 * std, size=(B, len(mean))).astype(np.float32)
-    elif env_id == "pyth_veh3dofconti":
+    elif env_id == "pyth_veh3dofconti" or env_id in _SURR_ENVS:
         P = cfg["pre_horizon"]
         t0 = 20.0 * rng.uniform(0.0, 1.0, size=B)
         path_num = rng.randint(0, 4, size=B)
@@ -141,6 +150,24 @@ def make_batch(cfg: Dict, seed: int, batch: int = None) -> Dict[str, torch.Tenso
         out.update(obs=veh_obs_f32(state, ref), state=state, ref_points=ref,
                    path_num=path_num.astype(np.float32), u_num=u_num.astype(np.float32),
                    ref_time=t0.astype(np.float32))
+        if env_id in _SURR_ENVS:
+            # surrounding vehicles around the first reference point (data env reset, pyth_veh3dofconti_surrcstr.py:81-116:
+            # longitudinal / lateral offsets, heading of the road, speed 5 +- 1); a share of them close enough to the ego
+            # vehicle that the collision constraint is active, small steering angles so that tan(delta) is exercised
+            ns = n_surr_of(cfg)
+            lon = rng.uniform(3.0, 14.0, size=(B, ns)) * rng.choice([-1.0, 1.0], size=(B, ns))
+            lat = rng.uniform(-3.5, 3.5, size=(B, ns))
+            sphi = ref[:, :1, 2] * (path_num[:, None] == 3) + rng.uniform(-0.05, 0.05, size=(B, ns))
+            sx = ref[:, :1, 0] + lon * np.cos(sphi) - lat * np.sin(sphi)
+            sy = ref[:, :1, 1] + lon * np.sin(sphi) + lat * np.cos(sphi)
+            su = 5.0 + rng.uniform(-1.0, 1.0, size=(B, ns))
+            if env_id.endswith("detour"):
+                su = su * (rng.uniform(size=(B, ns)) < 0.5)   # the detour env parks its vehicle (u = 0): keep half of them parked
+            sdelta = rng.uniform(-0.03, 0.03, size=(B, ns))
+            surr = np.stack((sx, sy, sphi, su, sdelta), axis=2).astype(np.float32)
+            rel = (surr[..., :4] - state[:, None, :4]).reshape(B, -1)
+            out["obs"] = np.concatenate((out["obs"], rel), axis=1).astype(np.float32)
+            out["surr_state"] = surr
     else:
         raise KeyError(env_id)
     A = act_dim_of(cfg)

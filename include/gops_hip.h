@@ -52,7 +52,12 @@ extern "C" {
 enum { GOPS_OK = 0, GOPS_ERR_BAD_ARG = -1, GOPS_ERR_UNSUPPORTED = -2, GOPS_ERR_WORKSPACE = -3 };
 
 /* env kinds: the three env models named by BASELINE.json + NONE (plain MLP batch evaluation) */
-enum { GOPS_ENV_NONE = 0, GOPS_ENV_LQ = 1, GOPS_ENV_IDPENDULUM = 2, GOPS_ENV_VEH3DOFCONTI = 3 };
+enum { GOPS_ENV_NONE = 0, GOPS_ENV_LQ = 1, GOPS_ENV_IDPENDULUM = 2, GOPS_ENV_VEH3DOFCONTI = 3,
+       /* veh3dofconti + surrounding vehicles + constraint outputs: pyth_veh3dofconti_surrcstr_model.py:42-148 and
+          pyth_veh3dofconti_detour_model.py:40-181 (the models behind FHADPExterior / Interior / Lagrangian) */
+       GOPS_ENV_VEH3DOF_SURR = 4 };
+#define GOPS_MAX_SURR 4        /* surrounding vehicles */
+#define GOPS_MAX_CONSTRAINT 3  /* constraint outputs per step */
 
 /* hidden activations: gops/utils/common_utils.py:26-55 */
 enum { GOPS_ACT_LINEAR = 0, GOPS_ACT_RELU = 1, GOPS_ACT_ELU = 2, GOPS_ACT_GELU = 3,
@@ -108,6 +113,15 @@ typedef struct GopsEnv {
     float lq_B[GOPS_MAX_LQ_STATE * GOPS_MAX_ACT];              /* row-major n x m */
     float lq_Q[GOPS_MAX_LQ_STATE], lq_R[GOPS_MAX_ACT];
     float lq_dt, lq_reward_scale, lq_reward_shift;
+    /* GOPS_ENV_VEH3DOF_SURR: obs_dim = 6 + 4 P + 4 n_surr; each surrounding vehicle follows its own kinematic
+     * bicycle (x, y, phi, u, delta; SurrVehicleModel :28-39) independently of the policy; the observation appends
+     * (x, y, phi, u)_surr - (x, y, phi, u)_ego per vehicle; constraint[0] = 2 r - min distance between the two ego
+     * circles and the two circles of every surrounding vehicle (bicircle model, :98-148); n_constraint = 3 adds the road
+     * boundary violations of the detour model (:143-151); the stage reward is
+     * -(w[0] dx^2 + w[1] dy^2 + w[2] dphi^2 + w[3] du^2 + w[4] omega^2 + w[5] steer^2 + w[6] a_x^2). */
+    int32_t n_surr, n_constraint;
+    float veh_length, veh_width, road_upper, road_lower;
+    float reward_w[7];
     /* gops_env_step only (rollouts reject it): 1 = the step of the DATA environment the reference's samplers drive
      * (gops/env/env_ocp/pyth_veh3dofconti.py:195-271, resources/lq_base.py:209-231, pyth_idpendulum.py:71-87) instead
      * of the env MODEL's: same dynamics and stage reward, but the data env's termination tests (veh3dofconti: world-frame
@@ -145,6 +159,9 @@ typedef struct GopsRolloutIn {
     const float* u_num;       /* [B] */
     const float* ref_time;    /* [B] */
     const float* head_pre;    /* open_loop only: [B, H, act_dim] policy-head outputs BEFORE the tanh squash */
+    const float* surr_state;  /* GOPS_ENV_VEH3DOF_SURR info["surr_state"] [B, n_surr, 5] (x, y, phi, u, delta) else NULL */
+    const float* grad_constraint; /* gops_rollout_backward, GOPS_ENV_VEH3DOF_SURR: d(loss)/d(constraint_sums) [3, B]
+                                 (rows as in GopsRolloutOut.constraint_sums); NULL = zeros */
 } GopsRolloutIn;
 
 typedef struct GopsRolloutOut {
@@ -153,6 +170,13 @@ typedef struct GopsRolloutOut {
     float* final_obs;         /* [B, obs_dim] or NULL */
     float* final_done;        /* [B] or NULL */
     float* final_state;       /* veh3dofconti [B,6] or NULL */
+    /* GOPS_ENV_VEH3DOF_SURR, or NULL: [4, B] discounted sums over the rollout of the UNMASKED info["constraint"] c_t
+     * (the algorithms read it regardless of `done`):
+     *   row 0  sum_t gamma^t sum_k max(c_tk, 0)^2            (fhadp_exterior.py:64, fhadp_interior.py:66)
+     *   row 1  sum_t gamma^t sum_k max(c_tk, 0)              (fhadp_lagrangian.py:66)
+     *   row 2  sum_t gamma^t sum_k log(-min(c_tk, 0) + 1e-8) (fhadp_interior.py:65)
+     *   row 3  1 if every c_tk < 0 (feasible trajectory, fhadp_interior.py:71) else 0 */
+    float* constraint_sums;
 } GopsRolloutOut;
 
 int gops_hip_version(void);
@@ -186,6 +210,8 @@ typedef struct GopsStepIO {
     const float* ref_time;
     float* next_obs; float* reward; float* next_done;
     float* next_state; float* next_ref_points; float* next_ref_time;
+    /* GOPS_ENV_VEH3DOF_SURR: info["surr_state"] [B, n_surr, 5] in / out, info["constraint"] [B, n_constraint] out */
+    const float* surr_state; float* next_surr_state; float* constraint;
 } GopsStepIO;
 int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream);
 

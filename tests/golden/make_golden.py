@@ -10,6 +10,7 @@ import json
 import os
 import sys
 import zlib
+from copy import deepcopy
 
 import numpy as np
 import torch
@@ -24,6 +25,9 @@ _ref_import.install()
 
 from gops.algorithm.fhadp import FHADP  # noqa: E402
 from gops.algorithm.fhadp2 import FHADP2  # noqa: E402
+from gops.algorithm.fhadp_exterior import FHADPExterior  # noqa: E402
+from gops.algorithm.fhadp_interior import FHADPInterior  # noqa: E402
+from gops.algorithm.fhadp_lagrangian import FHADPLagrangian  # noqa: E402
 from gops.algorithm.infadp import INFADP  # noqa: E402
 from gops.create_pkg.create_env_model import create_env_model  # noqa: E402
 
@@ -51,6 +55,11 @@ def alg_kwargs(cfg, seed, **extra):
         kw["pre_horizon"] = cfg.get("pre_horizon", cfg["horizon"])
     if "lq_config" in cfg:
         kw["lq_config"] = cfg["lq_config"]
+    if "surr_veh_num" in cfg:
+        kw["surr_veh_num"] = cfg["surr_veh_num"]
+    if cfg["alg"].startswith("FHADP") and cfg["alg"] not in ("FHADP", "FHADP2"):
+        kw["policy_func_name"] = "FiniteHorizonPolicy"
+        kw["pre_horizon"] = cfg.get("pre_horizon", cfg["horizon"])
     if cfg["alg"] == "FHADP2":
         kw["policy_func_name"] = "FiniteHorizonFullPolicy"
     kw.update(extra)
@@ -69,6 +78,10 @@ def build_alg(cfg, seed, **extra):
         alg.gamma = cfg.get("gamma", 1.0)
     elif cfg["alg"] == "FHADP2":
         alg = FHADP2(**kw)
+        alg.gamma = cfg.get("gamma", 1.0)
+    elif cfg["alg"] in ("FHADPExterior", "FHADPInterior", "FHADPLagrangian"):
+        cls = dict(FHADPExterior=FHADPExterior, FHADPInterior=FHADPInterior, FHADPLagrangian=FHADPLagrangian)[cfg["alg"]]
+        alg = cls(**kw)
         alg.gamma = cfg.get("gamma", 1.0)
     else:
         alg = INFADP(**kw)
@@ -355,6 +368,71 @@ def golden_fhadp2():
 
 
 # ------------------------------------------------------------------------------------------
+# 7. constrained FHADP variants on the veh3dofconti models with surrounding vehicles: model steps (obs / reward / done /
+#    surr_state / constraint) and loss terms + gradients of FHADPExterior / FHADPInterior / FHADPLagrangian
+# ------------------------------------------------------------------------------------------
+CSTR_STEP_CASES = {
+    "step_veh_surrcstr_p10": dict(env_id="pyth_veh3dofconti_surrcstr", pre_horizon=10),
+    "step_veh_detour_p10": dict(env_id="pyth_veh3dofconti_detour", pre_horizon=10),
+    "step_veh_surrcstr_p5_n2": dict(env_id="pyth_veh3dofconti_surrcstr", pre_horizon=5, surr_veh_num=2),
+}
+CSTR_ALG_CASES = {
+    "fhadp_ext_surrcstr": (dict(alg="FHADPExterior", env_id="pyth_veh3dofconti_surrcstr", batch=48, horizon=10, pre_horizon=10,
+                                hidden=(64, 64), act="elu", gamma=1.0), dict(penalty=2.5)),
+    "fhadp_int_surrcstr": (dict(alg="FHADPInterior", env_id="pyth_veh3dofconti_surrcstr", batch=48, horizon=10, pre_horizon=10,
+                                hidden=(64, 64), act="gelu", gamma=0.98), dict(penalty=1.7)),
+    "fhadp_lag_surrcstr": (dict(alg="FHADPLagrangian", env_id="pyth_veh3dofconti_surrcstr", batch=40, horizon=8, pre_horizon=8,
+                                hidden=(64, 64), act="tanh", gamma=1.0), dict(multiplier=0.8)),
+    "fhadp_int_detour": (dict(alg="FHADPInterior", env_id="pyth_veh3dofconti_detour", batch=48, horizon=12, pre_horizon=12,
+                              hidden=(64, 64), act="elu", gamma=1.0), dict(penalty=1.3)),
+    "fhadp_ext_detour": (dict(alg="FHADPExterior", env_id="pyth_veh3dofconti_detour", batch=33, horizon=9, pre_horizon=9,
+                              hidden=(64, 128), act="relu", gamma=0.99), dict(penalty=4.0)),
+}
+
+
+def golden_constrained():
+    for name, cfg in CSTR_STEP_CASES.items():
+        B, nsteps = 48, 6
+        data = make_batch(dict(cfg, batch=B), seed=19)
+        model = create_env_model(**cfg)
+        g = torch.Generator().manual_seed(23)
+        done = (torch.rand(B, generator=g) < 0.25).float()
+        info = {k: v.clone() for k, v in data.items()}
+        out = {"in/" + k: data[k].numpy().copy() for k in ("obs", "state", "ref_points", "path_num", "u_num", "ref_time", "surr_state")}
+        out["in/done"] = done.numpy().copy()
+        o, d = data["obs"].clone(), done
+        for s in range(nsteps):
+            a = torch.rand(B, 2, generator=g) * 2.6 - 1.3
+            o, r, d, info = model.forward(o, a, d, info)
+            out[f"s{s}/act"] = a.numpy()
+            out[f"s{s}/obs"], out[f"s{s}/rew"], out[f"s{s}/done"] = o.numpy().copy(), r.numpy().copy(), d.numpy().copy()
+            out[f"s{s}/state"] = info["state"].numpy().copy()
+            out[f"s{s}/ref_last"] = info["ref_points"][:, -1].numpy().copy()
+            out[f"s{s}/surr_state"] = info["surr_state"].numpy().copy()
+            out[f"s{s}/constraint"] = info["constraint"].numpy().copy()
+        out["meta/nsteps"] = nsteps
+        out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra={}))
+        save(name, **out)
+    for name, (cfg, extra) in CSTR_ALG_CASES.items():
+        seed = zlib.crc32(name.encode()) % 1000
+        alg = build_alg(cfg, seed, **extra)
+        data = make_batch(cfg, seed)
+        data["done"][-4:] = 1.0
+        out = {"in/" + k: v.numpy().copy() for k, v in data.items()}
+        out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra=extra, seed=seed))
+        out.update(sd_to_np(alg.networks.state_dict()))
+        alg.networks.policy.zero_grad()
+        loss, info = alg._compute_loss_policy(deepcopy(data))
+        loss.backward()
+        for i, gr in enumerate(grads_of(alg.networks.policy)):
+            out[f"grad/{i}"] = gr
+        out["loss"] = loss.item()
+        for k, v in info.items():
+            out["tb/" + k] = float(v)
+        save(name, **out)
+
+
+# ------------------------------------------------------------------------------------------
 # 6. DATA-environment transitions (the numpy envs the reference's samplers step: create_env + its wrappers)
 #    and the reference ReplayBuffer run on them - the semantics DeviceEnvSampler / the device ReplayBuffer
 #    reproduce (terminal penalty -100, data-env termination tests, no observation clipping)
@@ -427,9 +505,11 @@ def golden_data_envs():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained"]
     if "dataenv" in which:
         golden_data_envs()
+    if "constrained" in which:
+        golden_constrained()
     if "fhadp2" in which:
         golden_fhadp2()
     if "trained" in which:

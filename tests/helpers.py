@@ -4,7 +4,7 @@ import torch
 
 from oracle import adp_oracle as orc
 
-INFO_KEYS = ("state", "ref_points", "path_num", "u_num", "ref_time")
+INFO_KEYS = ("state", "ref_points", "path_num", "u_num", "ref_time", "surr_state")
 
 
 def oracle_env(cfg, extra, golden=None):
@@ -12,7 +12,7 @@ def oracle_env(cfg, extra, golden=None):
     with LAPACK when the fixture was recorded (fp32 `pinv`, whose last bits are host dependent and
     get amplified by long unstable LQ horizons) are taken from it instead of being recomputed."""
     env = orc.make_env(cfg["env_id"], lq_config=cfg.get("lq_config", "s4a2"),
-                       pre_horizon=cfg.get("pre_horizon", 10),
+                       pre_horizon=cfg.get("pre_horizon", 10), surr_veh_num=cfg.get("surr_veh_num"),
                        reward_scale=extra.get("reward_scale"), reward_shift=extra.get("reward_shift"))
     if golden is not None and "const/lq_inv_IA" in golden:
         env["lq"]["inv_IA"] = torch.from_numpy(np.array(golden["const/lq_inv_IA"]))
@@ -73,7 +73,10 @@ def reference_init_nets(cfg, seed, obs_dim, act_dim):
 # ---- HIP side: build C-ABI descriptors from the same (oracle-side) constants -------------------
 def hip_env_from_oracle(env, policy_net=None):
     from gops_amd import hip_backend as hb
-    kind = {"lq": hb.ENV_LQ, "idp": hb.ENV_IDP, "veh": hb.ENV_VEH}[env["kind"]]
+    kind = {"lq": hb.ENV_LQ, "idp": hb.ENV_IDP, "veh": hb.ENV_VEH, "veh_surr": hb.ENV_VEH_SURR}[env["kind"]]
+    surr = None
+    if env["kind"] == "veh_surr":
+        surr = {k: env[k] for k in ("n_surr", "n_constraint", "veh_length", "veh_width", "road_upper", "road_lower", "reward_w")}
     lq = None
     if env["kind"] == "lq":
         c = env["lq"]
@@ -85,7 +88,7 @@ def hip_env_from_oracle(env, policy_net=None):
                        policy_high=None if policy_net is None else policy_net["act_high"],
                        obs_low=env["obs_low"], obs_high=env["obs_high"], pre_horizon=env.get("P", 0),
                        reward_scale=env["reward_scale"] if env["shaping"] else None,
-                       reward_shift=env["reward_shift"] if env["shaping"] else None, lq=lq)
+                       reward_shift=env["reward_shift"] if env["shaping"] else None, lq=lq, surr=surr)
 
 
 def hip_mlp_from_net(net, device):

@@ -340,3 +340,48 @@ def test_infadp_graph_replay_matches_eager_updates(monkeypatch):
     assert all(c.graph is None for c in algs[1]._graphs.values())
     for a, b in zip(algs[0].networks.parameters(), algs[1].networks.parameters()):
         assert torch.equal(a, b)
+
+
+CSTR_ALG_CASES = ["fhadp_ext_surrcstr", "fhadp_int_surrcstr", "fhadp_lag_surrcstr", "fhadp_int_detour", "fhadp_ext_detour"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CSTR_ALG_CASES)
+def test_constrained_fhadp_classes_match_reference(name):
+    """FHADPExterior / FHADPInterior / FHADPLagrangian (create_alg surface) on the constrained veh3dofconti models, loaded
+    with the reference's weights: total / reward / constraint losses, feasible ratio and every policy gradient at 1e-4
+    against the reference's `_compute_loss_policy` + backward; then the penalty / multiplier schedules advance."""
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg, extra = meta["cfg"], meta["extra"]
+    kw = _kwargs(cfg, {}, meta["seed"])
+    kw.update(extra)
+    kw.update(algorithm=cfg["alg"], policy_func_name="FiniteHorizonPolicy", pre_horizon=cfg["pre_horizon"])
+    if "surr_veh_num" in cfg:
+        kw["surr_veh_num"] = cfg["surr_veh_num"]
+    alg = create_alg(**kw)
+    alg.gamma = cfg["gamma"]
+    sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("sd/")}
+    alg.load_state_dict(sd)
+    alg.networks.to("cuda")
+    data = data_from_golden(g)
+    tb, info = alg.get_remote_update_info(data, 0)
+    for key in ("Loss/Actor loss-RL iter", "Loss/Actor reward loss-RL iter", "Loss/Actor constraint loss-RL iter",
+                "Loss/Feasible ratio-RL iter", "Loss/Penalty coefficient-RL iter", "Loss/Lagrange multiplier-RL iter"):
+        if "tb/" + key in g:
+            want = float(g["tb/" + key])
+            assert abs(float(tb[key]) - want) <= 1e-4 * max(1.0, abs(want)), (name, key, float(tb[key]), want)
+    for i, gr in enumerate(info["grad"]):
+        assert rel_l2(gr.cpu(), g[f"grad/{i}"]) < 1e-4, (name, i, rel_l2(gr.cpu(), g[f"grad/{i}"]))
+    # schedules: penalty grows every `penalty_delay` updates / the multiplier takes an ascent step every `multiplier_delay`
+    before = [p.detach().clone() for p in alg.networks.policy.parameters()]
+    if hasattr(alg, "penalty"):
+        alg.penalty_delay, p0 = 2, alg.penalty
+        alg.local_update(data, 1)
+        assert alg.penalty == pytest.approx(p0 * alg.penalty_increase)
+    else:
+        alg.multiplier_delay, m0 = 2, alg.multiplier
+        alg.local_update(data, 1)
+        assert alg.multiplier > m0          # violation > 0: the multiplier rises
+    assert any(not torch.equal(a, b) for a, b in zip(before, alg.networks.policy.parameters()))
+    assert all(torch.isfinite(p).all() for p in alg.networks.policy.parameters())

@@ -437,3 +437,31 @@ def test_data_env_step_vs_reference_numpy_envs(name, dev):
         nets = reference_init_nets(cfg, 0, oenv["obs_dim"], oenv["act_dim"])
         mlp, _, _ = hip_mlp_from_net(nets["policy"], dev)
         hb.Rollout(henv, mlp, batch=4, horizon=2, gamma=1.0, finite_horizon=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["step_veh_surrcstr_p10", "step_veh_detour_p10", "step_veh_surrcstr_p5_n2"])
+def test_constrained_env_step_vs_reference_fixture(name, dev):
+    """gops_env_step of the constrained veh3dofconti models (GOPS_ENV_VEH3DOF_SURR): surrounding-vehicle observation
+    columns, surr_state, the unmasked constraint outputs, reward with the model's weights."""
+    from gops_amd import hip_backend as hb
+    g = load_golden(name)
+    meta = golden_meta(g)
+    env = hip_env_from_oracle(oracle_env(meta["cfg"], meta["extra"], g))
+    data = to_device(data_from_golden(g), dev)
+    obs, done = data["obs"], data["done"]
+    info = {k: data[k] for k in INFO_KEYS if k in data}
+    P = meta["cfg"]["pre_horizon"]
+    for s in range(int(g["meta/nsteps"])):
+        a = torch.from_numpy(g[f"s{s}/act"]).to(dev)
+        obs, r, done, info = hb.env_step(env, obs, a, done, info)
+        got_o, want_o = obs.cpu().numpy(), g[f"s{s}/obs"]
+        # ego / reference part: same appended-heading caveat as pyth_veh3dofconti (see test_env_step_vs_reference_fixture)
+        bad = ~np.isclose(got_o, want_o, rtol=1e-5, atol=2e-5)
+        assert bad.mean() < 0.012 and np.abs(got_o - want_o).max() < 2e-3 and rel_l2(got_o, want_o) < TOL
+        np.testing.assert_allclose(got_o[:, 6 + 4 * P:], want_o[:, 6 + 4 * P:], rtol=1e-5, atol=5e-5)   # surrounding vehicles: exact
+        np.testing.assert_allclose(r.cpu().numpy(), g[f"s{s}/rew"], rtol=1e-5, atol=2e-5)
+        assert np.array_equal(done.cpu().numpy() != 0, g[f"s{s}/done"])
+        np.testing.assert_allclose(info["state"].cpu().numpy(), g[f"s{s}/state"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(info["surr_state"].cpu().numpy(), g[f"s{s}/surr_state"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(info["constraint"].cpu().numpy(), g[f"s{s}/constraint"], rtol=1e-5, atol=5e-5)

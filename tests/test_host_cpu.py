@@ -62,10 +62,11 @@ def test_workspace_query_and_rejections_need_no_gpu():
 
 def test_registries_and_error_behaviour():
     from gops_amd.create_pkg import create_alg, create_apprfunc, create_env_model, create_trainer
-    assert set(create_alg.registry) == {"FHADP", "FHADP2", "INFADP"}
+    assert set(create_alg.registry) == {"FHADP", "FHADP2", "FHADPExterior", "FHADPInterior", "FHADPLagrangian", "INFADP"}
     assert {"mlp_DetermPolicy", "mlp_FiniteHorizonPolicy", "mlp_StateValue"} <= set(create_apprfunc.registry)
-    assert {"pyth_lq_model", "pyth_idpendulum_model", "pyth_veh3dofconti_model"} <= set(create_env_model.registry)
-    assert {"on_serial_trainer", "on_sync_trainer"} <= set(create_trainer.registry)
+    assert {"pyth_lq_model", "pyth_idpendulum_model", "pyth_veh3dofconti_model", "pyth_veh3dofconti_surrcstr_model",
+            "pyth_veh3dofconti_detour_model"} <= set(create_env_model.registry)
+    assert {"on_serial_trainer", "on_sync_trainer", "off_serial_trainer", "off_sync_trainer"} <= set(create_trainer.registry)
     with pytest.raises(KeyError, match="No registered algorithm with id"):
         create_alg.create_alg(algorithm="NOPE")
     with pytest.raises(KeyError, match="No registered env with id"):

@@ -154,3 +154,48 @@ def test_data_env_step_matches_reference_numpy_envs(name):
     assert t["done"].sum() > 0 or "shaped" in name
     nobs, r, done, ninfo = orc.data_env_forward(env, t["obs"], t["act"], info)
     check_data_env_transitions(nobs, r, done, ninfo, t, env["kind"] == "veh")
+
+
+CSTR_STEP_CASES = ["step_veh_surrcstr_p10", "step_veh_detour_p10", "step_veh_surrcstr_p5_n2"]
+CSTR_ALG_CASES = ["fhadp_ext_surrcstr", "fhadp_int_surrcstr", "fhadp_lag_surrcstr", "fhadp_int_detour", "fhadp_ext_detour"]
+CSTR_MODE = {"FHADPExterior": "exterior", "FHADPInterior": "interior", "FHADPLagrangian": "lagrangian"}
+
+
+@pytest.mark.parametrize("name", CSTR_STEP_CASES)
+def test_constrained_env_step_matches_reference(name):
+    """Veh3dofcontiSurrCstrModel / the detour model behind create_env_model's wrappers: obs (incl. the relative
+    surrounding-vehicle columns), reward, done, surr_state and the UNMASKED constraint of 6 consecutive steps."""
+    g = load_golden(name)
+    meta = golden_meta(g)
+    env = oracle_env(meta["cfg"], meta["extra"], g)
+    data = data_from_golden(g)
+    obs, done = data["obs"], data["done"]
+    info = {k: data[k] for k in INFO_KEYS if k in data}
+    for s in range(int(g["meta/nsteps"])):
+        obs, r, done, info = orc.env_forward(env, obs, torch.from_numpy(g[f"s{s}/act"]), done, info)
+        np.testing.assert_allclose(obs.numpy(), g[f"s{s}/obs"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(r.numpy(), g[f"s{s}/rew"], rtol=1e-5, atol=2e-5)
+        assert np.array_equal(done.numpy(), g[f"s{s}/done"])
+        np.testing.assert_allclose(info["surr_state"].numpy(), g[f"s{s}/surr_state"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(info["constraint"].numpy(), g[f"s{s}/constraint"], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", CSTR_ALG_CASES)
+def test_constrained_fhadp_gradients_match_reference(name):
+    """FHADPExterior / FHADPInterior / FHADPLagrangian._compute_loss_policy + backward of the reference against the
+    oracle restatement: total / reward / constraint losses and every policy gradient."""
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg = meta["cfg"]
+    env = oracle_env(cfg, {}, g)
+    nets, _ = nets_from_golden(g, cfg)
+    coef = meta["extra"].get("penalty", meta["extra"].get("multiplier"))
+    ref = orc.fhadp_constrained_gradient(env, nets["policy"], data_from_golden(g), cfg["horizon"], cfg["gamma"],
+                                         CSTR_MODE[cfg["alg"]], coef)
+    assert abs(ref["loss"].item() - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
+    assert abs(ref["loss_reward"].item() - float(g["tb/Loss/Actor reward loss-RL iter"])) <= 1e-5 * max(1.0, abs(ref["loss_reward"].item()))
+    assert abs(ref["loss_constraint"].item() - float(g["tb/Loss/Actor constraint loss-RL iter"])) <= 1e-5 * max(1.0, abs(ref["loss_constraint"].item()))
+    if "tb/Loss/Feasible ratio-RL iter" in g:
+        assert abs(ref["sums"][3].mean().item() - float(g["tb/Loss/Feasible ratio-RL iter"])) < 1e-6
+    for i, gr in enumerate(ref["grads"]):
+        assert rel_l2(gr, g[f"grad/{i}"]) < 1e-5, (name, i, rel_l2(gr, g[f"grad/{i}"]))

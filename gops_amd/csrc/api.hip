@@ -13,7 +13,7 @@
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);
 size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16);
-size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points);
+size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16);
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s);
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s);
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
@@ -219,7 +219,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     const bool veh = e.kind == GOPS_ENV_VEH3DOFCONTI || e.kind == GOPS_ENV_VEH3DOF_SURR;
     const int ref_pts = veh ? e.pre_horizon + 1 + desc.horizon
                                                           : (e.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
-    if (rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts) > 160 * 1024)
+    if (rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16) > 160 * 1024)
         return GOPS_ERR_UNSUPPORTED;
     for (int t = 0; t <= p.H; ++t) p.gpow[t] = (float)pow(desc.gamma, (double)t);
 

@@ -469,6 +469,9 @@ __device__ __forceinline__ void stash_tile(const float* lds, int ld, int ncols, 
     }
 }
 
+// Floats of LDS one hidden-activation / delta tile takes: [TB][ldh] floats, or [TB][ldh + 4] halfs in the F16 kernels.
+__host__ __device__ inline int hidden_tile_floats(int ldh, bool f16) { return f16 ? TB * (ldh + 4) / 2 : TB * ldh; }
+
 // Launch with up to 160 KiB of dynamic LDS (the default cap is 64 KiB).  The attribute belongs to a
 // kernel, and every template instantiation is its own kernel: the "already raised" flag is keyed on the
 // kernel's address (a function-local static would be shared by all instantiations of one signature).

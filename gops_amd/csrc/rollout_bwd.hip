@@ -11,8 +11,8 @@
 #include "rollout_f16.h"
 
 // LDS floats of the per-tile buffers (everything except the optional staged tiles at the end).
-__host__ __device__ inline int bwd_lds_floats(int ldx, int ldh, int ref_points) {
-    return TB * ldx + 2 * TB * ldh + TB * 4 + 4 * TB * 8 + 4 * ldh + 4 * TB * ref_points;
+__host__ __device__ inline int bwd_lds_floats(int ldx, int ldh, int ref_points, bool f16 = false) {
+    return TB * ldx + 2 * hidden_tile_floats(ldh, f16) + TB * 4 + 4 * TB * 8 + 4 * ldh + 4 * TB * ref_points;
 }
 
 // delta_y in s_gy[TB][4]  ->  hidden deltas (stashed to stash_d when non-null) and, if want_gx,
@@ -158,10 +158,9 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
 // F16: GOPS_DTYPE_F16 - deltas and act' operands are half, the contractions run on
 // v_mfma_f32_16x16x32_f16 (rollout_f16.h), and every adjoint carries the launch's power-of-two scale
 // (gscale[0]) that the reduce kernel takes out of the parameter gradients again.
-// SH (F16 only): 16-row tiles of W_0^T per wave when W_1^T and W_0^T are register-stationary in half
-// precision (StatWhT), 0 = streamed.
-template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, int SH = 0>
-__global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
+// (F16 kernels: 4 workgroups per CU - launch bound 4 waves / SIMD, <= 128 registers.)
+template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false>
+__global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;
     const int tid = threadIdx.x;
@@ -173,8 +172,8 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel
     const int ldx = p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* G = smem;                    // [TB][ldx] adjoint of obs_{t+1}
     float* da = G + TB * ldx;           // [TB][ldh]
-    float* db = da + TB * ldh;          // [TB][ldh]
-    float* s_gy = db + TB * ldh;        // [TB][4]
+    float* db = da + hidden_tile_floats(ldh, F16);    // [TB][ldh] floats, or [TB][ldh + 4] halfs (F16)
+    float* s_gy = db + hidden_tile_floats(ldh, F16);  // [TB][4]
     float* red = s_gy + TB * 4;         // [4][TB][8]
     float* s_wo = red + 4 * TB * 8;     // [4][ldh] head weights
     f32x4* s_ref = reinterpret_cast<f32x4*>(s_wo + 4 * ldh);   // veh: [TB][TL]
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel
     // One-workgroup-per-CU variants: LDS copies of this step's H_2 / H_1 (Z for GELU) tiles, [2][TB][256]
     constexpr bool STAGE = (SK1 > 0);   // (those variants are only selected for obs-256-256-act policies)
     float* s_stage = smem + bwd_lds_floats(ldx, ldh, VEH ? p.env.pre_horizon + 1 + p.H
-                                                                             : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0));
+                                                                             : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0), F16);
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
     float gv = (tid < nvalid) ? gptr(p.grad_v)[b0 + tid] : 0.f;
@@ -218,8 +217,6 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel
     typename std::conditional<(SK1 > 0), StatW<16, 4>, NoW>::type WT1;
     if constexpr (SK0 > 0) WT0.load(p.pol.wpt[0], kp0 >> 4, tid, p.pol.dims[1] >> 4);
     if constexpr (SK1 > 0) WT1.load(p.pol.wpt[1], p.pol.dims[1] >> 4, tid);
-    typename std::conditional<(SH > 0), StatWhT<(SH > 0 ? SH : 1)>, NoWh>::type WHT;
-    if constexpr (SH > 0) WHT.load(p.pol, tid);
 
     DbgClock dbg;
     dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
@@ -231,7 +228,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel
         }
         __syncthreads();
         if constexpr (F16)
-            mlp_backward_h(p.val, NoWh{}, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, reinterpret_cast<_Float16*>(da),
+            mlp_backward_h(p.val, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, reinterpret_cast<_Float16*>(da),
                            reinterpret_cast<_Float16*>(db), ld16, G, ldx, tid, p.st.tail_h, p.st.tail_z, nullptr, nullptr,
                            (size_t)b0, nvalid, true, O, [] {});
         else
@@ -565,7 +562,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel
         DBG_TICK(1)
         if (!p.open_loop) {
             if constexpr (F16)
-                mlp_backward_h(p.pol, WHT, s_wo, ldh, s_gy, reinterpret_cast<_Float16*>(da), reinterpret_cast<_Float16*>(db), ld16, G, ldx,
+                mlp_backward_h(p.pol, s_wo, ldh, s_gy, reinterpret_cast<_Float16*>(da), reinterpret_cast<_Float16*>(db), ld16, G, ldx,
                                tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, [] {});
             else
             mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
@@ -590,8 +587,8 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_bwd_kernel
 
 // ref_points: reference-table points per trajectory (veh3dofconti), 30 (= 5 x 24 / 4) for the
 // idpendulum sub-step parking area, else 0
-size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points) {
-    return sizeof(float) * (size_t)bwd_lds_floats(ldx, ldh, ref_points);
+size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16) {
+    return sizeof(float) * (size_t)bwd_lds_floats(ldx, ldh, ref_points, f16);
 }
 
 void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
@@ -602,12 +599,11 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
         else launch_with_lds(rollout_bwd_kernel<ENV, A, B, false>, grid, block, lds, stream, dp);         \
     } while (0)
 
-#define LAUNCH_BWD_H(ENV, SH)                                                                                       \
-    do {                                                                                                            \
-        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, true, SH>, grid, block, lds, stream, dp); \
-        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, true, SH>, grid, block, lds, stream, dp);       \
+#define LAUNCH_BWD_H(ENV)                                                                                       \
+    do {                                                                                                        \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, true>, grid, block, lds, stream, dp); \
+        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, true>, grid, block, lds, stream, dp);       \
     } while (0)
-int rollout_variant_h(const RolloutParams& p);
 
 #define LAUNCH_BWD2(ENV, A, B, PT)                                                                          \
     do {                                                                                                    \
@@ -618,23 +614,17 @@ int rollout_variant_h(const RolloutParams& p);
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
     size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, (p.env.kind == GOPS_ENV_VEH3DOFCONTI || p.env.kind == GOPS_ENV_VEH3DOF_SURR) ? p.env.pre_horizon + 1 + p.H
-                                                       : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0));
+                                                       : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0), p.f16 != 0);
     int sk[2];
     rollout_variant(p, sk, true);
     if (sk[1] > 0) lds += sizeof(float) * 2 * (2 * TB * 256 + TB * ENV_STASH + TB * 8);   // two staging halves
     const int key = sk[0] * 100 + sk[1];
     if (p.f16) {
-        // stationary W_1^T / W_0^T fragments: 1 tile of W_0^T per wave for <= 64 inputs, 2 for <= 128
-        const int sh = rollout_variant_h(p) == 0 ? 0 : ((p.pol.kp[0] >> 4) <= 4 ? 1 : 2);
         switch (p.env.kind) {
-            case GOPS_ENV_NONE: if (sh == 1) LAUNCH_BWD_H(GOPS_ENV_NONE, 1); else LAUNCH_BWD_H(GOPS_ENV_NONE, 0); break;
-            case GOPS_ENV_LQ: if (sh == 1) LAUNCH_BWD_H(GOPS_ENV_LQ, 1); else LAUNCH_BWD_H(GOPS_ENV_LQ, 0); break;
-            case GOPS_ENV_IDPENDULUM: if (sh == 1) LAUNCH_BWD_H(GOPS_ENV_IDPENDULUM, 1); else LAUNCH_BWD_H(GOPS_ENV_IDPENDULUM, 0); break;
-            case GOPS_ENV_VEH3DOFCONTI:
-                if (sh == 1) LAUNCH_BWD_H(GOPS_ENV_VEH3DOFCONTI, 1);
-                else if (sh == 2) LAUNCH_BWD_H(GOPS_ENV_VEH3DOFCONTI, 2);
-                else LAUNCH_BWD_H(GOPS_ENV_VEH3DOFCONTI, 0);
-                break;
+            case GOPS_ENV_NONE: LAUNCH_BWD_H(GOPS_ENV_NONE); break;
+            case GOPS_ENV_LQ: LAUNCH_BWD_H(GOPS_ENV_LQ); break;
+            case GOPS_ENV_IDPENDULUM: LAUNCH_BWD_H(GOPS_ENV_IDPENDULUM); break;
+            case GOPS_ENV_VEH3DOFCONTI: LAUNCH_BWD_H(GOPS_ENV_VEH3DOFCONTI); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

@@ -13,8 +13,6 @@
 // 64q + 16g .. + 15 of trajectory m: two 16-byte stores per quad, 128 contiguous bytes per stash row
 // and wave.
 #pragma once
-#include <type_traits>
-
 #include "common.h"
 
 #define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
@@ -47,10 +45,16 @@ __device__ __forceinline__ void gelu_pair(float z, float& h, float& dh) {
 }
 
 // acc[j] (n-tile j of quad q, see the header) += W_quad * act^T over kch chunks of 32 inputs.  The
-// weight fragments stream from L2 through a ring of PF chunks (L2 latency >> the 4 MFMAs of a chunk).
+// weight fragments stream from L2 through a ring of PF chunks (L2 latency >> the 4 MFMAs of a chunk).  Measured
+// at B = 65536 (cfg5): a deeper ring (4) or register-stationary fragments (16 K0 + 128 registers per lane for a
+// 256-256 policy) cost more in occupancy than they save - the step is bound by dependent VALU / LDS / scalar
+// latency, which 4 resident workgroups per CU hide better than 2 or 3.
+#ifndef GOPS_F16_PF
+#define GOPS_F16_PF 2   // chunks of weight fragments in flight per wave (16 registers each)
+#endif
 __device__ __forceinline__ void gemm_quad_h(const _Float16* act, int ld, int kch, const f16x8* Wp, int q,
                                             int lane, f32x4 (&acc)[4]) {
-    constexpr int PF = 4;
+    constexpr int PF = GOPS_F16_PF;
     const GLOBAL_AS f16x8* wb = gptr(Wp) + (size_t)q * 4 * kch * 64 + lane;
     const _Float16* brow = act + (lane & 15) * ld + 8 * (lane >> 4);
     f16x8 ring[PF][4];
@@ -79,55 +83,6 @@ __device__ __forceinline__ void gemm_quad_h(const _Float16* act, int ld, int kch
     }
 }
 
-// ---- register-stationary half fragments -----------------------------------------------------------
-// In half precision a wave's slice of a whole 256-256 policy is 16 K0 + 128 registers (K0 = chunks of
-// layer 0): it stays in registers for all H steps and the per-step weight stream from L2 (128 KB per
-// tile and step - the L2 -> CU bandwidth bound of the streamed form at large batches) disappears.
-// Wave w owns quad w of both layers (forward: W_0, W_1 rows; backward: W_1^T rows and NT0 16-row tiles
-// of W_0^T for the observation adjoint).
-template <int K0>
-struct StatWh {
-    f16x8 w0[4 * K0], w1[4 * 8];
-    __device__ __forceinline__ void load(const MlpDev& M, int tid) {
-        const int lane = tid & 63, q = tid >> 6;
-        const GLOBAL_AS f16x8* a = gptr(M.wph[0]) + (size_t)q * 4 * K0 * 64 + lane;
-        const GLOBAL_AS f16x8* b = gptr(M.wph[1]) + (size_t)q * 4 * 8 * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < 4 * K0; ++i) w0[i] = a[(size_t)i * 64];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) w1[i] = b[(size_t)i * 64];
-    }
-};
-template <int NT0>
-struct StatWhT {
-    f16x8 w1[4 * 8], w0[NT0 * 8];
-    __device__ __forceinline__ void load(const MlpDev& M, int tid) {
-        const int lane = tid & 63, q = tid >> 6, nt_tot = M.kp[0] >> 4;
-        const GLOBAL_AS f16x8* b = gptr(M.wpth[1]) + (size_t)q * 4 * 8 * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) w1[i] = b[(size_t)i * 64];
-#pragma unroll
-        for (int t = 0; t < NT0; ++t) {
-            const int nt = q + 4 * t;
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                w0[t * 8 + c] = (nt < nt_tot) ? gptr(M.wpth[0])[((size_t)nt * 8 + c) * 64 + lane] : zero8h();
-        }
-    }
-};
-struct NoWh {};   // streamed weights
-
-template <int KCH>
-__device__ __forceinline__ void gemm_quad_stat_h(const _Float16* act, int ld, const f16x8* w, int lane, f32x4 (&acc)[4]) {
-    const _Float16* brow = act + (lane & 15) * ld + 8 * (lane >> 4);
-#pragma unroll
-    for (int c = 0; c < KCH; ++c) {
-        const f16x8 b = ld8h(brow + 32 * c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = MFMA_F16(w[j * KCH + c], b, acc[j]);
-    }
-}
-
 // fp32 observation tile xs [TB][ldx] (columns < kp valid, the rest of a row zero) -> half tile x16
 // [TB][ld16] with kp32 columns (zero padded) and, when g16 is non-null, the stash rows g16[(row0+m)*kp32 ..].
 __device__ __forceinline__ void convert_x_h(const float* xs, int ldx, int kp, int kp32, _Float16* x16, int ld16,
@@ -150,8 +105,7 @@ __device__ __forceinline__ void convert_x_h(const float* xs, int ldx, int kp, in
 // Hidden layers of `M` on the half tile x16 (TB x kp32[0]).  Returns the LDS buffer holding the last
 // hidden activation.  stash_h[j] (and, for GELU, stash_g[j] <- act'(z)) receive rows row0 .. of the
 // tile for m < stash_rows when non-null.  s_bias: LDS fp32 biases, row j at s_bias + j * ldb.
-template <class SW>
-__device__ __forceinline__ const _Float16* mlp_hidden_forward_h(const MlpDev& M, const SW& sw, const _Float16* x16, int ldx16,
+__device__ __forceinline__ const _Float16* mlp_hidden_forward_h(const MlpDev& M, const _Float16* x16, int ldx16,
                                                                 _Float16* ha, _Float16* hb, int ld16, int tid,
                                                                 const float* s_bias, int ldb, float* const* stash_h,
                                                                 float* const* stash_g, size_t row0, int stash_rows) {
@@ -168,12 +122,7 @@ __device__ __forceinline__ const _Float16* mlp_hidden_forward_h(const MlpDev& M,
                              ? reinterpret_cast<_Float16*>(stash_g[j + 1]) + (row0 + m) * N : nullptr;
         for (int q = wave; q < nquads; q += 4) {
             f32x4 acc[4] = {};
-            if constexpr (std::is_same<SW, NoWh>::value) {
-                gemm_quad_h(cur, ldc, kch, M.wph[j], q, lane, acc);
-            } else {   // two 256-wide layers, quad == wave
-                if (j == 0) gemm_quad_stat_h<sizeof(sw.w0) / (4 * sizeof(f16x8))>(cur, ldc, sw.w0, lane, acc);
-                else gemm_quad_stat_h<8>(cur, ldc, sw.w1, lane, acc);
-            }
+            gemm_quad_h(cur, ldc, kch, M.wph[j], q, lane, acc);
             const int f0 = 64 * q + 16 * g;
             f32x4 bv[4];
 #pragma unroll
@@ -241,8 +190,8 @@ __device__ __forceinline__ void mlp_head_h(WP Wo, int ldw, BP bo, int K, int A, 
 // -> hidden deltas (half; stashed to st_d[j] when st_d is non-null) and, if want_gx, G[m][n] += (delta_1
 // W_0)[m][n] for n < ncols in fp32.  act' comes from the stash: act'(z) itself for GELU (st_z), else derived
 // from the stashed activation (st_h).
-template <class SW, class WP, class Hook>
-__device__ __forceinline__ void mlp_backward_h(const MlpDev& M, const SW& sw, WP Wo, int ldw, const float* s_gy, _Float16* da,
+template <class WP, class Hook>
+__device__ __forceinline__ void mlp_backward_h(const MlpDev& M, WP Wo, int ldw, const float* s_gy, _Float16* da,
                                                _Float16* db, int ld16, float* G, int ldg, int tid,
                                                float* const* st_h, float* const* st_z, float* const* st_d,
                                                float* stash_dy, size_t row0, int nvalid, bool want_gx, int ncols,
@@ -302,8 +251,7 @@ __device__ __forceinline__ void mlp_backward_h(const MlpDev& M, const SW& sw, WP
             f16x8 hv[2] = {zero8h(), zero8h()};
             if (m < nvalid) { hv[0] = ld8h(src + f0); hv[1] = ld8h(src + f0 + 8); }   // in flight during the GEMM
             f32x4 acc[4] = {};
-            if constexpr (std::is_same<SW, NoWh>::value) gemm_quad_h(cur, ld16, kch, M.wpth[j], q, lane, acc);
-            else gemm_quad_stat_h<8>(cur, ld16, sw.w1, lane, acc);   // j == 1 of a 256-256 policy, quad == wave
+            gemm_quad_h(cur, ld16, kch, M.wpth[j], q, lane, acc);
             act_dispatch(M.act, [&]<int ACT>() {
                 f16x8 o[2];
 #pragma unroll
@@ -329,27 +277,13 @@ __device__ __forceinline__ void mlp_backward_h(const MlpDev& M, const SW& sw, WP
     if (want_gx) {   // g_x = delta_1 W_0: plain 16-feature tiles over the (16-padded) inputs, fp32 into G
         const int kch = M.dims[1] >> 5, nt_tot = M.kp[0] >> 4;
         const _Float16* brow = cur + m * ld16 + 8 * g;
-        int t_idx = 0;
-        for (int nt = wave; nt < nt_tot; nt += 4, ++t_idx) {
+        for (int nt = wave; nt < nt_tot; nt += 4) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (std::is_same<SW, NoWh>::value) {
-                const GLOBAL_AS f16x8* wb = gptr(M.wpth[0]) + (size_t)nt * kch * 64 + lane;
-                for (int c = 0; c < kch; c += 2) {   // kch is even (hidden widths are multiples of 64)
-                    const f16x8 a0 = wb[(size_t)c * 64], a1 = wb[(size_t)(c + 1) * 64];
-                    acc0 = MFMA_F16(a0, ld8h(brow + 32 * c), acc0);
-                    acc1 = MFMA_F16(a1, ld8h(brow + 32 * (c + 1)), acc1);
-                }
-            } else {
-                constexpr int NT0 = sizeof(sw.w0) / (8 * sizeof(f16x8));
-#pragma unroll
-                for (int t = 0; t < NT0; ++t)
-                    if (t == t_idx) {   // (unrolled: the fragment array is only indexed with constants)
-#pragma unroll
-                        for (int c = 0; c < 8; c += 2) {
-                            acc0 = MFMA_F16(sw.w0[t * 8 + c], ld8h(brow + 32 * c), acc0);
-                            acc1 = MFMA_F16(sw.w0[t * 8 + c + 1], ld8h(brow + 32 * (c + 1)), acc1);
-                        }
-                    }
+            const GLOBAL_AS f16x8* wb = gptr(M.wpth[0]) + (size_t)nt * kch * 64 + lane;
+            for (int c = 0; c < kch; c += 2) {   // kch is even (hidden widths are multiples of 64)
+                const f16x8 a0 = wb[(size_t)c * 64], a1 = wb[(size_t)(c + 1) * 64];
+                acc0 = MFMA_F16(a0, ld8h(brow + 32 * c), acc0);
+                acc1 = MFMA_F16(a1, ld8h(brow + 32 * (c + 1)), acc1);
             }
             const int f = 16 * nt + 4 * g;
 #pragma unroll

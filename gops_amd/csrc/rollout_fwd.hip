@@ -117,10 +117,9 @@ __device__ __forceinline__ void mlp_head(WP Wo, int ldw, BP bo, int K, int A, co
 // that its streamed-GEMM registers do not add to the pressure of the stationary variants).
 // F16: GOPS_DTYPE_F16 - the hidden layers run on v_mfma_f32_16x16x32_f16 (rollout_f16.h) and the
 // activation stash is half precision; everything else in the step is the same fp32 code.
-// SH (F16 only): chunks of 32 inputs of layer 0 when the whole 256-256 policy is register-stationary in
-// half precision (StatWh), 0 = streamed.
-template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false, int SH = 0>
-__global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
+// (F16 kernels: 4 workgroups per CU - launch bound 4 waves / SIMD, <= 128 registers.)
+template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false>
+__global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;   // parameters live in device memory: uniform scalar loads
     const int tid = threadIdx.x;
@@ -133,8 +132,8 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
     const int ldx = p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* xs = smem;                       // [TB][ldx]  current observation (+ time column)
     float* ha = xs + TB * ldx;              // [TB][ldh]
-    float* hb = ha + TB * ldh;              // [TB][ldh]
-    float* s_state = hb + TB * ldh;         // [TB][8]
+    float* hb = ha + hidden_tile_floats(ldh, F16);       // [TB][ldh] floats, or [TB][ldh + 4] halfs (F16)
+    float* s_state = hb + hidden_tile_floats(ldh, F16);  // [TB][8]
     float* s_act = s_state + TB * 8;        // [TB][4] wrapped action
     float* s_th = s_act + TB * 4;           // [TB][4] tanh(head) (ENV_NONE: raw head output)
     float* s_done = s_th + TB * 4;          // [TB]
@@ -181,8 +180,6 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
     typename std::conditional<(SK1 > 0), StatW<(SK1 > 0 ? SK1 : 1), 4>, NoW>::type W1;
     if constexpr (SK0 > 0) W0.load(p.pol.wp[0], p.pol.dims[1] >> 4, tid, p.pol.kp[0] >> 4);
     if constexpr (SK1 > 0) W1.load(p.pol.wp[1], p.pol.dims[2] >> 4, tid);
-    typename std::conditional<(SH > 0), StatWh<(SH > 0 ? SH : 1)>, NoWh>::type WH;
-    if constexpr (SH > 0) WH.load(p.pol, tid);
     float v_acc = 0.f;
     float c_ext = 0.f, c_lin = 0.f, c_int = 0.f, c_feas = 1.f;   // SURR: discounted constraint sums of trajectory tid (tid < TB)
     float veh_s = 0.f, veh_c = 1.f;   // sin/cos of the current heading, carried across steps
@@ -215,7 +212,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
             float y[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
             if (!p.open_loop) {
                 if constexpr (F16) {
-                    const _Float16* hcur = mlp_hidden_forward_h(p.pol, WH, x16, ldx16, reinterpret_cast<_Float16*>(ha),
+                    const _Float16* hcur = mlp_hidden_forward_h(p.pol, x16, ldx16, reinterpret_cast<_Float16*>(ha),
                                                                 reinterpret_cast<_Float16*>(hb), ld16, tid, s_bias, ldh,
                                                                 p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
                                                                 row0, TB);
@@ -419,7 +416,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
         if constexpr (F16) {
             convert_x_h(xs, ldx, p.val.kp[0], p.val.kp32[0], x16, ldx16, nullptr, 0, tid);
             __syncthreads();
-            const _Float16* hcur = mlp_hidden_forward_h(p.val, NoWh{}, x16, ldx16, reinterpret_cast<_Float16*>(ha),
+            const _Float16* hcur = mlp_hidden_forward_h(p.val, x16, ldx16, reinterpret_cast<_Float16*>(ha),
                                                         reinterpret_cast<_Float16*>(hb), ld16, tid, s_bias, ldh,
                                                         p.need_grad ? p.st.tail_h : nullptr,
                                                         p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, nvalid);
@@ -457,7 +454,7 @@ __global__ __launch_bounds__(NTHREADS, (SH > 0) ? 2 : 1) void rollout_fwd_kernel
 }
 
 size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16) {
-    size_t b = sizeof(float) * (size_t)(TB * ldx + 2 * TB * ldh + TB * (8 + 4 + 4 + 1 + 1 + 2) + (4 + GOPS_MAX_LAYERS - 1) * ldh +
+    size_t b = sizeof(float) * (size_t)(TB * ldx + 2 * hidden_tile_floats(ldh, f16) + TB * (8 + 4 + 4 + 1 + 1 + 2) + (4 + GOPS_MAX_LAYERS - 1) * ldh +
                                         4 * TB * ref_points);
     if (f16) b += sizeof(_Float16) * (size_t)TB * ((((ldx - 4) + 31) & ~31) + 8);   // x16
     return b;
@@ -511,21 +508,11 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
         if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, A, B, true>, grid, block, lds, stream, dp);   \
         else launch_with_lds(rollout_fwd_kernel<ENV, A, B, false>, grid, block, lds, stream, dp);         \
     } while (0)
-#define LAUNCH_FWD_H(ENV, SH)                                                                                      \
+#define LAUNCH_FWD_H(ENV)                                                                                          \
     do {                                                                                                           \
-        if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, true, true, SH>, grid, block, lds, stream, dp);   \
-        else launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, false, true, SH>, grid, block, lds, stream, dp);         \
+        if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, true, true>, grid, block, lds, stream, dp);       \
+        else launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, false, true>, grid, block, lds, stream, dp);             \
     } while (0)
-
-// Half-precision stationary variant: chunks of layer 0 (1, 2 or 4) when the policy is in -> 256 -> 256 -> out
-// and its inputs fit 128 columns, else 0 (streamed).  GOPS_SH=0 forces the streamed kernels (A/B knob).
-int rollout_variant_h(const RolloutParams& p) {
-    const MlpDev& M = p.pol;
-    if (!p.f16 || p.open_loop || M.nl != 3 || M.dims[1] != 256 || M.dims[2] != 256) return 0;
-    if (const char* e = getenv("GOPS_SH")) if (atoi(e) == 0) return 0;
-    const int k0 = M.kp32[0] >> 5;
-    return (k0 == 1 || k0 == 2 || k0 == 4) ? k0 : 0;
-}
 
 // `p` is the host copy (for shape dispatch), `dp` the device copy the kernel reads.
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
@@ -534,14 +521,12 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
     int sk[2];
     rollout_variant(p, sk, false);
     const int key = sk[0] * 100 + sk[1];
-    if (p.f16) {
-        // The forward kernel streams its half weights from L2: the register-stationary form (StatWh, SH > 0)
-        // measured 6 % slower at B = 65536 (it costs a third of the occupancy); the backward sweep keeps it.
+    if (p.f16) {   // half-precision kernels: weights streamed from L2, four workgroups per CU
         switch (p.env.kind) {
-            case GOPS_ENV_NONE: LAUNCH_FWD_H(GOPS_ENV_NONE, 0); break;
-            case GOPS_ENV_LQ: LAUNCH_FWD_H(GOPS_ENV_LQ, 0); break;
-            case GOPS_ENV_IDPENDULUM: LAUNCH_FWD_H(GOPS_ENV_IDPENDULUM, 0); break;
-            case GOPS_ENV_VEH3DOFCONTI: LAUNCH_FWD_H(GOPS_ENV_VEH3DOFCONTI, 0); break;
+            case GOPS_ENV_NONE: LAUNCH_FWD_H(GOPS_ENV_NONE); break;
+            case GOPS_ENV_LQ: LAUNCH_FWD_H(GOPS_ENV_LQ); break;
+            case GOPS_ENV_IDPENDULUM: LAUNCH_FWD_H(GOPS_ENV_IDPENDULUM); break;
+            case GOPS_ENV_VEH3DOFCONTI: LAUNCH_FWD_H(GOPS_ENV_VEH3DOFCONTI); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

@@ -788,6 +788,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
         const size_t stride = (size_t)rows * ld;
         const float* p = part + (size_t)r * ld + c;
         int s = sl;
+        // 8 independent loads in flight per thread (the kernel is latency-bound: one 256-byte row segment per wave and
+        // split); the pairs are added in a fixed order, so the result does not depend on the unrolling
+        for (; s + 28 < splits; s += 32) {
+            const float v0 = p[(size_t)s * stride], v1 = p[(size_t)(s + 4) * stride], v2 = p[(size_t)(s + 8) * stride],
+                        v3 = p[(size_t)(s + 12) * stride], v4 = p[(size_t)(s + 16) * stride], v5 = p[(size_t)(s + 20) * stride],
+                        v6 = p[(size_t)(s + 24) * stride], v7 = p[(size_t)(s + 28) * stride];
+            acc0 += v0; acc1 += v1; acc2 += v2; acc3 += v3;
+            acc0 += v4; acc1 += v5; acc2 += v6; acc3 += v7;
+        }
         for (; s + 12 < splits; s += 16) {
             acc0 += p[(size_t)s * stride];
             acc1 += p[(size_t)(s + 4) * stride];

@@ -191,7 +191,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     p.need_grad = desc.need_grad ? 1 : 0;
     p.tail = desc.tail_value ? 1 : 0;
     p.env = e;
-    p.open_loop = desc.open_loop ? 1 : 0;
+    p.open_loop = desc.open_loop == 2 ? 2 : (desc.open_loop ? 1 : 0);
     p.f16 = f16 ? 1 : 0;
     if (p.open_loop) {
         // The kernels keep their tile / stash bookkeeping in terms of a policy: give them the
@@ -329,7 +329,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     p.in = in;
     p.grad_v = grad_v;
     p.g_head_pre = g_head_pre;
-    if (p.open_loop != (g_head_pre != nullptr ? 1 : 0)) return GOPS_ERR_BAD_ARG;
+    if ((p.open_loop != 0) != (g_head_pre != nullptr)) return GOPS_ERR_BAD_ARG;
     if (p.open_loop && in.head_pre == nullptr) return GOPS_ERR_BAD_ARG;
     if (!p.open_loop)
         for (int j = 0; j < p.pol.nl; ++j)

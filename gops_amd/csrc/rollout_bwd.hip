@@ -333,7 +333,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_bwd_kernel(cons
                 for (int a = 0; a < GOPS_MAX_ACT; ++a) {
                     sc[a] = (p.env.policy_high[a] - p.env.policy_low[a]) / 2.f;
                     abar[a] = sc[a] * th[a] + (p.env.policy_high[a] + p.env.policy_low[a]) / 2.f;
-                    u[a] = (a < A) ? wrap_action(p.env, a, abar[a]) : 0.f;
+                    u[a] = (a < A) ? (p.open_loop == 2 ? th[a] : wrap_action(p.env, a, abar[a])) : 0.f;   // open_loop 2: raw actions
                 }
                 const bool dn = dflag != 0.f;
                 const float g_rm = dn ? 0.f : g_r;
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_bwd_kernel(cons
                     if (i < O) G[m * ldx + i] = gx[i];
 #pragma unroll
                 for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                    s_gy[m * 4 + a] = (a < A) ? wrap_action_bwd(p.env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a]) : 0.f;
+                    s_gy[m * 4 + a] = (a < A) ? (p.open_loop == 2 ? gu[a] : wrap_action_bwd(p.env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a])) : 0.f;
             }
         } else {   // GOPS_ENV_VEH3DOFCONTI
             const int m = tid & 15, part = tid >> 4, lane = tid & 63, wave = tid >> 6;
@@ -552,8 +552,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_bwd_kernel(cons
                 }
                 g_steer += g_rm * ((SURR ? -2.f * p.env.reward_w[5] : -0.02f) * steer);
                 g_ax += g_rm * ((SURR ? -2.f * p.env.reward_w[6] : -0.02f) * ax);
-                s_gy[m * 4 + 0] = wrap_action_bwd(p.env, 0, abar0, g_steer) * sc0 * (1.f - th0 * th0);
-                s_gy[m * 4 + 1] = wrap_action_bwd(p.env, 1, abar1, g_ax) * sc1 * (1.f - th1 * th1);
+                s_gy[m * 4 + 0] = p.open_loop == 2 ? g_steer : wrap_action_bwd(p.env, 0, abar0, g_steer) * sc0 * (1.f - th0 * th0);
+                s_gy[m * 4 + 1] = p.open_loop == 2 ? g_ax : wrap_action_bwd(p.env, 1, abar1, g_ax) * sc1 * (1.f - th1 * th1);
                 s_gy[m * 4 + 2] = 0.f;
                 s_gy[m * 4 + 3] = 0.f;
             }

@@ -234,6 +234,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_fwd_kernel(cons
                 if (la < A) {
                     if (ENV == GOPS_ENV_NONE) {
                         s_th[hm * 4 + la] = ya;
+                    } else if (p.open_loop == 2) {   // shooting over the raw model: head_pre IS the model action
+                        s_th[hm * 4 + la] = ya;
+                        s_act[hm * 4 + la] = ya;
                     } else {
                         const ActC c = act_const(s_ac, la);
                         const float th = tanhf(ya);
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_fwd_kernel(cons
             if (ENV != GOPS_ENV_NONE && p.env.shaping) rr = (rr + p.env.reward_shift) * p.env.reward_scale;
             v_acc += rr * p.gpow[t];
             if (p.out.rewards != nullptr && tid < nvalid) gptr(p.out.rewards)[(size_t)t * p.B + b0 + tid] = rr;
-            if (done_m) s_done[tid] = 1.f;
+            if (done_m && !p.env.no_mask_at_done) s_done[tid] = 1.f;
         }
         DBG_TICK(5)
     }

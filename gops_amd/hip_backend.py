@@ -54,7 +54,7 @@ class GopsEnv(C.Structure):
                 ("lq_inv_IA", C.c_float * (MAX_LQ * MAX_LQ)), ("lq_B", C.c_float * (MAX_LQ * MAX_ACT)),
                 ("lq_Q", C.c_float * MAX_LQ), ("lq_R", C.c_float * MAX_ACT),
                 ("lq_dt", C.c_float), ("lq_reward_scale", C.c_float), ("lq_reward_shift", C.c_float),
-                ("n_surr", C.c_int32), ("n_constraint", C.c_int32), ("veh_length", C.c_float), ("veh_width", C.c_float),
+                ("no_mask_at_done", C.c_int32), ("n_surr", C.c_int32), ("n_constraint", C.c_int32), ("veh_length", C.c_float), ("veh_width", C.c_float),
                 ("road_upper", C.c_float), ("road_lower", C.c_float), ("reward_w", C.c_float * 7),
                 ("data_env", C.c_int32)]
 
@@ -248,7 +248,7 @@ class Rollout:
 
     def __init__(self, env: GopsEnv, policy: Optional[GopsMlp], *, batch: int, horizon: int, gamma: float,
                  finite_horizon: bool, need_grad: bool = True, value: Optional[GopsMlp] = None,
-                 device: Optional[torch.device] = None, dtype=None):
+                 device: Optional[torch.device] = None, dtype=None, raw_actions: bool = False):
         """`policy=None` selects the open-loop mode: `forward(data, head_pre=...)` takes the pre-tanh
         policy-head outputs of all steps [B, H, act_dim] and `backward_open_loop` returns their gradient.
         `dtype`: "fp32" (default, exact fp32 MFMA) or "fp16" (half-precision MFMA contractions and stash)."""
@@ -258,7 +258,8 @@ class Rollout:
         d.batch, d.horizon, d.finite_horizon = batch, horizon, int(finite_horizon)
         d.need_grad, d.tail_value, d.gamma = int(need_grad), int(value is not None), float(gamma)
         d.env = env
-        d.open_loop = int(policy is None)
+        # raw_actions (open loop only): `head_pre` holds the model's actions themselves (GopsRolloutDesc.open_loop = 2)
+        d.open_loop = (2 if raw_actions else 1) if policy is None else 0
         if policy is not None:
             d.policy = policy
         if value is not None:

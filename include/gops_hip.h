@@ -119,6 +119,9 @@ typedef struct GopsEnv {
      * circles and the two circles of every surrounding vehicle (bicircle model, :98-148); n_constraint = 3 adds the road
      * boundary violations of the detour model (:143-151); the stage reward is
      * -(w[0] dx^2 + w[1] dy^2 + w[2] dphi^2 + w[3] du^2 + w[4] omega^2 + w[5] steer^2 + w[6] a_x^2). */
+    /* 1: no MaskAtDoneModel in the chain (mask_at_done.py:33-40): the model keeps stepping after its done test fired,
+     * rewards are not zeroed (the raw model OptController drives, opt_controller.py:261-265) */
+    int32_t no_mask_at_done;
     int32_t n_surr, n_constraint;
     float veh_length, veh_width, road_upper, road_lower;
     float reward_w[7];
@@ -139,7 +142,11 @@ typedef struct GopsRolloutDesc {
     int32_t tail_value;       /* 1: v += (~done_H) gamma^H V(obs_H)   (infadp.py:182-184, 210) */
     int32_t open_loop;        /* 1: no policy evaluation inside the rollout - the pre-tanh head outputs of
                                  every step come from GopsRolloutIn.head_pre (FHADP2: one MLP evaluation
-                                 emits all H actions, gops/algorithm/fhadp2.py:100-121); `policy` is ignored */
+                                 emits all H actions, gops/algorithm/fhadp2.py:100-121); `policy` is ignored.
+                                 2: as 1, but head_pre holds the MODEL ACTIONS themselves (no tanh squash, no
+                                 ScaleAction / ClipAction): the shooting rollout of an optimal-control solver over
+                                 the raw model, gops/sys_simulator/opt_controller.py:240-300; the backward returns
+                                 d(loss)/d(action) */
     int32_t dtype;            /* GOPS_DTYPE_F32 (default) or GOPS_DTYPE_F16: arithmetic of the MLP contractions
                                  (hidden widths must then be multiples of 64) */
     int32_t reserved;

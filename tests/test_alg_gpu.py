@@ -385,3 +385,64 @@ def test_constrained_fhadp_classes_match_reference(name):
         assert alg.multiplier > m0          # violation > 0: the multiplier rises
     assert any(not torch.equal(a, b) for a, b in zip(before, alg.networks.policy.parameters()))
     assert all(torch.isfinite(p).all() for p in alg.networks.policy.parameters())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(env_id="pyth_lq", lq_config="s4a2"), dict(env_id="pyth_lq", lq_config="s6a3"),
+                                 dict(env_id="pyth_idpendulum"), dict(env_id="pyth_veh3dofconti", pre_horizon=10)],
+                         ids=lambda c: c["env_id"][5:] + c.get("lq_config", ""))
+def test_opt_controller_cost_and_jacobian_match_raw_model(cfg):
+    """OptController: cost and Jacobian of a shooting rollout over the RAW model (no wrappers, no
+    MaskAtDone) from ONE forward + ONE backward kernel launch, against the oracle's step-by-step rollout + autograd."""
+    from gops_amd.create_pkg.create_env_model import create_env_model
+    from gops_amd.sys_simulator.opt_controller import OptController
+    from gops_amd.utils.synthetic import make_batch
+    from oracle import adp_oracle as orc
+    model = create_env_model(**cfg, use_gpu=True)
+    T, interval = 12, 3
+    ctrl = OptController(model, num_pred_step=T, ctrl_interval=interval, gamma=0.97)
+    data = make_batch(dict(cfg, batch=3), 21)
+    env = orc.make_env(cfg["env_id"], lq_config=cfg.get("lq_config", "s4a2"), pre_horizon=cfg.get("pre_horizon", 10))
+    rng = np.random.RandomState(4)
+    lo, hi = ctrl.bounds.lb, ctrl.bounds.ub
+    for b in range(3):
+        u = rng.uniform(0.6 * lo, 0.6 * hi)                      # inside the action bounds, in model units
+        info = {k: data[k][b].numpy() for k in ("state", "ref_points", "path_num", "u_num", "ref_time") if k in data}
+        cost, jac = ctrl._cost_fcn_and_jac(u, data["obs"][b].numpy(), info)
+        acts = torch.tensor(u, dtype=torch.float32).reshape(T // interval, -1).repeat_interleave(interval, 0)[None]
+        oinfo = {k: data[k][b:b + 1] for k in info}
+        want_cost, want_obs, want_jac = orc.raw_shooting_cost(env, data["obs"][b:b + 1], oinfo, acts, 0.97)
+        assert abs(cost - want_cost.item()) <= 1e-4 * max(1.0, abs(want_cost.item())), (cfg, cost, want_cost)
+        want = want_jac[0].reshape(T // interval, interval, -1).sum(1).reshape(-1)
+        assert rel_l2(jac, want) < 1e-4, (cfg, rel_l2(jac, want))
+        fin, stage = ctrl._rollout(u, data["obs"][b].numpy(), info)
+        # veh3dofconti: the final observation holds 10 appended reference headings (fp32 finite differences, see
+        # test_env_step_vs_reference_fixture) - ego part exact, whole vector to 1e-3
+        assert rel_l2(fin.cpu()[:6], want_obs[0][:6]) < 1e-4 and rel_l2(fin.cpu(), want_obs[0]) < 1e-3
+        assert abs(stage.sum().item() - want_cost.item()) <= 1e-4 * max(1.0, abs(want_cost.item()))
+
+
+@pytest.mark.gpu
+def test_opt_controller_solves_lq_regulation():
+    """Receding-horizon control of pyth_lq s4a2 from a perturbed state: every solve lowers its cost below the zero-input
+    cost, respects the action bounds, and the closed loop (model steps on the GPU) regulates the state."""
+    from gops_amd.create_pkg.create_env_model import create_env_model
+    from gops_amd.sys_simulator.opt_controller import OptController
+    from gops_amd import hip_backend as hb
+    model = create_env_model("pyth_lq", lq_config="s4a2", use_gpu=True)
+    ctrl = OptController(model, num_pred_step=20, ctrl_interval=2, gamma=1.0, minimize_options={"maxiter": 60})
+    x = np.array([1.5, -0.6, 1.0, 0.5], dtype=np.float32)
+    zero_cost, _ = ctrl._cost_fcn_and_jac(np.zeros_like(ctrl.initial_guess), x, {})
+    raw = ctrl._rollout_obj.desc.env
+    norms = [float(np.linalg.norm(x))]
+    for _ in range(25):
+        u = ctrl(x)
+        assert np.all(u >= ctrl.bounds.lb[:2] - 1e-9) and np.all(u <= ctrl.bounds.ub[:2] + 1e-9)
+        assert ctrl.last_result.fun < zero_cost or norms[-1] < 0.2
+        # one step of the raw model with the (model-unit) action: min/max_action of `raw` are the identity scaling
+        o = torch.tensor(x, device="cuda").reshape(1, -1)
+        nobs, _, _, _ = hb.env_step(raw, o, torch.tensor(u, dtype=torch.float32, device="cuda").reshape(1, -1),
+                                    torch.zeros(1, device="cuda"), {})
+        x = nobs[0].cpu().numpy()
+        norms.append(float(np.linalg.norm(x)))
+    assert norms[-1] < 0.8 * norms[0] and all(b < a + 1e-6 for a, b in zip(norms, norms[1:])), norms   # 2.5 s of a slow plant

@@ -909,8 +909,10 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         float s[6], sn[6], s0[6];
         for (int i = 0; i < 6; ++i) s0[i] = s[i] = ob[i];
         IdpSub w;
-        for (int k = 0; k < 5; ++k) {
-            idp_substep(IC, s, 500.f * u[0], 0.002f, sn, w);
+        for (int k = 0; k < 5; ++k) {   // same arithmetic as the rollout kernels (one sincosf pair, then rotations)
+            if (k == 0) idp_substep<true>(IC, s, 500.f * u[0], 0.002f, sn, w);
+            else idp_substep<false>(IC, s, 500.f * u[0], 0.002f, sn, w);
+            idp_advance_trig(s, 0.002f, w, w);
             for (int i = 0; i < 6; ++i) s[i] = sn[i];
         }
         r = idp_reward(s, u[0]);

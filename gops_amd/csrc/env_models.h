@@ -80,12 +80,32 @@ struct IdpSub {     // intermediates of one sub-step that the adjoint re-uses
     float qdd[3];
 };
 
+// One explicit-Euler sub-step.  FIRST: the sin / cos of theta1, theta2 are evaluated here (sincosf); otherwise
+// w.s1 .. w.c2 hold them on entry.  On exit w_next (may alias w) holds the intermediates of THIS sub-step and, in
+// its s1 .. c2, the sin / cos of the NEXT state's angles: theta' = theta + tau * theta_dot is a rotation by
+// d = tau * theta_dot (|d| < 0.1 for any state the pendulum reaches), so sin / cos advance with a 5th / 4th order
+// series of d (error < 2e-11) instead of two more sincosf per sub-step - 2 instead of 15 libm calls per env step;
+// sin / cos(theta1 - theta2) follow from the angle-difference identities.  All within fp32 round-off (1e-7) of the
+// direct evaluation, far inside the reference's own 1e-5 step tolerance.
+__device__ __forceinline__ void idp_rotate(float& sn_, float& cs_, float d) {
+    const float d2 = d * d;
+    const float sd = d * (1.f + d2 * (-1.f / 6.f + d2 * (1.f / 120.f)));
+    const float cd = 1.f + d2 * (-0.5f + d2 * (1.f / 24.f));
+    const float s0 = sn_, c0 = cs_;
+    sn_ = s0 * cd + c0 * sd;
+    cs_ = c0 * cd - s0 * sd;
+}
+
+template <bool FIRST = true>
 __device__ __forceinline__ void idp_substep(const IdpConst& C, const float* s, float u, float tau,
                                             float* sn, IdpSub& w) {
-    const float th1 = s[1], th2 = s[2], th1d = s[4], th2d = s[5];
-    sincosf(th1, &w.s1, &w.c1);
-    sincosf(th2, &w.s2, &w.c2);
-    sincosf(th1 - th2, &w.s12, &w.c12);
+    const float th1d = s[4], th2d = s[5];
+    if (FIRST) {
+        sincosf(s[1], &w.s1, &w.c1);
+        sincosf(s[2], &w.s2, &w.c2);
+    }
+    w.s12 = w.s1 * w.c2 - w.c1 * w.s2;
+    w.c12 = w.c1 * w.c2 + w.s1 * w.s2;
     const float m00 = C.a, m01 = C.b * w.c1, m02 = C.e * w.c2, m11 = C.f, m12 = C.h * w.c12, m22 = C.k;
     const float f0 = C.b * (th1d * th1d) * w.s1 + C.e * (th2d * th2d) * w.s2 + u;
     const float f1 = -C.h * (th2d * th2d) * w.s12 + C.gb * w.s1;
@@ -108,6 +128,13 @@ __device__ __forceinline__ void idp_substep(const IdpConst& C, const float* s, f
     sn[3] = s[3] + tau * w.qdd[0];
     sn[4] = s[4] + tau * w.qdd[1];
     sn[5] = s[5] + tau * w.qdd[2];
+}
+// sin / cos of the angles after the sub-step whose intermediates are in `w` (input state s): for the next sub-step
+__device__ __forceinline__ void idp_advance_trig(const float* s, float tau, const IdpSub& w, IdpSub& nxt) {
+    float s1 = w.s1, c1 = w.c1, s2 = w.s2, c2 = w.c2;
+    idp_rotate(s1, c1, tau * s[4]);
+    idp_rotate(s2, c2, tau * s[5]);
+    nxt.s1 = s1; nxt.c1 = c1; nxt.s2 = s2; nxt.c2 = c2;
 }
 
 // adjoint of one sub-step: g (adjoint of sn, overwritten with adjoint of s), gu accumulated

@@ -362,10 +362,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_bwd_kernel(cons
 #pragma unroll
                     for (int i = 0; i < 6; ++i) sc_[i] = x[i];
                     const float a = u[0], force = 500.f * a;
+                    IdpSub w;
 #pragma unroll 1
                     for (int k = 0; k < 5; ++k) {
-                        IdpSub w;
-                        idp_substep(IC, sc_, force, 0.002f, sn_, w);
+                        if (k == 0) idp_substep<true>(IC, sc_, force, 0.002f, sn_, w);
+                        else idp_substep<false>(IC, sc_, force, 0.002f, sn_, w);   // w.s1 .. w.c2 advanced at the end of the last trip
                         float* pk = park + k * 24;
 #pragma unroll
                         for (int i = 0; i < 6; ++i) pk[i] = sc_[i];
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_bwd_kernel(cons
                         for (int i = 0; i < 6; ++i) pk[12 + i] = w.inv[i];
 #pragma unroll
                         for (int i = 0; i < 3; ++i) pk[18 + i] = w.qdd[i];
+                        idp_advance_trig(sc_, 0.002f, w, w);
 #pragma unroll
                         for (int i = 0; i < 6; ++i) sc_[i] = sn_[i];
                     }

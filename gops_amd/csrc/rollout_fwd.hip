@@ -296,12 +296,16 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_fwd_kernel(cons
                 const float a = s_act[m * 4];
                 const float u = 500.f * a;
                 IdpSub w;
+                idp_substep<true>(IC, s, u, 0.002f, sn, w);
 #pragma unroll 1
-                for (int k = 0; k < 5; ++k) {
-                    idp_substep(IC, s, u, 0.002f, sn, w);
+                for (int k = 1; k < 5; ++k) {
+                    idp_advance_trig(s, 0.002f, w, w);   // sin / cos of the new angles from the old ones (rotation by tau * theta_dot)
 #pragma unroll
                     for (int i = 0; i < 6; ++i) s[i] = sn[i];
+                    idp_substep<false>(IC, s, u, 0.002f, sn, w);
                 }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) s[i] = sn[i];
                 r = idp_reward(s, a);
                 done_m = idp_done(IC, s);
                 if (s_done[m] == 0.f) {

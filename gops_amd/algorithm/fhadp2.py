@@ -4,8 +4,9 @@ Same class surface as the reference's gops/algorithm/fhadp2.py (ApproxContainer 
 :49-121): `FiniteHorizonFullPolicy` maps obs_0 to all H actions in ONE MLP evaluation, the env model is
 rolled out with that sequence, `loss = -mean_b sum_t gamma^t r_t`.  The H-step env-model loop and its
 autograd replay run in the fused kernels' open-loop mode (`gops_rollout_forward` with
-`open_loop = 1`, `gops_rollout_backward_open_loop`); the single MLP evaluation and its backward are
-plain library GEMMs through torch.
+`open_loop = 1`, `gops_rollout_backward_open_loop`); the single MLP evaluation and its backward run in the
+library too (`gops_mlp_forward / _backward`: hidden stack on the rollout tiles, the act_dim * H wide output layer on its
+own kernels) - no autograd graph, no rocBLAS.
 """
 __all__ = ["FHADP2"]
 
@@ -15,7 +16,8 @@ from typing import Tuple
 import torch
 
 from gops_amd import hip_backend as hb
-from gops_amd.algorithm.base import _INFO_KEYS, AlgorithmBase, ApprBase, batch_to_device, cuda_device_of
+from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, batch_to_device, cuda_device_of,
+                                     grad_buffers)
 from gops_amd.create_pkg.create_apprfunc import create_apprfunc
 from gops_amd.create_pkg.create_env_model import create_env_model
 from gops_amd.utils.common_utils import get_apprfunc_dict, make_adam
@@ -76,8 +78,18 @@ class FHADP2(AlgorithmBase):
             env = self.envmodel.hip_env(policy.act_low_lim.cpu().numpy(), policy.act_high_lim.cpu().numpy())
             ro = hb.Rollout(env, None, batch=batch, horizon=self.forward_step, gamma=self.gamma,
                             finite_horizon=False, need_grad=True, device=device)
-            self._rollouts = {key: ro}
+            self._rollouts[key] = ro
         return ro
+
+    def _mlp_for(self, batch: int, device) -> hb.MlpNet:
+        mlp = self.networks.policy.hip_mlp()
+        key = ("mlp", batch, str(device))
+        net = self._rollouts.get(key)
+        if net is None:
+            net = self._rollouts[key] = hb.MlpNet(mlp, batch, device=device)
+        else:
+            net.mlp = mlp
+        return net
 
     def _compute_gradient(self, data):
         t0 = time.time()
@@ -85,13 +97,16 @@ class FHADP2(AlgorithmBase):
         batch = batch_to_device(data, device, ("obs", "done") + _INFO_KEYS)
         B = batch["obs"].shape[0]
         policy = self.networks.policy
-        for p in policy.parameters():
-            p.grad = None
-        pre = policy.pre_tanh(batch["obs"])                     # one MLP evaluation (rocBLAS), autograd graph kept
+        # ONE evaluation of the full-horizon policy emits all H actions (fhadp2.py:100-104): hidden stack on the rollout
+        # tiles, wide output layer on its own kernels (gops_mlp_forward); no autograd graph, no rocBLAS
+        net = self._mlp_for(B, device)
+        pre = net.forward(batch["obs"]).view(B, policy.pre_horizon, policy.act_dim)
         ro = self._rollout_for(B, device)
-        v_pi = ro.forward(batch, head_pre=pre.detach().contiguous())["v_pi"]
+        v_pi = ro.forward(batch, head_pre=pre)["v_pi"]
         loss_policy = -v_pi.mean()
         grad_v = torch.full((B,), -1.0 / B, dtype=torch.float32, device=device)
-        pre.backward(ro.backward_open_loop(grad_v))             # through the MLP into the parameters' .grad
+        g_pre = ro.backward_open_loop(grad_v)                    # d(loss)/d(head outputs) [B, H, A]
+        gw, gb = grad_buffers(policy)
+        net.backward(batch["obs"], g_pre.view(B, -1), gw, gb)    # through the MLP into the parameters' .grad
         self.tb_info[tb_tags["loss_actor"]] = loss_policy.item()
         self.tb_info[tb_tags["alg_time"]] = (time.time() - t0) * 1000  # ms

@@ -95,9 +95,8 @@ class FiniteHorizonPolicy(DetermPolicy):
 
 class FiniteHorizonFullPolicy(nn.Module, Action_Distribution, _HipMlpMixin):
     """Finite-horizon policy that emits the whole action sequence from one evaluation at obs_0
-    (reference gops/apprfunc/mlp.py:114-145): output width = act_dim * pre_horizon.  This single MLP
-    evaluation is a plain library GEMM chain (rocBLAS through torch); FHADP2's HIP rollout consumes
-    `pre_tanh(obs)` and returns its gradient."""
+    (reference gops/apprfunc/mlp.py:114-145): output width = act_dim * pre_horizon.  `forward` is the eager
+    definition for samplers; FHADP2 evaluates the same parameters through `gops_mlp_forward / _backward` (`hip_mlp()`)."""
 
     def __init__(self, **kwargs):
         super().__init__()

@@ -22,7 +22,10 @@ hipError_t launch_dw_gemm_f16(const void* D, int N, const void* X, int Kp, long 
                               int chunks_per_split, float* part, float* part_b, hipStream_t s);
 hipError_t launch_dw_out(const float* dy, const float* h, bool h_is_half, int K, int A, long long S, int splits,
                          float* part, float* part_b, hipStream_t s);
-void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, int cols, int ld, float* out);
+void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, int cols, int ld, float* out, int slab_rows = 0);
+hipError_t launch_linear_out_fwd(const float* h, int K, const float* Wo, const float* bo, int W, int B, float* y, hipStream_t s);
+hipError_t launch_linear_out_bwd(const float* gy, int W, int Wp, const float* Wo, int K, int B, long long S, float* gh,
+                                 float* gyp, hipStream_t s);
 hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s);
 hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s);
 hipError_t launch_adam(const GopsAdamTensors& T, GopsAdamState* st, double beta1, double beta2, float eps,
@@ -319,7 +322,8 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
 }
 
 int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const float* grad_v,
-                 const GopsMlpGrad& grad, float* g_head_pre, void* ws, size_t ws_bytes, hipStream_t s) {
+                 const GopsMlpGrad& grad, float* g_head_pre, void* ws, size_t ws_bytes, hipStream_t s,
+                 const float* ext_delta = nullptr) {
     if (!desc.need_grad || grad_v == nullptr) return GOPS_ERR_BAD_ARG;
     Plan plan;
     int rc = build_plan(desc, ws, plan);
@@ -331,8 +335,10 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     p.g_head_pre = g_head_pre;
     if ((p.open_loop != 0) != (g_head_pre != nullptr)) return GOPS_ERR_BAD_ARG;
     if (p.open_loop && in.head_pre == nullptr) return GOPS_ERR_BAD_ARG;
+    p.ext_delta = ext_delta;   // gops_mlp_backward: the head is a stand-in, its gradient is not formed
+    if (ext_delta != nullptr && desc.env.kind != GOPS_ENV_NONE) return GOPS_ERR_BAD_ARG;
     if (!p.open_loop)
-        for (int j = 0; j < p.pol.nl; ++j)
+        for (int j = 0; j < p.pol.nl - (ext_delta != nullptr ? 1 : 0); ++j)
             if (grad.weight[j] == nullptr || grad.bias[j] == nullptr) return GOPS_ERR_BAD_ARG;
     hipError_t e;
     static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
@@ -372,7 +378,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
         reduce_jobs_add(jobs, plan.dw_part[j], d.splits, N, K, Kp, grad.weight[j]);
         reduce_jobs_add(jobs, plan.dw_part_b[j], d.splits, 1, N, N, grad.bias[j]);
     }
-    {
+    if (ext_delta == nullptr) {
         const int K = p.pol.dims[L], A = p.pol.dims[p.pol.nl];
         long long splits = DW_OUT_SPLITS;
         if (splits > S) splits = S;
@@ -399,9 +405,118 @@ GopsRolloutDesc value_desc(const GopsMlp& value, int batch) {
     return d;
 }
 
+// ---- gops_mlp_*: hidden stack on the GOPS_ENV_NONE tiles + an output layer of any width ------------------------
+struct MlpPlan {
+    GopsRolloutDesc d;        // hidden stack with a 1-wide stand-in head (zero weights in the workspace)
+    size_t inner = 0;         // bytes of the rollout workspace at the front
+    float* zeros = nullptr;   // [K + 1] stand-in head weight + bias
+    float* v = nullptr;       // [B] stand-in output
+    float* gv = nullptr;      // [B] zeros: grad of the stand-in output
+    float* gh = nullptr;      // [S][K] adjoint of the last hidden activation
+    float* gyp = nullptr;     // [S][Wp] zero-padded copy of grad_y (delta operand of the output layer's dW GEMM)
+    float* part = nullptr;    // split-K slabs of the output layer [splits][Wp][K]
+    float* part_b = nullptr;  // [splits][Wp]
+    int K = 0, W = 0, Wp = 0;
+    long long S = 0;
+    size_t bytes = 0;
+};
+
+int plan_mlp(const GopsMlp& mlp, int batch, void* ws, MlpPlan& m) {
+    if (mlp.n_layers < 2 || mlp.n_layers > GOPS_MAX_LAYERS || batch < 1) return GOPS_ERR_BAD_ARG;
+    if (mlp.dtype != GOPS_DTYPE_F32) return GOPS_ERR_UNSUPPORTED;
+    m.W = mlp.sizes[mlp.n_layers];
+    m.K = mlp.sizes[mlp.n_layers - 1];
+    if (m.W < 1 || m.W > 4096 || (m.K & 15)) return GOPS_ERR_UNSUPPORTED;
+    m.Wp = pad16(m.W);
+    m.S = (long long)((batch + TB - 1) / TB) * TB;
+    GopsMlp hidden = mlp;
+    hidden.sizes[mlp.n_layers] = 1;
+    m.d = value_desc(hidden, batch);
+    Plan inner;
+    // the stand-in head pointers only have to be non-null for the size query
+    m.d.policy.weight[mlp.n_layers - 1] = reinterpret_cast<const float*>(&m);
+    m.d.policy.bias[mlp.n_layers - 1] = reinterpret_cast<const float*>(&m);
+    int rc = build_plan(m.d, nullptr, inner);
+    if (rc != GOPS_OK) return rc;
+    m.inner = (inner.bytes + kAlign - 1) / kAlign * kAlign;
+    Carver c(ws ? static_cast<char*>(ws) + m.inner : nullptr);
+    m.zeros = c.take((size_t)m.K + 16);
+    m.v = c.take((size_t)batch);
+    m.gv = c.take((size_t)batch);
+    m.gh = c.take((size_t)m.S * m.K);
+    m.gyp = c.take((size_t)m.S * m.Wp);
+    const DwPlan d = plan_dw(m.Wp, m.K, m.S);
+    m.part = c.take((size_t)d.splits * m.Wp * m.K);
+    m.part_b = c.take((size_t)d.splits * m.Wp);
+    m.bytes = m.inner + c.off + kAlign;
+    m.d.policy.weight[mlp.n_layers - 1] = m.zeros;
+    m.d.policy.bias[mlp.n_layers - 1] = m.zeros ? m.zeros + m.K : nullptr;
+    return GOPS_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t gops_mlp_workspace_bytes(const GopsMlp* mlp, int32_t batch) {
+    if (!mlp) return 0;
+    MlpPlan m;
+    return plan_mlp(*mlp, batch, nullptr, m) == GOPS_OK ? m.bytes : 0;
+}
+
+int gops_mlp_forward(const GopsMlp* mlp, int32_t batch, const float* x, float* y, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+    if (!mlp || !x || !y) return GOPS_ERR_BAD_ARG;
+    MlpPlan m;
+    int rc = plan_mlp(*mlp, batch, workspace, m);
+    if (rc != GOPS_OK) return rc;
+    if (workspace == nullptr || workspace_bytes < m.bytes) return GOPS_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(m.zeros, 0, ((size_t)m.K + 16) * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    GopsRolloutIn in;
+    memset(&in, 0, sizeof(in));
+    in.obs = x;
+    GopsRolloutOut out;
+    memset(&out, 0, sizeof(out));
+    out.v_pi = m.v;
+    if ((rc = run_forward(m.d, in, out, workspace, m.inner, s)) != GOPS_OK) return rc;   // stashes the hidden activations
+    Plan inner;
+    build_plan(m.d, workspace, inner);
+    const int L = mlp->n_layers - 1;
+    return (int)launch_linear_out_fwd(inner.p.st.h[L], m.K, mlp->weight[L], mlp->bias[L], m.W, batch, y, s);
+}
+
+int gops_mlp_backward(const GopsMlp* mlp, int32_t batch, const float* x, const float* grad_y, const GopsMlpGrad* grad,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!mlp || !x || !grad_y || !grad) return GOPS_ERR_BAD_ARG;
+    MlpPlan m;
+    int rc = plan_mlp(*mlp, batch, workspace, m);
+    if (rc != GOPS_OK) return rc;
+    if (workspace == nullptr || workspace_bytes < m.bytes) return GOPS_ERR_WORKSPACE;
+    const int L = mlp->n_layers - 1;
+    if (!grad->weight[L] || !grad->bias[L]) return GOPS_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    if ((e = hipMemsetAsync(m.gv, 0, (size_t)batch * sizeof(float), s)) != hipSuccess) return (int)e;
+    // output layer: g_h = g_y Wo (+ padded copy of g_y), dWo = g_y^T h and db = column sums through the regular dW GEMM
+    if ((e = launch_linear_out_bwd(grad_y, m.W, m.Wp, mlp->weight[L], m.K, batch, m.S, m.gh, m.gyp, s)) != hipSuccess) return (int)e;
+    Plan inner;
+    build_plan(m.d, workspace, inner);
+    const DwPlan d = plan_dw(m.Wp, m.K, m.S);
+    if ((e = launch_dw_gemm(m.gyp, m.Wp, inner.p.st.h[L], m.K, m.S, d.splits, d.chunks_per_split, m.part, m.part_b, d.big, s)) != hipSuccess)
+        return (int)e;
+    ReduceJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    reduce_jobs_add(jobs, m.part, d.splits, m.W, m.K, m.K, grad->weight[L], m.Wp);
+    reduce_jobs_add(jobs, m.part_b, d.splits, 1, m.W, m.Wp, grad->bias[L]);
+    if ((e = launch_reduce(jobs, s)) != hipSuccess) return (int)e;
+    // hidden stack: the sweep starts from g_h instead of a head
+    GopsRolloutIn in;
+    memset(&in, 0, sizeof(in));
+    in.obs = x;
+    return run_backward(m.d, in, m.gv, *grad, nullptr, workspace, m.inner, s, m.gh);
+}
 
 int gops_hip_version(void) { return GOPS_HIP_ABI_VERSION; }
 

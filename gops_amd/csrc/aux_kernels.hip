@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     if (valid) {
         const int r = idx / cols, c = idx - r * cols;
-        const size_t stride = (size_t)rows * ld;
+        const size_t stride = (size_t)jobs.slab_rows[j] * ld;
         const float* p = part + (size_t)r * ld + c;
         int s = sl;
         // 8 independent loads in flight per thread (the kernel is latency-bound: one 256-byte row segment per wave and
@@ -814,10 +814,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
     }
 }
 
-void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, int cols, int ld, float* out) {
+void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, int cols, int ld, float* out, int slab_rows) {
     const int i = jobs.n++;
     jobs.part[i] = part; jobs.out[i] = out;
     jobs.splits[i] = splits; jobs.rows[i] = rows; jobs.cols[i] = cols; jobs.ld[i] = ld;
+    jobs.slab_rows[i] = slab_rows > 0 ? slab_rows : rows;
     if (i == 0) jobs.block0[0] = 0;
     jobs.block0[i + 1] = jobs.block0[i] + (rows * cols + 63) / 64;
 }
@@ -825,6 +826,68 @@ void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, 
 hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s) {
     if (jobs.n == 0) return hipSuccess;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(jobs.block0[jobs.n]), dim3(256), 0, s, jobs);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Output layer of ANY width W (gops_mlp_forward / _backward: FiniteHorizonFullPolicy emits act_dim * pre_horizon
+// values): y = h Wo^T + b over the stashed last hidden activation h [S][K] (tile-major rows == batch rows for H = 1),
+// and its input adjoint g_h = g_y Wo together with a zero-padded copy g_yp [S][Wp] of g_y that the regular dW GEMM
+// takes as its delta operand.  63 MFLOP at B = 4096, W = 60: plain VALU, 16 rows per block staged in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_out_fwd_kernel(const float* __restrict__ h, int K, const float* __restrict__ Wo,
+                                                             const float* __restrict__ bo, int W, int B, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float hs[];   // [16][K]
+    const int b0 = blockIdx.x * 16, rows = min(16, B - b0);
+    for (int i = threadIdx.x; i < 16 * (K >> 2); i += 256) {
+        const int m = i / (K >> 2), c = i - m * (K >> 2);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        reinterpret_cast<f32x4*>(hs)[i] = (m < rows) ? reinterpret_cast<const f32x4*>(h + (size_t)(b0 + m) * K)[c] : z;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 16 * W; o += 256) {   // o = m * W + w: consecutive threads -> consecutive y elements
+        const int m = o / W, w = o - m * W;
+        if (m >= rows) continue;
+        const f32x4* wr = reinterpret_cast<const f32x4*>(Wo + (size_t)w * K);
+        const f32x4* hr = reinterpret_cast<const f32x4*>(hs + m * K);
+        float acc = 0.f;
+        for (int c = 0; c < (K >> 2); ++c) {
+            const f32x4 a = hr[c], bq = wr[c];
+            acc += a[0] * bq[0] + a[1] * bq[1] + a[2] * bq[2] + a[3] * bq[3];
+        }
+        y[(size_t)(b0 + m) * W + w] = acc + bo[w];
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_out_bwd_kernel(const float* __restrict__ gy, int W, int Wp, const float* __restrict__ Wo,
+                                                             int K, int B, long long S, float* __restrict__ gh, float* __restrict__ gyp) {
+    extern __shared__ __attribute__((aligned(16))) float gs[];   // [16][Wp]
+    const long long s0 = (long long)blockIdx.x * 16;
+    for (int i = threadIdx.x; i < 16 * Wp; i += 256) {
+        const int m = i / Wp, w = i - m * Wp;
+        const float v = (s0 + m < B && w < W) ? gy[(size_t)(s0 + m) * W + w] : 0.f;
+        gs[i] = v;
+        if (s0 + m < S) gyp[(size_t)(s0 + m) * Wp + w] = v;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 16 * K; o += 256) {   // o = m * K + k: coalesced reads of Wo rows and writes of g_h
+        const int m = o / K, k = o - m * K;
+        if (s0 + m >= S) continue;
+        float acc = 0.f;
+        for (int w = 0; w < W; ++w) acc += gs[m * Wp + w] * Wo[(size_t)w * K + k];
+        gh[(size_t)(s0 + m) * K + k] = acc;
+    }
+}
+
+hipError_t launch_linear_out_fwd(const float* h, int K, const float* Wo, const float* bo, int W, int B, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(linear_out_fwd_kernel, dim3((B + 15) / 16), dim3(256), 16 * K * sizeof(float), s, h, K, Wo, bo, W, B, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_linear_out_bwd(const float* gy, int W, int Wp, const float* Wo, int K, int B, long long S, float* gh,
+                                 float* gyp, hipStream_t s) {
+    hipLaunchKernelGGL(linear_out_bwd_kernel, dim3((unsigned)((S + 15) / 16)), dim3(256), 16 * Wp * sizeof(float), s, gy, W, Wp, Wo,
+                       K, B, S, gh, gyp);
     return hipGetLastError();
 }
 

@@ -68,6 +68,8 @@ struct RolloutParams {
     const float* grad_v;              // backward only
     int open_loop;                    // 1: head outputs come from in.head_pre, the MLP phases are skipped
     float* g_head_pre;                // open-loop backward: d(loss)/d(head_pre) [B][H][A]
+    const float* ext_delta;           // gops_mlp_backward (GOPS_ENV_NONE): adjoint of the LAST hidden activation [S][dims[L]],
+                                      // taken instead of the head's (delta_y W_o) product; the head then has no gradient
     const float* ref_table;           // veh: [B][P+1+H][4]
     const f32x4* surr_table;          // GOPS_ENV_VEH3DOF_SURR: [B][H+1][n_surr] (x, y, phi, u) of every surrounding vehicle after t steps
     unsigned long long* dbg;          // debug: per-phase cycle counters of block 0 (GOPS_DBG_TIMING)
@@ -114,6 +116,7 @@ struct ReduceJobs {
     const float* part[2 * GOPS_MAX_LAYERS];
     float* out[2 * GOPS_MAX_LAYERS];
     int splits[2 * GOPS_MAX_LAYERS], rows[2 * GOPS_MAX_LAYERS], cols[2 * GOPS_MAX_LAYERS], ld[2 * GOPS_MAX_LAYERS];
+    int slab_rows[2 * GOPS_MAX_LAYERS];    // rows of one split's slab (>= rows: the slab of a padded output layer has more)
     const float* unscale;                  // f16: device pointer to max|grad_v| (RolloutParams::gscale), else null
 };
 

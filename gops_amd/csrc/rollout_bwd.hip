@@ -25,7 +25,7 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
                                              float* const* stash_d, float* stash_dy, size_t row0,
                                              int nvalid, bool want_gx, int ncols, DbgClock& dbg,
                                              Hook&& after_head, const float* stage_head = nullptr,
-                                             const float* stage_h1 = nullptr) {
+                                             const float* stage_h1 = nullptr, const float* ext_delta = nullptr) {
     // stage_head / stage_h1: LDS copies (direct global->LDS loads issued at the top of the step) of the
     // tiles the head / the layer-1 epilogue take act' from: [TB][K] row-major, and [wave][TB][64]
     // (each wave's own 64 columns) - each wave reads only what its own lanes fetched.
@@ -48,9 +48,18 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
                     f32x4 hv = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (STAGED) hv = *reinterpret_cast<const f32x4*>(stage_head + hm * K + k);
                     else if (hm < nvalid) hv = ld4((ACT == GOPS_ACT_GELU ? zrow : hrow) + k);
+                    bool from_head = true;
+                    if constexpr (!STAGED) {   // gops_mlp_backward: the adjoint of this activation comes from the wide output layer
+                        if (ext_delta != nullptr) {
+                            from_head = false;
+                            if (hm < nvalid) acc = ld4(gptr(ext_delta) + (row0 + hm) * K + k);
+                        }
+                    }
+                    if (from_head) {
 #pragma unroll
-                    for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                        if (a < A) acc += gy[a] * ld4(Wo + a * ldw + k);
+                        for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                            if (a < A) acc += gy[a] * ld4(Wo + a * ldw + k);
+                    }
                     f32x4 dv;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dv[e] = (hm < nvalid) ? acc[e] * act_bwd_t<ACT>(hv[e], hv[e]) : 0.f;
@@ -62,9 +71,13 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
             } else {
                 for (int k = hp; k < K; k += 16) {
                     float acc = 0.f;
+                    if (!STAGED && ext_delta != nullptr) {
+                        if (hm < nvalid) acc = gptr(ext_delta)[(row0 + hm) * K + k];
+                    } else {
 #pragma unroll
-                    for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                        if (a < A) acc += gy[a] * Wo[a * ldw + k];
+                        for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                            if (a < A) acc += gy[a] * Wo[a * ldw + k];
+                    }
                     float dv = 0.f;
                     if (hm < nvalid) {
                         const float v = (ACT == GOPS_ACT_GELU ? zrow : hrow)[k];
@@ -568,7 +581,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_bwd_kernel(cons
                                tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, [] {});
             else
             mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
-                         nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up, st_cur, st_cur + TB * 256);
+                         nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up, st_cur, st_cur + TB * 256,
+                         ENV == GOPS_ENV_NONE ? p.ext_delta : nullptr);
         } else if (tid < nvalid) {   // open loop: the head adjoint IS the result; no policy input adjoint
             GLOBAL_AS float* gp = gptr(p.g_head_pre) + ((size_t)(b0 + tid) * p.H + t) * A;
 #pragma unroll

@@ -124,6 +124,13 @@ def lib() -> C.CDLL:
         l.gops_value_backward.restype = C.c_int
         l.gops_value_backward.argtypes = [C.POINTER(GopsMlp), C.c_int32, C.c_void_p, C.c_void_p,
                                           C.POINTER(GopsMlpGrad), C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gops_mlp_workspace_bytes.restype = C.c_size_t
+        l.gops_mlp_workspace_bytes.argtypes = [C.POINTER(GopsMlp), C.c_int32]
+        l.gops_mlp_forward.restype = C.c_int
+        l.gops_mlp_forward.argtypes = [C.POINTER(GopsMlp), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gops_mlp_backward.restype = C.c_int
+        l.gops_mlp_backward.argtypes = [C.POINTER(GopsMlp), C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(GopsMlpGrad),
+                                        C.c_void_p, C.c_size_t, C.c_void_p]
         l.gops_adam_step.restype = C.c_int
         l.gops_adam_step.argtypes = [C.POINTER(GopsAdamTensors), C.c_void_p, C.c_double, C.c_double, C.c_double,
                                      C.c_void_p]
@@ -137,7 +144,8 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = ("gops_hip_version", "gops_rollout_workspace_bytes", "gops_rollout_forward",
                     "gops_rollout_backward", "gops_rollout_backward_open_loop", "gops_env_step", "gops_value_workspace_bytes",
-                    "gops_value_forward", "gops_value_backward", "gops_adam_step", "gops_profile_enable",
+                    "gops_value_forward", "gops_value_backward", "gops_mlp_workspace_bytes", "gops_mlp_forward",
+                    "gops_mlp_backward", "gops_adam_step", "gops_profile_enable",
                     "gops_profile_reset", "gops_profile_read")
 
 _ERR = {-1: "GOPS_ERR_BAD_ARG", -2: "GOPS_ERR_UNSUPPORTED", -3: "GOPS_ERR_WORKSPACE"}
@@ -361,6 +369,31 @@ class ValueNet:
         check(lib().gops_value_backward(C.byref(self.mlp), self.batch, _ptr(obs), _ptr(grad_v), C.byref(g),
                                         self.workspace.data_ptr(), self.workspace.numel(), _stream()),
               "gops_value_backward")
+
+
+class MlpNet:
+    """Batch evaluation of an MLP with an output layer of any width and its backward into the parameters
+    (`gops_mlp_forward / _backward`): FiniteHorizonFullPolicy's single evaluation in FHADP2."""
+
+    def __init__(self, mlp: GopsMlp, batch: int, device: Optional[torch.device] = None):
+        self.mlp, self.batch = mlp, batch
+        self.out_dim = int(mlp.sizes[mlp.n_layers])
+        nbytes = lib().gops_mlp_workspace_bytes(C.byref(mlp), batch)
+        if nbytes == 0:
+            raise RuntimeError("gops_mlp_workspace_bytes: unsupported network for the HIP path")
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = torch.empty(self.batch, self.out_dim, dtype=torch.float32, device=self.device)
+        check(lib().gops_mlp_forward(C.byref(self.mlp), self.batch, _ptr(x), _ptr(y), self.workspace.data_ptr(),
+                                     self.workspace.numel(), _stream()), "gops_mlp_forward")
+        return y
+
+    def backward(self, x: torch.Tensor, grad_y: torch.Tensor, grad_w, grad_b):
+        g = make_mlp_grad(grad_w, grad_b)
+        check(lib().gops_mlp_backward(C.byref(self.mlp), self.batch, _ptr(x), _ptr(grad_y), C.byref(g),
+                                      self.workspace.data_ptr(), self.workspace.numel(), _stream()), "gops_mlp_backward")
 
 
 def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Tensor]] = None):

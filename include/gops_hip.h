@@ -230,6 +230,17 @@ int gops_value_backward(const GopsMlp* value, int32_t batch, const float* obs, c
                         const GopsMlpGrad* grad, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* Batch evaluation of an MLP whose output layer has ANY width, and its backward into the parameters:
+ * FiniteHorizonFullPolicy.pi (gops/apprfunc/mlp.py:114-145: obs -> hidden ... -> act_dim * pre_horizon, the single
+ * evaluation of FHADP2, gops/algorithm/fhadp2.py:100-104) and `pre.backward(grad)` (:89).  y, grad_y: [batch, sizes[n_layers]]
+ * row-major.  The hidden stack runs on the rollout kernels (GOPS_ENV_NONE tiles), the output layer on its own kernels;
+ * mlp->dtype must be GOPS_DTYPE_F32. */
+size_t gops_mlp_workspace_bytes(const GopsMlp* mlp, int32_t batch);
+int gops_mlp_forward(const GopsMlp* mlp, int32_t batch, const float* x, float* y, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int gops_mlp_backward(const GopsMlp* mlp, int32_t batch, const float* x, const float* grad_y,
+                      const GopsMlpGrad* grad, void* workspace, size_t workspace_bytes, void* stream);
+
 /* One Adam step (torch.optim.Adam defaults semantics: no weight decay, no amsgrad) over up to
  * GOPS_ADAM_MAX_TENSORS parameter tensors in ONE launch - replaces `self.networks.policy_optimizer.step()`
  * (gops/algorithm/fhadp.py:89, gops/algorithm/infadp.py:124).  The learning rate and the step count

@@ -446,3 +446,33 @@ def test_opt_controller_solves_lq_regulation():
         x = nobs[0].cpu().numpy()
         norms.append(float(np.linalg.norm(x)))
     assert norms[-1] < 0.8 * norms[0] and all(b < a + 1e-6 for a, b in zip(norms, norms[1:])), norms   # 2.5 s of a slow plant
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [dict(B=100, sizes=[10, 64, 64, 20], act="gelu"), dict(B=4096, sizes=[46, 256, 256, 60], act="elu"),
+                                  dict(B=17, sizes=[6, 32, 7], act="tanh"), dict(B=1, sizes=[4, 16, 48, 32, 130], act="relu")],
+                         ids=lambda c: f"B{c['B']}-{'x'.join(map(str, c['sizes']))}-{c['act']}")
+def test_wide_output_mlp_matches_torch(case):
+    """gops_mlp_forward / _backward (FiniteHorizonFullPolicy's evaluation in FHADP2: output width = act_dim * H, odd
+    widths, ragged batches) against torch fp32 autograd: outputs and every parameter gradient at 1e-4 / 1e-5."""
+    from gops_amd import hip_backend as hb
+    from oracle import adp_oracle as orc
+    torch.manual_seed(3)
+    sizes, B = case["sizes"], case["B"]
+    lin = [torch.nn.Linear(a, b) for a, b in zip(sizes[:-1], sizes[1:])]
+    ws = [l.weight.detach().cuda().contiguous() for l in lin]
+    bs = [l.bias.detach().cuda().contiguous() for l in lin]
+    x = torch.randn(B, sizes[0])
+    gy = torch.randn(B, sizes[-1])
+    net = hb.MlpNet(hb.make_mlp(ws, bs, case["act"]), B)
+    y = net.forward(x.cuda())
+    gw, gb = [torch.empty_like(w) for w in ws], [torch.empty_like(b) for b in bs]
+    net.backward(x.cuda(), gy.cuda().contiguous(), gw, gb)
+    torch.cuda.synchronize()
+    wr = [l.weight.detach().clone().requires_grad_(True) for l in lin]
+    br = [l.bias.detach().clone().requires_grad_(True) for l in lin]
+    yr = orc.mlp_forward(wr, br, x, case["act"])
+    grads = torch.autograd.grad(yr, wr + br, grad_outputs=gy)
+    assert rel_l2(y.cpu(), yr.detach()) < 1e-5
+    for got, want in zip(gw + gb, grads):
+        assert rel_l2(got.cpu(), want) < 1e-4, (case, tuple(want.shape), rel_l2(got.cpu(), want))

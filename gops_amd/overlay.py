@@ -36,6 +36,7 @@ OVERLAY = {
     "gops.trainer.on_sync_trainer": "gops_amd.trainer.on_sync_trainer",
     "gops.trainer.off_serial_trainer": "gops_amd.trainer.off_serial_trainer",
     "gops.trainer.off_sync_trainer": "gops_amd.trainer.off_sync_trainer",
+    "gops.trainer.off_async_trainer": "gops_amd.trainer.off_async_trainer",
     "gops.trainer.buffer.replay_buffer": "gops_amd.trainer.buffer.replay_buffer",
 }
 

@@ -66,7 +66,8 @@ def test_registries_and_error_behaviour():
     assert {"mlp_DetermPolicy", "mlp_FiniteHorizonPolicy", "mlp_StateValue"} <= set(create_apprfunc.registry)
     assert {"pyth_lq_model", "pyth_idpendulum_model", "pyth_veh3dofconti_model", "pyth_veh3dofconti_surrcstr_model",
             "pyth_veh3dofconti_detour_model"} <= set(create_env_model.registry)
-    assert {"on_serial_trainer", "on_sync_trainer", "off_serial_trainer", "off_sync_trainer"} <= set(create_trainer.registry)
+    assert {"on_serial_trainer", "on_sync_trainer", "off_serial_trainer", "off_sync_trainer",
+            "off_async_trainer"} <= set(create_trainer.registry)
     with pytest.raises(KeyError, match="No registered algorithm with id"):
         create_alg.create_alg(algorithm="NOPE")
     with pytest.raises(KeyError, match="No registered env with id"):
@@ -567,3 +568,78 @@ def test_replay_buffer_matches_reference_buffer_side_by_side(name):
     assert set(s) == set(a.buf) and all(v.dtype == torch.float32 and v.shape[0] == 16 for v in s.values())
     stored = {tuple(r.tolist()) for r in a.buf["obs"]}
     assert all(tuple(r.tolist()) in stored for r in s["obs"])
+
+
+_ASYNC_WORKER = r"""
+import os, sys, time, torch, torch.distributed as dist, numpy as np
+sys.path.insert(0, sys.argv[1])
+from gops_amd.trainer.off_async_trainer import OffAsyncTrainer
+from gops_amd.trainer.buffer.replay_buffer import ReplayBuffer
+dist.init_process_group("gloo")
+r, n = dist.get_rank(), dist.get_world_size()
+
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(7 + r)                         # different init per rank: the trainer must broadcast rank 0's
+        self.policy = torch.nn.Linear(3, 2)
+
+class Alg:   # FHADP-shaped update API; the gradient of rank r is the constant r + 1 (so the center's weights tell who was applied)
+    accepts_grad_scale = True
+    def __init__(self):
+        self.networks = Net()
+        self.tb_info = {}
+        self.seen_weights = []
+    def get_remote_update_info(self, data, it):
+        self.seen_weights.append(self.networks.policy.weight.detach().clone())
+        time.sleep(0.015 if r == 1 else 0.005)           # gradients take time; a slow worker must not hold the others back
+        return self.tb_info, {"grad": [torch.full_like(p, float(r + 1)) for p in self.networks.policy.parameters()]}
+    def remote_update(self, info):
+        with torch.no_grad():
+            for p, g in zip(self.networks.policy.parameters(), info["grad"]):
+                p -= 0.125 * g
+
+class Sampler:
+    networks = None
+    def sample(self):
+        g = np.random.RandomState(r)
+        return [(g.rand(3).astype(np.float32), np.zeros(1, np.float32), 0.0, False, {}, g.rand(3).astype(np.float32), {}, 0.0)
+                for _ in range(8)], {}
+    def get_total_sample_number(self): return 0
+
+alg = Alg()
+buf = ReplayBuffer(index=r, trainer="off_async_trainer", seed=1, obsv_dim=3, action_dim=1, buffer_max_size=64,
+                   additional_info={}, buffer_device="cpu")
+tr = OffAsyncTrainer(alg, Sampler(), buf, None, max_iteration=40, log_save_interval=1000, apprfunc_save_interval=1000,
+                     eval_interval=10 ** 9, save_folder=None, ini_network_dir=None, use_gpu=False, buffer_warm_size=16,
+                     replay_batch_size=8, sample_interval=2)
+w0 = alg.networks.policy.weight.detach().clone()
+tr.train()
+final = alg.networks.policy.weight.detach().clone()
+if r == 0:
+    assert tr.iteration == 40 and sum(tr.applied_from) == 40, (tr.iteration, tr.applied_from)
+    assert all(c > 0 for c in tr.applied_from), tr.applied_from      # every rank contributed, nobody was starved
+    expect = w0 - 0.125 * sum((k + 1) * c for k, c in enumerate(tr.applied_from))
+    assert torch.allclose(final, expect, atol=1e-5), (final, expect, tr.applied_from)
+else:
+    # a worker computed each gradient on weights it RECEIVED from the center (stale by at most its own round trip)
+    assert len(alg.seen_weights) >= 1 and tr._stop
+gathered = [torch.zeros_like(final) for _ in range(n)]
+dist.all_gather(gathered, final)
+assert all(torch.equal(g, gathered[0]) for g in gathered), "workers must end on the center's final weights"
+dist.destroy_process_group()
+open(os.path.join(sys.argv[2], f"ok_{r}"), "w").write("ok")
+"""
+
+
+def test_off_async_trainer_applies_gradients_in_arrival_order_world_size_3(tmp_path):
+    """Center network on rank 0 + two workers (gloo): 40 applied gradients, every rank contributes, the center's weights are
+    exactly w0 - lr * sum of the applied per-rank gradients, and every rank ends on the center's final weights."""
+    script = tmp_path / "worker.py"
+    script.write_text(_ASYNC_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+                          "--master-addr", "127.0.0.1", "--master-port", "29683", str(script), ROOT, str(tmp_path)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert all((tmp_path / f"ok_{k}").exists() for k in range(3))

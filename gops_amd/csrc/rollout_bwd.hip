@@ -173,7 +173,7 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
 // (gscale[0]) that the reduce kernel takes out of the parameter gradients again.
 // (F16 kernels: 4 workgroups per CU - launch bound 4 waves / SIMD, <= 128 registers.)
 template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false>
-__global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
+__global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1)) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;
     const int tid = threadIdx.x;

@@ -119,7 +119,7 @@ __device__ __forceinline__ void mlp_head(WP Wo, int ldw, BP bo, int K, int A, co
 // activation stash is half precision; everything else in the step is the same fp32 code.
 // (F16 kernels: 4 workgroups per CU - launch bound 4 waves / SIMD, <= 128 registers.)
 template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false>
-__global__ __launch_bounds__(NTHREADS, F16 ? 4 : 1) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
+__global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1)) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;   // parameters live in device memory: uniform scalar loads
     const int tid = threadIdx.x;

@@ -184,6 +184,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     if (e.kind == GOPS_ENV_VEH3DOF_SURR &&
         (e.act_dim != 2 || e.pre_horizon < 1 || e.n_surr < 1 || e.n_surr > GOPS_MAX_SURR ||
          (e.n_constraint != 1 && e.n_constraint != 3) || e.obs_dim != 6 + 4 * e.pre_horizon + 4 * e.n_surr || e.clip_obs ||
+         (e.surr_penalty && (e.n_surr != 1 || e.n_constraint != 1)) ||
          desc.open_loop || desc.dtype != GOPS_DTYPE_F32))
         return GOPS_ERR_BAD_ARG;
     if (e.clip_obs && e.obs_dim > 8) return GOPS_ERR_UNSUPPORTED;

@@ -991,6 +991,16 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         sincosf(s[2], &w.sphi, &w.cphi);
         veh_f_xu(VC, s, u[0], u[1], sn, w);
         r = surr ? veh_reward_w(env.reward_w, o6, u[0], u[1]) : veh_reward(o6, u[0], u[1]);
+        float pen_c = 0.f;
+        if (surr && env.surr_penalty) {   // collision penalty on the current pose / current surrounding vehicle
+            const float* s5 = io.surr_state + (size_t)b * env.n_surr * 5;
+            const f32x4 cur = {s5[0], s5[1], s5[2], s5[3]};
+            SurrCstr sc0;
+            surr_constraint<false>(env, s[0], s[1], w.sphi, w.cphi, &cur, sc0);
+            float dummy;
+            pen_c = sc0.c[0];
+            r -= surr_penalty(pen_c, dummy);
+        }
         const float nt = RADD(io.ref_time[b], 0.1f);
         const float pn = io.path_num[b], un = io.u_num[b];
         const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : 3;
@@ -1027,14 +1037,22 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
                 d5[0] = pts[i][0]; d5[1] = pts[i][1]; d5[2] = pts[i][2]; d5[3] = pts[i][3]; d5[4] = s5[4];
                 if (!dn) {
                     float* d = nob + 6 + 4 * P + 4 * i;
-                    d[0] = pts[i][0] - sn[0]; d[1] = pts[i][1] - sn[1]; d[2] = pts[i][2] - sn[2]; d[3] = pts[i][3] - sn[3];
+                    if (env.surr_penalty) {   // ego frame of the CURRENT state
+                        const float dx = pts[i][0] - s[0], dy = pts[i][1] - s[1];
+                        d[0] = dx * w.cphi + dy * w.sphi; d[1] = -dx * w.sphi + dy * w.cphi;
+                        d[2] = angle_normalize(pts[i][2] - s[2]); d[3] = pts[i][3] - s[3];
+                    } else {
+                        d[0] = pts[i][0] - sn[0]; d[1] = pts[i][1] - sn[1]; d[2] = pts[i][2] - sn[2]; d[3] = pts[i][3] - sn[3];
+                    }
                 }
             }
             SurrCstr sc;
             float sp, cp;
             sincosf(sn[2], &sp, &cp);
             surr_constraint<false>(env, sn[0], sn[1], sp, cp, pts, sc);
+            if (env.surr_penalty) sc.c[0] = pen_c;   // info["constraint"] is filled before the info dict is updated (:131-139)
             for (int k = 0; k < env.n_constraint; ++k) io.constraint[(size_t)b * env.n_constraint + k] = sc.c[k];
+            if (env.surr_penalty) done_m = false;
         }
         if (dn) for (int i = 0; i < O; ++i) nob[i] = ob[i];
         for (int i = 0; i < 6; ++i) io.next_state[(size_t)b * 6 + i] = sn[i];

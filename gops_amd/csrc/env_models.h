@@ -299,5 +299,14 @@ __device__ __forceinline__ void surr_constraint(const GopsEnv& e, float x, float
 
 __device__ __forceinline__ float veh_reward_w(const float* w, const float* o, float steer, float ax) {
     return -(w[0] * (o[0] * o[0]) + w[1] * (o[1] * o[1]) + w[2] * (o[2] * o[2]) + w[3] * (o[3] * o[3]) +
-             w[4] * (o[5] * o[5]) + w[5] * (steer * steer) + w[6] * (ax * ax));
+             w[4] * (o[5] * o[5]) + w[5] * (steer * steer) + w[6] * (ax * ax) + w[7] * (o[4] * o[4]));
+}
+
+// Collision penalty of pyth_veh3dofconti_surrcstr_penalty_model.py:145-160 as a function of the constraint value
+// c = 2 r - min distance (dis = -c):  pen = 15 (tanh(max(8 + 16 c, 0) - 4) + 1), and d pen / d c.
+__device__ __forceinline__ float surr_penalty(float c, float& dpen_dc) {
+    const float z = fmaxf(8.f + 16.f * c, 0.f);          // 8 - 8 dis / 0.5
+    const float th = tanhf(z - 4.f);
+    dpen_dc = (z > 0.f) ? 15.f * (1.f - th * th) * 16.f : 0.f;
+    return 15.f * (th + 1.f);
 }

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                         // adjoint of the (unmasked) constraint sums w.r.t. the new ego pose
                         SurrCstr sc;
                         surr_constraint<true>(p.env, sn[0], sn[1], e3[2], e3[3], pts, sc);
-                        for (int k = 0; k < p.env.n_constraint; ++k) {
+                        for (int k = 0; k < (p.env.surr_penalty ? 0 : p.env.n_constraint); ++k) {
                             const float c = sc.c[k];
                             float gck = gc_ext * 2.f * fmaxf(c, 0.f) + (c > 0.f ? gc_lin : 0.f);
                             if (c < 0.f) gck += gc_int * (-1.f / (-c + 1e-8f));
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                             lamn[2] += gck * sc.dphi[k];
                         }
                         // observation columns (x, y, phi, u)_surr - (x, y, phi, u)_ego: MaskAtDone keeps the adjoint on obs_t
-                        if (!dn) {
+                        if (!dn && !p.env.surr_penalty) {
 #pragma unroll
                             for (int i = 0; i < GOPS_MAX_SURR; ++i)
                                 if (i < ns) {
@@ -539,6 +539,36 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 }
                 float g_steer, g_ax;
                 veh_f_xu_bwd(VC, s, steer, w, lamn, lam, g_steer, g_ax);
+                if constexpr (SURR) {
+                    if (p.env.surr_penalty && m < nvalid) {
+                        // surrcstr_penalty: both the appended observation (ego frame of the CURRENT state, NEXT vehicle) and the
+                        // collision penalty in the reward depend on state_t, whose adjoint `lam` is now complete from the step
+                        const GLOBAL_AS f32x4* sp = gptr(p.surr_table) + ((size_t)(b0 + m) * (p.H + 1) + t) * p.env.n_surr;
+                        const f32x4 cur = sp[0], nxt = sp[p.env.n_surr];
+                        const float sphi = e3[0], cphi = e3[1];
+                        if (!dn) {
+                            float* gp = G + m * ldx + 6 + 4 * P;
+                            const float g0 = gp[0], g1 = gp[1], g2 = gp[2], g3 = gp[3];
+                            const float dx = nxt[0] - s[0], dy = nxt[1] - s[1];
+                            // x_tf = dx cos(phi) + dy sin(phi);  y_tf = -dx sin(phi) + dy cos(phi)
+                            lam[0] += -g0 * cphi + g1 * sphi;
+                            lam[1] += -g0 * sphi - g1 * cphi;
+                            lam[2] += g0 * (-dx * sphi + dy * cphi) + g1 * (-dx * cphi - dy * sphi) - g2;
+                            lam[3] -= g3;
+                            gp[0] = gp[1] = gp[2] = gp[3] = 0.f;
+                        }
+                        SurrCstr sc;
+                        surr_constraint<true>(p.env, s[0], s[1], sphi, cphi, &cur, sc);
+                        float dpen;
+                        (void)surr_penalty(sc.c[0], dpen);
+                        // r = ... - pen(c(state_t)), masked like the reward.  info["constraint"] of this model is computed from
+                        // DETACHED copies of the info dict (:129-139): the constraint sums carry no gradient here
+                        const float gpen = (dn ? 0.f : g_r) * (-dpen);
+                        lam[0] += gpen * sc.dx[0];
+                        lam[1] += gpen * sc.dy[0];
+                        lam[2] += gpen * sc.dphi[0];
+                    }
+                }
                 const float g_rm = dn ? 0.f : g_r;
                 if (m < nvalid) {
                     float xr[6];
@@ -557,6 +587,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                         G[m * ldx + 2] += g_rm * (-2.f * rw[2] * xr[2]);
                         G[m * ldx + 3] += g_rm * (-2.f * rw[3] * xr[3]);
                         G[m * ldx + 5] += g_rm * (-2.f * rw[4] * xr[5]);
+                        G[m * ldx + 4] += g_rm * (-2.f * rw[7] * xr[4]);
                     } else {
                         G[m * ldx + 0] += g_rm * (-0.08f * xr[0]);
                         G[m * ldx + 1] += g_rm * (-0.08f * xr[1]);

@@ -324,14 +324,26 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             VehStep w;
             w.sphi = veh_s; w.cphi = veh_c;
             veh_f_xu(VC, s, steer, ax, sn, w);
+            float pen_c = 0.f;   // surrcstr_penalty: constraint of the CURRENT pose
             if (part == 0) {
                 float o[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) o[i] = xs[m * ldx + i];
                 r = SURR ? veh_reward_w(p.env.reward_w, o, steer, ax) : veh_reward(o, steer, ax);
+                if constexpr (SURR) {
+                    if (p.env.surr_penalty && m < nvalid) {   // collision penalty on the CURRENT pose and surrounding vehicle
+                        const f32x4 cur = gptr(p.surr_table)[((size_t)(b0 + m) * (p.H + 1) + t) * p.env.n_surr];
+                        SurrCstr sc;
+                        surr_constraint<false>(p.env, s[0], s[1], veh_s, veh_c, &cur, sc);
+                        float dummy;
+                        pen_c = sc.c[0];
+                        r -= surr_penalty(pen_c, dummy);
+                    }
+                }
             }
             __syncthreads();   // every read of the old obs / state is done
             const float s_old = veh_s, c_old = veh_c;
+            const float s_old_s = s_old, s_old_c = c_old;   // sin / cos of the CURRENT heading (surrcstr_penalty observation)
             sincosf(sn[2], &veh_s, &veh_c);                 // also next step's f_xu heading terms
             if (p.need_grad && tid < TB) {   // 4th quad of the env stash row: the backward sweep reuses both sin / cos pairs
                 const f32x4 e3 = {s_old, c_old, veh_s, veh_c};
@@ -348,6 +360,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 const float utf = rp[3] - sn[3];
                 if (j == 0) {
                     done_m = (fabsf(xtf) > 10.f) || (fabsf(ytf) > 10.f) || (fabsf(ptf) > 3.14159265358979323846f);
+                    if (SURR && p.env.surr_penalty) done_m = false;   // judge_done of the penalty model: never (:236-246)
                     if (dflag == 0.f) {
                         xs[m * ldx + 0] = xtf; xs[m * ldx + 1] = ytf; xs[m * ldx + 2] = ptf;
                         xs[m * ldx + 3] = utf; xs[m * ldx + 4] = sn[4]; xs[m * ldx + 5] = sn[5];
@@ -376,16 +389,27 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                         pts[i] = (i < ns) ? sp[i] : z;
                     }
                     if (dflag == 0.f) {
+                        if (p.env.surr_penalty) {   // NEXT surrounding vehicle in the ego frame of the CURRENT state (:117-125)
+                            float* dst = xs + m * ldx + 6 + 4 * P;
+                            const float dx = pts[0][0] - s[0], dy = pts[0][1] - s[1];
+                            dst[0] = dx * s_old_c - dy * (-s_old_s);
+                            dst[1] = dx * (-s_old_s) + dy * s_old_c;
+                            dst[2] = angle_normalize(pts[0][2] - s[2]);
+                            dst[3] = pts[0][3] - s[3];
+                        } else {
 #pragma unroll
-                        for (int i = 0; i < GOPS_MAX_SURR; ++i)
-                            if (i < ns) {
-                                float* dst = xs + m * ldx + 6 + 4 * P + 4 * i;
-                                dst[0] = pts[i][0] - sn[0]; dst[1] = pts[i][1] - sn[1];
-                                dst[2] = pts[i][2] - sn[2]; dst[3] = pts[i][3] - sn[3];
-                            }
+                            for (int i = 0; i < GOPS_MAX_SURR; ++i)
+                                if (i < ns) {
+                                    float* dst = xs + m * ldx + 6 + 4 * P + 4 * i;
+                                    dst[0] = pts[i][0] - sn[0]; dst[1] = pts[i][1] - sn[1];
+                                    dst[2] = pts[i][2] - sn[2]; dst[3] = pts[i][3] - sn[3];
+                                }
+                        }
                     }
                     SurrCstr sc;
                     surr_constraint<false>(p.env, sn[0], sn[1], veh_s, veh_c, pts, sc);
+                    // the penalty model fills info["constraint"] before its info dict is updated (:131-139): CURRENT pose
+                    if (p.env.surr_penalty) sc.c[0] = pen_c;
                     float e2 = 0.f, e1 = 0.f, lg = 0.f;
                     for (int k = 0; k < p.env.n_constraint; ++k) {
                         const float cp = fmaxf(sc.c[k], 0.f), cm = fminf(sc.c[k], 0.f);

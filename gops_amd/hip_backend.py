@@ -54,8 +54,9 @@ class GopsEnv(C.Structure):
                 ("lq_inv_IA", C.c_float * (MAX_LQ * MAX_LQ)), ("lq_B", C.c_float * (MAX_LQ * MAX_ACT)),
                 ("lq_Q", C.c_float * MAX_LQ), ("lq_R", C.c_float * MAX_ACT),
                 ("lq_dt", C.c_float), ("lq_reward_scale", C.c_float), ("lq_reward_shift", C.c_float),
-                ("no_mask_at_done", C.c_int32), ("n_surr", C.c_int32), ("n_constraint", C.c_int32), ("veh_length", C.c_float), ("veh_width", C.c_float),
-                ("road_upper", C.c_float), ("road_lower", C.c_float), ("reward_w", C.c_float * 7),
+                ("no_mask_at_done", C.c_int32), ("n_surr", C.c_int32), ("n_constraint", C.c_int32), ("surr_penalty", C.c_int32),
+                ("veh_length", C.c_float), ("veh_width", C.c_float),
+                ("road_upper", C.c_float), ("road_lower", C.c_float), ("reward_w", C.c_float * 8),
                 ("data_env", C.c_int32)]
 
 
@@ -210,7 +211,8 @@ def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_ac
         e.n_surr, e.n_constraint = int(surr["n_surr"]), int(surr["n_constraint"])
         e.veh_length, e.veh_width = float(surr["veh_length"]), float(surr["veh_width"])
         e.road_upper, e.road_lower = float(surr.get("road_upper", 0.0)), float(surr.get("road_lower", 0.0))
-        _fill(e.reward_w, surr["reward_w"])
+        e.surr_penalty = int(bool(surr.get("penalty", False)))
+        _fill(e.reward_w, list(surr["reward_w"]) + [0.0] * (8 - len(surr["reward_w"])))
     e.kind, e.obs_dim, e.act_dim, e.pre_horizon = kind, obs_dim, act_dim, pre_horizon
     A = act_dim
 

@@ -110,7 +110,7 @@ def obs_dim_of(cfg: Dict) -> int:
     return len(_LQ_INIT[cfg.get("lq_config", "s4a2")][0])
 
 
-_SURR_ENVS = {"pyth_veh3dofconti_surrcstr": 4, "pyth_veh3dofconti_detour": 1}   # env id -> default surr_veh_num
+_SURR_ENVS = {"pyth_veh3dofconti_surrcstr": 4, "pyth_veh3dofconti_detour": 1, "pyth_veh3dofconti_surrcstr_penalty": 1}   # env id -> default surr_veh_num
 
 
 def n_surr_of(cfg: Dict) -> int:
@@ -166,6 +166,12 @@ def make_batch(cfg: Dict, seed: int, batch: int = None) -> Dict[str, torch.Tenso
             sdelta = rng.uniform(-0.03, 0.03, size=(B, ns))
             surr = np.stack((sx, sy, sphi, su, sdelta), axis=2).astype(np.float32)
             rel = (surr[..., :4] - state[:, None, :4]).reshape(B, -1)
+            if env_id.endswith("penalty"):   # the penalty model observes its vehicle in the ego frame (:117-125)
+                dx, dy = surr[:, 0, 0] - state[:, 0], surr[:, 0, 1] - state[:, 1]
+                c, sn = np.cos(-state[:, 2]), np.sin(-state[:, 2])
+                dphi = surr[:, 0, 2] - state[:, 2]
+                rel = np.stack((dx * c - dy * sn, dx * sn + dy * c, (dphi + np.pi) % (2 * np.pi) - np.pi,
+                                surr[:, 0, 3] - state[:, 3]), axis=1)
             out["obs"] = np.concatenate((out["obs"], rel), axis=1).astype(np.float32)
             out["surr_state"] = surr
     else:

@@ -118,13 +118,18 @@ typedef struct GopsEnv {
      * (x, y, phi, u)_surr - (x, y, phi, u)_ego per vehicle; constraint[0] = 2 r - min distance between the two ego
      * circles and the two circles of every surrounding vehicle (bicircle model, :98-148); n_constraint = 3 adds the road
      * boundary violations of the detour model (:143-151); the stage reward is
-     * -(w[0] dx^2 + w[1] dy^2 + w[2] dphi^2 + w[3] du^2 + w[4] omega^2 + w[5] steer^2 + w[6] a_x^2). */
+     * -(w[0] dx^2 + w[1] dy^2 + w[2] dphi^2 + w[3] du^2 + w[4] omega^2 + w[5] steer^2 + w[6] a_x^2 + w[7] v^2).
+     * surr_penalty = 1 selects pyth_veh3dofconti_surrcstr_penalty_model.py:74-246 (one surrounding vehicle): the stage
+     * reward also carries the collision penalty -15 (tanh(max(8 - 16 dis, 0) - 4) + 1), dis = min circle distance - 2 r,
+     * evaluated on the CURRENT state; the appended observation is the NEXT surrounding-vehicle state in the ego frame of
+     * the CURRENT state (x, y, phi rotated, u relative); the model never reports done; info["constraint"] (and the
+     * constraint sums) are those of the CURRENT pose and carry no gradient (the model computes them on detached copies). */
     /* 1: no MaskAtDoneModel in the chain (mask_at_done.py:33-40): the model keeps stepping after its done test fired,
      * rewards are not zeroed (the raw model OptController drives, opt_controller.py:261-265) */
     int32_t no_mask_at_done;
-    int32_t n_surr, n_constraint;
+    int32_t n_surr, n_constraint, surr_penalty;
     float veh_length, veh_width, road_upper, road_lower;
-    float reward_w[7];
+    float reward_w[8];
     /* gops_env_step only (rollouts reject it): 1 = the step of the DATA environment the reference's samplers drive
      * (gops/env/env_ocp/pyth_veh3dofconti.py:195-271, resources/lq_base.py:209-231, pyth_idpendulum.py:71-87) instead
      * of the env MODEL's: same dynamics and stage reward, but the data env's termination tests (veh3dofconti: world-frame

@@ -197,8 +197,17 @@ def perturb_targets(alg, seed):
             p.add_(0.05 * (torch.rand(p.shape, generator=g) - 0.5))
 
 
-def golden_small():
-    for name, (cfg, extra) in SMALL.items():
+# the collision-penalty model trains with plain FHADP (example_train/fhadp/fhadp_mlp_veh3dofconti_surrcstr_penalty_serial.py)
+PENALTY_SMALL = {
+    "fhadp_surrpen_p10_elu": (dict(alg="FHADP", env_id="pyth_veh3dofconti_surrcstr_penalty", batch=48, horizon=10,
+                                   pre_horizon=10, hidden=(64, 64), act="elu", gamma=1.0), {}),
+    "fhadp_surrpen_p25_gelu": (dict(alg="FHADP", env_id="pyth_veh3dofconti_surrcstr_penalty", batch=33, horizon=25,
+                                    pre_horizon=25, hidden=(128, 128), act="gelu", gamma=0.98), {}),
+}
+
+
+def golden_small(cases=None):
+    for name, (cfg, extra) in (SMALL if cases is None else cases).items():
         seed = zlib.crc32(name.encode()) % 1000
         alg = build_alg(cfg, seed, **extra)
         data = make_batch(cfg, seed)
@@ -390,8 +399,18 @@ CSTR_ALG_CASES = {
 }
 
 
-def golden_constrained():
-    for name, cfg in CSTR_STEP_CASES.items():
+PENALTY_STEP_CASES = {"step_veh_surrpen_p10": dict(env_id="pyth_veh3dofconti_surrcstr_penalty", pre_horizon=10)}
+# the penalty model also fills info["constraint"] (with the constraint of the CURRENT pose): the constrained classes run on it
+PENALTY_ALG_CASES = {
+    "fhadp_ext_surrpen": (dict(alg="FHADPExterior", env_id="pyth_veh3dofconti_surrcstr_penalty", batch=40, horizon=10, pre_horizon=10,
+                               hidden=(64, 64), act="elu", gamma=0.99), dict(penalty=3.0)),
+    "fhadp_int_surrpen": (dict(alg="FHADPInterior", env_id="pyth_veh3dofconti_surrcstr_penalty", batch=40, horizon=8, pre_horizon=8,
+                               hidden=(64, 64), act="tanh", gamma=1.0), dict(penalty=1.5)),
+}
+
+
+def golden_constrained(step_cases=None, alg_cases=None):
+    for name, cfg in (CSTR_STEP_CASES if step_cases is None else step_cases).items():
         B, nsteps = 48, 6
         data = make_batch(dict(cfg, batch=B), seed=19)
         model = create_env_model(**cfg)
@@ -413,7 +432,7 @@ def golden_constrained():
         out["meta/nsteps"] = nsteps
         out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra={}))
         save(name, **out)
-    for name, (cfg, extra) in CSTR_ALG_CASES.items():
+    for name, (cfg, extra) in (CSTR_ALG_CASES if alg_cases is None else alg_cases).items():
         seed = zlib.crc32(name.encode()) % 1000
         alg = build_alg(cfg, seed, **extra)
         data = make_batch(cfg, seed)
@@ -505,7 +524,10 @@ def golden_data_envs():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty"]
+    if "penalty" in which:
+        golden_constrained(PENALTY_STEP_CASES, PENALTY_ALG_CASES)
+        golden_small(PENALTY_SMALL)
     if "dataenv" in which:
         golden_data_envs()
     if "constrained" in which:

@@ -77,6 +77,7 @@ def hip_env_from_oracle(env, policy_net=None):
     surr = None
     if env["kind"] == "veh_surr":
         surr = {k: env[k] for k in ("n_surr", "n_constraint", "veh_length", "veh_width", "road_upper", "road_lower", "reward_w")}
+        surr["penalty"] = bool(env.get("penalty", False))
     lq = None
     if env["kind"] == "lq":
         c = env["lq"]

@@ -46,7 +46,7 @@ def _load_alg(name):
 
 
 @pytest.mark.parametrize("name", ["fhadp_idp_gelu", "fhadp_veh_p10_elu", "fhadp_lq_s4a2_tanh",
-                                  "fhadp_idp_selu_shaped"])
+                                  "fhadp_idp_selu_shaped", "fhadp_surrpen_p10_elu"])
 def test_fhadp_class_matches_reference(name):
     alg, g, cfg = _load_alg(name)
     alg.gamma = cfg["gamma"]
@@ -342,7 +342,8 @@ def test_infadp_graph_replay_matches_eager_updates(monkeypatch):
         assert torch.equal(a, b)
 
 
-CSTR_ALG_CASES = ["fhadp_ext_surrcstr", "fhadp_int_surrcstr", "fhadp_lag_surrcstr", "fhadp_int_detour", "fhadp_ext_detour"]
+CSTR_ALG_CASES = ["fhadp_ext_surrcstr", "fhadp_int_surrcstr", "fhadp_lag_surrcstr", "fhadp_int_detour", "fhadp_ext_detour",
+                  "fhadp_ext_surrpen", "fhadp_int_surrpen"]
 
 
 @pytest.mark.gpu

@@ -13,6 +13,8 @@ STEP_CASES = ["step_lq_s4a2", "step_lq_s6a3", "step_lq_s2a1_shaped", "step_idp",
               "step_veh_p30"]
 FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fhadp_idp_selu_shaped",
                "fhadp_veh_p10_elu", "fhadp_veh_p30_sigmoid",
+               # plain FHADP on the collision-penalty model (pyth_veh3dofconti_surrcstr_penalty)
+               "fhadp_surrpen_p10_elu", "fhadp_surrpen_p25_gelu",
                # the reference's shipped trained checkpoints (saturating policies, H = 80, limits != +-1)
                "fhadp_trained_idp_h80", "fhadp_trained_lqs3a1_h80"]
 INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu",
@@ -156,8 +158,9 @@ def test_data_env_step_matches_reference_numpy_envs(name):
     check_data_env_transitions(nobs, r, done, ninfo, t, env["kind"] == "veh")
 
 
-CSTR_STEP_CASES = ["step_veh_surrcstr_p10", "step_veh_detour_p10", "step_veh_surrcstr_p5_n2"]
-CSTR_ALG_CASES = ["fhadp_ext_surrcstr", "fhadp_int_surrcstr", "fhadp_lag_surrcstr", "fhadp_int_detour", "fhadp_ext_detour"]
+CSTR_STEP_CASES = ["step_veh_surrcstr_p10", "step_veh_detour_p10", "step_veh_surrcstr_p5_n2", "step_veh_surrpen_p10"]
+CSTR_ALG_CASES = ["fhadp_ext_surrcstr", "fhadp_int_surrcstr", "fhadp_lag_surrcstr", "fhadp_int_detour", "fhadp_ext_detour",
+                  "fhadp_ext_surrpen", "fhadp_int_surrpen"]
 CSTR_MODE = {"FHADPExterior": "exterior", "FHADPInterior": "interior", "FHADPLagrangian": "lagrangian"}
 
 

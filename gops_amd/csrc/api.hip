@@ -258,8 +258,9 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         p.st.env = c.take((size_t)S * ENV_STASH);
         if (p.tail) {
             for (int j = 1; j < p.val.nl; ++j) {
-                p.st.tail_h[j] = c.take(((size_t)p.B * p.val.dims[j] + el - 1) / el);
-                if (p.val.act == GOPS_ACT_GELU) p.st.tail_z[j] = c.take(((size_t)p.B * p.val.dims[j] + el - 1) / el);
+                const size_t rows = (size_t)((p.B + TB - 1) / TB) * TB;   // whole 16-row tiles (FM stash tiles are written whole)
+                p.st.tail_h[j] = c.take((rows * p.val.dims[j] + el - 1) / el);
+                if (p.val.act == GOPS_ACT_GELU) p.st.tail_z[j] = c.take((rows * p.val.dims[j] + el - 1) / el);
             }
         }
         p.st.tail_done = c.take((size_t)p.B);

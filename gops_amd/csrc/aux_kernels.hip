@@ -264,128 +264,30 @@ hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, fl
 
 // ---------------------------------------------------------------------------------------------
 // dW GEMM:  part[split][n][k] = sum_{s in split} D[s][n] * X[s][k]      (n < N, k < Kp)
-// Workgroup tile (32R x 32R) outputs, 2x2 waves, each wave R x R MFMA 16x16 tiles, samples staged
-// through LDS 32 at a time with a register prefetch of the next chunk.  Workgroups whose k-tile is
-// 0 also accumulate the bias gradient (column sums of D).
-// ---------------------------------------------------------------------------------------------
-#define DW_SC 32   // samples per staged chunk
-
-template <int R>
-__global__ __launch_bounds__(NTHREADS) void dw_gemm_kernel(const float* __restrict__ D, int N,
-                                                           const float* __restrict__ X, int Kp,
-                                                           long long S, int splits, int chunks_per_split,
-                                                           float* __restrict__ part,
-                                                           float* __restrict__ part_b) {
-    constexpr int T = 32 * R;          // tile edge
-    constexpr int LD = T + 16;         // (LD % 32 == 16): conflict-free ds_read_b32 fragments
-    constexpr int V = (DW_SC * T / 4) / NTHREADS;   // float4 per thread per operand per chunk
-    __shared__ __attribute__((aligned(16))) float Ds[DW_SC * LD];
-    __shared__ __attribute__((aligned(16))) float Xs[DW_SC * LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_k = (Kp + T - 1) / T, tiles = tiles_k * ((N + T - 1) / T);
-    // XCD-aware order: workgroup b runs on XCD b % 8.  All output tiles of one sample split read the
-    // same D / X chunks, so they get the same XCD and adjacent slots: the second reader of a chunk
-    // hits that XCD's L2 instead of HBM.
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int tile = local % tiles, split = (local / tiles) * 8 + xcd;
-    if (split >= splits) return;
-    const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
-    const int n0 = tile_n * T, k0 = tile_k * T;
-    const long long s_begin = (long long)split * chunks_per_split * DW_SC;
-    const int wn = wave >> 1, wk = wave & 1;
-
-    f32x4 acc[R][R] = {};
-    float bsum = 0.f;
-    f32x4 dreg[V], xreg[V];
-
-    auto gload = [&](long long s0) {
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-            const int idx = tid + q * NTHREADS;
-            const int row = idx / (T / 4), c4 = idx - row * (T / 4);
-            const long long s = s0 + row;
-            const int n = n0 + 4 * c4, k = k0 + 4 * c4;
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            dreg[q] = (s < S && n < N) ? *reinterpret_cast<const f32x4*>(D + s * N + n) : z;
-            xreg[q] = (s < S && k < Kp) ? *reinterpret_cast<const f32x4*>(X + s * Kp + k) : z;
-        }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-            const int idx = tid + q * NTHREADS;
-            const int row = idx / (T / 4), c4 = idx - row * (T / 4);
-            *reinterpret_cast<f32x4*>(Ds + row * LD + 4 * c4) = dreg[q];
-            *reinterpret_cast<f32x4*>(Xs + row * LD + 4 * c4) = xreg[q];
-        }
-    };
-
-    gload(s_begin);
-    for (int c = 0; c < chunks_per_split; ++c) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (c + 1 < chunks_per_split) gload(s_begin + (long long)(c + 1) * DW_SC);
-        if (part_b != nullptr && tile_k == 0 && tid < T) {
-#pragma unroll
-            for (int r = 0; r < DW_SC; ++r) bsum += Ds[r * LD + tid];
-        }
-        const float* dbase = Ds + (lane >> 4) * LD + wn * 16 * R + (lane & 15);
-        const float* xbase = Xs + (lane >> 4) * LD + wk * 16 * R + (lane & 15);
-        // fragment loads run one k-step ahead of the MFMAs that consume them (LDS latency hidden)
-        float a[2][R], b[2][R];
-#pragma unroll
-        for (int i = 0; i < R; ++i) { a[0][i] = dbase[16 * i]; b[0][i] = xbase[16 * i]; }
-#pragma unroll
-        for (int kk = 0; kk < DW_SC / 4; ++kk) {
-            const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk + 1 < DW_SC / 4) {
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    a[nxt][i] = dbase[(kk + 1) * 4 * LD + 16 * i];
-                    b[nxt][i] = xbase[(kk + 1) * 4 * LD + 16 * i];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs (hipcc would sink it to its use)
-#pragma unroll
-            for (int i = 0; i < R; ++i)
-#pragma unroll
-                for (int j = 0; j < R; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-        }
-    }
-    float* pbase = part + (size_t)split * N * Kp;
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int k = k0 + wk * 16 * R + 16 * j + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * 16 * R + 16 * i + 4 * (lane >> 4) + r;
-                if (n < N && k < Kp) pbase[(size_t)n * Kp + k] = acc[i][j][r];
-            }
-        }
-    if (part_b != nullptr && tile_k == 0 && tid < T && n0 + tid < N) part_b[(size_t)split * N + n0 + tid] = bsum;
-}
-
-// ---------------------------------------------------------------------------------------------
-// dW GEMM on the bf16 matrix cores with fp32 results ("bf16x3"): every fp32 operand a is split
-// EXACTLY into three bf16 planes a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1),
-// a3 = bf16(a - a1 - a2): 3 x 8 significant bits cover the 24 of fp32) and the product a*b is
-// accumulated in fp32 from the six plane products a1b1, a1b2, a2b1, a1b3, a2b2, a3b1; the three
-// dropped ones are below 2^-25 |ab|, i.e. under fp32 rounding.  v_mfma_f32_16x16x32_bf16 runs ~15x
-// the fp32 MFMA rate, so six of them are ~2.5x faster than the fp32 instruction for the same 32-deep
-// block and the GEMM becomes HBM-bound (it reads each stash tile once).
 //
-// Tile 128 x 128 outputs per workgroup, 2 x 2 waves of 64 x 64.  The contraction runs over samples,
-// which are the ROWS of both operands in memory, so the staging transposes: a thread loads 4 rows x
-// 4 columns (dwordx4, coalesced), splits, and writes plane fragments [g = s/8][col][8 samples] with
-// ds_write_b64; a lane's MFMA fragment (8 consecutive samples of one column) is then one ds_read_b128.
-// The 16-byte units are XOR-swizzled over the column index so that both directions are conflict-free.
+// Both operands are feature-major stash tensors (common.h StashDev: element (tile q, feature f, row m) at
+// (q * F + f) * 16 + m), and the contraction index IS the sample: an MFMA operand fragment - consecutive
+// samples of one feature - is therefore contiguous in memory and is loaded straight from global into the
+// registers of the lane that feeds it to the matrix core.  No LDS, no transposes, no barriers.
+//
+// Workgroup tile 32R x 32R outputs, 2 x 2 waves of 16R x 16R (R x R MFMA tiles).  A K-block is 32 samples = two
+// sample tiles q0, q0 + 1; lane (f = lane & 15, g = lane >> 4) of a fragment holds samples 4g .. 4g+3 of both
+// tiles: two dwordx4 loads, each of which covers a fully contiguous KiB per wave (16 features x 64 B).  (The order
+// of the 32 samples inside the contraction is free as long as both operands use the same one.)  The next
+// block's fragments are in flight while the current ones are multiplied.
+//
+// BF3: "bf16x3" products on v_mfma_f32_16x16x32_bf16 with fp32 results - every fp32 operand a is split EXACTLY
+// into three bf16 planes a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2): 3 x 8
+// significant bits cover the 24 of fp32) and a*b is accumulated in fp32 from the six plane products a1b1, a1b2,
+// a2b1, a1b3, a2b2, a3b1; the three dropped ones are below 2^-25 |ab|, i.e. under fp32 rounding.  Six of these
+// MFMAs cost 96 cycles against 256 for the eight v_mfma_f32_16x16x4_f32 of the same 32-deep block.
+// !BF3: the fp32 matrix-core instruction itself (A/B knob GOPS_DW_F32, and the reference for the split).
+//
+// Workgroups whose k-tile is 0 also accumulate the bias gradient (column sums of D).
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     bf16x2 v;
@@ -403,145 +305,149 @@ __device__ __forceinline__ void split3(float a, float b, unsigned (&pl)[3]) {
     pl[2] = pack_bf16(sa, sb);
 }
 
-#define DWB_T 128                      // tile edge
-#define DWB_PLANE (4 * DWB_T * 8)      // halfs per plane: [4 g][128 cols][8 samples]
+// 8 fp32 samples of one feature -> the three bf16x8 plane fragments
+__device__ __forceinline__ void split_frag(const f32x4& lo, const f32x4& hi, bf16x8 (&pl)[3]) {
+    unsigned p0[3], p1[3], p2[3], p3[3];
+    split3(lo[0], lo[1], p0);
+    split3(lo[2], lo[3], p1);
+    split3(hi[0], hi[1], p2);
+    split3(hi[2], hi[3], p3);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const u32x4 v = {p0[q], p1[q], p2[q], p3[q]};
+        pl[q] = __builtin_bit_cast(bf16x8, v);
+    }
+}
 
-#ifdef GOPS_DBG_BUILD
-#define GT(i) { if (tid == 0 && blockIdx.x == 0) { long long now = clock64(); tacc[i] += now - tlast; tlast = now; } }
-#else
-#define GT(i)
-#endif
-
-__global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_bf16x3_kernel(const float* __restrict__ D, int N,
-                                                                      const float* __restrict__ X, int Kp,
-                                                                      long long S, int splits, int chunks_per_split,
-                                                                      float* __restrict__ part,
-                                                                      float* __restrict__ part_b) {
-    __shared__ __attribute__((aligned(16))) __bf16 As[3 * DWB_PLANE];   // D^T planes
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[3 * DWB_PLANE];   // X planes
+template <int R, bool BF3>
+__global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_fm_kernel(const float* __restrict__ D, int N,
+                                                                  const float* __restrict__ X, int Kp,
+                                                                  long long Q, int splits, int chunks_per_split,
+                                                                  float* __restrict__ part,
+                                                                  float* __restrict__ part_b) {
+    constexpr int T = 32 * R;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_k = (Kp + DWB_T - 1) / DWB_T, tiles = tiles_k * ((N + DWB_T - 1) / DWB_T);
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;   // same XCD-aware order as dw_gemm_kernel
+    const int tiles_k = (Kp + T - 1) / T, tiles = tiles_k * ((N + T - 1) / T);
+    // XCD-aware order: workgroup b runs on XCD b % 8.  All output tiles of one sample split read the
+    // same D / X blocks, so they get the same XCD and adjacent slots: the second reader of a block
+    // hits that XCD's L2 instead of HBM.
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int tile = local % tiles, split = (local / tiles) * 8 + xcd;
     if (split >= splits) return;
     const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
-    const int n0 = tile_n * DWB_T, k0 = tile_k * DWB_T;
-    const long long s_begin = (long long)split * chunks_per_split * DW_SC;
     const int wn = wave >> 1, wk = wave & 1;
-#ifdef GOPS_DBG_BUILD
-    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
-#endif
+    const int nb = tile_n * T + wn * 16 * R, kb = tile_k * T + wk * 16 * R;   // first feature of this wave's rows / columns
+    const int f = lane & 15, g = lane >> 4;
+    const bool want_bias = part_b != nullptr && tile_k == 0 && wk == 0;
 
-    // Staging item of this thread: columns 4*c4 .. 4*c4+3, samples 4*s4 .. 4*s4+3 of the chunk.  Lane
-    // bits -> (s4 bit 0, c4 bits 0, 2, 3, 1, 4): the 16 lanes of a ds_write_b64 group then hit 16
-    // distinct 8-byte slots mod 128 B (conflict-free), and one load instruction still covers two full
-    // 512-byte rows.
-    const int c4 = ((lane >> 1) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 2) & 3) << 2) | ((lane >> 5) << 4);
-    const int s4 = (lane & 1) | (wave << 1);
-    int wofs[4];   // LDS half-offset of column 4*c4 + i: 16-byte unit index swizzled with column bits 4..5
+    // Per-fragment element offsets inside a sample tile.  Features past the matrix edge are CLAMPED to the last one
+    // (their products land in accumulator rows / columns that are never stored) and the block index of a prefetch is
+    // clamped to the split's last block, so that every load is unconditional: the loop body is one basic block that
+    // the scheduler can interleave freely (loads, bf16 splits and MFMAs of different fragments).
+    int doff[R], xoff[R];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = 4 * c4 + i, nsw = n ^ ((n >> 4) & 3);
-        wofs[i] = (((s4 >> 1) * DWB_T + nsw) << 3) + ((s4 & 1) << 2);
+    for (int i = 0; i < R; ++i) {
+        doff[i] = min(nb + 16 * i + f, N - 1) * 16 + 4 * g;
+        xoff[i] = min(kb + 16 * i + f, Kp - 1) * 16 + 4 * g;
     }
-    const bool want_bias = part_b != nullptr && tile_k == 0;
+    const GLOBAL_AS float* Dg = gptr(D);
+    const GLOBAL_AS float* Xg = gptr(X);
+    const size_t dtile = (size_t)N * 16, xtile = (size_t)Kp * 16;
+    const long long blk0 = (long long)split * chunks_per_split, nblk_all = (Q + 1) >> 1;
+    const int nblk = (int)min((long long)chunks_per_split, nblk_all - blk0);   // >= 1 by construction of the split count
+    const bool odd_tail = (Q & 1) && (blk0 + nblk == nblk_all);               // the very last block has one sample tile only
 
-    f32x4 acc[4][4] = {};
-    f32x4 dreg[4], xreg[4];
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-
-    auto gload = [&](long long s0) {
+    f32x4 acc[R][R] = {};
+    float bsum[R];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long long srow = s0 + 4 * s4 + r;
-            const int n = n0 + 4 * c4, k = k0 + 4 * c4;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            dreg[r] = (srow < S && n < N) ? *reinterpret_cast<const f32x4*>(D + srow * N + n) : z;
-            xreg[r] = (srow < S && k < Kp) ? *reinterpret_cast<const f32x4*>(X + srow * Kp + k) : z;
+    for (int i = 0; i < R; ++i) bsum[i] = 0.f;
+    // Raw fragments: ONE register set.  A fragment's registers are refilled with the same fragment of the NEXT block
+    // right after this block's copy has been split / consumed, so every load has a whole block of work to land
+    // and no second buffer adds to the register pressure (spilling here would put scratch traffic - and its
+    // in-order vmcnt waits - in front of the prefetches).
+    f32x4 dra[R][2], xra[R][2];
+    auto load_d = [&](long long blk, int i) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) dra[i][h] = ld4(Dg + (size_t)min(2 * blk + h, Q - 1) * dtile + doff[i]);
+    };
+    auto load_x = [&](long long blk, int j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) xra[j][h] = ld4(Xg + (size_t)min(2 * blk + h, Q - 1) * xtile + xoff[j]);
+    };
+    // one 32-sample block; LAST_HALF_EMPTY: the second sample tile does not exist (odd tile count): its (clamped,
+    // i.e. duplicate) fragments are replaced by zeros
+    auto block = [&]<bool LAST_HALF_EMPTY>(long long next_blk) {
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF3) {
+            bf16x8 b[R][3];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                split_frag(xra[j][0], LAST_HALF_EMPTY ? zero4 : xra[j][1], b[j]);
+                load_x(next_blk, j);
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const f32x4 d0 = dra[i][0], d1 = LAST_HALF_EMPTY ? zero4 : dra[i][1];
+                bf16x8 a[3];
+                split_frag(d0, d1, a);
+                bsum[i] += ((d0[0] + d0[1]) + (d0[2] + d0[3])) + ((d1[0] + d1[1]) + (d1[2] + d1[3]));   // (every wave: no branch in the block)
+                load_d(next_blk, i);
+                // six plane products, smallest terms first; consecutive MFMAs go to different accumulators
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int j = 0; j < R; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            f32x4 xc[R][2];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                xc[j][0] = xra[j][0]; xc[j][1] = LAST_HALF_EMPTY ? zero4 : xra[j][1];
+                load_x(next_blk, j);
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const f32x4 d0 = dra[i][0], d1 = LAST_HALF_EMPTY ? zero4 : dra[i][1];
+                bsum[i] += ((d0[0] + d0[1]) + (d0[2] + d0[3])) + ((d1[0] + d1[1]) + (d1[2] + d1[3]));   // (every wave: no branch in the block)
+                load_d(next_blk, i);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int j = 0; j < R; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u < 4 ? d0[u & 3] : d1[u & 3], xc[j][u >> 2][u & 3], acc[i][j], 0, 0, 0);
+            }
         }
     };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned p01[3], p23[3];
-            split3(dreg[0][i], dreg[1][i], p01);
-            split3(dreg[2][i], dreg[3][i], p23);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                *reinterpret_cast<uint2*>(As + pl * DWB_PLANE + wofs[i]) = make_uint2(p01[pl], p23[pl]);
-            split3(xreg[0][i], xreg[1][i], p01);
-            split3(xreg[2][i], xreg[3][i], p23);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                *reinterpret_cast<uint2*>(Bs + pl * DWB_PLANE + wofs[i]) = make_uint2(p01[pl], p23[pl]);
-            if (want_bias) bsum[i] += (dreg[0][i] + dreg[1][i]) + (dreg[2][i] + dreg[3][i]);
-        }
-    };
-    // fragment (8 consecutive samples of tile-local column `col`) of this lane: g = lane >> 4
-    auto frag = [&](const __bf16* base, int pl, int col) {
-        const int nsw = col ^ ((col >> 4) & 3);
-        return *reinterpret_cast<const bf16x8*>(base + pl * DWB_PLANE + ((((lane >> 4) * DWB_T) + nsw) << 3));
-    };
 
-    gload(s_begin);
-    for (int c = 0; c < chunks_per_split; ++c) {
-        GT(0)
-        __syncthreads();
-        GT(1)
-        lstore();
-        GT(2)
-        __syncthreads();
-        GT(3)
-        if (c + 1 < chunks_per_split) gload(s_begin + (long long)(c + 1) * DW_SC);
-        bf16x8 b[4][3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < R; ++j) load_x(blk0, j);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[j][pl] = frag(Bs, pl, wk * 64 + 16 * j + (lane & 15));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16x8 a[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[pl] = frag(As, pl, wn * 64 + 16 * i + (lane & 15));
-            // six plane products, smallest terms first; consecutive MFMAs go to different accumulators
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
-        }
-        GT(4)
-    }
-#ifdef GOPS_DBG_BUILD
-    if (tid == 0 && blockIdx.x == 0)
-        printf("[dw dbg] per chunk: loop-top->sync1 %lld | sync1 %lld | lstore(+load wait) %lld | sync2 %lld | frags+mfma %lld  (chunks %d)\n",
-               tacc[0] / chunks_per_split, tacc[1] / chunks_per_split, tacc[2] / chunks_per_split,
-               tacc[3] / chunks_per_split, tacc[4] / chunks_per_split, chunks_per_split);
-#endif
+    for (int i = 0; i < R; ++i) load_d(blk0, i);
+    const int nfull = odd_tail ? nblk - 1 : nblk;
+    const long long last_blk = blk0 + nblk - 1;
+    for (int c = 0; c < nfull; ++c) block.template operator()<false>(min(blk0 + c + 1, last_blk));
+    if (odd_tail) block.template operator()<true>(last_blk);
     float* pbase = part + (size_t)split * N * Kp;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + wk * 64 + 16 * j + (lane & 15);
+        for (int j = 0; j < R; ++j) {
+            const int k = kb + 16 * j + f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * 64 + 16 * i + 4 * (lane >> 4) + r;
+                const int n = nb + 16 * i + 4 * g + r;
                 if (n < N && k < Kp) pbase[(size_t)n * Kp + k] = acc[i][j][r];
             }
         }
-    if (want_bias) {   // column sums of D: 8 sample groups per column, combined in a fixed order
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(As);   // [8][128]
+    if (want_bias) {   // column sums of D: the four sample groups of a feature sit in lanes f, f+16, f+32, f+48
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[s4 * DWB_T + 4 * c4 + i] = bsum[i];
-        __syncthreads();
-        if (tid < DWB_T && n0 + tid < N) {
-            float t = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) t += red[q * DWB_T + tid];
-            part_b[(size_t)split * N + n0 + tid] = t;
+        for (int i = 0; i < R; ++i) {
+            float t = bsum[i];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            if (g == 0 && nb + 16 * i + f < N) part_b[(size_t)split * N + nb + 16 * i + f] = t;
         }
     }
 }
@@ -549,19 +455,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_bf16x3_kernel(const float
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
                           int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s) {
     static const bool force_f32 = getenv("GOPS_DW_F32") != nullptr;   // A/B knob: fp32 MFMA GEMM
-    if (big && !force_f32 && (N & 3) == 0 && (Kp & 3) == 0) {
-        const int T = DWB_T, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
-        hipLaunchKernelGGL(dw_gemm_bf16x3_kernel, dim3(tiles * ((splits + 7) / 8) * 8), dim3(NTHREADS), 0, s, D, N, X,
-                           Kp, S, splits, chunks_per_split, part, part_b);
-    } else if (big) {
-        const int T = 128, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
-        hipLaunchKernelGGL(dw_gemm_kernel<4>, dim3(tiles * ((splits + 7) / 8) * 8), dim3(NTHREADS), 0, s, D, N, X, Kp, S,
-                           splits, chunks_per_split, part, part_b);
-    } else {
-        const int T = 64, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
-        hipLaunchKernelGGL(dw_gemm_kernel<2>, dim3(tiles * ((splits + 7) / 8) * 8), dim3(NTHREADS), 0, s, D, N, X, Kp, S,
-                           splits, chunks_per_split, part, part_b);
-    }
+    const long long Q = (S + TB - 1) / TB;
+    const int T = big ? 128 : 64, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
+    const dim3 grid(tiles * ((splits + 7) / 8) * 8), block(NTHREADS);
+    if (big && !force_f32) hipLaunchKernelGGL((dw_gemm_fm_kernel<4, true>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
+    else if (big) hipLaunchKernelGGL((dw_gemm_fm_kernel<4, false>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
+    else if (!force_f32) hipLaunchKernelGGL((dw_gemm_fm_kernel<2, true>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
+    else hipLaunchKernelGGL((dw_gemm_fm_kernel<2, false>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
     return hipGetLastError();
 }
 
@@ -708,15 +608,15 @@ hipError_t launch_dw_gemm_f16(const void* D, int N, const void* X, int Kp, long 
 }
 
 // Output layer (width A <= 4) on the VALU: part[split][a][k] = sum_s dy[s][a] * h[s][k].
-// Thread = (4 columns, sample lane): 16-byte coalesced reads of h, four sample lanes per block
-// combined through LDS in a fixed order.
+// Row-major h (GOPS_DTYPE_F16 stash): thread = (4 columns, sample lane), 16-byte coalesced reads of h, four sample
+// lanes per block combined through LDS in a fixed order.
 __device__ __forceinline__ f32x4 ld4_as_f32(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 ld4_as_f32(const _Float16* p) {
     const f16x4 v = *reinterpret_cast<const f16x4*>(p);
     const f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
     return r;
 }
-template <class HT>   // float, or _Float16 for GOPS_DTYPE_F16 (dy stays fp32)
+template <class HT>   // _Float16 for GOPS_DTYPE_F16 (dy stays fp32)
 __global__ __launch_bounds__(NTHREADS) void dw_out_kernel(const float* __restrict__ dy,
                                                           const HT* __restrict__ h, int K, int A,
                                                           long long S, long long per_split,
@@ -758,14 +658,67 @@ __global__ __launch_bounds__(NTHREADS) void dw_out_kernel(const float* __restric
     }
 }
 
+// Feature-major fp32 h (common.h StashDev): a split is a run of whole sample tiles; thread (feature slot c, row
+// group rg = tid >> 6) reads the 16-byte vector of rows 4 rg .. 4 rg + 3 of feature k - a wave covers a contiguous
+// KiB - and multiplies it with the tile's 16 x 4 block of dy, which every thread fetches with uniform (scalar) loads.
+__global__ __launch_bounds__(NTHREADS) void dw_out_fm_kernel(const float* __restrict__ dy, const float* __restrict__ h, int K, int A,
+                                                             long long Q, long long tiles_per_split,
+                                                             float* __restrict__ part, float* __restrict__ part_b) {
+    __shared__ float red[4][GOPS_MAX_ACT][64];
+    __shared__ float redb[4][GOPS_MAX_ACT];
+    const int split = blockIdx.x, c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const long long q0 = split * tiles_per_split, q1 = min(Q, q0 + tiles_per_split);
+    const int npass = (K + 63) / 64;   // uniform trip count: every lane reaches the barriers
+    for (int pass = 0; pass < npass; ++pass) {
+        const int k = c + 64 * pass;
+        const bool col_ok = k < K;
+        float acc[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, accb[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
+        for (long long qb = q0; qb < q1; qb += 8) {   // 8 tiles' vectors in flight per thread (the kernel is latency-bound)
+            f32x4 hv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                hv[u] = (col_ok && qb + u < q1) ? ld4(gptr(h) + ((size_t)(qb + u) * K + k) * 16 + 4 * rg) : z;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (qb + u < q1) {
+                    const GLOBAL_AS f32x4* gp = gptr(reinterpret_cast<const f32x4*>(dy)) + (size_t)(qb + u) * 16 + 4 * rg;   // rows 4 rg .. +3: [4][4]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const f32x4 g = gp[r];
+#pragma unroll
+                        for (int a = 0; a < GOPS_MAX_ACT; ++a) { acc[a] += g[a] * hv[u][r]; accb[a] += g[a]; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < GOPS_MAX_ACT; ++a) red[rg][a][c] = acc[a];
+        if (c == 0 && pass == 0)
+            for (int a = 0; a < GOPS_MAX_ACT; ++a) redb[rg][a] = accb[a];
+        __syncthreads();
+        if (rg == 0 && col_ok) {
+            for (int a = 0; a < A; ++a)
+                part[((size_t)split * A + a) * K + k] = (red[0][a][c] + red[1][a][c]) + (red[2][a][c] + red[3][a][c]);
+            if (k == 0)
+                for (int a = 0; a < A; ++a)
+                    part_b[(size_t)split * A + a] = (redb[0][a] + redb[1][a]) + (redb[2][a] + redb[3][a]);
+        }
+        __syncthreads();
+    }
+}
+
 hipError_t launch_dw_out(const float* dy, const float* h, bool h_is_half, int K, int A, long long S, int splits,
                          float* part, float* part_b, hipStream_t s) {
-    const long long per = (S + splits - 1) / splits;
-    if (h_is_half)
+    if (h_is_half) {
+        const long long per = (S + splits - 1) / splits;
         hipLaunchKernelGGL(dw_out_kernel<_Float16>, dim3(splits), dim3(NTHREADS), 0, s, dy, reinterpret_cast<const _Float16*>(h),
                            K, A, S, per, part, part_b);
-    else
-        hipLaunchKernelGGL(dw_out_kernel<float>, dim3(splits), dim3(NTHREADS), 0, s, dy, h, K, A, S, per, part, part_b);
+    } else {   // splits beyond the tile count produce zero slabs (their loops are empty)
+        const long long Q = (S + TB - 1) / TB, per = (Q + splits - 1) / splits;
+        hipLaunchKernelGGL(dw_out_fm_kernel, dim3(splits), dim3(NTHREADS), 0, s, dy, h, K, A, Q, per, part, part_b);
+    }
     return hipGetLastError();
 }
 
@@ -837,19 +790,20 @@ hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void linear_out_fwd_kernel(const float* __restrict__ h, int K, const float* __restrict__ Wo,
                                                              const float* __restrict__ bo, int W, int B, float* __restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) float hs[];   // [16][K]
-    const int b0 = blockIdx.x * 16, rows = min(16, B - b0);
-    for (int i = threadIdx.x; i < 16 * (K >> 2); i += 256) {
-        const int m = i / (K >> 2), c = i - m * (K >> 2);
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        reinterpret_cast<f32x4*>(hs)[i] = (m < rows) ? reinterpret_cast<const f32x4*>(h + (size_t)(b0 + m) * K)[c] : z;
+    extern __shared__ __attribute__((aligned(16))) float hs[];   // [16][K + 4] row-major copy of the FM tile
+    const int b0 = blockIdx.x * 16, rows = min(16, B - b0), ld = K + 4;
+    for (int i = threadIdx.x; i < 4 * K; i += 256) {   // 16-byte unit i of the tile: feature i >> 2, rows 4 (i & 3) .. +3
+        const f32x4 v = reinterpret_cast<const f32x4*>(h + (size_t)blockIdx.x * 16 * K)[i];
+        const int k = i >> 2, m0 = (i & 3) << 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hs[(m0 + r) * ld + k] = v[r];
     }
     __syncthreads();
     for (int o = threadIdx.x; o < 16 * W; o += 256) {   // o = m * W + w: consecutive threads -> consecutive y elements
         const int m = o / W, w = o - m * W;
         if (m >= rows) continue;
         const f32x4* wr = reinterpret_cast<const f32x4*>(Wo + (size_t)w * K);
-        const f32x4* hr = reinterpret_cast<const f32x4*>(hs + m * K);
+        const f32x4* hr = reinterpret_cast<const f32x4*>(hs + m * ld);
         float acc = 0.f;
         for (int c = 0; c < (K >> 2); ++c) {
             const f32x4 a = hr[c], bq = wr[c];
@@ -859,17 +813,20 @@ __global__ __launch_bounds__(256) void linear_out_fwd_kernel(const float* __rest
     }
 }
 
+// g_h stays row-major [S][K] (rollout_bwd reads it as `ext_delta`); g_yp is the FM delta operand [S/16][Wp][16]
 __global__ __launch_bounds__(256) void linear_out_bwd_kernel(const float* __restrict__ gy, int W, int Wp, const float* __restrict__ Wo,
                                                              int K, int B, long long S, float* __restrict__ gh, float* __restrict__ gyp) {
     extern __shared__ __attribute__((aligned(16))) float gs[];   // [16][Wp]
     const long long s0 = (long long)blockIdx.x * 16;
     for (int i = threadIdx.x; i < 16 * Wp; i += 256) {
         const int m = i / Wp, w = i - m * Wp;
-        const float v = (s0 + m < B && w < W) ? gy[(size_t)(s0 + m) * W + w] : 0.f;
-        gs[i] = v;
-        if (s0 + m < S) gyp[(size_t)(s0 + m) * Wp + w] = v;
+        gs[i] = (s0 + m < B && w < W) ? gy[(size_t)(s0 + m) * W + w] : 0.f;
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < 16 * Wp; i += 256) {   // i = w * 16 + m: the FM tile in memory order
+        const int w = i >> 4, m = i & 15;
+        gyp[(size_t)blockIdx.x * 16 * Wp + i] = gs[m * Wp + w];
+    }
     for (int o = threadIdx.x; o < 16 * K; o += 256) {   // o = m * K + k: coalesced reads of Wo rows and writes of g_h
         const int m = o / K, k = o - m * K;
         if (s0 + m >= S) continue;
@@ -880,7 +837,7 @@ __global__ __launch_bounds__(256) void linear_out_bwd_kernel(const float* __rest
 }
 
 hipError_t launch_linear_out_fwd(const float* h, int K, const float* Wo, const float* bo, int W, int B, float* y, hipStream_t s) {
-    hipLaunchKernelGGL(linear_out_fwd_kernel, dim3((B + 15) / 16), dim3(256), 16 * K * sizeof(float), s, h, K, Wo, bo, W, B, y);
+    hipLaunchKernelGGL(linear_out_fwd_kernel, dim3((B + 15) / 16), dim3(256), 16 * (K + 4) * sizeof(float), s, h, K, Wo, bo, W, B, y);
     return hipGetLastError();
 }
 

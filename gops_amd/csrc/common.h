@@ -41,18 +41,23 @@ struct MlpDev {
     const f16x8* wpth[GOPS_MAX_LAYERS];
 };
 
+// fp32 stash tensors are FEATURE-MAJOR inside every 16-sample tile: element (sample tile q, feature n, row m) of a
+// tensor with N features sits at (q * N + n) * 16 + m (FM layout).  A lane of the rollout kernels' MFMA result layout
+// (feature n = lane & 15, rows 4 (lane >> 4) .. +3) then stores / loads ONE 16-byte vector, a wave's n-tile is 1 KiB
+// of contiguous memory, and the weight-gradient GEMM - whose contraction index is the sample - reads its MFMA
+// operand fragments (consecutive samples of one feature) straight from global memory with no transpose.
 struct StashDev {
-    float* x;                         // [S][kp0]  policy input rows (obs_t | t+1 | 0-pad)
-    float* h[GOPS_MAX_LAYERS];        // h[j] (j=1..L): [S][dims[j]] hidden activations
+    float* x;                         // FM [S/16][kp0][16]  policy input rows (obs_t | t+1 | 0-pad)
+    float* h[GOPS_MAX_LAYERS];        // h[j] (j=1..L): FM [S/16][dims[j]][16] hidden activations
     float* z[GOPS_MAX_LAYERS];        // pre-activations, only for GELU
-    float* d[GOPS_MAX_LAYERS];        // d[j] (j=1..L): [S][dims[j]] adjoint of z_j
+    float* d[GOPS_MAX_LAYERS];        // d[j] (j=1..L): FM [S/16][dims[j]][16] adjoint of z_j
     float* dy;                        // [S][4] adjoint of the head pre-activation
     float* env;                       // [S][ENV_STASH]
-    float* tail_h[GOPS_MAX_LAYERS];   // [B][dims[j]] hidden activations of the tail value net
+    float* tail_h[GOPS_MAX_LAYERS];   // FM [ceil(B/16)][dims[j]][16] hidden activations of the tail value net
     float* tail_z[GOPS_MAX_LAYERS];
     float* tail_done;                 // [B] done flag after the last step
-    // GOPS_DTYPE_F16: x / h / z / d / tail_h / tail_z hold _Float16 elements (x rows are kp32[0] wide, z holds
-    // act'(z) instead of z), and the first 8 observation columns are kept in fp32 for the env adjoints:
+    // GOPS_DTYPE_F16: x / h / z / d / tail_h / tail_z are ROW-major [S][width] _Float16 (x rows are kp32[0] wide, z
+    // holds act'(z) instead of z), and the first 8 observation columns are kept in fp32 for the env adjoints:
     float* xf;                        // [S][8]
 };
 
@@ -426,7 +431,7 @@ __device__ __forceinline__ unsigned touch_fetch(const MlpDev& M, const StashDev&
     }
     if (g >= 0 && g < TB * ENV_STASH / 32) return *gptr(reinterpret_cast<const unsigned*>(st.env + prow * ENV_STASH) + g * 32);
     g -= TB * ENV_STASH / 32;
-    if (g >= 0 && g < TB) return *gptr(reinterpret_cast<const unsigned*>(st.x + (prow + g) * M.kp[0]));
+    if (g >= 0 && g < 4) return *gptr(reinterpret_cast<const unsigned*>(st.x + prow * M.kp[0]) + g * 32);   // FM: columns 0..7
     return 0u;
 }
 
@@ -445,6 +450,17 @@ __device__ __forceinline__ void async_copy16_to_lds(const float* gsrc, const flo
                  : "=&s"(keep)
                  : "v"(gptr(gsrc)), "s"(m0v)
                  : "memory");
+}
+
+// Copy a [TB][ncols] row-major LDS tile (leading dim ld, ld % 16 == 4) to the FM stash tile at `g`
+// (g[n * 16 + m]): thread = (feature n, row group), four conflict-free ds_read_b32 down a column and one
+// 16-byte store; consecutive threads write consecutive 16-byte units.
+__device__ __forceinline__ void stash_tile_fm(const float* lds, int ld, int ncols, float* g, int tid) {
+    for (int idx = tid; idx < ncols * 4; idx += NTHREADS) {
+        const int n = idx >> 2, m0 = (idx & 3) << 2;
+        const f32x4 v = {lds[m0 * ld + n], lds[(m0 + 1) * ld + n], lds[(m0 + 2) * ld + n], lds[(m0 + 3) * ld + n]};
+        __builtin_nontemporal_store(v, gptr(reinterpret_cast<f32x4*>(g) + idx));
+    }
 }
 
 // Copy a [TB][ncols] LDS tile (leading dim ld) to global rows g[(row0+m)*ncols ...], coalesced.

@@ -17,6 +17,13 @@ __host__ __device__ inline int bwd_lds_floats(int ldx, int ldh, int ref_points, 
 
 // delta_y in s_gy[TB][4]  ->  hidden deltas (stashed to stash_d when non-null) and, if want_gx,
 // G[m][n] += (delta_1 W_0)[m][n] for n < ncols.
+//
+// Every delta tile is formed in the MFMA result layout (lane: feature n = lane & 15 of an n-tile, rows
+// 4 (lane >> 4) .. +3), which is exactly one 16-byte vector of the feature-major stash: act' comes from one
+// vector load of H_j (Z_j for GELU) - global, or the LDS image `stage` of the tile the caller fetched one step
+// ahead - and delta_j leaves for the stash as one non-temporal vector store from the registers that formed it.
+// The head delta_L = (delta_y W_o) * act'(z_L) is a K = act_dim <= 4 contraction: ONE v_mfma_f32_16x16x4_f32 per
+// n-tile (delta_y zero-padded to 4 columns), n-tiles dealt to the waves like in gemm_layer.
 template <bool STAGED, class W0T, class W1T, class WP, class Hook>
 __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, const W1T& WT1,
                                              WP Wo, int ldw, const float* s_gy, float* da,
@@ -26,68 +33,68 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
                                              int nvalid, bool want_gx, int ncols, DbgClock& dbg,
                                              Hook&& after_head, const float* stage_head = nullptr,
                                              const float* stage_h1 = nullptr, const float* ext_delta = nullptr) {
-    // stage_head / stage_h1: LDS copies (direct global->LDS loads issued at the top of the step) of the
-    // tiles the head / the layer-1 epilogue take act' from: [TB][K] row-major, and [wave][TB][64]
-    // (each wave's own 64 columns) - each wave reads only what its own lanes fetched.
+    // stage_head / stage_h1: LDS images (direct global->LDS loads issued at the top of the step) of the FM tiles
+    // the head / the layer-1 epilogue take act' from; each wave reads only the 4 KiB its own lanes fetched.
     const int lane = tid & 63;
     const int L = M.nl - 1, A = M.dims[M.nl];
     const bool gelu = (M.act == GOPS_ACT_GELU);
-    // ---- head: delta_L[m][k] = (sum_a gy[m][a] Wo[a][k]) * act'(z_L[m][k]) on the VALU ----
-    {
-        const int K = M.dims[L];
-        const int hm = tid >> 4, hp = tid & 15;
-        float gy[GOPS_MAX_ACT];
+    const int m0 = (lane >> 4) << 2;
+    // epilogue of the delta tile of layer j: out[m][n] = acc * act'(.), stash_d[j] tile <- the same vector
+    auto delta_epi = [&](int j, float* out, const float* stage, bool from_ext) {
+        const int N = M.dims[j];
+        const GLOBAL_AS float* src = gptr((gelu ? stash_z[j] : stash_h[j]) + row0 * N);
+        float* dst = (stash_d != nullptr) ? stash_d[j] + row0 * N : nullptr;
+        return [=, &M]<int CNT>(const f32x4 (&acc)[4], int nt0) {
+            act_dispatch(M.act, [&]<int ACT>() {
+                f32x4 hv[CNT];
+                if constexpr (!STAGED) {   // issue every stash load before the math (global latency)
 #pragma unroll
-        for (int a = 0; a < GOPS_MAX_ACT; ++a) gy[a] = (a < A) ? s_gy[hm * 4 + a] : 0.f;
-        const GLOBAL_AS float* hrow = gptr(stash_h[L] + (row0 + hm) * K);
-        const GLOBAL_AS float* zrow = gptr(gelu ? stash_z[L] + (row0 + hm) * K : stash_h[L]);
-        act_dispatch(M.act, [&]<int ACT>() {
-            if ((K & 63) == 0 && (ldw & 3) == 0) {
-#pragma unroll 4
-                for (int k = 4 * hp; k < K; k += 64) {
-                    f32x4 hv = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (STAGED) hv = *reinterpret_cast<const f32x4*>(stage_head + hm * K + k);
-                    else if (hm < nvalid) hv = ld4((ACT == GOPS_ACT_GELU ? zrow : hrow) + k);
-                    bool from_head = true;
-                    if constexpr (!STAGED) {   // gops_mlp_backward: the adjoint of this activation comes from the wide output layer
-                        if (ext_delta != nullptr) {
-                            from_head = false;
-                            if (hm < nvalid) acc = ld4(gptr(ext_delta) + (row0 + hm) * K + k);
-                        }
-                    }
-                    if (from_head) {
+                    for (int q = 0; q < CNT; ++q) hv[q] = ld4(src + (((nt0 + q) << 4) + (lane & 15)) * 16 + m0);
+                }
 #pragma unroll
-                        for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                            if (a < A) acc += gy[a] * ld4(Wo + a * ldw + k);
-                    }
+                for (int q = 0; q < CNT; ++q) {
+                    const int n = ((nt0 + q) << 4) + (lane & 15);
+                    if constexpr (STAGED) hv[q] = *reinterpret_cast<const f32x4*>(stage + n * 16 + m0);
                     f32x4 dv;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dv[e] = (hm < nvalid) ? acc[e] * act_bwd_t<ACT>(hv[e], hv[e]) : 0.f;
-                    *reinterpret_cast<f32x4*>(da + hm * ldh + k) = dv;
-                    // the delta tile goes to the stash from the registers that produced it
-                    if (stash_d != nullptr)
-                        __builtin_nontemporal_store(dv, gptr(reinterpret_cast<f32x4*>(stash_d[L] + (row0 + hm) * K + k)));
+                    for (int r = 0; r < 4; ++r) {
+                        float a = acc[q][r];
+                        if constexpr (!STAGED) {   // gops_mlp_backward: the adjoint of this activation comes from the wide output layer
+                            if (from_ext) a = (m0 + r < nvalid) ? gptr(ext_delta)[(row0 + m0 + r) * N + n] : 0.f;
+                        }
+                        dv[r] = (m0 + r < nvalid) ? a * act_bwd_t<ACT>(hv[q][r], hv[q][r]) : 0.f;
+                        out[(m0 + r) * ldh + n] = dv[r];
+                    }
+                    if (dst != nullptr) __builtin_nontemporal_store(dv, gptr(reinterpret_cast<f32x4*>(dst + n * 16 + m0)));
                 }
-            } else {
-                for (int k = hp; k < K; k += 16) {
-                    float acc = 0.f;
-                    if (!STAGED && ext_delta != nullptr) {
-                        if (hm < nvalid) acc = gptr(ext_delta)[(row0 + hm) * K + k];
-                    } else {
+            });
+        };
+    };
+    // ---- head: delta_L = (delta_y W_o) * act'(z_L) ----
+    {
+        const int nt_tot = M.dims[L] >> 4, per = (nt_tot + 3) >> 2;
+        const int wave = tid >> 6, kk = lane >> 4;
+        const bool from_ext = (!STAGED) && (ext_delta != nullptr);
+        const float ga = (kk < A && !from_ext) ? s_gy[(lane & 15) * 4 + kk] : 0.f;   // A operand: delta_y[m = lane & 15][k = lane >> 4]
+        auto epi = delta_epi(L, da, stage_head, from_ext);
+        int nt = wave * per;
+        const int nt_end = min(nt_tot, nt + per);
+        while (nt < nt_end) {
+            const int left = nt_end - nt;
+            f32x4 acc[4] = {};
+            auto tiles = [&]<int CNT>() {
+                float bw[CNT];
 #pragma unroll
-                        for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                            if (a < A) acc += gy[a] * Wo[a * ldw + k];
-                    }
-                    float dv = 0.f;
-                    if (hm < nvalid) {
-                        const float v = (ACT == GOPS_ACT_GELU ? zrow : hrow)[k];
-                        dv = acc * act_bwd_t<ACT>(v, v);
-                    }
-                    da[hm * ldh + k] = dv;
-                    if (stash_d != nullptr) gptr(stash_d[L])[(row0 + hm) * K + k] = dv;
-                }
-            }
-        });
+                for (int q = 0; q < CNT; ++q) bw[q] = (kk < A) ? Wo[kk * ldw + ((nt + q) << 4) + (lane & 15)] : 0.f;   // B: W_o[k][n]
+#pragma unroll
+                for (int q = 0; q < CNT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, bw[q], acc[q], 0, 0, 0);
+                epi.template operator()<CNT>(acc, nt);
+                nt += CNT;
+            };
+            if (left >= 4) tiles.template operator()<4>();
+            else if (left >= 2) tiles.template operator()<2>();
+            else tiles.template operator()<1>();
+        }
         if (stash_dy != nullptr && tid < TB) {
             f32x4 v = {s_gy[tid * 4 + 0], s_gy[tid * 4 + 1], s_gy[tid * 4 + 2], s_gy[tid * 4 + 3]};
 #pragma unroll
@@ -106,31 +113,7 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
     // ---- hidden layers j = L-1 .. 1: delta_j = (delta_{j+1} W_j) * act'(z_j) ----
     for (int j = L - 1; j >= 1; --j) {
         const int N = M.dims[j], kch = M.dims[j + 1] >> 4, nt_tot = N >> 4;
-        const GLOBAL_AS float* hbase = gptr(stash_h[j] + row0 * N);
-        const GLOBAL_AS float* zbase = gptr(gelu ? stash_z[j] + row0 * N : stash_h[j]);
-        auto epi = [&]<int CNT>(const f32x4 (&acc)[4], int nt0) {
-            act_dispatch(M.act, [&]<int ACT>() {
-                float hv[CNT][4];
-#pragma unroll
-                for (int q = 0; q < CNT; ++q)    // issue every stash load before the math
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = ((nt0 + q) << 4) + (lane & 15), m = ((lane >> 4) << 2) + r;
-                        // GELU's derivative needs z, every other activation's needs h
-                        if constexpr (STAGED) hv[q][r] = stage_h1[(tid >> 6) * (TB * 64) + m * 64 + (n & 63)];   // j == 1 only
-                        else hv[q][r] = (m < nvalid) ? (ACT == GOPS_ACT_GELU ? zbase : hbase)[(size_t)m * N + n] : 0.f;
-                    }
-#pragma unroll
-                for (int q = 0; q < CNT; ++q) {
-                    const int n = ((nt0 + q) << 4) + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = ((lane >> 4) << 2) + r;
-                        out[m * ldh + n] = (m < nvalid) ? acc[q][r] * act_bwd_t<ACT>(hv[q][r], hv[q][r]) : 0.f;
-                    }
-                }
-            });
-        };
+        auto epi = delta_epi(j, out, stage_h1, false);   // (staged variants: L == 2, so j == 1 only)
         bool done = false;
         if constexpr (!std::is_same<W1T, NoW>::value) {
             if (j == 1) { gemm_layer_stat(cur, ldh, WT1, nt_tot, tid, epi); done = true; }
@@ -139,7 +122,6 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
         DBG_TICK(6)
         __syncthreads();
         DBG_TICK(7)
-        if (stash_d != nullptr) stash_tile(out, ldh, N, stash_d[j], row0, TB, tid);
         DBG_TICK(8)
         float* tmp = cur; cur = out; out = tmp;
     }
@@ -205,8 +187,12 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         gc_ext = gcp[0]; gc_lin = gcp[(size_t)p.B]; gc_int = gcp[(size_t)2 * p.B];
     }
     const int ld16 = (p.ldh - 4) + 8;                 // F16: leading dimension (halfs) of the delta tiles
-    const float* xrows = F16 ? p.st.xf : p.st.x;      // fp32 observation columns the env adjoints read
-    const int xld = F16 ? 8 : p.pol.kp[0];
+    // fp32 observation column i of row m of the stash tile at row0 (the env adjoints read the first few):
+    // F16 keeps a row-major [S][8] fp32 copy, the fp32 stash is feature-major
+    auto x_col = [&](size_t row0, int m, int i) -> float {
+        if constexpr (F16) return gptr(p.st.xf)[(row0 + m) * 8 + i];
+        else return gptr(p.st.x)[(row0 * p.pol.kp[0]) + i * 16 + m];
+    };
     float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // adjoint of the veh3dof state (tid < TB)
     const IdpConst IC = idp_const();
     const VehConst VC = veh_const();
@@ -266,16 +252,16 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         const float* src2 = (gelu_s ? p.st.z[2] : p.st.h[2]) + r0 * 256;
         const float* src1 = (gelu_s ? p.st.z[1] : p.st.h[1]) + r0 * 256;
         const int ln = tid & 63, wv = tid >> 6;
+        // FM tiles are 16 KiB of contiguous memory, features 64 w .. 64 w + 63 (wave w's n-tiles) 4 KiB of it
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            async_copy16_to_lds(src2 + (4 * wv + q) * 256 + 4 * ln, dst + (4 * wv + q) * 256);
-            async_copy16_to_lds(src1 + (4 * q + (ln >> 4)) * 256 + 64 * wv + 4 * (ln & 15),
-                                dst + TB * 256 + wv * (TB * 64) + q * 256);
+            async_copy16_to_lds(src2 + wv * 1024 + q * 256 + 4 * ln, dst + wv * 1024 + q * 256);
+            async_copy16_to_lds(src1 + wv * 1024 + q * 256 + 4 * ln, dst + TB * 256 + wv * 1024 + q * 256);
         }
         if (wv == 0)        // env rows: 16 x 64 B, contiguous
             async_copy16_to_lds(p.st.env + r0 * ENV_STASH + 4 * ln, dst + 2 * TB * 256);
-        if (wv == 1 && ln < 2 * TB)   // first 8 floats of every observation row
-            async_copy16_to_lds(p.st.x + (r0 + (ln >> 1)) * kp0 + 4 * (ln & 1), dst + 2 * TB * 256 + TB * ENV_STASH);
+        if (wv == 1 && ln < 2 * TB)   // first 8 observation columns: 8 x 64 B, contiguous in the FM tile -> st_x[i * 16 + m]
+            async_copy16_to_lds(p.st.x + r0 * kp0 + 4 * ln, dst + 2 * TB * 256 + TB * ENV_STASH);
     };
     if constexpr (STAGE) {
         stage_step(p.H - 1);
@@ -329,14 +315,13 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                         e0 = er[0]; e1 = er[1];
 #pragma unroll
                         for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                            if (i < O) x[i] = st_x[m * 8 + i];
+                            if (i < O) x[i] = st_x[i * 16 + m];
                     } else {
                         const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
                         e0 = er[0]; e1 = er[1];
-                        const GLOBAL_AS float* xr = gptr(xrows + (row0 + m) * xld);
 #pragma unroll
                         for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                            if (i < O) x[i] = xr[i];
+                            if (i < O) x[i] = x_col(row0, m, i);
                     }
                     th[0] = e0[0]; th[1] = e0[1]; th[2] = e0[2]; th[3] = e0[3];
                     dflag = e1[0];
@@ -574,11 +559,10 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                     float xr[6];
                     if constexpr (STAGE) {
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) xr[i] = st_x[m * 8 + i];
+                        for (int i = 0; i < 6; ++i) xr[i] = st_x[i * 16 + m];
                     } else {
-                        const GLOBAL_AS float* xg = gptr(xrows + (row0 + m) * xld);
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) xr[i] = xg[i];
+                        for (int i = 0; i < 6; ++i) xr[i] = x_col(row0, m, i);
                     }
                     if constexpr (SURR) {
                         const float* rw = p.env.reward_w;

@@ -21,7 +21,7 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
                                                      const float* in, int ld_in, float* ha, float* hb,
                                                      int ldh, int tid, const float* s_bias,
                                                      float* const* stash_h, float* const* stash_z,
-                                                     size_t row0, int nvalid, int stash_rows, DbgClock& dbg) {
+                                                     size_t row0, DbgClock& dbg) {
     const int lane = tid & 63;
     const int L = M.nl - 1;
     const float* cur = in;
@@ -32,9 +32,9 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
         const float* bias = s_bias + j * ldh;   // LDS copy of the layer's bias
         const bool save_z = (stash_z != nullptr) && (M.act == GOPS_ACT_GELU);
         float* zrow = save_z ? stash_z[j + 1] + row0 * N : nullptr;
-        // The activation tile goes to the stash straight from the epilogue registers (fire-and-forget
-        // 64-byte row segments; a wave's four n-tiles make 256 contiguous bytes per row) instead of a
-        // separate LDS -> register -> global pass after the barrier.
+        // The activation tile goes to the FM stash straight from the epilogue registers: a lane's four rows of
+        // feature n are one fire-and-forget 16-byte store, a wave's n-tile 1 KiB of contiguous memory.  All 16
+        // rows are written (rows past the batch end hold the activations of a zero observation).
         float* hrow = (stash_h != nullptr) ? stash_h[j + 1] + row0 * N : nullptr;
         auto epi = [&]<int CNT>(const f32x4 (&acc)[4], int nt0) {
             DBG_TICK(14)
@@ -42,18 +42,19 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
                 float bn[CNT];
 #pragma unroll
                 for (int q = 0; q < CNT; ++q) bn[q] = bias[((nt0 + q) << 4) + (lane & 15)];
+                const int m0 = (lane >> 4) << 2;
 #pragma unroll
                 for (int q = 0; q < CNT; ++q) {
                     const int n = ((nt0 + q) << 4) + (lane & 15);
+                    f32x4 hv, zv;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int m = ((lane >> 4) << 2) + r;
-                        const float z = acc[q][r] + bn[q];
-                        const float h = act_fwd_t<ACT>(z);
-                        out[m * ldh + n] = h;
-                        if (hrow != nullptr && m < stash_rows) __builtin_nontemporal_store(h, gptr(hrow) + (size_t)m * N + n);
-                        if (ACT == GOPS_ACT_GELU && save_z && m < nvalid) gptr(zrow)[(size_t)m * N + n] = z;
+                        zv[r] = acc[q][r] + bn[q];
+                        hv[r] = act_fwd_t<ACT>(zv[r]);
+                        out[(m0 + r) * ldh + n] = hv[r];
                     }
+                    if (hrow != nullptr) __builtin_nontemporal_store(hv, gptr(reinterpret_cast<f32x4*>(hrow + n * 16 + m0)));
+                    if (ACT == GOPS_ACT_GELU && save_z) __builtin_nontemporal_store(zv, gptr(reinterpret_cast<f32x4*>(zrow + n * 16 + m0)));
                 }
             });
         };
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                     *reinterpret_cast<const f32x4*>(xs + (tid >> 1) * ldx + 4 * (tid & 1));
             __syncthreads();
         } else {
-            if (p.need_grad) stash_tile(xs, ldx, p.pol.kp[0], p.st.x, row0, TB, tid);
+            if (p.need_grad) stash_tile_fm(xs, ldx, p.pol.kp[0], p.st.x + row0 * p.pol.kp[0], tid);
         }
         DBG_TICK(1)
         {
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 } else {
                     float* hcur = mlp_hidden_forward(p.pol, W0, W1, xs, ldx, ha, hb, ldh, tid, s_bias,
                                                      p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
-                                                     row0, nvalid, TB, dbg);
+                                                     row0, dbg);
                     DBG_TICK(2)
                     mlp_head(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ldh, tid, y);
                 }
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         } else {
             float* hcur = mlp_hidden_forward(p.val, NoW{}, NoW{}, xs, ldx, ha, hb, ldh, tid, s_bias,
                                              p.need_grad ? p.st.tail_h : nullptr,
-                                             p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, nvalid, nvalid, dbg);
+                                             p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, dbg);
             mlp_head(gptr(p.val.w[Lv]), p.val.dims[Lv], gptr(p.val.b[Lv]), p.val.dims[Lv], 1, hcur, ldh, tid, y);
         }
         if ((tid & 15) == 0) s_th[(tid >> 4) * 4] = y[0];

@@ -289,24 +289,29 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    bf16x2 v;
-    v[0] = (__bf16)lo;   // v_cvt_pk_bf16_f32: round to nearest even
-    v[1] = (__bf16)hi;
-    return __builtin_bit_cast(unsigned, v);
-}
-
-// (a, b) -> three packed bf16 pairs; a == sum of the low halves, b == sum of the high halves, exactly.
+// (a, b) -> three packed bf16 pairs (low half from a, high half from b); a == the sum of its three planes EXACTLY, and
+// so is b.  Each plane is the TRUNCATION of the running residual to its top 16 bits (8 significant bits): the residual
+// after one plane has at most 16 significant bits left, after two at most 8, so the third truncation is exact - same
+// guarantee as rounding to nearest, but on full-rate integer / add instructions only (v_perm_b32 packs the two high
+// halves; v_cvt_pk_bf16_f32 is a quarter-rate instruction and made this split the bottleneck of the GEMM).
 __device__ __forceinline__ void split3(float a, float b, unsigned (&pl)[3]) {
-    pl[0] = pack_bf16(a, b);
-    const float ra = a - __uint_as_float(pl[0] << 16), rb = b - __uint_as_float(pl[0] & 0xffff0000u);
-    pl[1] = pack_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(pl[1] << 16), sb = rb - __uint_as_float(pl[1] & 0xffff0000u);
-    pl[2] = pack_bf16(sa, sb);
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    pl[0] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
+    const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+    pl[1] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
+    pl[2] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
 }
 
 // 8 fp32 samples of one feature -> the three bf16x8 plane fragments
 __device__ __forceinline__ void split_frag(const f32x4& lo, const f32x4& hi, bf16x8 (&pl)[3]) {
+#ifdef GOPS_EXP_NOSPLIT
+    const u32x4 v0 = {__float_as_uint(lo[0]), __float_as_uint(lo[1]), __float_as_uint(lo[2]), __float_as_uint(lo[3])};
+    const u32x4 v1 = {__float_as_uint(hi[0]), __float_as_uint(hi[1]), __float_as_uint(hi[2]), __float_as_uint(hi[3])};
+    pl[0] = __builtin_bit_cast(bf16x8, v0); pl[1] = __builtin_bit_cast(bf16x8, v1); pl[2] = __builtin_bit_cast(bf16x8, v0 ^ v1);
+    return;
+#endif
     unsigned p0[3], p1[3], p2[3], p3[3];
     split3(lo[0], lo[1], p0);
     split3(lo[2], lo[3], p1);
@@ -353,9 +358,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_fm_kernel(const float* __
     const GLOBAL_AS float* Dg = gptr(D);
     const GLOBAL_AS float* Xg = gptr(X);
     const size_t dtile = (size_t)N * 16, xtile = (size_t)Kp * 16;
-    const long long blk0 = (long long)split * chunks_per_split, nblk_all = (Q + 1) >> 1;
-    const int nblk = (int)min((long long)chunks_per_split, nblk_all - blk0);   // >= 1 by construction of the split count
-    const bool odd_tail = (Q & 1) && (blk0 + nblk == nblk_all);               // the very last block has one sample tile only
+    // Split s owns the 32-sample blocks s, s + splits, s + 2 splits, ...: at any moment the resident workgroups read
+    // one contiguous window of the stash (like a streaming kernel).  Contiguous per-split ranges would walk `splits`
+    // streams in lockstep at a fixed large stride, which lands them on the same few HBM channels.
+    const long long nblk_all = (Q + 1) >> 1;
+    const int nblk = (int)((nblk_all - split + splits - 1) / splits);         // >= 1: splits <= nblk_all
+    const bool odd_tail = (Q & 1) && ((nblk_all - 1) % splits == split);      // the very last block has one sample tile only
+    auto blk_of = [&](int c) { return (long long)split + (long long)min(c, nblk - 1) * splits; };
 
     f32x4 acc[R][R] = {};
     float bsum[R];
@@ -422,13 +431,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_fm_kernel(const float* __
     };
 
 #pragma unroll
-    for (int j = 0; j < R; ++j) load_x(blk0, j);
+    for (int j = 0; j < R; ++j) load_x(blk_of(0), j);
 #pragma unroll
-    for (int i = 0; i < R; ++i) load_d(blk0, i);
+    for (int i = 0; i < R; ++i) load_d(blk_of(0), i);
     const int nfull = odd_tail ? nblk - 1 : nblk;
-    const long long last_blk = blk0 + nblk - 1;
-    for (int c = 0; c < nfull; ++c) block.template operator()<false>(min(blk0 + c + 1, last_blk));
-    if (odd_tail) block.template operator()<true>(last_blk);
+    for (int c = 0; c < nfull; ++c) block.template operator()<false>(blk_of(c + 1));
+    if (odd_tail) block.template operator()<true>(blk_of(nblk));
     float* pbase = part + (size_t)split * N * Kp;
 #pragma unroll
     for (int i = 0; i < R; ++i)
@@ -452,13 +460,132 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_fm_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same GEMM for the large layers (N % 128 == 0, Kp % 128 == 0): the operand tiles of a
+// 32-sample block (128 features x 2 sample tiles of each operand = 4 x 8 KiB of CONTIGUOUS stash memory) travel
+// HBM -> LDS with global_load_lds_dwordx4 - no register holds them - into a ring of DWR_STAGES stages, DWR_STAGES - 1
+// blocks ahead of the block being multiplied; wave w copies region w of a stage (eight 1-KiB copies).  Two stages and
+// two workgroups per CU measured best (layer-2 GEMM of the target: 103 us; four stages with one workgroup per CU 141 us:
+// with a single wave per SIMD nothing overlaps the bf16 split on the VALU with the MFMAs).
+// Every element is fetched from L2 / HBM ONCE per workgroup (the register-direct kernel above fetches it once per
+// wave that needs it).  A lane's fragment (feature f = lane & 15, samples 4 g .. 4 g + 3 of both sample tiles) is two
+// conflict-free ds_read_b128 of the LDS image; it is split into the three bf16 planes in registers and multiplied.
+// One barrier per block: it publishes block c (each wave first waits for its own copies of that block) and frees the
+// stage that block c - 1 was read from for the copies of block c + DWR_STAGES - 1.
+// ---------------------------------------------------------------------------------------------
+#define DWR_STAGES 2
+#define DWR_STAGE_FLOATS (4 * 2048)   // [D tile q0][D tile q0+1][X tile q0][X tile q0+1], each [128 features][16 rows]
+
+__global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_ring_kernel(const float* __restrict__ D, int N,
+                                                                    const float* __restrict__ X, int Kp,
+                                                                    long long Q, int splits, int chunks_per_split,
+                                                                    float* __restrict__ part,
+                                                                    float* __restrict__ part_b) {
+    extern __shared__ __attribute__((aligned(16))) float ring[];   // [DWR_STAGES][DWR_STAGE_FLOATS]
+    constexpr int T = 128, R = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_k = Kp / T, tiles = tiles_k * (N / T);
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;   // XCD-aware order, as above
+    const int tile = local % tiles, split = (local / tiles) * 8 + xcd;
+    if (split >= splits) return;
+    const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int f = lane & 15, g = lane >> 4;
+    const bool want_bias = part_b != nullptr && tile_k == 0 && wk == 0;
+    const long long nblk_all = (Q + 1) >> 1;                                  // block c of this split is block split + c * splits
+    const int nblk = (int)((nblk_all - split + splits - 1) / splits);
+    const bool odd_tail = (Q & 1) && ((nblk_all - 1) % splits == split);
+
+    // this wave's copy job: region `wave` of a stage = sample tile (wave & 1) of operand (wave >> 1)
+    const float* csrc = (wave < 2) ? D + (size_t)tile_n * T * 16 : X + (size_t)tile_k * T * 16;
+    const size_t ctile = (size_t)((wave < 2) ? N : Kp) * 16;
+    auto copy_block = [&](int c, int stage) {   // block index clamped: the copy count per block is constant
+        const long long bq = min(((long long)split + (long long)min(c, nblk - 1) * splits) * 2 + (wave & 1), Q - 1);
+        const float* src = csrc + (size_t)bq * ctile + 4 * lane;
+        const float* dst = ring + stage * DWR_STAGE_FLOATS + wave * 2048;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) async_copy16_to_lds(src + u * 256, dst + u * 256);
+    };
+
+    f32x4 acc[R][R] = {};
+    float bsum[R] = {0.f, 0.f, 0.f, 0.f};
+    auto block = [&]<bool LAST_HALF_EMPTY>(int stage) {
+        const float* st = ring + stage * DWR_STAGE_FLOATS;
+        const float* da = st + (wn * 64 + f) * 16 + 4 * g;          // D fragments of row-tile i: + 256 i  (+ 2048: second tile)
+        const float* xa = st + 4096 + (wk * 64 + f) * 16 + 4 * g;   // X fragments of column-tile j
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#ifdef GOPS_EXP_NOMFMA
+        acc[0][0] += *reinterpret_cast<const f32x4*>(xa) + *reinterpret_cast<const f32x4*>(da);
+        return;
+#endif
+        bf16x8 b[R][3];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xa + 256 * j);
+            const f32x4 x1 = LAST_HALF_EMPTY ? zero4 : *reinterpret_cast<const f32x4*>(xa + 256 * j + 2048);
+            split_frag(x0, x1, b[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(da + 256 * i);
+            const f32x4 d1 = LAST_HALF_EMPTY ? zero4 : *reinterpret_cast<const f32x4*>(da + 256 * i + 2048);
+            bf16x8 a[3];
+            split_frag(d0, d1, a);
+            bsum[i] += ((d0[0] + d0[1]) + (d0[2] + d0[3])) + ((d1[0] + d1[1]) + (d1[2] + d1[3]));
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < DWR_STAGES - 1; ++d) copy_block(d, d);
+    const int nfull = odd_tail ? nblk - 1 : nblk;
+    for (int c = 0; c < nblk; ++c) {
+        // this wave's copies of block c have landed once at most the 8 x (DWR_STAGES - 2) younger ones are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (DWR_STAGES - 2)) : "memory");
+        __syncthreads();
+        copy_block(c + DWR_STAGES - 1, (c + DWR_STAGES - 1) % DWR_STAGES);
+        if (c < nfull) block.template operator()<false>(c % DWR_STAGES);
+        else block.template operator()<true>(c % DWR_STAGES);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail copies must not outlive the workgroup's LDS
+
+    const int nb = tile_n * T + wn * 64, kb = tile_k * T + wk * 64;
+    float* pbase = part + (size_t)split * N * Kp;
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int k = kb + 16 * j + f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pbase[(size_t)(nb + 16 * i + 4 * g + r) * Kp + k] = acc[i][j][r];
+        }
+    if (want_bias) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            float t = bsum[i];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            if (g == 0) part_b[(size_t)split * N + nb + 16 * i + f] = t;
+        }
+    }
+}
+
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
                           int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s) {
     static const bool force_f32 = getenv("GOPS_DW_F32") != nullptr;   // A/B knob: fp32 MFMA GEMM
     const long long Q = (S + TB - 1) / TB;
     const int T = big ? 128 : 64, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
     const dim3 grid(tiles * ((splits + 7) / 8) * 8), block(NTHREADS);
-    if (big && !force_f32) hipLaunchKernelGGL((dw_gemm_fm_kernel<4, true>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
+    static const bool no_ring = getenv("GOPS_DW_DIRECT") != nullptr;   // A/B knob: register-direct kernel for the large layers too
+    if (big && !force_f32 && !no_ring && (N % 128) == 0 && (Kp % 128) == 0)
+        launch_with_lds(dw_gemm_ring_kernel, grid, block, (size_t)DWR_STAGES * DWR_STAGE_FLOATS * sizeof(float), s, D, N, X, Kp, Q, splits,
+                        chunks_per_split, part, part_b);
+    else if (big && !force_f32) hipLaunchKernelGGL((dw_gemm_fm_kernel<4, true>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
     else if (big) hipLaunchKernelGGL((dw_gemm_fm_kernel<4, false>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
     else if (!force_f32) hipLaunchKernelGGL((dw_gemm_fm_kernel<2, true>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
     else hipLaunchKernelGGL((dw_gemm_fm_kernel<2, false>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
@@ -658,54 +785,44 @@ __global__ __launch_bounds__(NTHREADS) void dw_out_kernel(const float* __restric
     }
 }
 
-// Feature-major fp32 h (common.h StashDev): a split is a run of whole sample tiles; thread (feature slot c, row
-// group rg = tid >> 6) reads the 16-byte vector of rows 4 rg .. 4 rg + 3 of feature k - a wave covers a contiguous
-// KiB - and multiplies it with the tile's 16 x 4 block of dy, which every thread fetches with uniform (scalar) loads.
+// Feature-major fp32 h (common.h StashDev): a split is a run of whole sample tiles; thread k owns feature k - its 16
+// rows of a tile are 64 contiguous bytes, a wave reads 4 contiguous KiB per tile - and needs no cross-thread reduction;
+// the tile's 16 x 4 block of dy is the same for every thread (uniform loads through the scalar cache).
 __global__ __launch_bounds__(NTHREADS) void dw_out_fm_kernel(const float* __restrict__ dy, const float* __restrict__ h, int K, int A,
                                                              long long Q, long long tiles_per_split,
                                                              float* __restrict__ part, float* __restrict__ part_b) {
-    __shared__ float red[4][GOPS_MAX_ACT][64];
-    __shared__ float redb[4][GOPS_MAX_ACT];
-    const int split = blockIdx.x, c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int split = blockIdx.x;
     const long long q0 = split * tiles_per_split, q1 = min(Q, q0 + tiles_per_split);
-    const int npass = (K + 63) / 64;   // uniform trip count: every lane reaches the barriers
-    for (int pass = 0; pass < npass; ++pass) {
-        const int k = c + 64 * pass;
+    for (int k = threadIdx.x; k < ((K + NTHREADS - 1) / NTHREADS) * NTHREADS; k += NTHREADS) {
         const bool col_ok = k < K;
+        const int kc = col_ok ? k : K - 1;
         float acc[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, accb[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
-        for (long long qb = q0; qb < q1; qb += 8) {   // 8 tiles' vectors in flight per thread (the kernel is latency-bound)
-            f32x4 hv[8];
+        for (long long qb = q0; qb < q1; qb += 2) {   // two tiles (8 vectors) in flight per thread
+            f32x4 hv[2][4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                hv[u] = (col_ok && qb + u < q1) ? ld4(gptr(h) + ((size_t)(qb + u) * K + k) * 16 + 4 * rg) : z;
+            for (int u = 0; u < 2; ++u) {
+                const long long q = min(qb + u, q1 - 1);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) hv[u][rg] = ld4(gptr(h) + ((size_t)q * K + kc) * 16 + 4 * rg);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 if (qb + u < q1) {
-                    const GLOBAL_AS f32x4* gp = gptr(reinterpret_cast<const f32x4*>(dy)) + (size_t)(qb + u) * 16 + 4 * rg;   // rows 4 rg .. +3: [4][4]
+                    const f32x4* gp = reinterpret_cast<const f32x4*>(dy) + (size_t)(qb + u) * 16;   // uniform: [16 rows][4]
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const f32x4 g = gp[r];
+                    for (int m = 0; m < 16; ++m) {
+                        const f32x4 g = gp[m];
 #pragma unroll
-                        for (int a = 0; a < GOPS_MAX_ACT; ++a) { acc[a] += g[a] * hv[u][r]; accb[a] += g[a]; }
+                        for (int a = 0; a < GOPS_MAX_ACT; ++a) { acc[a] += g[a] * hv[u][m >> 2][m & 3]; accb[a] += g[a]; }
                     }
                 }
             }
         }
-#pragma unroll
-        for (int a = 0; a < GOPS_MAX_ACT; ++a) red[rg][a][c] = acc[a];
-        if (c == 0 && pass == 0)
-            for (int a = 0; a < GOPS_MAX_ACT; ++a) redb[rg][a] = accb[a];
-        __syncthreads();
-        if (rg == 0 && col_ok) {
-            for (int a = 0; a < A; ++a)
-                part[((size_t)split * A + a) * K + k] = (red[0][a][c] + red[1][a][c]) + (red[2][a][c] + red[3][a][c]);
+        if (col_ok) {
+            for (int a = 0; a < A; ++a) part[((size_t)split * A + a) * K + k] = acc[a];
             if (k == 0)
-                for (int a = 0; a < A; ++a)
-                    part_b[(size_t)split * A + a] = (redb[0][a] + redb[1][a]) + (redb[2][a] + redb[3][a]);
+                for (int a = 0; a < A; ++a) part_b[(size_t)split * A + a] = accb[a];
         }
-        __syncthreads();
     }
 }
 

@@ -49,7 +49,7 @@ struct MlpDev {
 struct StashDev {
     float* x;                         // FM [S/16][kp0][16]  policy input rows (obs_t | t+1 | 0-pad)
     float* h[GOPS_MAX_LAYERS];        // h[j] (j=1..L): FM [S/16][dims[j]][16] hidden activations
-    float* z[GOPS_MAX_LAYERS];        // pre-activations, only for GELU
+    float* z[GOPS_MAX_LAYERS];        // only for GELU: gelu'(z_j) (formed by the forward epilogue together with gelu(z_j))
     float* d[GOPS_MAX_LAYERS];        // d[j] (j=1..L): FM [S/16][dims[j]][16] adjoint of z_j
     float* dy;                        // [S][4] adjoint of the head pre-activation
     float* env;                       // [S][ENV_STASH]
@@ -141,6 +141,25 @@ __device__ __forceinline__ float f16_grad_scale(float m) {
 #define SELU_SCALE 1.0507009873554804934193349852946f
 #define SELU_ALPHA 1.6732632423543772848170429916717f
 
+// gelu(z) and gelu'(z) from ONE exponential: Phi(-|z|) = erfc(|z| / sqrt 2) / 2 by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7 on erfc: fp32 round-off class, far inside the 1e-4 parity bar) and
+// phi(z) = exp(-z^2/2) / sqrt(2 pi) with the same exponential.  ~17 branch-free VALU ops for both values (libm's
+// erff + expf are ~100 with divergent branches, and were the largest VALU item of the GELU workloads).  The forward
+// epilogue stashes gelu'(z) in the Z tensor, so the backward sweep evaluates no transcendental at all.
+__device__ __forceinline__ void gelu_pair(float z, float& h, float& dh) {
+    const float x = fabsf(z) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
+    const float e = __expf(-0.5f * z * z);
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float q = (0.5f * t) * poly * e;       // Phi(-|z|)
+    const float cdf = z < 0.f ? q : 1.f - q;
+    h = z * cdf;
+    dh = fmaf(z * 0.39894228040143267794f, e, cdf);
+}
+
 // ELU / SELU negative branch: exp(min(z,0)) - 1 on the hardware exponential (v_exp_f32, ~1 ulp of a
 // value <= 1, i.e. absolute error <= 1.2e-7 - fp32 round-off class, far inside the 1e-4 parity
 // bar) and written as max(z,0) + (e - 1) so that no lane diverges: for z > 0, e == 1 exactly.
@@ -148,23 +167,19 @@ template <int ACT>
 __device__ __forceinline__ float act_fwd_t(float z) {
     if (ACT == GOPS_ACT_RELU) return fmaxf(z, 0.f);
     if (ACT == GOPS_ACT_ELU) return fmaxf(z, 0.f) + (__expf(fminf(z, 0.f)) - 1.f);
-    if (ACT == GOPS_ACT_GELU) return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
+    if (ACT == GOPS_ACT_GELU) { float h, dh; gelu_pair(z, h, dh); return h; }
     if (ACT == GOPS_ACT_SELU) return SELU_SCALE * (fmaxf(z, 0.f) + SELU_ALPHA * (__expf(fminf(z, 0.f)) - 1.f));
     if (ACT == GOPS_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
     if (ACT == GOPS_ACT_TANH) return tanhf(z);
     return z;
 }
 
-// derivative act'(z); `h` is the stashed activation act(z), `z` only valid for GELU
+// derivative act'(z); `h` is the stashed activation act(z); for GELU `z` is the stashed DERIVATIVE (see gelu_pair)
 template <int ACT>
 __device__ __forceinline__ float act_bwd_t(float h, float z) {
     if (ACT == GOPS_ACT_RELU) return h > 0.f ? 1.f : 0.f;
     if (ACT == GOPS_ACT_ELU) return h > 0.f ? 1.f : h + 1.f;
-    if (ACT == GOPS_ACT_GELU) {
-        const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
-        const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
-        return cdf + z * pdf;
-    }
+    if (ACT == GOPS_ACT_GELU) return z;
     if (ACT == GOPS_ACT_SELU) return h > 0.f ? SELU_SCALE : h + SELU_SCALE * SELU_ALPHA;
     if (ACT == GOPS_ACT_SIGMOID) return h * (1.f - h);
     if (ACT == GOPS_ACT_TANH) return 1.f - h * h;

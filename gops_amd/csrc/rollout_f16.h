@@ -27,22 +27,7 @@ __device__ __forceinline__ f16x8 zero8h() {
     return z;
 }
 
-// gelu(z) and gelu'(z) from ONE exponential: Phi(-|z|) = erfc(|z|/sqrt 2)/2 by Abramowitz-Stegun
-// 7.1.26 (|error| <= 1.5e-7 on erfc, i.e. far below half's 2^-11 rounding of the result) and
-// phi(z) = exp(-z^2/2)/sqrt(2 pi) with the same exp(-z^2/2).  ~17 VALU ops for both values.
-__device__ __forceinline__ void gelu_pair(float z, float& h, float& dh) {
-    const float x = fabsf(z) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
-    const float e = __expf(-0.5f * z * z);
-    float poly = fmaf(t, 1.061405429f, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float q = (0.5f * t) * poly * e;       // Phi(-|z|)
-    const float cdf = z < 0.f ? q : 1.f - q;
-    h = z * cdf;
-    dh = fmaf(z * 0.39894228040143267794f, e, cdf);
-}
+// (gelu_pair: common.h)
 
 // acc[j] (n-tile j of quad q, see the header) += W_quad * act^T over kch chunks of 32 inputs.  The
 // weight fragments stream from L2 through a ring of PF chunks (L2 latency >> the 4 MFMAs of a chunk).  Measured

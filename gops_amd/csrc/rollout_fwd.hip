@@ -49,8 +49,11 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
                     f32x4 hv, zv;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        zv[r] = acc[q][r] + bn[q];
-                        hv[r] = act_fwd_t<ACT>(zv[r]);
+                        const float z = acc[q][r] + bn[q];
+                        float hr, dr = z;
+                        if constexpr (ACT == GOPS_ACT_GELU) gelu_pair(z, hr, dr);   // dr: gelu'(z), what the sweep needs
+                        else hr = act_fwd_t<ACT>(z);
+                        hv[r] = hr; zv[r] = dr;
                         out[(m0 + r) * ldh + n] = hv[r];
                     }
                     if (hrow != nullptr) __builtin_nontemporal_store(hv, gptr(reinterpret_cast<f32x4*>(hrow + n * 16 + m0)));

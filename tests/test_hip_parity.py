@@ -157,7 +157,7 @@ def test_infadp_vs_reference_fixture(name, dev):
     vn.backward(ddev["obs"], (2.0 / B) * (vo - backup), gw, gb)
     torch.cuda.synchronize()
     assert abs(loss_v - float(g["pev_loss"])) <= TOL * max(1.0, abs(float(g["pev_loss"])))
-    assert abs(vo.mean().item() - float(g["pev_vmean"])) <= TOL
+    assert abs(vo.mean().item() - float(g["pev_vmean"])) <= TOL * max(1.0, abs(float(g["pev_vmean"])))   # (trained idp: mean value 989)
     k = 0
     for w_, b_ in zip(gw, gb):
         for t in (w_, b_):

@@ -451,7 +451,12 @@ def test_opt_controller_solves_lq_regulation():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [dict(B=100, sizes=[10, 64, 64, 20], act="gelu"), dict(B=4096, sizes=[46, 256, 256, 60], act="elu"),
-                                  dict(B=17, sizes=[6, 32, 7], act="tanh"), dict(B=1, sizes=[4, 16, 48, 32, 130], act="relu")],
+                                  dict(B=17, sizes=[6, 32, 7], act="tanh"), dict(B=1, sizes=[4, 16, 48, 32, 130], act="relu"),
+                                  # weight-gradient GEMM variants: LDS-ring kernel with an odd number of 16-sample tiles (B = 4000
+                                  # -> 250 tiles, 272 -> 17), register-direct kernel with 128-tiles and ragged edges (192, 144 wide)
+                                  # and with 64-tiles; the output layer's GEMM sees Wp = 144 / 16 / 256
+                                  dict(B=4000, sizes=[30, 128, 256, 130], act="elu"), dict(B=272, sizes=[128, 256, 128, 3], act="relu"),
+                                  dict(B=1000, sizes=[20, 192, 144, 256], act="selu"), dict(B=48, sizes=[16, 64, 96, 64, 5], act="sigmoid")],
                          ids=lambda c: f"B{c['B']}-{'x'.join(map(str, c['sizes']))}-{c['act']}")
 def test_wide_output_mlp_matches_torch(case):
     """gops_mlp_forward / _backward (FiniteHorizonFullPolicy's evaluation in FHADP2: output width = act_dim * H, odd

@@ -30,8 +30,9 @@ class WrappedEnvModel:
     constants for the fused horizon rollout."""
 
     def __init__(self, model, *, min_action, max_action, clip_obs: bool,
-                 reward_scale: Optional[float], reward_shift: Optional[float]):
+                 reward_scale: Optional[float], reward_shift: Optional[float], obs_scale=None, obs_shift=None):
         self.model = model
+        self.obs_scale, self.obs_shift = obs_scale, obs_shift   # ScaleObservationModel constants (None: no such wrapper)
         self.min_action = torch.zeros_like(model.action_lower_bound) + torch.as_tensor(
             min_action, dtype=torch.float32, device=model.action_lower_bound.device)
         self.max_action = torch.zeros_like(model.action_upper_bound) + torch.as_tensor(
@@ -64,7 +65,8 @@ class WrappedEnvModel:
                 obs_low=m.obs_lower_bound.cpu() if (self.clip_obs or data_env) else None,
                 obs_high=m.obs_upper_bound.cpu() if (self.clip_obs or data_env) else None,
                 pre_horizon=getattr(m, "pre_horizon", 0), reward_scale=self.reward_scale,
-                reward_shift=self.reward_shift, data_env=data_env, **m.hip_constants())
+                reward_shift=self.reward_shift, data_env=data_env, obs_scale=self.obs_scale, obs_shift=self.obs_shift,
+                **m.hip_constants())
         return self._env_cache[key]
 
     def forward(self, obs: torch.Tensor, action: torch.Tensor, done: torch.Tensor, info: Dict
@@ -105,8 +107,10 @@ def create_env_model(
     # wrapper options outside the fused kernels' contract are refused, never silently ignored
     if repeat_num is not None:
         raise RuntimeError("ActionRepeatModel (repeat_num) is not supported by the HIP env models")
-    if obs_shift is not None or obs_scale is not None:
-        raise RuntimeError("ScaleObservationModel (obs_shift/obs_scale) is not supported by the HIP env models")
+    scaled = obs_shift is not None or obs_scale is not None
+    if scaled and (env_model.obs_dim > 8 or env_model.hip_kind not in (hb.ENV_LQ, hb.ENV_IDP)):
+        raise RuntimeError("ScaleObservationModel (obs_shift/obs_scale) is supported for pyth_lq / pyth_idpendulum only "
+                           "(observation dimension <= 8) by the HIP env models")
     if not mask_at_done:
         raise RuntimeError("mask_at_done=False is not supported by the HIP env models")
     # action_scale=True with clip_action=False needs no flag: ScaleActionModel already ends with
@@ -121,7 +125,10 @@ def create_env_model(
     return WrappedEnvModel(
         env_model, min_action=min_action, max_action=max_action, clip_obs=clip_obs,
         reward_scale=(1.0 if reward_scale is None else reward_scale) if shaping else None,
-        reward_shift=(0.0 if reward_shift is None else reward_shift) if shaping else None)
+        reward_shift=(0.0 if reward_shift is None else reward_shift) if shaping else None,
+        # create_env_model.py:115-118: either one given -> the wrapper is applied with the other at its neutral value
+        obs_scale=(1.0 if obs_scale is None else obs_scale) if scaled else None,
+        obs_shift=(0.0 if obs_shift is None else obs_shift) if scaled else None)
 
 
 # fill the registry: every env/env_*/env_model/<id>.py exporting env_model_creator or the CamelCase class

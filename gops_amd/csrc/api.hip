@@ -176,6 +176,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     }
     if (desc.tail_value && (rc = check_mlp(desc.value, e.obs_dim, 1, f16)) != GOPS_OK) return rc;
     if (e.kind == GOPS_ENV_NONE && (desc.horizon != 1 || desc.tail_value || desc.finite_horizon)) return GOPS_ERR_BAD_ARG;
+    if (e.scale_obs && e.kind != GOPS_ENV_LQ && e.kind != GOPS_ENV_IDPENDULUM) return GOPS_ERR_UNSUPPORTED;   // obs_dim <= 8 only
     if (e.kind == GOPS_ENV_LQ && (e.obs_dim > GOPS_MAX_LQ_STATE || e.act_dim > GOPS_MAX_ACT)) return GOPS_ERR_UNSUPPORTED;
     if (e.kind == GOPS_ENV_IDPENDULUM && (e.obs_dim != 6 || e.act_dim != 1 || e.clip_obs)) return GOPS_ERR_BAD_ARG;
     if (e.kind == GOPS_ENV_VEH3DOFCONTI &&
@@ -563,6 +564,7 @@ int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void*
         (!io->state || !io->ref_points || !io->path_num || !io->u_num || !io->ref_time ||
          !io->next_state || !io->next_ref_points || !io->next_ref_time)) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_LQ && env->obs_dim > GOPS_MAX_LQ_STATE) return GOPS_ERR_UNSUPPORTED;
+    if (env->scale_obs && env->kind != GOPS_ENV_LQ && env->kind != GOPS_ENV_IDPENDULUM) return GOPS_ERR_UNSUPPORTED;
     return (int)launch_env_step(*env, batch, *io, pdt_of(*env), static_cast<hipStream_t>(stream));
 }
 

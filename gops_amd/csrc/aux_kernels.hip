@@ -1032,10 +1032,10 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
     float* nob = io.next_obs + (size_t)b * O;
     if (env.kind == GOPS_ENV_LQ) {
         float x[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xn[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < O; ++i) x[i] = ob[i];
+        for (int i = 0; i < O; ++i) x[i] = obs_unscale(env, i, ob[i]);
         lq_forward(env, x, u, xn, r);
         for (int i = 0; i < O; ++i) {
-            const float v = dn ? x[i] : xn[i];
+            const float v = obs_rescale(env, i, dn ? x[i] : xn[i]);
             nob[i] = (env.clip_obs && !data) ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
             // data env (lq_base.py:224-231, 236-239): done when the NEXT state leaves the state bounds
             if (data && env.clip_obs && (xn[i] > env.obs_high[i] || xn[i] < env.obs_low[i])) done_m = true;   // clip_obs: bounds are finite
@@ -1044,7 +1044,7 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
     } else if (env.kind == GOPS_ENV_IDPENDULUM) {   // data env == model (pyth_idpendulum.py:71-87 calls the model's Dynamics)
         const IdpConst IC = idp_const();
         float s[6], sn[6], s0[6];
-        for (int i = 0; i < 6; ++i) s0[i] = s[i] = ob[i];
+        for (int i = 0; i < 6; ++i) s0[i] = s[i] = obs_unscale(env, i, ob[i]);
         IdpSub w;
         for (int k = 0; k < 5; ++k) {   // same arithmetic as the rollout kernels (one sincosf pair, then rotations)
             if (k == 0) idp_substep<true>(IC, s, 500.f * u[0], 0.002f, sn, w);
@@ -1054,7 +1054,7 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         }
         r = idp_reward(s, u[0]);
         done_m = idp_done(IC, s);
-        for (int i = 0; i < 6; ++i) nob[i] = dn ? s0[i] : s[i];
+        for (int i = 0; i < 6; ++i) nob[i] = (dn && !env.scale_obs) ? ob[i] : obs_rescale(env, i, dn ? s0[i] : s[i]);
     } else if (env.kind == GOPS_ENV_VEH3DOFCONTI || env.kind == GOPS_ENV_VEH3DOF_SURR) {
         const bool surr = env.kind == GOPS_ENV_VEH3DOF_SURR;
         const VehConst VC = veh_const();

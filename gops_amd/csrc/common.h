@@ -251,6 +251,10 @@ __device__ __forceinline__ float wrap_action_bwd(const GopsEnv& e, int i, float 
     return g;
 }
 
+// ScaleObservationModel (scale_observation.py:107-119): what the model steps / what the caller sees
+__device__ __forceinline__ float obs_unscale(const GopsEnv& e, int i, float o) { return e.scale_obs ? o / e.obs_scale[i] - e.obs_shift[i] : o; }
+__device__ __forceinline__ float obs_rescale(const GopsEnv& e, int i, float x) { return e.scale_obs ? (x + e.obs_shift[i]) * e.obs_scale[i] : x; }
+
 // ((x + pi) mod 2pi) - pi with Python/torch remainder semantics (gops/utils/math_utils.py:8-11)
 __device__ __forceinline__ float angle_normalize(float x) {
     const float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f;

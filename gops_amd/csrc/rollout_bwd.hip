@@ -129,15 +129,21 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
     if (want_gx) {
         const int kch = M.dims[1] >> 4, nt_tot = M.kp[0] >> 4;
         auto epi = [&]<int CNT>(const f32x4 (&acc)[4], int nt0) {
+            // every read of the tile first, then the adds, then the writes: as `G[..] += acc` hipcc serialises the 4 CNT
+            // read-modify-writes (each a full LDS round trip) because it cannot prove the addresses distinct
+            float gold[CNT][4];
+#pragma unroll
+            for (int q = 0; q < CNT; ++q) {
+                const int n = min(((nt0 + q) << 4) + (lane & 15), ncols - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gold[q][r] = G[(((lane >> 4) << 2) + r) * ldg + n];
+            }
 #pragma unroll
             for (int q = 0; q < CNT; ++q) {
                 const int n = ((nt0 + q) << 4) + (lane & 15);
                 if (n < ncols) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = ((lane >> 4) << 2) + r;
-                        G[m * ldg + n] += acc[q][r];
-                    }
+                    for (int r = 0; r < 4; ++r) G[(((lane >> 4) << 2) + r) * ldg + n] = gold[q][r] + acc[q][r];
                 }
             }
         };
@@ -325,6 +331,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                     }
                     th[0] = e0[0]; th[1] = e0[1]; th[2] = e0[2]; th[3] = e0[3];
                     dflag = e1[0];
+#pragma unroll
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                        if (i < O) x[i] = obs_unscale(p.env, i, x[i]);   // the stash holds the (scaled) policy input
                 }
                 float abar[GOPS_MAX_ACT], u[GOPS_MAX_ACT], sc[GOPS_MAX_ACT], gu[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -344,9 +353,14 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                         lq_forward(p.env, x, u, xn, rdummy);
 #pragma unroll
                         for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) {
-                            const float pre = dn ? x[i] : xn[i];
+                            const float pre = obs_rescale(p.env, i, dn ? x[i] : xn[i]);   // what ClipObservation saw
                             if (i < O && !(pre >= p.env.obs_low[i] && pre <= p.env.obs_high[i])) Gin[i] = 0.f;
                         }
+                    }
+                    if (p.env.scale_obs) {   // d(scaled next obs) / d(next obs) = scale
+#pragma unroll
+                        for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                            if (i < O) Gin[i] *= p.env.obs_scale[i];
                     }
                     float gxn[GOPS_MAX_LQ_STATE];
 #pragma unroll
@@ -355,6 +369,10 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 } else {
                     // Recompute the 5 Euler sub-steps once, parking each sub-step's input state and
                     // intermediates (M^-1, qdd, sin/cos) in LDS; then walk them backwards from there.
+                    if (p.env.scale_obs) {   // d(scaled next obs) / d(next obs) = scale
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) Gin[i] *= p.env.obs_scale[i];
+                    }
                     float* park = s_idp + m * (5 * 24);
                     float sc_[6], sn_[6];
 #pragma unroll
@@ -406,7 +424,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 }
 #pragma unroll
                 for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                    if (i < O) G[m * ldx + i] = gx[i];
+                    if (i < O) G[m * ldx + i] = p.env.scale_obs ? gx[i] / p.env.obs_scale[i] : gx[i];   // d(obs / scale - shift) / d(obs)
 #pragma unroll
                 for (int a = 0; a < GOPS_MAX_ACT; ++a)
                     s_gy[m * 4 + a] = (a < A) ? (p.open_loop == 2 ? gu[a] : wrap_action_bwd(p.env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a])) : 0.f;

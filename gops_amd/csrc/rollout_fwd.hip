@@ -277,18 +277,19 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 const int m = tid;
                 float x[GOPS_MAX_LQ_STATE], xn[GOPS_MAX_LQ_STATE], u[GOPS_MAX_ACT];
 #pragma unroll
-                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { x[i] = (i < O) ? xs[m * ldx + i] : 0.f; xn[i] = 0.f; }
+                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { x[i] = (i < O) ? obs_unscale(p.env, i, xs[m * ldx + i]) : 0.f; xn[i] = 0.f; }
 #pragma unroll
                 for (int j = 0; j < GOPS_MAX_ACT; ++j) u[j] = (j < A) ? s_act[m * 4 + j] : 0.f;
                 lq_forward(p.env, x, u, xn, r);
-                if (s_done[m] == 0.f) {
+                // MaskAtDone freezes the (unscaled) observation; ScaleObservation rescales, ClipObservation clips the result
+                const bool frozen = s_done[m] != 0.f;
+                if (!frozen || p.env.clip_obs || p.env.scale_obs) {
 #pragma unroll
                     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                        if (i < O) xs[m * ldx + i] = p.env.clip_obs ? clampf(xn[i], p.env.obs_low[i], p.env.obs_high[i]) : xn[i];
-                } else if (p.env.clip_obs) {
-#pragma unroll
-                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                        if (i < O) xs[m * ldx + i] = clampf(x[i], p.env.obs_low[i], p.env.obs_high[i]);
+                        if (i < O) {
+                            const float v = obs_rescale(p.env, i, frozen ? x[i] : xn[i]);
+                            xs[m * ldx + i] = p.env.clip_obs ? clampf(v, p.env.obs_low[i], p.env.obs_high[i]) : v;
+                        }
                 }
             }
         } else if (ENV == GOPS_ENV_IDPENDULUM) {
@@ -296,7 +297,10 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 const int m = tid;
                 float s[6], sn[6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) s[i] = xs[m * ldx + i];
+                for (int i = 0; i < 6; ++i) s[i] = obs_unscale(p.env, i, xs[m * ldx + i]);
+                float s_in[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) s_in[i] = s[i];
                 const float a = s_act[m * 4];
                 const float u = 500.f * a;
                 IdpSub w;
@@ -314,7 +318,10 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 done_m = idp_done(IC, s);
                 if (s_done[m] == 0.f) {
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) xs[m * ldx + i] = s[i];
+                    for (int i = 0; i < 6; ++i) xs[m * ldx + i] = obs_rescale(p.env, i, s[i]);
+                } else if (p.env.scale_obs) {   // frozen rows pass through unscale / rescale like in the reference
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) xs[m * ldx + i] = obs_rescale(p.env, i, s_in[i]);
                 }
             }
         } else {   // GOPS_ENV_VEH3DOFCONTI: all 256 threads, thread = (trajectory m, part)

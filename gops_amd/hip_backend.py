@@ -57,7 +57,7 @@ class GopsEnv(C.Structure):
                 ("no_mask_at_done", C.c_int32), ("n_surr", C.c_int32), ("n_constraint", C.c_int32), ("surr_penalty", C.c_int32),
                 ("veh_length", C.c_float), ("veh_width", C.c_float),
                 ("road_upper", C.c_float), ("road_lower", C.c_float), ("reward_w", C.c_float * 8),
-                ("data_env", C.c_int32)]
+                ("data_env", C.c_int32), ("scale_obs", C.c_int32), ("obs_scale", C.c_float * 8), ("obs_shift", C.c_float * 8)]
 
 
 class GopsRolloutDesc(C.Structure):
@@ -201,12 +201,26 @@ def make_mlp_grad(gw: Sequence[torch.Tensor], gb: Sequence[torch.Tensor]) -> Gop
 def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_action=-1.0, max_action=1.0,
              policy_low=None, policy_high=None, obs_low=None, obs_high=None, pre_horizon: int = 0,
              reward_scale: Optional[float] = None, reward_shift: Optional[float] = None,
-             lq: Optional[Dict] = None, data_env: bool = False, surr: Optional[Dict] = None) -> GopsEnv:
+             lq: Optional[Dict] = None, data_env: bool = False, surr: Optional[Dict] = None,
+             obs_scale=None, obs_shift=None) -> GopsEnv:
     """Constants of the wrapped env model (create_env_model.py:86-128) as a C struct.  `data_env=True` (for
     `env_step` only): the DATA environment's termination tests / terminal penalty instead of the model's; obs_low /
     obs_high are then the data env's state bounds (pyth_lq) and are NOT applied as a clip."""
     e = GopsEnv()
     e.data_env = int(bool(data_env))
+    if obs_scale is not None or obs_shift is not None:   # ScaleObservationModel: obs seen = (obs + shift) * scale
+        if obs_dim > 8:
+            raise RuntimeError("obs_scale / obs_shift: observation dimension > 8 is not supported by the HIP env models")
+
+        def bo(v, default):
+            v = torch.as_tensor(default if v is None else v, dtype=torch.float32).reshape(-1)
+            if v.numel() not in (1, obs_dim):
+                raise RuntimeError(f"obs_scale / obs_shift must be scalars or have {obs_dim} entries")
+            return (v.expand(obs_dim) if v.numel() == 1 else v).tolist() + [0.0] * (8 - obs_dim)
+        e.scale_obs = 1
+        _fill(e.obs_scale, bo(obs_scale, 1.0)); _fill(e.obs_shift, bo(obs_shift, 0.0))
+        for i in range(obs_dim, 8):
+            e.obs_scale[i] = 1.0
     if surr is not None:   # ENV_VEH_SURR: surrounding vehicles, constraint geometry, reward weights
         e.n_surr, e.n_constraint = int(surr["n_surr"]), int(surr["n_constraint"])
         e.veh_length, e.veh_width = float(surr["veh_length"]), float(surr["veh_width"])

@@ -63,6 +63,11 @@ class DeviceEnvSampler:
         if self._pool is None or self._pool_pos + k > size:
             host = make_batch(self.cfg, self.seed + 7919 * self._pools_made, batch=size)
             self._pool = {key: v.to(self.device) for key, v in host.items() if key == "obs" or key in _INFO}
+            # ScaleObservationData (scale_observation.py:53-62): the sampler hands out (obs + shift) * scale
+            sc, sh = getattr(self.env_model, "obs_scale", None), getattr(self.env_model, "obs_shift", None)
+            if sc is not None or sh is not None:
+                as_t = lambda v, d: torch.as_tensor(d if v is None else v, dtype=torch.float32, device=self.device)  # noqa: E731
+                self._pool["obs"] = (self._pool["obs"] + as_t(sh, 0.0)) * as_t(sc, 1.0)
             self._pool_pos, self._pools_made = 0, self._pools_made + 1
         sl = slice(self._pool_pos, self._pool_pos + k)
         self._pool_pos += k

@@ -137,6 +137,12 @@ typedef struct GopsEnv {
      * (veh3dofconti, lq), no observation clipping and no MaskAtDone (an episode that is done gets reset by the caller:
      * the `done` input is ignored). */
     int32_t data_env;
+    /* ScaleObservationModel (gops/env/wrapper/scale_observation.py:74-119; create_env_model.py:115-118 puts it between
+     * ShapingReward and ClipObservation): the observations the policy and the caller see are (obs + obs_shift) * obs_scale;
+     * the model steps obs / obs_scale - obs_shift.  GOPS_ENV_LQ / GOPS_ENV_IDPENDULUM only (obs_dim <= 8).  As in the
+     * reference, ClipObservationModel then clips the SCALED observation with the model's own (unscaled) bounds. */
+    int32_t scale_obs;
+    float obs_scale[8], obs_shift[8];
 } GopsEnv;
 
 typedef struct GopsRolloutDesc {

@@ -117,8 +117,26 @@ def save(name, **arrays):
 # ------------------------------------------------------------------------------------------
 # 1. single wrapped env-model steps (next_obs / reward / done; next state for veh3dof)
 # ------------------------------------------------------------------------------------------
-def golden_steps():
-    cases = {
+OBS_SCALE_STEP_CASES = {   # ScaleObservationModel (example_train/fhadp/fhadp_mlp_lqs3a1_serial.py: obs_scale [1, 2, 0.5]; lqs5a1: 10)
+    "step_lq_s3a1_obsscale": (dict(env_id="pyth_lq", lq_config="s3a1"), dict(obs_scale=[1, 2, 0.5])),
+    "step_lq_s5a1_obsscale_shift": (dict(env_id="pyth_lq", lq_config="s5a1"),
+                                    dict(obs_scale=10, obs_shift=[0.1, -0.2, 0.05, 0.0, 0.3], reward_scale=0.5, reward_shift=1.0)),
+    "step_idp_obsscale_shift": (dict(env_id="pyth_idpendulum"), dict(obs_scale=[1, 2, 2, 0.5, 0.5, 0.25], obs_shift=0.1)),
+}
+OBS_SCALE_SMALL = {
+    "fhadp_lq_s3a1_obsscale": (dict(alg="FHADP", env_id="pyth_lq", lq_config="s3a1", batch=40, horizon=20,
+                                    hidden=(64, 64), act="elu", gamma=0.99), dict(obs_scale=[1, 2, 0.5])),
+    "infadp_lq_s5a1_obsscale_shift": (dict(alg="INFADP", env_id="pyth_lq", lq_config="s5a1", batch=48, horizon=8,
+                                           hidden=(64, 64), act="gelu", gamma=0.99),
+                                      dict(obs_scale=10, obs_shift=[0.1, -0.2, 0.05, 0.0, 0.3])),
+    "fhadp_idp_obsscale_shift": (dict(alg="FHADP", env_id="pyth_idpendulum", batch=33, horizon=12,
+                                      hidden=(64, 64), act="tanh", gamma=1.0),
+                                 dict(obs_scale=[1, 2, 2, 0.5, 0.5, 0.25], obs_shift=0.1, reward_scale=0.1)),
+}
+
+
+def golden_steps(cases=None):
+    cases = cases or {
         "step_lq_s4a2": (dict(env_id="pyth_lq", lq_config="s4a2"), {}),
         "step_lq_s6a3": (dict(env_id="pyth_lq", lq_config="s6a3"), {}),
         "step_lq_s2a1_shaped": (dict(env_id="pyth_lq", lq_config="s2a1"),
@@ -524,7 +542,10 @@ def golden_data_envs():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale"]
+    if "obsscale" in which:
+        golden_steps(OBS_SCALE_STEP_CASES)
+        golden_small(OBS_SCALE_SMALL)
     if "penalty" in which:
         golden_constrained(PENALTY_STEP_CASES, PENALTY_ALG_CASES)
         golden_small(PENALTY_SMALL)

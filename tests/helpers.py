@@ -13,7 +13,8 @@ def oracle_env(cfg, extra, golden=None):
     get amplified by long unstable LQ horizons) are taken from it instead of being recomputed."""
     env = orc.make_env(cfg["env_id"], lq_config=cfg.get("lq_config", "s4a2"),
                        pre_horizon=cfg.get("pre_horizon", 10), surr_veh_num=cfg.get("surr_veh_num"),
-                       reward_scale=extra.get("reward_scale"), reward_shift=extra.get("reward_shift"))
+                       reward_scale=extra.get("reward_scale"), reward_shift=extra.get("reward_shift"),
+                       obs_scale=extra.get("obs_scale"), obs_shift=extra.get("obs_shift"))
     if golden is not None and "const/lq_inv_IA" in golden:
         env["lq"]["inv_IA"] = torch.from_numpy(np.array(golden["const/lq_inv_IA"]))
     return env
@@ -89,7 +90,9 @@ def hip_env_from_oracle(env, policy_net=None):
                        policy_high=None if policy_net is None else policy_net["act_high"],
                        obs_low=env["obs_low"], obs_high=env["obs_high"], pre_horizon=env.get("P", 0),
                        reward_scale=env["reward_scale"] if env["shaping"] else None,
-                       reward_shift=env["reward_shift"] if env["shaping"] else None, lq=lq, surr=surr)
+                       reward_shift=env["reward_shift"] if env["shaping"] else None, lq=lq, surr=surr,
+                       obs_scale=env["obs_scale"] if env.get("scale_obs") else None,
+                       obs_shift=env["obs_shift"] if env.get("scale_obs") else None)
 
 
 def hip_mlp_from_net(net, device):

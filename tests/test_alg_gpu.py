@@ -46,7 +46,8 @@ def _load_alg(name):
 
 
 @pytest.mark.parametrize("name", ["fhadp_idp_gelu", "fhadp_veh_p10_elu", "fhadp_lq_s4a2_tanh",
-                                  "fhadp_idp_selu_shaped", "fhadp_surrpen_p10_elu"])
+                                  "fhadp_idp_selu_shaped", "fhadp_surrpen_p10_elu", "fhadp_lq_s3a1_obsscale",
+                                  "fhadp_idp_obsscale_shift"])
 def test_fhadp_class_matches_reference(name):
     alg, g, cfg = _load_alg(name)
     alg.gamma = cfg["gamma"]
@@ -64,7 +65,7 @@ def test_fhadp_class_matches_reference(name):
     assert any((a - b).abs().max() > 0 for a, b in zip(after, before))
 
 
-@pytest.mark.parametrize("name", ["infadp_lq_s4a2_gelu", "infadp_veh_p10_relu"])
+@pytest.mark.parametrize("name", ["infadp_lq_s4a2_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift"])
 def test_infadp_class_matches_reference(name):
     alg, g, cfg = _load_alg(name)
     alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]

@@ -16,11 +16,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 STEP_CASES = ["step_lq_s4a2", "step_lq_s6a3", "step_lq_s2a1_shaped", "step_idp", "step_veh_p10",
-              "step_veh_p30"]
+              "step_veh_p30",
+              # ScaleObservationModel in the chain (obs_scale / obs_shift of the lqs3a1 / lqs5a1 example scripts)
+              "step_lq_s3a1_obsscale", "step_lq_s5a1_obsscale_shift", "step_idp_obsscale_shift"]
 FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fhadp_idp_selu_shaped",
                "fhadp_veh_p10_elu", "fhadp_veh_p30_sigmoid",
                # plain FHADP on the collision-penalty model (pyth_veh3dofconti_surrcstr_penalty)
                "fhadp_surrpen_p10_elu", "fhadp_surrpen_p25_gelu",
+               # ScaleObservationModel in the chain
+               "fhadp_lq_s3a1_obsscale", "fhadp_idp_obsscale_shift",
                # the reference's shipped trained checkpoints (saturating policies, H = 80, limits != +-1)
                "fhadp_trained_idp_h80", "fhadp_trained_lqs3a1_h80"]
 # One shipped checkpoint (trained LQ s3a1 policy, H = 80: clipped, unstable closed loop; ONE trajectory of the batch,
@@ -28,7 +32,7 @@ FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fh
 # weight by one ulp moves the REFERENCE's own fp32 gradient by 1e-4 .. 5e-4 (helpers.fp32_noise_floor), and the reference
 # itself is 3e-4 from the float64 value.  Measured HIP distance to float64: 7e-4; bound = 1.5x that.
 ILL_CONDITIONED = {"fhadp_trained_lqs3a1_h80": 1.1e-3}
-INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu",
+INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift",
                 "infadp_trained_lqs4a2", "infadp_trained_idp"]
 
 

@@ -47,7 +47,7 @@ def alg_kwargs(cfg, seed, **extra):
         policy_hidden_sizes=list(cfg["hidden"]), policy_hidden_activation=cfg["act"],
         policy_act_distribution="default", policy_learning_rate=1e-3, use_gpu=False,
     )
-    if cfg["alg"] == "INFADP":
+    if cfg["alg"] in ("INFADP", "MAC"):
         kw.update(value_func_type="MLP", value_func_name="StateValue",
                   value_hidden_sizes=list(cfg["hidden"]), value_hidden_activation=cfg["act"],
                   value_learning_rate=1e-3)
@@ -83,6 +83,11 @@ def build_alg(cfg, seed, **extra):
         cls = dict(FHADPExterior=FHADPExterior, FHADPInterior=FHADPInterior, FHADPLagrangian=FHADPLagrangian)[cfg["alg"]]
         alg = cls(**kw)
         alg.gamma = cfg.get("gamma", 1.0)
+    elif cfg["alg"] == "MAC":
+        from gops.algorithm.mac import MAC
+        alg = MAC(**kw)
+        alg.gamma = cfg.get("gamma", 0.99)
+        alg.forward_step = cfg["horizon"]
     else:
         alg = INFADP(**kw)
         alg.gamma = cfg.get("gamma", 0.99)
@@ -122,6 +127,12 @@ OBS_SCALE_STEP_CASES = {   # ScaleObservationModel (example_train/fhadp/fhadp_ml
     "step_lq_s5a1_obsscale_shift": (dict(env_id="pyth_lq", lq_config="s5a1"),
                                     dict(obs_scale=10, obs_shift=[0.1, -0.2, 0.05, 0.0, 0.3], reward_scale=0.5, reward_shift=1.0)),
     "step_idp_obsscale_shift": (dict(env_id="pyth_idpendulum"), dict(obs_scale=[1, 2, 2, 0.5, 0.5, 0.25], obs_shift=0.1)),
+}
+MAC_SMALL = {   # gops/algorithm/mac.py on the info-free models
+    "mac_lq_s4a2_gelu": (dict(alg="MAC", env_id="pyth_lq", lq_config="s4a2", batch=64, horizon=10,
+                              hidden=(64, 64), act="gelu", gamma=0.99), {}),
+    "mac_idp_elu": (dict(alg="MAC", env_id="pyth_idpendulum", batch=40, horizon=8,
+                         hidden=(64, 64), act="elu", gamma=0.97), {}),
 }
 OBS_SCALE_SMALL = {
     "fhadp_lq_s3a1_obsscale": (dict(alg="FHADP", env_id="pyth_lq", lq_config="s3a1", batch=40, horizon=20,
@@ -542,7 +553,10 @@ def golden_data_envs():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac"]
+    if "mac" in which:
+        np.random.seed(0)   # the reference's (inert) Bayes estimator draws from numpy's global RNG
+        golden_small(MAC_SMALL)
     if "obsscale" in which:
         golden_steps(OBS_SCALE_STEP_CASES)
         golden_small(OBS_SCALE_SMALL)

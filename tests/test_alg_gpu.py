@@ -23,7 +23,7 @@ def _kwargs(cfg, extra, seed):
               policy_func_name="FiniteHorizonPolicy" if cfg["alg"] == "FHADP" else "DetermPolicy",
               policy_hidden_sizes=list(cfg["hidden"]), policy_hidden_activation=cfg["act"],
               policy_act_distribution="default", policy_learning_rate=1e-3, use_gpu=True)
-    if cfg["alg"] == "INFADP":
+    if cfg["alg"] in ("INFADP", "MAC"):
         kw.update(value_func_type="MLP", value_func_name="StateValue", value_hidden_sizes=list(cfg["hidden"]),
                   value_hidden_activation=cfg["act"], value_learning_rate=1e-3)
     if "pre_horizon" in cfg or cfg["alg"] == "FHADP":
@@ -65,7 +65,7 @@ def test_fhadp_class_matches_reference(name):
     assert any((a - b).abs().max() > 0 for a, b in zip(after, before))
 
 
-@pytest.mark.parametrize("name", ["infadp_lq_s4a2_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift"])
+@pytest.mark.parametrize("name", ["infadp_lq_s4a2_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift", "mac_idp_elu"])
 def test_infadp_class_matches_reference(name):
     alg, g, cfg = _load_alg(name)
     alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]

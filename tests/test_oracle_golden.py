@@ -22,6 +22,7 @@ FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fh
                # the reference's shipped trained checkpoints (saturating policies, H = 80, limits != +-1)
                "fhadp_trained_idp_h80", "fhadp_trained_lqs3a1_h80"]
 INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift",
+                "mac_lq_s4a2_gelu", "mac_idp_elu",   # gops/algorithm/mac.py: INFADP's losses (its Bayes model-bias term is inert)
                 "infadp_trained_lqs4a2", "infadp_trained_idp"]
 
 

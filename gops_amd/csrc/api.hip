@@ -195,6 +195,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     p.fh = desc.finite_horizon ? 1 : 0;
     p.need_grad = desc.need_grad ? 1 : 0;
     p.tail = desc.tail_value ? 1 : 0;
+    p.tail_unmasked = (desc.tail_value && desc.tail_unmasked) ? 1 : 0;
     p.env = e;
     p.open_loop = desc.open_loop == 2 ? 2 : (desc.open_loop ? 1 : 0);
     p.f16 = f16 ? 1 : 0;

@@ -63,6 +63,7 @@ struct StashDev {
 
 struct RolloutParams {
     int B, H, fh, need_grad, tail;
+    int tail_unmasked;                // SPIL: the terminal value is added for finished trajectories too
     int ldx, ldh;                     // LDS leading dims: input tile / hidden tiles (floats)
     int touch_mode;                   // backward L2 warm-up: 0 off, 1 all at the step top, 2 spread over the step
     GopsEnv env;

@@ -302,6 +302,15 @@ __device__ __forceinline__ float veh_reward_w(const float* w, const float* o, fl
              w[4] * (o[5] * o[5]) + w[5] * (steer * steer) + w[6] * (ax * ax) + w[7] * (o[4] * o[4]));
 }
 
+// SPIL's constraint-to-cost map (gops/algorithm/spil.py:224-232): Phi(y) = (1 + tau m1) / (1 + m2 tau exp(clamp(y / tau, -10, 5)))
+// with m1 = 1, m2 = m1 / (1 + m1) * 0.9 = 0.45, tau = 0.07; dlog = Phi'(y) / Phi(y).
+__device__ __forceinline__ float spil_phi(float y, float& dlog) {
+    const float z = y / 0.07f, zc = fminf(fmaxf(z, -10.f), 5.f);
+    const float be = (0.45f * 0.07f) * expf(zc);
+    dlog = (z > -10.f && z < 5.f) ? -(be / (1.f + be)) / 0.07f : 0.f;
+    return (1.f + 0.07f * 1.f) / (1.f + be);
+}
+
 // Collision penalty of pyth_veh3dofconti_surrcstr_penalty_model.py:145-160 as a function of the constraint value
 // c = 2 r - min distance (dis = -c):  pen = 15 (tanh(max(8 + 16 c, 0) - 4) + 1), and d pen / d c.
 __device__ __forceinline__ float surr_penalty(float c, float& dpen_dc) {

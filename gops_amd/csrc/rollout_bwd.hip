@@ -192,6 +192,12 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         const GLOBAL_AS float* gcp = gptr(p.in.grad_constraint) + b0 + tid;
         gc_ext = gcp[0]; gc_lin = gcp[(size_t)p.B]; gc_int = gcp[(size_t)2 * p.B];
     }
+    float gc_mul[GOPS_MAX_CONSTRAINT] = {0.f, 0.f, 0.f};   // SPIL: d(loss)/d(P_k) * P_k of trajectory tid
+    if (SURR && tid < nvalid && p.in.grad_constraint_prod != nullptr) {
+#pragma unroll
+        for (int k = 0; k < GOPS_MAX_CONSTRAINT; ++k)
+            if (k < p.env.n_constraint) gc_mul[k] = gptr(p.in.grad_constraint_prod)[(size_t)k * p.B + b0 + tid];
+    }
     const int ld16 = (p.ldh - 4) + 8;                 // F16: leading dimension (halfs) of the delta tiles
     // fp32 observation column i of row m of the stash tile at row0 (the env adjoints read the first few):
     // F16 keeps a row-major [S][8] fp32 copy, the fp32 stash is feature-major
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     if (TAIL) {
         if (tid < TB) {
             const float dH = (tid < nvalid) ? gptr(p.st.tail_done)[b0 + tid] : 1.f;
-            s_gy[tid * 4 + 0] = gv * ((1.f - dH) * p.gpow[p.H]);
+            s_gy[tid * 4 + 0] = gv * ((p.tail_unmasked ? 1.f : 1.f - dH) * p.gpow[p.H]);
             s_gy[tid * 4 + 1] = s_gy[tid * 4 + 2] = s_gy[tid * 4 + 3] = 0.f;
         }
         __syncthreads();
@@ -519,14 +525,20 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                         // adjoint of the (unmasked) constraint sums w.r.t. the new ego pose
                         SurrCstr sc;
                         surr_constraint<true>(p.env, sn[0], sn[1], e3[2], e3[3], pts, sc);
-                        for (int k = 0; k < (p.env.surr_penalty ? 0 : p.env.n_constraint); ++k) {
-                            const float c = sc.c[k];
-                            float gck = gc_ext * 2.f * fmaxf(c, 0.f) + (c > 0.f ? gc_lin : 0.f);
-                            if (c < 0.f) gck += gc_int * (-1.f / (-c + 1e-8f));
-                            gck *= p.gpow[t];
-                            lamn[0] += gck * sc.dx[k];
-                            lamn[1] += gck * sc.dy[k];
-                            lamn[2] += gck * sc.dphi[k];
+#pragma unroll
+                        for (int k = 0; k < GOPS_MAX_CONSTRAINT; ++k) {
+                            if (k < (p.env.surr_penalty ? 0 : p.env.n_constraint)) {
+                                const float c = sc.c[k];
+                                float gck = gc_ext * 2.f * fmaxf(c, 0.f) + (c > 0.f ? gc_lin : 0.f);
+                                if (c < 0.f) gck += gc_int * (-1.f / (-c + 1e-8f));
+                                gck *= p.gpow[t];
+                                float dlog;
+                                (void)spil_phi(c, dlog);
+                                gck += gc_mul[k] * dlog;   // d P_k / d c_tk = P_k Phi'(c_tk) / Phi(c_tk); gc_mul carries dL/dP_k * P_k
+                                lamn[0] += gck * sc.dx[k];
+                                lamn[1] += gck * sc.dy[k];
+                                lamn[2] += gck * sc.dphi[k];
+                            }
                         }
                         // observation columns (x, y, phi, u)_surr - (x, y, phi, u)_ego: MaskAtDone keeps the adjoint on obs_t
                         if (!dn && !p.env.surr_penalty) {

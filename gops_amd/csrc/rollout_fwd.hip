@@ -186,6 +186,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     if constexpr (SK1 > 0) W1.load(p.pol.wp[1], p.pol.dims[2] >> 4, tid);
     float v_acc = 0.f;
     float c_ext = 0.f, c_lin = 0.f, c_int = 0.f, c_feas = 1.f;   // SURR: discounted constraint sums of trajectory tid (tid < TB)
+    float c_mul[GOPS_MAX_CONSTRAINT] = {1.f, 1.f, 1.f}, c_safe[GOPS_MAX_CONSTRAINT] = {1.f, 1.f, 1.f};   // SPIL products
     float veh_s = 0.f, veh_c = 1.f;   // sin/cos of the current heading, carried across steps
     const IdpConst IC = idp_const();
     const VehConst VC = veh_const();
@@ -422,12 +423,18 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                     // the penalty model fills info["constraint"] before its info dict is updated (:131-139): CURRENT pose
                     if (p.env.surr_penalty) sc.c[0] = pen_c;
                     float e2 = 0.f, e1 = 0.f, lg = 0.f;
-                    for (int k = 0; k < p.env.n_constraint; ++k) {
-                        const float cp = fmaxf(sc.c[k], 0.f), cm = fminf(sc.c[k], 0.f);
-                        e2 += cp * cp;
-                        e1 += cp;
-                        lg += logf(-cm + 1e-8f);
-                        if (!(sc.c[k] < 0.f)) c_feas = 0.f;
+#pragma unroll
+                    for (int k = 0; k < GOPS_MAX_CONSTRAINT; ++k) {
+                        if (k < p.env.n_constraint) {
+                            const float cp = fmaxf(sc.c[k], 0.f), cm = fminf(sc.c[k], 0.f);
+                            e2 += cp * cp;
+                            e1 += cp;
+                            lg += logf(-cm + 1e-8f);
+                            if (!(sc.c[k] < 0.f)) c_feas = 0.f;
+                            float dlog;
+                            c_mul[k] *= spil_phi(sc.c[k], dlog);
+                            if (!(sc.c[k] <= 0.f)) c_safe[k] = 0.f;
+                        }
                     }
                     c_ext += e2 * p.gpow[t];
                     c_lin += e1 * p.gpow[t];
@@ -471,12 +478,19 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         }
         if ((tid & 15) == 0) s_th[(tid >> 4) * 4] = y[0];
         __syncthreads();
-        if (tid < TB) v_acc += ((1.f - s_done[tid]) * p.gpow[p.H]) * s_th[tid * 4];
+        if (tid < TB) v_acc += ((p.tail_unmasked ? 1.f : 1.f - s_done[tid]) * p.gpow[p.H]) * s_th[tid * 4];
     }
 
     if (SURR && tid < nvalid && p.out.constraint_sums != nullptr) {
         GLOBAL_AS float* cs = gptr(p.out.constraint_sums) + b0 + tid;
         cs[0] = c_ext; cs[(size_t)p.B] = c_lin; cs[(size_t)2 * p.B] = c_int; cs[(size_t)3 * p.B] = c_feas;
+    }
+    if (SURR && tid < nvalid && p.out.constraint_prods != nullptr) {
+        GLOBAL_AS float* cp = gptr(p.out.constraint_prods) + b0 + tid;
+        const int nc = p.env.n_constraint;
+#pragma unroll
+        for (int k = 0; k < GOPS_MAX_CONSTRAINT; ++k)
+            if (k < nc) { cp[(size_t)k * p.B] = c_mul[k]; cp[(size_t)(nc + k) * p.B] = c_safe[k]; }
     }
     if (tid < nvalid) {
         gptr(p.out.v_pi)[b0 + tid] = v_acc;

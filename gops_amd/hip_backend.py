@@ -63,16 +63,17 @@ class GopsEnv(C.Structure):
 class GopsRolloutDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("horizon", C.c_int32), ("finite_horizon", C.c_int32),
                 ("need_grad", C.c_int32), ("tail_value", C.c_int32), ("open_loop", C.c_int32),
-                ("dtype", C.c_int32), ("reserved", C.c_int32), ("gamma", C.c_double), ("env", GopsEnv), ("policy", GopsMlp), ("value", GopsMlp)]
+                ("dtype", C.c_int32), ("tail_unmasked", C.c_int32), ("gamma", C.c_double), ("env", GopsEnv), ("policy", GopsMlp), ("value", GopsMlp)]
 
 
 class GopsRolloutIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "done", "state", "ref_points", "path_num", "u_num",
-                                          "ref_time", "head_pre", "surr_state", "grad_constraint")]
+                                          "ref_time", "head_pre", "surr_state", "grad_constraint", "grad_constraint_prod")]
 
 
 class GopsRolloutOut(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("v_pi", "rewards", "final_obs", "final_done", "final_state", "constraint_sums")]
+    _fields_ = [(k, C.c_void_p) for k in ("v_pi", "rewards", "final_obs", "final_done", "final_state", "constraint_sums",
+                                          "constraint_prods")]
 
 
 ADAM_MAX = 16
@@ -272,7 +273,8 @@ class Rollout:
 
     def __init__(self, env: GopsEnv, policy: Optional[GopsMlp], *, batch: int, horizon: int, gamma: float,
                  finite_horizon: bool, need_grad: bool = True, value: Optional[GopsMlp] = None,
-                 device: Optional[torch.device] = None, dtype=None, raw_actions: bool = False):
+                 device: Optional[torch.device] = None, dtype=None, raw_actions: bool = False,
+                 tail_unmasked: bool = False):
         """`policy=None` selects the open-loop mode: `forward(data, head_pre=...)` takes the pre-tanh
         policy-head outputs of all steps [B, H, act_dim] and `backward_open_loop` returns their gradient.
         `dtype`: "fp32" (default, exact fp32 MFMA) or "fp16" (half-precision MFMA contractions and stash)."""
@@ -281,6 +283,7 @@ class Rollout:
         d.dtype = dtype_id(dtype)
         d.batch, d.horizon, d.finite_horizon = batch, horizon, int(finite_horizon)
         d.need_grad, d.tail_value, d.gamma = int(need_grad), int(value is not None), float(gamma)
+        d.tail_unmasked = int(bool(tail_unmasked))   # SPIL's evaluation target: the terminal value is not masked at done
         d.env = env
         # raw_actions (open loop only): `head_pre` holds the model's actions themselves (GopsRolloutDesc.open_loop = 2)
         d.open_loop = (2 if raw_actions else 1) if policy is None else 0
@@ -337,16 +340,22 @@ class Rollout:
         if d.env.kind == ENV_VEH_SURR:   # [4, B]: sum c+^2, sum c+, sum log(-c- + eps), feasible  (discounted, unmasked)
             res["constraint_sums"] = torch.empty(4, B, dtype=torch.float32, device=self.device)
             out.constraint_sums = _ptr(res["constraint_sums"])
+            # [2 n_c, B]: prod_t Phi(c_tk) and prod_t [c_tk <= 0] per constraint k (SPIL)
+            nc = d.env.n_constraint
+            res["constraint_prods"] = torch.empty(2 * nc, B, dtype=torch.float32, device=self.device)
+            out.constraint_prods = _ptr(res["constraint_prods"])
         check(lib().gops_rollout_forward(C.byref(d), C.byref(i), C.byref(out), self.workspace.data_ptr(),
                                          self.workspace.numel(), _stream()), "gops_rollout_forward")
         return res
 
     def backward(self, grad_v: torch.Tensor, grad_w: List[torch.Tensor], grad_b: List[torch.Tensor],
-                 grad_constraint: Optional[torch.Tensor] = None):
-        """`grad_constraint` (ENV_VEH_SURR): d(loss)/d(constraint_sums rows 0..2), [3, B]."""
+                 grad_constraint: Optional[torch.Tensor] = None, grad_constraint_prod: Optional[torch.Tensor] = None):
+        """`grad_constraint` (ENV_VEH_SURR): d(loss)/d(constraint_sums rows 0..2), [3, B]; `grad_constraint_prod`:
+        d(loss)/d(P_k) * P_k for the Phi-products P_k = constraint_prods[k], [n_constraint, B]."""
         g = make_mlp_grad(grad_w, grad_b)
         self._in.grad_constraint = _ptr(grad_constraint)
-        self._grad_c = grad_constraint
+        self._in.grad_constraint_prod = _ptr(grad_constraint_prod)
+        self._grad_c = (grad_constraint, grad_constraint_prod)
         check(lib().gops_rollout_backward(C.byref(self.desc), C.byref(self._in), _ptr(grad_v), C.byref(g),
                                           self.workspace.data_ptr(), self.workspace.numel(), _stream()),
               "gops_rollout_backward")

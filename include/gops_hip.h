@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GOPS_HIP_ABI_VERSION 3
+#define GOPS_HIP_ABI_VERSION 4
 
 #define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
 #define GOPS_MAX_ACT 4      /* action dimensions */
@@ -160,7 +160,8 @@ typedef struct GopsRolloutDesc {
                                  d(loss)/d(action) */
     int32_t dtype;            /* GOPS_DTYPE_F32 (default) or GOPS_DTYPE_F16: arithmetic of the MLP contractions
                                  (hidden widths must then be multiples of 64) */
-    int32_t reserved;
+    int32_t tail_unmasked;    /* with tail_value: 1 = v += gamma^H V(obs_H) for finished trajectories too
+                                 (SPIL's evaluation target, gops/algorithm/spil.py:208) */
     double gamma;             /* discount; gamma^t is formed in double then rounded (fhadp.py:120) */
     GopsEnv env;
     GopsMlp policy;           /* out width = act_dim */
@@ -180,6 +181,8 @@ typedef struct GopsRolloutIn {
     const float* surr_state;  /* GOPS_ENV_VEH3DOF_SURR info["surr_state"] [B, n_surr, 5] (x, y, phi, u, delta) else NULL */
     const float* grad_constraint; /* gops_rollout_backward, GOPS_ENV_VEH3DOF_SURR: d(loss)/d(constraint_sums) [3, B]
                                  (rows as in GopsRolloutOut.constraint_sums); NULL = zeros */
+    const float* grad_constraint_prod; /* gops_rollout_backward, GOPS_ENV_VEH3DOF_SURR: [n_constraint, B]
+                                 d(loss)/d(P_k) * P_k for the products P_k of GopsRolloutOut.constraint_prods; NULL = zeros */
 } GopsRolloutIn;
 
 typedef struct GopsRolloutOut {
@@ -195,6 +198,10 @@ typedef struct GopsRolloutOut {
      *   row 2  sum_t gamma^t sum_k log(-min(c_tk, 0) + 1e-8) (fhadp_interior.py:65)
      *   row 3  1 if every c_tk < 0 (feasible trajectory, fhadp_interior.py:71) else 0 */
     float* constraint_sums;
+    /* GOPS_ENV_VEH3DOF_SURR, or NULL: [2 n_constraint, B] products over the rollout (gops/algorithm/spil.py:189-251):
+     *   rows 0 .. n_constraint-1        P_k = prod_t Phi(c_tk),  Phi(y) = 1.07 / (1 + 0.0315 exp(clamp(y / 0.07, -10, 5)))
+     *   rows n_constraint .. 2 n_c - 1  prod_t [c_tk <= 0]       (trajectory safe w.r.t. constraint k: 0 / 1) */
+    float* constraint_prods;
 } GopsRolloutOut;
 
 int gops_hip_version(void);

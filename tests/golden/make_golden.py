@@ -128,6 +128,45 @@ OBS_SCALE_STEP_CASES = {   # ScaleObservationModel (example_train/fhadp/fhadp_ml
                                     dict(obs_scale=10, obs_shift=[0.1, -0.2, 0.05, 0.0, 0.3], reward_scale=0.5, reward_shift=1.0)),
     "step_idp_obsscale_shift": (dict(env_id="pyth_idpendulum"), dict(obs_scale=[1, 2, 2, 0.5, 0.5, 0.25], obs_shift=0.1)),
 }
+SPIL_CASES = {   # gops/algorithm/spil.py on the constrained veh3dofconti models (one full update: PEV + PIM gradients)
+    "spil_surrcstr_p10": (dict(alg="SPIL", env_id="pyth_veh3dofconti_surrcstr", batch=48, horizon=10, pre_horizon=10,
+                               hidden=(64, 64), act="elu", gamma=0.99), dict(constraint_dim=1)),
+    "spil_detour_p8": (dict(alg="SPIL", env_id="pyth_veh3dofconti_detour", batch=40, horizon=8, pre_horizon=8,
+                            hidden=(64, 64), act="gelu", gamma=0.97), dict(constraint_dim=3)),
+}
+
+
+def golden_spil():
+    from gops.algorithm.spil import SPIL
+    for name, (cfg, extra) in SPIL_CASES.items():
+        seed = zlib.crc32(name.encode()) % 1000
+        torch.manual_seed(seed)
+        kw = alg_kwargs(dict(cfg, alg="INFADP"), seed, **extra)
+        kw["algorithm"] = "SPIL"
+        alg = SPIL(gamma=cfg["gamma"], forward_step=cfg["horizon"], **kw)
+        perturb_targets(alg, seed)
+        data = make_batch(cfg, seed)
+        data["done"][-4:] = 1.0
+        data["constraint"] = torch.zeros(cfg["batch"], extra["constraint_dim"])
+        # a non-trivial multiplier state, as after some updates
+        alg.delta_i = np.array([3.0, 1.0, 0.5][:extra["constraint_dim"]])
+        alg.safe_prob_pre = np.array([0.9, 0.8, 0.95][:extra["constraint_dim"]])
+        out = {"in/" + k: v.numpy().copy() for k, v in data.items()}
+        out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra=extra, seed=seed))
+        out["state/delta_i"], out["state/safe_prob_pre"] = alg.delta_i.copy(), alg.safe_prob_pre.copy()
+        out.update(sd_to_np(alg.networks.state_dict()))
+        tb, info = alg.get_remote_update_info(data, 0)
+        for i, gr in enumerate(info["v"]):
+            out[f"pev_grad/{i}"] = gr.detach().numpy().copy()
+        for i, gr in enumerate(info["policy"]):
+            out[f"pim_grad/{i}"] = gr.detach().numpy().copy()
+        out["pev_loss"], out["pev_vmean"] = tb["Loss/Critic loss-RL iter"], tb["Train/Critic avg value-RL iter"]
+        out["pim_loss"] = tb["Loss/Actor loss-RL iter"]
+        out["safe_prob"], out["lam"] = np.asarray(alg.safe_prob), np.asarray(alg.lam)
+        out["after/delta_i"] = alg.delta_i.copy()
+        save(name, **out)
+
+
 MAC_SMALL = {   # gops/algorithm/mac.py on the info-free models
     "mac_lq_s4a2_gelu": (dict(alg="MAC", env_id="pyth_lq", lq_config="s4a2", batch=64, horizon=10,
                               hidden=(64, 64), act="gelu", gamma=0.99), {}),
@@ -553,7 +592,9 @@ def golden_data_envs():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil"]
+    if "spil" in which:
+        golden_spil()
     if "mac" in which:
         np.random.seed(0)   # the reference's (inert) Bayes estimator draws from numpy's global RNG
         golden_small(MAC_SMALL)

@@ -23,13 +23,15 @@ def _kwargs(cfg, extra, seed):
               policy_func_name="FiniteHorizonPolicy" if cfg["alg"] == "FHADP" else "DetermPolicy",
               policy_hidden_sizes=list(cfg["hidden"]), policy_hidden_activation=cfg["act"],
               policy_act_distribution="default", policy_learning_rate=1e-3, use_gpu=True)
-    if cfg["alg"] in ("INFADP", "MAC"):
+    if cfg["alg"] in ("INFADP", "MAC", "SPIL"):
         kw.update(value_func_type="MLP", value_func_name="StateValue", value_hidden_sizes=list(cfg["hidden"]),
                   value_hidden_activation=cfg["act"], value_learning_rate=1e-3)
     if "pre_horizon" in cfg or cfg["alg"] == "FHADP":
         kw["pre_horizon"] = cfg.get("pre_horizon", cfg["horizon"])
     if "lq_config" in cfg:
         kw["lq_config"] = cfg["lq_config"]
+    if cfg["alg"] == "SPIL":
+        kw.update(policy_func_name="DetermPolicy", pre_horizon=cfg["pre_horizon"])
     kw.update(extra)
     return kw
 
@@ -483,3 +485,28 @@ def test_wide_output_mlp_matches_torch(case):
     assert rel_l2(y.cpu(), yr.detach()) < 1e-5
     for got, want in zip(gw + gb, grads):
         assert rel_l2(got.cpu(), want) < 1e-4, (case, tuple(want.shape), rel_l2(got.cpu(), want))
+
+
+@pytest.mark.parametrize("name", ["spil_surrcstr_p10", "spil_detour_p8"])
+def test_spil_class_matches_reference(name):
+    """SPIL (create_alg surface) on the constrained veh3dofconti models: one full update - value and policy gradients,
+    losses, safe probabilities and the PI multipliers - against the reference's, from its checkpoint layout."""
+    alg, g, cfg = _load_alg(name)
+    alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]
+    alg.delta_i, alg.safe_prob_pre = np.array(g["state/delta_i"]), np.array(g["state/safe_prob_pre"])
+    data = data_from_golden(g)
+    tb, info = alg.get_remote_update_info(data, 0)
+    assert list(info) == ["v", "policy"]
+    assert abs(float(tb["Loss/Critic loss-RL iter"]) - float(g["pev_loss"])) <= TOL * max(1.0, abs(float(g["pev_loss"])))
+    assert abs(float(tb["Train/Critic avg value-RL iter"]) - float(g["pev_vmean"])) <= TOL
+    np.testing.assert_allclose(alg.safe_prob, g["safe_prob"], atol=1e-6)
+    np.testing.assert_allclose(alg.lam, g["lam"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(alg.delta_i, g["after/delta_i"], rtol=1e-6, atol=1e-7)
+    assert abs(float(tb["Loss/Actor loss-RL iter"]) - float(g["pim_loss"])) <= TOL * max(1.0, abs(float(g["pim_loss"])))
+    for i, gr in enumerate(info["v"]):
+        assert rel_l2(gr.cpu(), g[f"pev_grad/{i}"]) < TOL, ("pev", i)
+    for i, gr in enumerate(info["policy"]):
+        assert rel_l2(gr.cpu(), g[f"pim_grad/{i}"]) < TOL, ("pim", i, rel_l2(gr.cpu(), g[f"pim_grad/{i}"]))
+    before = [p.detach().clone() for p in alg.networks.policy.parameters()]
+    alg.remote_update(info)
+    assert any((a - b).abs().max() > 0 for a, b in zip(alg.networks.policy.parameters(), before))

@@ -62,7 +62,7 @@ def test_workspace_query_and_rejections_need_no_gpu():
 
 def test_registries_and_error_behaviour():
     from gops_amd.create_pkg import create_alg, create_apprfunc, create_env_model, create_trainer
-    assert set(create_alg.registry) == {"FHADP", "FHADP2", "FHADPExterior", "FHADPInterior", "FHADPLagrangian", "INFADP", "MAC"}
+    assert set(create_alg.registry) == {"FHADP", "FHADP2", "FHADPExterior", "FHADPInterior", "FHADPLagrangian", "INFADP", "MAC", "SPIL"}
     assert {"mlp_DetermPolicy", "mlp_FiniteHorizonPolicy", "mlp_StateValue"} <= set(create_apprfunc.registry)
     assert {"pyth_lq_model", "pyth_idpendulum_model", "pyth_veh3dofconti_model", "pyth_veh3dofconti_surrcstr_model",
             "pyth_veh3dofconti_detour_model", "pyth_veh3dofconti_surrcstr_penalty_model"} <= set(create_env_model.registry)

@@ -207,3 +207,37 @@ def test_constrained_fhadp_gradients_match_reference(name):
         assert abs(ref["sums"][3].mean().item() - float(g["tb/Loss/Feasible ratio-RL iter"])) < 1e-6
     for i, gr in enumerate(ref["grads"]):
         assert rel_l2(gr, g[f"grad/{i}"]) < 1e-5, (name, i, rel_l2(gr, g[f"grad/{i}"]))
+
+
+def _spil_weights(delta_i, safe_prob_pre, safe_prob, chance=0.97, Kp=60, Ki=0.02, Kd=0):
+    """SPIL.__spil_get_weight (spil.py:253-270)."""
+    delta_p = chance - safe_prob
+    sepa = np.where(np.abs(delta_p) > 0.1, delta_p * 0.7, delta_p)
+    sepa = np.where(np.abs(delta_p) > 0.2, delta_p * 0, sepa)
+    delta_i = np.clip(delta_i + sepa, 0, 99999)
+    lam = np.clip(Ki * delta_i + Kp * delta_p + Kd * np.clip(safe_prob_pre - safe_prob, 0, 3333), 0, 3333)
+    return 1 / (1 + lam.sum()), lam / (1 + lam.sum()), lam
+
+
+@pytest.mark.parametrize("name", ["spil_surrcstr_p10", "spil_detour_p8"])
+def test_spil_gradients_match_reference(name):
+    """One full SPIL update of the reference (PEV with the unmasked terminal value + safe probabilities, the PI multiplier
+    rule, PIM over the Phi-products) against the oracle restatement."""
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg = meta["cfg"]
+    env = oracle_env(cfg, {}, g)
+    nets, _ = nets_from_golden(g, cfg)
+    data = data_from_golden(g)
+    pev = orc.spil_pev(env, nets["policy"], nets["v"], nets["v_target"], data, cfg["horizon"], cfg["gamma"])
+    assert abs(pev["loss"].item() - float(g["pev_loss"])) <= 1e-5 * max(1.0, abs(float(g["pev_loss"])))
+    assert abs(pev["v_mean"].item() - float(g["pev_vmean"])) <= 1e-5
+    np.testing.assert_allclose(pev["safe_prob"].numpy(), g["safe_prob"], atol=1e-7)
+    for i, gr in enumerate(pev["grads"]):
+        assert rel_l2(gr, g[f"pev_grad/{i}"]) < 1e-5, (name, "pev", i)
+    w_r, w_c, lam = _spil_weights(g["state/delta_i"], g["state/safe_prob_pre"], pev["safe_prob"].numpy())
+    np.testing.assert_allclose(lam, g["lam"], rtol=1e-6, atol=1e-7)
+    pim = orc.spil_pim(env, nets["policy"], data, cfg["horizon"], cfg["gamma"], w_r, w_c)
+    assert abs(pim["loss"].item() - float(g["pim_loss"])) <= 1e-5 * max(1.0, abs(float(g["pim_loss"])))
+    for i, gr in enumerate(pim["grads"]):
+        assert rel_l2(gr, g[f"pim_grad/{i}"]) < 1e-5, (name, "pim", i)

@@ -108,8 +108,8 @@ def create_env_model(
     if repeat_num is not None:
         raise RuntimeError("ActionRepeatModel (repeat_num) is not supported by the HIP env models")
     scaled = obs_shift is not None or obs_scale is not None
-    if scaled and (env_model.obs_dim > 8 or env_model.hip_kind not in (hb.ENV_LQ, hb.ENV_IDP)):
-        raise RuntimeError("ScaleObservationModel (obs_shift/obs_scale) is supported for pyth_lq / pyth_idpendulum only "
+    if scaled and (env_model.obs_dim > 8 or env_model.hip_kind not in (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_CARTPOLE, hb.ENV_PENDULUM)):
+        raise RuntimeError("ScaleObservationModel (obs_shift/obs_scale) is supported for pyth_lq / pyth_idpendulum / gym_* models only "
                            "(observation dimension <= 8) by the HIP env models")
     if not mask_at_done:
         raise RuntimeError("mask_at_done=False is not supported by the HIP env models")

@@ -163,7 +163,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     memset(&p, 0, sizeof(p));
     const GopsEnv& e = desc.env;
     if (desc.batch < 1 || desc.horizon < 1 || desc.horizon > GOPS_MAX_HORIZON) return GOPS_ERR_BAD_ARG;
-    if (e.kind < GOPS_ENV_NONE || e.kind > GOPS_ENV_VEH3DOF_SURR) return GOPS_ERR_BAD_ARG;
+    if (e.kind < GOPS_ENV_NONE || e.kind > GOPS_ENV_PENDULUM) return GOPS_ERR_BAD_ARG;
     if (e.obs_dim < 1 || e.data_env) return GOPS_ERR_BAD_ARG;   // data-env semantics exist for gops_env_step only
     const int pol_out = (e.kind == GOPS_ENV_NONE) ? 1 : e.act_dim;
     if (desc.dtype != GOPS_DTYPE_F32 && desc.dtype != GOPS_DTYPE_F16) return GOPS_ERR_BAD_ARG;
@@ -176,7 +176,10 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     }
     if (desc.tail_value && (rc = check_mlp(desc.value, e.obs_dim, 1, f16)) != GOPS_OK) return rc;
     if (e.kind == GOPS_ENV_NONE && (desc.horizon != 1 || desc.tail_value || desc.finite_horizon)) return GOPS_ERR_BAD_ARG;
-    if (e.scale_obs && e.kind != GOPS_ENV_LQ && e.kind != GOPS_ENV_IDPENDULUM) return GOPS_ERR_UNSUPPORTED;   // obs_dim <= 8 only
+    if (e.scale_obs && e.kind != GOPS_ENV_LQ && e.kind != GOPS_ENV_IDPENDULUM && e.kind < GOPS_ENV_CARTPOLE) return GOPS_ERR_UNSUPPORTED;   // obs_dim <= 8 only
+    if (e.kind == GOPS_ENV_CARTPOLE && (e.obs_dim != 4 || e.act_dim != 1)) return GOPS_ERR_BAD_ARG;
+    if (e.kind == GOPS_ENV_PENDULUM && (e.obs_dim != 3 || e.act_dim != 1)) return GOPS_ERR_BAD_ARG;
+    if (e.kind >= GOPS_ENV_CARTPOLE && f16) return GOPS_ERR_UNSUPPORTED;   // the half-precision kernels are built for the BASELINE envs
     if (e.kind == GOPS_ENV_LQ && (e.obs_dim > GOPS_MAX_LQ_STATE || e.act_dim > GOPS_MAX_ACT)) return GOPS_ERR_UNSUPPORTED;
     if (e.kind == GOPS_ENV_IDPENDULUM && (e.obs_dim != 6 || e.act_dim != 1 || e.clip_obs)) return GOPS_ERR_BAD_ARG;
     if (e.kind == GOPS_ENV_VEH3DOFCONTI &&
@@ -556,7 +559,8 @@ int gops_rollout_backward_open_loop(const GopsRolloutDesc* desc, const GopsRollo
 
 int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream) {
     if (!env || !io || batch < 1) return GOPS_ERR_BAD_ARG;
-    if (env->kind < GOPS_ENV_LQ || env->kind > GOPS_ENV_VEH3DOF_SURR) return GOPS_ERR_BAD_ARG;
+    if (env->kind < GOPS_ENV_LQ || env->kind > GOPS_ENV_PENDULUM) return GOPS_ERR_BAD_ARG;
+    if (env->kind >= GOPS_ENV_CARTPOLE && env->data_env) return GOPS_ERR_UNSUPPORTED;   // gym data envs are not restated
     if (!io->obs || !io->action || !io->next_obs || !io->reward || !io->next_done) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_VEH3DOF_SURR &&
         (env->data_env || env->n_surr < 1 || env->n_surr > GOPS_MAX_SURR || (env->n_constraint != 1 && env->n_constraint != 3) ||
@@ -565,7 +569,7 @@ int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void*
         (!io->state || !io->ref_points || !io->path_num || !io->u_num || !io->ref_time ||
          !io->next_state || !io->next_ref_points || !io->next_ref_time)) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_LQ && env->obs_dim > GOPS_MAX_LQ_STATE) return GOPS_ERR_UNSUPPORTED;
-    if (env->scale_obs && env->kind != GOPS_ENV_LQ && env->kind != GOPS_ENV_IDPENDULUM) return GOPS_ERR_UNSUPPORTED;
+    if (env->scale_obs && env->kind != GOPS_ENV_LQ && env->kind != GOPS_ENV_IDPENDULUM && env->kind < GOPS_ENV_CARTPOLE) return GOPS_ERR_UNSUPPORTED;
     return (int)launch_env_step(*env, batch, *io, pdt_of(*env), static_cast<hipStream_t>(stream));
 }
 

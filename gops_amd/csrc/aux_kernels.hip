@@ -1041,6 +1041,20 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
             if (data && env.clip_obs && (xn[i] > env.obs_high[i] || xn[i] < env.obs_low[i])) done_m = true;   // clip_obs: bounds are finite
         }
         if (data && done_m) r -= 100.f;
+    } else if (env.kind == GOPS_ENV_CARTPOLE || env.kind == GOPS_ENV_PENDULUM) {
+        const int NS = env.kind == GOPS_ENV_CARTPOLE ? 4 : 3;
+        float x[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NS; ++i) x[i] = obs_unscale(env, i, ob[i]);
+        if (env.kind == GOPS_ENV_CARTPOLE) {
+            cart_forward(cart_const(), x, u[0], xn, r, done_m);
+        } else {
+            PendStep w;
+            pend_forward(x, u[0], xn, r, w);
+        }
+        for (int i = 0; i < NS; ++i) {
+            const float v = obs_rescale(env, i, dn ? x[i] : xn[i]);
+            nob[i] = env.clip_obs ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
+        }
     } else if (env.kind == GOPS_ENV_IDPENDULUM) {   // data env == model (pyth_idpendulum.py:71-87 calls the model's Dynamics)
         const IdpConst IC = idp_const();
         float s[6], sn[6], s0[6];

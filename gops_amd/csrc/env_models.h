@@ -54,6 +54,88 @@ __device__ __forceinline__ void lq_backward(const GopsEnv& e, const float* x, co
     }
 }
 
+// ================================ gym_cartpoleconti ===========================================
+// gops/env/env_gym/env_model/gym_cartpoleconti_model.py:101-129: Euler step (dt = 0.02) of the cart-pole with
+// force = 10 a; done on the NEXT state (|x| > 2.4 or |theta| > 12 deg); reward = 1 - done (no gradient).
+// Python-double constants reach the fp32 tensors rounded once, like torch does.
+struct CartConst { float g, M, mp, L, pml, fmag, dt, xth, thth; };
+__device__ __forceinline__ CartConst cart_const() {
+    CartConst c;
+    c.g = 9.8f; c.M = (float)(0.1 + 1.0); c.mp = 0.1f; c.L = 0.5f; c.pml = (float)(0.1 * 0.5); c.fmag = 10.f; c.dt = 0.02f;
+    c.xth = 2.4f; c.thth = (float)(12 * 2 * 3.14159265358979323846 / 360);
+    return c;
+}
+__device__ __forceinline__ void cart_forward(const CartConst& C, const float* x, float a, float* xn, float& r, bool& done) {
+    float sth, cth;
+    sincosf(x[2], &sth, &cth);
+    const float force = C.fmag * a;
+    const float temp = (force + C.pml * x[3] * x[3] * sth) / C.M;
+    const float thacc = (C.g * sth - cth * temp) / (C.L * (4.0f / 3.0f - C.mp * cth * cth / C.M));
+    const float xacc = temp - C.pml * thacc * cth / C.M;
+    xn[0] = x[0] + C.dt * x[1];
+    xn[1] = x[1] + C.dt * xacc;
+    xn[2] = x[2] + C.dt * x[3];
+    xn[3] = x[3] + C.dt * thacc;
+    done = (xn[0] < -C.xth) || (xn[0] > C.xth) || (xn[2] < -C.thth) || (xn[2] > C.thth);
+    r = done ? 0.f : 1.f;
+}
+// adjoint of the state part: gxn (adjoint of x') -> gx (accumulated), ga (overwritten); the reward has no gradient
+__device__ __forceinline__ void cart_backward(const CartConst& C, const float* x, float a, const float* gxn, float* gx, float& ga) {
+    float s, c;
+    sincosf(x[2], &s, &c);
+    const float thd = x[3];
+    const float temp = (C.fmag * a + C.pml * thd * thd * s) / C.M;
+    const float D = C.L * (4.0f / 3.0f - C.mp * c * c / C.M), N = C.g * s - c * temp, thacc = N / D;
+    const float dtemp_dth = C.pml * thd * thd * c / C.M, dtemp_dthd = 2.f * C.pml * thd * s / C.M, dtemp_dF = 1.f / C.M;
+    const float dN_dth = C.g * c + s * temp - c * dtemp_dth, dD_dth = C.L * (2.f * C.mp * c * s / C.M);
+    const float dA_dth = (dN_dth * D - N * dD_dth) / (D * D);        // thetaacc
+    const float dA_dthd = -c * dtemp_dthd / D, dA_dF = -c * dtemp_dF / D;
+    const float k = C.pml / C.M;
+    const float dX_dth = dtemp_dth - k * (dA_dth * c - thacc * s);   // xacc
+    const float dX_dthd = dtemp_dthd - k * c * dA_dthd, dX_dF = dtemp_dF - k * c * dA_dF;
+    gx[0] += gxn[0];
+    gx[1] += gxn[1] + C.dt * gxn[0];
+    gx[2] += gxn[2] + C.dt * (gxn[1] * dX_dth + gxn[3] * dA_dth);
+    gx[3] += gxn[3] + C.dt * gxn[2] + C.dt * (gxn[1] * dX_dthd + gxn[3] * dA_dthd);
+    ga = C.fmag * C.dt * (gxn[1] * dX_dF + gxn[3] * dA_dF);
+}
+
+// ================================ gym_pendulum ================================================
+// gops/env/env_gym/env_model/gym_pendulum_model.py:72-115: obs = (cos th, sin th, thdot); th = arccs(sin, cos) with the
+// 0.9999 guard; thdot' = clamp(thdot + (-15 sin(th + pi) + 3 a) dt, +-8) (the UNCLAMPED value advances th), dt = 0.05;
+// reward = -(angle_normalize(th)^2 + 0.1 thdot^2 + 0.001 a^2) on the CURRENT state; never done.
+struct PendStep { float th, nw_raw, nth; };
+__device__ __forceinline__ float pend_th(float costh, float sinth) {
+    const float pi = 3.14159265358979323846f;
+    const float t = acosf(0.9999f * costh);
+    return (sinth > 0.f) ? t : (2.f * pi - t);
+}
+__device__ __forceinline__ void pend_forward(const float* x, float a, float* xn, float& r, PendStep& w) {
+    const float pi = 3.14159265358979323846f;
+    w.th = pend_th(x[0], x[1]);
+    w.nw_raw = x[2] + (-15.f * sinf(w.th + pi) + 3.f * a) * 0.05f;
+    w.nth = w.th + w.nw_raw * 0.05f;
+    sincosf(w.nth, &xn[1], &xn[0]);
+    xn[2] = fminf(fmaxf(w.nw_raw, -8.f), 8.f);
+    const float an = angle_normalize(w.th);
+    r = -(an * an + 0.1f * (x[2] * x[2]) + 0.001f * (a * a));
+}
+// adjoints: gxn (adjoint of x'), gr (adjoint of r) -> gx (accumulated), ga (overwritten)
+__device__ __forceinline__ void pend_backward(const float* x, float a, const float* gxn, float gr, float* gx, float& ga) {
+    const float pi = 3.14159265358979323846f;
+    float xn[3], r;
+    PendStep w;
+    pend_forward(x, a, xn, r, w);
+    const float g_nth = -xn[1] * gxn[0] + xn[0] * gxn[1];
+    const float g_raw = g_nth * 0.05f + ((w.nw_raw >= -8.f && w.nw_raw <= 8.f) ? gxn[2] : 0.f);
+    const float g_th = g_nth + g_raw * (-15.f * cosf(w.th + pi)) * 0.05f + gr * (-2.f * angle_normalize(w.th));
+    const float u = 0.9999f * x[0];
+    const float dth_dc = ((x[1] > 0.f) ? -1.f : 1.f) * 0.9999f / sqrtf(1.f - u * u);
+    gx[0] += g_th * dth_dc;
+    gx[2] += g_raw + gr * (-0.2f * x[2]);
+    ga = g_raw * (3.f * 0.05f) + gr * (-0.002f * a);
+}
+
 // ================================ pyth_idpendulum =============================================
 struct IdpConst {   // products of the Python-double constants, rounded once like torch does
     float a, b, e, f, h, k, gb, ge, l1, l2;

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 s_gy[tid * 4 + 0] = g_r;
                 s_gy[tid * 4 + 1] = s_gy[tid * 4 + 2] = s_gy[tid * 4 + 3] = 0.f;
             }
-        } else if (ENV == GOPS_ENV_LQ || ENV == GOPS_ENV_IDPENDULUM) {
+        } else if (ENV == GOPS_ENV_LQ || ENV == GOPS_ENV_IDPENDULUM || ENV == GOPS_ENV_CARTPOLE || ENV == GOPS_ENV_PENDULUM) {
             if (tid < TB) {
                 const int m = tid;
                 float th[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, dflag = 1.f;
@@ -353,7 +353,30 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 float Gin[GOPS_MAX_LQ_STATE], gx[GOPS_MAX_LQ_STATE];
 #pragma unroll
                 for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { Gin[i] = (i < O) ? G[m * ldx + i] : 0.f; gx[i] = 0.f; }
-                if (ENV == GOPS_ENV_LQ) {
+                if (ENV == GOPS_ENV_CARTPOLE || ENV == GOPS_ENV_PENDULUM) {
+                    constexpr int NS = (ENV == GOPS_ENV_CARTPOLE) ? 4 : 3;
+                    if (p.env.clip_obs) {   // ClipObservation on the (rescaled) next observation
+                        float xn[4] = {0.f, 0.f, 0.f, 0.f}, rdummy;
+                        bool ddummy;
+                        PendStep wdummy;
+                        if (ENV == GOPS_ENV_CARTPOLE) cart_forward(cart_const(), x, u[0], xn, rdummy, ddummy);
+                        else pend_forward(x, u[0], xn, rdummy, wdummy);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const float pre = obs_rescale(p.env, i, dn ? x[i] : xn[i]);
+                            if (!(pre >= p.env.obs_low[i] && pre <= p.env.obs_high[i])) Gin[i] = 0.f;
+                        }
+                    }
+                    if (p.env.scale_obs) {
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) Gin[i] *= p.env.obs_scale[i];
+                    }
+                    float gxn[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) { gxn[i] = dn ? 0.f : Gin[i]; gx[i] = dn ? Gin[i] : 0.f; }
+                    if (ENV == GOPS_ENV_CARTPOLE) cart_backward(cart_const(), x, u[0], gxn, gx, gu[0]);
+                    else pend_backward(x, u[0], gxn, g_rm, gx, gu[0]);
+                } else if (ENV == GOPS_ENV_LQ) {
                     if (p.env.clip_obs) {
                         float xn[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rdummy;
                         lq_forward(p.env, x, u, xn, rdummy);
@@ -704,6 +727,8 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
             else LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 0, 0);
             break;
         case GOPS_ENV_VEH3DOF_SURR: LAUNCH_BWD(GOPS_ENV_VEH3DOF_SURR, 0, 0); break;
+        case GOPS_ENV_CARTPOLE: LAUNCH_BWD(GOPS_ENV_CARTPOLE, 0, 0); break;
+        case GOPS_ENV_PENDULUM: LAUNCH_BWD(GOPS_ENV_PENDULUM, 0, 0); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -293,6 +293,29 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                         }
                 }
             }
+        } else if (ENV == GOPS_ENV_CARTPOLE || ENV == GOPS_ENV_PENDULUM) {
+            if (tid < TB) {   // gym-style models: obs == state, same wrapper handling as pyth_lq
+                const int m = tid;
+                constexpr int NS = (ENV == GOPS_ENV_CARTPOLE) ? 4 : 3;
+                float x[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < NS; ++i) x[i] = obs_unscale(p.env, i, xs[m * ldx + i]);
+                const float a = s_act[m * 4];
+                if (ENV == GOPS_ENV_CARTPOLE) {
+                    cart_forward(cart_const(), x, a, xn, r, done_m);
+                } else {
+                    PendStep w;
+                    pend_forward(x, a, xn, r, w);
+                }
+                const bool frozen = s_done[m] != 0.f;
+                if (!frozen || p.env.clip_obs || p.env.scale_obs) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const float v = obs_rescale(p.env, i, frozen ? x[i] : xn[i]);
+                        xs[m * ldx + i] = p.env.clip_obs ? clampf(v, p.env.obs_low[i], p.env.obs_high[i]) : v;
+                    }
+                }
+            }
         } else if (ENV == GOPS_ENV_IDPENDULUM) {
             if (tid < TB) {
                 const int m = tid;
@@ -522,7 +545,7 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
     sk[0] = sk[1] = 0;
     const MlpDev& M = p.pol;
     if (p.f16) return;   // the half-precision path streams its (half as large) weights from L2
-    if (p.env.kind == GOPS_ENV_VEH3DOF_SURR) return;   // constrained models: streamed kernels only
+    if (p.env.kind >= GOPS_ENV_VEH3DOF_SURR) return;   // constrained / gym-style models: streamed kernels only
     // Register-stationary weights pin one workgroup per CU.  That is the right trade only while there
     // is at most one tile per CU (B <= 16 * #CUs = 4096 on MI355X); with more tiles the streamed
     // kernels win because 2-3 workgroups per CU overlap each other's MFMA and VALU phases.
@@ -602,6 +625,8 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
             else LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 0, 0);
             break;
         case GOPS_ENV_VEH3DOF_SURR: LAUNCH_FWD(GOPS_ENV_VEH3DOF_SURR, 0, 0); break;
+        case GOPS_ENV_CARTPOLE: LAUNCH_FWD(GOPS_ENV_CARTPOLE, 0, 0); break;
+        case GOPS_ENV_PENDULUM: LAUNCH_FWD(GOPS_ENV_PENDULUM, 0, 0); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

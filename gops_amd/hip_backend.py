@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOPS_HIP_LIB") or os.path.join(_HERE, "libgops_hip.so")
 
 MAX_LAYERS, MAX_ACT, MAX_LQ, TILE = 5, 4, 6, 16
-ENV_NONE, ENV_LQ, ENV_IDP, ENV_VEH, ENV_VEH_SURR = 0, 1, 2, 3, 4
+ENV_NONE, ENV_LQ, ENV_IDP, ENV_VEH, ENV_VEH_SURR, ENV_CARTPOLE, ENV_PENDULUM = 0, 1, 2, 3, 4, 5, 6
 MAX_SURR = 4
 ACT_IDS = {"linear": 0, "relu": 1, "elu": 2, "gelu": 3, "selu": 4, "sigmoid": 5, "tanh": 6}
 DTYPE_IDS = {"fp32": 0, "f32": 0, "float32": 0, "fp16": 1, "f16": 1, "float16": 1, "half": 1}

@@ -103,6 +103,10 @@ def veh_obs_f32(state: np.ndarray, ref_points: np.ndarray) -> np.ndarray:
 def obs_dim_of(cfg: Dict) -> int:
     if cfg["env_id"] == "pyth_idpendulum":
         return 6
+    if cfg["env_id"] == "gym_cartpoleconti":
+        return 4
+    if cfg["env_id"] == "gym_pendulum":
+        return 3
     if cfg["env_id"] == "pyth_veh3dofconti":
         return 6 + 4 * cfg["pre_horizon"]
     if cfg["env_id"] in _SURR_ENVS:
@@ -118,7 +122,7 @@ def n_surr_of(cfg: Dict) -> int:
 
 
 def act_dim_of(cfg: Dict) -> int:
-    if cfg["env_id"] == "pyth_idpendulum":
+    if cfg["env_id"] in ("pyth_idpendulum", "gym_cartpoleconti", "gym_pendulum"):
         return 1
     if cfg["env_id"] == "pyth_veh3dofconti" or cfg["env_id"] in _SURR_ENVS:
         return 2
@@ -134,6 +138,12 @@ def make_batch(cfg: Dict, seed: int, batch: int = None) -> Dict[str, torch.Tenso
     if env_id == "pyth_idpendulum":
         h = np.array([5, 0.1, 0.1, 0.3, 0.3, 0.3], dtype=np.float32)
         out["obs"] = rng.uniform(-h, h, size=(B, 6)).astype(np.float32)
+    elif env_id == "gym_cartpoleconti":   # wide enough that some trajectories leave |x| <= 2.4 / |theta| <= 12 deg within a rollout
+        h = np.array([2.3, 1.0, 0.2, 1.0], dtype=np.float32)
+        out["obs"] = rng.uniform(-h, h, size=(B, 4)).astype(np.float32)
+    elif env_id == "gym_pendulum":        # (cos th, sin th, thdot), speeds up to the +-8 clamp
+        th = rng.uniform(-np.pi, np.pi, size=B)
+        out["obs"] = np.stack((np.cos(th), np.sin(th), rng.uniform(-8.0, 8.0, size=B)), axis=1).astype(np.float32)
     elif env_id == "pyth_lq":
         mean, std = (np.array(v, dtype=np.float32) for v in _LQ_INIT[cfg.get("lq_config", "s4a2")])
         out["obs"] = rng.uniform(mean - 3 * std, mean + 3 * std, size=(B, len(mean))).astype(np.float32)

@@ -55,7 +55,10 @@ enum { GOPS_OK = 0, GOPS_ERR_BAD_ARG = -1, GOPS_ERR_UNSUPPORTED = -2, GOPS_ERR_W
 enum { GOPS_ENV_NONE = 0, GOPS_ENV_LQ = 1, GOPS_ENV_IDPENDULUM = 2, GOPS_ENV_VEH3DOFCONTI = 3,
        /* veh3dofconti + surrounding vehicles + constraint outputs: pyth_veh3dofconti_surrcstr_model.py:42-148 and
           pyth_veh3dofconti_detour_model.py:40-181 (the models behind FHADPExterior / Interior / Lagrangian) */
-       GOPS_ENV_VEH3DOF_SURR = 4 };
+       GOPS_ENV_VEH3DOF_SURR = 4,
+       /* gym-style models of the INFADP / MAC example scripts (obs == state, no info):
+          gops/env/env_gym/env_model/gym_cartpoleconti_model.py:24-129 and gym_pendulum_model.py:26-115 */
+       GOPS_ENV_CARTPOLE = 5, GOPS_ENV_PENDULUM = 6 };
 #define GOPS_MAX_SURR 4        /* surrounding vehicles */
 #define GOPS_MAX_CONSTRAINT 3  /* constraint outputs per step */
 
@@ -139,7 +142,7 @@ typedef struct GopsEnv {
     int32_t data_env;
     /* ScaleObservationModel (gops/env/wrapper/scale_observation.py:74-119; create_env_model.py:115-118 puts it between
      * ShapingReward and ClipObservation): the observations the policy and the caller see are (obs + obs_shift) * obs_scale;
-     * the model steps obs / obs_scale - obs_shift.  GOPS_ENV_LQ / GOPS_ENV_IDPENDULUM only (obs_dim <= 8).  As in the
+     * the model steps obs / obs_scale - obs_shift.  GOPS_ENV_LQ / _IDPENDULUM / _CARTPOLE / _PENDULUM only (obs_dim <= 8).  As in the
      * reference, ClipObservationModel then clips the SCALED observation with the model's own (unscaled) bounds. */
     int32_t scale_obs;
     float obs_scale[8], obs_shift[8];

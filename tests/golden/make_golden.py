@@ -128,6 +128,21 @@ OBS_SCALE_STEP_CASES = {   # ScaleObservationModel (example_train/fhadp/fhadp_ml
                                     dict(obs_scale=10, obs_shift=[0.1, -0.2, 0.05, 0.0, 0.3], reward_scale=0.5, reward_shift=1.0)),
     "step_idp_obsscale_shift": (dict(env_id="pyth_idpendulum"), dict(obs_scale=[1, 2, 2, 0.5, 0.5, 0.25], obs_shift=0.1)),
 }
+GYM_STEP_CASES = {   # gym-style models of the INFADP / MAC example scripts (cartpoleconti uses obs_scale in its script)
+    "step_cartpole": (dict(env_id="gym_cartpoleconti"), {}),
+    "step_cartpole_obsscale": (dict(env_id="gym_cartpoleconti"), dict(obs_scale=[1.0, 0.5, 2.0, 0.25], reward_scale=0.5, reward_shift=0.1)),
+    "step_pendulum": (dict(env_id="gym_pendulum"), {}),
+}
+GYM_SMALL = {
+    "infadp_cartpole_gelu": (dict(alg="INFADP", env_id="gym_cartpoleconti", batch=64, horizon=10,
+                                  hidden=(64, 64), act="gelu", gamma=0.99), dict(obs_scale=[1.0, 1.0, 1.0, 1.0])),
+    "mac_pendulum_elu": (dict(alg="MAC", env_id="gym_pendulum", batch=48, horizon=12,
+                              hidden=(64, 64), act="elu", gamma=0.99), {}),
+    "infadp_pendulum_tanh": (dict(alg="INFADP", env_id="gym_pendulum", batch=33, horizon=8,
+                                  hidden=(64, 64), act="tanh", gamma=0.97), dict(reward_scale=0.1)),
+}
+
+
 SPIL_CASES = {   # gops/algorithm/spil.py on the constrained veh3dofconti models (one full update: PEV + PIM gradients)
     "spil_surrcstr_p10": (dict(alg="SPIL", env_id="pyth_veh3dofconti_surrcstr", batch=48, horizon=10, pre_horizon=10,
                                hidden=(64, 64), act="elu", gamma=0.99), dict(constraint_dim=1)),
@@ -221,7 +236,7 @@ def golden_steps(cases=None):
             out[f"s{s}/obs"] = o.numpy().copy()
             out[f"s{s}/rew"] = r.numpy().copy()
             out[f"s{s}/done"] = d.numpy().copy()
-            if "state" in info and info["state"] is not None:
+            if "ref_points" in info and info.get("state") is not None:
                 out[f"s{s}/state"] = info["state"].numpy().copy()
                 out[f"s{s}/ref_last"] = info["ref_points"][:, -1].numpy().copy()
         out["meta/nsteps"] = nsteps
@@ -592,7 +607,11 @@ def golden_data_envs():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym"]
+    if "gym" in which:
+        golden_steps(GYM_STEP_CASES)
+        np.random.seed(0)
+        golden_small(GYM_SMALL)
     if "spil" in which:
         golden_spil()
     if "mac" in which:

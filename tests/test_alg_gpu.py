@@ -67,7 +67,8 @@ def test_fhadp_class_matches_reference(name):
     assert any((a - b).abs().max() > 0 for a, b in zip(after, before))
 
 
-@pytest.mark.parametrize("name", ["infadp_lq_s4a2_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift", "mac_idp_elu"])
+@pytest.mark.parametrize("name", ["infadp_lq_s4a2_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift", "mac_idp_elu",
+                                  "infadp_cartpole_gelu", "mac_pendulum_elu"])
 def test_infadp_class_matches_reference(name):
     alg, g, cfg = _load_alg(name)
     alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]

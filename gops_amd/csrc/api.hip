@@ -163,7 +163,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     memset(&p, 0, sizeof(p));
     const GopsEnv& e = desc.env;
     if (desc.batch < 1 || desc.horizon < 1 || desc.horizon > GOPS_MAX_HORIZON) return GOPS_ERR_BAD_ARG;
-    if (e.kind < GOPS_ENV_NONE || e.kind > GOPS_ENV_PENDULUM) return GOPS_ERR_BAD_ARG;
+    if (e.kind < GOPS_ENV_NONE || e.kind > GOPS_ENV_VEH2DOF) return GOPS_ERR_BAD_ARG;
     if (e.obs_dim < 1 || e.data_env) return GOPS_ERR_BAD_ARG;   // data-env semantics exist for gops_env_step only
     const int pol_out = (e.kind == GOPS_ENV_NONE) ? 1 : e.act_dim;
     if (desc.dtype != GOPS_DTYPE_F32 && desc.dtype != GOPS_DTYPE_F16) return GOPS_ERR_BAD_ARG;
@@ -179,6 +179,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     if (e.scale_obs && e.kind != GOPS_ENV_LQ && e.kind != GOPS_ENV_IDPENDULUM && e.kind < GOPS_ENV_CARTPOLE) return GOPS_ERR_UNSUPPORTED;   // obs_dim <= 8 only
     if (e.kind == GOPS_ENV_CARTPOLE && (e.obs_dim != 4 || e.act_dim != 1)) return GOPS_ERR_BAD_ARG;
     if (e.kind == GOPS_ENV_PENDULUM && (e.obs_dim != 3 || e.act_dim != 1)) return GOPS_ERR_BAD_ARG;
+    if (e.kind == GOPS_ENV_VEH2DOF && (e.act_dim != 1 || e.pre_horizon < 1 || e.obs_dim != 4 + e.pre_horizon || e.clip_obs)) return GOPS_ERR_BAD_ARG;
     if (e.kind >= GOPS_ENV_CARTPOLE && f16) return GOPS_ERR_UNSUPPORTED;   // the half-precision kernels are built for the BASELINE envs
     if (e.kind == GOPS_ENV_LQ && (e.obs_dim > GOPS_MAX_LQ_STATE || e.act_dim > GOPS_MAX_ACT)) return GOPS_ERR_UNSUPPORTED;
     if (e.kind == GOPS_ENV_IDPENDULUM && (e.obs_dim != 6 || e.act_dim != 1 || e.clip_obs)) return GOPS_ERR_BAD_ARG;
@@ -225,7 +226,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     if (const char* tm = getenv("GOPS_TOUCH")) p.touch_mode = atoi(tm);   // tuning knob
     p.ldx = kp0 + 4;
     p.ldh = hmax + 4;
-    const bool veh = e.kind == GOPS_ENV_VEH3DOFCONTI || e.kind == GOPS_ENV_VEH3DOF_SURR;
+    const bool veh = env_has_ref_table(e.kind);
     const int ref_pts = veh ? e.pre_horizon + 1 + desc.horizon
                                                           : (e.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
     if (rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16) > 160 * 1024)
@@ -294,7 +295,7 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
     if (rc != GOPS_OK) return rc;
     if (ws == nullptr || ws_bytes < plan.bytes) return GOPS_ERR_WORKSPACE;
     if (in.obs == nullptr || out.v_pi == nullptr) return GOPS_ERR_BAD_ARG;
-    if ((desc.env.kind == GOPS_ENV_VEH3DOFCONTI || desc.env.kind == GOPS_ENV_VEH3DOF_SURR) &&
+    if (env_has_ref_table(desc.env.kind) &&
         (!in.state || !in.ref_points || !in.path_num || !in.u_num || !in.ref_time)) return GOPS_ERR_BAD_ARG;
     if (desc.env.kind == GOPS_ENV_VEH3DOF_SURR && !in.surr_state) return GOPS_ERR_BAD_ARG;
     RolloutParams& p = plan.p;
@@ -559,13 +560,13 @@ int gops_rollout_backward_open_loop(const GopsRolloutDesc* desc, const GopsRollo
 
 int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream) {
     if (!env || !io || batch < 1) return GOPS_ERR_BAD_ARG;
-    if (env->kind < GOPS_ENV_LQ || env->kind > GOPS_ENV_PENDULUM) return GOPS_ERR_BAD_ARG;
-    if (env->kind >= GOPS_ENV_CARTPOLE && env->data_env) return GOPS_ERR_UNSUPPORTED;   // gym data envs are not restated
+    if (env->kind < GOPS_ENV_LQ || env->kind > GOPS_ENV_VEH2DOF) return GOPS_ERR_BAD_ARG;
+    if (env->kind >= GOPS_ENV_CARTPOLE && env->data_env) return GOPS_ERR_UNSUPPORTED;   // these data envs are not restated
     if (!io->obs || !io->action || !io->next_obs || !io->reward || !io->next_done) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_VEH3DOF_SURR &&
         (env->data_env || env->n_surr < 1 || env->n_surr > GOPS_MAX_SURR || (env->n_constraint != 1 && env->n_constraint != 3) ||
          !io->surr_state || !io->next_surr_state || !io->constraint)) return GOPS_ERR_BAD_ARG;
-    if ((env->kind == GOPS_ENV_VEH3DOFCONTI || env->kind == GOPS_ENV_VEH3DOF_SURR) &&
+    if (env_has_ref_table(env->kind) &&
         (!io->state || !io->ref_points || !io->path_num || !io->u_num || !io->ref_time ||
          !io->next_state || !io->next_ref_points || !io->next_ref_time)) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_LQ && env->obs_dim > GOPS_MAX_LQ_STATE) return GOPS_ERR_UNSUPPORTED;

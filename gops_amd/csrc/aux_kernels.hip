@@ -156,13 +156,18 @@ __device__ __forceinline__ void ref_table_element(int B, int P, int H, const flo
                                                   const float* __restrict__ path_num,
                                                   const float* __restrict__ u_num,
                                                   const float* __restrict__ ref_time, float pdt,
-                                                  float* __restrict__ table, int idx) {
+                                                  float* __restrict__ table, int idx, bool yphi_only) {
     const int TL = P + 1 + H;
     if (idx >= B * TL) return;
     const int b = idx / TL, i = idx - b * TL;
     f32x4 v;
     if (i <= P) {
-        v = reinterpret_cast<const f32x4*>(ref_points)[(size_t)b * (P + 1) + i];
+        if (yphi_only) {   // pyth_veh2dofconti: info["ref_points"] [B, P+1, 2] = (y, phi)
+            const float* rp = ref_points + ((size_t)b * (P + 1) + i) * 2;
+            v = f32x4{0.f, rp[0], rp[1], 0.f};
+        } else {
+            v = reinterpret_cast<const f32x4*>(ref_points)[(size_t)b * (P + 1) + i];
+        }
     } else {
         float t = ref_time[b];
         for (int s = 0; s < i - P; ++s) t = RADD(t, 0.1f);
@@ -222,11 +227,11 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
             b -= nb;
         }
     }
-    if (p.env.kind == GOPS_ENV_VEH3DOFCONTI || p.env.kind == GOPS_ENV_VEH3DOF_SURR) {
+    if (env_has_ref_table(p.env.kind)) {
         const int nrt = (p.B * (P + 1 + p.H) + 255) / 256;
         if (b < nrt) {
             ref_table_element(p.B, P, p.H, p.in.ref_points, p.in.path_num, p.in.u_num, p.in.ref_time, pdt,
-                              const_cast<float*>(p.ref_table), b * 256 + threadIdx.x);
+                              const_cast<float*>(p.ref_table), b * 256 + threadIdx.x, p.env.kind == GOPS_ENV_VEH2DOF);
             return;
         }
         b -= nrt;
@@ -256,7 +261,7 @@ hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, fl
         if (!p.f16) { nb += pack_blocks(d); continue; }
         for (int j = 0; j < d.nl - 1; ++j) nb += pack_blocks_h(d, j);
     }
-    if (p.env.kind == GOPS_ENV_VEH3DOFCONTI || p.env.kind == GOPS_ENV_VEH3DOF_SURR) nb += (p.B * (P + 1 + p.H) + 255) / 256;
+    if (env_has_ref_table(p.env.kind)) nb += (p.B * (P + 1 + p.H) + 255) / 256;
     if (p.env.kind == GOPS_ENV_VEH3DOF_SURR) nb += (p.B * p.env.n_surr + 255) / 256;
     hipLaunchKernelGGL(prologue_kernel, dim3(nb), dim3(256), 0, s, p, dst, P, pdt);
     return hipGetLastError();
@@ -1069,6 +1074,33 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         r = idp_reward(s, u[0]);
         done_m = idp_done(IC, s);
         for (int i = 0; i < 6; ++i) nob[i] = (dn && !env.scale_obs) ? ob[i] : obs_rescale(env, i, dn ? s0[i] : s[i]);
+    } else if (env.kind == GOPS_ENV_VEH2DOF) {
+        const Veh2Const C2 = veh2_const();
+        const int P = env.pre_horizon;
+        float s[4], sn[4], o4[4];
+        for (int i = 0; i < 4; ++i) { s[i] = io.state[(size_t)b * 4 + i]; o4[i] = ob[i]; }
+        r = veh2_reward(o4, u[0]);
+        float sphi, cphi;
+        sincosf(s[1], &sphi, &cphi);
+        veh2_f_xu(C2, s, u[0], sphi, cphi, sn);
+        const float nt = RADD(io.ref_time[b], 0.1f);
+        const float pn = io.path_num[b], un = io.u_num[b];
+        const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : 3;
+        const f32x4 newp = ref_point(RADD(nt, pdt), path, un == 0.f ? 0 : 1);
+        const float* rin = io.ref_points + (size_t)b * (P + 1) * 2;
+        float* rout = io.next_ref_points + (size_t)b * (P + 1) * 2;
+        for (int i = 0; i < P; ++i) { rout[2 * i] = rin[2 * (i + 1)]; rout[2 * i + 1] = rin[2 * (i + 1) + 1]; }
+        rout[2 * P] = newp[1]; rout[2 * P + 1] = newp[2];
+        const float o0 = sn[0] - rout[0], o1 = sn[1] - rout[1];
+        done_m = (fabsf(o0) > 2.f) || (fabsf(o1) > 3.14159265358979323846f);
+        if (dn) {
+            for (int i = 0; i < O; ++i) nob[i] = ob[i];
+        } else {
+            nob[0] = o0; nob[1] = o1; nob[2] = sn[2]; nob[3] = sn[3];
+            for (int i = 1; i <= P; ++i) nob[3 + i] = sn[0] - rout[2 * i];
+        }
+        for (int i = 0; i < 4; ++i) io.next_state[(size_t)b * 4 + i] = sn[i];
+        io.next_ref_time[b] = nt;
     } else if (env.kind == GOPS_ENV_VEH3DOFCONTI || env.kind == GOPS_ENV_VEH3DOF_SURR) {
         const bool surr = env.kind == GOPS_ENV_VEH3DOF_SURR;
         const VehConst VC = veh_const();

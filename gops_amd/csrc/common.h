@@ -25,6 +25,11 @@ template <class T> __device__ __forceinline__ const GLOBAL_AS T* gptr(const T* p
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 ld4(const GLOBAL_AS float* p) { return *(const GLOBAL_AS f32x4*)p; }
 
+// models that read a reference-trajectory table [B][P + 1 + H][4] = (x, y, phi, u) built by the prologue
+__host__ __device__ inline bool env_has_ref_table(int kind) {
+    return kind == GOPS_ENV_VEH3DOFCONTI || kind == GOPS_ENV_VEH3DOF_SURR || kind == GOPS_ENV_VEH2DOF;
+}
+
 // ---- device-side descriptors (passed by value as kernel arguments) -------------------------
 struct MlpDev {
     int nl;                       // Linear layers

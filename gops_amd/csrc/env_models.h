@@ -258,6 +258,46 @@ __device__ __forceinline__ bool idp_done(const IdpConst& C, const float* s) {
     return (tip_y <= 1.0f) || (fabsf(s[0]) >= 15.f);
 }
 
+// ================================ pyth_veh2dofconti ===========================================
+// gops/env/env_ocp/env_model/pyth_veh2dofconti_model.py:24-174 (vehicle parameters pyth_veh2dofconti.py:24-34, u = 5):
+// linear 2-DOF lateral dynamics stepped in the ego frame (y = phi = 0), then placed back:
+//   v' = ((m v) u + c1 w - (c2 steer) u - c3 w) / den_v,  w' = ((Iz w) u + c1 v - (c4 steer) u) / den_w,
+//   y' = y + (u sin phi) dt + (dt v) cos phi,  phi' = angle_normalize(phi + dt w)
+// with the Python-double coefficient products rounded once (as torch does when a scalar meets an fp32 tensor).
+struct Veh2Const { float m, Iz, u, dt, c1, c2, c3, c4, den_v, den_w; };
+__device__ __forceinline__ Veh2Const veh2_const() {
+    const double k_f = -128915.5, k_r = -85943.6, l_f = 1.06, l_r = 1.85, m = 1412.0, I_z = 1536.7, u = 5.0, dt = 0.1;
+    Veh2Const c;
+    c.m = (float)m; c.Iz = (float)I_z; c.u = (float)u; c.dt = (float)dt;
+    c.c1 = (float)(dt * (l_f * k_f - l_r * k_r));
+    c.c2 = (float)(dt * k_f);
+    c.c3 = (float)(dt * m * (u * u));
+    c.c4 = (float)(dt * l_f * k_f);
+    c.den_v = (float)(m * u - dt * (k_f + k_r));
+    c.den_w = (float)(I_z * u - dt * (l_f * l_f * k_f + l_r * l_r * k_r));
+    return c;
+}
+__device__ __forceinline__ void veh2_f_xu(const Veh2Const& C, const float* s, float steer, float sphi, float cphi, float* sn) {
+    const float v = s[2], w = s[3];
+    sn[2] = (C.m * v * C.u + C.c1 * w - C.c2 * steer * C.u - C.c3 * w) / C.den_v;
+    sn[3] = (C.Iz * w * C.u + C.c1 * v - C.c4 * steer * C.u) / C.den_w;
+    sn[0] = s[0] + C.u * sphi * C.dt + (C.dt * v) * cphi;
+    sn[1] = angle_normalize(s[1] + C.dt * w);
+}
+// adjoint: ln (adjoint of the next state) -> l (adjoint of the state, overwritten), g_steer
+__device__ __forceinline__ void veh2_f_xu_bwd(const Veh2Const& C, const float* s, float sphi, float cphi, const float* ln,
+                                              float* l, float& g_steer) {
+    const float v = s[2];
+    l[0] = ln[0];
+    l[1] = ln[0] * (C.u * C.dt * cphi - C.dt * v * sphi) + ln[1];
+    l[2] = ln[0] * (C.dt * cphi) + ln[2] * (C.m * C.u / C.den_v) + ln[3] * (C.c1 / C.den_w);
+    l[3] = ln[1] * C.dt + ln[2] * ((C.c1 - C.c3) / C.den_v) + ln[3] * (C.Iz * C.u / C.den_w);
+    g_steer = ln[2] * (-C.c2 * C.u / C.den_v) + ln[3] * (-C.c4 * C.u / C.den_w);
+}
+__device__ __forceinline__ float veh2_reward(const float* o, float steer) {
+    return -(0.04f * (o[0] * o[0]) + 0.02f * (o[1] * o[1]) + 0.01f * (o[2] * o[2]) + 0.01f * (o[3] * o[3]) + 0.01f * (steer * steer));
+}
+
 // ================================ pyth_veh3dofconti ===========================================
 struct VehConst {
     float m, Iz, dt, c_lk, dt_kf, dt_m, den_v, dt_lfkf, den_w;

@@ -170,6 +170,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     const int O = p.env.obs_dim, A = p.env.act_dim;
     constexpr bool SURR = (ENV == GOPS_ENV_VEH3DOF_SURR);   // veh3dofconti + surrounding vehicles + constraint outputs
     constexpr bool VEH = (ENV == GOPS_ENV_VEH3DOFCONTI) || SURR;
+    constexpr bool VEH2 = (ENV == GOPS_ENV_VEH2DOF);
+    constexpr bool REF = VEH || VEH2;
     const int ldx = p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* G = smem;                    // [TB][ldx] adjoint of obs_{t+1}
     float* da = G + TB * ldx;           // [TB][ldh]
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     float* s_idp = reinterpret_cast<float*>(s_ref);             // idpendulum: [TB][5][24] sub-step parking
     // One-workgroup-per-CU variants: LDS copies of this step's H_2 / H_1 (Z for GELU) tiles, [2][TB][256]
     constexpr bool STAGE = (SK1 > 0);   // (those variants are only selected for obs-256-256-act policies)
-    float* s_stage = smem + bwd_lds_floats(ldx, ldh, VEH ? p.env.pre_horizon + 1 + p.H
+    float* s_stage = smem + bwd_lds_floats(ldx, ldh, REF ? p.env.pre_horizon + 1 + p.H
                                                                              : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0), F16);
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             const int a = idx / K, k = idx - a * K;
             s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
         }
-        if (VEH) {
+        if (REF) {
             const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
             for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -458,6 +460,49 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 for (int a = 0; a < GOPS_MAX_ACT; ++a)
                     s_gy[m * 4 + a] = (a < A) ? (p.open_loop == 2 ? gu[a] : wrap_action_bwd(p.env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a])) : 0.f;
             }
+        } else if (ENV == GOPS_ENV_VEH2DOF) {
+            if (tid < TB) {
+                const int m = tid, P = p.env.pre_horizon;
+                const Veh2Const C2 = veh2_const();
+                float th0 = 0.f, dflag = 1.f, steer = 0.f, s[4] = {0.f, 0.f, 0.f, 0.f}, o[4] = {0.f, 0.f, 0.f, 0.f};
+                if (m < nvalid) {
+                    const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
+                    const f32x4 e0 = er[0], e1 = er[1], e2 = er[2];
+                    th0 = e0[0]; steer = e0[2]; dflag = e1[0];
+                    s[0] = e1[1]; s[1] = e1[2]; s[2] = e1[3]; s[3] = e2[0];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = x_col(row0, m, i);
+                }
+                const bool dn = dflag != 0.f;
+                // adjoint of the next state: what later steps left in `lam` plus this step's observation adjoint
+                // (MaskAtDone: a finished trajectory's observation is frozen, its adjoint stays on obs_t)
+                float* gp = G + m * ldx;
+                float ln[4] = {lam[0], lam[1], lam[2], lam[3]};
+                if (!dn) {
+                    float gy = gp[0];
+                    for (int i = 1; i <= P; ++i) { gy += gp[3 + i]; gp[3 + i] = 0.f; }
+                    ln[0] += gy; ln[1] += gp[1]; ln[2] += gp[2]; ln[3] += gp[3];
+                    gp[0] = gp[1] = gp[2] = gp[3] = 0.f;
+                }
+                float sphi, cphi, g_steer;
+                sincosf(s[1], &sphi, &cphi);
+                float l[4];
+                veh2_f_xu_bwd(C2, s, sphi, cphi, ln, l, g_steer);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lam[i] = l[i];
+                const float g_rm = dn ? 0.f : g_r;
+                if (m < nvalid) {
+                    gp[0] += g_rm * (-0.08f * o[0]);
+                    gp[1] += g_rm * (-0.04f * o[1]);
+                    gp[2] += g_rm * (-0.02f * o[2]);
+                    gp[3] += g_rm * (-0.02f * o[3]);
+                }
+                g_steer += g_rm * (-0.02f * steer);
+                const float sc0 = (p.env.policy_high[0] - p.env.policy_low[0]) / 2.f;
+                const float abar0 = sc0 * th0 + (p.env.policy_high[0] + p.env.policy_low[0]) / 2.f;
+                s_gy[m * 4 + 0] = p.open_loop == 2 ? g_steer : wrap_action_bwd(p.env, 0, abar0, g_steer) * sc0 * (1.f - th0 * th0);
+                s_gy[m * 4 + 1] = s_gy[m * 4 + 2] = s_gy[m * 4 + 3] = 0.f;
+            }
         } else {   // GOPS_ENV_VEH3DOFCONTI
             const int m = tid & 15, part = tid >> 4, lane = tid & 63, wave = tid >> 6;
             const int P = p.env.pre_horizon;
@@ -697,7 +742,7 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
 
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, (p.env.kind == GOPS_ENV_VEH3DOFCONTI || p.env.kind == GOPS_ENV_VEH3DOF_SURR) ? p.env.pre_horizon + 1 + p.H
+    size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H
                                                        : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0), p.f16 != 0);
     int sk[2];
     rollout_variant(p, sk, true);
@@ -729,6 +774,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
         case GOPS_ENV_VEH3DOF_SURR: LAUNCH_BWD(GOPS_ENV_VEH3DOF_SURR, 0, 0); break;
         case GOPS_ENV_CARTPOLE: LAUNCH_BWD(GOPS_ENV_CARTPOLE, 0, 0); break;
         case GOPS_ENV_PENDULUM: LAUNCH_BWD(GOPS_ENV_PENDULUM, 0, 0); break;
+        case GOPS_ENV_VEH2DOF: LAUNCH_BWD(GOPS_ENV_VEH2DOF, 0, 0); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -132,6 +132,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     const int O = p.env.obs_dim, A = p.env.act_dim;
     constexpr bool SURR = (ENV == GOPS_ENV_VEH3DOF_SURR);   // veh3dofconti + surrounding vehicles + constraint outputs
     constexpr bool VEH = (ENV == GOPS_ENV_VEH3DOFCONTI) || SURR;
+    constexpr bool VEH2 = (ENV == GOPS_ENV_VEH2DOF);   // 2-DOF lateral model: state [4], reference points (y, phi)
+    constexpr bool REF = VEH || VEH2;                   // models with a reference-trajectory table
     // leading dimensions are compile-time constants in the register-stationary variants
     const int ldx = p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* xs = smem;                       // [TB][ldx]  current observation (+ time column)
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     f32x4* s_ref = reinterpret_cast<f32x4*>(s_bias + (GOPS_MAX_LAYERS - 1) * ldh);   // veh: [TB][TL]
     const int TL = p.env.pre_horizon + 1 + p.H;   // reference-table points per trajectory
     // F16: half copy of the policy / value input tile, [TB][ldx16], behind the reference-table region
-    _Float16* x16 = reinterpret_cast<_Float16*>(s_ref + (VEH ? TB * TL : 0));
+    _Float16* x16 = reinterpret_cast<_Float16*>(s_ref + (REF ? TB * TL : 0));
     const int ldx16 = (((p.ldx - 4) + 31) & ~31) + 8, ld16 = (p.ldh - 4) + 8;
     {   // one-time staging of everything the H-step loop would otherwise re-fetch from L2
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         stage_act_const(p.env, s_ac, tid);
         for (int j = 0; j < Lh; ++j)
             for (int n = tid; n < p.pol.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = gptr(p.pol.b[j])[n];
-        if (VEH) {
+        if (REF) {
             const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
             for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -178,6 +180,12 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         if (tid < TB * 6) {
             const int m = tid / 6, c = tid - m * 6;
             s_state[m * 8 + c] = (m < nvalid) ? gptr(p.in.state)[(size_t)(b0 + m) * 6 + c] : (c == 3 ? 1.f : 0.f);
+        }
+    }
+    if (VEH2) {
+        if (tid < TB * 8) {
+            const int m = tid >> 3, c = tid & 7;
+            s_state[m * 8 + c] = (m < nvalid && c < 4) ? gptr(p.in.state)[(size_t)(b0 + m) * 4 + c] : 0.f;
         }
     }
     typename std::conditional<(SK0 > 0), StatW<(SK0 > 0 ? SK0 : 1), 4>, NoW>::type W0;
@@ -260,6 +268,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 e0[2] = s_act[tid * 4 + 0];
                 e0[3] = s_act[tid * 4 + 1];
             }
+            if (VEH2) e0[2] = s_act[tid * 4 + 0];   // wrapped steer
             f32x4 e1 = {s_done[tid], s_state[tid * 8 + 0], s_state[tid * 8 + 1], s_state[tid * 8 + 2]};
             f32x4 e2 = {s_state[tid * 8 + 3], s_state[tid * 8 + 4], s_state[tid * 8 + 5], 0.f};
             er[0] = e0;
@@ -346,6 +355,29 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 } else if (p.env.scale_obs) {   // frozen rows pass through unscale / rescale like in the reference
 #pragma unroll
                     for (int i = 0; i < 6; ++i) xs[m * ldx + i] = obs_rescale(p.env, i, s_in[i]);
+                }
+            }
+        } else if (ENV == GOPS_ENV_VEH2DOF) {
+            if (tid < TB) {
+                const int m = tid, P = p.env.pre_horizon;
+                const Veh2Const C2 = veh2_const();
+                float s[4], sn[4], o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { s[i] = s_state[m * 8 + i]; o[i] = xs[m * ldx + i]; }
+                const float steer = s_act[m * 4];
+                r = veh2_reward(o, steer);
+                float sphi, cphi;
+                sincosf(s[1], &sphi, &cphi);
+                veh2_f_xu(C2, s, steer, sphi, cphi, sn);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_state[m * 8 + i] = sn[i];   // the info state advances whatever `done` says
+                const f32x4* tbl = s_ref + m * TL + (t + 1);              // reference points of the new time: (., y, phi, .)
+                const float o0 = sn[0] - tbl[0][1], o1 = sn[1] - tbl[0][2];
+                done_m = (fabsf(o0) > 2.f) || (fabsf(o1) > 3.14159265358979323846f);
+                if (s_done[m] == 0.f) {
+                    float* xo = xs + m * ldx;
+                    xo[0] = o0; xo[1] = o1; xo[2] = sn[2]; xo[3] = sn[3];
+                    for (int i = 1; i <= P; ++i) xo[3 + i] = sn[0] - tbl[i][1];
                 }
             }
         } else {   // GOPS_ENV_VEH3DOFCONTI: all 256 threads, thread = (trajectory m, part)
@@ -526,6 +558,10 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             if (m < nvalid) gptr(p.out.final_obs)[(size_t)(b0 + m) * O + c] = xs[m * ldx + c];
         }
     }
+    if (VEH2 && p.out.final_state != nullptr && tid < TB * 4) {
+        const int m = tid >> 2, c = tid & 3;
+        if (m < nvalid) gptr(p.out.final_state)[(size_t)(b0 + m) * 4 + c] = s_state[m * 8 + c];
+    }
     if (VEH && p.out.final_state != nullptr && tid < TB * 6) {
         const int m = tid / 6, c = tid - m * 6;
         if (m < nvalid) gptr(p.out.final_state)[(size_t)(b0 + m) * 6 + c] = s_state[m * 8 + c];
@@ -596,7 +632,7 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
 // `p` is the host copy (for shape dispatch), `dp` the device copy the kernel reads.
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, (p.env.kind == GOPS_ENV_VEH3DOFCONTI || p.env.kind == GOPS_ENV_VEH3DOF_SURR) ? p.env.pre_horizon + 1 + p.H : 0, p.f16 != 0);
+    const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0, p.f16 != 0);
     int sk[2];
     rollout_variant(p, sk, false);
     const int key = sk[0] * 100 + sk[1];
@@ -627,6 +663,7 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
         case GOPS_ENV_VEH3DOF_SURR: LAUNCH_FWD(GOPS_ENV_VEH3DOF_SURR, 0, 0); break;
         case GOPS_ENV_CARTPOLE: LAUNCH_FWD(GOPS_ENV_CARTPOLE, 0, 0); break;
         case GOPS_ENV_PENDULUM: LAUNCH_FWD(GOPS_ENV_PENDULUM, 0, 0); break;
+        case GOPS_ENV_VEH2DOF: LAUNCH_FWD(GOPS_ENV_VEH2DOF, 0, 0); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOPS_HIP_LIB") or os.path.join(_HERE, "libgops_hip.so")
 
 MAX_LAYERS, MAX_ACT, MAX_LQ, TILE = 5, 4, 6, 16
-ENV_NONE, ENV_LQ, ENV_IDP, ENV_VEH, ENV_VEH_SURR, ENV_CARTPOLE, ENV_PENDULUM = 0, 1, 2, 3, 4, 5, 6
+ENV_NONE, ENV_LQ, ENV_IDP, ENV_VEH, ENV_VEH_SURR, ENV_CARTPOLE, ENV_PENDULUM, ENV_VEH2DOF = 0, 1, 2, 3, 4, 5, 6, 7
 MAX_SURR = 4
 ACT_IDS = {"linear": 0, "relu": 1, "elu": 2, "gelu": 3, "selu": 4, "sigmoid": 5, "tanh": 6}
 DTYPE_IDS = {"fp32": 0, "f32": 0, "float32": 0, "fp16": 1, "f16": 1, "float16": 1, "half": 1}
@@ -318,7 +318,7 @@ class Rollout:
             i.head_pre = _ptr(head_pre)
             self._head_pre = head_pre
         i.obs, i.done = _ptr(data["obs"]), _ptr(data.get("done"))
-        if d.env.kind in (ENV_VEH, ENV_VEH_SURR):
+        if d.env.kind in (ENV_VEH, ENV_VEH_SURR, ENV_VEH2DOF):
             for k in ("state", "ref_points", "path_num", "u_num", "ref_time"):
                 setattr(i, k, _ptr(data[k]))
         if d.env.kind == ENV_VEH_SURR:
@@ -334,8 +334,8 @@ class Rollout:
             res["final_obs"] = torch.empty(B, O, dtype=torch.float32, device=self.device)
             res["final_done"] = torch.empty(B, dtype=torch.float32, device=self.device)
             out.final_obs, out.final_done = _ptr(res["final_obs"]), _ptr(res["final_done"])
-            if d.env.kind in (ENV_VEH, ENV_VEH_SURR):
-                res["final_state"] = torch.empty(B, 6, dtype=torch.float32, device=self.device)
+            if d.env.kind in (ENV_VEH, ENV_VEH_SURR, ENV_VEH2DOF):
+                res["final_state"] = torch.empty(B, 4 if d.env.kind == ENV_VEH2DOF else 6, dtype=torch.float32, device=self.device)
                 out.final_state = _ptr(res["final_state"])
         if d.env.kind == ENV_VEH_SURR:   # [4, B]: sum c+^2, sum c+, sum log(-c- + eps), feasible  (discounted, unmasked)
             res["constraint_sums"] = torch.empty(4, B, dtype=torch.float32, device=self.device)
@@ -429,7 +429,7 @@ def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Ten
     io.obs, io.action, io.done = _ptr(obs), _ptr(action), _ptr(done)
     io.next_obs, io.reward, io.next_done = _ptr(nobs), _ptr(rew), _ptr(ndone)
     ninfo = {}
-    if env.kind in (ENV_VEH, ENV_VEH_SURR):
+    if env.kind in (ENV_VEH, ENV_VEH_SURR, ENV_VEH2DOF):
         for k in ("state", "ref_points", "path_num", "u_num", "ref_time"):
             setattr(io, k, _ptr(info[k]))
         ninfo = dict(state=torch.empty_like(info["state"]), ref_points=torch.empty_like(info["ref_points"]),

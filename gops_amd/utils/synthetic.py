@@ -105,6 +105,8 @@ def obs_dim_of(cfg: Dict) -> int:
         return 6
     if cfg["env_id"] == "gym_cartpoleconti":
         return 4
+    if cfg["env_id"] == "pyth_veh2dofconti":
+        return 4 + cfg["pre_horizon"]
     if cfg["env_id"] == "gym_pendulum":
         return 3
     if cfg["env_id"] == "pyth_veh3dofconti":
@@ -122,7 +124,7 @@ def n_surr_of(cfg: Dict) -> int:
 
 
 def act_dim_of(cfg: Dict) -> int:
-    if cfg["env_id"] in ("pyth_idpendulum", "gym_cartpoleconti", "gym_pendulum"):
+    if cfg["env_id"] in ("pyth_idpendulum", "gym_cartpoleconti", "gym_pendulum", "pyth_veh2dofconti"):
         return 1
     if cfg["env_id"] == "pyth_veh3dofconti" or cfg["env_id"] in _SURR_ENVS:
         return 2
@@ -138,6 +140,21 @@ def make_batch(cfg: Dict, seed: int, batch: int = None) -> Dict[str, torch.Tenso
     if env_id == "pyth_idpendulum":
         h = np.array([5, 0.1, 0.1, 0.3, 0.3, 0.3], dtype=np.float32)
         out["obs"] = rng.uniform(-h, h, size=(B, 6)).astype(np.float32)
+    elif env_id == "pyth_veh2dofconti":
+        # data env reset (pyth_veh2dofconti.py:121-170): state = (y, phi) of the first reference point + U(+-[1, pi/6]), (v, omega) ~ U(+-0.2)
+        P = cfg["pre_horizon"]
+        t0 = 20.0 * rng.uniform(0.0, 1.0, size=B)
+        path_num = rng.randint(0, 4, size=B)
+        u_num = rng.randint(0, 2, size=B)
+        tt = t0[:, None] + 0.1 * np.arange(P + 1)[None, :]
+        ref4 = ref_points_f64(tt, path_num[:, None], u_num[:, None])
+        ref = ref4[:, :, 1:3].astype(np.float32)                         # (y, phi)
+        hi = np.array([1.0, np.pi / 6, 0.2, 0.2], dtype=np.float32)
+        delta = rng.uniform(-hi, hi, size=(B, 4)).astype(np.float32)
+        state = np.concatenate((ref[:, 0, :] + delta[:, :2], delta[:, 2:]), axis=1).astype(np.float32)
+        obs = np.concatenate((state[:, :2] - ref[:, 0], state[:, 2:], state[:, :1] - ref[:, 1:, 0]), axis=1).astype(np.float32)
+        out.update(obs=obs, state=state, ref_points=ref, path_num=path_num.astype(np.float32),
+                   u_num=u_num.astype(np.float32), ref_time=t0.astype(np.float32))
     elif env_id == "gym_cartpoleconti":   # wide enough that some trajectories leave |x| <= 2.4 / |theta| <= 12 deg within a rollout
         h = np.array([2.3, 1.0, 0.2, 1.0], dtype=np.float32)
         out["obs"] = rng.uniform(-h, h, size=(B, 4)).astype(np.float32)

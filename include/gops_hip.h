@@ -58,7 +58,11 @@ enum { GOPS_ENV_NONE = 0, GOPS_ENV_LQ = 1, GOPS_ENV_IDPENDULUM = 2, GOPS_ENV_VEH
        GOPS_ENV_VEH3DOF_SURR = 4,
        /* gym-style models of the INFADP / MAC example scripts (obs == state, no info):
           gops/env/env_gym/env_model/gym_cartpoleconti_model.py:24-129 and gym_pendulum_model.py:26-115 */
-       GOPS_ENV_CARTPOLE = 5, GOPS_ENV_PENDULUM = 6 };
+       GOPS_ENV_CARTPOLE = 5, GOPS_ENV_PENDULUM = 6,
+       /* pyth_veh2dofconti_model.py:24-174: lateral 2-DOF vehicle at constant speed tracking the reference path: state
+          (y, phi, v, omega) [B,4], action steer, obs = (y - y_ref0, phi - phi_ref0, v, omega, y - y_ref_1 .. y - y_ref_P),
+          info["ref_points"] [B, P+1, 2] = (y, phi) */
+       GOPS_ENV_VEH2DOF = 7 };
 #define GOPS_MAX_SURR 4        /* surrounding vehicles */
 #define GOPS_MAX_CONSTRAINT 3  /* constraint outputs per step */
 

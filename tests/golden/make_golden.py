@@ -128,6 +128,13 @@ OBS_SCALE_STEP_CASES = {   # ScaleObservationModel (example_train/fhadp/fhadp_ml
                                     dict(obs_scale=10, obs_shift=[0.1, -0.2, 0.05, 0.0, 0.3], reward_scale=0.5, reward_shift=1.0)),
     "step_idp_obsscale_shift": (dict(env_id="pyth_idpendulum"), dict(obs_scale=[1, 2, 2, 0.5, 0.5, 0.25], obs_shift=0.1)),
 }
+VEH2_STEP_CASES = {"step_veh2dof_p10": (dict(env_id="pyth_veh2dofconti", pre_horizon=10), {})}
+VEH2_SMALL = {   # example_train/fhadp/fhadp_mlp_veh2dofconti_serial.py, infadp/infadp_mlp_veh2dofconti_offserial.py
+    "fhadp_veh2dof_p10_elu": (dict(alg="FHADP", env_id="pyth_veh2dofconti", batch=48, horizon=10, pre_horizon=10,
+                                   hidden=(64, 64), act="elu", gamma=1.0), {}),
+    "infadp_veh2dof_p10_gelu": (dict(alg="INFADP", env_id="pyth_veh2dofconti", batch=40, horizon=8, pre_horizon=10,
+                                     hidden=(64, 64), act="gelu", gamma=0.99), {}),
+}
 GYM_STEP_CASES = {   # gym-style models of the INFADP / MAC example scripts (cartpoleconti uses obs_scale in its script)
     "step_cartpole": (dict(env_id="gym_cartpoleconti"), {}),
     "step_cartpole_obsscale": (dict(env_id="gym_cartpoleconti"), dict(obs_scale=[1.0, 0.5, 2.0, 0.25], reward_scale=0.5, reward_shift=0.1)),
@@ -301,6 +308,11 @@ def golden_small(cases=None):
             data["state"][:3, 1] += 9.3  # |delta_y| crosses 10 m within the horizon -> done
             from gops_amd.utils.synthetic import veh_obs_f32
             data["obs"] = torch.from_numpy(veh_obs_f32(data["state"].numpy(), data["ref_points"].numpy()))
+            data["obs2"] = data["obs"].clone()
+        if cfg["env_id"] == "pyth_veh2dofconti":
+            data["state"][:4, 0] += 1.6  # |delta_y| crosses 2 m within the horizon -> done
+            st, rp = data["state"], data["ref_points"]
+            data["obs"] = torch.cat((st[:, :2] - rp[:, 0], st[:, 2:], st[:, :1] - rp[:, 1:, 0]), dim=1)
             data["obs2"] = data["obs"].clone()
         data["done"][-3:] = 1.0  # already-done rows in the batch
         out = {"in/" + k: v.numpy().copy() for k, v in data.items()}
@@ -607,7 +619,10 @@ def golden_data_envs():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof"]
+    if "veh2dof" in which:
+        golden_steps(VEH2_STEP_CASES)
+        golden_small(VEH2_SMALL)
     if "gym" in which:
         golden_steps(GYM_STEP_CASES)
         np.random.seed(0)

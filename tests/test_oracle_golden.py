@@ -14,17 +14,20 @@ STEP_CASES = ["step_lq_s4a2", "step_lq_s6a3", "step_lq_s2a1_shaped", "step_idp",
               # ScaleObservationModel in the chain (obs_scale / obs_shift of the lqs3a1 / lqs5a1 example scripts)
               "step_lq_s3a1_obsscale", "step_lq_s5a1_obsscale_shift", "step_idp_obsscale_shift",
               # gym-style models (INFADP / MAC example scripts)
-              "step_cartpole", "step_cartpole_obsscale", "step_pendulum"]
+              "step_cartpole", "step_cartpole_obsscale", "step_pendulum",
+              "step_veh2dof_p10"]
 FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fhadp_idp_selu_shaped",
                "fhadp_veh_p10_elu", "fhadp_veh_p30_sigmoid",
                # plain FHADP on the collision-penalty model (pyth_veh3dofconti_surrcstr_penalty)
                "fhadp_surrpen_p10_elu", "fhadp_surrpen_p25_gelu",
                # ScaleObservationModel in the chain
                "fhadp_lq_s3a1_obsscale", "fhadp_idp_obsscale_shift",
+               "fhadp_veh2dof_p10_elu",   # pyth_veh2dofconti
                # the reference's shipped trained checkpoints (saturating policies, H = 80, limits != +-1)
                "fhadp_trained_idp_h80", "fhadp_trained_lqs3a1_h80"]
 INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift",
-                "mac_lq_s4a2_gelu", "mac_idp_elu", "infadp_cartpole_gelu", "mac_pendulum_elu", "infadp_pendulum_tanh",   # gops/algorithm/mac.py: INFADP's losses (its Bayes model-bias term is inert)
+                "mac_lq_s4a2_gelu", "mac_idp_elu", "infadp_cartpole_gelu", "mac_pendulum_elu", "infadp_pendulum_tanh",
+                "infadp_veh2dof_p10_gelu",   # gops/algorithm/mac.py: INFADP's losses (its Bayes model-bias term is inert)
                 "infadp_trained_lqs4a2", "infadp_trained_idp"]
 
 

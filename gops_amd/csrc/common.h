@@ -321,9 +321,18 @@ struct StreamB {
                     f32x4 bcur[NT];
 #pragma unroll
                     for (int j = 0; j < NT; ++j) bcur[j] = ring[d][j];
+#ifdef GOPS_STREAMB_EXACT_REFILL
+                    // refill only while there is a chunk to fetch: a clamped (redundant) load stays pending on its
+                    // registers and makes the next GEMM that re-uses them drain vmcnt(0) in front of its first MFMA
+                    if (c + PF < kchunks) {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) ring[d][j] = wbase[((size_t)j * kchunks + c + PF) * 64];
+                    }
+#else
                     const int cn = (c + PF < kchunks) ? c + PF : kchunks - 1;
 #pragma unroll
                     for (int j = 0; j < NT; ++j) ring[d][j] = wbase[((size_t)j * kchunks + cn) * 64];
+#endif
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -397,6 +406,8 @@ struct StatW {
     }
 };
 struct NoW {};   // placeholder for a streamed layer
+// every load issued so far complete (a real S_WAITCNT vmcnt(0) that the waitcnt pass accounts for)
+__device__ __forceinline__ void settle_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 // K-chunks 0..KCH-1 come from the stationary fragments, chunks KCH..kch_total-1 (if any) are
 // streamed from the packed weights like mfma_gemm does.

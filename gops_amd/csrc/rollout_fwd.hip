@@ -8,6 +8,7 @@
 
 #include <type_traits>
 
+#define GOPS_STREAMB_EXACT_REFILL   // (this translation unit only: the backward kernels' register allocation degrades with it)
 #include "common.h"
 #include "env_models.h"
 #include "rollout_f16.h"
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
     __syncthreads();
     if (VEH) sincosf(s_state[(tid & 15) * 8 + 2], &veh_s, &veh_c);
+    settle_loads();
     for (int t = 0; t < p.H; ++t) {
         if (p.fh && tid < TB) xs[tid * ldx + O] = (float)(t + 1);
         __syncthreads();

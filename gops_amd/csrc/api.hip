@@ -322,9 +322,9 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
         unsigned long long h[16];
         (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
         fprintf(stderr, "[gops dbg] fwd cycles/step: top+sync %llu | xstash %llu | hidden-rest %llu | head %llu | envstash %llu | env %llu"
-                " || L0 epi %llu sync %llu stash %llu | L1 epi %llu sync %llu stash %llu | gemm(L0+L1) %llu\n",
+                " || L0 epi %llu sync %llu stash %llu | L1 epi %llu sync %llu stash %llu | gemm(L0+L1) %llu || head: dot %llu tanh+wrap %llu barrier %llu\n",
                 h[0] / p.H, h[1] / p.H, h[2] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H, h[8] / p.H, h[9] / p.H,
-                h[10] / p.H, h[11] / p.H, h[12] / p.H, h[13] / p.H, h[14] / p.H);
+                h[10] / p.H, h[11] / p.H, h[12] / p.H, h[13] / p.H, h[14] / p.H, h[6] / p.H, h[7] / p.H, h[3] / p.H);
     }
     return ret;
 }

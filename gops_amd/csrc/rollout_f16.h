@@ -148,26 +148,45 @@ __device__ __forceinline__ const _Float16* mlp_hidden_forward_h(const MlpDev& M,
 
 // Output layer (width A <= 4) on the VALU in fp32 from the half activations: thread (hm = tid >> 4,
 // hp = tid & 15) strides over k; y[a] is valid in every lane of the 16-lane group.  Wo: [A][ldw] fp32.
-template <class WP, class BP>
+// ZEROED: Wo / bo are the LDS copies whose rows a >= A are zero-filled - all four outputs are formed unconditionally so that
+// the reads of a thread are issued back to back (see mlp_head in rollout_fwd.hip).
+template <bool ZEROED, class WP, class BP>
 __device__ __forceinline__ void mlp_head_h(WP Wo, int ldw, BP bo, int K, int A, const _Float16* hcur, int ld16,
                                            int tid, float (&y)[GOPS_MAX_ACT]) {
     const int hm = tid >> 4, hp = tid & 15;
 #pragma unroll
     for (int a = 0; a < GOPS_MAX_ACT; ++a) y[a] = 0.f;
+#pragma unroll 2
     for (int k = 8 * hp; k < K; k += 128) {
         const f16x8 hv = ld8h(hcur + hm * ld16 + k);
+        if constexpr (ZEROED) {
+            f32x4 w0[GOPS_MAX_ACT], w1[GOPS_MAX_ACT];
 #pragma unroll
-        for (int a = 0; a < GOPS_MAX_ACT; ++a)
-            if (a < A) {
-                const f32x4 w0 = ld4(Wo + a * ldw + k), w1 = ld4(Wo + a * ldw + k + 4);
-                y[a] += ((float)hv[0] * w0[0] + (float)hv[1] * w0[1] + (float)hv[2] * w0[2] + (float)hv[3] * w0[3]) +
-                        ((float)hv[4] * w1[0] + (float)hv[5] * w1[1] + (float)hv[6] * w1[2] + (float)hv[7] * w1[3]);
-            }
+            for (int a = 0; a < GOPS_MAX_ACT; ++a) { w0[a] = ld4(Wo + a * ldw + k); w1[a] = ld4(Wo + a * ldw + k + 4); }
+#pragma unroll
+            for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                y[a] += ((float)hv[0] * w0[a][0] + (float)hv[1] * w0[a][1] + (float)hv[2] * w0[a][2] + (float)hv[3] * w0[a][3]) +
+                        ((float)hv[4] * w1[a][0] + (float)hv[5] * w1[a][1] + (float)hv[6] * w1[a][2] + (float)hv[7] * w1[a][3]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                if (a < A) {
+                    const f32x4 w0 = ld4(Wo + a * ldw + k), w1 = ld4(Wo + a * ldw + k + 4);
+                    y[a] += ((float)hv[0] * w0[0] + (float)hv[1] * w0[1] + (float)hv[2] * w0[2] + (float)hv[3] * w0[3]) +
+                            ((float)hv[4] * w1[0] + (float)hv[5] * w1[1] + (float)hv[6] * w1[2] + (float)hv[7] * w1[3]);
+                }
+        }
     }
+    if constexpr (ZEROED) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(&bo[0]);
 #pragma unroll
-    for (int a = 0; a < GOPS_MAX_ACT; ++a) {
-        y[a] = row16_sum(y[a]);
-        if (a < A) y[a] += bo[a];
+        for (int a = 0; a < GOPS_MAX_ACT; ++a) y[a] = row16_sum(y[a]) + bv[a];
+    } else {
+#pragma unroll
+        for (int a = 0; a < GOPS_MAX_ACT; ++a) {
+            y[a] = row16_sum(y[a]);
+            if (a < A) y[a] += bo[a];
+        }
     }
 }
 

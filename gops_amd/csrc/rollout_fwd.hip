@@ -82,9 +82,12 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
 }
 
 // Output layer (width A <= 4) on the VALU: thread (hm = tid>>4, hp = tid&15) strides over k.
-// Wo is [A][ldw] (an LDS copy made once per launch, or the global weight with ldw = K); the
-// result y[a] is valid in the lanes with hp == 0.
-template <class WP, class BP>
+// Wo is [4][ldw] in LDS with the rows a >= A ZERO-FILLED (staged once per launch) and bo likewise: all four
+// outputs are formed unconditionally, so the 5 x (K / 64) vector reads of a thread are issued back to back.  (With an
+// `if (a < A)` around each product hipcc built one basic block per product - every LDS read followed by its own wait,
+// 2.3 k cycles per step for K = 256.)  The result y[a] is valid in every lane of the trajectory's 16-lane group.
+// ZEROED = false: Wo / bo are the caller's global tensors with exactly A rows (tail value net: A = 1).
+template <bool ZEROED, class WP, class BP>
 __device__ __forceinline__ void mlp_head(WP Wo, int ldw, BP bo, int K, int A, const float* hcur, int ldh,
                                          int tid, float (&y)[GOPS_MAX_ACT]) {
     const int hm = tid >> 4, hp = tid & 15;
@@ -94,12 +97,21 @@ __device__ __forceinline__ void mlp_head(WP Wo, int ldw, BP bo, int K, int A, co
 #pragma unroll 4
         for (int k = 4 * hp; k < K; k += 64) {
             const f32x4 hv = *reinterpret_cast<const f32x4*>(hcur + hm * ldh + k);
+            if constexpr (ZEROED) {
+                f32x4 wv[GOPS_MAX_ACT];
 #pragma unroll
-            for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                if (a < A) {
-                    const f32x4 wv = ld4(Wo + a * ldw + k);
-                    y[a] += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
-                }
+                for (int a = 0; a < GOPS_MAX_ACT; ++a) wv[a] = ld4(Wo + a * ldw + k);
+#pragma unroll
+                for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                    y[a] += hv[0] * wv[a][0] + hv[1] * wv[a][1] + hv[2] * wv[a][2] + hv[3] * wv[a][3];
+            } else {
+#pragma unroll
+                for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                    if (a < A) {
+                        const f32x4 wv = ld4(Wo + a * ldw + k);
+                        y[a] += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+                    }
+            }
         }
     } else {
         for (int k = hp; k < K; k += 16) {
@@ -109,10 +121,16 @@ __device__ __forceinline__ void mlp_head(WP Wo, int ldw, BP bo, int K, int A, co
                 if (a < A) y[a] += hv * Wo[a * ldw + k];
         }
     }
+    if constexpr (ZEROED) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(&bo[0]);
 #pragma unroll
-    for (int a = 0; a < GOPS_MAX_ACT; ++a) {
-        y[a] = row16_sum(y[a]);
-        if (a < A) y[a] += bo[a];
+        for (int a = 0; a < GOPS_MAX_ACT; ++a) y[a] = row16_sum(y[a]) + bv[a];
+    } else {
+#pragma unroll
+        for (int a = 0; a < GOPS_MAX_ACT; ++a) {
+            y[a] = row16_sum(y[a]);
+            if (a < A) y[a] += bo[a];
+        }
     }
 }
 
@@ -155,11 +173,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     const int ldx16 = (((p.ldx - 4) + 31) & ~31) + 8, ld16 = (p.ldh - 4) + 8;
     {   // one-time staging of everything the H-step loop would otherwise re-fetch from L2
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
-        for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
-            const int a = idx / K, k = idx - a * K;
-            s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
+        for (int idx = tid; idx < GOPS_MAX_ACT * ldh; idx += NTHREADS) {   // rows a >= Ao (and the pad columns) are zero: mlp_head<true>
+            const int a = idx / ldh, k = idx - a * ldh;
+            s_wo[idx] = (a < Ao && k < K) ? gptr(p.pol.w[Lh])[a * K + k] : 0.f;
         }
-        if (tid < Ao) s_bo[tid] = gptr(p.pol.b[Lh])[tid];
+        if (tid < GOPS_MAX_ACT) s_bo[tid] = (tid < Ao) ? gptr(p.pol.b[Lh])[tid] : 0.f;
         stage_act_const(p.env, s_ac, tid);
         for (int j = 0; j < Lh; ++j)
             for (int n = tid; n < p.pol.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = gptr(p.pol.b[j])[n];
@@ -232,13 +250,14 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                                                                 p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
                                                                 row0, TB);
                     DBG_TICK(2)
-                    mlp_head_h(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ld16, tid, y);
+                    mlp_head_h<true>(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ld16, tid, y);
                 } else {
                     float* hcur = mlp_hidden_forward(p.pol, W0, W1, xs, ldx, ha, hb, ldh, tid, s_bias,
                                                      p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
                                                      row0, dbg);
                     DBG_TICK(2)
-                    mlp_head(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ldh, tid, y);
+                    mlp_head<true>(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ldh, tid, y);
+                    DBG_TICK(6)
                 }
             }
             {   // lane a of each 16-lane trajectory group squashes and wraps action a (row16_sum left y in every lane)
@@ -261,6 +280,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 }
             }
         }
+        DBG_TICK(7)
         __syncthreads();
         DBG_TICK(3)
         if (p.need_grad && tid < TB) {   // env stash row: tanh outputs, done_t, state_t
@@ -526,12 +546,12 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                                                         reinterpret_cast<_Float16*>(hb), ld16, tid, s_bias, ldh,
                                                         p.need_grad ? p.st.tail_h : nullptr,
                                                         p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, nvalid);
-            mlp_head_h(gptr(p.val.w[Lv]), p.val.dims[Lv], gptr(p.val.b[Lv]), p.val.dims[Lv], 1, hcur, ld16, tid, y);
+            mlp_head_h<false>(gptr(p.val.w[Lv]), p.val.dims[Lv], gptr(p.val.b[Lv]), p.val.dims[Lv], 1, hcur, ld16, tid, y);
         } else {
             float* hcur = mlp_hidden_forward(p.val, NoW{}, NoW{}, xs, ldx, ha, hb, ldh, tid, s_bias,
                                              p.need_grad ? p.st.tail_h : nullptr,
                                              p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, dbg);
-            mlp_head(gptr(p.val.w[Lv]), p.val.dims[Lv], gptr(p.val.b[Lv]), p.val.dims[Lv], 1, hcur, ldh, tid, y);
+            mlp_head<false>(gptr(p.val.w[Lv]), p.val.dims[Lv], gptr(p.val.b[Lv]), p.val.dims[Lv], 1, hcur, ldh, tid, y);
         }
         if ((tid & 15) == 0) s_th[(tid >> 4) * 4] = y[0];
         __syncthreads();

@@ -11,6 +11,7 @@ from typing import Tuple
 
 import torch
 
+from gops_amd import hip_backend as hb
 from gops_amd.algorithm.base import grad_buffers
 from gops_amd.algorithm.fhadp import ApproxContainer, FHADP   # noqa: F401  (ApproxContainer: create_alg looks it up here)
 from gops_amd.utils.tensorboard_setup import tb_tags
@@ -30,11 +31,11 @@ class ConstrainedFHADP(FHADP):
         """Host-side schedule step (penalty / multiplier), once per computed gradient like the reference."""
 
     def _gradient_kernels(self, batch):
-        if "surr_state" not in batch:
-            raise RuntimeError(f"{type(self).__name__} needs a model with constraint outputs "
-                               "(pyth_veh3dofconti_surrcstr / _detour): batch has no 'surr_state'")
         B, device = batch["obs"].shape[0], batch["obs"].device
         ro = self._rollout_for(B, device)
+        if ro.desc.env.kind != hb.ENV_VEH_SURR or (ro.desc.env.n_surr > 0 and "surr_state" not in batch):
+            raise RuntimeError(f"{type(self).__name__} needs a model with constraint outputs "
+                               "(pyth_veh3dofconti_surrcstr / _detour / _errcstr) and its info in the batch")
         res = ro.forward(batch)
         gc, scalars = self._constraint_terms(res["v_pi"], res["constraint_sums"], B)
         gw, gb = grad_buffers(self.networks.policy)

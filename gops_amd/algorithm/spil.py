@@ -85,7 +85,7 @@ class SPIL(AlgorithmBase):
         if ro is None:
             env = self.envmodel.hip_env(nets.policy.act_low_lim.cpu().numpy(), nets.policy.act_high_lim.cpu().numpy())
             if env.kind != hb.ENV_VEH_SURR:
-                raise RuntimeError("SPIL needs a model with constraint outputs (pyth_veh3dofconti_surrcstr / _detour)")
+                raise RuntimeError("SPIL needs a model with constraint outputs (pyth_veh3dofconti_surrcstr / _detour / _errcstr)")
             if env.n_constraint != self.n_constraint:
                 raise RuntimeError(f"constraint_dim = {self.n_constraint}, but the model has {env.n_constraint} constraints")
             ro = hb.Rollout(env, pol, batch=batch, horizon=self.forward_step, gamma=self.gamma, finite_horizon=False,
@@ -110,8 +110,6 @@ class SPIL(AlgorithmBase):
         if self.reward_scale != 1.0:
             raise RuntimeError("SPIL.reward_scale != 1 is not supported by the HIP rollout (the terminal value is unscaled)")
         batch = batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
-        if "surr_state" not in batch:
-            raise RuntimeError("SPIL needs a model with constraint outputs: batch has no 'surr_state'")
         B, device, nc = batch["obs"].shape[0], batch["obs"].device, self.n_constraint
         # ---- policy evaluation -----------------------------------------------------------------
         res = self._rollout_for(B, device, need_grad=False).forward(batch)

@@ -187,8 +187,9 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         (e.act_dim != 2 || e.pre_horizon < 1 || e.obs_dim != 6 + 4 * e.pre_horizon || e.clip_obs))
         return GOPS_ERR_BAD_ARG;
     if (e.kind == GOPS_ENV_VEH3DOF_SURR &&
-        (e.act_dim != 2 || e.pre_horizon < 1 || e.n_surr < 1 || e.n_surr > GOPS_MAX_SURR ||
-         (e.n_constraint != 1 && e.n_constraint != 3) || e.obs_dim != 6 + 4 * e.pre_horizon + 4 * e.n_surr || e.clip_obs ||
+        (e.act_dim != 2 || e.pre_horizon < 1 || e.n_surr < (e.cstr_err ? 0 : 1) || e.n_surr > (e.cstr_err ? 0 : GOPS_MAX_SURR) ||
+         (e.cstr_err ? e.n_constraint != 2 : (e.n_constraint != 1 && e.n_constraint != 3)) ||
+         e.obs_dim != 6 + 4 * e.pre_horizon + 4 * e.n_surr || e.clip_obs ||
          (e.surr_penalty && (e.n_surr != 1 || e.n_constraint != 1)) ||
          desc.open_loop || desc.dtype != GOPS_DTYPE_F32))
         return GOPS_ERR_BAD_ARG;
@@ -297,7 +298,7 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
     if (in.obs == nullptr || out.v_pi == nullptr) return GOPS_ERR_BAD_ARG;
     if (env_has_ref_table(desc.env.kind) &&
         (!in.state || !in.ref_points || !in.path_num || !in.u_num || !in.ref_time)) return GOPS_ERR_BAD_ARG;
-    if (desc.env.kind == GOPS_ENV_VEH3DOF_SURR && !in.surr_state) return GOPS_ERR_BAD_ARG;
+    if (desc.env.kind == GOPS_ENV_VEH3DOF_SURR && desc.env.n_surr > 0 && !in.surr_state) return GOPS_ERR_BAD_ARG;
     RolloutParams& p = plan.p;
     p.in = in;
     p.out = out;
@@ -564,8 +565,9 @@ int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void*
     if (env->kind >= GOPS_ENV_CARTPOLE && env->data_env) return GOPS_ERR_UNSUPPORTED;   // these data envs are not restated
     if (!io->obs || !io->action || !io->next_obs || !io->reward || !io->next_done) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_VEH3DOF_SURR &&
-        (env->data_env || env->n_surr < 1 || env->n_surr > GOPS_MAX_SURR || (env->n_constraint != 1 && env->n_constraint != 3) ||
-         !io->surr_state || !io->next_surr_state || !io->constraint)) return GOPS_ERR_BAD_ARG;
+        (env->data_env || env->n_surr < (env->cstr_err ? 0 : 1) || env->n_surr > (env->cstr_err ? 0 : GOPS_MAX_SURR) ||
+         (env->cstr_err ? env->n_constraint != 2 : (env->n_constraint != 1 && env->n_constraint != 3)) ||
+         (env->n_surr > 0 && (!io->surr_state || !io->next_surr_state)) || !io->constraint)) return GOPS_ERR_BAD_ARG;
     if (env_has_ref_table(env->kind) &&
         (!io->state || !io->ref_points || !io->path_num || !io->u_num || !io->ref_time ||
          !io->next_state || !io->next_ref_points || !io->next_ref_time)) return GOPS_ERR_BAD_ARG;

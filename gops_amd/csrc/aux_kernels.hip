@@ -1171,6 +1171,7 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
             sincosf(sn[2], &sp, &cp);
             surr_constraint<false>(env, sn[0], sn[1], sp, cp, pts, sc);
             if (env.surr_penalty) sc.c[0] = pen_c;   // info["constraint"] is filled before the info dict is updated (:131-139)
+            if (env.cstr_err) { sc.c[0] = fabsf(o6[1]) - env.err_tol[0]; sc.c[1] = fabsf(o6[3]) - env.err_tol[1]; }   // current obs
             for (int k = 0; k < env.n_constraint; ++k) io.constraint[(size_t)b * env.n_constraint + k] = sc.c[k];
             if (env.surr_penalty) done_m = false;
         }

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                         surr_constraint<true>(p.env, sn[0], sn[1], e3[2], e3[3], pts, sc);
 #pragma unroll
                         for (int k = 0; k < GOPS_MAX_CONSTRAINT; ++k) {
-                            if (k < (p.env.surr_penalty ? 0 : p.env.n_constraint)) {
+                            if (k < ((p.env.surr_penalty || p.env.cstr_err) ? 0 : p.env.n_constraint)) {
                                 const float c = sc.c[k];
                                 float gck = gc_ext * 2.f * fmaxf(c, 0.f) + (c > 0.f ? gc_lin : 0.f);
                                 if (c < 0.f) gck += gc_int * (-1.f / (-c + 1e-8f));
@@ -670,6 +670,19 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                         G[m * ldx + 3] += g_rm * (-2.f * rw[3] * xr[3]);
                         G[m * ldx + 5] += g_rm * (-2.f * rw[4] * xr[5]);
                         G[m * ldx + 4] += g_rm * (-2.f * rw[7] * xr[4]);
+                        if (p.env.cstr_err) {   // errcstr: c_k = |obs[1 / 3]| - tol of THIS observation (unmasked sums / products)
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const float e = xr[1 + 2 * k], c = fabsf(e) - p.env.err_tol[k];
+                                float gck = gc_ext * 2.f * fmaxf(c, 0.f) + (c > 0.f ? gc_lin : 0.f);
+                                if (c < 0.f) gck += gc_int * (-1.f / (-c + 1e-8f));
+                                gck *= p.gpow[t];
+                                float dlog;
+                                (void)spil_phi(c, dlog);
+                                gck += gc_mul[k] * dlog;
+                                G[m * ldx + 1 + 2 * k] += gck * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+                            }
+                        }
                     } else {
                         G[m * ldx + 0] += g_rm * (-0.08f * xr[0]);
                         G[m * ldx + 1] += g_rm * (-0.08f * xr[1]);

@@ -414,12 +414,17 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             w.sphi = veh_s; w.cphi = veh_c;
             veh_f_xu(VC, s, steer, ax, sn, w);
             float pen_c = 0.f;   // surrcstr_penalty: constraint of the CURRENT pose
+            float err_c0 = 0.f, err_c1 = 0.f;   // errcstr: |delta_y| - tol, |delta_u| - tol of the current observation
             if (part == 0) {
                 float o[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) o[i] = xs[m * ldx + i];
                 r = SURR ? veh_reward_w(p.env.reward_w, o, steer, ax) : veh_reward(o, steer, ax);
                 if constexpr (SURR) {
+                    if (p.env.cstr_err) {   // errcstr model: constraints on the tracking errors of the CURRENT observation
+                        err_c0 = fabsf(o[1]) - p.env.err_tol[0];
+                        err_c1 = fabsf(o[3]) - p.env.err_tol[1];
+                    }
                     if (p.env.surr_penalty && m < nvalid) {   // collision penalty on the CURRENT pose and surrounding vehicle
                         const f32x4 cur = gptr(p.surr_table)[((size_t)(b0 + m) * (p.H + 1) + t) * p.env.n_surr];
                         SurrCstr sc;
@@ -499,6 +504,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                     surr_constraint<false>(p.env, sn[0], sn[1], veh_s, veh_c, pts, sc);
                     // the penalty model fills info["constraint"] before its info dict is updated (:131-139): CURRENT pose
                     if (p.env.surr_penalty) sc.c[0] = pen_c;
+                    if (p.env.cstr_err) { sc.c[0] = err_c0; sc.c[1] = err_c1; }
                     float e2 = 0.f, e1 = 0.f, lg = 0.f;
 #pragma unroll
                     for (int k = 0; k < GOPS_MAX_CONSTRAINT; ++k) {

@@ -57,7 +57,8 @@ class GopsEnv(C.Structure):
                 ("no_mask_at_done", C.c_int32), ("n_surr", C.c_int32), ("n_constraint", C.c_int32), ("surr_penalty", C.c_int32),
                 ("veh_length", C.c_float), ("veh_width", C.c_float),
                 ("road_upper", C.c_float), ("road_lower", C.c_float), ("reward_w", C.c_float * 8),
-                ("data_env", C.c_int32), ("scale_obs", C.c_int32), ("obs_scale", C.c_float * 8), ("obs_shift", C.c_float * 8)]
+                ("data_env", C.c_int32), ("scale_obs", C.c_int32), ("obs_scale", C.c_float * 8), ("obs_shift", C.c_float * 8),
+                ("cstr_err", C.c_int32), ("err_tol", C.c_float * 2)]
 
 
 class GopsRolloutDesc(C.Structure):
@@ -227,6 +228,9 @@ def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_ac
         e.veh_length, e.veh_width = float(surr["veh_length"]), float(surr["veh_width"])
         e.road_upper, e.road_lower = float(surr.get("road_upper", 0.0)), float(surr.get("road_lower", 0.0))
         e.surr_penalty = int(bool(surr.get("penalty", False)))
+        if surr.get("err_tol") is not None:   # pyth_veh3dofconti_errcstr: constraints on the tracking errors of the observation
+            e.cstr_err = 1
+            _fill(e.err_tol, [float(v) for v in surr["err_tol"]])
         _fill(e.reward_w, list(surr["reward_w"]) + [0.0] * (8 - len(surr["reward_w"])))
     e.kind, e.obs_dim, e.act_dim, e.pre_horizon = kind, obs_dim, act_dim, pre_horizon
     A = act_dim
@@ -322,7 +326,7 @@ class Rollout:
             for k in ("state", "ref_points", "path_num", "u_num", "ref_time"):
                 setattr(i, k, _ptr(data[k]))
         if d.env.kind == ENV_VEH_SURR:
-            i.surr_state = _ptr(data["surr_state"])
+            i.surr_state = _ptr(data.get("surr_state"))   # (None for the errcstr model: no surrounding vehicles)
         self._keep = dict(data)   # the kernels (and a later backward) read these tensors: keep them alive
         out = GopsRolloutOut()
         res = {"v_pi": torch.empty(B, dtype=torch.float32, device=self.device)}
@@ -436,7 +440,10 @@ def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Ten
                      ref_time=torch.empty_like(info["ref_time"]), path_num=info["path_num"], u_num=info["u_num"])
         io.next_state, io.next_ref_points = _ptr(ninfo["state"]), _ptr(ninfo["ref_points"])
         io.next_ref_time = _ptr(ninfo["ref_time"])
-    if env.kind == ENV_VEH_SURR:
+    if env.kind == ENV_VEH_SURR and env.n_surr == 0:
+        ninfo["constraint"] = torch.empty(B, env.n_constraint, dtype=torch.float32, device=obs.device)
+        io.constraint = _ptr(ninfo["constraint"])
+    elif env.kind == ENV_VEH_SURR:
         ninfo["surr_state"] = torch.empty_like(info["surr_state"])
         ninfo["constraint"] = torch.empty(B, env.n_constraint, dtype=torch.float32, device=obs.device)
         io.surr_state, io.next_surr_state = _ptr(info["surr_state"]), _ptr(ninfo["surr_state"])

@@ -109,7 +109,7 @@ def obs_dim_of(cfg: Dict) -> int:
         return 4 + cfg["pre_horizon"]
     if cfg["env_id"] == "gym_pendulum":
         return 3
-    if cfg["env_id"] == "pyth_veh3dofconti":
+    if cfg["env_id"] in ("pyth_veh3dofconti", "pyth_veh3dofconti_errcstr"):
         return 6 + 4 * cfg["pre_horizon"]
     if cfg["env_id"] in _SURR_ENVS:
         return 6 + 4 * cfg["pre_horizon"] + 4 * n_surr_of(cfg)
@@ -126,7 +126,7 @@ def n_surr_of(cfg: Dict) -> int:
 def act_dim_of(cfg: Dict) -> int:
     if cfg["env_id"] in ("pyth_idpendulum", "gym_cartpoleconti", "gym_pendulum", "pyth_veh2dofconti"):
         return 1
-    if cfg["env_id"] == "pyth_veh3dofconti" or cfg["env_id"] in _SURR_ENVS:
+    if cfg["env_id"] in ("pyth_veh3dofconti", "pyth_veh3dofconti_errcstr") or cfg["env_id"] in _SURR_ENVS:
         return 2
     return _LQ_ACT_DIM[cfg.get("lq_config", "s4a2")]
 
@@ -164,7 +164,7 @@ def make_batch(cfg: Dict, seed: int, batch: int = None) -> Dict[str, torch.Tenso
     elif env_id == "pyth_lq":
         mean, std = (np.array(v, dtype=np.float32) for v in _LQ_INIT[cfg.get("lq_config", "s4a2")])
         out["obs"] = rng.uniform(mean - 3 * std, mean + 3 * std, size=(B, len(mean))).astype(np.float32)
-    elif env_id == "pyth_veh3dofconti" or env_id in _SURR_ENVS:
+    elif env_id in ("pyth_veh3dofconti", "pyth_veh3dofconti_errcstr") or env_id in _SURR_ENVS:
         P = cfg["pre_horizon"]
         t0 = 20.0 * rng.uniform(0.0, 1.0, size=B)
         path_num = rng.randint(0, 4, size=B)

@@ -150,6 +150,11 @@ typedef struct GopsEnv {
      * reference, ClipObservationModel then clips the SCALED observation with the model's own (unscaled) bounds. */
     int32_t scale_obs;
     float obs_scale[8], obs_shift[8];
+    /* GOPS_ENV_VEH3DOF_SURR with cstr_err = 1: pyth_veh3dofconti_errcstr_model.py:22-55 - no surrounding vehicles
+     * (n_surr = 0), n_constraint = 2: info["constraint"] = (|obs[1]| - err_tol[0], |obs[3]| - err_tol[1]) of the CURRENT
+     * observation (lateral and speed tracking errors). */
+    int32_t cstr_err;
+    float err_tol[2];
 } GopsEnv;
 
 typedef struct GopsRolloutDesc {

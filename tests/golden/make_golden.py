@@ -150,7 +150,16 @@ GYM_SMALL = {
 }
 
 
+ERR_STEP_CASES = {"step_veh_errcstr_p10": dict(env_id="pyth_veh3dofconti_errcstr", pre_horizon=10)}
+ERR_ALG_CASES = {
+    "fhadp_ext_errcstr": (dict(alg="FHADPExterior", env_id="pyth_veh3dofconti_errcstr", batch=48, horizon=10, pre_horizon=10,
+                               hidden=(64, 64), act="elu", gamma=0.99), dict(penalty=2.0)),
+    "fhadp_lag_errcstr": (dict(alg="FHADPLagrangian", env_id="pyth_veh3dofconti_errcstr", batch=40, horizon=8, pre_horizon=8,
+                               hidden=(64, 64), act="tanh", gamma=1.0), dict(multiplier=0.6)),
+}
 SPIL_CASES = {   # gops/algorithm/spil.py on the constrained veh3dofconti models (one full update: PEV + PIM gradients)
+    "spil_errcstr_p10": (dict(alg="SPIL", env_id="pyth_veh3dofconti_errcstr", batch=48, horizon=10, pre_horizon=10,
+                              hidden=(64, 64), act="relu", gamma=0.99), dict(constraint_dim=2)),
     "spil_surrcstr_p10": (dict(alg="SPIL", env_id="pyth_veh3dofconti_surrcstr", batch=48, horizon=10, pre_horizon=10,
                                hidden=(64, 64), act="elu", gamma=0.99), dict(constraint_dim=1)),
     "spil_detour_p8": (dict(alg="SPIL", env_id="pyth_veh3dofconti_detour", batch=40, horizon=8, pre_horizon=8,
@@ -512,7 +521,8 @@ def golden_constrained(step_cases=None, alg_cases=None):
         g = torch.Generator().manual_seed(23)
         done = (torch.rand(B, generator=g) < 0.25).float()
         info = {k: v.clone() for k, v in data.items()}
-        out = {"in/" + k: data[k].numpy().copy() for k in ("obs", "state", "ref_points", "path_num", "u_num", "ref_time", "surr_state")}
+        out = {"in/" + k: data[k].numpy().copy() for k in ("obs", "state", "ref_points", "path_num", "u_num", "ref_time", "surr_state")
+               if k in data}
         out["in/done"] = done.numpy().copy()
         o, d = data["obs"].clone(), done
         for s in range(nsteps):
@@ -522,7 +532,8 @@ def golden_constrained(step_cases=None, alg_cases=None):
             out[f"s{s}/obs"], out[f"s{s}/rew"], out[f"s{s}/done"] = o.numpy().copy(), r.numpy().copy(), d.numpy().copy()
             out[f"s{s}/state"] = info["state"].numpy().copy()
             out[f"s{s}/ref_last"] = info["ref_points"][:, -1].numpy().copy()
-            out[f"s{s}/surr_state"] = info["surr_state"].numpy().copy()
+            if "surr_state" in info:
+                out[f"s{s}/surr_state"] = info["surr_state"].numpy().copy()
             out[f"s{s}/constraint"] = info["constraint"].numpy().copy()
         out["meta/nsteps"] = nsteps
         out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra={}))
@@ -619,7 +630,7 @@ def golden_data_envs():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof", "errcstr"]
     if "veh2dof" in which:
         golden_steps(VEH2_STEP_CASES)
         golden_small(VEH2_SMALL)
@@ -627,6 +638,8 @@ if __name__ == "__main__":
         golden_steps(GYM_STEP_CASES)
         np.random.seed(0)
         golden_small(GYM_SMALL)
+    if "errcstr" in which:
+        golden_constrained(ERR_STEP_CASES, ERR_ALG_CASES)
     if "spil" in which:
         golden_spil()
     if "mac" in which:

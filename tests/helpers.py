@@ -74,12 +74,13 @@ def reference_init_nets(cfg, seed, obs_dim, act_dim):
 # ---- HIP side: build C-ABI descriptors from the same (oracle-side) constants -------------------
 def hip_env_from_oracle(env, policy_net=None):
     from gops_amd import hip_backend as hb
-    kind = {"lq": hb.ENV_LQ, "idp": hb.ENV_IDP, "veh": hb.ENV_VEH, "veh_surr": hb.ENV_VEH_SURR,
+    kind = {"veh_err": hb.ENV_VEH_SURR, "lq": hb.ENV_LQ, "idp": hb.ENV_IDP, "veh": hb.ENV_VEH, "veh_surr": hb.ENV_VEH_SURR,
             "cartpole": hb.ENV_CARTPOLE, "pendulum": hb.ENV_PENDULUM, "veh2": hb.ENV_VEH2DOF}[env["kind"]]
     surr = None
-    if env["kind"] == "veh_surr":
+    if env["kind"] in ("veh_surr", "veh_err"):
         surr = {k: env[k] for k in ("n_surr", "n_constraint", "veh_length", "veh_width", "road_upper", "road_lower", "reward_w")}
         surr["penalty"] = bool(env.get("penalty", False))
+        surr["err_tol"] = env.get("err_tol")
     lq = None
     if env["kind"] == "lq":
         c = env["lq"]

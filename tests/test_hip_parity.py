@@ -460,7 +460,7 @@ def test_data_env_step_vs_reference_numpy_envs(name, dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["step_veh_surrcstr_p10", "step_veh_detour_p10", "step_veh_surrcstr_p5_n2",
-                                  "step_veh_surrpen_p10"])
+                                  "step_veh_surrpen_p10", "step_veh_errcstr_p10"])
 def test_constrained_env_step_vs_reference_fixture(name, dev):
     """gops_env_step of the constrained veh3dofconti models (GOPS_ENV_VEH3DOF_SURR): surrounding-vehicle observation
     columns, surr_state, the unmasked constraint outputs, reward with the model's weights."""
@@ -484,5 +484,6 @@ def test_constrained_env_step_vs_reference_fixture(name, dev):
         np.testing.assert_allclose(r.cpu().numpy(), g[f"s{s}/rew"], rtol=2e-5 if "surrpen" in name else 1e-5, atol=2e-5)
         assert np.array_equal(done.cpu().numpy() != 0, g[f"s{s}/done"])
         np.testing.assert_allclose(info["state"].cpu().numpy(), g[f"s{s}/state"], rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(info["surr_state"].cpu().numpy(), g[f"s{s}/surr_state"], rtol=1e-5, atol=2e-5)
+        if f"s{s}/surr_state" in g:
+            np.testing.assert_allclose(info["surr_state"].cpu().numpy(), g[f"s{s}/surr_state"], rtol=1e-5, atol=2e-5)
         np.testing.assert_allclose(info["constraint"].cpu().numpy(), g[f"s{s}/constraint"], rtol=1e-5, atol=5e-5)

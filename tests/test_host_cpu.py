@@ -66,7 +66,7 @@ def test_registries_and_error_behaviour():
     assert {"mlp_DetermPolicy", "mlp_FiniteHorizonPolicy", "mlp_StateValue"} <= set(create_apprfunc.registry)
     assert {"pyth_lq_model", "pyth_idpendulum_model", "pyth_veh3dofconti_model", "pyth_veh3dofconti_surrcstr_model",
             "pyth_veh3dofconti_detour_model", "pyth_veh3dofconti_surrcstr_penalty_model", "gym_cartpoleconti_model",
-            "gym_pendulum_model", "pyth_veh2dofconti_model"} <= set(create_env_model.registry)
+            "gym_pendulum_model", "pyth_veh2dofconti_model", "pyth_veh3dofconti_errcstr_model"} <= set(create_env_model.registry)
     assert {"on_serial_trainer", "on_sync_trainer", "off_serial_trainer", "off_sync_trainer",
             "off_async_trainer"} <= set(create_trainer.registry)
     with pytest.raises(KeyError, match="No registered algorithm with id"):

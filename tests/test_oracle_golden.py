@@ -168,9 +168,10 @@ def test_data_env_step_matches_reference_numpy_envs(name):
     check_data_env_transitions(nobs, r, done, ninfo, t, env["kind"] == "veh")
 
 
-CSTR_STEP_CASES = ["step_veh_surrcstr_p10", "step_veh_detour_p10", "step_veh_surrcstr_p5_n2", "step_veh_surrpen_p10"]
+CSTR_STEP_CASES = ["step_veh_surrcstr_p10", "step_veh_detour_p10", "step_veh_surrcstr_p5_n2", "step_veh_surrpen_p10",
+                   "step_veh_errcstr_p10"]
 CSTR_ALG_CASES = ["fhadp_ext_surrcstr", "fhadp_int_surrcstr", "fhadp_lag_surrcstr", "fhadp_int_detour", "fhadp_ext_detour",
-                  "fhadp_ext_surrpen", "fhadp_int_surrpen"]
+                  "fhadp_ext_surrpen", "fhadp_int_surrpen", "fhadp_ext_errcstr", "fhadp_lag_errcstr"]
 CSTR_MODE = {"FHADPExterior": "exterior", "FHADPInterior": "interior", "FHADPLagrangian": "lagrangian"}
 
 
@@ -189,7 +190,8 @@ def test_constrained_env_step_matches_reference(name):
         np.testing.assert_allclose(obs.numpy(), g[f"s{s}/obs"], rtol=1e-5, atol=2e-5)
         np.testing.assert_allclose(r.numpy(), g[f"s{s}/rew"], rtol=1e-5, atol=2e-5)
         assert np.array_equal(done.numpy(), g[f"s{s}/done"])
-        np.testing.assert_allclose(info["surr_state"].numpy(), g[f"s{s}/surr_state"], rtol=1e-5, atol=2e-5)
+        if f"s{s}/surr_state" in g:
+            np.testing.assert_allclose(info["surr_state"].numpy(), g[f"s{s}/surr_state"], rtol=1e-5, atol=2e-5)
         np.testing.assert_allclose(info["constraint"].numpy(), g[f"s{s}/constraint"], rtol=1e-5, atol=2e-5)
 
 
@@ -224,7 +226,7 @@ def _spil_weights(delta_i, safe_prob_pre, safe_prob, chance=0.97, Kp=60, Ki=0.02
     return 1 / (1 + lam.sum()), lam / (1 + lam.sum()), lam
 
 
-@pytest.mark.parametrize("name", ["spil_surrcstr_p10", "spil_detour_p8"])
+@pytest.mark.parametrize("name", ["spil_surrcstr_p10", "spil_detour_p8", "spil_errcstr_p10"])
 def test_spil_gradients_match_reference(name):
     """One full SPIL update of the reference (PEV with the unmasked terminal value + safe probabilities, the PI multiplier
     rule, PIM over the Phi-products) against the oracle restatement."""

@@ -520,7 +520,9 @@ print("plumbing ok", seen["alg"])
                                     "example_train/fhadp/fhadp_mlp_veh3dofconti_surrcstr_penalty_serial.py",
                                     "example_train/fhadp/fhadp_mlp_lqs3a1_serial.py",
                                     "example_train/fhadp/fhadp_mlp_veh2dofconti_serial.py",
-                                    "example_train/infadp/infadp_mlp_veh2dofconti_offserial.py"])
+                                    "example_train/infadp/infadp_mlp_veh2dofconti_offserial.py",
+                                    "example_train/spil/spil_mlp_veh3dofconti_errcstr_offserial.py",
+                                    "example_train/spil/spil_mlp_veh3dofconti_surrcstr_offserial.py"])
 def test_example_scripts_run_unchanged_through_the_overlay(script, tmp_path):
     """BASELINE configs[0] plumbing: the reference's UNMODIFIED example scripts (their own argparse block, create_env,
     init_args, create_sampler, create_evaluator - a Ray actor handle, here from an in-process stub) executed with

@@ -33,7 +33,7 @@ class ConstrainedFHADP(FHADP):
     def _gradient_kernels(self, batch):
         B, device = batch["obs"].shape[0], batch["obs"].device
         ro = self._rollout_for(B, device)
-        if ro.desc.env.kind != hb.ENV_VEH_SURR or (ro.desc.env.n_surr > 0 and "surr_state" not in batch):
+        if not hb.has_constraints(ro.desc.env) or (ro.desc.env.n_surr > 0 and "surr_state" not in batch):
             raise RuntimeError(f"{type(self).__name__} needs a model with constraint outputs "
                                "(pyth_veh3dofconti_surrcstr / _detour / _errcstr) and its info in the batch")
         res = ro.forward(batch)

@@ -84,7 +84,7 @@ class SPIL(AlgorithmBase):
         ro = self._cache.get(key)
         if ro is None:
             env = self.envmodel.hip_env(nets.policy.act_low_lim.cpu().numpy(), nets.policy.act_high_lim.cpu().numpy())
-            if env.kind != hb.ENV_VEH_SURR:
+            if not hb.has_constraints(env):
                 raise RuntimeError("SPIL needs a model with constraint outputs (pyth_veh3dofconti_surrcstr / _detour / _errcstr)")
             if env.n_constraint != self.n_constraint:
                 raise RuntimeError(f"constraint_dim = {self.n_constraint}, but the model has {env.n_constraint} constraints")

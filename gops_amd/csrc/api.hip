@@ -179,7 +179,8 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     if (e.scale_obs && e.kind != GOPS_ENV_LQ && e.kind != GOPS_ENV_IDPENDULUM && e.kind < GOPS_ENV_CARTPOLE) return GOPS_ERR_UNSUPPORTED;   // obs_dim <= 8 only
     if (e.kind == GOPS_ENV_CARTPOLE && (e.obs_dim != 4 || e.act_dim != 1)) return GOPS_ERR_BAD_ARG;
     if (e.kind == GOPS_ENV_PENDULUM && (e.obs_dim != 3 || e.act_dim != 1)) return GOPS_ERR_BAD_ARG;
-    if (e.kind == GOPS_ENV_VEH2DOF && (e.act_dim != 1 || e.pre_horizon < 1 || e.obs_dim != 4 + e.pre_horizon || e.clip_obs)) return GOPS_ERR_BAD_ARG;
+    if (e.kind == GOPS_ENV_VEH2DOF && (e.act_dim != 1 || e.pre_horizon < 1 || e.obs_dim != 4 + e.pre_horizon || e.clip_obs ||
+                                        (e.cstr_err && e.n_constraint != 1))) return GOPS_ERR_BAD_ARG;
     if (e.kind >= GOPS_ENV_CARTPOLE && f16) return GOPS_ERR_UNSUPPORTED;   // the half-precision kernels are built for the BASELINE envs
     if (e.kind == GOPS_ENV_LQ && (e.obs_dim > GOPS_MAX_LQ_STATE || e.act_dim > GOPS_MAX_ACT)) return GOPS_ERR_UNSUPPORTED;
     if (e.kind == GOPS_ENV_IDPENDULUM && (e.obs_dim != 6 || e.act_dim != 1 || e.clip_obs)) return GOPS_ERR_BAD_ARG;

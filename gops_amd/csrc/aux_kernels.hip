@@ -1101,6 +1101,7 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         }
         for (int i = 0; i < 4; ++i) io.next_state[(size_t)b * 4 + i] = sn[i];
         io.next_ref_time[b] = nt;
+        if (env.cstr_err && io.constraint != nullptr) io.constraint[b] = fabsf(o4[0]) - env.err_tol[0];   // of the observation it was called with
     } else if (env.kind == GOPS_ENV_VEH3DOFCONTI || env.kind == GOPS_ENV_VEH3DOF_SURR) {
         const bool surr = env.kind == GOPS_ENV_VEH3DOF_SURR;
         const VehConst VC = veh_const();

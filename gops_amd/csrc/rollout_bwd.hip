@@ -190,12 +190,12 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     float gv = (tid < nvalid) ? gptr(p.grad_v)[b0 + tid] : 0.f;
     if constexpr (F16) gv *= f16_grad_scale(gptr(p.gscale)[0]);
     float gc_ext = 0.f, gc_lin = 0.f, gc_int = 0.f;   // SURR: d(loss)/d(constraint sums) of trajectory tid
-    if (SURR && tid < nvalid && p.in.grad_constraint != nullptr) {
+    if ((SURR || ENV == GOPS_ENV_VEH2DOF) && tid < nvalid && p.in.grad_constraint != nullptr) {
         const GLOBAL_AS float* gcp = gptr(p.in.grad_constraint) + b0 + tid;
         gc_ext = gcp[0]; gc_lin = gcp[(size_t)p.B]; gc_int = gcp[(size_t)2 * p.B];
     }
     float gc_mul[GOPS_MAX_CONSTRAINT] = {0.f, 0.f, 0.f};   // SPIL: d(loss)/d(P_k) * P_k of trajectory tid
-    if (SURR && tid < nvalid && p.in.grad_constraint_prod != nullptr) {
+    if ((SURR || ENV == GOPS_ENV_VEH2DOF) && tid < nvalid && p.in.grad_constraint_prod != nullptr) {
 #pragma unroll
         for (int k = 0; k < GOPS_MAX_CONSTRAINT; ++k)
             if (k < p.env.n_constraint) gc_mul[k] = gptr(p.in.grad_constraint_prod)[(size_t)k * p.B + b0 + tid];
@@ -496,6 +496,16 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                     gp[1] += g_rm * (-0.04f * o[1]);
                     gp[2] += g_rm * (-0.02f * o[2]);
                     gp[3] += g_rm * (-0.02f * o[3]);
+                    if (p.env.cstr_err) {   // errcstr: c = |obs[0]| - tol of THIS observation (unmasked sums / products)
+                        const float c = fabsf(o[0]) - p.env.err_tol[0];
+                        float gck = gc_ext * 2.f * fmaxf(c, 0.f) + (c > 0.f ? gc_lin : 0.f);
+                        if (c < 0.f) gck += gc_int * (-1.f / (-c + 1e-8f));
+                        gck *= p.gpow[t];
+                        float dlog;
+                        (void)spil_phi(c, dlog);
+                        gck += gc_mul[0] * dlog;
+                        gp[0] += gck * (o[0] > 0.f ? 1.f : (o[0] < 0.f ? -1.f : 0.f));
+                    }
                 }
                 g_steer += g_rm * (-0.02f * steer);
                 const float sc0 = (p.env.policy_high[0] - p.env.policy_low[0]) / 2.f;

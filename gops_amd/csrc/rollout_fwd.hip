@@ -388,6 +388,17 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 for (int i = 0; i < 4; ++i) { s[i] = s_state[m * 8 + i]; o[i] = xs[m * ldx + i]; }
                 const float steer = s_act[m * 4];
                 r = veh2_reward(o, steer);
+                if (p.env.cstr_err && m < nvalid) {   // pyth_veh2dofconti_errcstr: c = |delta_y| - tol of the CURRENT observation (unmasked)
+                    const float c = fabsf(o[0]) - p.env.err_tol[0];
+                    const float cp = fmaxf(c, 0.f), cm = fminf(c, 0.f);
+                    c_ext += cp * cp * p.gpow[t];
+                    c_lin += cp * p.gpow[t];
+                    c_int += logf(-cm + 1e-8f) * p.gpow[t];
+                    if (!(c < 0.f)) c_feas = 0.f;
+                    float dlog;
+                    c_mul[0] *= spil_phi(c, dlog);
+                    if (!(c <= 0.f)) c_safe[0] = 0.f;
+                }
                 float sphi, cphi;
                 sincosf(s[1], &sphi, &cphi);
                 veh2_f_xu(C2, s, steer, sphi, cphi, sn);
@@ -564,11 +575,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         if (tid < TB) v_acc += ((p.tail_unmasked ? 1.f : 1.f - s_done[tid]) * p.gpow[p.H]) * s_th[tid * 4];
     }
 
-    if (SURR && tid < nvalid && p.out.constraint_sums != nullptr) {
+    if ((SURR || VEH2) && tid < nvalid && p.out.constraint_sums != nullptr) {
         GLOBAL_AS float* cs = gptr(p.out.constraint_sums) + b0 + tid;
         cs[0] = c_ext; cs[(size_t)p.B] = c_lin; cs[(size_t)2 * p.B] = c_int; cs[(size_t)3 * p.B] = c_feas;
     }
-    if (SURR && tid < nvalid && p.out.constraint_prods != nullptr) {
+    if ((SURR || VEH2) && tid < nvalid && p.out.constraint_prods != nullptr) {
         GLOBAL_AS float* cp = gptr(p.out.constraint_prods) + b0 + tid;
         const int nc = p.env.n_constraint;
 #pragma unroll

@@ -268,6 +268,11 @@ def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_ac
     return e
 
 
+def has_constraints(env: GopsEnv) -> bool:
+    """Models whose rollout returns constraint sums / products (and whose env step fills info["constraint"])."""
+    return env.kind == ENV_VEH_SURR or (env.kind == ENV_VEH2DOF and env.cstr_err != 0)
+
+
 class Rollout:
     """One configured horizon rollout (forward + backward) bound to caller-owned tensors.
 
@@ -341,7 +346,7 @@ class Rollout:
             if d.env.kind in (ENV_VEH, ENV_VEH_SURR, ENV_VEH2DOF):
                 res["final_state"] = torch.empty(B, 4 if d.env.kind == ENV_VEH2DOF else 6, dtype=torch.float32, device=self.device)
                 out.final_state = _ptr(res["final_state"])
-        if d.env.kind == ENV_VEH_SURR:   # [4, B]: sum c+^2, sum c+, sum log(-c- + eps), feasible  (discounted, unmasked)
+        if has_constraints(d.env):   # [4, B]: sum c+^2, sum c+, sum log(-c- + eps), feasible  (discounted, unmasked)
             res["constraint_sums"] = torch.empty(4, B, dtype=torch.float32, device=self.device)
             out.constraint_sums = _ptr(res["constraint_sums"])
             # [2 n_c, B]: prod_t Phi(c_tk) and prod_t [c_tk <= 0] per constraint k (SPIL)
@@ -440,7 +445,7 @@ def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Ten
                      ref_time=torch.empty_like(info["ref_time"]), path_num=info["path_num"], u_num=info["u_num"])
         io.next_state, io.next_ref_points = _ptr(ninfo["state"]), _ptr(ninfo["ref_points"])
         io.next_ref_time = _ptr(ninfo["ref_time"])
-    if env.kind == ENV_VEH_SURR and env.n_surr == 0:
+    if has_constraints(env) and env.n_surr == 0:
         ninfo["constraint"] = torch.empty(B, env.n_constraint, dtype=torch.float32, device=obs.device)
         io.constraint = _ptr(ninfo["constraint"])
     elif env.kind == ENV_VEH_SURR:

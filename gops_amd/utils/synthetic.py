@@ -105,7 +105,7 @@ def obs_dim_of(cfg: Dict) -> int:
         return 6
     if cfg["env_id"] == "gym_cartpoleconti":
         return 4
-    if cfg["env_id"] == "pyth_veh2dofconti":
+    if cfg["env_id"] in ("pyth_veh2dofconti", "pyth_veh2dofconti_errcstr"):
         return 4 + cfg["pre_horizon"]
     if cfg["env_id"] == "gym_pendulum":
         return 3
@@ -124,7 +124,7 @@ def n_surr_of(cfg: Dict) -> int:
 
 
 def act_dim_of(cfg: Dict) -> int:
-    if cfg["env_id"] in ("pyth_idpendulum", "gym_cartpoleconti", "gym_pendulum", "pyth_veh2dofconti"):
+    if cfg["env_id"] in ("pyth_idpendulum", "gym_cartpoleconti", "gym_pendulum", "pyth_veh2dofconti", "pyth_veh2dofconti_errcstr"):
         return 1
     if cfg["env_id"] in ("pyth_veh3dofconti", "pyth_veh3dofconti_errcstr") or cfg["env_id"] in _SURR_ENVS:
         return 2
@@ -140,7 +140,7 @@ def make_batch(cfg: Dict, seed: int, batch: int = None) -> Dict[str, torch.Tenso
     if env_id == "pyth_idpendulum":
         h = np.array([5, 0.1, 0.1, 0.3, 0.3, 0.3], dtype=np.float32)
         out["obs"] = rng.uniform(-h, h, size=(B, 6)).astype(np.float32)
-    elif env_id == "pyth_veh2dofconti":
+    elif env_id in ("pyth_veh2dofconti", "pyth_veh2dofconti_errcstr"):
         # data env reset (pyth_veh2dofconti.py:121-170): state = (y, phi) of the first reference point + U(+-[1, pi/6]), (v, omega) ~ U(+-0.2)
         P = cfg["pre_horizon"]
         t0 = 20.0 * rng.uniform(0.0, 1.0, size=B)

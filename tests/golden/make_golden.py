@@ -150,14 +150,19 @@ GYM_SMALL = {
 }
 
 
-ERR_STEP_CASES = {"step_veh_errcstr_p10": dict(env_id="pyth_veh3dofconti_errcstr", pre_horizon=10)}
+ERR_STEP_CASES = {"step_veh_errcstr_p10": dict(env_id="pyth_veh3dofconti_errcstr", pre_horizon=10),
+                  "step_veh2dof_errcstr_p10": dict(env_id="pyth_veh2dofconti_errcstr", pre_horizon=10)}
 ERR_ALG_CASES = {
     "fhadp_ext_errcstr": (dict(alg="FHADPExterior", env_id="pyth_veh3dofconti_errcstr", batch=48, horizon=10, pre_horizon=10,
                                hidden=(64, 64), act="elu", gamma=0.99), dict(penalty=2.0)),
+    "fhadp_int_veh2dof_errcstr": (dict(alg="FHADPInterior", env_id="pyth_veh2dofconti_errcstr", batch=40, horizon=10, pre_horizon=10,
+                                       hidden=(64, 64), act="gelu", gamma=1.0), dict(penalty=1.5)),
     "fhadp_lag_errcstr": (dict(alg="FHADPLagrangian", env_id="pyth_veh3dofconti_errcstr", batch=40, horizon=8, pre_horizon=8,
                                hidden=(64, 64), act="tanh", gamma=1.0), dict(multiplier=0.6)),
 }
 SPIL_CASES = {   # gops/algorithm/spil.py on the constrained veh3dofconti models (one full update: PEV + PIM gradients)
+    "spil_veh2dof_errcstr_p10": (dict(alg="SPIL", env_id="pyth_veh2dofconti_errcstr", batch=40, horizon=10, pre_horizon=10,
+                                      hidden=(64, 64), act="elu", gamma=0.99), dict(constraint_dim=1)),
     "spil_errcstr_p10": (dict(alg="SPIL", env_id="pyth_veh3dofconti_errcstr", batch=48, horizon=10, pre_horizon=10,
                               hidden=(64, 64), act="relu", gamma=0.99), dict(constraint_dim=2)),
     "spil_surrcstr_p10": (dict(alg="SPIL", env_id="pyth_veh3dofconti_surrcstr", batch=48, horizon=10, pre_horizon=10,
@@ -526,7 +531,7 @@ def golden_constrained(step_cases=None, alg_cases=None):
         out["in/done"] = done.numpy().copy()
         o, d = data["obs"].clone(), done
         for s in range(nsteps):
-            a = torch.rand(B, 2, generator=g) * 2.6 - 1.3
+            a = torch.rand(B, act_dim_of(cfg), generator=g) * 2.6 - 1.3
             o, r, d, info = model.forward(o, a, d, info)
             out[f"s{s}/act"] = a.numpy()
             out[f"s{s}/obs"], out[f"s{s}/rew"], out[f"s{s}/done"] = o.numpy().copy(), r.numpy().copy(), d.numpy().copy()

@@ -77,7 +77,7 @@ def hip_env_from_oracle(env, policy_net=None):
     kind = {"veh_err": hb.ENV_VEH_SURR, "lq": hb.ENV_LQ, "idp": hb.ENV_IDP, "veh": hb.ENV_VEH, "veh_surr": hb.ENV_VEH_SURR,
             "cartpole": hb.ENV_CARTPOLE, "pendulum": hb.ENV_PENDULUM, "veh2": hb.ENV_VEH2DOF}[env["kind"]]
     surr = None
-    if env["kind"] in ("veh_surr", "veh_err"):
+    if env["kind"] in ("veh_surr", "veh_err") or env.get("err_tol") is not None:
         surr = {k: env[k] for k in ("n_surr", "n_constraint", "veh_length", "veh_width", "road_upper", "road_lower", "reward_w")}
         surr["penalty"] = bool(env.get("penalty", False))
         surr["err_tol"] = env.get("err_tol")

@@ -347,7 +347,8 @@ def test_infadp_graph_replay_matches_eager_updates(monkeypatch):
 
 
 CSTR_ALG_CASES = ["fhadp_ext_surrcstr", "fhadp_int_surrcstr", "fhadp_lag_surrcstr", "fhadp_int_detour", "fhadp_ext_detour",
-                  "fhadp_ext_surrpen", "fhadp_int_surrpen", "fhadp_ext_errcstr", "fhadp_lag_errcstr"]
+                  "fhadp_ext_surrpen", "fhadp_int_surrpen", "fhadp_ext_errcstr", "fhadp_lag_errcstr",
+                  "fhadp_int_veh2dof_errcstr"]
 
 
 @pytest.mark.gpu
@@ -488,7 +489,7 @@ def test_wide_output_mlp_matches_torch(case):
         assert rel_l2(got.cpu(), want) < 1e-4, (case, tuple(want.shape), rel_l2(got.cpu(), want))
 
 
-@pytest.mark.parametrize("name", ["spil_surrcstr_p10", "spil_detour_p8", "spil_errcstr_p10"])
+@pytest.mark.parametrize("name", ["spil_surrcstr_p10", "spil_detour_p8", "spil_errcstr_p10", "spil_veh2dof_errcstr_p10"])
 def test_spil_class_matches_reference(name):
     """SPIL (create_alg surface) on the constrained veh3dofconti models: one full update - value and policy gradients,
     losses, safe probabilities and the PI multipliers - against the reference's, from its checkpoint layout."""

@@ -460,7 +460,8 @@ def test_data_env_step_vs_reference_numpy_envs(name, dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["step_veh_surrcstr_p10", "step_veh_detour_p10", "step_veh_surrcstr_p5_n2",
-                                  "step_veh_surrpen_p10", "step_veh_errcstr_p10"])
+                                  "step_veh_surrpen_p10", "step_veh_errcstr_p10",
+                                  "step_veh2dof_errcstr_p10"])
 def test_constrained_env_step_vs_reference_fixture(name, dev):
     """gops_env_step of the constrained veh3dofconti models (GOPS_ENV_VEH3DOF_SURR): surrounding-vehicle observation
     columns, surr_state, the unmasked constraint outputs, reward with the model's weights."""

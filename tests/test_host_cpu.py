@@ -66,7 +66,8 @@ def test_registries_and_error_behaviour():
     assert {"mlp_DetermPolicy", "mlp_FiniteHorizonPolicy", "mlp_StateValue"} <= set(create_apprfunc.registry)
     assert {"pyth_lq_model", "pyth_idpendulum_model", "pyth_veh3dofconti_model", "pyth_veh3dofconti_surrcstr_model",
             "pyth_veh3dofconti_detour_model", "pyth_veh3dofconti_surrcstr_penalty_model", "gym_cartpoleconti_model",
-            "gym_pendulum_model", "pyth_veh2dofconti_model", "pyth_veh3dofconti_errcstr_model"} <= set(create_env_model.registry)
+            "gym_pendulum_model", "pyth_veh2dofconti_model", "pyth_veh3dofconti_errcstr_model",
+            "pyth_veh2dofconti_errcstr_model"} <= set(create_env_model.registry)
     assert {"on_serial_trainer", "on_sync_trainer", "off_serial_trainer", "off_sync_trainer",
             "off_async_trainer"} <= set(create_trainer.registry)
     with pytest.raises(KeyError, match="No registered algorithm with id"):
@@ -522,7 +523,8 @@ print("plumbing ok", seen["alg"])
                                     "example_train/fhadp/fhadp_mlp_veh2dofconti_serial.py",
                                     "example_train/infadp/infadp_mlp_veh2dofconti_offserial.py",
                                     "example_train/spil/spil_mlp_veh3dofconti_errcstr_offserial.py",
-                                    "example_train/spil/spil_mlp_veh3dofconti_surrcstr_offserial.py"])
+                                    "example_train/spil/spil_mlp_veh3dofconti_surrcstr_offserial.py",
+                                    "example_train/spil/spil_mlp_veh2dofconti_errcstr_offserial.py"])
 def test_example_scripts_run_unchanged_through_the_overlay(script, tmp_path):
     """BASELINE configs[0] plumbing: the reference's UNMODIFIED example scripts (their own argparse block, create_env,
     init_args, create_sampler, create_evaluator - a Ray actor handle, here from an in-process stub) executed with

@@ -169,9 +169,10 @@ def test_data_env_step_matches_reference_numpy_envs(name):
 
 
 CSTR_STEP_CASES = ["step_veh_surrcstr_p10", "step_veh_detour_p10", "step_veh_surrcstr_p5_n2", "step_veh_surrpen_p10",
-                   "step_veh_errcstr_p10"]
+                   "step_veh_errcstr_p10", "step_veh2dof_errcstr_p10"]
 CSTR_ALG_CASES = ["fhadp_ext_surrcstr", "fhadp_int_surrcstr", "fhadp_lag_surrcstr", "fhadp_int_detour", "fhadp_ext_detour",
-                  "fhadp_ext_surrpen", "fhadp_int_surrpen", "fhadp_ext_errcstr", "fhadp_lag_errcstr"]
+                  "fhadp_ext_surrpen", "fhadp_int_surrpen", "fhadp_ext_errcstr", "fhadp_lag_errcstr",
+                  "fhadp_int_veh2dof_errcstr"]
 CSTR_MODE = {"FHADPExterior": "exterior", "FHADPInterior": "interior", "FHADPLagrangian": "lagrangian"}
 
 
@@ -226,7 +227,7 @@ def _spil_weights(delta_i, safe_prob_pre, safe_prob, chance=0.97, Kp=60, Ki=0.02
     return 1 / (1 + lam.sum()), lam / (1 + lam.sum()), lam
 
 
-@pytest.mark.parametrize("name", ["spil_surrcstr_p10", "spil_detour_p8", "spil_errcstr_p10"])
+@pytest.mark.parametrize("name", ["spil_surrcstr_p10", "spil_detour_p8", "spil_errcstr_p10", "spil_veh2dof_errcstr_p10"])
 def test_spil_gradients_match_reference(name):
     """One full SPIL update of the reference (PEV with the unmasked terminal value + safe probabilities, the PI multiplier
     rule, PIM over the Phi-products) against the oracle restatement."""

@@ -1,5 +1,5 @@
 """MLP approximate functions of the ADP path: DetermPolicy, FiniteHorizonPolicy,
-FiniteHorizonFullPolicy, StateValue.
+FiniteHorizonFullPolicy, StateValue, ActionValue.
 
 Module structure, parameter names (`pi.0.weight` ... / `v.0.weight` ...), registered buffers and
 `forward` semantics follow the reference (gops/apprfunc/mlp.py:36-41,50-111,309-329) so that its
@@ -7,7 +7,7 @@ Module structure, parameter names (`pi.0.weight` ... / `v.0.weight` ...), regist
 and evaluators for single observations; inside `compute_gradient` the same parameters are read
 in place by the fused HIP rollout (`hip_mlp()`), which never calls `forward`.
 """
-__all__ = ["DetermPolicy", "FiniteHorizonPolicy", "FiniteHorizonFullPolicy", "StateValue"]
+__all__ = ["DetermPolicy", "FiniteHorizonPolicy", "FiniteHorizonFullPolicy", "StateValue", "ActionValue"]
 
 import weakref
 
@@ -139,3 +139,22 @@ class StateValue(nn.Module, Action_Distribution, _HipMlpMixin):
 
     def forward(self, obs):
         return torch.squeeze(self.v(obs), -1)
+
+
+class ActionValue(nn.Module, Action_Distribution, _HipMlpMixin):
+    """Action-value function: (obs, act) -> scalar over the concatenated input (reference gops/apprfunc/mlp.py:224-245,
+    parameter names `q.0.weight` ...).  MPG evaluates it through `gops_mlp_forward / _backward(_x)` (`hip_mlp()`)."""
+
+    _net_attr = "q"
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self._hidden_activation = kwargs["hidden_activation"]
+        self._output_activation = kwargs.get("output_activation", "linear")
+        self.q = mlp([kwargs["obs_dim"] + kwargs["act_dim"]] + list(kwargs["hidden_sizes"]) + [1],
+                     get_activation_func(self._hidden_activation),
+                     get_activation_func(self._output_activation))
+        self.action_distribution_cls = kwargs["action_distribution_cls"]
+
+    def forward(self, obs, act):
+        return torch.squeeze(self.q(torch.cat([obs, act], dim=-1)), -1)

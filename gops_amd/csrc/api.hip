@@ -333,7 +333,7 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
 
 int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const float* grad_v,
                  const GopsMlpGrad& grad, float* g_head_pre, void* ws, size_t ws_bytes, hipStream_t s,
-                 const float* ext_delta = nullptr) {
+                 const float* ext_delta = nullptr, const GopsRolloutAdjoint* adj = nullptr, bool want_params = true) {
     if (!desc.need_grad || grad_v == nullptr) return GOPS_ERR_BAD_ARG;
     Plan plan;
     int rc = build_plan(desc, ws, plan);
@@ -347,10 +347,26 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     if (p.open_loop && in.head_pre == nullptr) return GOPS_ERR_BAD_ARG;
     p.ext_delta = ext_delta;   // gops_mlp_backward: the head is a stand-in, its gradient is not formed
     if (ext_delta != nullptr && desc.env.kind != GOPS_ENV_NONE) return GOPS_ERR_BAD_ARG;
-    if (!p.open_loop)
+    if (!p.open_loop && want_params)
         for (int j = 0; j < p.pol.nl - (ext_delta != nullptr ? 1 : 0); ++j)
             if (grad.weight[j] == nullptr || grad.bias[j] == nullptr) return GOPS_ERR_BAD_ARG;
     hipError_t e;
+    if (adj != nullptr) {   // gops_rollout_backward_adj / gops_mlp_backward_x: the EXT kernels
+        const int k = desc.env.kind;
+        if (p.open_loop || p.tail || p.f16) return GOPS_ERR_UNSUPPORTED;
+        if (k != GOPS_ENV_NONE && k != GOPS_ENV_LQ && k != GOPS_ENV_IDPENDULUM && k != GOPS_ENV_CARTPOLE && k != GOPS_ENV_PENDULUM)
+            return GOPS_ERR_UNSUPPORTED;
+        p.ext = 1;
+        p.adj_gfo = adj->grad_final_obs;
+        p.adj_gobs = adj->grad_obs;
+        p.adj_first_only = (adj->first_step_only != 0 && p.H > 1) ? 1 : 0;
+        if (p.adj_first_only && want_params) {   // the sweep writes the step-0 deltas only: the rest of the stash is zero
+            const size_t S0 = (size_t)((p.B + TB - 1) / TB) * TB * p.H;
+            for (int j = 1; j < p.pol.nl; ++j)
+                if ((e = hipMemsetAsync(p.st.d[j], 0, S0 * p.pol.dims[j] * sizeof(float), s)) != hipSuccess) return (int)e;
+            if ((e = hipMemsetAsync(p.st.dy, 0, S0 * 4 * sizeof(float), s)) != hipSuccess) return (int)e;
+        }
+    }
     static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
     const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
     if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
@@ -368,7 +384,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
                 h[0] / p.H, h[10] / p.H, h[11] / p.H, h[1] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H, h[6] / p.H, h[7] / p.H,
                 h[8] / p.H, h[9] / p.H, h[2] / p.H);
     }
-    if (p.open_loop) return GOPS_OK;   // no parameters behind the rollout: the head adjoint is the result
+    if (p.open_loop || !want_params) return GOPS_OK;   // no parameters behind the rollout / none wanted
     ProfScope scope(desc.env.kind == GOPS_ENV_NONE ? 5 : 2, s);
     const long long S = (long long)((p.B + TB - 1) / TB) * TB * p.H;
     const int L = p.pol.nl - 1;
@@ -497,15 +513,15 @@ int gops_mlp_forward(const GopsMlp* mlp, int32_t batch, const float* x, float* y
     return (int)launch_linear_out_fwd(inner.p.st.h[L], m.K, mlp->weight[L], mlp->bias[L], m.W, batch, y, s);
 }
 
-int gops_mlp_backward(const GopsMlp* mlp, int32_t batch, const float* x, const float* grad_y, const GopsMlpGrad* grad,
-                      void* workspace, size_t workspace_bytes, void* stream) {
-    if (!mlp || !x || !grad_y || !grad) return GOPS_ERR_BAD_ARG;
+static int mlp_backward_impl(const GopsMlp* mlp, int32_t batch, const float* x, const float* grad_y, const GopsMlpGrad* grad,
+                             float* grad_x, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!mlp || !x || !grad_y || (!grad && !grad_x)) return GOPS_ERR_BAD_ARG;
     MlpPlan m;
     int rc = plan_mlp(*mlp, batch, workspace, m);
     if (rc != GOPS_OK) return rc;
     if (workspace == nullptr || workspace_bytes < m.bytes) return GOPS_ERR_WORKSPACE;
     const int L = mlp->n_layers - 1;
-    if (!grad->weight[L] || !grad->bias[L]) return GOPS_ERR_BAD_ARG;
+    if (grad && (!grad->weight[L] || !grad->bias[L])) return GOPS_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e;
     if ((e = hipMemsetAsync(m.gv, 0, (size_t)batch * sizeof(float), s)) != hipSuccess) return (int)e;
@@ -513,19 +529,39 @@ int gops_mlp_backward(const GopsMlp* mlp, int32_t batch, const float* x, const f
     if ((e = launch_linear_out_bwd(grad_y, m.W, m.Wp, mlp->weight[L], m.K, batch, m.S, m.gh, m.gyp, s)) != hipSuccess) return (int)e;
     Plan inner;
     build_plan(m.d, workspace, inner);
-    const DwPlan d = plan_dw(m.Wp, m.K, m.S);
-    if ((e = launch_dw_gemm(m.gyp, m.Wp, inner.p.st.h[L], m.K, m.S, d.splits, d.chunks_per_split, m.part, m.part_b, d.big, s)) != hipSuccess)
-        return (int)e;
-    ReduceJobs jobs;
-    memset(&jobs, 0, sizeof(jobs));
-    reduce_jobs_add(jobs, m.part, d.splits, m.W, m.K, m.K, grad->weight[L], m.Wp);
-    reduce_jobs_add(jobs, m.part_b, d.splits, 1, m.W, m.Wp, grad->bias[L]);
-    if ((e = launch_reduce(jobs, s)) != hipSuccess) return (int)e;
+    if (grad) {
+        const DwPlan d = plan_dw(m.Wp, m.K, m.S);
+        if ((e = launch_dw_gemm(m.gyp, m.Wp, inner.p.st.h[L], m.K, m.S, d.splits, d.chunks_per_split, m.part, m.part_b, d.big, s)) != hipSuccess)
+            return (int)e;
+        ReduceJobs jobs;
+        memset(&jobs, 0, sizeof(jobs));
+        reduce_jobs_add(jobs, m.part, d.splits, m.W, m.K, m.K, grad->weight[L], m.Wp);
+        reduce_jobs_add(jobs, m.part_b, d.splits, 1, m.W, m.Wp, grad->bias[L]);
+        if ((e = launch_reduce(jobs, s)) != hipSuccess) return (int)e;
+    }
     // hidden stack: the sweep starts from g_h instead of a head
     GopsRolloutIn in;
     memset(&in, 0, sizeof(in));
     in.obs = x;
-    return run_backward(m.d, in, m.gv, *grad, nullptr, workspace, m.inner, s, m.gh);
+    GopsMlpGrad none;
+    memset(&none, 0, sizeof(none));
+    GopsRolloutAdjoint adj;
+    memset(&adj, 0, sizeof(adj));
+    adj.grad_obs = grad_x;
+    return run_backward(m.d, in, m.gv, grad ? *grad : none, nullptr, workspace, m.inner, s, m.gh, grad_x ? &adj : nullptr,
+                        grad != nullptr);
+}
+
+int gops_mlp_backward(const GopsMlp* mlp, int32_t batch, const float* x, const float* grad_y, const GopsMlpGrad* grad,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!grad) return GOPS_ERR_BAD_ARG;
+    return mlp_backward_impl(mlp, batch, x, grad_y, grad, nullptr, workspace, workspace_bytes, stream);
+}
+
+int gops_mlp_backward_x(const GopsMlp* mlp, int32_t batch, const float* x, const float* grad_y, const GopsMlpGrad* grad,
+                        float* grad_x, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!grad_x) return GOPS_ERR_BAD_ARG;
+    return mlp_backward_impl(mlp, batch, x, grad_y, grad, grad_x, workspace, workspace_bytes, stream);
 }
 
 int gops_hip_version(void) { return GOPS_HIP_ABI_VERSION; }
@@ -549,6 +585,16 @@ int gops_rollout_backward(const GopsRolloutDesc* desc, const GopsRolloutIn* in, 
     if (!desc || !in || !policy_grad) return GOPS_ERR_BAD_ARG;
     return run_backward(*desc, *in, grad_v, *policy_grad, nullptr, workspace, workspace_bytes,
                         static_cast<hipStream_t>(stream));
+}
+
+int gops_rollout_backward_adj(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const float* grad_v,
+                              const GopsMlpGrad* policy_grad, const GopsRolloutAdjoint* adj, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    if (!desc || !in || !adj) return GOPS_ERR_BAD_ARG;
+    GopsMlpGrad none;
+    memset(&none, 0, sizeof(none));
+    return run_backward(*desc, *in, grad_v, policy_grad ? *policy_grad : none, nullptr, workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream), nullptr, adj, policy_grad != nullptr);
 }
 
 int gops_rollout_backward_open_loop(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const float* grad_v,

@@ -81,6 +81,10 @@ struct RolloutParams {
     float* g_head_pre;                // open-loop backward: d(loss)/d(head_pre) [B][H][A]
     const float* ext_delta;           // gops_mlp_backward (GOPS_ENV_NONE): adjoint of the LAST hidden activation [S][dims[L]],
                                       // taken instead of the head's (delta_y W_o) product; the head then has no gradient
+    const float* adj_gfo;             // EXT backward kernels (gops_rollout_backward_adj): d(loss)/d(final_obs) [B][obs_dim] or null
+    float* adj_gobs;                  //   out: d(loss)/d(obs_0) [B][obs_dim] or null
+    int adj_first_only;               //   1: the delta stash is written at step 0 only (zeroed beforehand)
+    int ext;                          //   1: launch the EXT instantiation
     const float* ref_table;           // veh: [B][P+1+H][4]
     const f32x4* surr_table;          // GOPS_ENV_VEH3DOF_SURR: [B][H+1][n_surr] (x, y, phi, u) of every surrounding vehicle after t steps
     unsigned long long* dbg;          // debug: per-phase cycle counters of block 0 (GOPS_DBG_TIMING)

@@ -160,7 +160,9 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
 // v_mfma_f32_16x16x32_f16 (rollout_f16.h), and every adjoint carries the launch's power-of-two scale
 // (gscale[0]) that the reduce kernel takes out of the parameter gradients again.
 // (F16 kernels: 4 workgroups per CU - launch bound 4 waves / SIMD, <= 128 registers.)
-template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false>
+// EXT (streamed fp32 kernels of the obs == state env kinds only): terminal observation adjoint in, initial
+// observation adjoint out, parameter deltas of step 0 only - gops_rollout_backward_adj / gops_mlp_backward_x
+template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, bool EXT = false>
 __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1)) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;
@@ -187,6 +189,15 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                                                                              : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0), F16);
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
+    if constexpr (EXT) {
+        if (p.adj_gfo != nullptr) {   // the caller's terminal term: G starts as d(loss)/d(obs_H)
+            __syncthreads();
+            for (int idx = tid; idx < nvalid * O; idx += NTHREADS) {
+                const int m = idx / O, i = idx - m * O;
+                G[m * ldx + i] = gptr(p.adj_gfo)[(size_t)(b0 + m) * O + i];
+            }
+        }
+    }
     float gv = (tid < nvalid) ? gptr(p.grad_v)[b0 + tid] : 0.f;
     if constexpr (F16) gv *= f16_grad_scale(gptr(p.gscale)[0]);
     float gc_ext = 0.f, gc_lin = 0.f, gc_int = 0.f;   // SURR: d(loss)/d(constraint sums) of trajectory tid
@@ -716,6 +727,13 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 mlp_backward_h(p.pol, s_wo, ldh, s_gy, reinterpret_cast<_Float16*>(da), reinterpret_cast<_Float16*>(db), ld16, G, ldx,
                                tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, [] {});
             else
+            if constexpr (EXT) {
+                const bool keep = !(p.adj_first_only && t > 0);   // later steps act through the frozen policy copy
+                mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z,
+                             keep ? p.st.d : nullptr, keep ? p.st.dy : nullptr, row0, nvalid,
+                             /*want_gx=*/(t > 0 && ENV != GOPS_ENV_NONE) || p.adj_gobs != nullptr, O, dbg, warm_up, st_cur,
+                             st_cur + TB * 256, ENV == GOPS_ENV_NONE ? p.ext_delta : nullptr);
+            } else
             mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
                          nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up, st_cur, st_cur + TB * 256,
                          ENV == GOPS_ENV_NONE ? p.ext_delta : nullptr);
@@ -735,6 +753,14 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     }
     if (l2_sink == 0x9e3779b9u && p.dbg != nullptr) gptr(p.dbg)[15] = l2_sink;   // keeps the warm-up loads alive
     dbg.dump(p.dbg);
+    if constexpr (EXT) {
+        if (p.adj_gobs != nullptr) {   // (the loop's closing barrier made every G update visible)
+            for (int idx = tid; idx < nvalid * O; idx += NTHREADS) {
+                const int m = idx / O, i = idx - m * O;
+                gptr(p.adj_gobs)[(size_t)(b0 + m) * O + i] = G[m * ldx + i];
+            }
+        }
+    }
 }
 
 // ref_points: reference-table points per trajectory (veh3dofconti), 30 (= 5 x 24 / 4) for the
@@ -767,6 +793,18 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
     size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H
                                                        : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0), p.f16 != 0);
+    if (p.ext) {   // adjoint I/O: streamed fp32 kernels of the obs == state kinds
+        if (p.f16 || p.tail) return hipErrorInvalidValue;
+        switch (p.env.kind) {
+            case GOPS_ENV_NONE: launch_with_lds(rollout_bwd_kernel<GOPS_ENV_NONE, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp); break;
+            case GOPS_ENV_LQ: launch_with_lds(rollout_bwd_kernel<GOPS_ENV_LQ, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp); break;
+            case GOPS_ENV_IDPENDULUM: launch_with_lds(rollout_bwd_kernel<GOPS_ENV_IDPENDULUM, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp); break;
+            case GOPS_ENV_CARTPOLE: launch_with_lds(rollout_bwd_kernel<GOPS_ENV_CARTPOLE, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp); break;
+            case GOPS_ENV_PENDULUM: launch_with_lds(rollout_bwd_kernel<GOPS_ENV_PENDULUM, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     int sk[2];
     rollout_variant(p, sk, true);
     if (sk[1] > 0) lds += sizeof(float) * 2 * (2 * TB * 256 + TB * ENV_STASH + TB * 8);   // two staging halves

@@ -80,6 +80,11 @@ class GopsRolloutOut(C.Structure):
 ADAM_MAX = 16
 
 
+class GopsRolloutAdjoint(C.Structure):
+    _fields_ = [("grad_final_obs", C.c_void_p), ("grad_obs", C.c_void_p), ("first_step_only", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class GopsAdamTensors(C.Structure):
     _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("numel", C.c_int64 * ADAM_MAX),
                 ("param", C.c_void_p * ADAM_MAX), ("grad", C.c_void_p * ADAM_MAX),
@@ -117,6 +122,10 @@ def lib() -> C.CDLL:
         l.gops_rollout_backward.restype = C.c_int
         l.gops_rollout_backward.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn), C.c_void_p,
                                             C.POINTER(GopsMlpGrad), C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gops_rollout_backward_adj.restype = C.c_int
+        l.gops_rollout_backward_adj.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn), C.c_void_p,
+                                                C.POINTER(GopsMlpGrad), C.POINTER(GopsRolloutAdjoint), C.c_void_p,
+                                                C.c_size_t, C.c_void_p]
         l.gops_env_step.restype = C.c_int
         l.gops_env_step.argtypes = [C.POINTER(GopsEnv), C.c_int32, C.POINTER(GopsStepIO), C.c_void_p]
         l.gops_value_workspace_bytes.restype = C.c_size_t
@@ -134,6 +143,9 @@ def lib() -> C.CDLL:
         l.gops_mlp_backward.restype = C.c_int
         l.gops_mlp_backward.argtypes = [C.POINTER(GopsMlp), C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(GopsMlpGrad),
                                         C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gops_mlp_backward_x.restype = C.c_int
+        l.gops_mlp_backward_x.argtypes = [C.POINTER(GopsMlp), C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(GopsMlpGrad),
+                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         l.gops_adam_step.restype = C.c_int
         l.gops_adam_step.argtypes = [C.POINTER(GopsAdamTensors), C.c_void_p, C.c_double, C.c_double, C.c_double,
                                      C.c_void_p]
@@ -146,9 +158,9 @@ def lib() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = ("gops_hip_version", "gops_rollout_workspace_bytes", "gops_rollout_forward",
-                    "gops_rollout_backward", "gops_rollout_backward_open_loop", "gops_env_step", "gops_value_workspace_bytes",
+                    "gops_rollout_backward", "gops_rollout_backward_open_loop", "gops_rollout_backward_adj", "gops_env_step", "gops_value_workspace_bytes",
                     "gops_value_forward", "gops_value_backward", "gops_mlp_workspace_bytes", "gops_mlp_forward",
-                    "gops_mlp_backward", "gops_adam_step", "gops_profile_enable",
+                    "gops_mlp_backward", "gops_mlp_backward_x", "gops_adam_step", "gops_profile_enable",
                     "gops_profile_reset", "gops_profile_read")
 
 _ERR = {-1: "GOPS_ERR_BAD_ARG", -2: "GOPS_ERR_UNSUPPORTED", -3: "GOPS_ERR_WORKSPACE"}
@@ -370,6 +382,24 @@ class Rollout:
               "gops_rollout_backward")
 
 
+    def backward_adj(self, grad_v: torch.Tensor, grad_w: Optional[List[torch.Tensor]] = None,
+                     grad_b: Optional[List[torch.Tensor]] = None, *, grad_final_obs: Optional[torch.Tensor] = None,
+                     want_grad_obs: bool = False, first_step_only: bool = False) -> Optional[torch.Tensor]:
+        """`gops_rollout_backward_adj`: the sweep seeded with d(loss)/d(final_obs), optionally returning
+        d(loss)/d(obs) of the initial observation; `first_step_only`: parameter gradients through the action of step 0
+        only (MPG's model return, mpg.py:340-353).  `grad_w is None`: no parameter gradients."""
+        d = self.desc
+        adj = GopsRolloutAdjoint()
+        adj.grad_final_obs = _ptr(grad_final_obs)
+        g_obs = torch.empty(d.batch, d.env.obs_dim, dtype=torch.float32, device=self.device) if want_grad_obs else None
+        adj.grad_obs = _ptr(g_obs)
+        adj.first_step_only = int(bool(first_step_only))
+        g = make_mlp_grad(grad_w, grad_b) if grad_w is not None else None
+        check(lib().gops_rollout_backward_adj(C.byref(d), C.byref(self._in), _ptr(grad_v), C.byref(g) if g is not None else None,
+                                              C.byref(adj), self.workspace.data_ptr(), self.workspace.numel(), _stream()),
+              "gops_rollout_backward_adj")
+        return g_obs
+
     def backward_open_loop(self, grad_v: torch.Tensor) -> torch.Tensor:
         """d(loss)/d(head_pre) [B, H, act_dim] of the last open-loop forward."""
         d = self.desc
@@ -428,6 +458,15 @@ class MlpNet:
         g = make_mlp_grad(grad_w, grad_b)
         check(lib().gops_mlp_backward(C.byref(self.mlp), self.batch, _ptr(x), _ptr(grad_y), C.byref(g),
                                       self.workspace.data_ptr(), self.workspace.numel(), _stream()), "gops_mlp_backward")
+
+    def backward_x(self, x: torch.Tensor, grad_y: torch.Tensor, grad_w=None, grad_b=None) -> torch.Tensor:
+        """`gops_mlp_backward_x`: returns d(loss)/d(x); parameter gradients too when grad_w / grad_b are given."""
+        g = make_mlp_grad(grad_w, grad_b) if grad_w is not None else None
+        gx = torch.empty(self.batch, int(self.mlp.sizes[0]), dtype=torch.float32, device=self.device)
+        check(lib().gops_mlp_backward_x(C.byref(self.mlp), self.batch, _ptr(x), _ptr(grad_y), C.byref(g) if g is not None else None,
+                                        _ptr(gx), self.workspace.data_ptr(), self.workspace.numel(), _stream()),
+              "gops_mlp_backward_x")
+        return gx
 
 
 def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Tensor]] = None):

@@ -29,6 +29,7 @@ OVERLAY = {
     "gops.algorithm.infadp": "gops_amd.algorithm.infadp",
     "gops.algorithm.mac": "gops_amd.algorithm.mac",
     "gops.algorithm.spil": "gops_amd.algorithm.spil",
+    "gops.algorithm.mpg": "gops_amd.algorithm.mpg",
     "gops.apprfunc.mlp": "gops_amd.apprfunc.mlp",
     # NOT overlaid: gops.env.env_ocp.env_model.pyth_*_model.  The reference's DATA envs import helpers from those
     # modules (`from ...env_model.pyth_idpendulum_model import Dynamics`, pyth_idpendulum.py:20), and nothing on the

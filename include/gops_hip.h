@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GOPS_HIP_ABI_VERSION 4
+#define GOPS_HIP_ABI_VERSION 5
 
 #define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
 #define GOPS_MAX_ACT 4      /* action dimensions */
@@ -238,6 +238,25 @@ int gops_rollout_backward_open_loop(const GopsRolloutDesc* desc, const GopsRollo
                                     const float* grad_v, float* grad_head_pre,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Adjoints around a closed-loop rollout (ABI v5): what a caller needs to put a rollout in the middle of a larger
+ * differentiable expression.  MPG's model return (gops/algorithm/mpg.py:340-353) is
+ *     sum_t gamma^t r_t + gamma^H q1_target(o_H, policy(o_H))
+ * where only step 0 acts through `policy`; later steps act through the frozen copy `policy4rollout` (same weights,
+ * requires_grad False: gradients still flow through its INPUT).  The terminal term is evaluated by the caller
+ * (gops_mlp_forward / gops_mlp_backward_x) and comes back as `grad_final_obs`.
+ * Supported for the env kinds whose observation is the model state (GOPS_ENV_NONE, _LQ, _IDPENDULUM, _CARTPOLE,
+ * _PENDULUM), fp32, tail_value = 0, closed loop. */
+typedef struct GopsRolloutAdjoint {
+    const float* grad_final_obs;  /* [B, obs_dim] d(loss)/d(final_obs) (GopsRolloutOut.final_obs); NULL = zeros */
+    float* grad_obs;              /* out [B, obs_dim]: d(loss)/d(obs) of the initial observation; NULL = not wanted */
+    int32_t first_step_only;      /* 1: parameter gradients only through the action of step 0 (mpg.py:343-349) */
+    int32_t reserved;
+} GopsRolloutAdjoint;
+/* gops_rollout_backward with the adjoints above; policy_grad may be NULL (no parameter gradients wanted). */
+int gops_rollout_backward_adj(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const float* grad_v,
+                              const GopsMlpGrad* policy_grad, const GopsRolloutAdjoint* adj,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* One wrapped env-model step.  `action` is the raw (pre-wrapper) action [B, act_dim].  For
  * veh3dofconti the info tensors are updated into the next_* outputs (may alias the inputs
  * except ref_points). */
@@ -270,6 +289,12 @@ int gops_mlp_forward(const GopsMlp* mlp, int32_t batch, const float* x, float* y
                      size_t workspace_bytes, void* stream);
 int gops_mlp_backward(const GopsMlp* mlp, int32_t batch, const float* x, const float* grad_y,
                       const GopsMlpGrad* grad, void* workspace, size_t workspace_bytes, void* stream);
+/* gops_mlp_backward that also returns d(loss)/d(x) [batch, sizes[0]] (ABI v5); `grad` may be NULL when only the input
+ * adjoint is wanted: `q1(o, policy(o))` differentiated with respect to the action with frozen q parameters
+ * (gops/algorithm/mpg.py:186-191,338) and the policy evaluated at the rollout's last observation (:352-354). */
+int gops_mlp_backward_x(const GopsMlp* mlp, int32_t batch, const float* x, const float* grad_y,
+                        const GopsMlpGrad* grad, float* grad_x, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /* One Adam step (torch.optim.Adam defaults semantics: no weight decay, no amsgrad) over up to
  * GOPS_ADAM_MAX_TENSORS parameter tensors in ONE launch - replaces `self.networks.policy_optimizer.step()`

@@ -203,6 +203,55 @@ def golden_spil():
         save(name, **out)
 
 
+MPG_CASES = {   # gops/algorithm/mpg.py: one compute_gradient (twin-Q regression + mixed policy gradient) per case
+    "mpg_cartpole_mixed_weight": (dict(alg="MPG", env_id="gym_cartpoleconti", batch=64, horizon=10, hidden=(64, 64), act="relu",
+                                       gamma=0.99), dict(pge_method="mixed_weight", eta=0.3, terminal_iter=10000), 3000, 0.1),
+    "mpg_pendulum_mixed_state": (dict(alg="MPG", env_id="gym_pendulum", batch=48, horizon=8, hidden=(64, 64), act="elu",
+                                      gamma=0.99), dict(pge_method="mixed_state", kappa=0.5), 7, 0.1),
+    "mpg_lq_s4a2_mixed_weight": (dict(alg="MPG", env_id="pyth_lq", lq_config="s4a2", batch=40, horizon=6, hidden=(64, 64),
+                                      act="gelu", gamma=0.97), dict(pge_method="mixed_weight", eta=0.1, terminal_iter=100), 80, 1.0),
+    "mpg_idp_mixed_state": (dict(alg="MPG", env_id="pyth_idpendulum", batch=33, horizon=5, hidden=(32, 32), act="tanh",
+                                 gamma=0.99), dict(pge_method="mixed_state", kappa=0.15), 0, 0.5),
+}
+
+
+def golden_mpg():
+    from gops.algorithm.mpg import MPG
+    for name, (cfg, extra, iteration, reward_scale) in MPG_CASES.items():
+        seed = zlib.crc32(name.encode()) % 1000
+        torch.manual_seed(seed)
+        kw = alg_kwargs(dict(cfg, alg="INFADP"), seed, **extra)
+        kw.update(algorithm="MPG", value_func_name="ActionValue", value_output_activation="linear")
+        alg = MPG(gamma=cfg["gamma"], forward_step=cfg["horizon"], tau=0.1, **kw)
+        alg.reward_scale = reward_scale
+        g = torch.Generator().manual_seed(seed + 1000)
+        nets = alg.networks
+        moved = [nets.q1_target, nets.q2_target, nets.policy_target]
+        if extra["pge_method"] == "mixed_state":   # the model pair starts as a copy of (q1, q2): move it apart
+            moved += [nets.q1_model, nets.q2_model, nets.q1_model_target, nets.q2_model_target]
+        with torch.no_grad():
+            for net in moved:
+                for p in net.parameters():
+                    p.add_(0.1 * (torch.rand(p.shape, generator=g) - 0.5))
+        B, A = cfg["batch"], act_dim_of(cfg)
+        obs = make_batch(cfg, seed)["obs"]
+        data = dict(obs=obs, act=torch.rand(B, A, generator=g) * 2 - 1, rew=torch.randn(B, generator=g),
+                    obs2=obs + 0.05 * torch.randn(obs.shape, generator=g), done=(torch.rand(B, generator=g) < 0.15).float())
+        out = {"in/" + k: v.numpy().copy() for k, v in data.items()}
+        out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra=extra, seed=seed, iteration=iteration, reward_scale=reward_scale))
+        out.update(sd_to_np(nets.state_dict()))
+        out.update(model_consts(alg.envmodel))
+        tb, info = alg.get_remote_update_info(data, iteration)
+        for key, grads in info.items():
+            if key.endswith("_grad"):
+                for i, gr in enumerate(grads):
+                    out[f"{key}/{i}"] = gr.detach().numpy().copy()
+        for k, v in tb.items():
+            if k.startswith("MPG/"):
+                out["tb/" + k] = np.float64(v)
+        save(name, **out)
+
+
 MAC_SMALL = {   # gops/algorithm/mac.py on the info-free models
     "mac_lq_s4a2_gelu": (dict(alg="MAC", env_id="pyth_lq", lq_config="s4a2", batch=64, horizon=10,
                               hidden=(64, 64), act="gelu", gamma=0.99), {}),
@@ -635,7 +684,7 @@ def golden_data_envs():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof", "errcstr"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof", "errcstr", "mpg"]
     if "veh2dof" in which:
         golden_steps(VEH2_STEP_CASES)
         golden_small(VEH2_SMALL)
@@ -645,6 +694,8 @@ if __name__ == "__main__":
         golden_small(GYM_SMALL)
     if "errcstr" in which:
         golden_constrained(ERR_STEP_CASES, ERR_ALG_CASES)
+    if "mpg" in which:
+        golden_mpg()
     if "spil" in which:
         golden_spil()
     if "mac" in which:

@@ -37,6 +37,21 @@ def nets_from_golden(g, cfg):
     return nets, sd
 
 
+def mpg_nets_from_golden(g, cfg):
+    """Oracle parameter dicts of an MPG fixture's state_dict (q1, q2, [q1_model, q2_model], targets, policy)."""
+    sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("sd/")}
+    nets = {}
+    for name in ("policy", "policy_target"):
+        net = orc.net_from_state_dict(sd, f"{name}.pi", cfg["act"], requires_grad=(name == "policy"))
+        net["act_high"], net["act_low"] = sd[f"{name}.act_high_lim"], sd[f"{name}.act_low_lim"]
+        nets[name] = net
+    for name in ("q1", "q2", "q1_model", "q2_model"):
+        if f"{name}.q.0.weight" in sd:
+            nets[name] = orc.net_from_state_dict(sd, f"{name}.q", cfg["act"])
+            nets[name + "_target"] = orc.net_from_state_dict(sd, f"{name}_target.q", cfg["act"], requires_grad=False)
+    return nets, sd
+
+
 def reference_init_nets(cfg, seed, obs_dim, act_dim):
     """Re-create the reference's random init: torch.manual_seed(seed) then nn.Linear layers in
     the reference's construction order (fhadp.py:42-44; infadp.py:41-45: value first)."""

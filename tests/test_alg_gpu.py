@@ -7,8 +7,9 @@ import torch
 from conftest import golden_meta, load_golden, rel_l2
 from helpers import data_from_golden
 
+from gops_amd import hip_backend as hb
 from gops_amd.create_pkg.create_alg import create_alg
-from gops_amd.utils.synthetic import act_dim_of, obs_dim_of
+from gops_amd.utils.synthetic import act_dim_of, make_batch, obs_dim_of
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -32,6 +33,9 @@ def _kwargs(cfg, extra, seed):
         kw["lq_config"] = cfg["lq_config"]
     if cfg["alg"] == "SPIL":
         kw.update(policy_func_name="DetermPolicy", pre_horizon=cfg["pre_horizon"])
+    if cfg["alg"] == "MPG":
+        kw.update(value_func_type="MLP", value_func_name="ActionValue", value_hidden_sizes=list(cfg["hidden"]),
+                  value_hidden_activation=cfg["act"], value_learning_rate=1e-3)
     kw.update(extra)
     return kw
 
@@ -512,3 +516,116 @@ def test_spil_class_matches_reference(name):
     before = [p.detach().clone() for p in alg.networks.policy.parameters()]
     alg.remote_update(info)
     assert any((a - b).abs().max() > 0 for a, b in zip(alg.networks.policy.parameters(), before))
+
+
+# ---- adjoint I/O around rollouts / MLP batches (ABI v5) and MPG ---------------------------------------------------------
+@pytest.mark.parametrize("case", [dict(sizes=[5, 64, 64, 1], act="relu", B=70, params=True),
+                                  dict(sizes=[4, 64, 64, 2], act="gelu", B=33, params=True),
+                                  dict(sizes=[7, 32, 32, 1], act="tanh", B=16, params=False),
+                                  dict(sizes=[37, 256, 256, 3], act="elu", B=300, params=False)])
+def test_mlp_backward_x_matches_autograd(case):
+    """`gops_mlp_backward_x`: d(loss)/d(x) of an MLP batch (with or without parameter gradients) against torch autograd
+    of the oracle's restatement."""
+    from oracle import adp_oracle as orc
+    torch.manual_seed(5)
+    sizes, B = case["sizes"], case["B"]
+    lin = [torch.nn.Linear(a, b) for a, b in zip(sizes[:-1], sizes[1:])]
+    ws = [l.weight.detach().cuda().contiguous() for l in lin]
+    bs = [l.bias.detach().cuda().contiguous() for l in lin]
+    x, gy = torch.randn(B, sizes[0]), torch.randn(B, sizes[-1])
+    net = hb.MlpNet(hb.make_mlp(ws, bs, case["act"]), B)
+    y = net.forward(x.cuda())
+    gw, gb = ([torch.empty_like(w) for w in ws], [torch.empty_like(b) for b in bs]) if case["params"] else (None, None)
+    gx = net.backward_x(x.cuda(), gy.cuda().contiguous(), gw, gb)
+    torch.cuda.synchronize()
+    xr = x.clone().requires_grad_(True)
+    wr = [l.weight.detach().clone().requires_grad_(True) for l in lin]
+    br = [l.bias.detach().clone().requires_grad_(True) for l in lin]
+    yr = orc.mlp_forward(wr, br, xr, case["act"])
+    grads = torch.autograd.grad(yr, [xr] + wr + br, grad_outputs=gy)
+    assert rel_l2(y.cpu(), yr.detach()) < 1e-5
+    assert rel_l2(gx.cpu(), grads[0]) < TOL, rel_l2(gx.cpu(), grads[0])
+    if case["params"]:
+        for got, want in zip(gw + gb, grads[1:]):
+            assert rel_l2(got.cpu(), want) < TOL, (case, tuple(want.shape))
+
+
+@pytest.mark.parametrize("env_kw,horizon,act,first_only", [
+    (dict(env_id="pyth_lq", lq_config="s4a2"), 6, "gelu", True),
+    (dict(env_id="pyth_lq", lq_config="s3a1"), 9, "elu", False),
+    (dict(env_id="pyth_idpendulum"), 5, "tanh", True),
+    (dict(env_id="gym_cartpoleconti"), 10, "relu", True),
+    (dict(env_id="gym_pendulum"), 8, "elu", True),
+    (dict(env_id="gym_pendulum"), 1, "relu", True),
+])
+def test_rollout_backward_adj_matches_autograd(env_kw, horizon, act, first_only):
+    """`gops_rollout_backward_adj`: the sweep seeded with d(loss)/d(final_obs), returning d(loss)/d(obs_0), with the
+    parameter gradients of step 0 only (later steps through a frozen copy of the policy, mpg.py:343-349) or of every
+    step, against torch autograd over the oracle's rollout."""
+    from helpers import hip_env_from_oracle, hip_mlp_from_net
+    from oracle import adp_oracle as orc
+    cfg = dict(env_kw, alg="INFADP", batch=37, horizon=horizon, hidden=(64, 64), act=act, gamma=0.97)
+    env = orc.make_env(cfg["env_id"], lq_config=cfg.get("lq_config", "s4a2"))
+    O, A, B = env["obs_dim"], env["act_dim"], cfg["batch"]
+    net = orc.make_net([O, 64, 64, A], act, seed=11, act_high=torch.ones(A), act_low=-torch.ones(A))
+    data = make_batch(cfg, 3)
+    data["done"][-3:] = 1.0   # finished trajectories: MaskAtDone freezes the observation, the adjoint passes through
+    gen = torch.Generator().manual_seed(9)
+    gv, gfo = torch.randn(B, generator=gen) / B, torch.randn(B, O, generator=gen) / B
+    # oracle: loss = sum_b gv_b v_b + <gfo, final_obs>
+    obs0 = data["obs"].clone().requires_grad_(True)
+    frozen = dict(net, w=[w.detach() for w in net["w"]], b=[b.detach() for b in net["b"]])
+    o, done, info, v = obs0, data["done"].bool(), data, 0
+    for t in range(horizon):
+        a = orc.policy_forward(net if (t == 0 or not first_only) else frozen, o, None)
+        o, r, done, info = orc.env_forward(env, o, a, done, info)
+        v = v + r * cfg["gamma"] ** t
+    loss = (gv * v).sum() + (gfo * o).sum()
+    params = [p for pair in zip(net["w"], net["b"]) for p in pair]
+    want = torch.autograd.grad(loss, [obs0] + params)
+    # HIP
+    dev = torch.device("cuda")
+    mlp, ws, bs = hip_mlp_from_net(net, dev)
+    ro = hb.Rollout(hip_env_from_oracle(env, net), mlp, batch=B, horizon=horizon, gamma=cfg["gamma"], finite_horizon=False)
+    res = ro.forward({k: v_.to(dev).contiguous() for k, v_ in data.items() if k in ("obs", "done")}, want_final=True)
+    gw, gb = [torch.empty_like(w) for w in ws], [torch.empty_like(b) for b in bs]
+    g_obs = ro.backward_adj(gv.to(dev), gw, gb, grad_final_obs=gfo.to(dev).contiguous(), want_grad_obs=True,
+                            first_step_only=first_only)
+    torch.cuda.synchronize()
+    assert rel_l2(res["final_obs"].cpu(), o.detach()) < 1e-5
+    assert rel_l2(g_obs.cpu(), want[0]) < TOL, rel_l2(g_obs.cpu(), want[0])
+    got = [p for pair in zip(gw, gb) for p in pair]
+    for i, (g_, w_) in enumerate(zip(got, want[1:])):
+        assert rel_l2(g_.cpu(), w_) < TOL, (i, rel_l2(g_.cpu(), w_))
+    # no parameter gradients wanted: the input adjoint alone
+    g_obs2 = ro.backward_adj(gv.to(dev), grad_final_obs=gfo.to(dev).contiguous(), want_grad_obs=True, first_step_only=first_only)
+    assert torch.equal(g_obs2, g_obs)
+
+
+@pytest.mark.parametrize("name", ["mpg_cartpole_mixed_weight", "mpg_pendulum_mixed_state", "mpg_lq_s4a2_mixed_weight",
+                                  "mpg_idp_mixed_state"])
+def test_mpg_class_matches_reference(name):
+    """MPG (create_alg surface): one compute_gradient - the gradients of q1, q2 (q1_model, q2_model) and of the policy
+    (data-driven + model-driven mix) and the logged scalars - against the reference's, from its checkpoint layout;
+    then one update through the public API."""
+    alg, g, cfg = _load_alg(name)
+    meta = golden_meta(g)
+    alg.gamma, alg.forward_step, alg.reward_scale = cfg["gamma"], cfg["horizon"], meta["reward_scale"]
+    data = data_from_golden(g)
+    tb, info = alg.get_remote_update_info(data, meta["iteration"])
+    for k in [k for k in g if k.startswith("tb/")]:
+        want = float(g[k])
+        assert abs(float(tb[k[3:]]) - want) <= TOL * max(1.0, abs(want)), (k, tb[k[3:]], want)
+    nets = [k[:-5] for k in info if k.endswith("_grad")]
+    assert set(nets) == {k.split("/")[0][:-5] for k in g if "_grad/" in k}
+    for n in nets:
+        for i, gr in enumerate(info[f"{n}_grad"]):
+            assert rel_l2(gr.cpu(), g[f"{n}_grad/{i}"]) < TOL, (n, i, rel_l2(gr.cpu(), g[f"{n}_grad/{i}"]))
+    before = {n: [p.detach().clone() for p in getattr(alg.networks, n).parameters()] for n in nets + ["q1_target", "policy4rollout"]}
+    alg.remote_update(info)
+    for n in nets + ["q1_target", "policy4rollout"]:
+        after = list(getattr(alg.networks, n).parameters())
+        assert all(torch.isfinite(a).all() for a in after)
+        assert any((a - b).abs().max() > 0 for a, b in zip(after, before[n])), n
+    for a, b in zip(alg.networks.policy4rollout.parameters(), alg.networks.policy.parameters()):
+        assert torch.equal(a, b)

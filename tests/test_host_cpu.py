@@ -62,7 +62,7 @@ def test_workspace_query_and_rejections_need_no_gpu():
 
 def test_registries_and_error_behaviour():
     from gops_amd.create_pkg import create_alg, create_apprfunc, create_env_model, create_trainer
-    assert set(create_alg.registry) == {"FHADP", "FHADP2", "FHADPExterior", "FHADPInterior", "FHADPLagrangian", "INFADP", "MAC", "SPIL"}
+    assert set(create_alg.registry) == {"FHADP", "FHADP2", "FHADPExterior", "FHADPInterior", "FHADPLagrangian", "INFADP", "MAC", "MPG", "SPIL"}
     assert {"mlp_DetermPolicy", "mlp_FiniteHorizonPolicy", "mlp_StateValue"} <= set(create_apprfunc.registry)
     assert {"pyth_lq_model", "pyth_idpendulum_model", "pyth_veh3dofconti_model", "pyth_veh3dofconti_surrcstr_model",
             "pyth_veh3dofconti_detour_model", "pyth_veh3dofconti_surrcstr_penalty_model", "gym_cartpoleconti_model",
@@ -524,7 +524,8 @@ print("plumbing ok", seen["alg"])
                                     "example_train/infadp/infadp_mlp_veh2dofconti_offserial.py",
                                     "example_train/spil/spil_mlp_veh3dofconti_errcstr_offserial.py",
                                     "example_train/spil/spil_mlp_veh3dofconti_surrcstr_offserial.py",
-                                    "example_train/spil/spil_mlp_veh2dofconti_errcstr_offserial.py"])
+                                    "example_train/spil/spil_mlp_veh2dofconti_errcstr_offserial.py",
+                                    "example_train/mpg/mpg_mlp_cartpoleconti_offserial.py"])   # (the pendulum scripts need the gym package for their data env)
 def test_example_scripts_run_unchanged_through_the_overlay(script, tmp_path):
     """BASELINE configs[0] plumbing: the reference's UNMODIFIED example scripts (their own argparse block, create_env,
     init_args, create_sampler, create_evaluator - a Ray actor handle, here from an in-process stub) executed with

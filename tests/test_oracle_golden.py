@@ -249,3 +249,26 @@ def test_spil_gradients_match_reference(name):
     assert abs(pim["loss"].item() - float(g["pim_loss"])) <= 1e-5 * max(1.0, abs(float(g["pim_loss"])))
     for i, gr in enumerate(pim["grads"]):
         assert rel_l2(gr, g[f"pim_grad/{i}"]) < 1e-5, (name, "pim", i)
+
+
+MPG_FIXTURES = ["mpg_cartpole_mixed_weight", "mpg_pendulum_mixed_state", "mpg_lq_s4a2_mixed_weight", "mpg_idp_mixed_state"]
+
+
+@pytest.mark.parametrize("name", MPG_FIXTURES)
+def test_mpg_gradients_match_reference(name):
+    """One MPG.__compute_gradient of the reference (twin-Q regression on the clipped double-Q backup, mixed policy
+    gradient through q1(o, pi(o)) and through the model rollout with the frozen policy4rollout + q1_target tail)
+    against the oracle restatement: every gradient of every trained network and the logged scalars."""
+    from helpers import mpg_nets_from_golden
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg = meta["cfg"]
+    env = oracle_env(cfg, {}, g)
+    nets, _ = mpg_nets_from_golden(g, cfg)
+    out = orc.mpg_gradient(env, nets, data_from_golden(g), meta["iteration"], forward_step=cfg["horizon"], gamma=cfg["gamma"],
+                           reward_scale=meta["reward_scale"], **meta["extra"])
+    for k, v in out["tb"].items():
+        assert abs(v - float(g["tb/" + k])) <= 1e-5 * max(1.0, abs(float(g["tb/" + k]))), (name, k, v, float(g["tb/" + k]))
+    for net, grads in out["grads"].items():
+        for i, gr in enumerate(grads):
+            assert rel_l2(gr, g[f"{net}_grad/{i}"]) < 1e-5, (name, net, i, rel_l2(gr, g[f"{net}_grad/{i}"]))

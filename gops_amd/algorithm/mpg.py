@@ -92,6 +92,7 @@ class MPG(AlgorithmBase):
         self.reward_scale = 1.0
         self.delay_update = delay_update
         self.forward_step = forward_step
+        self.tb_info = dict()
         self._cache = {}
         self._tmp = {}
 
@@ -278,4 +279,5 @@ class MPG(AlgorithmBase):
         info["MPG/loss_pi-RL iter"] = loss_pi
         tb_info = {k: (v.item() if torch.is_tensor(v) else float(v)) for k, v in info.items()}   # host sync, as in the reference
         tb_info[tb_tags["alg_time"]] = (time.time() - start_time) * 1000
+        self.tb_info = tb_info
         return tb_info

@@ -629,3 +629,31 @@ def test_mpg_class_matches_reference(name):
         assert any((a - b).abs().max() > 0 for a, b in zip(after, before[n])), n
     for a, b in zip(alg.networks.policy4rollout.parameters(), alg.networks.policy.parameters()):
         assert torch.equal(a, b)
+
+
+def test_mpg_learns_with_device_sampler(tmp_path):
+    """MPG end to end on the GPU: N pendulum models stepped by gops_env_step with exploration noise, device replay buffer,
+    off_serial_trainer; the twin-Q regression loss falls and every network stays finite."""
+    from gops_amd.create_pkg.create_buffer import create_buffer
+    from gops_amd.create_pkg.create_trainer import create_trainer
+    from gops_amd.trainer.sampler.device_env_sampler import DeviceEnvSampler
+    cfg = dict(alg="MPG", env_id="gym_pendulum", batch=256, horizon=10, hidden=(64, 64), act="relu", gamma=0.99)
+    torch.manual_seed(0)
+    kw = _kwargs(cfg, dict(pge_method="mixed_weight", eta=0.3, terminal_iter=1e8, forward_step=10, tau=0.1), 0)
+    kw.update(trainer="off_serial_trainer", buffer_name="replay_buffer", buffer_max_size=20000, buffer_warm_size=2048,
+              replay_batch_size=256, sample_interval=1, additional_info={}, max_iteration=80, log_save_interval=1000,
+              apprfunc_save_interval=1000, eval_interval=10 ** 9, save_folder=str(tmp_path), ini_network_dir=None)
+    alg = create_alg(**kw)
+    alg.reward_scale = 0.1
+    alg.networks.to("cuda")
+    smp = DeviceEnvSampler(cfg, alg.envmodel, n_envs=256, steps_per_sample=2, max_episode_steps=50, seed=3, noise_std=0.2,
+                           env_step="model")
+    buf = create_buffer(**kw)
+    trainer = create_trainer(alg, smp, buf, None, **kw)
+    losses = []
+    for _ in range(80):
+        trainer.step()
+        trainer.iteration += 1
+        losses.append(alg.tb_info["MPG/loss_q-RL iter"])
+    assert all(np.isfinite(losses)) and np.mean(losses[-10:]) < 0.5 * np.mean(losses[:5]), (losses[:5], losses[-10:])
+    assert all(torch.isfinite(p).all() for p in alg.networks.parameters())

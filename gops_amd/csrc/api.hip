@@ -27,6 +27,7 @@ hipError_t launch_linear_out_fwd(const float* h, int K, const float* Wo, const f
 hipError_t launch_linear_out_bwd(const float* gy, int W, int Wp, const float* Wo, int K, int B, long long S, float* gh,
                                  float* gyp, hipStream_t s);
 hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s);
+hipError_t launch_fill_zero(float* p, size_t n, hipStream_t s);
 hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s);
 hipError_t launch_adam(const GopsAdamTensors& T, GopsAdamState* st, double beta1, double beta2, float eps,
                        hipStream_t s);
@@ -305,7 +306,7 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
     p.out = out;
     if (p.open_loop) {
         if (in.head_pre == nullptr) return GOPS_ERR_BAD_ARG;
-        hipError_t me = hipMemsetAsync(plan.dummy, 0, plan.dummy_floats * sizeof(float), s);
+        hipError_t me = launch_fill_zero(plan.dummy, plan.dummy_floats, s);
         if (me != hipSuccess) return (int)me;
     }
     static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
@@ -363,8 +364,8 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
         if (p.adj_first_only && want_params) {   // the sweep writes the step-0 deltas only: the rest of the stash is zero
             const size_t S0 = (size_t)((p.B + TB - 1) / TB) * TB * p.H;
             for (int j = 1; j < p.pol.nl; ++j)
-                if ((e = hipMemsetAsync(p.st.d[j], 0, S0 * p.pol.dims[j] * sizeof(float), s)) != hipSuccess) return (int)e;
-            if ((e = hipMemsetAsync(p.st.dy, 0, S0 * 4 * sizeof(float), s)) != hipSuccess) return (int)e;
+                if ((e = launch_fill_zero(p.st.d[j], S0 * p.pol.dims[j], s)) != hipSuccess) return (int)e;
+            if ((e = launch_fill_zero(p.st.dy, S0 * 4, s)) != hipSuccess) return (int)e;
         }
     }
     static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
@@ -498,7 +499,7 @@ int gops_mlp_forward(const GopsMlp* mlp, int32_t batch, const float* x, float* y
     if (rc != GOPS_OK) return rc;
     if (workspace == nullptr || workspace_bytes < m.bytes) return GOPS_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(m.zeros, 0, ((size_t)m.K + 16) * sizeof(float), s);
+    hipError_t e = launch_fill_zero(m.zeros, (size_t)m.K + 16, s);
     if (e != hipSuccess) return (int)e;
     GopsRolloutIn in;
     memset(&in, 0, sizeof(in));
@@ -524,7 +525,7 @@ static int mlp_backward_impl(const GopsMlp* mlp, int32_t batch, const float* x, 
     if (grad && (!grad->weight[L] || !grad->bias[L])) return GOPS_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e;
-    if ((e = hipMemsetAsync(m.gv, 0, (size_t)batch * sizeof(float), s)) != hipSuccess) return (int)e;
+    if ((e = launch_fill_zero(m.gv, (size_t)batch, s)) != hipSuccess) return (int)e;
     // output layer: g_h = g_y Wo (+ padded copy of g_y), dWo = g_y^T h and db = column sums through the regular dW GEMM
     if ((e = launch_linear_out_bwd(grad_y, m.W, m.Wp, mlp->weight[L], m.K, batch, m.S, m.gh, m.gyp, s)) != hipSuccess) return (int)e;
     Plan inner;

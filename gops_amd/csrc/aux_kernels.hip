@@ -1,6 +1,7 @@
 // Support kernels around the rollout: MFMA-fragment weight packing, the veh3dofconti reference
 // table, the weight-gradient GEMMs (dW = delta^T * input over all B*H samples), partial-sum
 // reduction, and the single-step env-model entry point.
+#include <algorithm>
 #include "common.h"
 #include "env_models.h"
 
@@ -1008,6 +1009,23 @@ __global__ __launch_bounds__(256) void adam_kernel(const GopsAdamTensors T, Gops
             st->beta2_pow = b2p;
         }
     }
+}
+
+// Zero fill as a KERNEL on the caller's stream: inside a captured HIP graph a hipMemsetAsync becomes a memset node,
+// which was measured to race with the neighbouring kernel nodes on replay (non-reproducible gradients); a kernel node
+// is ordered like every other launch.
+__global__ __launch_bounds__(256) void fill_zero_kernel(f32x4* __restrict__ p4, size_t n4, float* __restrict__ tail, int ntail) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p4[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
+
+hipError_t launch_fill_zero(float* p, size_t n, hipStream_t s) {   // p is 16-byte aligned (workspace carving)
+    if (n == 0) return hipSuccess;
+    const size_t n4 = n >> 2;
+    const unsigned blocks = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (n4 + 255) / 256));
+    hipLaunchKernelGGL(fill_zero_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<f32x4*>(p), n4, p + (n4 << 2), (int)(n & 3));
+    return hipGetLastError();
 }
 
 hipError_t launch_adam(const GopsAdamTensors& T, GopsAdamState* st, double beta1, double beta2, float eps,

@@ -657,3 +657,38 @@ def test_mpg_learns_with_device_sampler(tmp_path):
         losses.append(alg.tb_info["MPG/loss_q-RL iter"])
     assert all(np.isfinite(losses)) and np.mean(losses[-10:]) < 0.5 * np.mean(losses[:5]), (losses[:5], losses[-10:])
     assert all(torch.isfinite(p).all() for p in alg.networks.parameters())
+
+
+@pytest.mark.parametrize("pge", ["mixed_weight", "mixed_state"])
+def test_mpg_graph_replay_equals_eager(pge, monkeypatch):
+    """local_update captured into a HIP graph (gradient + Adam per network + Polyak, iteration-dependent mixing weights
+    as a graph input) walks exactly the parameter trajectory of the eager launches."""
+    # (B = 256 for 30 iterations: the configuration in which memset NODES inside the captured graph - hipMemsetAsync in
+    # the library - were seen to race with the neighbouring kernels; the library zero-fills with a kernel since)
+    cfg = dict(alg="MPG", env_id="gym_pendulum", batch=256, horizon=10, hidden=(64, 64), act="relu", gamma=0.99)
+    extra = dict(pge_method=pge, forward_step=10, tau=0.1, delay_update=2, **(dict(eta=0.3, terminal_iter=20) if pge == "mixed_weight" else dict(kappa=0.5)))
+    B = cfg["batch"]
+
+    def run(mode):
+        monkeypatch.setenv("GOPS_HIP_GRAPH", mode)
+        torch.manual_seed(4)
+        alg = create_alg(**_kwargs(cfg, extra, 4))
+        alg.networks.to("cuda")
+        logs = []
+        for it in range(30):
+            gen = torch.Generator().manual_seed(100 + it)
+            obs = make_batch(cfg, 60 + it)["obs"]
+            data = dict(obs=obs, act=torch.rand(B, 1, generator=gen) * 2 - 1, rew=torch.randn(B, generator=gen),
+                        obs2=obs + 0.05 * torch.randn(obs.shape, generator=gen), done=(torch.rand(B, generator=gen) < 0.1).float())
+            logs.append(dict(alg.local_update(data, it)))
+        return alg, logs
+
+    eager, log_e = run("0")
+    graph, log_g = run("1")
+    assert any(c.graph is not None for c in graph._graphs.values()) and all(c.graph is None for c in eager._graphs.values())
+    for (ne, pe), (ng, pg) in zip(eager.networks.named_parameters(), graph.networks.named_parameters()):
+        assert ne == ng and torch.equal(pe, pg), ne
+    for a, b in zip(log_e, log_g):
+        for k in a:
+            if not k.startswith("Time/"):
+                assert a[k] == b[k], k

@@ -525,7 +525,15 @@ print("plumbing ok", seen["alg"])
                                     "example_train/spil/spil_mlp_veh3dofconti_errcstr_offserial.py",
                                     "example_train/spil/spil_mlp_veh3dofconti_surrcstr_offserial.py",
                                     "example_train/spil/spil_mlp_veh2dofconti_errcstr_offserial.py",
-                                    "example_train/mpg/mpg_mlp_cartpoleconti_offserial.py"])   # (the pendulum scripts need the gym package for their data env)
+                                    "example_train/mpg/mpg_mlp_cartpoleconti_offserial.py",
+                                    "example_train/fhadp/fhadp2_mlp_veh3dofconti_serial.py",
+                                    "example_train/fhadp/fhadp_mlp_lqs2a1_serial.py",
+                                    "example_train/fhadp/fhadp_mlp_lqs5a1_serial.py",
+                                    "example_train/infadp/infadp_mlp_idpendulum_serial.py",
+                                    "example_train/infadp/infadp_mlp_cartpoleconti_offserial.py",
+                                    "example_train/infadp/infadp_mlp_veh3dofconti_offserial.py",
+                                    "example_train/infadp/infadp_mlp_lqs6a3_offserial.py",
+                                    "example_train/mac/mac_mlp_cartpoleconti_offserial.py"])   # (the pendulum scripts need the gym package for their data env)
 def test_example_scripts_run_unchanged_through_the_overlay(script, tmp_path):
     """BASELINE configs[0] plumbing: the reference's UNMODIFIED example scripts (their own argparse block, create_env,
     init_args, create_sampler, create_evaluator - a Ray actor handle, here from an in-process stub) executed with

@@ -50,11 +50,13 @@ class GradAllReducer:
         """`defer_scale`: leave the SUM in the buffers and hand the 1/N to the consumer as
         `update_info["_grad_scale"]` - the HIP Adam kernel multiplies it in as it reads the gradients
         (`hip_backend.HipAdam.grad_scale`), which saves the elementwise launch between the collective and
-        the optimizer step.  Entries whose name starts with "_" are not gradients and are left alone."""
+        the optimizer step.  Entries whose name starts with "_", and entries that are not lists of tensors, are left alone."""
         n = world_size()
         if n == 1:
             return update_info
-        tensors = [g for name in sorted(update_info) if not name.startswith("_") for g in update_info[name]]
+        # (MPG's update_info also carries its iteration counter, mpg.py:434: non-list entries are not gradients)
+        tensors = [g for name in sorted(update_info)
+                   if not name.startswith("_") and isinstance(update_info[name], (list, tuple)) for g in update_info[name]]
         flat = _as_one_buffer(tensors)
         in_place = flat is not None
         if not in_place:

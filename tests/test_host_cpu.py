@@ -164,8 +164,9 @@ batches = [torch.rand(4, 3, generator=torch.Generator().manual_seed(k)) for k in
 expect = w0 - 0.5 * torch.cat(batches).mean(0, keepdim=True)   # gradient of the CONCATENATED batch
 assert torch.allclose(alg.networks.weight, expect, atol=1e-7), (alg.networks.weight, expect)
 red = GradAllReducer()
-info = {"policy": [torch.full((5,), float(r)), torch.full((2, 2), 10.0 * r)], "v": [torch.ones(3) * (r + 1)]}
+info = {"policy": [torch.full((5,), float(r)), torch.full((2, 2), 10.0 * r)], "v": [torch.ones(3) * (r + 1)], "iteration": 7}
 red.average_(info)
+assert info["iteration"] == 7   # MPG's update_info carries its iteration counter: not a gradient
 assert torch.allclose(info["policy"][0], torch.full((5,), (n - 1) / 2))
 assert torch.allclose(info["v"][0], torch.ones(3) * (n + 1) / 2)
 # a network's gradients as allocated by the algorithms: views into one flat buffer, reduced in place

@@ -190,8 +190,9 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16"],
                     help="arithmetic of the MLP contractions: fp32 (exact, parity path) or fp16 (half-precision MFMA, BASELINE cfg5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager-gpu-baseline", action="store_true",
-                    help="also time the oracle restatement as PyTorch eager ops on the GPU (reported inside cpu_baseline)")
+    ap.add_argument("--eager-gpu-baseline", action=argparse.BooleanOptionalAction, default=True,
+                    help="also time the oracle restatement as PyTorch eager ops on the GPU (FHADP workloads; ~1 s; reported "
+                         "inside cpu_baseline as eager_gpu_steps_per_s)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -66,7 +66,7 @@ class WrappedEnvModel:
                 obs_high=m.obs_upper_bound.cpu() if (self.clip_obs or data_env) else None,
                 pre_horizon=getattr(m, "pre_horizon", 0), reward_scale=self.reward_scale,
                 reward_shift=self.reward_shift, data_env=data_env, obs_scale=self.obs_scale, obs_shift=self.obs_shift,
-                **m.hip_constants())
+                ref_c=getattr(m, "ref_c", None), **m.hip_constants())
         return self._env_cache[key]
 
     def forward(self, obs: torch.Tensor, action: torch.Tensor, done: torch.Tensor, info: Dict

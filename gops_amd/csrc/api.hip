@@ -77,6 +77,20 @@ struct ProfScope {
 };
 
 // ---- workspace plan ----------------------------------------------------------------------------
+// GopsEnv.ref_c of the default MultiRefTrajModel parameters (ref_traj_data.py:18-37), folded like the reference folds
+// its Python scalars (double arithmetic, one rounding to fp32)
+void fill_ref_defaults(GopsEnv& e) {
+    if (e.ref_custom) return;
+    const double PI = 3.14159265358979323846, w = 2.0 * PI / 10.0;
+    const double c[24] = {-1.0 / w, w, 0.0, 5.0, 1.0 / w * 1.0, 1.0,                  // sine speed: A = 1, omega = 2 pi / 10, phi = 0, b = 5
+                          5.0,                                                      // constant speed
+                          1.5, w, 0.0,                                              // sine path
+                          5.0, 9.0, 14.0, 18.0, 0.0, 3.5, 3.5 / 4.0, -3.5 / 4.0,    // double lane
+                          10.0, 2.0 * 3.0 / 10.0, -2.0 * 3.0 / 10.0, 10.0 / 2.0,    // triangle: A = 3, T = 10
+                          100.0, 0.0};                                              // circle
+    for (int i = 0; i < 24; ++i) e.ref_c[i] = (float)c[i];
+}
+
 struct Carver {
     char* base;
     size_t off = 0;
@@ -204,6 +218,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     p.tail = desc.tail_value ? 1 : 0;
     p.tail_unmasked = (desc.tail_value && desc.tail_unmasked) ? 1 : 0;
     p.env = e;
+    fill_ref_defaults(p.env);
     p.open_loop = desc.open_loop == 2 ? 2 : (desc.open_loop ? 1 : 0);
     p.f16 = f16 ? 1 : 0;
     if (p.open_loop) {
@@ -621,7 +636,9 @@ int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void*
          !io->next_state || !io->next_ref_points || !io->next_ref_time)) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_LQ && env->obs_dim > GOPS_MAX_LQ_STATE) return GOPS_ERR_UNSUPPORTED;
     if (env->scale_obs && env->kind != GOPS_ENV_LQ && env->kind != GOPS_ENV_IDPENDULUM && env->kind < GOPS_ENV_CARTPOLE) return GOPS_ERR_UNSUPPORTED;
-    return (int)launch_env_step(*env, batch, *io, pdt_of(*env), static_cast<hipStream_t>(stream));
+    GopsEnv e = *env;
+    fill_ref_defaults(e);
+    return (int)launch_env_step(e, batch, *io, pdt_of(e), static_cast<hipStream_t>(stream));
 }
 
 size_t gops_value_workspace_bytes(const GopsMlp* value, int32_t batch) {

@@ -103,50 +103,46 @@ hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipS
 #define RADD(a, b) __fadd_rn((a), (b))
 #define RSUB(a, b) __fsub_rn((a), (b))
 
-__device__ __forceinline__ float ref_arc(float t, int u_num) {
-    const float W = (float)(2.0 * 3.14159265358979323846 / 10.0);
-    if (u_num == 0) {
-        const float c1 = (float)(-1.0 / (2.0 * 3.14159265358979323846 / 10.0));
-        const float c2 = (float)(1.0 / (2.0 * 3.14159265358979323846 / 10.0));
-        return RADD(RADD(RMUL(c1, COSF_CR(RMUL(W, t))), RMUL(5.0f, t)), c2);
-    }
-    return RMUL(5.0f, t);
+// `c` = GopsEnv.ref_c (include/gops_hip.h): the reference's path / speed parameters, folded on the host where the
+// reference folds Python scalars.  With the default set every expression below rounds exactly like the constants the
+// first version of this file had spelled out (x + 0.0f and 1.0f * x are exact).
+__device__ __forceinline__ float ref_arc(const float* __restrict__ c, float t, int u_num) {
+    if (u_num == 0) return RADD(RADD(RMUL(c[0], COSF_CR(RADD(RMUL(c[1], t), c[2]))), RMUL(c[3], t)), c[4]);
+    return RMUL(c[6], t);
 }
 
-__device__ __forceinline__ void ref_xy(float t, int path, int u_num, float& x, float& y) {
-    const float W = (float)(2.0 * 3.14159265358979323846 / 10.0);
-    const float s = ref_arc(t, u_num);
+__device__ __forceinline__ void ref_xy(const float* __restrict__ c, float t, int path, int u_num, float& x, float& y) {
+    const float s = ref_arc(c, t, u_num);
     if (path == 0) {
         x = s;
-        y = RMUL(1.5f, SINF_CR(RMUL(W, t)));
+        y = RMUL(c[7], SINF_CR(RADD(RMUL(c[8], t), c[9])));
     } else if (path == 1) {
         x = s;
-        if (t <= 5.0f) y = 0.f;
-        else if (t <= 9.0f) y = RADD(RMUL(0.875f, RSUB(t, 5.0f)), 0.f);
-        else if (t <= 14.0f) y = 3.5f;
-        else if (t <= 18.0f) y = RADD(RMUL(-0.875f, RSUB(t, 14.0f)), 3.5f);
-        else y = 0.f;
+        if (t <= c[10]) y = c[14];
+        else if (t <= c[11]) y = RADD(RMUL(c[16], RSUB(t, c[10])), c[14]);
+        else if (t <= c[12]) y = c[15];
+        else if (t <= c[13]) y = RADD(RMUL(c[17], RSUB(t, c[12])), c[15]);
+        else y = c[14];
     } else if (path == 2) {
         x = s;
-        float sm = fmodf(t, 10.0f);
-        if (sm < 0.f) sm += 10.0f;
-        if (sm <= 5.0f) y = RMUL(0.6f, sm);
-        else if (sm < 10.0f) y = RMUL(-0.6f, RSUB(sm, 10.0f));
+        float sm = fmodf(t, c[18]);
+        if (sm != 0.f && ((c[18] < 0.f) != (sm < 0.f))) sm += c[18];   // torch.remainder: sign of the divisor
+        if (sm <= c[21]) y = RMUL(c[19], sm);
+        else if (sm < c[18]) y = RMUL(c[20], RSUB(sm, c[18]));
         else y = 0.f;
     } else {
-        const float q = s / 100.0f;
-        x = RMUL(100.0f, SINF_CR(q));
-        y = RMUL(100.0f, RSUB(COSF_CR(q), 1.0f));
+        const float q = s / c[22];
+        x = RMUL(c[22], SINF_CR(q));
+        y = RMUL(c[22], RSUB(COSF_CR(q), 1.0f));
     }
 }
 
-__device__ __forceinline__ f32x4 ref_point(float t, int path, int u_num) {
-    const float W = (float)(2.0 * 3.14159265358979323846 / 10.0);
+__device__ __forceinline__ f32x4 ref_point(const float* __restrict__ c, float t, int path, int u_num) {
     float x0, y0, x1, y1;
-    ref_xy(t, path, u_num, x0, y0);
-    ref_xy(RADD(t, 0.001f), path, u_num, x1, y1);
+    ref_xy(c, t, path, u_num, x0, y0);
+    ref_xy(c, RADD(t, 0.001f), path, u_num, x1, y1);
     const float phi = (float)atan2((double)RSUB(y1, y0), (double)RSUB(x1, x0));
-    const float u = (u_num == 0) ? RADD(SINF_CR(RMUL(W, t)), 5.0f) : 5.0f;
+    const float u = (u_num == 0) ? RADD(RMUL(c[5], SINF_CR(RADD(RMUL(c[1], t), c[2]))), c[3]) : c[6];
     f32x4 r = {x0, y0, phi, u};
     return r;
 }
@@ -157,7 +153,8 @@ __device__ __forceinline__ void ref_table_element(int B, int P, int H, const flo
                                                   const float* __restrict__ path_num,
                                                   const float* __restrict__ u_num,
                                                   const float* __restrict__ ref_time, float pdt,
-                                                  float* __restrict__ table, int idx, bool yphi_only) {
+                                                  float* __restrict__ table, int idx, bool yphi_only,
+                                                  const float* __restrict__ refc) {
     const int TL = P + 1 + H;
     if (idx >= B * TL) return;
     const int b = idx / TL, i = idx - b * TL;
@@ -176,7 +173,7 @@ __device__ __forceinline__ void ref_table_element(int B, int P, int H, const flo
         const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : (pn == 3.f) ? 3 : -1;
         const int us = (un == 0.f) ? 0 : (un == 1.f) ? 1 : -1;
         if (path < 0 || us < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};   // ids outside the registered sets
-        else v = ref_point(RADD(t, pdt), path, us);
+        else v = ref_point(refc, RADD(t, pdt), path, us);
     }
     reinterpret_cast<f32x4*>(table)[idx] = v;
 }
@@ -232,7 +229,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
         const int nrt = (p.B * (P + 1 + p.H) + 255) / 256;
         if (b < nrt) {
             ref_table_element(p.B, P, p.H, p.in.ref_points, p.in.path_num, p.in.u_num, p.in.ref_time, pdt,
-                              const_cast<float*>(p.ref_table), b * 256 + threadIdx.x, p.env.kind == GOPS_ENV_VEH2DOF);
+                              const_cast<float*>(p.ref_table), b * 256 + threadIdx.x, p.env.kind == GOPS_ENV_VEH2DOF, p.env.ref_c);
             return;
         }
         b -= nrt;
@@ -1104,7 +1101,7 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         const float nt = RADD(io.ref_time[b], 0.1f);
         const float pn = io.path_num[b], un = io.u_num[b];
         const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : 3;
-        const f32x4 newp = ref_point(RADD(nt, pdt), path, un == 0.f ? 0 : 1);
+        const f32x4 newp = ref_point(env.ref_c, RADD(nt, pdt), path, un == 0.f ? 0 : 1);
         const float* rin = io.ref_points + (size_t)b * (P + 1) * 2;
         float* rout = io.next_ref_points + (size_t)b * (P + 1) * 2;
         for (int i = 0; i < P; ++i) { rout[2 * i] = rin[2 * (i + 1)]; rout[2 * i + 1] = rin[2 * (i + 1) + 1]; }
@@ -1143,7 +1140,7 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         const float nt = RADD(io.ref_time[b], 0.1f);
         const float pn = io.path_num[b], un = io.u_num[b];
         const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : 3;
-        const f32x4 newp = ref_point(RADD(nt, pdt), path, un == 0.f ? 0 : 1);
+        const f32x4 newp = ref_point(env.ref_c, RADD(nt, pdt), path, un == 0.f ? 0 : 1);
         const f32x4* rin = reinterpret_cast<const f32x4*>(io.ref_points) + (size_t)b * (P + 1);
         f32x4* rout = reinterpret_cast<f32x4*>(io.next_ref_points) + (size_t)b * (P + 1);
         float cn, snn;

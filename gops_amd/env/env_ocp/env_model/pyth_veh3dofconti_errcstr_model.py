@@ -10,6 +10,7 @@ import torch
 
 from gops_amd import hip_backend as hb
 from gops_amd.env.env_ocp.env_model.pyth_base_model import PythBaseModel
+from gops_amd.env.env_ocp.resources.ref_traj_params import ref_constants
 from gops_amd.env.env_ocp.env_model.pyth_veh3dofconti_surrcstr_model import TRACKING_WEIGHTS
 
 
@@ -19,9 +20,8 @@ class Veh3dofcontiErrCstrModel(PythBaseModel):
     def __init__(self, pre_horizon: int = 10, device: Union[torch.device, str, None] = None,
                  path_para: Optional[Dict[str, Dict]] = None, u_para: Optional[Dict[str, Dict]] = None,
                  y_error_tol: float = 0.2, u_error_tol: float = 2.0, **kwargs):
-        if path_para is not None or u_para is not None:
-            raise RuntimeError("custom path_para/u_para are not supported by the HIP reference-trajectory "
-                               "kernel (it implements the default parameter set)")
+        # custom reference-trajectory parameters travel to the kernels as a table of folded constants (GopsEnv.ref_c)
+        self.ref_c = ref_constants(path_para, u_para) if (path_para is not None or u_para is not None) else None
         self.pre_horizon = pre_horizon
         self.y_error_tol, self.u_error_tol = y_error_tol, u_error_tol
         super().__init__(obs_dim=6 + 4 * pre_horizon, action_dim=2, dt=0.1,

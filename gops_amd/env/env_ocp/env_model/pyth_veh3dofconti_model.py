@@ -10,6 +10,7 @@ import torch
 
 from gops_amd import hip_backend as hb
 from gops_amd.env.env_ocp.env_model.pyth_base_model import PythBaseModel
+from gops_amd.env.env_ocp.resources.ref_traj_params import ref_constants
 
 
 class Veh3dofcontiModel(PythBaseModel):
@@ -18,9 +19,8 @@ class Veh3dofcontiModel(PythBaseModel):
     def __init__(self, pre_horizon: int = 10, device: Union[torch.device, str, None] = None,
                  path_para: Optional[Dict[str, Dict]] = None, u_para: Optional[Dict[str, Dict]] = None,
                  max_steer: float = np.pi / 6, **kwargs):
-        if path_para is not None or u_para is not None:
-            raise RuntimeError("custom path_para/u_para are not supported by the HIP reference-trajectory "
-                               "kernel (it implements the default parameter set)")
+        # custom reference-trajectory parameters travel to the kernels as a table of folded constants (GopsEnv.ref_c)
+        self.ref_c = ref_constants(path_para, u_para) if (path_para is not None or u_para is not None) else None
         self.pre_horizon = pre_horizon
         super().__init__(obs_dim=6 + 4 * pre_horizon, action_dim=2, dt=0.1,
                          action_lower_bound=[-max_steer, -3], action_upper_bound=[max_steer, 3],

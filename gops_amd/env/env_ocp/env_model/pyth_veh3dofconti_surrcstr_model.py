@@ -10,6 +10,7 @@ import torch
 
 from gops_amd import hip_backend as hb
 from gops_amd.env.env_ocp.env_model.pyth_base_model import PythBaseModel
+from gops_amd.env.env_ocp.resources.ref_traj_params import ref_constants
 
 # stage-reward weights of pyth_veh3dofconti (pyth_veh3dofconti_model.py:161-177): dx^2, dy^2, dphi^2, du^2, omega^2, steer^2, a_x^2
 TRACKING_WEIGHTS = (0.04, 0.04, 0.02, 0.02, 0.01, 0.01, 0.01)
@@ -24,9 +25,8 @@ class Veh3dofcontiSurrCstrModel(PythBaseModel):
     def __init__(self, pre_horizon: int = 10, device: Union[torch.device, str, None] = None,
                  path_para: Optional[Dict[str, Dict]] = None, u_para: Optional[Dict[str, Dict]] = None,
                  surr_veh_num: int = 4, veh_length: float = 4.8, veh_width: float = 2.0, **kwargs):
-        if path_para is not None or u_para is not None:
-            raise RuntimeError("custom path_para/u_para are not supported by the HIP reference-trajectory "
-                               "kernel (it implements the default parameter set)")
+        # custom reference-trajectory parameters travel to the kernels as a table of folded constants (GopsEnv.ref_c)
+        self.ref_c = ref_constants(path_para, u_para) if (path_para is not None or u_para is not None) else None
         if not 1 <= surr_veh_num <= hb.MAX_SURR:
             raise RuntimeError(f"surr_veh_num must be 1..{hb.MAX_SURR} for the HIP env models")
         self.pre_horizon, self.surr_veh_num = pre_horizon, surr_veh_num

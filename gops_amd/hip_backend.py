@@ -58,7 +58,8 @@ class GopsEnv(C.Structure):
                 ("veh_length", C.c_float), ("veh_width", C.c_float),
                 ("road_upper", C.c_float), ("road_lower", C.c_float), ("reward_w", C.c_float * 8),
                 ("data_env", C.c_int32), ("scale_obs", C.c_int32), ("obs_scale", C.c_float * 8), ("obs_shift", C.c_float * 8),
-                ("cstr_err", C.c_int32), ("err_tol", C.c_float * 2)]
+                ("cstr_err", C.c_int32), ("err_tol", C.c_float * 2),
+                ("ref_custom", C.c_int32), ("ref_c", C.c_float * 24)]
 
 
 class GopsRolloutDesc(C.Structure):
@@ -216,12 +217,16 @@ def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_ac
              policy_low=None, policy_high=None, obs_low=None, obs_high=None, pre_horizon: int = 0,
              reward_scale: Optional[float] = None, reward_shift: Optional[float] = None,
              lq: Optional[Dict] = None, data_env: bool = False, surr: Optional[Dict] = None,
-             obs_scale=None, obs_shift=None) -> GopsEnv:
+             obs_scale=None, obs_shift=None, ref_c=None) -> GopsEnv:
     """Constants of the wrapped env model (create_env_model.py:86-128) as a C struct.  `data_env=True` (for
     `env_step` only): the DATA environment's termination tests / terminal penalty instead of the model's; obs_low /
     obs_high are then the data env's state bounds (pyth_lq) and are NOT applied as a clip."""
     e = GopsEnv()
     e.data_env = int(bool(data_env))
+    if ref_c is not None:   # custom path_para / u_para of the reference trajectories (resources/ref_traj_params.py)
+        assert len(ref_c) == 24
+        e.ref_custom = 1
+        _fill(e.ref_c, [float(v) for v in ref_c])
     if obs_scale is not None or obs_shift is not None:   # ScaleObservationModel: obs seen = (obs + shift) * scale
         if obs_dim > 8:
             raise RuntimeError("obs_scale / obs_shift: observation dimension > 8 is not supported by the HIP env models")

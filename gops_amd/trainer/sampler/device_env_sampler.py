@@ -39,6 +39,9 @@ class DeviceEnvSampler:
         """cfg: workload dict as in `gops_amd.utils.synthetic.CONFIGS` (env_id, pre_horizon, lq_config);
         env_model: the wrapped model from `create_env_model` (its constants drive the step kernel)."""
         self.cfg, self.env_model = dict(cfg), env_model
+        if getattr(getattr(env_model, "unwrapped", env_model), "ref_c", None) is not None:
+            raise RuntimeError("DeviceEnvSampler draws its reset states from the DEFAULT reference trajectories "
+                               "(gops_amd.utils.synthetic); a model with custom path_para / u_para needs its own reset pool")
         self.n, self.steps, self.max_steps = n_envs, steps_per_sample, max_episode_steps
         self.device = torch.device(device)
         self.seed, self.pool_factor, self.noise_std = seed, pool_factor, noise_std

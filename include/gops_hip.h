@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GOPS_HIP_ABI_VERSION 5
+#define GOPS_HIP_ABI_VERSION 6
 
 #define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
 #define GOPS_MAX_ACT 4      /* action dimensions */
@@ -155,6 +155,18 @@ typedef struct GopsEnv {
      * observation (lateral and speed tracking errors). */
     int32_t cstr_err;
     float err_tol[2];
+    /* Reference-trajectory parameters of the veh3dofconti / veh2dofconti families (MultiRefTrajModel(path_para, u_para),
+     * gops/env/env_ocp/resources/ref_traj_model.py:26-52; defaults ref_traj_data.py:18-37).  ref_custom = 0: the library
+     * uses the default set.  ref_custom = 1: ref_c holds the constants, each folded in double on the host exactly where
+     * the reference folds Python scalars and then rounded to fp32:
+     *   [0] -A/omega  [1] omega  [2] phi  [3] b  [4] A/omega*cos(phi)  [5] A      sine speed profile
+     *   [6] u                                                                   constant speed profile
+     *   [7] A  [8] omega  [9] phi                                                sine path
+     *   [10..13] t1..t4  [14] y1  [15] y2  [16] (y2-y1)/(t2-t1)  [17] (y1-y2)/(t4-t3)   double-lane path
+     *   [18] T  [19] 2A/T  [20] -2A/T  [21] T/2                                  triangle path
+     *   [22] r                                                                  circle path */
+    int32_t ref_custom;
+    float ref_c[24];
 } GopsEnv;
 
 typedef struct GopsRolloutDesc {

@@ -203,6 +203,16 @@ def golden_spil():
         save(name, **out)
 
 
+# MultiRefTrajModel(path_para, u_para): every path and both speed profiles away from their defaults
+REFPARA = dict(path_para={"sine": {"A": 2.0, "omega": 0.5, "phi": 0.3},
+                          "double_lane": {"t1": 4.0, "t2": 8.5, "t3": 13.0, "t4": 17.5, "y1": 0.5, "y2": 3.0},
+                          "triangle": {"A": 2.5, "T": 8.0}, "circle": {"r": 80.0}},
+               u_para={"sine": {"A": 1.5, "omega": 0.7, "phi": 0.2, "b": 6.0}, "constant": {"u": 4.0}})
+REFPARA_STEP_CASES = {"step_veh_p10_refpara": (dict(env_id="pyth_veh3dofconti", pre_horizon=10), REFPARA),
+                      "step_veh2dof_p10_refpara": (dict(env_id="pyth_veh2dofconti", pre_horizon=10), REFPARA)}
+REFPARA_SMALL = {"fhadp_veh_p10_refpara": (dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=48, horizon=10, pre_horizon=10,
+                                                hidden=(64, 64), act="elu", gamma=1.0), REFPARA)}
+
 MPG_CASES = {   # gops/algorithm/mpg.py: one compute_gradient (twin-Q regression + mixed policy gradient) per case
     "mpg_cartpole_mixed_weight": (dict(alg="MPG", env_id="gym_cartpoleconti", batch=64, horizon=10, hidden=(64, 64), act="relu",
                                        gamma=0.99), dict(pge_method="mixed_weight", eta=0.3, terminal_iter=10000), 3000, 0.1),
@@ -684,7 +694,7 @@ def golden_data_envs():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof", "errcstr", "mpg"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof", "errcstr", "mpg", "refpara"]
     if "veh2dof" in which:
         golden_steps(VEH2_STEP_CASES)
         golden_small(VEH2_SMALL)
@@ -694,6 +704,9 @@ if __name__ == "__main__":
         golden_small(GYM_SMALL)
     if "errcstr" in which:
         golden_constrained(ERR_STEP_CASES, ERR_ALG_CASES)
+    if "refpara" in which:
+        golden_steps(REFPARA_STEP_CASES)
+        golden_small(REFPARA_SMALL)
     if "mpg" in which:
         golden_mpg()
     if "spil" in which:

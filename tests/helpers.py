@@ -14,7 +14,8 @@ def oracle_env(cfg, extra, golden=None):
     env = orc.make_env(cfg["env_id"], lq_config=cfg.get("lq_config", "s4a2"),
                        pre_horizon=cfg.get("pre_horizon", 10), surr_veh_num=cfg.get("surr_veh_num"),
                        reward_scale=extra.get("reward_scale"), reward_shift=extra.get("reward_shift"),
-                       obs_scale=extra.get("obs_scale"), obs_shift=extra.get("obs_shift"))
+                       obs_scale=extra.get("obs_scale"), obs_shift=extra.get("obs_shift"),
+                       path_para=extra.get("path_para"), u_para=extra.get("u_para"))
     if golden is not None and "const/lq_inv_IA" in golden:
         env["lq"]["inv_IA"] = torch.from_numpy(np.array(golden["const/lq_inv_IA"]))
     return env
@@ -89,6 +90,7 @@ def reference_init_nets(cfg, seed, obs_dim, act_dim):
 # ---- HIP side: build C-ABI descriptors from the same (oracle-side) constants -------------------
 def hip_env_from_oracle(env, policy_net=None):
     from gops_amd import hip_backend as hb
+    from gops_amd.env.env_ocp.resources.ref_traj_params import ref_constants
     kind = {"veh_err": hb.ENV_VEH_SURR, "lq": hb.ENV_LQ, "idp": hb.ENV_IDP, "veh": hb.ENV_VEH, "veh_surr": hb.ENV_VEH_SURR,
             "cartpole": hb.ENV_CARTPOLE, "pendulum": hb.ENV_PENDULUM, "veh2": hb.ENV_VEH2DOF}[env["kind"]]
     surr = None
@@ -109,7 +111,8 @@ def hip_env_from_oracle(env, policy_net=None):
                        reward_scale=env["reward_scale"] if env["shaping"] else None,
                        reward_shift=env["reward_shift"] if env["shaping"] else None, lq=lq, surr=surr,
                        obs_scale=env["obs_scale"] if env.get("scale_obs") else None,
-                       obs_shift=env["obs_shift"] if env.get("scale_obs") else None)
+                       obs_shift=env["obs_shift"] if env.get("scale_obs") else None,
+                       ref_c=ref_constants(env.get("path_para"), env.get("u_para")) if "ref_params" in env else None)
 
 
 def hip_mlp_from_net(net, device):

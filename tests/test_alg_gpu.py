@@ -53,7 +53,7 @@ def _load_alg(name):
 
 @pytest.mark.parametrize("name", ["fhadp_idp_gelu", "fhadp_veh_p10_elu", "fhadp_lq_s4a2_tanh",
                                   "fhadp_idp_selu_shaped", "fhadp_surrpen_p10_elu", "fhadp_lq_s3a1_obsscale",
-                                  "fhadp_idp_obsscale_shift", "fhadp_veh2dof_p10_elu"])
+                                  "fhadp_idp_obsscale_shift", "fhadp_veh2dof_p10_elu", "fhadp_veh_p10_refpara"])
 def test_fhadp_class_matches_reference(name):
     alg, g, cfg = _load_alg(name)
     alg.gamma = cfg["gamma"]

@@ -15,7 +15,8 @@ STEP_CASES = ["step_lq_s4a2", "step_lq_s6a3", "step_lq_s2a1_shaped", "step_idp",
               "step_lq_s3a1_obsscale", "step_lq_s5a1_obsscale_shift", "step_idp_obsscale_shift",
               # gym-style models (INFADP / MAC example scripts)
               "step_cartpole", "step_cartpole_obsscale", "step_pendulum",
-              "step_veh2dof_p10"]
+              "step_veh2dof_p10",
+              "step_veh_p10_refpara", "step_veh2dof_p10_refpara"]   # custom path_para / u_para
 FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fhadp_idp_selu_shaped",
                "fhadp_veh_p10_elu", "fhadp_veh_p30_sigmoid",
                # plain FHADP on the collision-penalty model (pyth_veh3dofconti_surrcstr_penalty)
@@ -23,6 +24,7 @@ FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fh
                # ScaleObservationModel in the chain
                "fhadp_lq_s3a1_obsscale", "fhadp_idp_obsscale_shift",
                "fhadp_veh2dof_p10_elu",   # pyth_veh2dofconti
+               "fhadp_veh_p10_refpara",   # custom path_para / u_para
                # the reference's shipped trained checkpoints (saturating policies, H = 80, limits != +-1)
                "fhadp_trained_idp_h80", "fhadp_trained_lqs3a1_h80"]
 INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift",

@@ -692,3 +692,28 @@ def test_mpg_graph_replay_equals_eager(pge, monkeypatch):
         for k in a:
             if not k.startswith("Time/"):
                 assert a[k] == b[k], k
+
+
+def test_mpg_gradient_is_the_mean_over_batch_shards():
+    """Size-independent property at a BASELINE-sized batch (B = 4096, H = 30, 256-wide networks): with fixed mixing
+    weights every MPG gradient is a batch mean, so the gradient of the whole batch equals the average of the gradients
+    of its two halves (what the data-parallel trainer relies on)."""
+    cfg = dict(alg="MPG", env_id="pyth_lq", lq_config="s4a2", batch=4096, horizon=30, hidden=(256, 256), act="elu", gamma=0.99)
+    extra = dict(pge_method="mixed_weight", eta=0.2, terminal_iter=100, forward_step=30, tau=0.1)
+    torch.manual_seed(2)
+    alg = create_alg(**_kwargs(cfg, extra, 2))
+    alg.networks.to("cuda")
+    gen = torch.Generator().manual_seed(5)
+    obs = make_batch(cfg, 9)["obs"]
+    B, A = cfg["batch"], act_dim_of(cfg)
+    data = dict(obs=obs, act=torch.rand(B, A, generator=gen) * 2 - 1, rew=torch.randn(B, generator=gen),
+                obs2=obs + 0.05 * torch.randn(obs.shape, generator=gen), done=(torch.rand(B, generator=gen) < 0.1).float())
+
+    def grads(sl):
+        _, info = alg.get_remote_update_info({k: v[sl] for k, v in data.items()}, 40)
+        return {k: [g.clone() for g in v] for k, v in info.items() if k.endswith("_grad")}
+
+    whole, lo, hi = grads(slice(0, B)), grads(slice(0, B // 2)), grads(slice(B // 2, B))
+    for k in whole:
+        for i, g in enumerate(whole[k]):
+            assert rel_l2(0.5 * (lo[k][i] + hi[k][i]).cpu(), g.cpu()) < 1e-4, (k, i, rel_l2(0.5 * (lo[k][i] + hi[k][i]).cpu(), g.cpu()))

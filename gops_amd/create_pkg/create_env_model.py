@@ -30,8 +30,10 @@ class WrappedEnvModel:
     constants for the fused horizon rollout."""
 
     def __init__(self, model, *, min_action, max_action, clip_obs: bool,
-                 reward_scale: Optional[float], reward_shift: Optional[float], obs_scale=None, obs_shift=None):
+                 reward_scale: Optional[float], reward_shift: Optional[float], obs_scale=None, obs_shift=None,
+                 repeat_num: Optional[int] = None, sum_reward: bool = True):
         self.model = model
+        self.repeat_num, self.sum_reward = repeat_num, sum_reward   # ActionRepeatModel constants (None: no such wrapper)
         self.obs_scale, self.obs_shift = obs_scale, obs_shift   # ScaleObservationModel constants (None: no such wrapper)
         self.min_action = torch.zeros_like(model.action_lower_bound) + torch.as_tensor(
             min_action, dtype=torch.float32, device=model.action_lower_bound.device)
@@ -66,7 +68,7 @@ class WrappedEnvModel:
                 obs_high=m.obs_upper_bound.cpu() if (self.clip_obs or data_env) else None,
                 pre_horizon=getattr(m, "pre_horizon", 0), reward_scale=self.reward_scale,
                 reward_shift=self.reward_shift, data_env=data_env, obs_scale=self.obs_scale, obs_shift=self.obs_shift,
-                ref_c=getattr(m, "ref_c", None), **m.hip_constants())
+                ref_c=getattr(m, "ref_c", None), repeat_num=self.repeat_num, sum_reward=self.sum_reward, **m.hip_constants())
         return self._env_cache[key]
 
     def forward(self, obs: torch.Tensor, action: torch.Tensor, done: torch.Tensor, info: Dict
@@ -105,8 +107,12 @@ def create_env_model(
     env_model = registry.build(env_id + "_model", **kwargs, device="cuda" if kwargs.get("use_gpu", False) else "cpu")
 
     # wrapper options outside the fused kernels' contract are refused, never silently ignored
-    if repeat_num is not None:
-        raise RuntimeError("ActionRepeatModel (repeat_num) is not supported by the HIP env models")
+    if repeat_num is not None:   # ActionRepeatModel: in the kernels of the models whose observation is the state
+        if env_model.hip_kind not in (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_CARTPOLE, hb.ENV_PENDULUM):
+            raise RuntimeError("ActionRepeatModel (repeat_num) is supported for pyth_lq / pyth_idpendulum / gym_* models only "
+                               "by the HIP env models (the reference wrapper does not advance `info`)")
+        if not 1 <= int(repeat_num) <= hb.MAX_REPEAT:
+            raise RuntimeError(f"repeat_num must be 1..{hb.MAX_REPEAT} for the HIP env models")
     scaled = obs_shift is not None or obs_scale is not None
     if scaled and (env_model.obs_dim > 8 or env_model.hip_kind not in (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_CARTPOLE, hb.ENV_PENDULUM)):
         raise RuntimeError("ScaleObservationModel (obs_shift/obs_scale) is supported for pyth_lq / pyth_idpendulum / gym_* models only "
@@ -128,7 +134,8 @@ def create_env_model(
         reward_shift=(0.0 if reward_shift is None else reward_shift) if shaping else None,
         # create_env_model.py:115-118: either one given -> the wrapper is applied with the other at its neutral value
         obs_scale=(1.0 if obs_scale is None else obs_scale) if scaled else None,
-        obs_shift=(0.0 if obs_shift is None else obs_shift) if scaled else None)
+        obs_shift=(0.0 if obs_shift is None else obs_shift) if scaled else None,
+        repeat_num=None if repeat_num is None else int(repeat_num), sum_reward=bool(sum_reward))
 
 
 # fill the registry: every env/env_*/env_model/<id>.py exporting env_model_creator or the CamelCase class

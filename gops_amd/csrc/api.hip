@@ -210,6 +210,10 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
          desc.open_loop || desc.dtype != GOPS_DTYPE_F32))
         return GOPS_ERR_BAD_ARG;
     if (e.clip_obs && e.obs_dim > 8) return GOPS_ERR_UNSUPPORTED;
+    if (e.repeat_num < 0 || e.repeat_num > GOPS_MAX_REPEAT) return GOPS_ERR_BAD_ARG;
+    if (e.repeat_num > 1 && (f16 || (e.kind != GOPS_ENV_LQ && e.kind != GOPS_ENV_IDPENDULUM && e.kind != GOPS_ENV_CARTPOLE &&
+                                     e.kind != GOPS_ENV_PENDULUM)))
+        return GOPS_ERR_UNSUPPORTED;   // ActionRepeatModel: obs == state models, fp32
 
     p.B = desc.batch;
     p.H = desc.horizon;
@@ -367,6 +371,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
         for (int j = 0; j < p.pol.nl - (ext_delta != nullptr ? 1 : 0); ++j)
             if (grad.weight[j] == nullptr || grad.bias[j] == nullptr) return GOPS_ERR_BAD_ARG;
     hipError_t e;
+    if (desc.env.repeat_num > 1) p.ext = 1;   // ActionRepeatModel: the general (EXT) instantiations of the sweep
     if (adj != nullptr) {   // gops_rollout_backward_adj / gops_mlp_backward_x: the EXT kernels
         const int k = desc.env.kind;
         if (p.open_loop || p.tail || p.f16) return GOPS_ERR_UNSUPPORTED;
@@ -636,6 +641,10 @@ int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void*
          !io->next_state || !io->next_ref_points || !io->next_ref_time)) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_LQ && env->obs_dim > GOPS_MAX_LQ_STATE) return GOPS_ERR_UNSUPPORTED;
     if (env->scale_obs && env->kind != GOPS_ENV_LQ && env->kind != GOPS_ENV_IDPENDULUM && env->kind < GOPS_ENV_CARTPOLE) return GOPS_ERR_UNSUPPORTED;
+    if (env->repeat_num < 0 || env->repeat_num > GOPS_MAX_REPEAT) return GOPS_ERR_BAD_ARG;
+    if (env->repeat_num > 1 && (env->data_env || (env->kind != GOPS_ENV_LQ && env->kind != GOPS_ENV_IDPENDULUM &&
+                                                  env->kind != GOPS_ENV_CARTPOLE && env->kind != GOPS_ENV_PENDULUM)))
+        return GOPS_ERR_UNSUPPORTED;
     GopsEnv e = *env;
     fill_ref_defaults(e);
     return (int)launch_env_step(e, batch, *io, pdt_of(e), static_cast<hipStream_t>(stream));

@@ -1046,6 +1046,8 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
     float u[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
     for (int a = 0; a < A; ++a) u[a] = wrap_action(env, a, io.action[(size_t)b * A + a]);
     const bool dn = !data && io.done != nullptr && io.done[b] != 0.f;
+    const int nrep = (env.repeat_num > 1 && !data) ? env.repeat_num : 1;
+    const bool last_only = nrep > 1 && env.repeat_last_reward != 0;
     float r = 0.f;
     bool done_m = false;
     const float* ob = io.obs + (size_t)b * O;
@@ -1053,7 +1055,14 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
     if (env.kind == GOPS_ENV_LQ) {
         float x[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xn[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < O; ++i) x[i] = obs_unscale(env, i, ob[i]);
-        lq_forward(env, x, u, xn, r);
+        float rs = 0.f;
+        for (int rep = 0; rep < nrep; ++rep) {   // ActionRepeatModel: sub-steps with the initial done flag (nrep = 1 otherwise)
+            if (rep > 0 && !dn)
+                for (int i = 0; i < O; ++i) x[i] = xn[i];
+            lq_forward(env, x, u, xn, r);
+            rs = last_only ? r : rs + r;
+        }
+        r = rs;
         for (int i = 0; i < O; ++i) {
             const float v = obs_rescale(env, i, dn ? x[i] : xn[i]);
             nob[i] = (env.clip_obs && !data) ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
@@ -1065,12 +1074,19 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         const int NS = env.kind == GOPS_ENV_CARTPOLE ? 4 : 3;
         float x[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < NS; ++i) x[i] = obs_unscale(env, i, ob[i]);
-        if (env.kind == GOPS_ENV_CARTPOLE) {
-            cart_forward(cart_const(), x, u[0], xn, r, done_m);
-        } else {
-            PendStep w;
-            pend_forward(x, u[0], xn, r, w);
+        float rs = 0.f;
+        for (int rep = 0; rep < nrep; ++rep) {
+            if (rep > 0 && !dn)
+                for (int i = 0; i < NS; ++i) x[i] = xn[i];
+            if (env.kind == GOPS_ENV_CARTPOLE) {
+                cart_forward(cart_const(), x, u[0], xn, r, done_m);
+            } else {
+                PendStep w;
+                pend_forward(x, u[0], xn, r, w);
+            }
+            rs = last_only ? r : rs + r;
         }
+        r = rs;
         for (int i = 0; i < NS; ++i) {
             const float v = obs_rescale(env, i, dn ? x[i] : xn[i]);
             nob[i] = env.clip_obs ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
@@ -1079,15 +1095,20 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         const IdpConst IC = idp_const();
         float s[6], sn[6], s0[6];
         for (int i = 0; i < 6; ++i) s0[i] = s[i] = obs_unscale(env, i, ob[i]);
-        IdpSub w;
-        for (int k = 0; k < 5; ++k) {   // same arithmetic as the rollout kernels (one sincosf pair, then rotations)
-            if (k == 0) idp_substep<true>(IC, s, 500.f * u[0], 0.002f, sn, w);
-            else idp_substep<false>(IC, s, 500.f * u[0], 0.002f, sn, w);
-            idp_advance_trig(s, 0.002f, w, w);
-            for (int i = 0; i < 6; ++i) s[i] = sn[i];
+        float rs = 0.f;
+        for (int rep = 0; rep < nrep; ++rep) {
+            IdpSub w;
+            for (int k = 0; k < 5; ++k) {   // same arithmetic as the rollout kernels (one sincosf pair, then rotations)
+                if (k == 0) idp_substep<true>(IC, s, 500.f * u[0], 0.002f, sn, w);
+                else idp_substep<false>(IC, s, 500.f * u[0], 0.002f, sn, w);
+                idp_advance_trig(s, 0.002f, w, w);
+                for (int i = 0; i < 6; ++i) s[i] = sn[i];
+            }
+            r = idp_reward(s, u[0]);
+            rs = last_only ? r : rs + r;
+            done_m = idp_done(IC, s);
         }
-        r = idp_reward(s, u[0]);
-        done_m = idp_done(IC, s);
+        r = rs;
         for (int i = 0; i < 6; ++i) nob[i] = (dn && !env.scale_obs) ? ob[i] : obs_rescale(env, i, dn ? s0[i] : s[i]);
     } else if (env.kind == GOPS_ENV_VEH2DOF) {
         const Veh2Const C2 = veh2_const();

@@ -366,7 +366,146 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 float Gin[GOPS_MAX_LQ_STATE], gx[GOPS_MAX_LQ_STATE];
 #pragma unroll
                 for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { Gin[i] = (i < O) ? G[m * ldx + i] : 0.f; gx[i] = 0.f; }
-                if (ENV == GOPS_ENV_CARTPOLE || ENV == GOPS_ENV_PENDULUM) {
+                bool repeated = false;
+                if constexpr (EXT) {
+                    if (p.env.repeat_num > 1) {
+                        // ActionRepeatModel: x^(k+1) = step(x^(k), u), k < n, with the initial done flag; the sub-step
+                        // states are recomputed from the stashed observation, then the sub-steps are walked backwards
+                        // (every sub-step's reward carries g_r, or only the last one's)
+                        repeated = true;
+                        const int nrep = min(p.env.repeat_num, GOPS_MAX_REPEAT);
+                        auto fwd1 = [&](const float* xi, float* xo) {
+                            float rd = 0.f;
+                            if constexpr (ENV == GOPS_ENV_LQ) {
+                                lq_forward(p.env, xi, u, xo, rd);
+                            } else if constexpr (ENV == GOPS_ENV_CARTPOLE) {
+                                bool dd;
+                                cart_forward(cart_const(), xi, u[0], xo, rd, dd);
+                            } else if constexpr (ENV == GOPS_ENV_PENDULUM) {
+                                PendStep w;
+                                pend_forward(xi, u[0], xo, rd, w);
+                            } else {
+                                float s5[6];
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) s5[i] = xi[i];
+                                IdpSub w;
+                                idp_substep<true>(IC, s5, 500.f * u[0], 0.002f, xo, w);
+#pragma unroll 1
+                                for (int k = 1; k < 5; ++k) {
+                                    idp_advance_trig(s5, 0.002f, w, w);
+#pragma unroll
+                                    for (int i = 0; i < 6; ++i) s5[i] = xo[i];
+                                    idp_substep<false>(IC, s5, 500.f * u[0], 0.002f, xo, w);
+                                }
+                            }
+                        };
+                        auto bwd1 = [&](const float* xi, const float* gn, float gr, float* gxo, float* guo) {
+#pragma unroll
+                            for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) gxo[i] = 0.f;
+                            if constexpr (ENV == GOPS_ENV_LQ) {
+                                lq_backward(p.env, xi, u, gn, gr, gxo, guo);
+                            } else if constexpr (ENV == GOPS_ENV_CARTPOLE) {
+                                cart_backward(cart_const(), xi, u[0], gn, gxo, guo[0]);
+                            } else if constexpr (ENV == GOPS_ENV_PENDULUM) {
+                                pend_backward(xi, u[0], gn, gr, gxo, guo[0]);
+                            } else {
+                                float* park = s_idp + m * (5 * 24);
+                                float sc_[6], sn_[6];
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) sc_[i] = xi[i];
+                                const float a = u[0], force = 500.f * a;
+                                IdpSub w;
+#pragma unroll 1
+                                for (int k = 0; k < 5; ++k) {
+                                    if (k == 0) idp_substep<true>(IC, sc_, force, 0.002f, sn_, w);
+                                    else idp_substep<false>(IC, sc_, force, 0.002f, sn_, w);
+                                    float* pk = park + k * 24;
+#pragma unroll
+                                    for (int i = 0; i < 6; ++i) pk[i] = sc_[i];
+                                    pk[6] = w.s1; pk[7] = w.c1; pk[8] = w.s2; pk[9] = w.c2; pk[10] = w.s12; pk[11] = w.c12;
+#pragma unroll
+                                    for (int i = 0; i < 6; ++i) pk[12 + i] = w.inv[i];
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) pk[18 + i] = w.qdd[i];
+                                    idp_advance_trig(sc_, 0.002f, w, w);
+#pragma unroll
+                                    for (int i = 0; i < 6; ++i) sc_[i] = sn_[i];
+                                }
+                                float g[6];
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) g[i] = gn[i];
+                                g[1] += gr * (-10.f * sc_[1]);
+                                g[2] += gr * (-20.f * sc_[2]);
+                                g[3] += gr * (-1.f * sc_[3]);
+                                g[4] += gr * (-1.f * sc_[4]);
+                                g[5] += gr * (-2.f * sc_[5]);
+                                float gforce = 0.f;
+#pragma unroll 1
+                                for (int k = 4; k >= 0; --k) {
+                                    const float* pk = park + k * 24;
+                                    IdpSub wk;
+                                    float sk[6];
+#pragma unroll
+                                    for (int i = 0; i < 6; ++i) sk[i] = pk[i];
+                                    wk.s1 = pk[6]; wk.c1 = pk[7]; wk.s2 = pk[8]; wk.c2 = pk[9]; wk.s12 = pk[10]; wk.c12 = pk[11];
+#pragma unroll
+                                    for (int i = 0; i < 6; ++i) wk.inv[i] = pk[12 + i];
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) wk.qdd[i] = pk[18 + i];
+                                    idp_substep_bwd(IC, sk, 0.002f, wk, g, gforce);
+                                }
+                                guo[0] = 500.f * gforce + gr * (-2.f * a);
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) gxo[i] = g[i];
+                            }
+                        };
+                        float xk[GOPS_MAX_REPEAT][GOPS_MAX_LQ_STATE], xfin[GOPS_MAX_LQ_STATE];
+#pragma unroll
+                        for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { xk[0][i] = x[i]; xfin[i] = x[i]; }
+#pragma unroll
+                        for (int rep = 1; rep < GOPS_MAX_REPEAT; ++rep) {
+#pragma unroll
+                            for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) xk[rep][i] = 0.f;
+                            if (rep < nrep && !dn) fwd1(xk[rep - 1], xk[rep]);
+                        }
+                        if (p.env.clip_obs && ENV != GOPS_ENV_IDPENDULUM) {   // ClipObservation saw the last sub-step's (rescaled) result
+                            if (!dn) {
+#pragma unroll
+                                for (int rep = 0; rep < GOPS_MAX_REPEAT; ++rep)
+                                    if (rep == nrep - 1) fwd1(xk[rep], xfin);
+                            }
+#pragma unroll
+                            for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) {
+                                const float pre = obs_rescale(p.env, i, xfin[i]);
+                                if (i < O && !(pre >= p.env.obs_low[i] && pre <= p.env.obs_high[i])) Gin[i] = 0.f;
+                            }
+                        }
+                        if (p.env.scale_obs) {
+#pragma unroll
+                            for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                                if (i < O) Gin[i] *= p.env.obs_scale[i];
+                        }
+                        float g[GOPS_MAX_LQ_STATE];
+#pragma unroll
+                        for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) g[i] = dn ? 0.f : Gin[i];
+#pragma unroll
+                        for (int rep = GOPS_MAX_REPEAT - 1; rep >= 0; --rep) {
+                            if (rep < nrep && !dn) {
+                                const float gr = (!p.env.repeat_last_reward || rep == nrep - 1) ? g_rm : 0.f;
+                                float gxo[GOPS_MAX_LQ_STATE], guo[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
+                                bwd1(xk[rep], g, gr, gxo, guo);
+#pragma unroll
+                                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) g[i] = gxo[i];
+#pragma unroll
+                                for (int a = 0; a < GOPS_MAX_ACT; ++a) gu[a] += guo[a];
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) gx[i] = dn ? Gin[i] : g[i];
+                    }
+                }
+                if (repeated) {
+                } else if (ENV == GOPS_ENV_CARTPOLE || ENV == GOPS_ENV_PENDULUM) {
                     constexpr int NS = (ENV == GOPS_ENV_CARTPOLE) ? 4 : 3;
                     if (p.env.clip_obs) {   // ClipObservation on the (rescaled) next observation
                         float xn[4] = {0.f, 0.f, 0.f, 0.f}, rdummy;
@@ -793,14 +932,22 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
     size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H
                                                        : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0), p.f16 != 0);
-    if (p.ext) {   // adjoint I/O: streamed fp32 kernels of the obs == state kinds
-        if (p.f16 || p.tail) return hipErrorInvalidValue;
+    if (p.ext) {   // adjoint I/O / ActionRepeat: streamed fp32 kernels of the obs == state kinds
+        if (p.f16) return hipErrorInvalidValue;
+#define LAUNCH_BWD_EXT(ENV)                                                                                             \
+    do {                                                                                                                \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, false, true>, grid, block, lds, stream, dp);  \
+        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp);        \
+    } while (0)
         switch (p.env.kind) {
-            case GOPS_ENV_NONE: launch_with_lds(rollout_bwd_kernel<GOPS_ENV_NONE, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp); break;
-            case GOPS_ENV_LQ: launch_with_lds(rollout_bwd_kernel<GOPS_ENV_LQ, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp); break;
-            case GOPS_ENV_IDPENDULUM: launch_with_lds(rollout_bwd_kernel<GOPS_ENV_IDPENDULUM, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp); break;
-            case GOPS_ENV_CARTPOLE: launch_with_lds(rollout_bwd_kernel<GOPS_ENV_CARTPOLE, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp); break;
-            case GOPS_ENV_PENDULUM: launch_with_lds(rollout_bwd_kernel<GOPS_ENV_PENDULUM, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp); break;
+            case GOPS_ENV_NONE:
+                if (p.tail) return hipErrorInvalidValue;
+                launch_with_lds(rollout_bwd_kernel<GOPS_ENV_NONE, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp);
+                break;
+            case GOPS_ENV_LQ: LAUNCH_BWD_EXT(GOPS_ENV_LQ); break;
+            case GOPS_ENV_IDPENDULUM: LAUNCH_BWD_EXT(GOPS_ENV_IDPENDULUM); break;
+            case GOPS_ENV_CARTPOLE: LAUNCH_BWD_EXT(GOPS_ENV_CARTPOLE); break;
+            case GOPS_ENV_PENDULUM: LAUNCH_BWD_EXT(GOPS_ENV_PENDULUM); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

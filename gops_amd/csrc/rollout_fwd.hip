@@ -141,7 +141,9 @@ __device__ __forceinline__ void mlp_head(WP Wo, int ldw, BP bo, int K, int A, co
 // F16: GOPS_DTYPE_F16 - the hidden layers run on v_mfma_f32_16x16x32_f16 (rollout_f16.h) and the
 // activation stash is half precision; everything else in the step is the same fp32 code.
 // (F16 kernels: 4 workgroups per CU - launch bound 4 waves / SIMD, <= 128 registers.)
-template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false>
+// GEN (streamed fp32 kernels of the obs == state env kinds): ActionRepeatModel - the env blocks loop over
+// GopsEnv.repeat_num sub-steps; with GEN = false the loops have the compile-time trip count 1
+template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false, bool GEN = false>
 __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1)) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;   // parameters live in device memory: uniform scalar loads
@@ -312,9 +314,19 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { x[i] = (i < O) ? obs_unscale(p.env, i, xs[m * ldx + i]) : 0.f; xn[i] = 0.f; }
 #pragma unroll
                 for (int j = 0; j < GOPS_MAX_ACT; ++j) u[j] = (j < A) ? s_act[m * 4 + j] : 0.f;
-                lq_forward(p.env, x, u, xn, r);
                 // MaskAtDone freezes the (unscaled) observation; ScaleObservation rescales, ClipObservation clips the result
                 const bool frozen = s_done[m] != 0.f;
+                const int nrep = GEN ? p.env.repeat_num : 1;   // ActionRepeat: sub-steps with the initial done flag
+                float rs = 0.f;
+                for (int rep = 0; rep < nrep; ++rep) {
+                    if (rep > 0 && !frozen) {
+#pragma unroll
+                        for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) x[i] = xn[i];
+                    }
+                    lq_forward(p.env, x, u, xn, r);
+                    rs = (GEN && !p.env.repeat_last_reward) ? rs + r : r;
+                }
+                r = rs;
                 if (!frozen || p.env.clip_obs || p.env.scale_obs) {
 #pragma unroll
                     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
@@ -332,13 +344,23 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
 #pragma unroll
                 for (int i = 0; i < NS; ++i) x[i] = obs_unscale(p.env, i, xs[m * ldx + i]);
                 const float a = s_act[m * 4];
-                if (ENV == GOPS_ENV_CARTPOLE) {
-                    cart_forward(cart_const(), x, a, xn, r, done_m);
-                } else {
-                    PendStep w;
-                    pend_forward(x, a, xn, r, w);
-                }
                 const bool frozen = s_done[m] != 0.f;
+                const int nrep = GEN ? p.env.repeat_num : 1;
+                float rs = 0.f;
+                for (int rep = 0; rep < nrep; ++rep) {
+                    if (rep > 0 && !frozen) {
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) x[i] = xn[i];
+                    }
+                    if (ENV == GOPS_ENV_CARTPOLE) {
+                        cart_forward(cart_const(), x, a, xn, r, done_m);
+                    } else {
+                        PendStep w;
+                        pend_forward(x, a, xn, r, w);
+                    }
+                    rs = (GEN && !p.env.repeat_last_reward) ? rs + r : r;
+                }
+                r = rs;
                 if (!frozen || p.env.clip_obs || p.env.scale_obs) {
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
@@ -358,19 +380,25 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 for (int i = 0; i < 6; ++i) s_in[i] = s[i];
                 const float a = s_act[m * 4];
                 const float u = 500.f * a;
-                IdpSub w;
-                idp_substep<true>(IC, s, u, 0.002f, sn, w);
+                const int nrep = GEN ? p.env.repeat_num : 1;   // (finished rows advance too: nothing of them is written)
+                float rs = 0.f;
+                for (int rep = 0; rep < nrep; ++rep) {
+                    IdpSub w;
+                    idp_substep<true>(IC, s, u, 0.002f, sn, w);
 #pragma unroll 1
-                for (int k = 1; k < 5; ++k) {
-                    idp_advance_trig(s, 0.002f, w, w);   // sin / cos of the new angles from the old ones (rotation by tau * theta_dot)
+                    for (int k = 1; k < 5; ++k) {
+                        idp_advance_trig(s, 0.002f, w, w);   // sin / cos of the new angles from the old ones (rotation by tau * theta_dot)
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) s[i] = sn[i];
+                        idp_substep<false>(IC, s, u, 0.002f, sn, w);
+                    }
 #pragma unroll
                     for (int i = 0; i < 6; ++i) s[i] = sn[i];
-                    idp_substep<false>(IC, s, u, 0.002f, sn, w);
+                    r = idp_reward(s, a);
+                    rs = (GEN && !p.env.repeat_last_reward) ? rs + r : r;
+                    done_m = idp_done(IC, s);
                 }
-#pragma unroll
-                for (int i = 0; i < 6; ++i) s[i] = sn[i];
-                r = idp_reward(s, a);
-                done_m = idp_done(IC, s);
+                r = rs;
                 if (s_done[m] == 0.f) {
 #pragma unroll
                     for (int i = 0; i < 6; ++i) xs[m * ldx + i] = obs_rescale(p.env, i, s[i]);
@@ -620,6 +648,7 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
     sk[0] = sk[1] = 0;
     const MlpDev& M = p.pol;
     if (p.f16) return;   // the half-precision path streams its (half as large) weights from L2
+    if (p.env.repeat_num > 1 || p.ext) return;   // GEN / EXT instantiations exist for the streamed kernels only
     if (p.env.kind >= GOPS_ENV_VEH3DOF_SURR) return;   // constrained / gym-style models: streamed kernels only
     // Register-stationary weights pin one workgroup per CU.  That is the right trade only while there
     // is at most one tile per CU (B <= 16 * #CUs = 4096 on MI355X); with more tiles the streamed
@@ -681,6 +710,21 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
             case GOPS_ENV_LQ: LAUNCH_FWD_H(GOPS_ENV_LQ); break;
             case GOPS_ENV_IDPENDULUM: LAUNCH_FWD_H(GOPS_ENV_IDPENDULUM); break;
             case GOPS_ENV_VEH3DOFCONTI: LAUNCH_FWD_H(GOPS_ENV_VEH3DOFCONTI); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    if (p.env.repeat_num > 1) {   // ActionRepeatModel: the GEN instantiations (streamed)
+#define LAUNCH_FWD_GEN(ENV)                                                                                        \
+    do {                                                                                                           \
+        if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, true, false, true>, grid, block, lds, stream, dp);  \
+        else launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, false, false, true>, grid, block, lds, stream, dp);        \
+    } while (0)
+        switch (p.env.kind) {
+            case GOPS_ENV_LQ: LAUNCH_FWD_GEN(GOPS_ENV_LQ); break;
+            case GOPS_ENV_IDPENDULUM: LAUNCH_FWD_GEN(GOPS_ENV_IDPENDULUM); break;
+            case GOPS_ENV_CARTPOLE: LAUNCH_FWD_GEN(GOPS_ENV_CARTPOLE); break;
+            case GOPS_ENV_PENDULUM: LAUNCH_FWD_GEN(GOPS_ENV_PENDULUM); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

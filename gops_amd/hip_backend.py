@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("GOPS_HIP_LIB") or os.path.join(_HERE, "libgops_hip.so
 MAX_LAYERS, MAX_ACT, MAX_LQ, TILE = 5, 4, 6, 16
 ENV_NONE, ENV_LQ, ENV_IDP, ENV_VEH, ENV_VEH_SURR, ENV_CARTPOLE, ENV_PENDULUM, ENV_VEH2DOF = 0, 1, 2, 3, 4, 5, 6, 7
 MAX_SURR = 4
+MAX_REPEAT = 8   # GOPS_MAX_REPEAT
 ACT_IDS = {"linear": 0, "relu": 1, "elu": 2, "gelu": 3, "selu": 4, "sigmoid": 5, "tanh": 6}
 DTYPE_IDS = {"fp32": 0, "f32": 0, "float32": 0, "fp16": 1, "f16": 1, "float16": 1, "half": 1}
 
@@ -59,7 +60,8 @@ class GopsEnv(C.Structure):
                 ("road_upper", C.c_float), ("road_lower", C.c_float), ("reward_w", C.c_float * 8),
                 ("data_env", C.c_int32), ("scale_obs", C.c_int32), ("obs_scale", C.c_float * 8), ("obs_shift", C.c_float * 8),
                 ("cstr_err", C.c_int32), ("err_tol", C.c_float * 2),
-                ("ref_custom", C.c_int32), ("ref_c", C.c_float * 24)]
+                ("ref_custom", C.c_int32), ("ref_c", C.c_float * 24),
+                ("repeat_num", C.c_int32), ("repeat_last_reward", C.c_int32)]
 
 
 class GopsRolloutDesc(C.Structure):
@@ -217,12 +219,14 @@ def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_ac
              policy_low=None, policy_high=None, obs_low=None, obs_high=None, pre_horizon: int = 0,
              reward_scale: Optional[float] = None, reward_shift: Optional[float] = None,
              lq: Optional[Dict] = None, data_env: bool = False, surr: Optional[Dict] = None,
-             obs_scale=None, obs_shift=None, ref_c=None) -> GopsEnv:
+             obs_scale=None, obs_shift=None, ref_c=None, repeat_num: Optional[int] = None, sum_reward: bool = True) -> GopsEnv:
     """Constants of the wrapped env model (create_env_model.py:86-128) as a C struct.  `data_env=True` (for
     `env_step` only): the DATA environment's termination tests / terminal penalty instead of the model's; obs_low /
     obs_high are then the data env's state bounds (pyth_lq) and are NOT applied as a clip."""
     e = GopsEnv()
     e.data_env = int(bool(data_env))
+    if repeat_num is not None:   # ActionRepeatModel (repeat_num = 1 is the identity wrapper)
+        e.repeat_num, e.repeat_last_reward = int(repeat_num), int(not sum_reward)
     if ref_c is not None:   # custom path_para / u_para of the reference trajectories (resources/ref_traj_params.py)
         assert len(ref_c) == 24
         e.ref_custom = 1

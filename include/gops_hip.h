@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GOPS_HIP_ABI_VERSION 6
+#define GOPS_HIP_ABI_VERSION 7
 
 #define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
 #define GOPS_MAX_ACT 4      /* action dimensions */
@@ -65,6 +65,7 @@ enum { GOPS_ENV_NONE = 0, GOPS_ENV_LQ = 1, GOPS_ENV_IDPENDULUM = 2, GOPS_ENV_VEH
        GOPS_ENV_VEH2DOF = 7 };
 #define GOPS_MAX_SURR 4        /* surrounding vehicles */
 #define GOPS_MAX_CONSTRAINT 3  /* constraint outputs per step */
+#define GOPS_MAX_REPEAT 8      /* ActionRepeatModel: sub-steps per env step */
 
 /* hidden activations: gops/utils/common_utils.py:26-55 */
 enum { GOPS_ACT_LINEAR = 0, GOPS_ACT_RELU = 1, GOPS_ACT_ELU = 2, GOPS_ACT_GELU = 3,
@@ -167,6 +168,13 @@ typedef struct GopsEnv {
      *   [22] r                                                                  circle path */
     int32_t ref_custom;
     float ref_c[24];
+    /* ActionRepeatModel around MaskAtDoneModel (gops/create_pkg/create_env_model.py:104-107, gops/env/wrapper/
+     * action_repeat.py:54-87): repeat_num >= 2 applies the masked base step repeat_num times to the advancing observation
+     * with the INITIAL done flags; the rewards are summed (repeat_last_reward = 1: only the last one is returned), done is
+     * the last sub-step's.  0 / 1 = no wrapper.  Supported for the models whose observation is the state (GOPS_ENV_LQ,
+     * _IDPENDULUM, _CARTPOLE, _PENDULUM; the reference wrapper does not advance `info`), fp32, repeat_num <= GOPS_MAX_REPEAT. */
+    int32_t repeat_num;
+    int32_t repeat_last_reward;
 } GopsEnv;
 
 typedef struct GopsRolloutDesc {

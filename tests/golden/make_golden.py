@@ -213,6 +213,25 @@ REFPARA_STEP_CASES = {"step_veh_p10_refpara": (dict(env_id="pyth_veh3dofconti", 
 REFPARA_SMALL = {"fhadp_veh_p10_refpara": (dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=48, horizon=10, pre_horizon=10,
                                                 hidden=(64, 64), act="elu", gamma=1.0), REFPARA)}
 
+# ActionRepeatModel (repeat_num / sum_reward of create_env_model; example_train/fhadp/fhadp_mlp_idpendulum_serial.py:41)
+REPEAT_STEP_CASES = {
+    "step_idp_repeat3": (dict(env_id="pyth_idpendulum"), dict(repeat_num=3)),
+    "step_lq_s3a1_repeat2_last_obsscale": (dict(env_id="pyth_lq", lq_config="s3a1"),
+                                           dict(repeat_num=2, sum_reward=False, obs_scale=[1, 2, 0.5], reward_scale=0.5, reward_shift=1.0)),
+    "step_cartpole_repeat4": (dict(env_id="gym_cartpoleconti"), dict(repeat_num=4)),
+    "step_pendulum_repeat2": (dict(env_id="gym_pendulum"), dict(repeat_num=2, sum_reward=False)),
+}
+REPEAT_SMALL = {
+    "fhadp_idp_repeat2_gelu": (dict(alg="FHADP", env_id="pyth_idpendulum", batch=40, horizon=8, hidden=(64, 64), act="gelu",
+                                    gamma=1.0), dict(repeat_num=2)),
+    "infadp_lq_s4a2_repeat3_elu": (dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=48, horizon=6, hidden=(64, 64),
+                                        act="elu", gamma=0.99), dict(repeat_num=3, sum_reward=False)),
+    "fhadp_pendulum_repeat3_tanh": (dict(alg="FHADP", env_id="gym_pendulum", batch=33, horizon=7, hidden=(64, 64), act="tanh",
+                                         gamma=0.98), dict(repeat_num=3)),
+    "infadp_cartpole_repeat2_relu": (dict(alg="INFADP", env_id="gym_cartpoleconti", batch=40, horizon=8, hidden=(64, 64),
+                                          act="relu", gamma=0.99), dict(repeat_num=2)),
+}
+
 MPG_CASES = {   # gops/algorithm/mpg.py: one compute_gradient (twin-Q regression + mixed policy gradient) per case
     "mpg_cartpole_mixed_weight": (dict(alg="MPG", env_id="gym_cartpoleconti", batch=64, horizon=10, hidden=(64, 64), act="relu",
                                        gamma=0.99), dict(pge_method="mixed_weight", eta=0.3, terminal_iter=10000), 3000, 0.1),
@@ -694,7 +713,7 @@ def golden_data_envs():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof", "errcstr", "mpg", "refpara"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof", "errcstr", "mpg", "refpara", "repeat"]
     if "veh2dof" in which:
         golden_steps(VEH2_STEP_CASES)
         golden_small(VEH2_SMALL)
@@ -704,6 +723,10 @@ if __name__ == "__main__":
         golden_small(GYM_SMALL)
     if "errcstr" in which:
         golden_constrained(ERR_STEP_CASES, ERR_ALG_CASES)
+    if "repeat" in which:
+        golden_steps(REPEAT_STEP_CASES)
+        np.random.seed(0)
+        golden_small(REPEAT_SMALL)
     if "refpara" in which:
         golden_steps(REFPARA_STEP_CASES)
         golden_small(REFPARA_SMALL)

@@ -15,7 +15,8 @@ def oracle_env(cfg, extra, golden=None):
                        pre_horizon=cfg.get("pre_horizon", 10), surr_veh_num=cfg.get("surr_veh_num"),
                        reward_scale=extra.get("reward_scale"), reward_shift=extra.get("reward_shift"),
                        obs_scale=extra.get("obs_scale"), obs_shift=extra.get("obs_shift"),
-                       path_para=extra.get("path_para"), u_para=extra.get("u_para"))
+                       path_para=extra.get("path_para"), u_para=extra.get("u_para"),
+                       repeat_num=extra.get("repeat_num"), sum_reward=extra.get("sum_reward", True))
     if golden is not None and "const/lq_inv_IA" in golden:
         env["lq"]["inv_IA"] = torch.from_numpy(np.array(golden["const/lq_inv_IA"]))
     return env
@@ -112,7 +113,8 @@ def hip_env_from_oracle(env, policy_net=None):
                        reward_shift=env["reward_shift"] if env["shaping"] else None, lq=lq, surr=surr,
                        obs_scale=env["obs_scale"] if env.get("scale_obs") else None,
                        obs_shift=env["obs_shift"] if env.get("scale_obs") else None,
-                       ref_c=ref_constants(env.get("path_para"), env.get("u_para")) if "ref_params" in env else None)
+                       ref_c=ref_constants(env.get("path_para"), env.get("u_para")) if "ref_params" in env else None,
+                       repeat_num=env.get("repeat_num"), sum_reward=env.get("sum_reward", True))
 
 
 def hip_mlp_from_net(net, device):

@@ -53,7 +53,8 @@ def _load_alg(name):
 
 @pytest.mark.parametrize("name", ["fhadp_idp_gelu", "fhadp_veh_p10_elu", "fhadp_lq_s4a2_tanh",
                                   "fhadp_idp_selu_shaped", "fhadp_surrpen_p10_elu", "fhadp_lq_s3a1_obsscale",
-                                  "fhadp_idp_obsscale_shift", "fhadp_veh2dof_p10_elu", "fhadp_veh_p10_refpara"])
+                                  "fhadp_idp_obsscale_shift", "fhadp_veh2dof_p10_elu", "fhadp_veh_p10_refpara",
+                                  "fhadp_idp_repeat2_gelu", "fhadp_pendulum_repeat3_tanh"])
 def test_fhadp_class_matches_reference(name):
     alg, g, cfg = _load_alg(name)
     alg.gamma = cfg["gamma"]
@@ -72,7 +73,8 @@ def test_fhadp_class_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", ["infadp_lq_s4a2_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift", "mac_idp_elu",
-                                  "infadp_cartpole_gelu", "mac_pendulum_elu"])
+                                  "infadp_cartpole_gelu", "mac_pendulum_elu", "infadp_lq_s4a2_repeat3_elu",
+                                  "infadp_cartpole_repeat2_relu"])
 def test_infadp_class_matches_reference(name):
     alg, g, cfg = _load_alg(name)
     alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]

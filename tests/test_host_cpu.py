@@ -78,8 +78,15 @@ def test_registries_and_error_behaviour():
         create_apprfunc.create_apprfunc(apprfunc="MLP", name="Nope")
     with pytest.raises(KeyError, match="No registered trainer with id"):
         create_trainer.create_trainer(None, None, None, None, trainer="nope_trainer")
-    with pytest.raises(RuntimeError):
-        create_env_model.create_env_model("pyth_lq", repeat_num=2)
+    # wrapper options outside the kernels' contract are refused, never silently ignored
+    with pytest.raises(RuntimeError, match="repeat_num"):
+        create_env_model.create_env_model("pyth_veh3dofconti", repeat_num=2)   # the reference wrapper does not advance `info`
+    with pytest.raises(RuntimeError, match="repeat_num must be"):
+        create_env_model.create_env_model("pyth_lq", repeat_num=9)
+    with pytest.raises(RuntimeError, match="mask_at_done"):
+        create_env_model.create_env_model("pyth_lq", mask_at_done=False)
+    m = create_env_model.create_env_model("pyth_idpendulum", repeat_num=3, sum_reward=False)
+    assert m.hip_env().repeat_num == 3 and m.hip_env().repeat_last_reward == 1
 
 
 def test_state_dict_layout_and_parameter_api():

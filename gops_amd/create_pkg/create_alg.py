@@ -29,12 +29,45 @@ def _defaults(kwargs: dict) -> dict:
     return out
 
 
+class _RemoteMethod:
+    """`handle.method.remote(*args)` of a Ray actor, in-process: returns the value itself."""
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    def __call__(self, *args, **kwargs):
+        return self._fn(*args, **kwargs)
+
+    def remote(self, *args, **kwargs):
+        return self._fn(*args, **kwargs)
+
+
+class LocalActor:
+    """What the reference's example scripts expect from `create_alg` for the off_sync / off_async trainers: a list of
+    actor handles whose methods are reached through `.remote(...)` (create_alg.py:87-93, e.g.
+    `for alg_id in alg: alg_id.set_parameters.remote({...})`, example_train/mac/mac_mlp_cartpoleconti_async.py:153-154).
+    One process per GPU here: the list has ONE entry, this rank's replica; the trainers unwrap it (`.unwrap()`)."""
+
+    def __init__(self, obj):
+        object.__setattr__(self, "_obj", obj)
+
+    def unwrap(self):
+        return self._obj
+
+    def __getattr__(self, name):
+        attr = getattr(self._obj, name)
+        return _RemoteMethod(attr) if callable(attr) else attr
+
+
 def create_alg(**kwargs) -> object:
     registry.lookup(kwargs["algorithm"])          # unknown algorithm: KeyError before anything else
     trainer = kwargs.get("trainer")
     if trainer is not None and not trainer.startswith(_TRAINER_KINDS):
         raise RuntimeError(f"trainer {trainer} not recognized")
-    return registry.build(kwargs["algorithm"], **_defaults(kwargs))
+    alg = registry.build(kwargs["algorithm"], **_defaults(kwargs))
+    if trainer is not None and trainer.startswith(("off_async", "off_sync")):
+        return [LocalActor(alg)]                   # the reference returns a list of actor handles for these trainers
+    return alg
 
 
 def create_approx_contrainer(algorithm: str, **kwargs) -> object:

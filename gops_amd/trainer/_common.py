@@ -51,8 +51,12 @@ class TrainerBase:
         if torch.cuda.is_available() and not next(self.networks.parameters()).is_cuda:
             self.networks.to(torch.device("cuda", torch.cuda.current_device()))
         self._host_networks = None
+        # a Ray actor handle (the reference's create_sampler for the sync / async trainers, create_sampler.py:71-81): its
+        # methods go through `.remote()`, and it receives the weights as a state_dict instead of sharing the container
+        self._sampler_remote = self.sampler is not None and hasattr(getattr(self.sampler, "sample", None), "remote")
         if self.sampler is not None:
-            self.sampler.networks = self.networks
+            if not self._sampler_remote:
+                self.sampler.networks = self.networks
             self._refresh_sampler_networks()
         self.max_iteration = kwargs.get("max_iteration")
         self.log_save_interval = kwargs["log_save_interval"]
@@ -73,7 +77,12 @@ class TrainerBase:
         their own host copy of the container, refreshed from the learner's weights before each sampling call (a
         0.4 MB device-to-host copy); the learner's parameters never move.  Device samplers (`on_device`) share the
         learner's container."""
-        if self.sampler is None or getattr(self.sampler, "on_device", False):
+        if self.sampler is None:
+            return
+        if self._sampler_remote:   # (sampler/base.py:80-81: `self.networks.load_state_dict(state_dict)` on the actor)
+            call_maybe_remote(self.sampler, "load_state_dict", {k: v.cpu() for k, v in self.networks.state_dict().items()})
+            return
+        if getattr(self.sampler, "on_device", False):
             return
         if next(self.networks.parameters()).is_cuda:
             if self._host_networks is None:
@@ -113,7 +122,7 @@ class TrainerBase:
             self.writer.add_scalar(tb_tags["TAR of RL iteration"], total_avg_return, self.iteration)
             self.writer.add_scalar(tb_tags["TAR of total time"], total_avg_return, int(time.time() - self.start_time))
             self.writer.add_scalar(tb_tags["TAR of collected samples"], total_avg_return,
-                                   self.sampler.get_total_sample_number())
+                                   call_maybe_remote(self.sampler, "get_total_sample_number"))
 
     def train(self):
         while self.iteration < self.max_iteration:

@@ -39,6 +39,7 @@ class OffAsyncTrainer(OffSerialTrainer):
             buffer = buffer[rank() % len(buffer)]
         if isinstance(alg, (list, tuple)):
             alg = alg[rank() % len(alg)]
+        alg = alg.unwrap() if hasattr(alg, "unwrap") else alg   # create_alg's in-process actor handle
         super().__init__(alg, sampler, buffer, evaluator, **kwargs)
         broadcast_parameters(self.networks, src=0)
         self._refresh_sampler_networks()

@@ -10,7 +10,7 @@ ModuleOnDevice, :81); the evaluator runs in-process (no Ray).
 """
 import time
 
-from gops_amd.trainer._common import TrainerBase
+from gops_amd.trainer._common import TrainerBase, call_maybe_remote
 
 __all__ = ["OffSerialTrainer"]
 
@@ -30,7 +30,7 @@ class OffSerialTrainer(TrainerBase):
 
     def _sampler_samples(self):
         self._refresh_sampler_networks()   # host samplers: fresh CPU copy of the weights (TrainerBase)
-        return self.sampler.sample()
+        return call_maybe_remote(self.sampler, "sample")
 
     def _store(self, samples):
         """Lists of Experience tuples (reference samplers) or a dict of batched device tensors

@@ -28,6 +28,7 @@ class OffSyncTrainer(OffSerialTrainer):
             buffer = buffer[rank() % len(buffer)]
         if isinstance(alg, (list, tuple)):
             alg = alg[rank() % len(alg)]
+        alg = alg.unwrap() if hasattr(alg, "unwrap") else alg   # create_alg's in-process actor handle
         super().__init__(alg, sampler, buffer, evaluator, **kwargs)
         self.reducer = GradAllReducer()
         broadcast_parameters(self.networks, src=0)   # identical replicas (TrainerBase already moved them to the GPU)

@@ -1,6 +1,6 @@
 """Serial on-policy trainer: sample -> alg.local_update -> log / save / evaluate
 (constructor and kwargs of gops/trainer/on_serial_trainer.py:30-152; shared machinery in `_common.py`)."""
-from gops_amd.trainer._common import TrainerBase
+from gops_amd.trainer._common import TrainerBase, call_maybe_remote
 
 __all__ = ["OnSerialTrainer"]
 
@@ -8,7 +8,7 @@ __all__ = ["OnSerialTrainer"]
 class OnSerialTrainer(TrainerBase):
     def _sample(self):
         self._refresh_sampler_networks()   # host samplers: fresh CPU copy of the weights (TrainerBase)
-        samples, sampler_tb = self.sampler.sample_with_replay_format()
+        samples, sampler_tb = call_maybe_remote(self.sampler, "sample_with_replay_format")
         self.sampler_tb_dict.add_average(sampler_tb)
         return samples
 

@@ -497,7 +497,7 @@ def train_one(self):                                   # the script calls traine
     seen["trainer"] = type(self).__module__ + "." + type(self).__name__
     seen["alg"] = type(self.alg).__module__
     seen["buffer"] = type(self.buffer).__module__ if getattr(self, "buffer", None) is not None else None
-    seen["sampler"] = type(self.sampler).__module__
+    seen["sampler"] = type(getattr(self.sampler, "_obj", self.sampler)).__module__   # (async scripts: an actor handle)
     seen["evaluator"] = type(self.evaluator).__name__
     seen["warm"] = len(self.buffer) if getattr(self, "buffer", None) is not None else None
     try:
@@ -506,10 +506,13 @@ def train_one(self):                                   # the script calls traine
     except RuntimeError as e:
         seen["step"] = str(e)
 tc.TrainerBase.train = train_one
+import gops_amd.trainer.off_async_trainer as oat
+oat.OffAsyncTrainer.train = train_one
 sys.argv = [SCRIPT, "--save_folder", SAVE, "--max_iteration", "2", "--buffer_warm_size", "128", "--sample_batch_size", "64"]
 runpy.run_path(SCRIPT, run_name="__main__")
 import torch
-assert seen["trainer"] == "gops_amd.trainer.off_serial_trainer.OffSerialTrainer", seen
+want = "off_async_trainer.OffAsyncTrainer" if "_async" in os.path.basename(SCRIPT) else "off_serial_trainer.OffSerialTrainer"
+assert seen["trainer"] == "gops_amd.trainer." + want, seen
 assert seen["alg"].startswith("gops_amd.algorithm."), seen
 assert seen["buffer"] == "gops_amd.trainer.buffer.replay_buffer", seen
 assert seen["sampler"].startswith("gops.trainer.sampler"), seen          # the reference's own numpy-env sampler
@@ -541,7 +544,12 @@ print("plumbing ok", seen["alg"])
                                     "example_train/infadp/infadp_mlp_cartpoleconti_offserial.py",
                                     "example_train/infadp/infadp_mlp_veh3dofconti_offserial.py",
                                     "example_train/infadp/infadp_mlp_lqs6a3_offserial.py",
-                                    "example_train/mac/mac_mlp_cartpoleconti_offserial.py"])   # (the pendulum scripts need the gym package for their data env)
+                                    "example_train/mac/mac_mlp_cartpoleconti_offserial.py",
+                                    # off_async scripts: `create_alg` hands out a list of actor-like handles
+                                    # (`alg_id.set_parameters.remote(...)`), the samplers are actor handles of the reference
+                                    "example_train/fhadp/fhadp_mlp_idpendulum_async.py",
+                                    "example_train/infadp/infadp_mlp_cartpoleconti_async.py",
+                                    "example_train/mpg/mpg_mlp_cartpoleconti_async.py"])   # (the pendulum scripts need the gym package for their data env)
 def test_example_scripts_run_unchanged_through_the_overlay(script, tmp_path):
     """BASELINE configs[0] plumbing: the reference's UNMODIFIED example scripts (their own argparse block, create_env,
     init_args, create_sampler, create_evaluator - a Ray actor handle, here from an in-process stub) executed with

@@ -549,7 +549,8 @@ print("plumbing ok", seen["alg"])
                                     # (`alg_id.set_parameters.remote(...)`), the samplers are actor handles of the reference
                                     "example_train/fhadp/fhadp_mlp_idpendulum_async.py",
                                     "example_train/infadp/infadp_mlp_cartpoleconti_async.py",
-                                    "example_train/mpg/mpg_mlp_cartpoleconti_async.py"])   # (the pendulum scripts need the gym package for their data env)
+                                    "example_train/mpg/mpg_mlp_cartpoleconti_async.py",
+                                    "example_train/mac/mac_mlp_cartpoleconti_async.py"])   # (the pendulum scripts need the gym package for their data env)
 def test_example_scripts_run_unchanged_through_the_overlay(script, tmp_path):
     """BASELINE configs[0] plumbing: the reference's UNMODIFIED example scripts (their own argparse block, create_env,
     init_args, create_sampler, create_evaluator - a Ray actor handle, here from an in-process stub) executed with

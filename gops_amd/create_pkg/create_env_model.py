@@ -31,8 +31,9 @@ class WrappedEnvModel:
 
     def __init__(self, model, *, min_action, max_action, clip_obs: bool,
                  reward_scale: Optional[float], reward_shift: Optional[float], obs_scale=None, obs_shift=None,
-                 repeat_num: Optional[int] = None, sum_reward: bool = True):
+                 repeat_num: Optional[int] = None, sum_reward: bool = True, mask_at_done: bool = True):
         self.model = model
+        self.mask_at_done = mask_at_done   # False: no MaskAtDoneModel in the chain (GopsEnv.no_mask_at_done)
         self.repeat_num, self.sum_reward = repeat_num, sum_reward   # ActionRepeatModel constants (None: no such wrapper)
         self.obs_scale, self.obs_shift = obs_scale, obs_shift   # ScaleObservationModel constants (None: no such wrapper)
         self.min_action = torch.zeros_like(model.action_lower_bound) + torch.as_tensor(
@@ -68,7 +69,8 @@ class WrappedEnvModel:
                 obs_high=m.obs_upper_bound.cpu() if (self.clip_obs or data_env) else None,
                 pre_horizon=getattr(m, "pre_horizon", 0), reward_scale=self.reward_scale,
                 reward_shift=self.reward_shift, data_env=data_env, obs_scale=self.obs_scale, obs_shift=self.obs_shift,
-                ref_c=getattr(m, "ref_c", None), repeat_num=self.repeat_num, sum_reward=self.sum_reward, **m.hip_constants())
+                ref_c=getattr(m, "ref_c", None), repeat_num=self.repeat_num, sum_reward=self.sum_reward,
+                mask_at_done=self.mask_at_done, **m.hip_constants())
         return self._env_cache[key]
 
     def forward(self, obs: torch.Tensor, action: torch.Tensor, done: torch.Tensor, info: Dict
@@ -117,8 +119,8 @@ def create_env_model(
     if scaled and (env_model.obs_dim > 8 or env_model.hip_kind not in (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_CARTPOLE, hb.ENV_PENDULUM)):
         raise RuntimeError("ScaleObservationModel (obs_shift/obs_scale) is supported for pyth_lq / pyth_idpendulum / gym_* models only "
                            "(observation dimension <= 8) by the HIP env models")
-    if not mask_at_done:
-        raise RuntimeError("mask_at_done=False is not supported by the HIP env models")
+    if not mask_at_done and env_model.hip_kind == hb.ENV_VEH_SURR:
+        raise RuntimeError("mask_at_done=False is not supported for the constrained veh3dofconti models by the HIP env models")
     # action_scale=True with clip_action=False needs no flag: ScaleActionModel already ends with
     # clip(., action_lower_bound, action_upper_bound) (scale_action.py:75-83) and ClipActionModel applies that same
     # clamp once more (clip_action.py:34-36) - idempotent, so the kernels' chain is exact for both settings.
@@ -135,7 +137,7 @@ def create_env_model(
         # create_env_model.py:115-118: either one given -> the wrapper is applied with the other at its neutral value
         obs_scale=(1.0 if obs_scale is None else obs_scale) if scaled else None,
         obs_shift=(0.0 if obs_shift is None else obs_shift) if scaled else None,
-        repeat_num=None if repeat_num is None else int(repeat_num), sum_reward=bool(sum_reward))
+        repeat_num=None if repeat_num is None else int(repeat_num), sum_reward=bool(sum_reward), mask_at_done=bool(mask_at_done))
 
 
 # fill the registry: every env/env_*/env_model/<id>.py exporting env_model_creator or the CamelCase class

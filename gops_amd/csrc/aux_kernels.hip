@@ -1045,7 +1045,7 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
     const bool data = env.data_env != 0;   // the DATA environment's step (include/gops_hip.h: GopsEnv.data_env)
     float u[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
     for (int a = 0; a < A; ++a) u[a] = wrap_action(env, a, io.action[(size_t)b * A + a]);
-    const bool dn = !data && io.done != nullptr && io.done[b] != 0.f;
+    const bool dn = !data && !env.no_mask_at_done && io.done != nullptr && io.done[b] != 0.f;   // (no MaskAtDoneModel: done flags ignored)
     const int nrep = (env.repeat_num > 1 && !data) ? env.repeat_num : 1;
     const bool last_only = nrep > 1 && env.repeat_last_reward != 0;
     float r = 0.f;

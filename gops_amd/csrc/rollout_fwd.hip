@@ -196,7 +196,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         const int m = idx / ldx, c = idx - m * ldx;
         xs[idx] = (c < O && m < nvalid) ? gptr(p.in.obs)[(size_t)(b0 + m) * O + c] : 0.f;
     }
-    if (tid < TB) s_done[tid] = (tid < nvalid && p.in.done != nullptr && gptr(p.in.done)[b0 + tid] != 0.f) ? 1.f : 0.f;
+    // (no MaskAtDoneModel in the chain: the base models ignore the done flags they are handed)
+    if (tid < TB) s_done[tid] = (tid < nvalid && p.in.done != nullptr && !p.env.no_mask_at_done && gptr(p.in.done)[b0 + tid] != 0.f) ? 1.f : 0.f;
     if (VEH) {
         if (tid < TB * 6) {
             const int m = tid / 6, c = tid - m * 6;
@@ -575,6 +576,28 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         DBG_TICK(5)
     }
     __syncthreads();
+    if (p.env.no_mask_at_done && !SURR && tid < TB) {
+        // mask_at_done = False: nothing was frozen or masked on the way; the rollout's done is the base model's test on
+        // the LAST next state, which is the final observation (every done test of these models reads the new state only)
+        const float* o = xs + tid * ldx;
+        const float pi = 3.14159265358979323846f;
+        bool dl = false;
+        if (ENV == GOPS_ENV_IDPENDULUM) {
+            float s6[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) s6[i] = obs_unscale(p.env, i, o[i]);
+            dl = idp_done(IC, s6);
+        } else if (ENV == GOPS_ENV_CARTPOLE) {
+            const CartConst C = cart_const();
+            const float x0 = obs_unscale(p.env, 0, o[0]), x2 = obs_unscale(p.env, 2, o[2]);
+            dl = (x0 < -C.xth) || (x0 > C.xth) || (x2 < -C.thth) || (x2 > C.thth);
+        } else if (ENV == GOPS_ENV_VEH3DOFCONTI) {
+            dl = (fabsf(o[0]) > 10.f) || (fabsf(o[1]) > 10.f) || (fabsf(o[2]) > pi);
+        } else if (ENV == GOPS_ENV_VEH2DOF) {
+            dl = (fabsf(o[0]) > 2.f) || (fabsf(o[1]) > pi);
+        }
+        s_done[tid] = dl ? 1.f : 0.f;
+    }
     dbg.dump(p.dbg);
 
     if (TAIL) {   // v += (~done_H) * gamma^H * V_target(obs_H)   (infadp.py:182-184, 210)

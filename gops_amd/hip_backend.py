@@ -219,12 +219,14 @@ def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_ac
              policy_low=None, policy_high=None, obs_low=None, obs_high=None, pre_horizon: int = 0,
              reward_scale: Optional[float] = None, reward_shift: Optional[float] = None,
              lq: Optional[Dict] = None, data_env: bool = False, surr: Optional[Dict] = None,
-             obs_scale=None, obs_shift=None, ref_c=None, repeat_num: Optional[int] = None, sum_reward: bool = True) -> GopsEnv:
+             obs_scale=None, obs_shift=None, ref_c=None, repeat_num: Optional[int] = None, sum_reward: bool = True,
+             mask_at_done: bool = True) -> GopsEnv:
     """Constants of the wrapped env model (create_env_model.py:86-128) as a C struct.  `data_env=True` (for
     `env_step` only): the DATA environment's termination tests / terminal penalty instead of the model's; obs_low /
     obs_high are then the data env's state bounds (pyth_lq) and are NOT applied as a clip."""
     e = GopsEnv()
     e.data_env = int(bool(data_env))
+    e.no_mask_at_done = int(not mask_at_done)   # create_env_model(mask_at_done=False): no MaskAtDoneModel in the chain
     if repeat_num is not None:   # ActionRepeatModel (repeat_num = 1 is the identity wrapper)
         e.repeat_num, e.repeat_last_reward = int(repeat_num), int(not sum_reward)
     if ref_c is not None:   # custom path_para / u_para of the reference trajectories (resources/ref_traj_params.py)

@@ -133,7 +133,9 @@ typedef struct GopsEnv {
      * the CURRENT state (x, y, phi rotated, u relative); the model never reports done; info["constraint"] (and the
      * constraint sums) are those of the CURRENT pose and carry no gradient (the model computes them on detached copies). */
     /* 1: no MaskAtDoneModel in the chain (mask_at_done.py:33-40): the model keeps stepping after its done test fired,
-     * rewards are not zeroed (the raw model OptController drives, opt_controller.py:261-265) */
+     * rewards are not zeroed (the raw model OptController drives, opt_controller.py:261-265; create_env_model(mask_at_done =
+     * False), create_env_model.py:104-105).  The done flags handed in are ignored; final_done (and the mask of a tail
+     * value) is the base model's done test on the LAST state.  Not for GOPS_ENV_VEH3DOF_SURR (final_done stays 0 there). */
     int32_t no_mask_at_done;
     int32_t n_surr, n_constraint, surr_penalty;
     float veh_length, veh_width, road_upper, road_lower;

@@ -232,6 +232,19 @@ REPEAT_SMALL = {
                                           act="relu", gamma=0.99), dict(repeat_num=2)),
 }
 
+# create_env_model(mask_at_done=False): no MaskAtDoneModel in the chain
+NOMASK_STEP_CASES = {"step_idp_nomask": (dict(env_id="pyth_idpendulum"), dict(mask_at_done=False)),
+                     "step_veh_p10_nomask": (dict(env_id="pyth_veh3dofconti", pre_horizon=10), dict(mask_at_done=False)),
+                     "step_cartpole_nomask_repeat2": (dict(env_id="gym_cartpoleconti"), dict(mask_at_done=False, repeat_num=2))}
+NOMASK_SMALL = {
+    "fhadp_veh_p10_nomask_elu": (dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=48, horizon=10, pre_horizon=10,
+                                      hidden=(64, 64), act="elu", gamma=1.0), dict(mask_at_done=False)),
+    "infadp_cartpole_nomask_relu": (dict(alg="INFADP", env_id="gym_cartpoleconti", batch=64, horizon=12, hidden=(64, 64),
+                                         act="relu", gamma=0.99), dict(mask_at_done=False)),
+    "infadp_veh2dof_nomask_gelu": (dict(alg="INFADP", env_id="pyth_veh2dofconti", batch=40, horizon=8, pre_horizon=10,
+                                        hidden=(64, 64), act="gelu", gamma=0.99), dict(mask_at_done=False)),
+}
+
 MPG_CASES = {   # gops/algorithm/mpg.py: one compute_gradient (twin-Q regression + mixed policy gradient) per case
     "mpg_cartpole_mixed_weight": (dict(alg="MPG", env_id="gym_cartpoleconti", batch=64, horizon=10, hidden=(64, 64), act="relu",
                                        gamma=0.99), dict(pge_method="mixed_weight", eta=0.3, terminal_iter=10000), 3000, 0.1),
@@ -713,7 +726,7 @@ def golden_data_envs():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof", "errcstr", "mpg", "refpara", "repeat"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof", "errcstr", "mpg", "refpara", "repeat", "nomask"]
     if "veh2dof" in which:
         golden_steps(VEH2_STEP_CASES)
         golden_small(VEH2_SMALL)
@@ -723,6 +736,10 @@ if __name__ == "__main__":
         golden_small(GYM_SMALL)
     if "errcstr" in which:
         golden_constrained(ERR_STEP_CASES, ERR_ALG_CASES)
+    if "nomask" in which:
+        golden_steps(NOMASK_STEP_CASES)
+        np.random.seed(0)
+        golden_small(NOMASK_SMALL)
     if "repeat" in which:
         golden_steps(REPEAT_STEP_CASES)
         np.random.seed(0)

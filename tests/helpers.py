@@ -16,7 +16,8 @@ def oracle_env(cfg, extra, golden=None):
                        reward_scale=extra.get("reward_scale"), reward_shift=extra.get("reward_shift"),
                        obs_scale=extra.get("obs_scale"), obs_shift=extra.get("obs_shift"),
                        path_para=extra.get("path_para"), u_para=extra.get("u_para"),
-                       repeat_num=extra.get("repeat_num"), sum_reward=extra.get("sum_reward", True))
+                       repeat_num=extra.get("repeat_num"), sum_reward=extra.get("sum_reward", True),
+                       mask_at_done=extra.get("mask_at_done", True))
     if golden is not None and "const/lq_inv_IA" in golden:
         env["lq"]["inv_IA"] = torch.from_numpy(np.array(golden["const/lq_inv_IA"]))
     return env
@@ -114,7 +115,8 @@ def hip_env_from_oracle(env, policy_net=None):
                        obs_scale=env["obs_scale"] if env.get("scale_obs") else None,
                        obs_shift=env["obs_shift"] if env.get("scale_obs") else None,
                        ref_c=ref_constants(env.get("path_para"), env.get("u_para")) if "ref_params" in env else None,
-                       repeat_num=env.get("repeat_num"), sum_reward=env.get("sum_reward", True))
+                       repeat_num=env.get("repeat_num"), sum_reward=env.get("sum_reward", True),
+                       mask_at_done=env.get("mask_at_done", True))
 
 
 def hip_mlp_from_net(net, device):

@@ -54,7 +54,7 @@ def _load_alg(name):
 @pytest.mark.parametrize("name", ["fhadp_idp_gelu", "fhadp_veh_p10_elu", "fhadp_lq_s4a2_tanh",
                                   "fhadp_idp_selu_shaped", "fhadp_surrpen_p10_elu", "fhadp_lq_s3a1_obsscale",
                                   "fhadp_idp_obsscale_shift", "fhadp_veh2dof_p10_elu", "fhadp_veh_p10_refpara",
-                                  "fhadp_idp_repeat2_gelu", "fhadp_pendulum_repeat3_tanh"])
+                                  "fhadp_idp_repeat2_gelu", "fhadp_pendulum_repeat3_tanh", "fhadp_veh_p10_nomask_elu"])
 def test_fhadp_class_matches_reference(name):
     alg, g, cfg = _load_alg(name)
     alg.gamma = cfg["gamma"]
@@ -74,7 +74,7 @@ def test_fhadp_class_matches_reference(name):
 
 @pytest.mark.parametrize("name", ["infadp_lq_s4a2_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift", "mac_idp_elu",
                                   "infadp_cartpole_gelu", "mac_pendulum_elu", "infadp_lq_s4a2_repeat3_elu",
-                                  "infadp_cartpole_repeat2_relu"])
+                                  "infadp_cartpole_repeat2_relu", "infadp_cartpole_nomask_relu", "infadp_veh2dof_nomask_gelu"])
 def test_infadp_class_matches_reference(name):
     alg, g, cfg = _load_alg(name)
     alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]

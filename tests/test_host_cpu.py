@@ -84,7 +84,8 @@ def test_registries_and_error_behaviour():
     with pytest.raises(RuntimeError, match="repeat_num must be"):
         create_env_model.create_env_model("pyth_lq", repeat_num=9)
     with pytest.raises(RuntimeError, match="mask_at_done"):
-        create_env_model.create_env_model("pyth_lq", mask_at_done=False)
+        create_env_model.create_env_model("pyth_veh3dofconti_surrcstr", mask_at_done=False)
+    assert create_env_model.create_env_model("pyth_lq", mask_at_done=False).hip_env().no_mask_at_done == 1
     m = create_env_model.create_env_model("pyth_idpendulum", repeat_num=3, sum_reward=False)
     assert m.hip_env().repeat_num == 3 and m.hip_env().repeat_last_reward == 1
 

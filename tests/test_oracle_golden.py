@@ -18,7 +18,9 @@ STEP_CASES = ["step_lq_s4a2", "step_lq_s6a3", "step_lq_s2a1_shaped", "step_idp",
               "step_veh2dof_p10",
               "step_veh_p10_refpara", "step_veh2dof_p10_refpara",   # custom path_para / u_para
               # ActionRepeatModel (repeat_num / sum_reward)
-              "step_idp_repeat3", "step_lq_s3a1_repeat2_last_obsscale", "step_cartpole_repeat4", "step_pendulum_repeat2"]
+              "step_idp_repeat3", "step_lq_s3a1_repeat2_last_obsscale", "step_cartpole_repeat4", "step_pendulum_repeat2",
+              # mask_at_done = False
+              "step_idp_nomask", "step_veh_p10_nomask", "step_cartpole_nomask_repeat2"]
 FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fhadp_idp_selu_shaped",
                "fhadp_veh_p10_elu", "fhadp_veh_p30_sigmoid",
                # plain FHADP on the collision-penalty model (pyth_veh3dofconti_surrcstr_penalty)
@@ -28,12 +30,14 @@ FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fh
                "fhadp_veh2dof_p10_elu",   # pyth_veh2dofconti
                "fhadp_veh_p10_refpara",   # custom path_para / u_para
                "fhadp_idp_repeat2_gelu", "fhadp_pendulum_repeat3_tanh",   # ActionRepeatModel
+               "fhadp_veh_p10_nomask_elu",   # mask_at_done = False
                # the reference's shipped trained checkpoints (saturating policies, H = 80, limits != +-1)
                "fhadp_trained_idp_h80", "fhadp_trained_lqs3a1_h80"]
 INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift",
                 "mac_lq_s4a2_gelu", "mac_idp_elu", "infadp_cartpole_gelu", "mac_pendulum_elu", "infadp_pendulum_tanh",
                 "infadp_veh2dof_p10_gelu",   # gops/algorithm/mac.py: INFADP's losses (its Bayes model-bias term is inert)
                 "infadp_lq_s4a2_repeat3_elu", "infadp_cartpole_repeat2_relu",   # ActionRepeatModel
+                "infadp_cartpole_nomask_relu", "infadp_veh2dof_nomask_gelu",   # mask_at_done = False
                 "infadp_trained_lqs4a2", "infadp_trained_idp"]
 
 

@@ -1087,9 +1087,12 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
             rs = last_only ? r : rs + r;
         }
         r = rs;
+        // data env (env_gym/gym_cartpoleconti.py:102-137): the same physics, reward 1 also for the step that ends the
+        // episode, no observation clip
+        if (data && env.kind == GOPS_ENV_CARTPOLE) r = 1.f;
         for (int i = 0; i < NS; ++i) {
             const float v = obs_rescale(env, i, dn ? x[i] : xn[i]);
-            nob[i] = env.clip_obs ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
+            nob[i] = (env.clip_obs && !data) ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
         }
     } else if (env.kind == GOPS_ENV_IDPENDULUM) {   // data env == model (pyth_idpendulum.py:71-87 calls the model's Dynamics)
         const IdpConst IC = idp_const();

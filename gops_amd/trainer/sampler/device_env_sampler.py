@@ -5,7 +5,8 @@ The reference's samplers step numpy data environments one env and one step at a 
 section 8(f) rank 3).  The data environments of this path share their dynamics and stage reward with the env
 models but NOT their termination rules or terminal reward (pyth_veh3dofconti.py:224-226,263-271: -100 at done,
 world-frame |dx| > 5, |dy| > 2 against the model's ego-frame 10 / 10; lq_base.py:224-239: done when the state leaves
-its bounds, -100, no clipping; pyth_idpendulum.py:71-87 is identical to its model).  `env_step="data"` (default)
+its bounds, -100, no clipping; pyth_idpendulum.py:71-87 is identical to its model; gym_cartpoleconti.py:102-137: reward 1
+also for the step that ends an episode).  `env_step="data"` (default)
 selects those data-env semantics in the step kernel (`GopsEnv.data_env`, checked against transitions recorded from the
 reference's numpy envs: tests/golden/dataenv_*.npz); `env_step="model"` steps the env model instead.  N environment
 instances are advanced together by `gops_env_step`:
@@ -65,6 +66,11 @@ class DeviceEnvSampler:
         size = self.pool_factor * self.n
         if self._pool is None or self._pool_pos + k > size:
             host = make_batch(self.cfg, self.seed + 7919 * self._pools_made, batch=size)
+            if self.cfg["env_id"] == "gym_cartpoleconti" and self.data_env:
+                # the data env's own reset distribution (env_gym/gym_cartpoleconti.py:139-147: uniform +-0.05 in every state);
+                # make_batch's wide cartpole states exist to exercise the done thresholds inside short rollouts
+                rng = np.random.RandomState(self.seed + 7919 * self._pools_made)
+                host["obs"] = torch.from_numpy(rng.uniform(-0.05, 0.05, size=(size, 4)).astype(np.float32))
             self._pool = {key: v.to(self.device) for key, v in host.items() if key == "obs" or key in _INFO}
             # ScaleObservationData (scale_observation.py:53-62): the sampler hands out (obs + shift) * scale
             sc, sh = getattr(self.env_model, "obs_scale", None), getattr(self.env_model, "obs_shift", None)

@@ -663,16 +663,19 @@ DATA_ENV_CASES = {
     "dataenv_lq_s4a2": dict(env_id="pyth_lq", lq_config="s4a2"),
     "dataenv_idp": dict(env_id="pyth_idpendulum"),
     "dataenv_lq_s2a1_shaped": dict(env_id="pyth_lq", lq_config="s2a1", reward_scale=0.5, reward_shift=1.0),
+    "dataenv_cartpole": dict(env_id="gym_cartpoleconti", reward_scale=0.5),
 }
 
 
-def golden_data_envs():
+def golden_data_envs(only=None):
     from gops.create_pkg.create_env import create_env
     from gops.trainer.buffer.replay_buffer import ReplayBuffer as RefBuffer
     for _old, _new in (("float_", np.float64), ("int_", np.int64), ("bool8", np.bool_)):   # reference targets numpy 1.x
         if not hasattr(np, _old):
             setattr(np, _old, _new)
     for name, cfg in DATA_ENV_CASES.items():
+        if only is not None and name not in only:
+            continue
         env = create_env(**cfg)
         rng = np.random.RandomState(zlib.crc32(name.encode()) % 10000)
         rows = []
@@ -762,6 +765,8 @@ if __name__ == "__main__":
         golden_small(PENALTY_SMALL)
     if "dataenv" in which:
         golden_data_envs()
+    if "dataenv_cartpole" in which:
+        golden_data_envs(only=("dataenv_cartpole",))
     if "constrained" in which:
         golden_constrained()
     if "fhadp2" in which:

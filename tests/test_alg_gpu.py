@@ -650,6 +650,12 @@ def test_mpg_learns_with_device_sampler(tmp_path):
     alg.networks.to("cuda")
     smp = DeviceEnvSampler(cfg, alg.envmodel, n_envs=256, steps_per_sample=2, max_episode_steps=50, seed=3, noise_std=0.2,
                            env_step="model")
+    # (the gym_cartpoleconti DATA env is restated too: its semantics are the sampler's default there)
+    cp = DeviceEnvSampler(dict(cfg, env_id="gym_cartpoleconti"), create_alg(**dict(kw, env_id="gym_cartpoleconti", obsv_dim=4)).envmodel,
+                          n_envs=32, steps_per_sample=3, max_episode_steps=50, seed=1)
+    cp.networks = create_alg(**dict(kw, env_id="gym_cartpoleconti", obsv_dim=4)).networks.to("cuda")
+    cb, _ = cp.sample()
+    assert cb["obs"].abs().max() < 0.6 and bool((cb["rew"] == 1.0).all())   # reset at +-0.05, reward 1 per step
     buf = create_buffer(**kw)
     trainer = create_trainer(alg, smp, buf, None, **kw)
     losses = []

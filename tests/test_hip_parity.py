@@ -437,7 +437,7 @@ def test_stationary_staged_variants_match_oracle(cfg, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped"])
+@pytest.mark.parametrize("name", ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped", "dataenv_cartpole"])
 def test_data_env_step_vs_reference_numpy_envs(name, dev):
     """gops_env_step with GopsEnv.data_env = 1 (what DeviceEnvSampler steps) against transitions recorded from the
     reference's numpy DATA envs: terminal -100, data-env termination tests, no observation clipping."""

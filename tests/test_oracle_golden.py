@@ -134,7 +134,7 @@ def test_fhadp2_gradient_matches_reference(name):
         assert rel_l2(gr, g[f"grad/{i}"]) < 1e-5, (name, i)
 
 
-DATA_ENV_CASES = ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped"]
+DATA_ENV_CASES = ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped", "dataenv_cartpole"]
 
 
 def _dataenv_inputs(g):

@@ -49,6 +49,10 @@ class DeviceEnvSampler:
         if env_step not in ("data", "model"):
             raise ValueError("env_step must be 'data' (the data environment's step) or 'model' (the env model's)")
         self.data_env = env_step == "data"
+        kind = getattr(getattr(env_model, "unwrapped", env_model), "hip_kind", None)
+        if self.data_env and kind not in (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_VEH, hb.ENV_CARTPOLE):
+            raise RuntimeError(f"the DATA environment of {self.cfg.get('env_id')} is not restated in the step kernel "
+                               "(pyth_lq, pyth_idpendulum, pyth_veh3dofconti and gym_cartpoleconti are): pass env_step='model'")
         self.networks = None
         self.total = 0
         self._pool, self._pool_pos, self._pools_made = None, 0, 0

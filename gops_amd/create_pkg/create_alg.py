@@ -1,6 +1,8 @@
 """create_alg: algorithms keyed by the upper-camel file name (`fhadp.py` -> "FHADP"); each module exports
 that class and `ApproxContainer` (surface of gops/create_pkg/create_alg.py:47-97).  Parallel trainers are
 one process per GPU here (torch.distributed over RCCL), so every trainer kind gets a plain local object."""
+import inspect
+
 from gops_amd.create_pkg._registry import Registry
 from gops_amd.utils.gops_path import algorithm_path, underline2camel
 
@@ -56,7 +58,7 @@ class LocalActor:
 
     def __getattr__(self, name):
         attr = getattr(self._obj, name)
-        return _RemoteMethod(attr) if callable(attr) else attr
+        return _RemoteMethod(attr) if inspect.ismethod(attr) or inspect.isfunction(attr) else attr
 
 
 def create_alg(**kwargs) -> object:

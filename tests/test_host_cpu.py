@@ -90,6 +90,20 @@ def test_registries_and_error_behaviour():
     assert m.hip_env().repeat_num == 3 and m.hip_env().repeat_last_reward == 1
 
 
+def test_create_alg_hands_out_actor_handles_for_the_ray_trainers():
+    """For off_sync / off_async the reference's create_alg returns a list of Ray actor handles (create_alg.py:87-93) and
+    the example scripts talk to them through `.remote(...)`; here the list holds this rank's replica behind the same
+    call syntax, and the trainers unwrap it."""
+    from gops_amd.create_pkg.create_alg import LocalActor, create_alg
+    algs = create_alg(**dict(_fhadp_kwargs(), trainer="off_async_trainer"))
+    assert isinstance(algs, list) and len(algs) == 1 and isinstance(algs[0], LocalActor)
+    for a in algs:
+        a.set_parameters.remote({"gamma": 0.95})          # the scripts' idiom
+    assert algs[0].unwrap().gamma == 0.95 and algs[0].get_parameters.remote()["gamma"] == 0.95
+    assert algs[0].networks is algs[0].unwrap().networks   # plain attributes pass through
+    assert not isinstance(create_alg(**dict(_fhadp_kwargs(), trainer="on_sync_trainer")), list)   # (create_alg.py:80-85)
+
+
 def test_state_dict_layout_and_parameter_api():
     from gops_amd.create_pkg.create_alg import create_alg
     alg = create_alg(**_fhadp_kwargs())

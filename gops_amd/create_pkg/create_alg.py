@@ -1,6 +1,7 @@
 """create_alg: algorithms keyed by the upper-camel file name (`fhadp.py` -> "FHADP"); each module exports
 that class and `ApproxContainer` (surface of gops/create_pkg/create_alg.py:47-97).  Parallel trainers are
-one process per GPU here (torch.distributed over RCCL), so every trainer kind gets a plain local object."""
+one process per GPU here (torch.distributed over RCCL): every trainer kind gets this rank's local object - for the
+off_sync / off_async trainers behind the list-of-actor-handles shape the reference's scripts expect (`LocalActor`)."""
 import inspect
 
 from gops_amd.create_pkg._registry import Registry

@@ -501,3 +501,25 @@ def test_constrained_env_step_vs_reference_fixture(name, dev):
         if f"s{s}/surr_state" in g:
             np.testing.assert_allclose(info["surr_state"].cpu().numpy(), g[f"s{s}/surr_state"], rtol=1e-5, atol=2e-5)
         np.testing.assert_allclose(info["constraint"].cpu().numpy(), g[f"s{s}/constraint"], rtol=1e-5, atol=5e-5)
+
+
+def test_default_reference_constants_are_the_same_on_both_sides_of_the_abi(dev):
+    """GopsEnv.ref_custom = 0 lets the library fill in the default reference-trajectory constants; the Python side
+    (`resources/ref_traj_params.ref_constants()`) folds the same defaults for custom parameter sets.  Handing the
+    Python-folded DEFAULTS over as a custom set must give bit-identical steps."""
+    from gops_amd import hip_backend as hb
+    from gops_amd.env.env_ocp.resources.ref_traj_params import ref_constants
+    g = load_golden("step_veh_p10")
+    meta = golden_meta(g)
+    oenv = oracle_env(meta["cfg"], meta["extra"], g)
+    env0 = hip_env_from_oracle(oenv)
+    env1 = hip_env_from_oracle(oenv)
+    env1.ref_custom = 1
+    for i, v in enumerate(ref_constants()):
+        env1.ref_c[i] = v
+    data = to_device(data_from_golden(g), dev)
+    info = {k: data[k] for k in INFO_KEYS if k in data}
+    a = torch.from_numpy(g["s0/act"]).to(dev)
+    o0, r0, d0, i0 = hb.env_step(env0, data["obs"], a, data["done"], info)
+    o1, r1, d1, i1 = hb.env_step(env1, data["obs"], a, data["done"], info)
+    assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(i0["ref_points"], i1["ref_points"])

@@ -630,7 +630,8 @@ int gops_rollout_backward_open_loop(const GopsRolloutDesc* desc, const GopsRollo
 int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream) {
     if (!env || !io || batch < 1) return GOPS_ERR_BAD_ARG;
     if (env->kind < GOPS_ENV_LQ || env->kind > GOPS_ENV_VEH2DOF) return GOPS_ERR_BAD_ARG;
-    if (env->kind >= GOPS_ENV_PENDULUM && env->data_env) return GOPS_ERR_UNSUPPORTED;   // these data envs are not restated (cartpole is)
+    if (env->data_env && (env->kind == GOPS_ENV_PENDULUM || (env->kind == GOPS_ENV_VEH2DOF && env->cstr_err)))
+        return GOPS_ERR_UNSUPPORTED;   // these data envs are not restated
     if (!io->obs || !io->action || !io->next_obs || !io->reward || !io->next_done) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_VEH3DOF_SURR &&
         (env->data_env || env->n_surr < (env->cstr_err ? 0 : 1) || env->n_surr > (env->cstr_err ? 0 : GOPS_MAX_SURR) ||

@@ -1132,6 +1132,7 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         rout[2 * P] = newp[1]; rout[2 * P + 1] = newp[2];
         const float o0 = sn[0] - rout[0], o1 = sn[1] - rout[1];
         done_m = (fabsf(o0) > 2.f) || (fabsf(o1) > 3.14159265358979323846f);
+        if (data && done_m) r -= 100.f;   // data env (pyth_veh2dofconti.py:179-219): the model's step, -100 at done
         if (dn) {
             for (int i = 0; i < O; ++i) nob[i] = ob[i];
         } else {

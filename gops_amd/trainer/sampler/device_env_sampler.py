@@ -6,7 +6,7 @@ section 8(f) rank 3).  The data environments of this path share their dynamics a
 models but NOT their termination rules or terminal reward (pyth_veh3dofconti.py:224-226,263-271: -100 at done,
 world-frame |dx| > 5, |dy| > 2 against the model's ego-frame 10 / 10; lq_base.py:224-239: done when the state leaves
 its bounds, -100, no clipping; pyth_idpendulum.py:71-87 is identical to its model; gym_cartpoleconti.py:102-137: reward 1
-also for the step that ends an episode).  `env_step="data"` (default)
+also for the step that ends an episode; pyth_veh2dofconti.py:179-219: the model's step, -100 at done).  `env_step="data"` (default)
 selects those data-env semantics in the step kernel (`GopsEnv.data_env`, checked against transitions recorded from the
 reference's numpy envs: tests/golden/dataenv_*.npz); `env_step="model"` steps the env model instead.  N environment
 instances are advanced together by `gops_env_step`:
@@ -50,9 +50,11 @@ class DeviceEnvSampler:
             raise ValueError("env_step must be 'data' (the data environment's step) or 'model' (the env model's)")
         self.data_env = env_step == "data"
         kind = getattr(getattr(env_model, "unwrapped", env_model), "hip_kind", None)
-        if self.data_env and kind not in (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_VEH, hb.ENV_CARTPOLE):
+        if self.data_env and (kind not in (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_VEH, hb.ENV_CARTPOLE, hb.ENV_VEH2DOF)
+                              or self.cfg.get("env_id", "").endswith("errcstr")):
             raise RuntimeError(f"the DATA environment of {self.cfg.get('env_id')} is not restated in the step kernel "
-                               "(pyth_lq, pyth_idpendulum, pyth_veh3dofconti and gym_cartpoleconti are): pass env_step='model'")
+                               "(pyth_lq, pyth_idpendulum, pyth_veh3dofconti, pyth_veh2dofconti and gym_cartpoleconti are): "
+                               "pass env_step='model'")
         self.networks = None
         self.total = 0
         self._pool, self._pool_pos, self._pools_made = None, 0, 0

@@ -664,6 +664,7 @@ DATA_ENV_CASES = {
     "dataenv_idp": dict(env_id="pyth_idpendulum"),
     "dataenv_lq_s2a1_shaped": dict(env_id="pyth_lq", lq_config="s2a1", reward_scale=0.5, reward_shift=1.0),
     "dataenv_cartpole": dict(env_id="gym_cartpoleconti", reward_scale=0.5),
+    "dataenv_veh2dof_p10": dict(env_id="pyth_veh2dofconti", pre_horizon=10),
 }
 
 
@@ -767,6 +768,8 @@ if __name__ == "__main__":
         golden_data_envs()
     if "dataenv_cartpole" in which:
         golden_data_envs(only=("dataenv_cartpole",))
+    if "dataenv_veh2dof" in which:
+        golden_data_envs(only=("dataenv_veh2dof_p10",))
     if "constrained" in which:
         golden_constrained()
     if "fhadp2" in which:

@@ -437,7 +437,7 @@ def test_stationary_staged_variants_match_oracle(cfg, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped", "dataenv_cartpole"])
+@pytest.mark.parametrize("name", ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped", "dataenv_cartpole", "dataenv_veh2dof_p10"])
 def test_data_env_step_vs_reference_numpy_envs(name, dev):
     """gops_env_step with GopsEnv.data_env = 1 (what DeviceEnvSampler steps) against transitions recorded from the
     reference's numpy DATA envs: terminal -100, data-env termination tests, no observation clipping."""
@@ -456,7 +456,8 @@ def test_data_env_step_vs_reference_numpy_envs(name, dev):
     # `done` is ignored in data-env mode: pass ones to prove it
     nobs, r, done, ninfo = hb.env_step(henv, t["obs"].to(dev), t["act"].to(dev), torch.ones(B, device=dev), dinfo)
     check_data_env_transitions(nobs.cpu().numpy(), r.cpu().numpy(), done.cpu().numpy(),
-                               {k: v.cpu().numpy() for k, v in ninfo.items()}, t, oenv["kind"] == "veh")
+                               {k: v.cpu().numpy() for k, v in ninfo.items()}, t,
+                               "veh2" if oenv["kind"] == "veh2" else oenv["kind"] == "veh")
     # the model-step mode on the same inputs differs exactly where the two sets of rules differ
     henv.data_env = 0
     _, r_m, done_m, _ = hb.env_step(henv, t["obs"].to(dev), t["act"].to(dev), torch.zeros(B, device=dev), dinfo)

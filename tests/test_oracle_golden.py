@@ -134,7 +134,7 @@ def test_fhadp2_gradient_matches_reference(name):
         assert rel_l2(gr, g[f"grad/{i}"]) < 1e-5, (name, i)
 
 
-DATA_ENV_CASES = ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped", "dataenv_cartpole"]
+DATA_ENV_CASES = ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped", "dataenv_cartpole", "dataenv_veh2dof_p10"]
 
 
 def _dataenv_inputs(g):
@@ -151,6 +151,14 @@ def check_data_env_transitions(got_obs2, got_rew, got_done, got_info, t, veh):
     want_o, got_o = t["obs2"].numpy(), np.asarray(got_obs2)
     assert np.array_equal(np.asarray(got_done) != 0, t["done"].numpy() != 0)
     np.testing.assert_allclose(np.asarray(got_rew), t["rew"].numpy(), rtol=2e-5, atol=2e-4)
+    if veh == "veh2":   # obs holds y offsets only; the appended point's HEADING is the finite-difference one (ref_points[:, -1, 1])
+        np.testing.assert_allclose(got_o, want_o, rtol=1e-5, atol=5e-5)
+        np.testing.assert_allclose(np.asarray(got_info["state"]), t["next_state"].numpy(), rtol=1e-5, atol=2e-5)
+        rp, want_rp = np.asarray(got_info["ref_points"]), t["next_ref_points"].numpy()
+        np.testing.assert_allclose(rp[:, :, 0], want_rp[:, :, 0], rtol=1e-5, atol=5e-5)
+        np.testing.assert_allclose(rp[:, :-1, 1], want_rp[:, :-1, 1], rtol=1e-5, atol=2e-5)
+        assert np.abs(rp[:, -1, 1] - want_rp[:, -1, 1]).max() < 5e-3
+        return
     if not veh:
         np.testing.assert_allclose(got_o, want_o, rtol=1e-5, atol=2e-5)
         return
@@ -175,7 +183,7 @@ def test_data_env_step_matches_reference_numpy_envs(name):
     t, info = _dataenv_inputs(g)
     assert t["done"].sum() > 0 or "shaped" in name
     nobs, r, done, ninfo = orc.data_env_forward(env, t["obs"], t["act"], info)
-    check_data_env_transitions(nobs, r, done, ninfo, t, env["kind"] == "veh")
+    check_data_env_transitions(nobs, r, done, ninfo, t, "veh2" if env["kind"] == "veh2" else env["kind"] == "veh")
 
 
 CSTR_STEP_CASES = ["step_veh_surrcstr_p10", "step_veh_detour_p10", "step_veh_surrcstr_p5_n2", "step_veh_surrpen_p10",

@@ -92,6 +92,9 @@ struct RolloutParams {
     float* gscale;                    // f16 backward: gscale[0] = max|grad_v| of the launch (upload_params_kernel)
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double
 };
+// upload_params_kernel / prologue_kernel take the block BY VALUE: it has to fit the 4 KiB kernel-argument segment
+static_assert(sizeof(RolloutParams) <= 3840, "RolloutParams outgrew the kernel-argument segment (move gpow[] out)");
+
 
 // per-phase cycle accounting of block 0 / thread 0 (debug builds of the timing knob only)
 #ifdef GOPS_DBG_BUILD   // make -C gops_amd/csrc DBG=1 : in-kernel phase timing (costs ~32 VGPRs)

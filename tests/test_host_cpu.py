@@ -90,6 +90,31 @@ def test_registries_and_error_behaviour():
     assert m.hip_env().repeat_num == 3 and m.hip_env().repeat_last_reward == 1
 
 
+def test_reference_trajectory_constants_fold_like_the_reference():
+    """`ref_constants` (GopsEnv.ref_c): the caller's path_para / u_para update the default set per profile (unknown profile
+    names raise like the reference's dict update), and every derived constant is folded in double where the reference
+    multiplies Python scalars."""
+    import math
+    from gops_amd.env.env_ocp.resources.ref_traj_params import merged, ref_constants
+    c = ref_constants()
+    w = 2 * math.pi / 10
+    assert len(c) == 24 and c[:7] == [-1.0 / w, w, 0.0, 5.0, 1.0 / w, 1.0, 5.0]
+    assert c[7:10] == [1.5, w, 0.0] and c[10:18] == [5.0, 9.0, 14.0, 18.0, 0.0, 3.5, 0.875, -0.875]
+    assert c[18:23] == [10.0, 0.6, -0.6, 5.0, 100.0]
+    c2 = ref_constants({"double_lane": {"y2": 3.0, "t2": 8.5}}, {"sine": {"phi": 0.2, "A": 1.5}})
+    assert c2[16] == (3.0 - 0.0) / (8.5 - 5.0) and c2[17] == (0.0 - 3.0) / (18.0 - 14.0)
+    assert c2[0] == -1.5 / w and c2[4] == 1.5 / w * math.cos(0.2) and c2[7:10] == c[7:10]
+    path, speed = merged({"circle": {"r": 80.0}}, None)
+    assert path["circle"]["r"] == 80.0 and path["sine"]["A"] == 1.5 and speed["constant"]["u"] == 5.0
+    with pytest.raises(KeyError):
+        ref_constants({"spiral": {"r": 1.0}})
+    from gops_amd.create_pkg import create_env_model
+    m = create_env_model.create_env_model("pyth_veh3dofconti", pre_horizon=10, path_para={"circle": {"r": 80.0}})
+    e = m.hip_env()
+    assert e.ref_custom == 1 and e.ref_c[22] == 80.0
+    assert create_env_model.create_env_model("pyth_veh3dofconti", pre_horizon=10).hip_env().ref_custom == 0
+
+
 def test_create_alg_hands_out_actor_handles_for_the_ray_trainers():
     """For off_sync / off_async the reference's create_alg returns a list of Ray actor handles (create_alg.py:87-93) and
     the example scripts talk to them through `.remote(...)`; here the list holds this rank's replica behind the same

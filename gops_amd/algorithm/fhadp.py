@@ -69,10 +69,12 @@ class FHADP(AlgorithmBase):
             opt.step()
             return loss
 
+        opt.grad_scale = 1.0   # (a data-parallel remote_update may have left 1/N behind)
         loss = self._update_graph.run(self._signature(batch), batch, update,
                                       before_replay=opt.sync_hyper, on_replay=opt.advance,
                                       work=batch["obs"].shape[0] * self.pre_horizon,
                                       on_capture_fail=opt.resync_device_state)
+        self._after_gradient(loss)   # host-side schedules: once per computed gradient, eager / captured / replayed alike
         self._log(loss)
         return self.tb_info
 
@@ -85,6 +87,7 @@ class FHADP(AlgorithmBase):
         batch = self._device_batch(data)
         loss = self._grad_graph.run(self._signature(batch), batch, self._gradient_kernels,
                                    work=batch["obs"].shape[0] * self.pre_horizon)
+        self._after_gradient(loss)
         self._fill_tb(loss, lazy=True)                       # device scalars, read at log time
         self.tb_info[tb_tags["alg_time"]] = (time.time() - self._t0) * 1000   # ms of host enqueue time
         return self.tb_info, {"grad": [p._grad for p in self.networks.policy.parameters()]}
@@ -95,6 +98,7 @@ class FHADP(AlgorithmBase):
         opt = self.networks.policy_optimizer
         opt.grad_scale = float(update_info.get("_grad_scale", 1.0))
         opt.step()
+        opt.grad_scale = 1.0   # a later local_update on this object must not inherit the 1/N
 
     # ------------------------------------------------------------------------------------------
     def _rollout_for(self, batch: int, device) -> hb.Rollout:
@@ -147,9 +151,16 @@ class FHADP(AlgorithmBase):
         ro.backward(self._grad_v(B, device), gw, gb)
         return loss_policy
 
+    def _after_gradient(self, out):
+        """Host-side bookkeeping that belongs to ONE computed gradient (penalty / multiplier schedules of the
+        constrained variants).  Called by every update path after the gradient kernels were enqueued - as eager
+        launches, during graph capture, or by graph replay - so a schedule advances exactly like the reference's,
+        which steps it inside `_compute_loss_policy` (fhadp_exterior.py:68-70)."""
+
     def _compute_gradient(self, data, sync=True):
         self._t0 = time.time()
         loss_policy = self._gradient_kernels(self._device_batch(data))
+        self._after_gradient(loss_policy)
         if sync:
             self._log(loss_policy)
         return loss_policy

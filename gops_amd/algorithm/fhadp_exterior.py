@@ -23,12 +23,23 @@ class ConstrainedFHADP(FHADP):
 
     LOG_KEYS: Tuple[str, ...] = ()
 
-    def _constraint_terms(self, v_pi, cs, B):
-        """-> (grad_constraint [3, B], stacked device scalars in LOG_KEYS order)."""
+    def _coef_host(self) -> float:
+        """Host value of the coefficient (penalty / multiplier) the NEXT gradient uses."""
         raise NotImplementedError
 
-    def _after_gradient(self):
-        """Host-side schedule step (penalty / multiplier), once per computed gradient like the reference."""
+    def _constraint_terms(self, v_pi, cs, B, coef):
+        """`coef`: the coefficient as a device tensor [1] -> (grad_constraint [3, B], stacked device scalars in
+        LOG_KEYS order)."""
+        raise NotImplementedError
+
+    def _device_batch(self, data):
+        # The coefficient travels with the batch as a device scalar: a captured update reads it from the graph's
+        # static input (refreshed by the per-replay batch copy), so the schedule below keeps advancing under replay
+        # and a schedule step does not invalidate the graph.
+        batch = super()._device_batch(data)
+        self._coef_used = float(self._coef_host())
+        batch["_coef"] = torch.full((1,), self._coef_used, dtype=torch.float32, device=batch["obs"].device)
+        return batch
 
     def _gradient_kernels(self, batch):
         B, device = batch["obs"].shape[0], batch["obs"].device
@@ -37,11 +48,9 @@ class ConstrainedFHADP(FHADP):
             raise RuntimeError(f"{type(self).__name__} needs a model with constraint outputs "
                                "(pyth_veh3dofconti_surrcstr / _detour / _errcstr) and its info in the batch")
         res = ro.forward(batch)
-        gc, scalars = self._constraint_terms(res["v_pi"], res["constraint_sums"], B)
+        gc, scalars = self._constraint_terms(res["v_pi"], res["constraint_sums"], B, batch["_coef"])
         gw, gb = grad_buffers(self.networks.policy)
         ro.backward(self._grad_v(B, device), gw, gb, grad_constraint=gc)
-        if not torch.cuda.is_current_stream_capturing():
-            self._after_gradient()
         return scalars
 
     def _fill_tb(self, out, lazy=False):
@@ -68,20 +77,19 @@ class FHADPExterior(ConstrainedFHADP):
     def adjustable_parameters(self) -> Tuple[str]:
         return (*super().adjustable_parameters, "penalty", "penalty_increase", "penalty_delay")
 
-    def _extra_signature(self):
-        return (float(self.penalty),)
+    def _coef_host(self):
+        return self.penalty
 
-    def _constraint_terms(self, v_pi, cs, B):
+    def _constraint_terms(self, v_pi, cs, B, coef):
         loss_reward, loss_constraint = -v_pi.mean(), cs[0].mean()
         gc = torch.zeros(3, B, dtype=torch.float32, device=v_pi.device)
-        gc[0] = self.penalty / B
-        self._penalty_used = self.penalty
-        return gc, torch.stack((loss_reward + self.penalty * loss_constraint, loss_reward, loss_constraint))
+        gc[0] = coef / B
+        return gc, torch.stack(((loss_reward + coef * loss_constraint).reshape(()), loss_reward, loss_constraint))
 
-    def _after_gradient(self):   # fhadp_exterior.py:68-70
+    def _after_gradient(self, out):   # fhadp_exterior.py:68-70
         self.update_step += 1
         if self.update_step % self.penalty_delay == 0:
             self.penalty = min(self.penalty * self.penalty_increase, self.max_penalty)
 
-    def _fill_host_tb(self):
+    def _fill_host_tb(self):   # the reference logs the coefficient AFTER the schedule step (fhadp_exterior.py:72-77)
         self.tb_info["Loss/Penalty coefficient-RL iter"] = self.penalty

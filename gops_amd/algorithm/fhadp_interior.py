@@ -32,21 +32,21 @@ class FHADPInterior(ConstrainedFHADP):
     def adjustable_parameters(self) -> Tuple[str]:
         return (*super().adjustable_parameters, "penalty", "penalty_increase", "penalty_delay")
 
-    def _extra_signature(self):
-        return (float(self.penalty),)
+    def _coef_host(self):
+        return self.penalty
 
-    def _constraint_terms(self, v_pi, cs, B):
+    def _constraint_terms(self, v_pi, cs, B, coef):
         feasible = cs[3]
         loss_reward = -v_pi.mean()
         loss_int = (cs[2] * feasible).mean()
         loss_ext = (cs[0] * (1.0 - feasible)).mean()
         gc = torch.zeros(3, B, dtype=torch.float32, device=v_pi.device)
-        gc[2] = feasible * (1.0 / (self.penalty * B))
-        gc[0] = (1.0 - feasible) * (self.penalty / B)
-        loss = loss_reward + (1.0 / self.penalty) * loss_int + self.penalty * loss_ext
+        gc[2] = feasible * (1.0 / (coef * B))
+        gc[0] = (1.0 - feasible) * (coef / B)
+        loss = (loss_reward + (1.0 / coef) * loss_int + coef * loss_ext).reshape(())
         return gc, torch.stack((loss, loss_reward, loss_ext, feasible.mean()))
 
-    def _after_gradient(self):   # fhadp_interior.py:80-82
+    def _after_gradient(self, out):   # fhadp_interior.py:80-82
         self.update_step += 1
         if self.update_step % self.penalty_delay == 0:
             self.penalty = min(self.penalty * self.penalty_increase, self.max_penalty)

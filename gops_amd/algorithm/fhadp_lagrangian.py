@@ -31,7 +31,6 @@ class FHADPLagrangian(ConstrainedFHADP):
         self.multiplier_optim = Adam([self.multiplier_param], lr=multiplier_lr)
         self.multiplier_lr, self.multiplier_delay = multiplier_lr, multiplier_delay
         self.update_step = 0
-        self._last_violation = None
 
     @property
     def multiplier(self) -> float:
@@ -46,24 +45,23 @@ class FHADPLagrangian(ConstrainedFHADP):
     def adjustable_parameters(self) -> Tuple[str]:
         return (*super().adjustable_parameters, "multiplier", "multiplier_lr", "multiplier_delay")
 
-    def _extra_signature(self):
-        return (float(self.multiplier),)
+    def _coef_host(self):
+        return self.multiplier
 
-    def _constraint_terms(self, v_pi, cs, B):
-        mult = self.multiplier
+    def _constraint_terms(self, v_pi, cs, B, coef):
         loss_reward, loss_constraint = -v_pi.mean(), cs[1].mean()
         gc = torch.zeros(3, B, dtype=torch.float32, device=v_pi.device)
-        gc[1] = mult / B
-        self._last_violation = loss_constraint
-        return gc, torch.stack((loss_reward + mult * loss_constraint, loss_reward, loss_constraint))
+        gc[1] = coef / B
+        return gc, torch.stack(((loss_reward + coef * loss_constraint).reshape(()), loss_reward, loss_constraint))
 
-    def _after_gradient(self):   # fhadp_lagrangian.py:72-77 (the host reads the mean violation only every `multiplier_delay` updates)
+    def _after_gradient(self, out):   # fhadp_lagrangian.py:72-77 (the host reads the mean violation only every `multiplier_delay` updates)
         self.update_step += 1
         if self.update_step % self.multiplier_delay == 0:
-            multiplier_loss = -self.multiplier_param * self._last_violation.item()
+            # out[2] = mean violation of THIS gradient: the eager result, or the captured graph's static output
+            multiplier_loss = -self.multiplier_param * out[2].item()
             self.multiplier_optim.zero_grad()
             multiplier_loss.backward()
             self.multiplier_optim.step()
 
-    def _fill_host_tb(self):
-        self.tb_info["Loss/Lagrange multiplier-RL iter"] = self.multiplier
+    def _fill_host_tb(self):   # the reference logs the multiplier the loss was formed with (fhadp_lagrangian.py:70, 83)
+        self.tb_info["Loss/Lagrange multiplier-RL iter"] = self._coef_used

@@ -85,6 +85,7 @@ class INFADP(AlgorithmBase):
             self._update([mode])
             return scalars
 
+        opt.grad_scale = 1.0   # (a data-parallel remote_update may have left 1/N behind)
         cache = self._graphs.setdefault(mode, StepGraphCache())
         scalars = cache.run(self._signature(mode, batch), batch, update, before_replay=opt.sync_hyper,
                             on_replay=opt.advance, work=batch["obs"].shape[0] * self.forward_step,
@@ -116,6 +117,8 @@ class INFADP(AlgorithmBase):
                 p.grad = grad
             self.networks.optimizer_dict[net_name].grad_scale = float(update_info.get("_grad_scale", 1.0))
         self._update(names)
+        for net_name in names:   # a later local_update on this object must not inherit the 1/N
+            self.networks.optimizer_dict[net_name].grad_scale = 1.0
 
     def _update(self, update_list):
         tau = self.tau

@@ -80,6 +80,11 @@ class MPG(AlgorithmBase):
         super().__init__(index, **kwargs)
         self.networks = ApproxContainer(**kwargs)
         self.envmodel = create_env_model(**kwargs)
+        # the model return's sweep is gops_rollout_backward_adj: built for the models whose observation is the state
+        kind = getattr(getattr(self.envmodel, "model", self.envmodel), "hip_kind", None)
+        if kind is not None and kind not in (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_CARTPOLE, hb.ENV_PENDULUM):
+            raise RuntimeError(f"MPG on the HIP path supports pyth_lq, pyth_idpendulum, gym_cartpoleconti and gym_pendulum models "
+                               f"(adjoint I/O of the rollout sweep); env model '{kwargs.get('env_id')}' is not among them")
         self.pge_method = kwargs["pge_method"]
         if self.pge_method == "mixed_weight":
             self.terminal_iter = terminal_iter

@@ -18,8 +18,13 @@ receive fresh weights.  A gradient is therefore at most one round trip old, as i
 applied gradients (the reference's `self.iteration`); rank 0 logs, saves and evaluates.
 
 Wire format (one fixed-size fp32 message per direction, so both sides can post their receives up front):
-    worker -> center : [net index, gradient of that net (flat, parameters() order), zero padding]
+    worker -> center : [key style | presence flag per gradient slot | presence flag + value per scalar slot |
+                        one region per trainable network of the container (flat, parameters() order; zeros when absent)]
     center -> worker : [stop flag, every parameter and buffer of the container (flat)]
+A gradient slot is a trainable child network of the container; `update_info` may name it "<net>" (INFADP / SPIL: any
+subset per iteration, SPIL ships "v" AND "policy"), "<net>_grad" (MPG: q1 / q2 / [q1_model / q2_model] / policy) or
+"grad" (FHADP: the policy); scalar entries (MPG's "iteration") travel in the header.  The layout is derived from the
+container alone, so it is identical on every rank before the first message.
 """
 import torch
 import torch.distributed as dist
@@ -50,17 +55,18 @@ class OffAsyncTrainer(OffSerialTrainer):
         self.n = world_size()
         self._state = [p.data for p in self.networks.parameters()] + [b.data for b in self.networks.buffers()]
         device = self._state[0].device
-        # the nets a gradient can belong to, in a fixed order shared by all ranks (FHADP: "grad"; INFADP: "policy", "v")
-        self._net_params = {}
-        nd = getattr(self.networks, "net_dict", None)
-        if nd:
-            for name in sorted(nd):
-                self._net_params[name] = list(nd[name].parameters())
-        else:
-            self._net_params["grad"] = list(self.networks.policy.parameters())
-        self._net_names = sorted(self._net_params)
-        gmax = max(sum(p.numel() for p in ps) for ps in self._net_params.values())
-        self._grad_msg = torch.zeros(1 + gmax, dtype=torch.float32, device=device)
+        # gradient slots: every child network with trainable parameters, in a fixed (sorted) order shared by all ranks
+        self._slots = []      # (net name, parameters, offset of its region in the message body)
+        off = 0
+        for name, mod in sorted(self.networks.named_children()):
+            params = [p for p in mod.parameters() if p.requires_grad]
+            if params:
+                self._slots.append((name, params, off))
+                off += sum(p.numel() for p in params)
+        self._slot_of = {name: i for i, (name, _, _) in enumerate(self._slots)}
+        self._scalar_names = ("iteration",)
+        self._head = 1 + len(self._slots) + 2 * len(self._scalar_names)   # [key style | slot flags | (flag, value) per scalar]
+        self._grad_msg = torch.zeros(self._head + off, dtype=torch.float32, device=device)
         self._weight_msg = torch.zeros(1 + sum(t.numel() for t in self._state), dtype=torch.float32, device=device)
         self._stop = False
         self.local_iteration = 0          # this rank's own gradient count (drives INFADP's PEV / PIM alternation)
@@ -75,20 +81,52 @@ class OffAsyncTrainer(OffSerialTrainer):
             self._inbox = torch.zeros_like(self._grad_msg)
 
     # ---- message packing ----------------------------------------------------------------------
+    def _slot_index(self, key: str) -> int:
+        for cand in (key, key[:-5] if key.endswith("_grad") else None, "policy" if key == "grad" else None):
+            if cand is not None and cand in self._slot_of:
+                return self._slot_of[cand]
+        raise ValueError(f"off_async_trainer: update_info entry '{key}' names no trainable network of "
+                         f"{type(self.networks).__name__} (slots: {[n for n, _, _ in self._slots]})")
+
     def _pack_grad(self, update_info):
-        name = next(k for k in update_info if not k.startswith("_"))
-        flat = _flatten_dense_tensors([g.reshape(-1) for g in update_info[name]])
-        self._grad_msg.zero_()
-        self._grad_msg[0] = float(self._net_names.index(name))
-        self._grad_msg[1:1 + flat.numel()] = flat
-        return self._grad_msg
+        """Every gradient list and every known scalar of `update_info` (entries starting with "_" are local hints)."""
+        msg = self._grad_msg
+        msg.zero_()
+        keys = [k for k, v in update_info.items() if not k.startswith("_") and isinstance(v, (list, tuple))]
+        # how this algorithm class names its gradient lists: "grad" (FHADP), "<net>_grad" (MPG) or "<net>"
+        msg[0] = 2.0 if keys == ["grad"] else (1.0 if keys and all(k.endswith("_grad") for k in keys) else 0.0)
+        for key, val in update_info.items():
+            if key.startswith("_"):
+                continue
+            if isinstance(val, (list, tuple)):
+                i = self._slot_index(key)
+                _, params, off = self._slots[i]
+                if len(val) != len(params):
+                    raise ValueError(f"off_async_trainer: '{key}' carries {len(val)} tensors, the network has {len(params)}")
+                flat = _flatten_dense_tensors([g.reshape(-1) for g in val])
+                msg[1 + i] = 1.0
+                msg[self._head + off:self._head + off + flat.numel()] = flat
+            elif key in self._scalar_names:
+                j = 1 + len(self._slots) + 2 * self._scalar_names.index(key)
+                msg[j], msg[j + 1] = 1.0, float(val)
+            else:
+                raise ValueError(f"off_async_trainer: cannot ship update_info['{key}'] ({type(val).__name__})")
+        return msg
 
     def _unpack_grad(self, msg):
-        name = self._net_names[int(round(float(msg[0].item())))]
-        params = self._net_params[name]
-        n = sum(p.numel() for p in params)
-        grads = _unflatten_dense_tensors(msg[1:1 + n], [p.data for p in params])
-        return {name: [g.clone() for g in grads]}
+        head = msg[:self._head].tolist()   # one host read for style, flags and scalars
+        style = int(round(head[0]))
+        info = {}
+        for i, (name, params, off) in enumerate(self._slots):
+            if head[1 + i] != 0.0:
+                n = sum(p.numel() for p in params)
+                grads = _unflatten_dense_tensors(msg[self._head + off:self._head + off + n], [p.data for p in params])
+                info[{0: name, 1: name + "_grad", 2: "grad"}[style]] = [g.clone() for g in grads]
+        for k, sname in enumerate(self._scalar_names):
+            j = 1 + len(self._slots) + 2 * k
+            if head[j] != 0.0:
+                info[sname] = int(round(head[j + 1]))   # (fp32 header: exact up to 2^24 iterations)
+        return info
 
     def _pack_weights(self, stop: bool):
         self._weight_msg[0] = 1.0 if stop else 0.0

@@ -400,6 +400,57 @@ def test_constrained_fhadp_classes_match_reference(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["fhadp_ext_surrcstr", "fhadp_int_detour", "fhadp_lag_surrcstr"])
+def test_constrained_fhadp_schedule_advances_under_graph_replay(name, monkeypatch):
+    """The penalty / multiplier schedule is host-side bookkeeping of every computed gradient (reference:
+    fhadp_exterior.py:68-70, fhadp_interior.py:80-82, fhadp_lagrangian.py:72-77).  With the update captured as a HIP
+    graph the coefficient is a graph INPUT (it travels with the batch), so over 9 updates a graph learner and an eager
+    learner walk the same schedule and stay bit-identical, and the graph is captured once and kept."""
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg, extra = meta["cfg"], meta["extra"]
+    sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("sd/")}
+    data = data_from_golden(g)
+    algs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GOPS_HIP_GRAPH", flag)
+        kw = _kwargs(cfg, {}, meta["seed"])
+        kw.update(extra)
+        kw.update(algorithm=cfg["alg"], policy_func_name="FiniteHorizonPolicy", pre_horizon=cfg["pre_horizon"])
+        if "surr_veh_num" in cfg:
+            kw["surr_veh_num"] = cfg["surr_veh_num"]
+        alg = create_alg(**kw)
+        alg.gamma = cfg["gamma"]
+        alg.load_state_dict(sd)
+        alg.networks.to("cuda")
+        if hasattr(alg, "penalty"):
+            alg.penalty_delay = 2
+        else:
+            alg.multiplier_delay = 2
+        algs.append(alg)
+    coef = lambda a: a.penalty if hasattr(a, "penalty") else a.multiplier
+    c0 = coef(algs[0])
+    trace = []
+    for it in range(9):
+        infos = []
+        for alg, flag in zip(algs, ("1", "0")):
+            monkeypatch.setenv("GOPS_HIP_GRAPH", flag)
+            infos.append(dict(alg.local_update(data, it)))
+        strip = lambda d: {k: v for k, v in d.items() if "time" not in k.lower()}
+        assert strip(infos[0]) == strip(infos[1]), (it, infos)
+        assert coef(algs[0]) == coef(algs[1])
+        trace.append(coef(algs[0]))
+    assert algs[0].update_step == algs[1].update_step == 9
+    assert algs[0]._update_graph.graph is not None and algs[1]._update_graph.graph is None
+    if hasattr(algs[0], "penalty"):   # four schedule steps in nine updates (delay 2)
+        assert trace[-1] == pytest.approx(c0 * algs[0].penalty_increase ** 4)
+    else:                             # violation > 0 in this fixture: the multiplier keeps rising, also under replay
+        assert trace[-1] > trace[4] > c0
+    for a, b in zip(algs[0].networks.parameters(), algs[1].networks.parameters()):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [dict(env_id="pyth_lq", lq_config="s4a2"), dict(env_id="pyth_lq", lq_config="s6a3"),
                                  dict(env_id="pyth_idpendulum"), dict(env_id="pyth_veh3dofconti", pre_horizon=10)],
                          ids=lambda c: c["env_id"][5:] + c.get("lq_config", ""))

@@ -718,3 +718,103 @@ def test_off_async_trainer_applies_gradients_in_arrival_order_world_size_3(tmp_p
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert all((tmp_path / f"ok_{k}").exists() for k in range(3))
+
+
+_ASYNC_MULTINET_WORKER = r"""
+import os, sys, time, torch, torch.distributed as dist, numpy as np
+sys.path.insert(0, sys.argv[1])
+from gops_amd.trainer.off_async_trainer import OffAsyncTrainer
+from gops_amd.trainer.buffer.replay_buffer import ReplayBuffer
+dist.init_process_group("gloo")
+r, n = dist.get_rank(), dist.get_world_size()
+STYLE = sys.argv[3]
+
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.q1, self.q2, self.policy = torch.nn.Linear(3, 2), torch.nn.Linear(3, 1), torch.nn.Linear(3, 2)
+        self.q1_target = torch.nn.Linear(3, 2)
+        for p in self.q1_target.parameters():
+            p.requires_grad = False
+        self.net_dict = {"q1": self.q1, "q2": self.q2, "policy": self.policy}
+
+class Alg:   # MPG-shaped ("<net>_grad" lists + the iteration counter) or SPIL-shaped ("v"-like subsets, here q1 / policy alternating + both)
+    def __init__(self):
+        self.networks = Net()
+        self.tb_info = {}
+        self.applied = []
+    def get_remote_update_info(self, data, it):
+        time.sleep(0.004)
+        nets = self.networks
+        g = lambda mod, c: [torch.full_like(p, c) for p in mod.parameters()]
+        if STYLE == "mpg":
+            return self.tb_info, {"q1_grad": g(nets.q1, 1.0 + r), "q2_grad": g(nets.q2, 10.0 + r), "policy_grad": g(nets.policy, 100.0 + r),
+                                  "iteration": 1000 * r + it}
+        names = [["q1"], ["policy"], ["q1", "policy"]][it % 3]
+        return self.tb_info, {nm: g(nets.net_dict[nm], {"q1": 1.0, "policy": 100.0}[nm] + r) for nm in names}
+    def remote_update(self, info):
+        rec = {}
+        for k, v in info.items():
+            if isinstance(v, list):
+                net = k[:-5] if k.endswith("_grad") else k
+                assert len(v) == 2 and all(t.shape == p.shape for t, p in zip(v, self.networks.net_dict[net].parameters())), k
+                assert all(torch.all(t == v[0].flatten()[0]) for t in v), k
+                rec[k] = float(v[0].flatten()[0])
+                with torch.no_grad():
+                    for p_, g_ in zip(self.networks.net_dict[net].parameters(), v):
+                        p_ -= 0.001 * g_
+            else:
+                rec[k] = v
+        self.applied.append(rec)
+
+class Sampler:
+    networks = None
+    def sample(self):
+        g = np.random.RandomState(r)
+        return [(g.rand(3).astype(np.float32), np.zeros(1, np.float32), 0.0, False, {}, g.rand(3).astype(np.float32), {}, 0.0)
+                for _ in range(8)], {}
+    def get_total_sample_number(self): return 0
+
+alg = Alg()
+buf = ReplayBuffer(index=r, trainer="off_async_trainer", seed=1, obsv_dim=3, action_dim=1, buffer_max_size=64,
+                   additional_info={}, buffer_device="cpu")
+tr = OffAsyncTrainer(alg, Sampler(), buf, None, max_iteration=30, log_save_interval=1000, apprfunc_save_interval=1000,
+                     eval_interval=10 ** 9, save_folder=None, ini_network_dir=None, use_gpu=False, buffer_warm_size=16,
+                     replay_batch_size=8, sample_interval=2)
+assert [nm for nm, _, _ in tr._slots] == ["policy", "q1", "q2"]          # trainable nets only, sorted: the frozen target has no slot
+tr.train()
+if r == 0:
+    assert len(alg.applied) == 30 and tr.applied_from[1] > 0, tr.applied_from
+    remote = 0
+    for rec in alg.applied:
+        if STYLE == "mpg":   # every list and the scalar arrive, each from ONE source rank
+            src = int(rec["q1_grad"] - 1.0)
+            assert rec == {"q1_grad": 1.0 + src, "q2_grad": 10.0 + src, "policy_grad": 100.0 + src, "iteration": rec["iteration"]}, rec
+            assert rec["iteration"] // 1000 == src
+            remote += src
+        else:                # one or two nets per message, never a dropped one
+            assert set(rec) in ({"q1"}, {"policy"}, {"q1", "policy"}), rec
+            srcs = {int(v - {"q1": 1.0, "policy": 100.0}[k]) for k, v in rec.items()}
+            assert len(srcs) == 1
+            remote += srcs.pop()
+    assert remote == tr.applied_from[1]
+    if STYLE != "mpg":
+        assert any(len(rec) == 2 for rec in alg.applied)
+dist.destroy_process_group()
+open(os.path.join(sys.argv[2], f"ok_{r}"), "w").write("ok")
+"""
+
+
+@pytest.mark.parametrize("style,port", [("mpg", 29687), ("spil", 29688)])
+def test_off_async_trainer_ships_every_gradient_list_and_scalar(tmp_path, style, port):
+    """update_info of the multi-network algorithms crosses the wire whole: MPG's {q1_grad, q2_grad, policy_grad, iteration}
+    and SPIL's per-iteration subsets ({v}, {policy} or both) - world size 2, gloo."""
+    script = tmp_path / "worker.py"
+    script.write_text(_ASYNC_MULTINET_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(tmp_path), style],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert all((tmp_path / f"ok_{k}").exists() for k in range(2))

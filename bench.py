@@ -5,7 +5,9 @@ A "step" is one trainer iteration of the hot path on one batch: FHADP `compute_g
 forward rollout + backward sweep + weight-gradient GEMMs through libgops_hip.so), the gradient
 all-reduce when N > 1, and the Adam update.  Inputs are synthetic and already resident in HBM.
 Metric (BASELINE.json): env-model steps/s = N * B * H * K / wall time, weak scaling (per-GPU batch
-fixed).  Launch for N > 1:  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
+fixed).  N > 1:  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...  - or plain
+`python bench.py --gpus N`, which starts the N ranks itself.  The default 1-GPU run also times every other
+BASELINE.json workload briefly and reports them in the `workloads` field of the one JSON line.
 """
 import argparse
 import contextlib
@@ -181,42 +183,65 @@ def pmc_traffic(pmc, source, kernel_key):
     return {"bytes": max(hits), "source": source} if hits else None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="target_veh3dof_fhadp_b4096_h30")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16"],
-                    help="arithmetic of the MLP contractions: fp32 (exact, parity path) or fp16 (half-precision MFMA, BASELINE cfg5)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager-gpu-baseline", action=argparse.BooleanOptionalAction, default=True,
-                    help="also time the oracle restatement as PyTorch eager ops on the GPU (FHADP workloads; ~1 s; reported "
-                         "inside cpu_baseline as eager_gpu_steps_per_s)")
-    args = ap.parse_args()
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev_index = local_rank % torch.cuda.device_count()   # (== local_rank on a node with >= N GPUs)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL ("nccl") is the product path; GOPS_BENCH_BACKEND=gloo only exists to exercise this
-        # script's multi-rank logic on a single-GPU box (ranks then share the device)
-        backend = os.environ.get("GOPS_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
 
-    cfg = CONFIGS[args.workload]
+def relaunch_distributed(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (same contract as the driver's
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`).  On a box with
+    fewer than N GPUs the ranks share the devices and exchange gradients over gloo - this exercises the N > 1 code
+    path (rendezvous, per-rank shards, collective, deferred 1/N, max-over-ranks timing) and says so in the JSON line."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < args.gpus:
+        env.setdefault("GOPS_BENCH_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def roofline_of(cfg, dt, kern, pmc, pmc_src, workload):
+    """Roofline record of the slowest of the three rollout kernels (forward, sweep, weight-gradient group)."""
+    B, H = cfg["batch"], cfg["horizon"]
+    tail = cfg["alg"] == "INFADP"
+    flops = {0: 2.0 * (mac_per_step(cfg) * B * H + (mac_per_step(cfg, "value") * B if tail else 0)),
+             2: 2.0 * mac_per_step(cfg) * B * H}
+    flops[1] = flops[0]
+    flops.update({3: 2.0 * mac_per_step(cfg, "value") * B, 4: 2.0 * mac_per_step(cfg, "value") * B,
+                  5: 2.0 * mac_per_step(cfg, "value") * B})
+    bps = bytes_per_step(cfg, dt)
+    alg_bytes = {0: 0.5 * bps * B * H, 1: 0.5 * bps * B * H, 2: 0.5 * bps * B * H}   # stash written once / read once / read once
+    dom = max((0, 1, 2), key=lambda k: kern[k][0])
+    dom_ms = kern[dom][0]
+    peak_tf = MFMA_PEAK_TFLOPS[dt]
+    if dt == "f32":   # exact-fp32 MFMA: arithmetic intensity 115 FLOP/B >> machine balance -> the matrix pipe binds
+        achieved = flops[dom] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": peak_tf,
+                    "unit": "TFLOP/s", "frac": achieved / peak_tf,
+                    "traffic": pmc_traffic(pmc, pmc_src, KERNEL_NAMES[dom].split("(")[0]),
+                    "algorithmic_flops_per_launch": flops[dom], "avg_ms": dom_ms}
+    else:             # half-precision MFMA is 16x faster: the stash traffic binds (SURVEY 8d, cfg5)
+        achieved = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": pmc_traffic(pmc, pmc_src, KERNEL_NAMES[dom].split("(")[0]),
+                    "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_ms": dom_ms}
+    return roofline, flops
+
+
+def run_workload(workload, dtype, steps, warmup, profile_steps, ctx):
+    """Times `steps` updates of one workload on this rank's GPU (all ranks call it together) and returns the
+    measurements; rank 0 turns them into the record."""
+    rank, world, device, dist = ctx["rank"], ctx["world"], ctx["device"], ctx["dist"]
+    cfg = CONFIGS[workload]
     torch.manual_seed(0)   # identical random-init weights on every replica
     with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
-        alg = create_alg(**alg_kwargs(cfg, 0), mlp_dtype=args.dtype)
+        alg = create_alg(**alg_kwargs(cfg, 0), mlp_dtype=dtype)
     alg.networks.to(device)
     if cfg["alg"] == "INFADP":   # cfg3 / cfg5: one step = one local_update, PEV and PIM alternate
         alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]
@@ -236,90 +261,158 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for it in range(args.warmup):
+    for it in range(warmup):
         step(it)
     barrier()
     t0 = time.perf_counter()
-    for it in range(args.steps):
-        step(args.warmup + it)
+    for it in range(steps):
+        step(warmup + it)
     barrier()
     elapsed = time.perf_counter() - t0
     # Per-kernel durations (roofline): HIP events around each launch on the launch stream.  Events
     # cannot be read back from inside a replayed graph, so the same steps are issued once more as
     # plain launches (same kernels, same batch, same stream) right after the timed region.
+    graph_mode = os.environ.get("GOPS_HIP_GRAPH")
     os.environ["GOPS_HIP_GRAPH"] = "0"
     hb.profile_reset()
     hb.profile_enable(True)
-    for it in range(min(args.steps, 100)):
-        step(args.warmup + args.steps + it)
+    for it in range(profile_steps):
+        step(warmup + steps + it)
     barrier()
     hb.profile_enable(False)
+    if graph_mode is None:
+        del os.environ["GOPS_HIP_GRAPH"]
+    else:
+        os.environ["GOPS_HIP_GRAPH"] = graph_mode
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    kern = {k: hb.profile_read(k) for k in range(6)}
+    hb.profile_reset()
+    del alg, data
+    torch.cuda.empty_cache()
+    return {"elapsed": elapsed, "kern": kern}
 
+
+def record_of(workload, dtype, steps, warmup, world, m):
+    cfg = CONFIGS[workload]
+    B, H = cfg["batch"], cfg["horizon"]
+    dt = "f16" if dtype == "fp16" else "f32"
+    elapsed, kern = m["elapsed"], m["kern"]
+    value = world * B * H * steps / elapsed
+    pmc, pmc_src = pmc_profile(workload, dt)
+    roofline, flops = roofline_of(cfg, dt, kern, pmc, pmc_src, workload)
+    peak_tf = MFMA_PEAK_TFLOPS[dt]
+    bps = bytes_per_step(cfg, dt)
+    # whole-update fractions of both roofs (SURVEY 8d asks for both next to each other)
+    per_step_flops = 6.0 * mac_per_step(cfg)
+    hbm_measured = None
+    if pmc is not None:   # counter bytes of every kernel of one update / the update's time
+        tot = [kernel_bytes(c) * c.get("launches_per_update", 1.0) for c in pmc.values() if kernel_bytes(c) is not None]
+        if tot:
+            hbm_measured = sum(tot) / (elapsed / steps) / 1e9 / HBM_PEAK_GBS
+    alg_name = cfg["alg"]
+    return {
+        "metric": f"env-model steps/sec (batch x H), {alg_name} compute_gradient + update",
+        "value": value, "unit": "env-model steps/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt,
+        "data": "synthetic (seeded initial states, random-init networks)",
+        "config": {"workload": workload, "env_id": cfg["env_id"], "algorithm": alg_name,
+                   "batch_per_gpu": B, "horizon": H, "policy_mlp": mlp_sizes(cfg),
+                   "activation": cfg["act"], "parallelism": f"dp{world}"},
+        "rollouts_per_sec": world * B * steps / elapsed,
+        "roofline": roofline,
+        "flops_fraction": value / world * per_step_flops / (peak_tf * 1e12),
+        "alg_hbm_fraction": value / world * bps / (HBM_PEAK_GBS * 1e9),
+        "hbm_fraction": hbm_measured,
+        "hbm_fraction_source": pmc_src if hbm_measured is not None else None,
+        "kernels_ms": {KERNEL_NAMES[k]: {"avg_ms": kern[k][0], "launches": kern[k][1],
+                                         "tflops": (flops[k] / (kern[k][0] * 1e-3) / 1e12) if kern[k][0] > 0 else 0.0}
+                       for k in kern if kern[k][1] > 0},
+    }
+
+
+HEADLINE = "target_veh3dof_fhadp_b4096_h30"
+# every BASELINE.json workload, each as (workload, dtype): timed by the default run so that all of them sit under the
+# driver's clock (cfg5 in both arithmetics: BASELINE names the fp16 MFMA path for it)
+ALL_WORKLOADS = [("cfg1_idp_fhadp_b64_h10", "fp32"), ("cfg2_idp_fhadp_b4096_h30", "fp32"),
+                 ("cfg3_veh3dof_infadp_b8192", "fp32"), ("cfg4_veh3dof_fhadp_b4096_h50", "fp32"),
+                 ("cfg5_lq_infadp_b65536", "fp32"), ("cfg5_lq_infadp_b65536", "fp16")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=None,
+                    help="one BASELINE workload (default: the north_star target as the headline, plus a short timing of every "
+                         "other BASELINE workload in the `workloads` field)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16"],
+                    help="arithmetic of the MLP contractions: fp32 (exact, parity path) or fp16 (half-precision MFMA, BASELINE cfg5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true")
+    ap.add_argument("--eager-gpu-baseline", action=argparse.BooleanOptionalAction, default=True,
+                    help="also time the oracle restatement as PyTorch eager ops on the GPU (FHADP workloads; ~1 s; reported "
+                         "inside cpu_baseline as eager_gpu_steps_per_s)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_distributed(args))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    dev_index = local_rank % torch.cuda.device_count()   # (== local_rank on a node with >= N GPUs)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    dist, backend = None, None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL ("nccl") is the product path; gloo only exists to exercise this script's multi-rank logic on a box
+        # with fewer GPUs than ranks (the ranks then share devices)
+        backend = os.environ.get("GOPS_BENCH_BACKEND", "nccl" if torch.cuda.device_count() >= world else "gloo")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            # gloo's C++ side prints its connection report on stdout, which carries exactly one JSON line: send the
+            # process's fd 1 to stderr while the group forms
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
+    ctx = {"rank": rank, "world": world, "device": device, "dist": dist}
+
+    workload = args.workload or HEADLINE
+    m = run_workload(workload, args.dtype, args.steps, args.warmup, min(args.steps, 100), ctx)
+    out = record_of(workload, args.dtype, args.steps, args.warmup, world, m) if rank == 0 else None
+    if world > 1 and rank == 0:
+        out["backend"] = "nccl (RCCL)" if backend == "nccl" else f"{backend} - {world} ranks on {torch.cuda.device_count()} GPU(s): multi-rank logic only, not a scaling number"
+    if args.workload is None and world == 1 and not args.no_other_workloads:
+        # the other BASELINE workloads, ~1 s each: same timing method, fewer steps
+        others = {}
+        for name, dtype in ALL_WORKLOADS:
+            k_steps, k_warm = min(args.steps, 20), min(args.warmup, 5)
+            mm = run_workload(name, dtype, k_steps, k_warm, min(k_steps, 10), ctx)
+            r = record_of(name, dtype, k_steps, k_warm, world, mm)
+            others[name + ("_f16" if dtype == "fp16" else "")] = {
+                "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k_steps, "dtype": r["dtype"],
+                "roofline": {k: r["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_ms")},
+                "kernels_ms": {k: v["avg_ms"] for k, v in r["kernels_ms"].items()}}
+        out["workloads"] = others
     if rank == 0:
-        B, H = cfg["batch"], cfg["horizon"]
-        dt = "f16" if args.dtype == "fp16" else "f32"
-        steps_total = world * B * H * args.steps
-        value = steps_total / elapsed
-        kern = {k: hb.profile_read(k) for k in range(6)}
-        # algorithmic work of ONE launch of each rollout kernel: 2 MAC per sample-step for each of
-        # forward / input-adjoint sweep / weight gradients; INFADP's forward and sweep also carry the tail value net
-        tail = cfg["alg"] == "INFADP"
-        flops = {0: 2.0 * (mac_per_step(cfg) * B * H + (mac_per_step(cfg, "value") * B if tail else 0)),
-                 2: 2.0 * mac_per_step(cfg) * B * H}
-        flops[1] = flops[0]
-        flops.update({3: 2.0 * mac_per_step(cfg, "value") * B, 4: 2.0 * mac_per_step(cfg, "value") * B,
-                      5: 2.0 * mac_per_step(cfg, "value") * B})
-        bps = bytes_per_step(cfg, dt)
-        alg_bytes = {0: 0.5 * bps * B * H, 1: 0.5 * bps * B * H, 2: 0.5 * bps * B * H}   # stash written once / read once / read once
-        dom = max((0, 1, 2), key=lambda k: kern[k][0])
-        dom_ms = kern[dom][0]
-        pmc, pmc_src = pmc_profile(args.workload, dt)
-        peak_tf = MFMA_PEAK_TFLOPS[dt]
-        if dt == "f32":   # exact-fp32 MFMA: arithmetic intensity 115 FLOP/B >> machine balance -> the matrix pipe binds
-            achieved = flops[dom] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-            roofline = {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": peak_tf,
-                        "unit": "TFLOP/s", "frac": achieved / peak_tf,
-                        "traffic": pmc_traffic(pmc, pmc_src, KERNEL_NAMES[dom].split("(")[0]),
-                        "algorithmic_flops_per_launch": flops[dom], "avg_ms": dom_ms}
-        else:             # half-precision MFMA is 16x faster: the stash traffic binds
-            achieved = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-            roofline = {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": pmc_traffic(pmc, pmc_src, KERNEL_NAMES[dom].split("(")[0]),
-                        "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_ms": dom_ms}
-        # whole-update fractions of both roofs (SURVEY 8d asks for both next to each other)
-        per_step_flops = 6.0 * mac_per_step(cfg)
-        hbm_measured = None
-        if pmc is not None:   # counter bytes of every kernel of one update / the update's time
-            tot = [kernel_bytes(c) * c.get("launches_per_update", 1.0) for c in pmc.values() if kernel_bytes(c) is not None]
-            if tot:
-                hbm_measured = sum(tot) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
-        alg_name = cfg["alg"]
-        out = {
-            "metric": f"env-model steps/sec (batch x H), {alg_name} compute_gradient + update",
-            "value": value, "unit": "env-model steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt,
-            "data": "synthetic (seeded initial states, random-init networks)",
-            "config": {"workload": args.workload, "env_id": cfg["env_id"], "algorithm": alg_name,
-                       "batch_per_gpu": B, "horizon": H, "policy_mlp": mlp_sizes(cfg),
-                       "activation": cfg["act"], "parallelism": f"dp{world}"},
-            "rollouts_per_sec": world * B * args.steps / elapsed,
-            "roofline": roofline,
-            "flops_fraction": value / world * per_step_flops / (peak_tf * 1e12),
-            "alg_hbm_fraction": value / world * bps / (HBM_PEAK_GBS * 1e9),
-            "hbm_fraction": hbm_measured,
-            "hbm_fraction_source": pmc_src if hbm_measured is not None else None,
-            "kernels_ms": {KERNEL_NAMES[k]: {"avg_ms": kern[k][0], "launches": kern[k][1],
-                                             "tflops": (flops[k] / (kern[k][0] * 1e-3) / 1e12) if kern[k][0] > 0 else 0.0}
-                           for k in kern if kern[k][1] > 0},
-        }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, 0, args.workload, args.eager_gpu_baseline)
+            out["cpu_baseline"] = cpu_baseline(CONFIGS[workload], 0, workload, args.eager_gpu_baseline)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

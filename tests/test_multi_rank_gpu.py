@@ -1,0 +1,120 @@
+"""GPU: the data-parallel update path with the REAL algorithm classes, two ranks sharing the one GPU of the test box.
+
+`FHADP / INFADP.get_remote_update_info -> GradAllReducer.average_(defer_scale=True) -> remote_update` is what
+`on_sync_trainer` / `off_sync_trainer` / `bench.py --gpus N` run per update (reference semantics:
+gops/trainer/on_sync_trainer.py:84-105,189-194 - the N samplers' batches concatenated into one update;
+off_sync_trainer.py:183-208 - the mean of N replica gradients).  The collective runs over gloo on CUDA tensors here
+(one GPU, two processes); on an 8-GPU node the same code runs over RCCL.  Checked: after several updates every rank
+holds the weights a single process reaches with `local_update` on the concatenated 2B batch, and the captured HIP
+graph of the gradient kernels keeps replaying between the collectives.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+ROOT, ALG = sys.argv[1], sys.argv[2]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+os.environ["GOPS_HIP_GRAPH"] = "1"          # capture even these small steps: the collective sits BETWEEN two graphs
+from gops_amd.create_pkg.create_alg import create_alg
+from gops_amd.trainer.grad_sync import GradAllReducer, broadcast_parameters
+from gops_amd.utils.synthetic import make_batch
+from test_alg_gpu import _kwargs
+
+dist.init_process_group("gloo")
+r, n = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+B, ITERS = 96, 7
+if ALG == "FHADP":
+    cfg = dict(alg="FHADP", env_id="pyth_idpendulum", batch=n * B, horizon=8, hidden=(64, 64), act="gelu", gamma=0.99)
+else:
+    cfg = dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=n * B, horizon=6, hidden=(64, 64), act="elu", gamma=0.99)
+
+def make():
+    torch.manual_seed(11)
+    alg = create_alg(**_kwargs(dict(cfg, batch=B), {}, 11))
+    if ALG == "INFADP":
+        alg.forward_step = cfg["horizon"]
+    alg.gamma = cfg["gamma"]
+    alg.networks.to(dev)
+    return alg
+
+alg = make()
+broadcast_parameters(alg.networks, src=0)
+reducer = GradAllReducer()
+full = [{k: v.to(dev) for k, v in make_batch(cfg, 500 + it).items()} for it in range(ITERS)]
+for it in range(ITERS):
+    shard = {k: v[r * B:(r + 1) * B].contiguous() for k, v in full[it].items()}
+    _, info = alg.get_remote_update_info(shard, it)
+    reducer.average_(info, defer_scale=True)
+    assert info["_grad_scale"] == 1.0 / n
+    alg.remote_update(info)
+torch.cuda.synchronize()
+if ALG == "FHADP":
+    assert alg._grad_graph.graph is not None, "the gradient kernels were not replayed as a HIP graph"
+
+# single process, concatenated batch (what the reference's on_sync_trainer feeds its one learner)
+os.environ["GOPS_HIP_GRAPH"] = "0"
+ref = make()
+for it in range(ITERS):
+    ref.local_update(full[it], it)
+torch.cuda.synchronize()
+worst = 0.0
+for (name, a), b in zip(alg.networks.named_parameters(), ref.networks.parameters()):
+    d = (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+    worst = max(worst, d)
+    assert d <= 1e-6, (name, d)
+moved = max((a - b).abs().max().item() for a, b in zip(make().networks.parameters(), ref.networks.parameters()))
+assert moved > 1e-3, moved                       # the updates did move the weights
+# every rank ends on the same weights
+flat = torch.cat([p.detach().reshape(-1) for p in alg.networks.parameters()])
+both = [torch.zeros_like(flat) for _ in range(n)]
+dist.all_gather(both, flat)
+assert all(torch.equal(both[0], t) for t in both)
+# a local_update afterwards steps with plain gradients again (the 1/N of the remote path does not linger)
+for opt in alg.networks.optimizer_dict.values():
+    assert opt.grad_scale == 1.0
+print(f"rank {r}: {ALG} data-parallel == single-process on the 2B batch, worst rel diff {worst:.2e}", flush=True)
+dist.barrier()
+dist.destroy_process_group()
+open(os.path.join(sys.argv[3], f"ok_{r}"), "w").write("ok")
+"""
+
+
+@pytest.mark.parametrize("alg,port", [("FHADP", 29711), ("INFADP", 29712)])
+def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path, alg, port):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, alg, str(tmp_path)],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert all((tmp_path / f"ok_{k}").exists() for k in range(2))
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver runs `--gpus 1`): bench.py starts the two
+    ranks itself; on this 1-GPU box they share the device and reduce over gloo, and the JSON line says so."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--workload", "cfg1_idp_fhadp_b64_h10"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["scaling"] == "weak"
+    assert rec["value"] > 0 and rec["steps"] == 4
+    import torch
+    assert ("gloo" in rec["backend"]) == (torch.cuda.device_count() < 2)

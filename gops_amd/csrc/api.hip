@@ -12,8 +12,9 @@
 
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);
-size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16);
-size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16);
+size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int split_k0);
+size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split);
+bool split_eligible(const RolloutParams& p);
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s);
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s);
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
@@ -251,8 +252,9 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     const bool veh = env_has_ref_table(e.kind);
     const int ref_pts = veh ? e.pre_horizon + 1 + desc.horizon
                                                           : (e.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
-    if (rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16) > 160 * 1024)
+    if (rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16, 0) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16, false) > 160 * 1024)
         return GOPS_ERR_UNSUPPORTED;
+    p.sp.on = split_eligible(p) ? 1 : 0;
     for (int t = 0; t <= p.H; ++t) p.gpow[t] = (float)pow(desc.gamma, (double)t);
 
     Carver c(ws);
@@ -266,6 +268,24 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     }
     carve_packs(c, p.pol, f16);
     if (p.tail) carve_packs(c, p.val, f16);
+    if (p.sp.on) {   // plane-split operands (2 bytes per element and plane) + one scale per n-tile
+        SplitDev& sp = p.sp;
+        const int n1 = p.pol.dims[1], n2 = p.pol.dims[2];
+        sp.kc[0] = p.pol.kp32[0] >> 5;
+        sp.kc[1] = n1 >> 5;
+        auto take_pair = [&](size_t elems, const bf16x8*& w1, const f16x8*& r) {
+            w1 = reinterpret_cast<const bf16x8*>(c.take((elems + 1) / 2));
+            r = reinterpret_cast<const f16x8*>(c.take((elems + 1) / 2));
+        };
+        take_pair((size_t)n1 * 32 * sp.kc[0], sp.w1[0], sp.r[0]);
+        take_pair((size_t)n2 * 32 * sp.kc[1], sp.w1[1], sp.r[1]);
+        take_pair((size_t)n1 * n2, sp.w1t[1], sp.rt[1]);                 // tiles over the n1 inputs of layer 1, slots over its n2 outputs
+        take_pair((size_t)p.pol.kp[0] * n1, sp.w1t[0], sp.rt[0]);        // tiles over the (16-padded) inputs of layer 0, slots over its n1 outputs
+        sp.inv[0] = c.take(n1 >> 4);
+        sp.inv[1] = c.take(n2 >> 4);
+        sp.invt[1] = c.take(n1 >> 4);
+        sp.invt[0] = c.take(p.pol.kp[0] >> 4);
+    }
     if (f16) p.gscale = c.take(4);
     // stash rows: every tile stores all 16 rows of every step (tile-major order)
     const long long S = (long long)((p.B + TB - 1) / TB) * TB * p.H;
@@ -343,6 +363,13 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
     if (dbg) {
         unsigned long long h[16];
         (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+        if (p.sp.on)
+            fprintf(stderr, "[gops dbg] fwd SPLIT cycles/step: top+sync %llu | xstash+convert+sync %llu | gemm0 %llu | epi0+planes %llu | sync %llu | "
+                    "gemm1 %llu | epi1+head fma %llu | head reduce %llu | sync+combine %llu | tanh+wrap %llu | sync %llu | envstash %llu | env %llu || sum %llu\n",
+                    h[0] / p.H, h[1] / p.H, h[14] / p.H, h[8] / p.H, h[9] / p.H, h[11] / p.H, h[12] / p.H, h[2] / p.H, h[6] / p.H, h[7] / p.H,
+                    h[3] / p.H, h[4] / p.H, h[5] / p.H,
+                    (h[0] + h[1] + h[14] + h[8] + h[9] + h[11] + h[12] + h[2] + h[6] + h[7] + h[3] + h[4] + h[5]) / p.H);
+        else
         fprintf(stderr, "[gops dbg] fwd cycles/step: top+sync %llu | xstash %llu | hidden-rest %llu | head %llu | envstash %llu | env %llu"
                 " || L0 epi %llu sync %llu stash %llu | L1 epi %llu sync %llu stash %llu | gemm(L0+L1) %llu || head: dot %llu tanh+wrap %llu barrier %llu\n",
                 h[0] / p.H, h[1] / p.H, h[2] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H, h[8] / p.H, h[9] / p.H,
@@ -400,6 +427,12 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     if (dbg) {
         unsigned long long h[16];
         (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+        if (p.sp.on)
+            fprintf(stderr, "[gops dbg] bwd SPLIT cycles/step: top %llu | env points %llu | reduce+sync %llu | env finish+sync %llu | head delta+planes %llu | "
+                    "sync %llu | hook %llu | gemm1+epi+planes %llu | sync %llu | gemm0+G %llu | end sync %llu || sum %llu\n",
+                    h[0] / p.H, h[10] / p.H, h[11] / p.H, h[1] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H, h[6] / p.H, (h[7] + h[8]) / p.H, h[9] / p.H,
+                    h[2] / p.H, (h[0] + h[10] + h[11] + h[1] + h[3] + h[4] + h[5] + h[6] + h[7] + h[8] + h[9] + h[2]) / p.H);
+        else
         fprintf(stderr, "[gops dbg] bwd cycles/step: touch %llu | env(points %llu, reduce+sync %llu, finish %llu) | head-bwd %llu sync %llu stash %llu | "
                 "gemm1+epi %llu sync %llu stash %llu | gemm0+epi %llu | end sync %llu\n",
                 h[0] / p.H, h[10] / p.H, h[11] / p.H, h[1] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H, h[6] / p.H, h[7] / p.H,

@@ -56,6 +56,60 @@ __device__ __forceinline__ void pack_element_h(const float* __restrict__ W, int 
     }
 }
 
+// Plane-split operands (common.h SplitDev).  One block packs one n-tile: 16 columns x 32 kc contraction slots.
+//   forward,  layer j: column = OUTPUT feature 16 nt + col, slot s <-> input feature (j == 0 ? s : split_perm(s))
+//   backward, layer j: column = INPUT feature 16 nt + col,  slot s <-> output feature split_perm(s)
+// element ((c * 64 + lane) * 8 + i) of the tile = (column lane & 15, slot 32 c + 8 (lane >> 4) + i): the B operand of
+// v_mfma_f32_16x16x32_{bf16,f16} for chunk c.  w1 = bf16(w) (round to nearest even), rf = f16((w - w1) * s_r) with the
+// power of two s_r that brings the tile's largest residual into [2^13, 2^14); inv[nt] = 1 / s_r.
+__device__ __forceinline__ float bf16_round(float w) {
+    unsigned u = __float_as_uint(w);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xffff0000u);
+}
+__device__ __forceinline__ void pack_split_tile(const float* __restrict__ W, int N, int K, bool transposed, bool perm_slots,
+                                                int kc, int nt, unsigned short* __restrict__ w1, _Float16* __restrict__ rf,
+                                                float* __restrict__ inv) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x, total = 16 * 32 * kc;
+    auto wval = [&](int e) -> float {
+        const int i = e & 7, lane = (e >> 3) & 63, c = e >> 9;
+        const int col = 16 * nt + (lane & 15), slot = 32 * c + 8 * (lane >> 4) + i;
+        const int f = perm_slots ? split_perm(slot) : slot;
+        if (!transposed) return (col < N && f < K) ? W[(size_t)col * K + f] : 0.f;   // W[out = col][in = f]
+        return (f < N && col < K) ? W[(size_t)f * K + col] : 0.f;                     // W[out = f][in = col]
+    };
+    float mx = 0.f;
+    for (int e = tid; e < total; e += 256) {
+        const float w = wval(e);
+        mx = fmaxf(mx, fabsf(w - bf16_round(w)));
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) red[tid] = fmaxf(red[tid], red[tid + h]);
+        __syncthreads();
+    }
+    mx = red[0];
+    float s_r = 1.f;
+    if (mx > 0.f && mx < 3.0e38f) {
+        int ex;
+        (void)frexpf(mx, &ex);   // mx = f * 2^ex, f in [0.5, 1)
+        s_r = ldexpf(1.f, 14 - ex);
+    }
+    const size_t off = (size_t)nt * total;
+    for (int e = tid; e < total; e += 256) {
+        const float w = wval(e), h = bf16_round(w);
+        w1[off + e] = (unsigned short)(__float_as_uint(h) >> 16);
+        rf[off + e] = (_Float16)((w - h) * s_r);
+    }
+    if (tid == 0) inv[nt] = 1.f / s_r;
+}
+__host__ __device__ inline int split_pack_blocks(const RolloutParams& p) {
+    if (!p.sp.on) return 0;
+    return (p.pol.dims[1] >> 4) + (p.pol.dims[2] >> 4) + (p.pol.dims[1] >> 4) + (p.pol.kp[0] >> 4);
+}
+
 // Copies the by-value parameter block into device memory (stream ordered, no host staging): the
 // rollout kernels then read it with uniform scalar loads instead of a per-lane scratch copy.
 // F16 launches: every block also folds its slice of grad_v into max|g| (atomicMax on the bit pattern - for
@@ -225,6 +279,32 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
             b -= nb;
         }
     }
+    if (p.sp.on) {   // plane-split operands of the stationary kernels: one block per n-tile
+        const MlpDev& d = p.pol;
+        const int n1 = d.dims[1] >> 4, n2 = d.dims[2] >> 4, k0 = d.kp[0] >> 4;
+        auto us = [](const bf16x8* q) { return const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(q)); };
+        auto hf = [](const f16x8* q) { return const_cast<_Float16*>(reinterpret_cast<const _Float16*>(q)); };
+        if (b < n1) {            // forward layer 0: natural input order
+            pack_split_tile(d.w[0], d.dims[1], d.dims[0], false, false, p.sp.kc[0], b, us(p.sp.w1[0]), hf(p.sp.r[0]), const_cast<float*>(p.sp.inv[0]));
+            return;
+        }
+        b -= n1;
+        if (b < n2) {            // forward layer 1: its input is the plane image of H_1
+            pack_split_tile(d.w[1], d.dims[2], d.dims[1], false, true, p.sp.kc[1], b, us(p.sp.w1[1]), hf(p.sp.r[1]), const_cast<float*>(p.sp.inv[1]));
+            return;
+        }
+        b -= n2;
+        if (b < n1) {            // backward delta_2 -> delta_1 through W_1: tiles over its inputs, slots over its outputs
+            pack_split_tile(d.w[1], d.dims[2], d.dims[1], true, true, d.dims[2] >> 5, b, us(p.sp.w1t[1]), hf(p.sp.rt[1]), const_cast<float*>(p.sp.invt[1]));
+            return;
+        }
+        b -= n1;
+        if (b < k0) {            // backward delta_1 -> g_x through W_0
+            pack_split_tile(d.w[0], d.dims[1], d.dims[0], true, true, d.dims[1] >> 5, b, us(p.sp.w1t[0]), hf(p.sp.rt[0]), const_cast<float*>(p.sp.invt[0]));
+            return;
+        }
+        b -= k0;
+    }
     if (env_has_ref_table(p.env.kind)) {
         const int nrt = (p.B * (P + 1 + p.H) + 255) / 256;
         if (b < nrt) {
@@ -259,6 +339,7 @@ hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, fl
         if (!p.f16) { nb += pack_blocks(d); continue; }
         for (int j = 0; j < d.nl - 1; ++j) nb += pack_blocks_h(d, j);
     }
+    nb += split_pack_blocks(p);
     if (env_has_ref_table(p.env.kind)) nb += (p.B * (P + 1 + p.H) + 255) / 256;
     if (p.env.kind == GOPS_ENV_VEH3DOF_SURR) nb += (p.B * p.env.n_surr + 255) / 256;
     hipLaunchKernelGGL(prologue_kernel, dim3(nb), dim3(256), 0, s, p, dst, P, pdt);
@@ -288,24 +369,7 @@ hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, fl
 //
 // Workgroups whose k-tile is 0 also accumulate the bias gradient (column sums of D).
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// (a, b) -> three packed bf16 pairs (low half from a, high half from b); a == the sum of its three planes EXACTLY, and
-// so is b.  Each plane is the TRUNCATION of the running residual to its top 16 bits (8 significant bits): the residual
-// after one plane has at most 16 significant bits left, after two at most 8, so the third truncation is exact - same
-// guarantee as rounding to nearest, but on full-rate integer / add instructions only (v_perm_b32 packs the two high
-// halves; v_cvt_pk_bf16_f32 is a quarter-rate instruction and made this split the bottleneck of the GEMM).
-__device__ __forceinline__ void split3(float a, float b, unsigned (&pl)[3]) {
-    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-    pl[0] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-    const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
-    const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
-    pl[1] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
-    const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
-    pl[2] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
-}
+// (split3: common.h)
 
 // 8 fp32 samples of one feature -> the three bf16x8 plane fragments
 __device__ __forceinline__ void split_frag(const f32x4& lo, const f32x4& hi, bf16x8 (&pl)[3]) {
@@ -610,7 +674,6 @@ hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long lo
 #define DWH_T 128                       // tile edge
 #define DWH_PLANE (8 * DWH_T * 8)       // halfs per operand: [8 g][128 cols][8 samples]
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_f16_kernel(const _Float16* __restrict__ D, int N,

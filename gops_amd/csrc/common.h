@@ -15,6 +15,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));   // one A / B fragment of v_mfma_f32_16x16x32_f16
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));    // one A / B fragment of v_mfma_f32_16x16x32_bf16
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // Pointers that reach the kernels through the parameter block are generic to the compiler, and
 // generic accesses become FLAT instructions, which count on lgkmcnt as well as vmcnt: every LDS wait
@@ -45,6 +49,32 @@ struct MlpDev {
     const f16x8* wph[GOPS_MAX_LAYERS];
     const f16x8* wpth[GOPS_MAX_LAYERS];
 };
+
+// Plane-split contractions of the register-stationary kernels (policy: obs -> 256 -> 256 -> act, fp32 results).
+// An fp32 weight w is carried as  w1 = bf16(w)  (round to nearest)  +  rf = f16((w - w1) * s_r)  - 2 + 2 bytes, the
+// same register footprint as the fp32 value, >= 19 significant bits (|w - w1 - rf / s_r| <= 2^-19 |w|, 6e-7 |w| rms); an fp32
+// activation a as its three exact bf16 truncation planes a = a1 + a2 + a3 plus af = f16(a * s_a).  Then
+//     a * w  =  (a1 + a2 + a3) * w1  [3 x v_mfma_f32_16x16x32_bf16, exact products, fp32 accumulation]
+//            +  af * rf / (s_a s_r)  [1 x v_mfma_f32_16x16x32_f16 into a second accumulator]     + O(2^-19 |a w|)
+// i.e. 4 x 16-cycle matrix instructions per 32-deep block against 8 x 32-cycle v_mfma_f32_16x16x4_f32.  The bf16 main
+// term has fp32's exponent range; only the 2^-9-sized correction goes through half precision (saturating conversion,
+// s_r per n-tile from the packing kernel, s_a a power of two: fixed forward, per tile and step from max|delta_y| backward).
+struct SplitDev {
+    int on;                     // 1: the stationary kernels run the plane-split contractions (else fp32 MFMA)
+    int kc[2];                  // 32-wide k-chunks of hidden layer j's input
+    const bf16x8* w1[2];        // forward B operand [n-tile][chunk][lane]: bf16(W_j[16 nt + (lane & 15)][slot feature])
+    const f16x8* r[2];          //   residual plane, scaled per n-tile
+    const float* inv[2];        //   [n-tile] 1 / s_r
+    const bf16x8* w1t[2];       // backward (delta_{j+1} W_j): n-tiles over the layer's INPUT features, chunks over its outputs
+    const f16x8* rt[2];
+    const float* invt[2];
+};
+#define SPLIT_FWD_SA 1.0f       // forward: af = f16(a) (saturating: beyond 65504 only the 2^-9-sized correction term degrades)
+// position e of a hidden tile's plane row (the order plane_store writes, = the contraction order of the next GEMM) -> feature
+__host__ __device__ inline int split_perm(int e) { return 64 * (e >> 6) + 16 * (e & 3) + ((e & 63) >> 2); }
+// LDS image of a [TB][K] activation tile: 4 planes (a1, a2, a3 bf16; af f16), each [TB] rows of rowb bytes (16 bytes of pad)
+__host__ __device__ inline int split_rowb(int K) { return 2 * K + 16; }
+__host__ __device__ inline int split_tile_floats(int K) { return TB * split_rowb(K); }   // 4 planes x TB x rowb bytes
 
 // fp32 stash tensors are FEATURE-MAJOR inside every 16-sample tile: element (sample tile q, feature n, row m) of a
 // tensor with N features sits at (q * N + n) * 16 + m (FM layout).  A lane of the rollout kernels' MFMA result layout
@@ -90,6 +120,7 @@ struct RolloutParams {
     unsigned long long* dbg;          // debug: per-phase cycle counters of block 0 (GOPS_DBG_TIMING)
     int f16;                          // 1: GOPS_DTYPE_F16
     float* gscale;                    // f16 backward: gscale[0] = max|grad_v| of the launch (upload_params_kernel)
+    SplitDev sp;                      // plane-split contractions of the stationary fp32 kernels
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double
 };
 // upload_params_kernel / prologue_kernel take the block BY VALUE: it has to fit the 4 KiB kernel-argument segment
@@ -295,6 +326,154 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_f<0x141>(v);   // row_half_mirror
     v += dpp_f<0x140>(v);   // row_mirror
     return v;
+}
+
+// ---- exact bf16 planes of fp32 values --------------------------------------------------------------------
+// (a, b) -> three packed bf16 pairs (low half from a, high half from b); a == the sum of its three planes EXACTLY, and
+// so is b.  Each plane is the TRUNCATION of the running residual to its top 16 bits (8 significant bits): the residual
+// after one plane has at most 16 significant bits left, after two at most 8, so the third truncation is exact - same
+// guarantee as rounding to nearest, but on full-rate integer / add instructions only (v_perm_b32 packs the two high
+// halves; v_cvt_pk_bf16_f32 is a quarter-rate instruction).
+__device__ __forceinline__ void split3(float a, float b, unsigned (&pl)[3]) {
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    pl[0] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
+    const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+    pl[1] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
+    pl[2] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+}
+// (a, b) -> packed half pair, round to nearest (v_cvt_pk_f16_f32), saturating at +-65504 instead of producing inf
+__device__ __forceinline__ unsigned pk_half(float a, float b) {
+    const f16x2 h = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+    return __builtin_bit_cast(unsigned, h);
+}
+
+// Plane image of a hidden tile, written from the MFMA result layout: lane (n = lane & 15, g = lane >> 4) of wave w holds
+// v[q][r] = element (row 4 g + r, feature 64 w + 16 q + n) of its four n-tiles q.  The four features of a row go out as
+// ONE 8-byte store per plane (16 consecutive lanes = 128 contiguous bytes), i.e. position 64 w + 4 n + q of the row holds
+// feature 64 w + 16 q + n: split_perm().  The weights of the consuming GEMM are packed in the same order.
+__device__ __forceinline__ void plane_store(char* planes, int rowb, int wave, int lane, const f32x4 (&v)[4], float s16) {
+    const int pstride = TB * rowb;
+    char* base = planes + ((lane >> 4) << 2) * rowb + 128 * wave + 8 * (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        unsigned p01[3], p23[3];
+        split3(v[0][r], v[1][r], p01);
+        split3(v[2][r], v[3][r], p23);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const u32x2 w = {p01[pl], p23[pl]};
+            *reinterpret_cast<u32x2*>(base + r * rowb + pl * pstride) = w;
+        }
+        const u32x2 h = {pk_half(v[0][r] * s16, v[1][r] * s16), pk_half(v[2][r] * s16, v[3][r] * s16)};
+        *reinterpret_cast<u32x2*>(base + r * rowb + 3 * pstride) = h;
+    }
+}
+
+// Plane image of the fp32 input tile xs [TB][ldx] (columns < kp valid / zero) in natural column order, kp32 columns.
+__device__ __forceinline__ void plane_convert_x(const float* xs, int ldx, int kp, int kp32, char* planes, int rowb, int tid, float s16) {
+    const int upr = kp32 >> 3, pstride = TB * rowb;
+    for (int idx = tid; idx < TB * upr; idx += NTHREADS) {
+        const int m = idx / upr, u = idx - m * upr, c = u << 3;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (c < kp) { a = *reinterpret_cast<const f32x4*>(xs + m * ldx + c); b = *reinterpret_cast<const f32x4*>(xs + m * ldx + c + 4); }
+        unsigned p0[3], p1[3], p2[3], p3[3];
+        split3(a[0], a[1], p0); split3(a[2], a[3], p1); split3(b[0], b[1], p2); split3(b[2], b[3], p3);
+        char* dst = planes + m * rowb + 16 * u;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const u32x4 w = {p0[pl], p1[pl], p2[pl], p3[pl]};
+            *reinterpret_cast<u32x4*>(dst + pl * pstride) = w;
+        }
+        const u32x4 h = {pk_half(a[0] * s16, a[1] * s16), pk_half(a[2] * s16, a[3] * s16), pk_half(b[0] * s16, b[1] * s16), pk_half(b[2] * s16, b[3] * s16)};
+        *reinterpret_cast<u32x4*>(dst + 3 * pstride) = h;
+    }
+}
+
+// Plane-split weights of one layer for this wave's NT n-tiles x KCH chunks of 32 inputs.  The bf16 plane is register-
+// stationary; the half residual plane is register-stationary too (RLDS = false) or lives in LDS (RLDS = true: `rl` points
+// at the workgroup's copy of the packed plane, fragment (n-tile nt, chunk c) of lane l at rl[((nt * KCH + c) * 64 + l)],
+// read with conflict-free ds_read_b128 a few MFMAs ahead of its use).  One 256 x 256 layer is 256 registers per lane with
+// both planes resident; two such layers do not fit beside the rest of the kernel, so layer 0 keeps its residual plane in LDS.
+template <int KCH, int NT, bool RLDS>
+struct StatQ {
+    bf16x8 w[KCH * NT];
+    f16x8 r[RLDS ? 1 : KCH * NT];
+    const f16x8* rl;   // RLDS: this lane's first fragment of this wave's first n-tile
+    float inv[NT];     // 1 / s_r of the n-tiles
+    // lds_r (RLDS): LDS region of nt_tot * KCH * 64 fragments, filled here by all NTHREADS threads (caller: barrier before use)
+    __device__ __forceinline__ void load(const bf16x8* __restrict__ W1, const f16x8* __restrict__ R, const float* __restrict__ inv_r,
+                                         int nt_tot, int tid, f16x8* lds_r = nullptr) {
+        const int lane = tid & 63, nt0 = (tid >> 6) * NT;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const bool ok = nt0 + j < nt_tot;
+            inv[j] = ok ? gptr(inv_r)[nt0 + j] : 0.f;
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const size_t at = ((size_t)(ok ? nt0 + j : 0) * KCH + c) * 64 + lane;
+                w[c * NT + j] = gptr(W1)[at];
+                if constexpr (!RLDS) r[c * NT + j] = gptr(R)[at];
+            }
+        }
+        if constexpr (RLDS) {
+            for (int i = tid; i < nt_tot * KCH * 64; i += NTHREADS) lds_r[i] = gptr(R)[i];
+            rl = lds_r + (size_t)(nt0 < nt_tot ? nt0 : 0) * KCH * 64 + lane;
+        }
+    }
+};
+
+// acc (bf16 main term) / accr (f16 residual term, still scaled) of this wave's NT n-tiles over the plane image `planes`.
+// Every A fragment is refreshed IN PLACE with the next chunk's right after its last use (one register set, the LDS read has
+// the other planes' MFMAs to land); an LDS-resident residual plane is fetched at the top of the chunk, 3 NT MFMAs ahead.
+template <int KCH, int NT, bool RLDS>
+__device__ __forceinline__ void gemm_split(const char* planes, int rowb, const StatQ<KCH, NT, RLDS>& W, int lane,
+                                           f32x4 (&acc)[NT], f32x4 (&accr)[NT]) {
+    const int pstride = TB * rowb;
+    const char* arow = planes + (lane & 15) * rowb + (lane >> 4) * 16;
+    bf16x8 a1 = *reinterpret_cast<const bf16x8*>(arow), a2 = *reinterpret_cast<const bf16x8*>(arow + pstride);
+    bf16x8 a3 = *reinterpret_cast<const bf16x8*>(arow + 2 * pstride);
+    f16x8 af = *reinterpret_cast<const f16x8*>(arow + 3 * pstride);
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        f16x8 rr[NT];
+        if constexpr (RLDS) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) rr[j] = W.rl[(j * KCH + c) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, W.w[c * NT + j], acc[j], 0, 0, 0);
+        if (c + 1 < KCH) a3 = *reinterpret_cast<const bf16x8*>(arow + 64 * (c + 1) + 2 * pstride);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, W.w[c * NT + j], acc[j], 0, 0, 0);
+        if (c + 1 < KCH) a2 = *reinterpret_cast<const bf16x8*>(arow + 64 * (c + 1) + pstride);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, W.w[c * NT + j], acc[j], 0, 0, 0);
+        if (c + 1 < KCH) a1 = *reinterpret_cast<const bf16x8*>(arow + 64 * (c + 1));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if constexpr (RLDS) accr[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, rr[j], accr[j], 0, 0, 0);
+            else accr[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, W.r[c * NT + j], accr[j], 0, 0, 0);
+        }
+        if (c + 1 < KCH) af = *reinterpret_cast<const f16x8*>(arow + 64 * (c + 1) + 3 * pstride);
+    }
+}
+
+__device__ __forceinline__ float row16_max(float v) {   // max over each aligned group of 16 lanes, result in every lane
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return v;
+}
+// Backward sweep: power of two s that brings the tile's largest |delta_y| = mx into [8, 16) (half-precision plane of the
+// deltas: whatever the magnitude of the gradients, the correction term sees mid-range halfs); out[0] = s, out[1] = 1 / s.
+__device__ __forceinline__ void split_delta_scale(float mx, float* out) {
+    int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);   // biased exponent; mx >= 0
+    e = e < 4 ? 4 : (e > 250 ? 250 : e);                  // (zero / denormal / inf / nan tiles: any finite power of two will do)
+    out[0] = __uint_as_float((unsigned)(257 - e) << 23);   // 2^(130 - e): mx * s in [8, 16)
+    out[1] = __uint_as_float((unsigned)(e - 3) << 23);     // 2^(e - 130)
 }
 
 // ---- MFMA tile GEMM: acc[j] (16 x 16 tile nt0+j) += A[16 x 16*kchunks] * Wp ------------------

@@ -11,8 +11,11 @@
 #include "rollout_f16.h"
 
 // LDS floats of the per-tile buffers (everything except the optional staged tiles at the end).
-__host__ __device__ inline int bwd_lds_floats(int ldx, int ldh, int ref_points, bool f16 = false) {
-    return TB * ldx + 2 * hidden_tile_floats(ldh, f16) + TB * 4 + 4 * TB * 8 + 4 * ldh + 4 * TB * ref_points;
+// split: the plane-split sweep keeps the plane images of delta_2 / delta_1 where the fp32 delta tiles would be (the
+// tail value net's fp32 tiles, dead once the loop starts, alias them) and needs no LDS copy of the head weights
+__host__ __device__ inline int bwd_lds_floats(int ldx, int ldh, int ref_points, bool f16 = false, bool split = false) {
+    return TB * ldx + (split ? 2 * split_tile_floats(256) : 2 * hidden_tile_floats(ldh, f16)) + TB * 4 + 4 + 4 * TB * 8 +
+           (split ? 0 : 4 * ldh) + 4 * TB * ref_points;
 }
 
 // delta_y in s_gy[TB][4]  ->  hidden deltas (stashed to stash_d when non-null) and, if want_gx,
@@ -153,6 +156,119 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
     }
 }
 
+// Plane-split backward through the policy MLP (common.h SplitDev): delta_y (s_gy) -> delta_2 -> delta_1 -> g_x.
+// The head delta is one exact fp32 MFMA per n-tile as in mlp_backward; every delta tile leaves its epilogue registers
+// three ways: one 16-byte vector to the fp32 FM stash (weight-gradient GEMM), and - through plane_store - as the bf16 / f16
+// plane image the next contraction reads.  The half plane carries the step's power-of-two scale s_scale[0] (from
+// max|delta_y| of the tile), taken out again with the residual accumulator's factor.
+template <int PT0>
+struct SplitSweep {
+    StatQ<8, 4, false> QT1;      // delta_2 -> delta_1 through W_1: both planes in registers
+    StatQ<8, PT0, true> QT0;     // delta_1 -> g_x through W_0: bf16 plane in registers, half residual plane in LDS
+    float wo[4];                 // W_o[k = lane >> 4][64 wave + 16 q + (lane & 15)]: B operand of the head-delta MFMA
+    f32x4 hv[4];                 // act' operands of this lane's four columns: H_2 (Z_2 for GELU) of the step, then H_1
+    __device__ __forceinline__ void load(const RolloutParams& p, int tid, f16x8* rt0_lds) {
+        const int lane = tid & 63, wave = tid >> 6;
+        const MlpDev& M = p.pol;
+        QT1.load(p.sp.w1t[1], p.sp.rt[1], p.sp.invt[1], M.dims[1] >> 4, tid);
+        QT0.load(p.sp.w1t[0], p.sp.rt[0], p.sp.invt[0], M.kp[0] >> 4, tid, rt0_lds);
+        const int K = M.dims[2], A = M.dims[3], kk = lane >> 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wo[q] = (kk < A) ? gptr(M.w[2])[kk * K + 64 * wave + 16 * q + (lane & 15)] : 0.f;
+    }
+    // The act' operands come straight from the FM stash into registers (one 16-byte vector per column), issued a phase
+    // ahead of their use: H_2 at the top of the step (used after the env adjoint), H_1 right after the head (used after the
+    // delta_1 contraction).  (The fp32-MFMA variants stage these tiles in LDS; here that LDS holds W_0's residual plane.)
+    __device__ __forceinline__ void fetch(const RolloutParams& p, int j, size_t row0, int tid) {
+        const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
+        const GLOBAL_AS float* src = gptr((p.pol.act == GOPS_ACT_GELU ? p.st.z[j] : p.st.h[j]) + row0 * 256);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[q] = ld4(src + (64 * wave + 16 * q + (lane & 15)) * 16 + m0);
+    }
+    template <class Hook>
+    __device__ __forceinline__ void run(const RolloutParams& p, const float* s_gy, const float* s_scale, char* dq2, char* dq1,
+                                        float* G, int ldg, int tid, size_t row0, int nvalid, bool want_gx, int ncols,
+                                        DbgClock& dbg, Hook&& after_head) {
+        const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
+        const MlpDev& M = p.pol;
+        constexpr int ROWB = 2 * 256 + 16;
+        const int A = M.dims[3];
+        const float s = s_scale[0], inv_s = s_scale[1];
+        // delta tile of layer j from the contraction result `a`: * act'(.), zero for padding rows, -> stash + plane image
+        auto finish = [&](int j, f32x4 (&a)[4], char* planes) {
+            float* dst = p.st.d[j] + row0 * 256;
+            act_dispatch(M.act, [&]<int ACT>() {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = 64 * wave + 16 * q + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[q][r] = (m0 + r < nvalid) ? a[q][r] * act_bwd_t<ACT>(hv[q][r], hv[q][r]) : 0.f;
+                    __builtin_nontemporal_store(a[q], gptr(reinterpret_cast<f32x4*>(dst + n * 16 + m0)));
+                }
+            });
+            plane_store(planes, ROWB, wave, lane, a, s);
+        };
+        {   // ---- head: delta_2 = (delta_y W_o) * act'(z_2) ----
+            const int kk = lane >> 4;
+            const float ga = (kk < A) ? s_gy[(lane & 15) * 4 + kk] : 0.f;   // A operand: delta_y[m = lane & 15][k = lane >> 4]
+            f32x4 acc[4] = {};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, wo[q], acc[q], 0, 0, 0);
+            finish(2, acc, dq2);
+            fetch(p, 1, row0, tid);   // H_1 of this step: lands behind the delta_1 contraction
+            if (tid < TB) {
+                f32x4 v = {s_gy[tid * 4 + 0], s_gy[tid * 4 + 1], s_gy[tid * 4 + 2], s_gy[tid * 4 + 3]};
+#pragma unroll
+                for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                    if (a >= A || tid >= nvalid) v[a] = 0.f;
+                *gptr(reinterpret_cast<f32x4*>(p.st.dy + (row0 + tid) * 4)) = v;
+            }
+        }
+        DBG_TICK(3)
+        __syncthreads();
+        DBG_TICK(4)
+        after_head();
+        DBG_TICK(5)
+        {   // ---- delta_1 = (delta_2 W_1) * act'(z_1) ----
+            f32x4 acc[4] = {}, accr[4] = {};
+            gemm_split<8, 4, false>(dq2, ROWB, QT1, lane, acc, accr);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float sc = QT1.inv[q] * inv_s;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[q][r] = fmaf(accr[q][r], sc, acc[q][r]);
+            }
+            finish(1, acc, dq1);
+        }
+        DBG_TICK(6)
+        __syncthreads();
+        DBG_TICK(7)
+        DBG_TICK(8)
+        if (want_gx) {   // ---- input adjoint g_x = delta_1 W_0, accumulated into G ----
+            f32x4 acc[PT0] = {}, accr[PT0] = {};
+            gemm_split<8, PT0, true>(dq1, ROWB, QT0, lane, acc, accr);
+            float gold[PT0][4];
+#pragma unroll
+            for (int j = 0; j < PT0; ++j) {
+                const int n = min(16 * (PT0 * wave + j) + (lane & 15), ncols - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gold[j][r] = G[(m0 + r) * ldg + n];
+            }
+#pragma unroll
+            for (int j = 0; j < PT0; ++j) {
+                const int n = 16 * (PT0 * wave + j) + (lane & 15);
+                const float sc = QT0.inv[j] * inv_s;
+                if (n < ncols) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) G[(m0 + r) * ldg + n] = gold[j][r] + fmaf(accr[j][r], sc, acc[j][r]);
+                }
+            }
+            DBG_TICK(9)
+        }
+    }
+};
+struct NoSweep {};
+
 // SK0 / SK1 as in the forward kernel: here the stationary fragments are the TRANSPOSED packings
 // (delta_2 -> delta_1 through W_1: 16 chunks x 4 tiles).  SK0 here = number of the 16 K-chunks of
 // delta_1 -> g_x (through W_0^T, PT0 n-tiles per wave) that stay in registers; the rest streams.
@@ -162,7 +278,8 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
 // (F16 kernels: 4 workgroups per CU - launch bound 4 waves / SIMD, <= 128 registers.)
 // EXT (streamed fp32 kernels of the obs == state env kinds only): terminal observation adjoint in, initial
 // observation adjoint out, parameter deltas of step 0 only - gops_rollout_backward_adj / gops_mlp_backward_x
-template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, bool EXT = false>
+// SPLIT: plane-split contractions (SplitSweep; SK1 > 0, PT0 = n-tiles of g_x per wave)
+template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, bool EXT = false, bool SPLIT = false>
 __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1)) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;
@@ -178,15 +295,19 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     float* G = smem;                    // [TB][ldx] adjoint of obs_{t+1}
     float* da = G + TB * ldx;           // [TB][ldh]
     float* db = da + hidden_tile_floats(ldh, F16);    // [TB][ldh] floats, or [TB][ldh + 4] halfs (F16)
-    float* s_gy = db + hidden_tile_floats(ldh, F16);  // [TB][4]
-    float* red = s_gy + TB * 4;         // [4][TB][8]
-    float* s_wo = red + 4 * TB * 8;     // [4][ldh] head weights
-    f32x4* s_ref = reinterpret_cast<f32x4*>(s_wo + 4 * ldh);   // veh: [TB][TL]
+    // SPLIT: the plane images of delta_2 / delta_1 take the place of the fp32 delta tiles (which only the tail value net uses)
+    char* dq2 = reinterpret_cast<char*>(da);
+    char* dq1 = dq2 + 4 * split_tile_floats(256);
+    float* s_gy = SPLIT ? da + 2 * split_tile_floats(256) : db + hidden_tile_floats(ldh, F16);  // [TB][4]
+    float* s_scale = s_gy + TB * 4;     // [4] SPLIT: this step's power-of-two delta scale and its inverse
+    float* red = s_scale + 4;           // [4][TB][8]
+    float* s_wo = red + 4 * TB * 8;     // [4][ldh] head weights (not in the SPLIT layout: SplitSweep keeps its columns in registers)
+    f32x4* s_ref = reinterpret_cast<f32x4*>(s_wo + (SPLIT ? 0 : 4 * ldh));   // veh: [TB][TL]
     float* s_idp = reinterpret_cast<float*>(s_ref);             // idpendulum: [TB][5][24] sub-step parking
     // One-workgroup-per-CU variants: LDS copies of this step's H_2 / H_1 (Z for GELU) tiles, [2][TB][256]
     constexpr bool STAGE = (SK1 > 0);   // (those variants are only selected for obs-256-256-act policies)
     float* s_stage = smem + bwd_lds_floats(ldx, ldh, REF ? p.env.pre_horizon + 1 + p.H
-                                                                             : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0), F16);
+                                                                             : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0), F16, SPLIT);
 
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
     if constexpr (EXT) {
@@ -225,9 +346,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     const int kp0 = p.pol.kp[0];
     {
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
-        for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
-            const int a = idx / K, k = idx - a * K;
-            s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
+        if constexpr (!SPLIT) {
+            for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
+                const int a = idx / K, k = idx - a * K;
+                s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
+            }
         }
         if (REF) {
             const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
@@ -237,10 +360,13 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             }
         }
     }
-    typename std::conditional<(SK0 > 0), StatW<(SK0 > 0 ? SK0 : 1), PT0>, NoW>::type WT0;
-    typename std::conditional<(SK1 > 0), StatW<16, 4>, NoW>::type WT1;
-    if constexpr (SK0 > 0) WT0.load(p.pol.wpt[0], kp0 >> 4, tid, p.pol.dims[1] >> 4);
-    if constexpr (SK1 > 0) WT1.load(p.pol.wpt[1], p.pol.dims[1] >> 4, tid);
+    typename std::conditional<(SK0 > 0 && !SPLIT), StatW<(SK0 > 0 ? SK0 : 1), PT0>, NoW>::type WT0;
+    typename std::conditional<(SK1 > 0 && !SPLIT), StatW<16, 4>, NoW>::type WT1;
+    if constexpr (SK0 > 0 && !SPLIT) WT0.load(p.pol.wpt[0], kp0 >> 4, tid, p.pol.dims[1] >> 4);
+    if constexpr (SK1 > 0 && !SPLIT) WT1.load(p.pol.wpt[1], p.pol.dims[1] >> 4, tid);
+    typename std::conditional<SPLIT, SplitSweep<PT0>, NoSweep>::type SS;
+    // SPLIT: W_0's residual plane ((kp0 / 16) n-tiles x 8 chunks x 1 KiB) behind the two small staging halves
+    if constexpr (SPLIT) SS.load(p, tid, reinterpret_cast<f16x8*>(s_stage + 2 * (TB * ENV_STASH + TB * 8)));
 
     DbgClock dbg;
     dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
@@ -269,7 +395,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     // exactly what its own lanes read later: rows 4w..4w+3 of H_2 (one 1-KiB row per instruction) and
     // columns 64w..64w+63 of H_1 (4 rows x 64 columns per instruction); the small rows are fetched by
     // waves 0 / 1 and read by everyone after the end-of-step barrier (which drains the loads).
-    constexpr int STAGE_FLOATS = 2 * TB * 256 + TB * ENV_STASH + TB * 8;
+    constexpr int STAGE_TILES = SPLIT ? 0 : 2 * TB * 256;   // (SPLIT: act' operands go stash -> registers, SplitSweep::fetch)
+    constexpr int STAGE_FLOATS = STAGE_TILES + TB * ENV_STASH + TB * 8;
     auto stage_step = [&](int tt) {
         const size_t r0 = ((size_t)blockIdx.x * p.H + tt) * TB;
         const float* dst = s_stage + (tt & 1) * STAGE_FLOATS;
@@ -278,15 +405,17 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         const float* src1 = (gelu_s ? p.st.z[1] : p.st.h[1]) + r0 * 256;
         const int ln = tid & 63, wv = tid >> 6;
         // FM tiles are 16 KiB of contiguous memory, features 64 w .. 64 w + 63 (wave w's n-tiles) 4 KiB of it
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            async_copy16_to_lds(src2 + wv * 1024 + q * 256 + 4 * ln, dst + wv * 1024 + q * 256);
-            async_copy16_to_lds(src1 + wv * 1024 + q * 256 + 4 * ln, dst + TB * 256 + wv * 1024 + q * 256);
+            for (int q = 0; q < 4; ++q) {
+                async_copy16_to_lds(src2 + wv * 1024 + q * 256 + 4 * ln, dst + wv * 1024 + q * 256);
+                async_copy16_to_lds(src1 + wv * 1024 + q * 256 + 4 * ln, dst + TB * 256 + wv * 1024 + q * 256);
+            }
         }
         if (wv == 0)        // env rows: 16 x 64 B, contiguous
-            async_copy16_to_lds(p.st.env + r0 * ENV_STASH + 4 * ln, dst + 2 * TB * 256);
+            async_copy16_to_lds(p.st.env + r0 * ENV_STASH + 4 * ln, dst + STAGE_TILES);
         if (wv == 1 && ln < 2 * TB)   // first 8 observation columns: 8 x 64 B, contiguous in the FM tile -> st_x[i * 16 + m]
-            async_copy16_to_lds(p.st.x + r0 * kp0 + 4 * ln, dst + 2 * TB * 256 + TB * ENV_STASH);
+            async_copy16_to_lds(p.st.x + r0 * kp0 + 4 * ln, dst + STAGE_TILES + TB * ENV_STASH);
     };
     if constexpr (STAGE) {
         stage_step(p.H - 1);
@@ -299,7 +428,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         const size_t row0 = ((size_t)blockIdx.x * p.H + t) * TB;   // tile-major stash rows
         const size_t prow = row0 - TB;
         const float* st_cur = s_stage + (t & 1) * STAGE_FLOATS;       // this step's staged data (STAGE only)
-        const float* st_env = st_cur + 2 * TB * 256;
+        const float* st_env = st_cur + STAGE_TILES;
         const float* st_x = st_env + TB * ENV_STASH;
         // (the staged variants fetch their tiles straight into LDS and measured faster without it)
         const int tmode = (t > 0 && !STAGE && !F16) ? p.touch_mode : 0;
@@ -321,6 +450,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             // loaded value in the iteration (g_r above): hipcc drains vmcnt(0) there on every trip, and the
             // copies must not be outstanding at that point.
             if (t > 0) stage_step(t - 1);
+            if constexpr (SPLIT) SS.fetch(p, 2, row0, tid);   // act' operands of the head delta: in flight during the env adjoint
         }
 
         if (ENV == GOPS_ENV_NONE) {
@@ -859,8 +989,18 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 s_gy[m * 4 + 3] = 0.f;
             }
         }
+        if constexpr (SPLIT) {
+            if (tid < TB) {   // (the same 16 threads wrote s_gy above) -> this step's delta scale
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(s_gy + tid * 4);
+                const float mx = row16_max(fmaxf(fmaxf(fabsf(g4[0]), fabsf(g4[1])), fmaxf(fabsf(g4[2]), fabsf(g4[3]))));
+                if (tid == 0) split_delta_scale(mx, s_scale);
+            }
+        }
         __syncthreads();
         DBG_TICK(1)
+        if constexpr (SPLIT) {
+            SS.run(p, s_gy, s_scale, dq2, dq1, G, ldx, tid, row0, nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up);
+        } else
         if (!p.open_loop) {
             if constexpr (F16)
                 mlp_backward_h(p.pol, s_wo, ldh, s_gy, reinterpret_cast<_Float16*>(da), reinterpret_cast<_Float16*>(db), ld16, G, ldx,
@@ -904,8 +1044,10 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
 
 // ref_points: reference-table points per trajectory (veh3dofconti), 30 (= 5 x 24 / 4) for the
 // idpendulum sub-step parking area, else 0
-size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16) {
-    return sizeof(float) * (size_t)bwd_lds_floats(ldx, ldh, ref_points, f16);
+size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split) {
+    size_t b = sizeof(float) * (size_t)bwd_lds_floats(ldx, ldh, ref_points, f16, split);
+    if (split) b += sizeof(float) * 2 * (TB * ENV_STASH + TB * 8) + (size_t)((ldx - 4) >> 4) * 8 * 1024;   // small staging halves + W_0's residual plane
+    return b;
 }
 
 void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
@@ -930,8 +1072,8 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
 
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H
-                                                       : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0), p.f16 != 0);
+    const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
+    size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, p.f16 != 0, false);
     if (p.ext) {   // adjoint I/O / ActionRepeat: streamed fp32 kernels of the obs == state kinds
         if (p.f16) return hipErrorInvalidValue;
 #define LAUNCH_BWD_EXT(ENV)                                                                                             \
@@ -950,6 +1092,21 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
             case GOPS_ENV_PENDULUM: LAUNCH_BWD_EXT(GOPS_ENV_PENDULUM); break;
             default: return hipErrorInvalidValue;
         }
+        return hipGetLastError();
+    }
+    if (p.sp.on) {   // plane-split stationary sweep: PT0 = n-tiles of g_x per wave
+        lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, true);
+#define LAUNCH_BWD_SPLIT(ENV, PT)                                                                                                  \
+    do {                                                                                                                          \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, true, PT, false, false, true>, grid, block, lds, stream, dp);    \
+        else launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, false, PT, false, false, true>, grid, block, lds, stream, dp);          \
+    } while (0)
+        const int pt = (p.pol.kp[0] + 63) >> 6;
+        if (p.env.kind == GOPS_ENV_LQ && pt == 1) LAUNCH_BWD_SPLIT(GOPS_ENV_LQ, 1);
+        else if (p.env.kind == GOPS_ENV_IDPENDULUM && pt == 1) LAUNCH_BWD_SPLIT(GOPS_ENV_IDPENDULUM, 1);
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && pt == 1) LAUNCH_BWD_SPLIT(GOPS_ENV_VEH3DOFCONTI, 1);
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && pt == 2) LAUNCH_BWD_SPLIT(GOPS_ENV_VEH3DOFCONTI, 2);
+        else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     int sk[2];

@@ -134,6 +134,117 @@ __device__ __forceinline__ void mlp_head(WP Wo, int ldw, BP bo, int K, int A, co
     }
 }
 
+// Plane-split policy evaluation of the register-stationary kernels (common.h SplitDev): obs tile xs -> head
+// pre-activation.  Per step: the observation tile becomes a plane image (natural column order), hidden layer 0 runs on
+// it and leaves the plane image of H_1 (plane_store order), hidden layer 1 runs on that; H_1 / H_2 (and gelu' for GELU)
+// go to the fp32 FM stash straight from the epilogue registers like in mlp_hidden_forward.  The output layer is formed
+// from the H_2 registers: every lane multiplies its 4 x 4 values with its own four head-weight columns (registers,
+// loaded once), 16-lane DPP sums give the per-wave partial of each (row, action), and the four waves' partials meet in
+// s_part - H_2 never touches LDS.  Returns the head pre-activation of (trajectory tid >> 4, action tid & 15) for
+// tid & 15 < A (after the barrier that publishes s_part).
+template <int KC0, int AMAX>   // AMAX: compile-time bound of the action dimension (registers of the head partials)
+struct SplitPolicy {
+    StatQ<KC0, 4, true> Q0;      // layer 0: bf16 plane in registers, half residual plane in LDS
+    StatQ<8, 4, false> Q1;       // layer 1: both planes in registers
+    // r0_lds: LDS region for layer 0's residual plane (16 n-tiles x KC0 chunks x 1 KiB); the caller's barrier publishes it
+    __device__ __forceinline__ void load(const RolloutParams& p, int tid, f16x8* r0_lds) {
+        const MlpDev& M = p.pol;
+        Q0.load(p.sp.w1[0], p.sp.r[0], p.sp.inv[0], M.dims[1] >> 4, tid, r0_lds);
+        Q1.load(p.sp.w1[1], p.sp.r[1], p.sp.inv[1], M.dims[2] >> 4, tid);
+    }
+    // s_bias: [.][ldb] hidden biases; s_wo4: [256][4] head weights, feature-major, rows a >= A zero; s_bo: [4] head bias
+    __device__ __forceinline__ float run(const RolloutParams& p, const float* xs, int ldx, char* xq, int rowb0, char* hq,
+                                         float* s_part, const float* s_bias, int ldb, const float* s_wo4, const float* s_bo,
+                                         int tid, bool stash, size_t row0, DbgClock& dbg) {
+        const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
+        const MlpDev& M = p.pol;
+        constexpr int ROWB1 = 2 * 256 + 16;
+        plane_convert_x(xs, ldx, M.kp[0], 32 * KC0, xq, rowb0, tid, SPLIT_FWD_SA);
+        __syncthreads();
+        DBG_TICK(1)
+        const bool gelu = M.act == GOPS_ACT_GELU;
+        // ---- hidden layer 0 ----
+        {
+            f32x4 acc[4] = {}, accr[4] = {};
+            gemm_split<KC0, 4, true>(xq, rowb0, Q0, lane, acc, accr);
+            DBG_TICK(14)
+            float* hrow = stash ? p.st.h[1] + row0 * 256 : nullptr;
+            float* zrow = (stash && gelu) ? p.st.z[1] + row0 * 256 : nullptr;
+            f32x4 hv[4];
+            act_dispatch(M.act, [&]<int ACT>() {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = 64 * wave + 16 * q + (lane & 15);
+                    const float sc = Q0.inv[q] * (1.f / SPLIT_FWD_SA), bn = s_bias[n];
+                    f32x4 zv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = fmaf(accr[q][r], sc, acc[q][r]) + bn;
+                        float hr, dr = z;
+                        if constexpr (ACT == GOPS_ACT_GELU) gelu_pair(z, hr, dr);
+                        else hr = act_fwd_t<ACT>(z);
+                        hv[q][r] = hr; zv[r] = dr;
+                    }
+                    if (hrow != nullptr) __builtin_nontemporal_store(hv[q], gptr(reinterpret_cast<f32x4*>(hrow + n * 16 + m0)));
+                    if (ACT == GOPS_ACT_GELU && zrow != nullptr) __builtin_nontemporal_store(zv, gptr(reinterpret_cast<f32x4*>(zrow + n * 16 + m0)));
+                }
+            });
+            plane_store(hq, ROWB1, wave, lane, hv, SPLIT_FWD_SA);
+        }
+        DBG_TICK(8)
+        __syncthreads();
+        DBG_TICK(9)
+        // ---- hidden layer 1 + output layer partials ----
+        {
+            f32x4 acc[4] = {}, accr[4] = {};
+            gemm_split<8, 4, false>(hq, ROWB1, Q1, lane, acc, accr);
+            DBG_TICK(11)
+            float* hrow = stash ? p.st.h[2] + row0 * 256 : nullptr;
+            float* zrow = (stash && gelu) ? p.st.z[2] + row0 * 256 : nullptr;
+            float part[4][AMAX] = {};
+            act_dispatch(M.act, [&]<int ACT>() {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = 64 * wave + 16 * q + (lane & 15);
+                    const float sc = Q1.inv[q] * (1.f / SPLIT_FWD_SA), bn = s_bias[ldb + n];
+                    const f32x4 wq = *reinterpret_cast<const f32x4*>(s_wo4 + n * 4);
+                    f32x4 h4, zv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = fmaf(accr[q][r], sc, acc[q][r]) + bn;
+                        float hr, dr = z;
+                        if constexpr (ACT == GOPS_ACT_GELU) gelu_pair(z, hr, dr);
+                        else hr = act_fwd_t<ACT>(z);
+                        h4[r] = hr; zv[r] = dr;
+#pragma unroll
+                        for (int a = 0; a < AMAX; ++a) part[r][a] = fmaf(hr, wq[a], part[r][a]);
+                    }
+                    if (hrow != nullptr) __builtin_nontemporal_store(h4, gptr(reinterpret_cast<f32x4*>(hrow + n * 16 + m0)));
+                    if (ACT == GOPS_ACT_GELU && zrow != nullptr) __builtin_nontemporal_store(zv, gptr(reinterpret_cast<f32x4*>(zrow + n * 16 + m0)));
+                }
+            });
+            DBG_TICK(12)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) ps[a] = row16_sum(part[r][a]);
+                if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(s_part + (wave * TB + m0 + r) * 4) = ps;
+            }
+        }
+        DBG_TICK(2)
+        __syncthreads();
+        const int hm = tid >> 4, la = tid & 15;
+        float ya = 0.f;
+        if (la < GOPS_MAX_ACT)
+            ya = ((s_part[(0 * TB + hm) * 4 + la] + s_part[(1 * TB + hm) * 4 + la]) +
+                  (s_part[(2 * TB + hm) * 4 + la] + s_part[(3 * TB + hm) * 4 + la])) + s_bo[la];
+        DBG_TICK(6)
+        return ya;
+    }
+};
+struct NoSplit {};
+
 // SK0 / SK1: k-chunks (16 inputs each) of hidden layers 0 / 1 when their weights are register-
 // stationary (the layer must then be 256 wide), 0 = streamed.
 // TAIL: the INFADP terminal value V_target(obs_H) is evaluated after the loop (compiled out for FHADP so
@@ -143,7 +254,8 @@ __device__ __forceinline__ void mlp_head(WP Wo, int ldw, BP bo, int K, int A, co
 // (F16 kernels: 4 workgroups per CU - launch bound 4 waves / SIMD, <= 128 registers.)
 // GEN (streamed fp32 kernels of the obs == state env kinds): ActionRepeatModel - the env blocks loop over
 // GopsEnv.repeat_num sub-steps; with GEN = false the loops have the compile-time trip count 1
-template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false, bool GEN = false>
+// SPLIT: plane-split contractions (SplitPolicy): SK0 then counts the 32-wide chunks of layer 0, SK1 = 8
+template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false, bool GEN = false, bool SPLIT = false>
 __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1)) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;   // parameters live in device memory: uniform scalar loads
@@ -158,9 +270,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     // leading dimensions are compile-time constants in the register-stationary variants
     const int ldx = p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* xs = smem;                       // [TB][ldx]  current observation (+ time column)
-    float* ha = xs + TB * ldx;              // [TB][ldh]
+    float* ha = xs + TB * ldx;              // [TB][ldh]  (SPLIT: only the tail value net uses ha / hb; they alias the plane images)
     float* hb = ha + hidden_tile_floats(ldh, F16);       // [TB][ldh] floats, or [TB][ldh + 4] halfs (F16)
-    float* s_state = hb + hidden_tile_floats(ldh, F16);  // [TB][8]
+    float* s_state = SPLIT ? xs + TB * ldx : hb + hidden_tile_floats(ldh, F16);  // [TB][8]
     float* s_act = s_state + TB * 8;        // [TB][4] wrapped action
     float* s_th = s_act + TB * 4;           // [TB][4] tanh(head) (ENV_NONE: raw head output)
     float* s_done = s_th + TB * 4;          // [TB]
@@ -176,8 +288,13 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     {   // one-time staging of everything the H-step loop would otherwise re-fetch from L2
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
         for (int idx = tid; idx < GOPS_MAX_ACT * ldh; idx += NTHREADS) {   // rows a >= Ao (and the pad columns) are zero: mlp_head<true>
-            const int a = idx / ldh, k = idx - a * ldh;
-            s_wo[idx] = (a < Ao && k < K) ? gptr(p.pol.w[Lh])[a * K + k] : 0.f;
+            if constexpr (SPLIT) {   // feature-major [K][4]: a lane reads the four action weights of one of its columns as one vector
+                const int k = idx >> 2, a = idx & 3;
+                s_wo[idx] = (a < Ao && k < K) ? gptr(p.pol.w[Lh])[a * K + k] : 0.f;
+            } else {
+                const int a = idx / ldh, k = idx - a * ldh;
+                s_wo[idx] = (a < Ao && k < K) ? gptr(p.pol.w[Lh])[a * K + k] : 0.f;
+            }
         }
         if (tid < GOPS_MAX_ACT) s_bo[tid] = (tid < Ao) ? gptr(p.pol.b[Lh])[tid] : 0.f;
         stage_act_const(p.env, s_ac, tid);
@@ -210,10 +327,23 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             s_state[m * 8 + c] = (m < nvalid && c < 4) ? gptr(p.in.state)[(size_t)(b0 + m) * 4 + c] : 0.f;
         }
     }
-    typename std::conditional<(SK0 > 0), StatW<(SK0 > 0 ? SK0 : 1), 4>, NoW>::type W0;
-    typename std::conditional<(SK1 > 0), StatW<(SK1 > 0 ? SK1 : 1), 4>, NoW>::type W1;
-    if constexpr (SK0 > 0) W0.load(p.pol.wp[0], p.pol.dims[1] >> 4, tid, p.pol.kp[0] >> 4);
-    if constexpr (SK1 > 0) W1.load(p.pol.wp[1], p.pol.dims[2] >> 4, tid);
+    typename std::conditional<(SK0 > 0 && !SPLIT), StatW<(SK0 > 0 ? SK0 : 1), 4>, NoW>::type W0;
+    typename std::conditional<(SK1 > 0 && !SPLIT), StatW<(SK1 > 0 ? SK1 : 1), 4>, NoW>::type W1;
+    if constexpr (SK0 > 0 && !SPLIT) W0.load(p.pol.wp[0], p.pol.dims[1] >> 4, tid, p.pol.kp[0] >> 4);
+    if constexpr (SK1 > 0 && !SPLIT) W1.load(p.pol.wp[1], p.pol.dims[2] >> 4, tid);
+    // SPLIT: plane images of the observation tile and of H_1 behind the reference-table region, then the head partials
+    constexpr int AMAX = (ENV == GOPS_ENV_IDPENDULUM) ? 1 : ((ENV == GOPS_ENV_VEH3DOFCONTI) ? 2 : GOPS_MAX_ACT);
+    typename std::conditional<SPLIT, SplitPolicy<(SK0 > 0 ? SK0 : 1), AMAX>, NoSplit>::type SP;
+    const int rowb0 = split_rowb(32 * SK0);
+    char* xq = reinterpret_cast<char*>(s_ref + (REF ? TB * TL : 0));
+    char* hq = xq + 4 * TB * rowb0;
+    float* s_part = reinterpret_cast<float*>(hq + 4 * TB * split_rowb(256));   // [4 waves][TB][4]
+    f16x8* r0_lds = reinterpret_cast<f16x8*>(s_part + 4 * TB * 4);             // layer 0's residual plane: 16 n-tiles x SK0 KiB
+    if constexpr (SPLIT) {
+        SP.load(p, tid, r0_lds);
+        ha = reinterpret_cast<float*>(xq);   // tail value net (after the loop): its fp32 tiles alias the dead plane images
+        hb = ha + TB * ldh;
+    }
     float v_acc = 0.f;
     float c_ext = 0.f, c_lin = 0.f, c_int = 0.f, c_feas = 1.f;   // SURR: discounted constraint sums of trajectory tid (tid < TB)
     float c_mul[GOPS_MAX_CONSTRAINT] = {1.f, 1.f, 1.f}, c_safe[GOPS_MAX_CONSTRAINT] = {1.f, 1.f, 1.f};   // SPIL products
@@ -243,9 +373,13 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         } else {
             if (p.need_grad) stash_tile_fm(xs, ldx, p.pol.kp[0], p.st.x + row0 * p.pol.kp[0], tid);
         }
-        DBG_TICK(1)
+        if constexpr (!SPLIT) DBG_TICK(1)
         {
             float y[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
+            float ya_split = 0.f;
+            if constexpr (SPLIT) {
+                ya_split = SP.run(p, xs, ldx, xq, rowb0, hq, s_part, s_bias, ldh, s_wo, s_bo, tid, p.need_grad != 0, row0, dbg);
+            } else
             if (!p.open_loop) {
                 if constexpr (F16) {
                     const _Float16* hcur = mlp_hidden_forward_h(p.pol, x16, ldx16, reinterpret_cast<_Float16*>(ha),
@@ -266,6 +400,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             {   // lane a of each 16-lane trajectory group squashes and wraps action a (row16_sum left y in every lane)
                 const int hm = tid >> 4, la = tid & 15;
                 float ya = (la == 0) ? y[0] : (la == 1) ? y[1] : (la == 2) ? y[2] : y[3];
+                if constexpr (SPLIT) ya = ya_split;
                 if (p.open_loop && la < A && hm < nvalid)   // FHADP2: the sequence was emitted by one MLP evaluation outside
                     ya = gptr(p.in.head_pre)[((size_t)(b0 + hm) * p.H + t) * A + la];
                 if (la < A) {
@@ -658,11 +793,44 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     }
 }
 
-size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16) {
+// split_k0: input width (multiple of 32) of hidden layer 0 when the plane-split kernel runs, else 0
+size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int split_k0) {
     size_t b = sizeof(float) * (size_t)(TB * ldx + 2 * hidden_tile_floats(ldh, f16) + TB * (8 + 4 + 4 + 1 + 1 + 2) + (4 + GOPS_MAX_LAYERS - 1) * ldh +
                                         4 * TB * ref_points);
     if (f16) b += sizeof(_Float16) * (size_t)TB * ((((ldx - 4) + 31) & ~31) + 8);   // x16
+    if (split_k0 > 0) {   // plane images of X and H_1, head partials, layer 0's residual plane; no fp32 hidden tiles of their own
+        b += (size_t)4 * TB * (split_rowb(split_k0) + split_rowb(256)) + sizeof(float) * 4 * TB * 4 + (size_t)(split_k0 / 32) * 16384;
+        b -= sizeof(float) * 2 * (size_t)hidden_tile_floats(ldh, false);
+    }
     return b;
+}
+size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split);
+
+static int device_cus() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    return n_cu;
+}
+
+// Plane-split contractions (common.h SplitDev) replace the fp32 MFMAs of the register-stationary kernels for a closed-loop
+// obs -> 256 -> 256 -> act policy on the BASELINE env kinds with at most one tile per CU and an input of at most 128
+// columns (4 chunks of 32: the planes of both layers then fit the register file).  GOPS_SPLIT=0 keeps the fp32 MFMAs.
+bool split_eligible(const RolloutParams& p) {
+    const MlpDev& M = p.pol;
+    if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
+    if (p.env.kind != GOPS_ENV_LQ && p.env.kind != GOPS_ENV_IDPENDULUM && p.env.kind != GOPS_ENV_VEH3DOFCONTI) return false;
+    if (M.nl != 3 || M.dims[1] != 256 || M.dims[2] != 256 || p.ldh != 260 || M.kp32[0] > 128 || p.ldx != M.kp[0] + 4) return false;
+    if ((p.B + TB - 1) / TB > device_cus() && getenv("GOPS_SK") == nullptr) return false;
+    if (const char* e = getenv("GOPS_SPLIT")) if (e[0] == '0') return false;
+    if (const char* e = getenv("GOPS_SK")) if (e[0] == '0') return false;   // "0,..": streamed kernels forced
+    const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
+    if (rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? ref_pts : 0, false, M.kp32[0]) > 160 * 1024) return false;
+    if (rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, true) > 160 * 1024) return false;
+    return true;
 }
 
 // Picks the register-stationary variant when the policy is (kp0 in {16,48,128}) -> 256 -> 256 ...,
@@ -676,13 +844,7 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
     // Register-stationary weights pin one workgroup per CU.  That is the right trade only while there
     // is at most one tile per CU (B <= 16 * #CUs = 4096 on MI355X); with more tiles the streamed
     // kernels win because 2-3 workgroups per CU overlap each other's MFMA and VALU phases.
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
-    if ((p.B + TB - 1) / TB > n_cu && getenv("GOPS_SK") == nullptr) return;
+    if ((p.B + TB - 1) / TB > device_cus() && getenv("GOPS_SK") == nullptr) return;
     if (M.nl - 1 < 2 || M.dims[1] != 256 || M.dims[2] != 256 || p.env.kind == GOPS_ENV_NONE || p.ldh != 260) return;
     sk[1] = 16;
     const int k0 = M.kp[0] >> 4;
@@ -723,10 +885,26 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
 // `p` is the host copy (for shape dispatch), `dp` the device copy the kernel reads.
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0, p.f16 != 0);
+    const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0, p.f16 != 0,
+                                             p.sp.on ? 32 * p.sp.kc[0] : 0);
     int sk[2];
     rollout_variant(p, sk, false);
     const int key = sk[0] * 100 + sk[1];
+    if (p.sp.on) {   // plane-split stationary kernels: layer 0 in KC0 chunks of 32 inputs
+#define LAUNCH_FWD_SPLIT(ENV, KC0)                                                                                           \
+    do {                                                                                                                     \
+        if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, KC0, 8, true, false, false, true>, grid, block, lds, stream, dp);  \
+        else launch_with_lds(rollout_fwd_kernel<ENV, KC0, 8, false, false, false, true>, grid, block, lds, stream, dp);        \
+    } while (0)
+        const int kc0 = p.sp.kc[0];
+        if (p.env.kind == GOPS_ENV_LQ && kc0 == 1) LAUNCH_FWD_SPLIT(GOPS_ENV_LQ, 1);
+        else if (p.env.kind == GOPS_ENV_IDPENDULUM && kc0 == 1) LAUNCH_FWD_SPLIT(GOPS_ENV_IDPENDULUM, 1);
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 2) LAUNCH_FWD_SPLIT(GOPS_ENV_VEH3DOFCONTI, 2);
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 3) LAUNCH_FWD_SPLIT(GOPS_ENV_VEH3DOFCONTI, 3);
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 4) LAUNCH_FWD_SPLIT(GOPS_ENV_VEH3DOFCONTI, 4);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (p.f16) {   // half-precision kernels: weights streamed from L2, four workgroups per CU
         switch (p.env.kind) {
             case GOPS_ENV_NONE: LAUNCH_FWD_H(GOPS_ENV_NONE); break;

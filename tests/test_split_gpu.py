@@ -1,0 +1,100 @@
+"""GPU: the plane-split contractions of the register-stationary kernels (csrc/common.h SplitDev: bf16 + scaled f16 weight
+planes, exact bf16 planes + an f16 plane of the activations / deltas) against the oracle at the 1e-4 bar, and against the
+exact-fp32-MFMA kernels of the same library (GOPS_SPLIT=0) to see what the 19-bit weights cost: every env kind and
+layer-0 chunk count the split kernels are instantiated for, ragged batches, every hidden activation, INFADP's tail value."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from helpers import hip_env_from_oracle, hip_mlp_from_net, reference_init_nets, to_device
+from oracle import adp_oracle as orc
+
+from gops_amd.utils.synthetic import act_dim_of, make_batch, obs_dim_of
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+CASES = {
+    # name: config (policy 256-256 -> the stationary kernels; at most one 16-trajectory tile per CU)
+    "veh_p30_elu": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=200, horizon=12, pre_horizon=30, hidden=(256, 256), act="elu", gamma=0.99),
+    "veh_p20_gelu": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=96, horizon=9, pre_horizon=20, hidden=(256, 256), act="gelu", gamma=1.0),
+    "veh_p10_tanh": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=77, horizon=10, pre_horizon=10, hidden=(256, 256), act="tanh", gamma=0.95),
+    "idp_gelu": dict(alg="FHADP", env_id="pyth_idpendulum", batch=130, horizon=15, hidden=(256, 256), act="gelu", gamma=1.0),
+    "idp_selu": dict(alg="FHADP", env_id="pyth_idpendulum", batch=64, horizon=8, hidden=(256, 256), act="selu", gamma=0.9),
+    "lq_s4a2_relu": dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=100, horizon=20, hidden=(256, 256), act="relu", gamma=0.99),
+    "lq_s6a3_sigmoid": dict(alg="FHADP", env_id="pyth_lq", lq_config="s6a3", batch=33, horizon=10, hidden=(256, 256), act="sigmoid", gamma=1.0),
+    "lq_s2a1_elu": dict(alg="FHADP", env_id="pyth_lq", lq_config="s2a1", batch=16, horizon=25, hidden=(256, 256), act="elu", gamma=0.97),
+}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+def _run(cfg, nets, data, env, dev, monkeypatch, split):
+    from gops_amd import hip_backend as hb
+    monkeypatch.setenv("GOPS_SPLIT", "1" if split else "0")
+    henv = hip_env_from_oracle(env, nets["policy"])
+    mlp, ws, bs = hip_mlp_from_net(nets["policy"], dev)
+    B = data["obs"].shape[0]
+    ro = hb.Rollout(henv, mlp, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=True)
+    res = ro.forward(to_device(data, dev), want_rewards=True, want_final=True)
+    gw, gb = [torch.empty_like(w) for w in ws], [torch.empty_like(b) for b in bs]
+    ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
+    torch.cuda.synchronize()
+    return res, [t for pair in zip(gw, gb) for t in pair]
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_split_kernels_vs_oracle_and_fp32_mfma(name, dev, monkeypatch):
+    cfg = CASES[name]
+    data = make_batch(cfg, 3)
+    nets = reference_init_nets(cfg, 3, obs_dim_of(cfg), act_dim_of(cfg))
+    env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
+    ref = orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+    res, grads = _run(cfg, nets, data, env, dev, monkeypatch, split=True)
+    res0, grads0 = _run(cfg, nets, data, env, dev, monkeypatch, split=False)
+    assert rel_l2(res["v_pi"].cpu(), ref["v_pi"]) < TOL
+    assert rel_l2(res["rewards"].cpu(), ref["rewards"]) < TOL
+    assert rel_l2(res["final_obs"].cpu(), ref["final_obs"]) < TOL
+    assert np.array_equal(res["final_done"].cpu().numpy() != 0, ref["final_done"].numpy())
+    flat = torch.cat([g.reshape(-1).cpu() for g in grads])
+    flat0 = torch.cat([g.reshape(-1).cpu() for g in grads0])
+    flat_ref = torch.cat([g.reshape(-1) for g in ref["grads"]])
+    err, err0 = rel_l2(flat, flat_ref), rel_l2(flat0, flat_ref)
+    worst = max(rel_l2(g.cpu(), w) for g, w in zip(grads, ref["grads"]))
+    print(f"{name}: gradient rel-L2 to the oracle: plane-split {err:.2e} (worst tensor {worst:.2e}), fp32 MFMA {err0:.2e}; "
+          f"split vs fp32 MFMA {rel_l2(flat, flat0):.2e}; v_pi {rel_l2(res['v_pi'].cpu(), ref['v_pi']):.2e}")
+    assert err < TOL and worst < TOL, (name, err, worst)
+    assert rel_l2(flat, flat0) < 5e-5, (name, rel_l2(flat, flat0))   # the two arithmetic paths agree far inside the bar
+
+
+def test_split_kernels_with_tail_value(dev, monkeypatch):
+    """INFADP's policy-improvement gradient (tail value net after the loop: its fp32 tiles alias the plane images)."""
+    from gops_amd import hip_backend as hb
+    cfg = dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=90, horizon=8, hidden=(256, 256), act="gelu", gamma=0.99)
+    data = make_batch(cfg, 8)
+    nets = reference_init_nets(cfg, 8, obs_dim_of(cfg), act_dim_of(cfg))
+    env = orc.make_env("pyth_lq", lq_config="s4a2")
+    want = orc.infadp_pim_gradient(env, nets["policy"], nets["v_target"], data, cfg["horizon"], cfg["gamma"])
+    out = {}
+    for split in (True, False):
+        monkeypatch.setenv("GOPS_SPLIT", "1" if split else "0")
+        henv = hip_env_from_oracle(env, nets["policy"])
+        pol, pw, pb = hip_mlp_from_net(nets["policy"], dev)
+        vt, _, _ = hip_mlp_from_net(nets["v_target"], dev)
+        B = data["obs"].shape[0]
+        ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=False, need_grad=True, value=vt)
+        res = ro.forward(to_device(data, dev))
+        gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]
+        ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
+        torch.cuda.synchronize()
+        out[split] = (res["v_pi"].cpu(), torch.cat([t.reshape(-1).cpu() for pair in zip(gw, gb) for t in pair]))
+    flat_ref = torch.cat([g.reshape(-1) for g in want["grads"]])
+    for split in (True, False):
+        assert abs(-out[split][0].double().mean().item() - float(want["loss"])) <= TOL * max(1.0, abs(float(want["loss"])))
+        assert rel_l2(out[split][1], flat_ref) < TOL, (split, rel_l2(out[split][1], flat_ref))
+    print(f"tail: split {rel_l2(out[True][1], flat_ref):.2e} fp32 MFMA {rel_l2(out[False][1], flat_ref):.2e}")

@@ -69,6 +69,9 @@ struct SplitDev {
     const f16x8* rt[2];
     const float* invt[2];
 };
+#ifndef GOPS_PIN_MODE
+#define GOPS_PIN_MODE 2   // layer-1 bf16 planes of the split kernels pinned to AGPRs (StatQ PIN; modes 1 / 2 / 3 measured within 1 %, r03)
+#endif
 #define SPLIT_FWD_SA 1.0f       // forward: af = f16(a) (saturating: beyond 65504 only the 2^-9-sized correction term degrades)
 // position e of a hidden tile's plane row (the order plane_store writes, = the contraction order of the next GEMM) -> feature
 __host__ __device__ inline int split_perm(int e) { return 64 * (e >> 6) + 16 * (e & 3) + ((e & 63) >> 2); }
@@ -216,6 +219,19 @@ __device__ __forceinline__ float act_fwd_t(float z) {
     if (ACT == GOPS_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
     if (ACT == GOPS_ACT_TANH) return tanhf(z);
     return z;
+}
+
+// tanh on the hardware exponential: (1 - t) / (1 + t) with t = exp(-2|x|) away from zero (relative error ~5e-7 worst
+// case, just above the switch point), the odd series up to x^7 below |x| = 1/8 (truncation 2e-10); branch-free.  libm's
+// tanhf is ~200 instructions with divergent branches and sat on the critical path of every step (head -> action).
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x), x2 = x * x;
+    const float t = __expf(-2.f * ax);
+    const float big = (1.f - t) * __builtin_amdgcn_rcpf(1.f + t);
+    float poly = fmaf(x2, -17.f / 315.f, 2.f / 15.f);
+    poly = fmaf(poly, x2, -1.f / 3.f);
+    poly = fmaf(poly, x2, 1.f);
+    return ax < 0.125f ? x * poly : copysignf(big, x);
 }
 
 // derivative act'(z); `h` is the stashed activation act(z); for GELU `z` is the stashed DERIVATIVE (see gelu_pair)
@@ -391,12 +407,30 @@ __device__ __forceinline__ void plane_convert_x(const float* xs, int ldx, int kp
     }
 }
 
+// A value pinned to the accumulator half of the register file (v_accvgpr_write_b32 with an "a"-constrained result): the
+// MFMA reads its B operand from there directly.  Left to itself hipcc keeps as many weight fragments as fit in VGPRs,
+// parks the rest in AGPRs as SPILLS and copies each back (4 x v_accvgpr_read_b32 = 16 issue cycles) in front of the MFMA
+// that needs it - as long as the 16-cycle MFMA itself.
+template <class V>
+__device__ __forceinline__ V pin_agpr(const V& x) {
+    static_assert(sizeof(V) == 16, "128-bit fragments");
+    const u32x4 u = __builtin_bit_cast(u32x4, x);
+    u32x4 r;
+    unsigned t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        asm("v_accvgpr_write_b32 %0, %1" : "=a"(t) : "v"(u[i]));
+        r[i] = t;
+    }
+    return __builtin_bit_cast(V, r);
+}
+
 // Plane-split weights of one layer for this wave's NT n-tiles x KCH chunks of 32 inputs.  The bf16 plane is register-
 // stationary; the half residual plane is register-stationary too (RLDS = false) or lives in LDS (RLDS = true: `rl` points
 // at the workgroup's copy of the packed plane, fragment (n-tile nt, chunk c) of lane l at rl[((nt * KCH + c) * 64 + l)],
 // read with conflict-free ds_read_b128 a few MFMAs ahead of its use).  One 256 x 256 layer is 256 registers per lane with
 // both planes resident; two such layers do not fit beside the rest of the kernel, so layer 0 keeps its residual plane in LDS.
-template <int KCH, int NT, bool RLDS>
+template <int KCH, int NT, bool RLDS, int PIN = 0>   // PIN: planes pinned to AGPRs (pin_agpr): bit 0 the residual plane, bit 1 the bf16 plane
 struct StatQ {
     bf16x8 w[KCH * NT];
     f16x8 r[RLDS ? 1 : KCH * NT];
@@ -413,8 +447,12 @@ struct StatQ {
 #pragma unroll
             for (int c = 0; c < KCH; ++c) {
                 const size_t at = ((size_t)(ok ? nt0 + j : 0) * KCH + c) * 64 + lane;
-                w[c * NT + j] = gptr(W1)[at];
-                if constexpr (!RLDS) r[c * NT + j] = gptr(R)[at];
+                if constexpr ((PIN & 2) != 0) w[c * NT + j] = pin_agpr(gptr(W1)[at]);
+                else w[c * NT + j] = gptr(W1)[at];
+                if constexpr (!RLDS) {
+                    if constexpr ((PIN & 1) != 0) r[c * NT + j] = pin_agpr(gptr(R)[at]);
+                    else r[c * NT + j] = gptr(R)[at];
+                }
             }
         }
         if constexpr (RLDS) {
@@ -425,10 +463,11 @@ struct StatQ {
 };
 
 // acc (bf16 main term) / accr (f16 residual term, still scaled) of this wave's NT n-tiles over the plane image `planes`.
-// Every A fragment is refreshed IN PLACE with the next chunk's right after its last use (one register set, the LDS read has
-// the other planes' MFMAs to land); an LDS-resident residual plane is fetched at the top of the chunk, 3 NT MFMAs ahead.
-template <int KCH, int NT, bool RLDS>
-__device__ __forceinline__ void gemm_split(const char* planes, int rowb, const StatQ<KCH, NT, RLDS>& W, int lane,
+// The four A fragments of chunk c + 1 (and an LDS-resident residual plane's fragments of chunk c) are requested ahead of
+// chunk c's 4 NT MFMAs - pinned there with a scheduling barrier, because left alone hipcc sinks every ds_read to just
+// in front of its first use and each group of NT MFMAs then waits out a full LDS round trip.
+template <int KCH, int NT, bool RLDS, int PIN>
+__device__ __forceinline__ void gemm_split(const char* planes, int rowb, const StatQ<KCH, NT, RLDS, PIN>& W, int lane,
                                            f32x4 (&acc)[NT], f32x4 (&accr)[NT]) {
     const int pstride = TB * rowb;
     const char* arow = planes + (lane & 15) * rowb + (lane >> 4) * 16;
@@ -442,21 +481,28 @@ __device__ __forceinline__ void gemm_split(const char* planes, int rowb, const S
 #pragma unroll
             for (int j = 0; j < NT; ++j) rr[j] = W.rl[(j * KCH + c) * 64];
         }
+        bf16x8 n1 = a1, n2 = a2, n3 = a3;
+        f16x8 nf = af;
+        if (c + 1 < KCH) {
+            n3 = *reinterpret_cast<const bf16x8*>(arow + 64 * (c + 1) + 2 * pstride);
+            n2 = *reinterpret_cast<const bf16x8*>(arow + 64 * (c + 1) + pstride);
+            n1 = *reinterpret_cast<const bf16x8*>(arow + 64 * (c + 1));
+            nf = *reinterpret_cast<const f16x8*>(arow + 64 * (c + 1) + 3 * pstride);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, W.w[c * NT + j], acc[j], 0, 0, 0);
-        if (c + 1 < KCH) a3 = *reinterpret_cast<const bf16x8*>(arow + 64 * (c + 1) + 2 * pstride);
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, W.w[c * NT + j], acc[j], 0, 0, 0);
-        if (c + 1 < KCH) a2 = *reinterpret_cast<const bf16x8*>(arow + 64 * (c + 1) + pstride);
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, W.w[c * NT + j], acc[j], 0, 0, 0);
-        if (c + 1 < KCH) a1 = *reinterpret_cast<const bf16x8*>(arow + 64 * (c + 1));
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             if constexpr (RLDS) accr[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, rr[j], accr[j], 0, 0, 0);
             else accr[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, W.r[c * NT + j], accr[j], 0, 0, 0);
         }
-        if (c + 1 < KCH) af = *reinterpret_cast<const f16x8*>(arow + 64 * (c + 1) + 3 * pstride);
+        __builtin_amdgcn_sched_barrier(0);
+        a1 = n1; a2 = n2; a3 = n3; af = nf;
     }
 }
 

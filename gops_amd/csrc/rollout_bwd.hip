@@ -163,7 +163,7 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
 // max|delta_y| of the tile), taken out again with the residual accumulator's factor.
 template <int PT0>
 struct SplitSweep {
-    StatQ<8, 4, false> QT1;      // delta_2 -> delta_1 through W_1: both planes in registers
+    StatQ<8, 4, false, GOPS_PIN_MODE> QT1;      // delta_2 -> delta_1 through W_1: both planes in registers
     StatQ<8, PT0, true> QT0;     // delta_1 -> g_x through W_0: bf16 plane in registers, half residual plane in LDS
     float wo[4];                 // W_o[k = lane >> 4][64 wave + 16 q + (lane & 15)]: B operand of the head-delta MFMA
     f32x4 hv[4];                 // act' operands of this lane's four columns: H_2 (Z_2 for GELU) of the step, then H_1
@@ -231,7 +231,7 @@ struct SplitSweep {
         DBG_TICK(5)
         {   // ---- delta_1 = (delta_2 W_1) * act'(z_1) ----
             f32x4 acc[4] = {}, accr[4] = {};
-            gemm_split<8, 4, false>(dq2, ROWB, QT1, lane, acc, accr);
+            gemm_split(dq2, ROWB, QT1, lane, acc, accr);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float sc = QT1.inv[q] * inv_s;
@@ -246,7 +246,7 @@ struct SplitSweep {
         DBG_TICK(8)
         if (want_gx) {   // ---- input adjoint g_x = delta_1 W_0, accumulated into G ----
             f32x4 acc[PT0] = {}, accr[PT0] = {};
-            gemm_split<8, PT0, true>(dq1, ROWB, QT0, lane, acc, accr);
+            gemm_split(dq1, ROWB, QT0, lane, acc, accr);
             float gold[PT0][4];
 #pragma unroll
             for (int j = 0; j < PT0; ++j) {

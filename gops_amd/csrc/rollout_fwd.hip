@@ -145,7 +145,7 @@ __device__ __forceinline__ void mlp_head(WP Wo, int ldw, BP bo, int K, int A, co
 template <int KC0, int AMAX>   // AMAX: compile-time bound of the action dimension (registers of the head partials)
 struct SplitPolicy {
     StatQ<KC0, 4, true> Q0;      // layer 0: bf16 plane in registers, half residual plane in LDS
-    StatQ<8, 4, false> Q1;       // layer 1: both planes in registers
+    StatQ<8, 4, false, GOPS_PIN_MODE> Q1;       // layer 1: both planes in registers
     // r0_lds: LDS region for layer 0's residual plane (16 n-tiles x KC0 chunks x 1 KiB); the caller's barrier publishes it
     __device__ __forceinline__ void load(const RolloutParams& p, int tid, f16x8* r0_lds) {
         const MlpDev& M = p.pol;
@@ -166,7 +166,7 @@ struct SplitPolicy {
         // ---- hidden layer 0 ----
         {
             f32x4 acc[4] = {}, accr[4] = {};
-            gemm_split<KC0, 4, true>(xq, rowb0, Q0, lane, acc, accr);
+            gemm_split(xq, rowb0, Q0, lane, acc, accr);
             DBG_TICK(14)
             float* hrow = stash ? p.st.h[1] + row0 * 256 : nullptr;
             float* zrow = (stash && gelu) ? p.st.z[1] + row0 * 256 : nullptr;
@@ -197,7 +197,7 @@ struct SplitPolicy {
         // ---- hidden layer 1 + output layer partials ----
         {
             f32x4 acc[4] = {}, accr[4] = {};
-            gemm_split<8, 4, false>(hq, ROWB1, Q1, lane, acc, accr);
+            gemm_split(hq, ROWB1, Q1, lane, acc, accr);
             DBG_TICK(11)
             float* hrow = stash ? p.st.h[2] + row0 * 256 : nullptr;
             float* zrow = (stash && gelu) ? p.st.z[2] + row0 * 256 : nullptr;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                         s_act[hm * 4 + la] = ya;
                     } else {
                         const ActC c = act_const(s_ac, la);
-                        const float th = tanhf(ya);
+                        const float th = SPLIT ? fast_tanh(ya) : tanhf(ya);
                         s_th[hm * 4 + la] = th;
                         s_act[hm * 4 + la] = wrap_action(c, c.sc * th + c.of);
                     }

@@ -4,6 +4,7 @@
 // the env state (registers).  Per step: env-model adjoint -> adjoint of the action -> wrapper /
 // tanh -> head -> hidden-layer deltas on MFMA with the transposed-packed weights.  The deltas are
 // written to the stash; the weight gradients are formed afterwards by the dW GEMM kernels.
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -279,13 +280,15 @@ struct NoSweep {};
 // EXT (streamed fp32 kernels of the obs == state env kinds only): terminal observation adjoint in, initial
 // observation adjoint out, parameter deltas of step 0 only - gops_rollout_backward_adj / gops_mlp_backward_x
 // SPLIT: plane-split contractions (SplitSweep; SK1 > 0, PT0 = n-tiles of g_x per wave)
-template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, bool EXT = false, bool SPLIT = false>
+// MULTI (SPLIT only): more tiles than workgroups - grid-stride walk over the tiles
+template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, bool EXT = false, bool SPLIT = false, bool MULTI = false>
 __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1)) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;
     const int tid = threadIdx.x;
-    const int b0 = blockIdx.x * TB;
-    const int nvalid = min(TB, p.B - b0);
+    int tile = blockIdx.x;   // SPLIT: grid-stride walk over the tiles with the weights resident (else one tile per workgroup)
+    int b0 = tile * TB;
+    int nvalid = min(TB, p.B - b0);
     const int O = p.env.obs_dim, A = p.env.act_dim;
     constexpr bool SURR = (ENV == GOPS_ENV_VEH3DOF_SURR);   // veh3dofconti + surrounding vehicles + constraint outputs
     constexpr bool VEH = (ENV == GOPS_ENV_VEH3DOFCONTI) || SURR;
@@ -309,6 +312,69 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     float* s_stage = smem + bwd_lds_floats(ldx, ldh, REF ? p.env.pre_horizon + 1 + p.H
                                                                              : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0), F16, SPLIT);
 
+    const int ld16 = (p.ldh - 4) + 8;                 // F16: leading dimension (halfs) of the delta tiles
+    // fp32 observation column i of row m of the stash tile at row0 (the env adjoints read the first few):
+    // F16 keeps a row-major [S][8] fp32 copy, the fp32 stash is feature-major
+    auto x_col = [&](size_t row0, int m, int i) -> float {
+        if constexpr (F16) return gptr(p.st.xf)[(row0 + m) * 8 + i];
+        else return gptr(p.st.x)[(row0 * p.pol.kp[0]) + i * 16 + m];
+    };
+    const IdpConst IC = idp_const();
+    const VehConst VC = veh_const();
+    const int TL = p.env.pre_horizon + 1 + p.H;
+    const int kp0 = p.pol.kp[0];
+    {
+        const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
+        if constexpr (!SPLIT) {
+            for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
+                const int a = idx / K, k = idx - a * K;
+                s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
+            }
+        }
+    }
+    typename std::conditional<(SK0 > 0 && !SPLIT), StatW<(SK0 > 0 ? SK0 : 1), PT0>, NoW>::type WT0;
+    typename std::conditional<(SK1 > 0 && !SPLIT), StatW<16, 4>, NoW>::type WT1;
+    if constexpr (SK0 > 0 && !SPLIT) WT0.load(p.pol.wpt[0], kp0 >> 4, tid, p.pol.dims[1] >> 4);
+    if constexpr (SK1 > 0 && !SPLIT) WT1.load(p.pol.wpt[1], p.pol.dims[1] >> 4, tid);
+    typename std::conditional<SPLIT, SplitSweep<PT0>, NoSweep>::type SS;
+    // SPLIT: W_0's residual plane ((kp0 / 16) n-tiles x 8 chunks x 1 KiB) behind the two small staging halves
+    if constexpr (SPLIT) SS.load(p, tid, reinterpret_cast<f16x8*>(s_stage + 2 * (TB * ENV_STASH + TB * 8)));
+
+    DbgClock dbg;
+    dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
+    // One-workgroup-per-CU variants: everything step tt reads from the stash - the H_2 / H_1 tiles the
+    // head and the layer-1 epilogue take act' from (Z for GELU), the env rows and the first 8 columns of
+    // the observation rows - is fetched straight into LDS (global_load_lds: no VGPRs) ONE STEP AHEAD, into
+    // the half of the staging area selected by the step's parity.  For the tiles each wave fetches
+    // exactly what its own lanes read later: rows 4w..4w+3 of H_2 (one 1-KiB row per instruction) and
+    // columns 64w..64w+63 of H_1 (4 rows x 64 columns per instruction); the small rows are fetched by
+    // waves 0 / 1 and read by everyone after the end-of-step barrier (which drains the loads).
+    constexpr int STAGE_TILES = SPLIT ? 0 : 2 * TB * 256;   // (SPLIT: act' operands go stash -> registers, SplitSweep::fetch)
+    constexpr int STAGE_FLOATS = STAGE_TILES + TB * ENV_STASH + TB * 8;
+    auto stage_step = [&](int tt) {
+        const size_t r0 = ((size_t)tile * p.H + tt) * TB;
+        const float* dst = s_stage + (tt & 1) * STAGE_FLOATS;
+        const bool gelu_s = p.pol.act == GOPS_ACT_GELU;
+        const float* src2 = (gelu_s ? p.st.z[2] : p.st.h[2]) + r0 * 256;
+        const float* src1 = (gelu_s ? p.st.z[1] : p.st.h[1]) + r0 * 256;
+        const int ln = tid & 63, wv = tid >> 6;
+        // FM tiles are 16 KiB of contiguous memory, features 64 w .. 64 w + 63 (wave w's n-tiles) 4 KiB of it
+        if constexpr (!SPLIT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                async_copy16_to_lds(src2 + wv * 1024 + q * 256 + 4 * ln, dst + wv * 1024 + q * 256);
+                async_copy16_to_lds(src1 + wv * 1024 + q * 256 + 4 * ln, dst + TB * 256 + wv * 1024 + q * 256);
+            }
+        }
+        if (wv == 0)        // env rows: 16 x 64 B, contiguous
+            async_copy16_to_lds(p.st.env + r0 * ENV_STASH + 4 * ln, dst + STAGE_TILES);
+        if (wv == 1 && ln < 2 * TB)   // first 8 observation columns: 8 x 64 B, contiguous in the FM tile -> st_x[i * 16 + m]
+            async_copy16_to_lds(p.st.x + r0 * kp0 + 4 * ln, dst + STAGE_TILES + TB * ENV_STASH);
+    };
+    const int ntiles = (p.B + TB - 1) / TB;
+    do {   // ---- one tile of 16 trajectories ----
+    b0 = tile * TB;
+    nvalid = min(TB, p.B - b0);
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
     if constexpr (EXT) {
         if (p.adj_gfo != nullptr) {   // the caller's terminal term: G starts as d(loss)/d(obs_H)
@@ -332,44 +398,14 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         for (int k = 0; k < GOPS_MAX_CONSTRAINT; ++k)
             if (k < p.env.n_constraint) gc_mul[k] = gptr(p.in.grad_constraint_prod)[(size_t)k * p.B + b0 + tid];
     }
-    const int ld16 = (p.ldh - 4) + 8;                 // F16: leading dimension (halfs) of the delta tiles
-    // fp32 observation column i of row m of the stash tile at row0 (the env adjoints read the first few):
-    // F16 keeps a row-major [S][8] fp32 copy, the fp32 stash is feature-major
-    auto x_col = [&](size_t row0, int m, int i) -> float {
-        if constexpr (F16) return gptr(p.st.xf)[(row0 + m) * 8 + i];
-        else return gptr(p.st.x)[(row0 * p.pol.kp[0]) + i * 16 + m];
-    };
     float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // adjoint of the veh3dof state (tid < TB)
-    const IdpConst IC = idp_const();
-    const VehConst VC = veh_const();
-    const int TL = p.env.pre_horizon + 1 + p.H;
-    const int kp0 = p.pol.kp[0];
-    {
-        const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
-        if constexpr (!SPLIT) {
-            for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
-                const int a = idx / K, k = idx - a * K;
-                s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
-            }
-        }
-        if (REF) {
-            const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
-            for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                s_ref[idx] = (idx < nvalid * TL) ? tbl[idx] : z;
-            }
+    if (REF) {
+        const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
+        for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            s_ref[idx] = (idx < nvalid * TL) ? tbl[idx] : z;
         }
     }
-    typename std::conditional<(SK0 > 0 && !SPLIT), StatW<(SK0 > 0 ? SK0 : 1), PT0>, NoW>::type WT0;
-    typename std::conditional<(SK1 > 0 && !SPLIT), StatW<16, 4>, NoW>::type WT1;
-    if constexpr (SK0 > 0 && !SPLIT) WT0.load(p.pol.wpt[0], kp0 >> 4, tid, p.pol.dims[1] >> 4);
-    if constexpr (SK1 > 0 && !SPLIT) WT1.load(p.pol.wpt[1], p.pol.dims[1] >> 4, tid);
-    typename std::conditional<SPLIT, SplitSweep<PT0>, NoSweep>::type SS;
-    // SPLIT: W_0's residual plane ((kp0 / 16) n-tiles x 8 chunks x 1 KiB) behind the two small staging halves
-    if constexpr (SPLIT) SS.load(p, tid, reinterpret_cast<f16x8*>(s_stage + 2 * (TB * ENV_STASH + TB * 8)));
-
-    DbgClock dbg;
-    dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
     if (TAIL) {
         if (tid < TB) {
             const float dH = (tid < nvalid) ? gptr(p.st.tail_done)[b0 + tid] : 1.f;
@@ -388,35 +424,6 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     }
     __syncthreads();
 
-    // One-workgroup-per-CU variants: everything step tt reads from the stash - the H_2 / H_1 tiles the
-    // head and the layer-1 epilogue take act' from (Z for GELU), the env rows and the first 8 columns of
-    // the observation rows - is fetched straight into LDS (global_load_lds: no VGPRs) ONE STEP AHEAD, into
-    // the half of the staging area selected by the step's parity.  For the tiles each wave fetches
-    // exactly what its own lanes read later: rows 4w..4w+3 of H_2 (one 1-KiB row per instruction) and
-    // columns 64w..64w+63 of H_1 (4 rows x 64 columns per instruction); the small rows are fetched by
-    // waves 0 / 1 and read by everyone after the end-of-step barrier (which drains the loads).
-    constexpr int STAGE_TILES = SPLIT ? 0 : 2 * TB * 256;   // (SPLIT: act' operands go stash -> registers, SplitSweep::fetch)
-    constexpr int STAGE_FLOATS = STAGE_TILES + TB * ENV_STASH + TB * 8;
-    auto stage_step = [&](int tt) {
-        const size_t r0 = ((size_t)blockIdx.x * p.H + tt) * TB;
-        const float* dst = s_stage + (tt & 1) * STAGE_FLOATS;
-        const bool gelu_s = p.pol.act == GOPS_ACT_GELU;
-        const float* src2 = (gelu_s ? p.st.z[2] : p.st.h[2]) + r0 * 256;
-        const float* src1 = (gelu_s ? p.st.z[1] : p.st.h[1]) + r0 * 256;
-        const int ln = tid & 63, wv = tid >> 6;
-        // FM tiles are 16 KiB of contiguous memory, features 64 w .. 64 w + 63 (wave w's n-tiles) 4 KiB of it
-        if constexpr (!SPLIT) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                async_copy16_to_lds(src2 + wv * 1024 + q * 256 + 4 * ln, dst + wv * 1024 + q * 256);
-                async_copy16_to_lds(src1 + wv * 1024 + q * 256 + 4 * ln, dst + TB * 256 + wv * 1024 + q * 256);
-            }
-        }
-        if (wv == 0)        // env rows: 16 x 64 B, contiguous
-            async_copy16_to_lds(p.st.env + r0 * ENV_STASH + 4 * ln, dst + STAGE_TILES);
-        if (wv == 1 && ln < 2 * TB)   // first 8 observation columns: 8 x 64 B, contiguous in the FM tile -> st_x[i * 16 + m]
-            async_copy16_to_lds(p.st.x + r0 * kp0 + 4 * ln, dst + STAGE_TILES + TB * ENV_STASH);
-    };
     if constexpr (STAGE) {
         stage_step(p.H - 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
 
     unsigned l2_sink = 0, l2_pf[TOUCH_SLOTS] = {0u, 0u, 0u, 0u};
     for (int t = p.H - 1; t >= 0; --t) {
-        const size_t row0 = ((size_t)blockIdx.x * p.H + t) * TB;   // tile-major stash rows
+        const size_t row0 = ((size_t)tile * p.H + t) * TB;   // tile-major stash rows
         const size_t prow = row0 - TB;
         const float* st_cur = s_stage + (t & 1) * STAGE_FLOATS;       // this step's staged data (STAGE only)
         const float* st_env = st_cur + STAGE_TILES;
@@ -1031,7 +1038,6 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         DBG_TICK(2)
     }
     if (l2_sink == 0x9e3779b9u && p.dbg != nullptr) gptr(p.dbg)[15] = l2_sink;   // keeps the warm-up loads alive
-    dbg.dump(p.dbg);
     if constexpr (EXT) {
         if (p.adj_gobs != nullptr) {   // (the loop's closing barrier made every G update visible)
             for (int idx = tid; idx < nvalid * O; idx += NTHREADS) {
@@ -1040,6 +1046,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             }
         }
     }
+    } while (SPLIT && MULTI && (tile += gridDim.x) < ntiles);   // (every step ends with a barrier: the next tile's set-up may overwrite G / s_ref)
+    dbg.dump(p.dbg);
 }
 
 // ref_points: reference-table points per trajectory (veh3dofconti), 30 (= 5 x 24 / 4) for the
@@ -1051,6 +1059,7 @@ size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool sp
 }
 
 void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
+int split_grid_limit();   // rollout_fwd.hip: CUs of the device
 
 #define LAUNCH_BWD(ENV, A, B)                                                                            \
     do {                                                                                                 \
@@ -1098,10 +1107,15 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
         lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, true);
 #define LAUNCH_BWD_SPLIT(ENV, PT)                                                                                                  \
     do {                                                                                                                          \
-        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, true, PT, false, false, true>, grid, block, lds, stream, dp);    \
+        if (multi) {                                                                                                              \
+            if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, true, PT, false, false, true, true>, grid, block, lds, stream, dp);    \
+            else launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, false, PT, false, false, true, true>, grid, block, lds, stream, dp);          \
+        } else if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, true, PT, false, false, true>, grid, block, lds, stream, dp);    \
         else launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, false, PT, false, false, true>, grid, block, lds, stream, dp);          \
     } while (0)
         const int pt = (p.pol.kp[0] + 63) >> 6;
+        const dim3 grid(std::min<int>((p.B + TB - 1) / TB, split_grid_limit()));   // one workgroup per CU, grid-stride over the tiles
+        const bool multi = (p.B + TB - 1) / TB > split_grid_limit();
         if (p.env.kind == GOPS_ENV_LQ && pt == 1) LAUNCH_BWD_SPLIT(GOPS_ENV_LQ, 1);
         else if (p.env.kind == GOPS_ENV_IDPENDULUM && pt == 1) LAUNCH_BWD_SPLIT(GOPS_ENV_IDPENDULUM, 1);
         else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && pt == 1) LAUNCH_BWD_SPLIT(GOPS_ENV_VEH3DOFCONTI, 1);

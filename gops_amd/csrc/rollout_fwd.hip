@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #define GOPS_STREAMB_EXACT_REFILL   // (this translation unit only: the backward kernels' register allocation degrades with it)
@@ -255,13 +256,18 @@ struct NoSplit {};
 // GEN (streamed fp32 kernels of the obs == state env kinds): ActionRepeatModel - the env blocks loop over
 // GopsEnv.repeat_num sub-steps; with GEN = false the loops have the compile-time trip count 1
 // SPLIT: plane-split contractions (SplitPolicy): SK0 then counts the 32-wide chunks of layer 0, SK1 = 8
-template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false, bool GEN = false, bool SPLIT = false>
+// MULTI (SPLIT only): more tiles than workgroups - the kernel walks its tiles grid-stride (the single-tile instantiation
+// keeps fewer values live across the step loop)
+template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false, bool GEN = false, bool SPLIT = false, bool MULTI = false>
 __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1)) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;   // parameters live in device memory: uniform scalar loads
     const int tid = threadIdx.x;
-    const int b0 = blockIdx.x * TB;
-    const int nvalid = min(TB, p.B - b0);
+    // SPLIT kernels are launched with at most one workgroup per CU and walk tiles tile, tile + gridDim.x, ... with their
+    // weights resident; every other variant has one tile per workgroup (the tile loop below runs once)
+    int tile = blockIdx.x;
+    int b0 = tile * TB;
+    int nvalid = min(TB, p.B - b0);
     const int O = p.env.obs_dim, A = p.env.act_dim;
     constexpr bool SURR = (ENV == GOPS_ENV_VEH3DOF_SURR);   // veh3dofconti + surrounding vehicles + constraint outputs
     constexpr bool VEH = (ENV == GOPS_ENV_VEH3DOFCONTI) || SURR;
@@ -300,32 +306,6 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         stage_act_const(p.env, s_ac, tid);
         for (int j = 0; j < Lh; ++j)
             for (int n = tid; n < p.pol.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = gptr(p.pol.b[j])[n];
-        if (REF) {
-            const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
-            for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                s_ref[idx] = (idx < nvalid * TL) ? tbl[idx] : z;
-            }
-        }
-    }
-
-    for (int idx = tid; idx < TB * ldx; idx += NTHREADS) {
-        const int m = idx / ldx, c = idx - m * ldx;
-        xs[idx] = (c < O && m < nvalid) ? gptr(p.in.obs)[(size_t)(b0 + m) * O + c] : 0.f;
-    }
-    // (no MaskAtDoneModel in the chain: the base models ignore the done flags they are handed)
-    if (tid < TB) s_done[tid] = (tid < nvalid && p.in.done != nullptr && !p.env.no_mask_at_done && gptr(p.in.done)[b0 + tid] != 0.f) ? 1.f : 0.f;
-    if (VEH) {
-        if (tid < TB * 6) {
-            const int m = tid / 6, c = tid - m * 6;
-            s_state[m * 8 + c] = (m < nvalid) ? gptr(p.in.state)[(size_t)(b0 + m) * 6 + c] : (c == 3 ? 1.f : 0.f);
-        }
-    }
-    if (VEH2) {
-        if (tid < TB * 8) {
-            const int m = tid >> 3, c = tid & 7;
-            s_state[m * 8 + c] = (m < nvalid && c < 4) ? gptr(p.in.state)[(size_t)(b0 + m) * 4 + c] : 0.f;
-        }
     }
     typename std::conditional<(SK0 > 0 && !SPLIT), StatW<(SK0 > 0 ? SK0 : 1), 4>, NoW>::type W0;
     typename std::conditional<(SK1 > 0 && !SPLIT), StatW<(SK1 > 0 ? SK1 : 1), 4>, NoW>::type W1;
@@ -344,15 +324,48 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         ha = reinterpret_cast<float*>(xq);   // tail value net (after the loop): its fp32 tiles alias the dead plane images
         hb = ha + TB * ldh;
     }
-    float v_acc = 0.f;
-    float c_ext = 0.f, c_lin = 0.f, c_int = 0.f, c_feas = 1.f;   // SURR: discounted constraint sums of trajectory tid (tid < TB)
-    float c_mul[GOPS_MAX_CONSTRAINT] = {1.f, 1.f, 1.f}, c_safe[GOPS_MAX_CONSTRAINT] = {1.f, 1.f, 1.f};   // SPIL products
-    float veh_s = 0.f, veh_c = 1.f;   // sin/cos of the current heading, carried across steps
     const IdpConst IC = idp_const();
     const VehConst VC = veh_const();
 
     DbgClock dbg;
     dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
+    const int ntiles = (p.B + TB - 1) / TB;
+    do {   // ---- one tile of 16 trajectories (SPLIT: a grid-stride walk over the tiles) ----
+    b0 = tile * TB;
+    nvalid = min(TB, p.B - b0);
+    if constexpr (SPLIT && MULTI && TAIL) {   // the previous tile's tail value net left ITS biases in s_bias
+        for (int j = 0; j < p.pol.nl - 1; ++j)
+            for (int n = tid; n < p.pol.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = gptr(p.pol.b[j])[n];
+    }
+    if (REF) {
+        const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
+        for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            s_ref[idx] = (idx < nvalid * TL) ? tbl[idx] : z;
+        }
+    }
+    for (int idx = tid; idx < TB * ldx; idx += NTHREADS) {
+        const int m = idx / ldx, c = idx - m * ldx;
+        xs[idx] = (c < O && m < nvalid) ? gptr(p.in.obs)[(size_t)(b0 + m) * O + c] : 0.f;
+    }
+    // (no MaskAtDoneModel in the chain: the base models ignore the done flags they are handed)
+    if (tid < TB) s_done[tid] = (tid < nvalid && p.in.done != nullptr && !p.env.no_mask_at_done && gptr(p.in.done)[b0 + tid] != 0.f) ? 1.f : 0.f;
+    if (VEH) {
+        if (tid < TB * 6) {
+            const int m = tid / 6, c = tid - m * 6;
+            s_state[m * 8 + c] = (m < nvalid) ? gptr(p.in.state)[(size_t)(b0 + m) * 6 + c] : (c == 3 ? 1.f : 0.f);
+        }
+    }
+    if (VEH2) {
+        if (tid < TB * 8) {
+            const int m = tid >> 3, c = tid & 7;
+            s_state[m * 8 + c] = (m < nvalid && c < 4) ? gptr(p.in.state)[(size_t)(b0 + m) * 4 + c] : 0.f;
+        }
+    }
+    float v_acc = 0.f;
+    float c_ext = 0.f, c_lin = 0.f, c_int = 0.f, c_feas = 1.f;   // SURR: discounted constraint sums of trajectory tid (tid < TB)
+    float c_mul[GOPS_MAX_CONSTRAINT] = {1.f, 1.f, 1.f}, c_safe[GOPS_MAX_CONSTRAINT] = {1.f, 1.f, 1.f};   // SPIL products
+    float veh_s = 0.f, veh_c = 1.f;   // sin/cos of the current heading, carried across steps
     __syncthreads();
     if (VEH) sincosf(s_state[(tid & 15) * 8 + 2], &veh_s, &veh_c);
     settle_loads();
@@ -360,7 +373,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         if (p.fh && tid < TB) xs[tid * ldx + O] = (float)(t + 1);
         __syncthreads();
         DBG_TICK(0)
-        const size_t row0 = ((size_t)blockIdx.x * p.H + t) * TB;   // tile-major stash: a tile's rows are contiguous over t
+        const size_t row0 = ((size_t)tile * p.H + t) * TB;   // tile-major stash: a tile's rows are contiguous over t
         if constexpr (F16) {
             // half copy of the input tile (LDS, and the stash rows the weight-gradient GEMM reads); the env
             // adjoints get the first 8 observation columns in fp32
@@ -733,7 +746,6 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         }
         s_done[tid] = dl ? 1.f : 0.f;
     }
-    dbg.dump(p.dbg);
 
     if (TAIL) {   // v += (~done_H) * gamma^H * V_target(obs_H)   (infadp.py:182-184, 210)
         if (p.fh && tid < TB) xs[tid * ldx + O] = 0.f;
@@ -791,6 +803,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         const int m = tid / 6, c = tid - m * 6;
         if (m < nvalid) gptr(p.out.final_state)[(size_t)(b0 + m) * 6 + c] = s_state[m * 8 + c];
     }
+    if constexpr (SPLIT && MULTI) __syncthreads();   // the next tile's set-up overwrites xs / s_state / s_done / s_ref
+    } while (SPLIT && MULTI && (tile += gridDim.x) < ntiles);
+    dbg.dump(p.dbg);
 }
 
 // split_k0: input width (multiple of 32) of hidden layer 0 when the plane-split kernel runs, else 0
@@ -816,15 +831,21 @@ static int device_cus() {
     return n_cu;
 }
 
+int split_grid_limit() { return device_cus(); }
+
 // Plane-split contractions (common.h SplitDev) replace the fp32 MFMAs of the register-stationary kernels for a closed-loop
-// obs -> 256 -> 256 -> act policy on the BASELINE env kinds with at most one tile per CU and an input of at most 128
-// columns (4 chunks of 32: the planes of both layers then fit the register file).  GOPS_SPLIT=0 keeps the fp32 MFMAs.
+// obs -> 256 -> 256 -> act policy on the BASELINE env kinds with an input of at most 128 columns (4 chunks of 32: the
+// planes of both layers then fit the register file + LDS).  One workgroup per CU keeps the weights resident and walks
+// the tiles grid-stride, whatever the batch size.  GOPS_SPLIT=0 keeps the fp32-MFMA kernels.
 bool split_eligible(const RolloutParams& p) {
     const MlpDev& M = p.pol;
     if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
     if (p.env.kind != GOPS_ENV_LQ && p.env.kind != GOPS_ENV_IDPENDULUM && p.env.kind != GOPS_ENV_VEH3DOFCONTI) return false;
     if (M.nl != 3 || M.dims[1] != 256 || M.dims[2] != 256 || p.ldh != 260 || M.kp32[0] > 128 || p.ldx != M.kp[0] + 4) return false;
-    if ((p.B + TB - 1) / TB > device_cus() && getenv("GOPS_SK") == nullptr) return false;
+    // More tiles than CUs AND a tail value net: the tail is evaluated per tile with fp32 weights streamed from L2 by the one
+    // resident workgroup, which exposes every L2 round trip (measured at B = 65536: no faster than the streamed kernels with
+    // their three workgroups per CU) - those launches stay on the streamed kernels.
+    if (p.tail && (p.B + TB - 1) / TB > device_cus() && getenv("GOPS_SPLIT_TAIL_MULTI") == nullptr) return false;
     if (const char* e = getenv("GOPS_SPLIT")) if (e[0] == '0') return false;
     if (const char* e = getenv("GOPS_SK")) if (e[0] == '0') return false;   // "0,..": streamed kernels forced
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
@@ -893,10 +914,15 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
     if (p.sp.on) {   // plane-split stationary kernels: layer 0 in KC0 chunks of 32 inputs
 #define LAUNCH_FWD_SPLIT(ENV, KC0)                                                                                           \
     do {                                                                                                                     \
-        if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, KC0, 8, true, false, false, true>, grid, block, lds, stream, dp);  \
+        if (multi) {                                                                                                         \
+            if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, KC0, 8, true, false, false, true, true>, grid, block, lds, stream, dp);  \
+            else launch_with_lds(rollout_fwd_kernel<ENV, KC0, 8, false, false, false, true, true>, grid, block, lds, stream, dp);        \
+        } else if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, KC0, 8, true, false, false, true>, grid, block, lds, stream, dp);  \
         else launch_with_lds(rollout_fwd_kernel<ENV, KC0, 8, false, false, false, true>, grid, block, lds, stream, dp);        \
     } while (0)
         const int kc0 = p.sp.kc[0];
+        const dim3 grid(std::min<int>((p.B + TB - 1) / TB, device_cus()));   // one workgroup per CU, grid-stride over the tiles
+        const bool multi = (p.B + TB - 1) / TB > device_cus();
         if (p.env.kind == GOPS_ENV_LQ && kc0 == 1) LAUNCH_FWD_SPLIT(GOPS_ENV_LQ, 1);
         else if (p.env.kind == GOPS_ENV_IDPENDULUM && kc0 == 1) LAUNCH_FWD_SPLIT(GOPS_ENV_IDPENDULUM, 1);
         else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 2) LAUNCH_FWD_SPLIT(GOPS_ENV_VEH3DOFCONTI, 2);

@@ -25,6 +25,9 @@ CASES = {
     "lq_s4a2_relu": dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=100, horizon=20, hidden=(256, 256), act="relu", gamma=0.99),
     "lq_s6a3_sigmoid": dict(alg="FHADP", env_id="pyth_lq", lq_config="s6a3", batch=33, horizon=10, hidden=(256, 256), act="sigmoid", gamma=1.0),
     "lq_s2a1_elu": dict(alg="FHADP", env_id="pyth_lq", lq_config="s2a1", batch=16, horizon=25, hidden=(256, 256), act="elu", gamma=0.97),
+    # more tiles than CUs: the workgroups walk their tiles grid-stride with the weights resident (ragged last tile included)
+    "lq_s4a2_multi": dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=4096 + 16 * 37 + 5, horizon=5, hidden=(256, 256), act="gelu", gamma=0.99),
+    "veh_p10_multi": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=4096 + 16 * 9 + 3, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=1.0),
 }
 
 
@@ -72,10 +75,13 @@ def test_split_kernels_vs_oracle_and_fp32_mfma(name, dev, monkeypatch):
     assert rel_l2(flat, flat0) < 5e-5, (name, rel_l2(flat, flat0))   # the two arithmetic paths agree far inside the bar
 
 
-def test_split_kernels_with_tail_value(dev, monkeypatch):
-    """INFADP's policy-improvement gradient (tail value net after the loop: its fp32 tiles alias the plane images)."""
+@pytest.mark.parametrize("batch", [90, 4096 + 16 * 11 + 7])
+def test_split_kernels_with_tail_value(batch, dev, monkeypatch):
+    """INFADP's policy-improvement gradient (tail value net after the loop: its fp32 tiles alias the plane images); the
+    second batch has more tiles than CUs (grid-stride tile walk: the policy biases are re-staged after every tail)."""
     from gops_amd import hip_backend as hb
-    cfg = dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=90, horizon=8, hidden=(256, 256), act="gelu", gamma=0.99)
+    monkeypatch.setenv("GOPS_SPLIT_TAIL_MULTI", "1")   # (by default tail + more tiles than CUs stays on the streamed kernels)
+    cfg = dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=batch, horizon=8, hidden=(256, 256), act="gelu", gamma=0.99)
     data = make_batch(cfg, 8)
     nets = reference_init_nets(cfg, 8, obs_dim_of(cfg), act_dim_of(cfg))
     env = orc.make_env("pyth_lq", lq_config="s4a2")

@@ -18,7 +18,7 @@ bool split_eligible(const RolloutParams& p);
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s);
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s);
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
-                          int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s);
+                          int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s, const float* dscale = nullptr);
 hipError_t launch_dw_gemm_f16(const void* D, int N, const void* X, int Kp, long long S, int splits,
                               int chunks_per_split, float* part, float* part_b, hipStream_t s);
 hipError_t launch_dw_out(const float* dy, const float* h, bool h_is_half, int K, int A, long long S, int splits,
@@ -286,7 +286,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         sp.invt[1] = c.take(n1 >> 4);
         sp.invt[0] = c.take(p.pol.kp[0] >> 4);
     }
-    if (f16) p.gscale = c.take(4);
+    p.gscale = c.take(4);   // max|grad_v| of a backward launch (f16 sweep scale; delta scale of the weight-gradient GEMM)
     // stash rows: every tile stores all 16 rows of every step (tile-major order)
     const long long S = (long long)((p.B + TB - 1) / TB) * TB * p.H;
     if (veh) p.ref_table = c.take((size_t)p.B * (e.pre_horizon + 1 + p.H) * 4);
@@ -445,6 +445,11 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     ReduceJobs jobs;
     memset(&jobs, 0, sizeof(jobs));
     if (p.f16) jobs.unscale = p.gscale;   // the sweep ran on gradients scaled by f16_grad_scale(max|grad_v|)
+    // Two-half-plane weight-gradient GEMM (launch_dw_gemm): its delta scale is derived from max|grad_v|, which bounds the
+    // deltas only when grad_v is the sweep's one gradient source - a terminal observation adjoint or constraint-sum
+    // gradients can be orders of magnitude larger, so those launches keep the exact three-plane product.
+    const float* dw_scale = (adj == nullptr && in.grad_constraint == nullptr && in.grad_constraint_prod == nullptr && ext_delta == nullptr)
+                                ? p.gscale : nullptr;
     for (int j = 0; j < L; ++j) {   // dW_j = D_{j+1}^T * (j == 0 ? X : H_j)
         const int N = p.pol.dims[j + 1], Kp = p.f16 ? p.pol.kp32[j] : p.pol.kp[j], K = p.pol.dims[j];
         const DwPlan d = plan_dw(N, Kp, S, p.f16 != 0);
@@ -454,7 +459,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
                                         plan.dw_part_b[j], s)) != hipSuccess) return (int)e;
         } else
         if ((e = launch_dw_gemm(p.st.d[j + 1], N, X, Kp, S, d.splits, d.chunks_per_split, plan.dw_part[j],
-                                plan.dw_part_b[j], d.big, s)) != hipSuccess) return (int)e;
+                                plan.dw_part_b[j], d.big, s, dw_scale)) != hipSuccess) return (int)e;
         reduce_jobs_add(jobs, plan.dw_part[j], d.splits, N, K, Kp, grad.weight[j]);
         reduce_jobs_add(jobs, plan.dw_part_b[j], d.splits, 1, N, N, grad.bias[j]);
     }

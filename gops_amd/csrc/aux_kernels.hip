@@ -120,8 +120,9 @@ __global__ __launch_bounds__(256) void upload_params_kernel(const RolloutParams 
         const unsigned* src = reinterpret_cast<const unsigned*>(&p);
         unsigned* d = reinterpret_cast<unsigned*>(dst);
         for (unsigned i = threadIdx.x; i < sizeof(RolloutParams) / 4; i += blockDim.x) d[i] = src[i];
+        if (p.gscale != nullptr && threadIdx.x == 0) p.gscale[1] = 0.f;   // saturation flag of the two-half-plane weight-gradient GEMM
     }
-    if (p.f16 && p.gscale != nullptr && p.grad_v != nullptr) {
+    if (p.gscale != nullptr && p.grad_v != nullptr) {
         __shared__ float red[256];
         float mx = 0.f;
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.B; i += gridDim.x * blockDim.x) mx = fmaxf(mx, fabsf(p.grad_v[i]));
@@ -137,8 +138,8 @@ __global__ __launch_bounds__(256) void upload_params_kernel(const RolloutParams 
 
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s) {
     static_assert(sizeof(RolloutParams) % 4 == 0, "parameter block must be dword sized");
-    int nb = 1;
-    if (p.f16) { nb = (p.B + 4095) / 4096; nb = nb < 1 ? 1 : (nb > 128 ? 128 : nb); }   // >= 16 elements per thread
+    int nb = (p.B + 4095) / 4096;
+    nb = nb < 1 ? 1 : (nb > 128 ? 128 : nb);   // >= 16 elements per thread
     hipLaunchKernelGGL(upload_params_kernel, dim3(nb), dim3(256), 0, s, p, dst);
     return hipGetLastError();
 }
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
         const unsigned* src = reinterpret_cast<const unsigned*>(&p);
         unsigned* d = reinterpret_cast<unsigned*>(dst);
         for (unsigned i = threadIdx.x; i < sizeof(RolloutParams) / 4; i += blockDim.x) d[i] = src[i];
-        if (p.f16 && p.gscale != nullptr && threadIdx.x == 0) p.gscale[0] = 0.f;   // max|grad_v| of the coming backward
+        if (p.gscale != nullptr && threadIdx.x == 0) p.gscale[0] = 0.f;   // max|grad_v| of the coming backward
         return;
     }
     b -= 1;
@@ -540,14 +541,60 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_fm_kernel(const float* __
 // One barrier per block: it publishes block c (each wave first waits for its own copies of that block) and frees the
 // stage that block c - 1 was read from for the copies of block c + DWR_STAGES - 1.
 // ---------------------------------------------------------------------------------------------
+// Two-half-plane form of an fp32 operand fragment for the H2 variant of the ring GEMM: with v = x * s,
+//     hi = f16(v)  (round toward zero: a finite v never becomes inf),   lo = f16((v - hi) * 2^11)  (likewise),
+// so v = hi + lo * 2^-11 to 2^-21 |v| (22 significant bits), and the product of two such operands is
+//     d * a = dh * ah + (dh * al + dl * ah) * 2^-11 + O(2^-21 |d a|)
+// - three v_mfma_f32_16x16x32_f16 per 32-sample block instead of the six bf16 MFMAs of the exact three-plane split, and 3-4
+// VALU instructions per element instead of 5.5.  Mode 2 (adopted) keeps lo UNSCALED (lo = f16(v - hi), one accumulator):
+// lo is a normal half for |v| >= 0.06 and a subnormal one below (absolute error <= 6e-8 in scaled units), so the scales
+// put typical magnitudes near 1..30: activations as they are, deltas times the power of two that brings max|grad_v| into
+// [16, 32).  Range: |x * s| >= 65504 saturates (round toward zero never produces inf); the converting threads watch for it
+// and raise a flag, on which a guarded second launch redoes the GEMM with the exact three-plane split - a diverged
+// rollout costs time, never a wrong gradient.
+#ifndef GOPS_DW_H2_MODE
+#define GOPS_DW_H2_MODE 2   // 1: lo planes scaled by 2^11, two accumulators, one workgroup per CU (r03: 251 us at the target, slower than the
+                            // exact split); 2: unscaled lo planes, ONE accumulator, two workgroups per CU (177 us; the matrix core takes
+                            // subnormal half inputs as they are - measured: same 2e-7 distance to the exact GEMM as mode 1)
+#endif
+#if GOPS_DW_H2_MODE == 2
+#define DW_H2_SA 1.0f      // (unscaled lo planes: keep typical magnitudes near 1 so that lo stays a normal half)
+#define DW_H2_LO 1.0f
+#else
+#define DW_H2_SA 0.0625f   // activations / observations: up to 1.05e6 before the main term saturates
+#define DW_H2_LO 2048.f
+#endif
+__device__ __forceinline__ void split2h(const f32x4& lo4, const f32x4& hi4, float s, f16x8& ph, f16x8& pl) {
+    const float s2 = s * DW_H2_LO;
+    u32x4 uh, ul;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = e < 2 ? lo4[2 * e] : hi4[2 * e - 4], x1 = e < 2 ? lo4[2 * e + 1] : hi4[2 * e - 3];
+        const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0 * s, x1 * s));
+        const float r0 = fmaf((float)h[0], -DW_H2_LO, x0 * s2), r1 = fmaf((float)h[1], -DW_H2_LO, x1 * s2);   // (v - hi) * 2^11, exact
+        uh[e] = __builtin_bit_cast(unsigned, h);
+        ul[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+    }
+    ph = __builtin_bit_cast(f16x8, uh);
+    pl = __builtin_bit_cast(f16x8, ul);
+}
+
 #define DWR_STAGES 2
 #define DWR_STAGE_FLOATS (4 * 2048)   // [D tile q0][D tile q0+1][X tile q0][X tile q0+1], each [128 features][16 rows]
 
-__global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_ring_kernel(const float* __restrict__ D, int N,
+// H2: the two-half-plane products (split2h) instead of the exact three-plane bf16 split; dscale -> max|grad_v| of the launch
+// (RolloutParams::gscale): the deltas are multiplied by f16_grad_scale(max|grad_v|) / 64 before they are halved.  The
+// staged fp32 tiles of a block are converted IN PLACE, once per workgroup: work item (operand, feature f, sample group g)
+// reads the two 16-byte vectors that are lane (f, g)'s fragment (rows 4g..4g+3 of both sample tiles), forms the hi / lo
+// half planes of those 8 samples and writes hi where the first tile's vector was, lo where the second's was - 1024 items
+// per block, 4 per thread, the same items every block (so the bias column sums accumulate in the converting thread).  The
+// MFMA phase then reads ready-made operands (two ds_read_b128 per fragment) and issues no VALU work at all.
+template <bool H2>
+__global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) void dw_gemm_ring_kernel(const float* __restrict__ D, int N,
                                                                     const float* __restrict__ X, int Kp,
                                                                     long long Q, int splits, int chunks_per_split,
                                                                     float* __restrict__ part,
-                                                                    float* __restrict__ part_b) {
+                                                                    float* __restrict__ part_b, const float* __restrict__ dscale) {
     extern __shared__ __attribute__((aligned(16))) float ring[];   // [DWR_STAGES][DWR_STAGE_FLOATS]
     constexpr int T = 128, R = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -555,6 +602,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_ring_kernel(const float* 
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;   // XCD-aware order, as above
     const int tile = local % tiles, split = (local / tiles) * 8 + xcd;
     if (split >= splits) return;
+    if constexpr (!H2) {   // guarded re-run behind an H2 launch: only when that launch saw a saturated half plane (dscale[1] != 0)
+        if (dscale != nullptr && reinterpret_cast<const GLOBAL_AS unsigned*>(gptr(dscale))[1] == 0u) return;
+    }
     const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
     const int wn = wave >> 1, wk = wave & 1;
     const int f = lane & 15, g = lane >> 4;
@@ -575,12 +625,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_ring_kernel(const float* 
     };
 
     f32x4 acc[R][R] = {};
+    constexpr bool TWO_ACC = H2 && GOPS_DW_H2_MODE == 1;
+    f32x4 accx[TWO_ACC ? R : 1][TWO_ACC ? R : 1] = {};   // cross terms (dh * al + dl * ah), scaled by 2^11
     float bsum[R] = {0.f, 0.f, 0.f, 0.f};
+    float sd = 1.f;
+    if constexpr (H2) sd = f16_grad_scale(gptr(dscale)[0]) * (GOPS_DW_H2_MODE == 2 ? 16.f : 0.015625f);
     auto block = [&]<bool LAST_HALF_EMPTY>(int stage) {
         const float* st = ring + stage * DWR_STAGE_FLOATS;
         const float* da = st + (wn * 64 + f) * 16 + 4 * g;          // D fragments of row-tile i: + 256 i  (+ 2048: second tile)
         const float* xa = st + 4096 + (wk * 64 + f) * 16 + 4 * g;   // X fragments of column-tile j
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (H2) {   // operands were converted in place by convert_stage(): hi plane in the first tile's slot, lo in the second's
+            f16x8 bh[R], bl[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(xa + 256 * j);
+                bl[j] = *reinterpret_cast<const f16x8*>(xa + 256 * j + 2048);
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(da + 256 * i), al = *reinterpret_cast<const f16x8*>(da + 256 * i + 2048);
+                if constexpr (TWO_ACC) {
+#pragma unroll
+                    for (int j = 0; j < R; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], accx[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < R; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], accx[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < R; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < R; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < R; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+            }
+            return;
+        }
 #ifdef GOPS_EXP_NOMFMA
         acc[0][0] += *reinterpret_cast<const f32x4*>(xa) + *reinterpret_cast<const f32x4*>(da);
         return;
@@ -608,6 +688,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_ring_kernel(const float* 
         }
     };
 
+    // H2: in-place conversion of a landed stage; item id = tid + 256 k: operand id >> 9, feature (id >> 2) & 127, group id & 3
+    float vmax = 0.f;             // largest scaled magnitude this thread converted (saturation watch)
+    float csum[2] = {0.f, 0.f};   // column sums of D over the two D items of this thread (features tid >> 2 and 64 + (tid >> 2), group tid & 3)
+    auto convert_stage = [&]<bool LAST_HALF_EMPTY>(int stage) {
+        float* st = ring + stage * DWR_STAGE_FLOATS;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int id = tid + NTHREADS * k, op = id >> 9, fe = (id >> 2) & 127, gg = id & 3;
+            float* at = st + op * 4096 + fe * 16 + 4 * gg;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(at);
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v1 = LAST_HALF_EMPTY ? zero4 : *reinterpret_cast<const f32x4*>(at + 2048);
+            if (k < 2) csum[k] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+            const float sc = k < 2 ? sd : DW_H2_SA;
+            const float m0 = fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3])));
+            const float m1 = fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3])));
+            vmax = fmaxf(vmax, fmaxf(m0, m1) * sc);   // (NaN-free inputs: a NaN in the stash is NaN in the result either way)
+            f16x8 ph, pl;
+            split2h(v0, v1, sc, ph, pl);
+            *reinterpret_cast<f16x8*>(at) = ph;
+            *reinterpret_cast<f16x8*>(at + 2048) = pl;
+        }
+    };
 #pragma unroll
     for (int d = 0; d < DWR_STAGES - 1; ++d) copy_block(d, d);
     const int nfull = odd_tail ? nblk - 1 : nblk;
@@ -616,6 +719,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_ring_kernel(const float* 
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (DWR_STAGES - 2)) : "memory");
         __syncthreads();
         copy_block(c + DWR_STAGES - 1, (c + DWR_STAGES - 1) % DWR_STAGES);
+        if constexpr (H2) {
+            if (c < nfull) convert_stage.template operator()<false>(c % DWR_STAGES);
+            else convert_stage.template operator()<true>(c % DWR_STAGES);
+            __syncthreads();
+        }
         if (c < nfull) block.template operator()<false>(c % DWR_STAGES);
         else block.template operator()<true>(c % DWR_STAGES);
     }
@@ -623,14 +731,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_ring_kernel(const float* 
 
     const int nb = tile_n * T + wn * 64, kb = tile_k * T + wk * 64;
     float* pbase = part + (size_t)split * N * Kp;
+    const float unscale = H2 ? 1.f / (sd * DW_H2_SA) : 1.f;   // (powers of two: exact)
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int k = kb + 16 * j + f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pbase[(size_t)(nb + 16 * i + 4 * g + r) * Kp + k] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r];
+                if constexpr (TWO_ACC) v = fmaf(accx[i][j][r], 1.f / 2048.f, v);
+                if constexpr (H2) v *= unscale;
+                pbase[(size_t)(nb + 16 * i + 4 * g + r) * Kp + k] = v;
+            }
         }
+    if constexpr (H2) {
+        if (!(vmax < 65504.f)) atomicOr(const_cast<unsigned*>(reinterpret_cast<const unsigned*>(dscale)) + 1, 1u);   // half plane saturated: redo exactly
+    }
+    if constexpr (H2) {   // the converting threads hold the column sums: groups gg = tid & 3 of a feature sit in 4 adjacent lanes
+        if (part_b != nullptr && tile_k == 0) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float t = csum[k];
+                t += __shfl_xor(t, 1);
+                t += __shfl_xor(t, 2);
+                if ((tid & 3) == 0) part_b[(size_t)split * N + tile_n * T + 64 * k + (tid >> 2)] = t;
+            }
+        }
+    } else
     if (want_bias) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -642,16 +770,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_ring_kernel(const float* 
     }
 }
 
+// dscale: device pointer to max|grad_v| of the launch (the deltas' magnitude reference), or null: with it the large
+// layers run the two-half-plane products (22 significant bits per operand), without it - or with GOPS_DW_EXACT set -
+// the exact three-plane bf16 split.
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
-                          int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s) {
+                          int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s, const float* dscale) {
     static const bool force_f32 = getenv("GOPS_DW_F32") != nullptr;   // A/B knob: fp32 MFMA GEMM
+    static const bool force_exact = getenv("GOPS_DW_EXACT") != nullptr;
+    const bool no_guard = getenv("GOPS_DW_NOGUARD") != nullptr;   // test knob: skip the exact re-run behind a saturated launch
     const long long Q = (S + TB - 1) / TB;
     const int T = big ? 128 : 64, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
     const dim3 grid(tiles * ((splits + 7) / 8) * 8), block(NTHREADS);
     static const bool no_ring = getenv("GOPS_DW_DIRECT") != nullptr;   // A/B knob: register-direct kernel for the large layers too
-    if (big && !force_f32 && !no_ring && (N % 128) == 0 && (Kp % 128) == 0)
-        launch_with_lds(dw_gemm_ring_kernel, grid, block, (size_t)DWR_STAGES * DWR_STAGE_FLOATS * sizeof(float), s, D, N, X, Kp, Q, splits,
-                        chunks_per_split, part, part_b);
+    if (big && !force_f32 && !no_ring && (N % 128) == 0 && (Kp % 128) == 0) {
+        const float* none = nullptr;
+        if (dscale != nullptr && !force_exact) {
+            launch_with_lds(dw_gemm_ring_kernel<true>, grid, block, (size_t)DWR_STAGES * DWR_STAGE_FLOATS * sizeof(float), s, D, N, X, Kp, Q,
+                            splits, chunks_per_split, part, part_b, dscale);
+            // guarded exact re-run: every workgroup returns at once unless the launch above flagged a saturated half plane
+            if (!no_guard) launch_with_lds(dw_gemm_ring_kernel<false>, grid, block, (size_t)DWR_STAGES * DWR_STAGE_FLOATS * sizeof(float), s, D, N, X, Kp, Q,
+                            splits, chunks_per_split, part, part_b, dscale);
+        } else {
+            launch_with_lds(dw_gemm_ring_kernel<false>, grid, block, (size_t)DWR_STAGES * DWR_STAGE_FLOATS * sizeof(float), s, D, N, X, Kp, Q,
+                            splits, chunks_per_split, part, part_b, none);
+        }
+    }
     else if (big && !force_f32) hipLaunchKernelGGL((dw_gemm_fm_kernel<4, true>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
     else if (big) hipLaunchKernelGGL((dw_gemm_fm_kernel<4, false>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
     else if (!force_f32) hipLaunchKernelGGL((dw_gemm_fm_kernel<2, true>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);

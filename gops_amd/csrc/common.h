@@ -72,7 +72,8 @@ struct SplitDev {
 #ifndef GOPS_PIN_MODE
 #define GOPS_PIN_MODE 2   // layer-1 bf16 planes of the split kernels pinned to AGPRs (StatQ PIN; modes 1 / 2 / 3 measured within 1 %, r03)
 #endif
-#define SPLIT_FWD_SA 1.0f       // forward: af = f16(a) (saturating: beyond 65504 only the 2^-9-sized correction term degrades)
+#define SPLIT_FWD_SA 0.015625f  // forward: af = f16(a / 64): the correction term saturates only beyond |a| = 4.2e6; below |a| = 4e-3 af is a
+                                // subnormal half (absolute error 4e-6 * 2^-8 |w| per term: under the fp32 rounding of a unit-sized term)
 // position e of a hidden tile's plane row (the order plane_store writes, = the contraction order of the next GEMM) -> feature
 __host__ __device__ inline int split_perm(int e) { return 64 * (e >> 6) + 16 * (e & 3) + ((e & 63) >> 2); }
 // LDS image of a [TB][K] activation tile: 4 planes (a1, a2, a3 bf16; af f16), each [TB] rows of rowb bytes (16 bytes of pad)

@@ -104,3 +104,28 @@ def test_split_kernels_with_tail_value(batch, dev, monkeypatch):
         assert abs(-out[split][0].double().mean().item() - float(want["loss"])) <= TOL * max(1.0, abs(float(want["loss"])))
         assert rel_l2(out[split][1], flat_ref) < TOL, (split, rel_l2(out[split][1], flat_ref))
     print(f"tail: split {rel_l2(out[True][1], flat_ref):.2e} fp32 MFMA {rel_l2(out[False][1], flat_ref):.2e}")
+
+
+def test_weight_gradient_gemm_redoes_saturated_blocks_exactly(dev, monkeypatch):
+    """The two-half-plane weight-gradient GEMM saturates beyond |x| = 65504; the converting threads flag it and a guarded
+    second launch redoes the GEMM with the exact three-plane split.  A policy whose first layer is scaled up so that H_1
+    reaches ~1e5 must still meet the 1e-4 bar against the oracle (and it does not with the guard disabled: that is what
+    GOPS_DW_NOGUARD=1 is for)."""
+    cfg = dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=64, horizon=3, hidden=(256, 256), act="relu", gamma=0.99)
+    data = make_batch(cfg, 21)
+    nets = reference_init_nets(cfg, 21, obs_dim_of(cfg), act_dim_of(cfg))
+    with torch.no_grad():
+        nets["policy"]["w"][0].mul_(2.0e5)
+        nets["policy"]["w"][1].mul_(1.0e-5)
+    env = orc.make_env("pyth_lq", lq_config="s4a2")
+    ref = orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+    h1 = torch.relu(torch.nn.functional.linear(torch.cat((data["obs"], torch.ones(64, 1)), 1), nets["policy"]["w"][0], nets["policy"]["b"][0]))
+    assert h1.max().item() > 65504.0 * 1.2   # the premise: H_1 is beyond the half range
+    res, grads = _run(cfg, nets, data, env, dev, monkeypatch, split=True)
+    worst = max(rel_l2(g.cpu(), w) for g, w in zip(grads, ref["grads"]))
+    assert rel_l2(res["v_pi"].cpu(), ref["v_pi"]) < TOL and worst < TOL, worst
+    monkeypatch.setenv("GOPS_DW_NOGUARD", "1")
+    _, grads_ng = _run(cfg, nets, data, env, dev, monkeypatch, split=True)
+    worst_ng = rel_l2(grads_ng[2].cpu(), ref["grads"][2])   # dW of layer 1 = D_2^T H_1
+    print(f"saturated H_1: worst tensor with the guard {worst:.2e}; layer-1 weight gradient without it {worst_ng:.2e}")
+    assert worst_ng > 10 * TOL

@@ -18,6 +18,7 @@ from gops_amd import hip_backend as hb
 from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, batch_to_device, cuda_device_of,
                                      grad_buffers)
 from gops_amd.utils.hip_graph import StepGraphCache
+from gops_amd.utils.lazy_scalar import LazyScalar, lazy_enabled, scalar
 from gops_amd.create_pkg.create_apprfunc import create_apprfunc
 from gops_amd.create_pkg.create_env_model import create_env_model
 from gops_amd.utils.common_utils import get_apprfunc_dict
@@ -117,8 +118,12 @@ class FHADP(AlgorithmBase):
 
     def _fill_tb(self, out, lazy=False):
         """`out` is what `_gradient_kernels` returned - here mean(v_pi), whose negative is the loss.  lazy: leave
-        device tensors in tb_info (no host sync); else read them back (`.item()`, as the reference does)."""
-        self.tb_info[tb_tags["loss_actor"]] = -out if lazy else -out.item()
+        device tensors in tb_info (data-parallel path); else a LazyScalar (utils/lazy_scalar.py: read back on first
+        use; GOPS_EAGER_LOG=1: `.item()` right here, as the reference does)."""
+        if out.dim() == 1:   # the per-trajectory returns themselves (eager launches): their mean is formed when the entry is read
+            self.tb_info[tb_tags["loss_actor"]] = LazyScalar(out, negate=True, mean=True) if lazy else scalar(out, negate=True, mean=True)
+        else:
+            self.tb_info[tb_tags["loss_actor"]] = -out if lazy else scalar(out, negate=True)
 
     def _log(self, out):
         self._fill_tb(out)   # host sync, as in the reference
@@ -146,7 +151,9 @@ class FHADP(AlgorithmBase):
         B, device = batch["obs"].shape[0], batch["obs"].device
         ro = self._rollout_for(B, device)
         v_pi = ro.forward(batch)["v_pi"]
-        loss_policy = v_pi.mean()   # negated on the host when logged (saves a kernel)
+        # the loss is only logged: inside a captured graph its mean is one more node; as eager launches (large batches) the
+        # reduction kernel is left to whoever reads the log entry (LazyScalar) - v_pi is a fresh tensor of this update
+        loss_policy = v_pi if (lazy_enabled() and not torch.cuda.is_current_stream_capturing() and type(self) is FHADP) else v_pi.mean()
         gw, gb = grad_buffers(self.networks.policy)
         ro.backward(self._grad_v(B, device), gw, gb)
         return loss_policy

@@ -21,6 +21,7 @@ from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, batch_
 from gops_amd.create_pkg.create_apprfunc import create_apprfunc
 from gops_amd.create_pkg.create_env_model import create_env_model
 from gops_amd.utils.common_utils import get_apprfunc_dict, make_adam
+from gops_amd.utils.lazy_scalar import scalar
 from gops_amd.utils.tensorboard_setup import tb_tags
 
 
@@ -108,5 +109,5 @@ class FHADP2(AlgorithmBase):
         g_pre = ro.backward_open_loop(grad_v)                    # d(loss)/d(head outputs) [B, H, A]
         gw, gb = grad_buffers(policy)
         net.backward(batch["obs"], g_pre.view(B, -1), gw, gb)    # through the MLP into the parameters' .grad
-        self.tb_info[tb_tags["loss_actor"]] = loss_policy.item()
+        self.tb_info[tb_tags["loss_actor"]] = scalar(loss_policy)
         self.tb_info[tb_tags["alg_time"]] = (time.time() - t0) * 1000  # ms

@@ -14,6 +14,7 @@ import torch
 from gops_amd import hip_backend as hb
 from gops_amd.algorithm.base import grad_buffers
 from gops_amd.algorithm.fhadp import ApproxContainer, FHADP   # noqa: F401  (ApproxContainer: create_alg looks it up here)
+from gops_amd.utils.lazy_scalar import scalar
 from gops_amd.utils.tensorboard_setup import tb_tags
 
 
@@ -54,9 +55,8 @@ class ConstrainedFHADP(FHADP):
         return scalars
 
     def _fill_tb(self, out, lazy=False):
-        vals = out if lazy else out.tolist()
-        for k, v in zip(self.LOG_KEYS, vals):
-            self.tb_info[k] = v
+        for i, k in enumerate(self.LOG_KEYS):
+            self.tb_info[k] = out[i] if lazy else scalar(out, i)
         self._fill_host_tb()
 
     def _fill_host_tb(self):

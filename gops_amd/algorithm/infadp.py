@@ -18,6 +18,7 @@ from gops_amd import hip_backend as hb
 from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, batch_to_device, cuda_device_of,
                                      grad_buffers)
 from gops_amd.utils.hip_graph import StepGraphCache
+from gops_amd.utils.lazy_scalar import scalar
 from gops_amd.create_pkg.create_apprfunc import create_apprfunc
 from gops_amd.create_pkg.create_env_model import create_env_model
 from gops_amd.utils.common_utils import get_apprfunc_dict
@@ -186,11 +187,11 @@ class INFADP(AlgorithmBase):
         return gv
 
     def _log(self, mode: str, scalars: torch.Tensor, start_time: float):
-        vals = scalars.tolist()   # host sync, as in the reference
+        # (LazyScalar: read back on first use; GOPS_EAGER_LOG=1: host sync here, as in the reference)
         if mode == "v":
-            self.tb_info[tb_tags["loss_critic"]], self.tb_info[tb_tags["critic_avg_value"]] = vals
+            self.tb_info[tb_tags["loss_critic"]], self.tb_info[tb_tags["critic_avg_value"]] = scalar(scalars, 0), scalar(scalars, 1)
         else:
-            self.tb_info[tb_tags["loss_actor"]] = vals[0]
+            self.tb_info[tb_tags["loss_actor"]] = scalar(scalars, 0)
         self.tb_info[tb_tags["alg_time"]] = (time.time() - start_time) * 1000  # ms
 
     def _compute_gradient(self, data, iteration):

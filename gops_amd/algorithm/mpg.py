@@ -26,6 +26,7 @@ from gops_amd.algorithm.base import AlgorithmBase, ApprBase, batch_to_device, cu
 from gops_amd.create_pkg.create_apprfunc import create_apprfunc
 from gops_amd.create_pkg.create_env_model import create_env_model
 from gops_amd.utils.common_utils import get_apprfunc_dict, make_adam
+from gops_amd.utils.lazy_scalar import scalar
 from gops_amd.utils.hip_graph import StepGraphCache
 from gops_amd.utils.tensorboard_setup import tb_tags
 
@@ -145,7 +146,7 @@ class MPG(AlgorithmBase):
         return names + ["MPG/data_loss-RL iter", "MPG/model_loss-RL iter", "MPG/loss_pi-RL iter"]
 
     def _log(self, scalars: torch.Tensor, start_time: float) -> dict:
-        tb_info = dict(zip(self._scalar_names(), scalars.tolist()))   # host sync, as in the reference
+        tb_info = {name: scalar(scalars, i) for i, name in enumerate(self._scalar_names())}   # (GOPS_EAGER_LOG=1: host sync here)
         tb_info[tb_tags["alg_time"]] = (time.time() - start_time) * 1000
         self.tb_info = tb_info
         return tb_info

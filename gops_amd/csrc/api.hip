@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -15,6 +16,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
 size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int split_k0);
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split);
 bool split_eligible(const RolloutParams& p);
+int split_grid_limit();
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s);
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s);
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
@@ -419,6 +421,15 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
     if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
     p.dbg = dbg ? dbg_buf : nullptr;
+    // Split sweep, activation other than GELU: the output layer's weight gradient is accumulated inside the sweep (one
+    // partial per workgroup) - no dw_out pass.  (GELU's act' operand is gelu'(z), not H_2.)
+    const bool fused_out = p.sp.on && !p.ext && !p.open_loop && want_params && ext_delta == nullptr && p.pol.act != GOPS_ACT_GELU &&
+                           getenv("GOPS_NO_FUSED_DWOUT") == nullptr;
+    const int sweep_grid = std::min((p.B + TB - 1) / TB, split_grid_limit());
+    if (fused_out) {
+        p.sp.out_part = plan.dw_part[p.pol.nl - 1];
+        p.sp.out_part_b = plan.dw_part_b[p.pol.nl - 1];
+    }
     if ((e = launch_upload_params(p, plan.dev_params, s)) != hipSuccess) return (int)e;
     {
         ProfScope scope(desc.env.kind == GOPS_ENV_NONE ? 4 : 1, s);
@@ -465,8 +476,9 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     }
     if (ext_delta == nullptr) {
         const int K = p.pol.dims[L], A = p.pol.dims[p.pol.nl];
-        long long splits = DW_OUT_SPLITS;
+        long long splits = fused_out ? sweep_grid : DW_OUT_SPLITS;
         if (splits > S) splits = S;
+        if (!fused_out)
         if ((e = launch_dw_out(p.st.dy, p.st.h[L], p.f16 != 0, K, A, S, (int)splits, plan.dw_part[L], plan.dw_part_b[L], s)) != hipSuccess) return (int)e;
         reduce_jobs_add(jobs, plan.dw_part[L], (int)splits, A, K, K, grad.weight[L]);
         reduce_jobs_add(jobs, plan.dw_part_b[L], (int)splits, 1, A, A, grad.bias[L]);

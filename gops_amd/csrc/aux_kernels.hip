@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256) void upload_params_kernel(const RolloutParams 
         const unsigned* src = reinterpret_cast<const unsigned*>(&p);
         unsigned* d = reinterpret_cast<unsigned*>(dst);
         for (unsigned i = threadIdx.x; i < sizeof(RolloutParams) / 4; i += blockDim.x) d[i] = src[i];
-        if (p.gscale != nullptr && threadIdx.x == 0) p.gscale[1] = 0.f;   // saturation flag of the two-half-plane weight-gradient GEMM
     }
     if (p.gscale != nullptr && p.grad_v != nullptr) {
         __shared__ float red[256];
@@ -550,8 +549,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_fm_kernel(const float* __
 // lo is a normal half for |v| >= 0.06 and a subnormal one below (absolute error <= 6e-8 in scaled units), so the scales
 // put typical magnitudes near 1..30: activations as they are, deltas times the power of two that brings max|grad_v| into
 // [16, 32).  Range: |x * s| >= 65504 saturates (round toward zero never produces inf); the converting threads watch for it
-// and raise a flag, on which a guarded second launch redoes the GEMM with the exact three-plane split - a diverged
-// rollout costs time, never a wrong gradient.
+// and a workgroup whose operands saturated repeats ITS blocks with the exact three-plane split before it stores anything -
+// a diverged rollout costs time, never a wrong gradient.
 #ifndef GOPS_DW_H2_MODE
 #define GOPS_DW_H2_MODE 2   // 1: lo planes scaled by 2^11, two accumulators, one workgroup per CU (r03: 251 us at the target, slower than the
                             // exact split); 2: unscaled lo planes, ONE accumulator, two workgroups per CU (177 us; the matrix core takes
@@ -594,7 +593,7 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
                                                                     const float* __restrict__ X, int Kp,
                                                                     long long Q, int splits, int chunks_per_split,
                                                                     float* __restrict__ part,
-                                                                    float* __restrict__ part_b, const float* __restrict__ dscale) {
+                                                                    float* __restrict__ part_b, const float* __restrict__ dscale, int getenv_guard) {
     extern __shared__ __attribute__((aligned(16))) float ring[];   // [DWR_STAGES][DWR_STAGE_FLOATS]
     constexpr int T = 128, R = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -602,9 +601,6 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;   // XCD-aware order, as above
     const int tile = local % tiles, split = (local / tiles) * 8 + xcd;
     if (split >= splits) return;
-    if constexpr (!H2) {   // guarded re-run behind an H2 launch: only when that launch saw a saturated half plane (dscale[1] != 0)
-        if (dscale != nullptr && reinterpret_cast<const GLOBAL_AS unsigned*>(gptr(dscale))[1] == 0u) return;
-    }
     const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
     const int wn = wave >> 1, wk = wave & 1;
     const int f = lane & 15, g = lane >> 4;
@@ -630,12 +626,12 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
     float bsum[R] = {0.f, 0.f, 0.f, 0.f};
     float sd = 1.f;
     if constexpr (H2) sd = f16_grad_scale(gptr(dscale)[0]) * (GOPS_DW_H2_MODE == 2 ? 16.f : 0.015625f);
-    auto block = [&]<bool LAST_HALF_EMPTY>(int stage) {
+    auto block = [&]<bool LAST_HALF_EMPTY, bool M2>(int stage) {
         const float* st = ring + stage * DWR_STAGE_FLOATS;
         const float* da = st + (wn * 64 + f) * 16 + 4 * g;          // D fragments of row-tile i: + 256 i  (+ 2048: second tile)
         const float* xa = st + 4096 + (wk * 64 + f) * 16 + 4 * g;   // X fragments of column-tile j
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (H2) {   // operands were converted in place by convert_stage(): hi plane in the first tile's slot, lo in the second's
+        if constexpr (M2) {   // operands were converted in place by convert_stage(): hi plane in the first tile's slot, lo in the second's
             f16x8 bh[R], bl[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
@@ -711,27 +707,53 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
             *reinterpret_cast<f16x8*>(at + 2048) = pl;
         }
     };
-#pragma unroll
-    for (int d = 0; d < DWR_STAGES - 1; ++d) copy_block(d, d);
     const int nfull = odd_tail ? nblk - 1 : nblk;
-    for (int c = 0; c < nblk; ++c) {
-        // this wave's copies of block c have landed once at most the 8 x (DWR_STAGES - 2) younger ones are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (DWR_STAGES - 2)) : "memory");
-        __syncthreads();
-        copy_block(c + DWR_STAGES - 1, (c + DWR_STAGES - 1) % DWR_STAGES);
-        if constexpr (H2) {
-            if (c < nfull) convert_stage.template operator()<false>(c % DWR_STAGES);
-            else convert_stage.template operator()<true>(c % DWR_STAGES);
+    // one pass over this workgroup's blocks: M2 = two-half-plane products (with the in-place conversion), else the exact split
+    auto run = [&]<bool M2>() {
+#pragma unroll
+        for (int d = 0; d < DWR_STAGES - 1; ++d) copy_block(d, d);
+        for (int c = 0; c < nblk; ++c) {
+            // this wave's copies of block c have landed once at most the 8 x (DWR_STAGES - 2) younger ones are outstanding
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (DWR_STAGES - 2)) : "memory");
             __syncthreads();
+            copy_block(c + DWR_STAGES - 1, (c + DWR_STAGES - 1) % DWR_STAGES);
+            if constexpr (M2) {
+                if (c < nfull) convert_stage.template operator()<false>(c % DWR_STAGES);
+                else convert_stage.template operator()<true>(c % DWR_STAGES);
+                __syncthreads();
+            }
+            if (c < nfull) block.template operator()<false, M2>(c % DWR_STAGES);
+            else block.template operator()<true, M2>(c % DWR_STAGES);
         }
-        if (c < nfull) block.template operator()<false>(c % DWR_STAGES);
-        else block.template operator()<true>(c % DWR_STAGES);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail copies must not outlive the workgroup's LDS / the pass
+    };
+    bool redone = false;
+    if constexpr (H2) {
+        if (tid == 0) ring[DWR_STAGES * DWR_STAGE_FLOATS] = 0.f;
+        run.template operator()<true>();
+        // A half plane of THIS workgroup's operands saturated (|x * s| >= 65504: a diverged rollout): its products are wrong,
+        // so the workgroup repeats its blocks with the exact three-plane split - time, never a wrong gradient.  (The
+        // column sums were formed from the fp32 values and stand.)
+        // (the flag word sits behind the ring in DYNAMIC LDS: __syncthreads_or would add static LDS to a 64-KiB dynamic
+        // allocation, and hipFuncSetAttribute then refuses the 160-KiB dynamic limit the launch needs)
+        unsigned* sat = reinterpret_cast<unsigned*>(ring + DWR_STAGES * DWR_STAGE_FLOATS);
+        if (!(vmax < 65504.f)) *sat = 1u;   // (zeroed by thread 0 before the first barrier of the pass above)
+        __syncthreads();
+        if (*sat != 0u && getenv_guard) {
+            redone = true;
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int j = 0; j < R; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            run.template operator()<false>();
+        }
+    } else {
+        run.template operator()<false>();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail copies must not outlive the workgroup's LDS
 
     const int nb = tile_n * T + wn * 64, kb = tile_k * T + wk * 64;
     float* pbase = part + (size_t)split * N * Kp;
-    const float unscale = H2 ? 1.f / (sd * DW_H2_SA) : 1.f;   // (powers of two: exact)
+    const float unscale = (H2 && !redone) ? 1.f / (sd * DW_H2_SA) : 1.f;   // (powers of two: exact)
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
@@ -745,9 +767,6 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
                 pbase[(size_t)(nb + 16 * i + 4 * g + r) * Kp + k] = v;
             }
         }
-    if constexpr (H2) {
-        if (!(vmax < 65504.f)) atomicOr(const_cast<unsigned*>(reinterpret_cast<const unsigned*>(dscale)) + 1, 1u);   // half plane saturated: redo exactly
-    }
     if constexpr (H2) {   // the converting threads hold the column sums: groups gg = tid & 3 of a feature sit in 4 adjacent lanes
         if (part_b != nullptr && tile_k == 0) {
 #pragma unroll
@@ -785,14 +804,11 @@ hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long lo
     if (big && !force_f32 && !no_ring && (N % 128) == 0 && (Kp % 128) == 0) {
         const float* none = nullptr;
         if (dscale != nullptr && !force_exact) {
-            launch_with_lds(dw_gemm_ring_kernel<true>, grid, block, (size_t)DWR_STAGES * DWR_STAGE_FLOATS * sizeof(float), s, D, N, X, Kp, Q,
-                            splits, chunks_per_split, part, part_b, dscale);
-            // guarded exact re-run: every workgroup returns at once unless the launch above flagged a saturated half plane
-            if (!no_guard) launch_with_lds(dw_gemm_ring_kernel<false>, grid, block, (size_t)DWR_STAGES * DWR_STAGE_FLOATS * sizeof(float), s, D, N, X, Kp, Q,
-                            splits, chunks_per_split, part, part_b, dscale);
+            launch_with_lds(dw_gemm_ring_kernel<true>, grid, block, (size_t)DWR_STAGES * DWR_STAGE_FLOATS * sizeof(float) + 16, s, D, N, X, Kp, Q,
+                            splits, chunks_per_split, part, part_b, dscale, no_guard ? 0 : 1);
         } else {
             launch_with_lds(dw_gemm_ring_kernel<false>, grid, block, (size_t)DWR_STAGES * DWR_STAGE_FLOATS * sizeof(float), s, D, N, X, Kp, Q,
-                            splits, chunks_per_split, part, part_b, none);
+                            splits, chunks_per_split, part, part_b, none, 1);
         }
     }
     else if (big && !force_f32) hipLaunchKernelGGL((dw_gemm_fm_kernel<4, true>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);

@@ -68,6 +68,8 @@ struct SplitDev {
     const bf16x8* w1t[2];       // backward (delta_{j+1} W_j): n-tiles over the layer's INPUT features, chunks over its outputs
     const f16x8* rt[2];
     const float* invt[2];
+    float* out_part;            // backward: per-workgroup partials of the output layer's weight gradient [grid][A][K] (null: the
+    float* out_part_b;          //   separate dw_out pass forms it), and of its bias gradient [grid][A]
 };
 #ifndef GOPS_PIN_MODE
 #define GOPS_PIN_MODE 2   // layer-1 bf16 planes of the split kernels pinned to AGPRs (StatQ PIN; modes 1 / 2 / 3 measured within 1 %, r03)

@@ -162,8 +162,14 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
 // three ways: one 16-byte vector to the fp32 FM stash (weight-gradient GEMM), and - through plane_store - as the bf16 / f16
 // plane image the next contraction reads.  The half plane carries the step's power-of-two scale s_scale[0] (from
 // max|delta_y| of the tile), taken out again with the residual accumulator's factor.
-template <int PT0>
+// AMAX: compile-time bound of the action dimension.  The output layer's weight gradient dW_o = sum delta_y^T H_2 is formed
+// here as well (activations other than GELU, where the act' operand IS H_2): every lane keeps dW_o[a][its four columns]
+// over its four rows in AMAX x 4 registers across all steps (and tiles) of the workgroup; one partial per workgroup goes to
+// the split-K reduction - the separate dw_out pass over H_2 (126 MB at the target) is not launched.
+template <int PT0, int AMAX>
 struct SplitSweep {
+    float dwo[AMAX][4];          // dW_o[a][64 wave + 16 q + (lane & 15)], partial over rows 4 (lane >> 4) .. +3
+    float dbo[AMAX];             // d b_o[a], same partial
     StatQ<8, 4, false, GOPS_PIN_MODE> QT1;      // delta_2 -> delta_1 through W_1: both planes in registers
     StatQ<8, PT0, true> QT0;     // delta_1 -> g_x through W_0: bf16 plane in registers, half residual plane in LDS
     float wo[4];                 // W_o[k = lane >> 4][64 wave + 16 q + (lane & 15)]: B operand of the head-delta MFMA
@@ -176,6 +182,30 @@ struct SplitSweep {
         const int K = M.dims[2], A = M.dims[3], kk = lane >> 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) wo[q] = (kk < A) ? gptr(M.w[2])[kk * K + 64 * wave + 16 * q + (lane & 15)] : 0.f;
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) {
+            dbo[a] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dwo[a][q] = 0.f;
+        }
+    }
+    // this workgroup's partial of dW_o / d b_o -> part[blockIdx.x][a][K], part_b[blockIdx.x][a]   (rows a >= A of a slab are not read)
+    __device__ __forceinline__ void store_out_grad(const RolloutParams& p, float* part, float* part_b, int tid) {
+        const int lane = tid & 63, wave = tid >> 6, K = p.pol.dims[2], A = p.pol.dims[3];
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) {
+            float tb = dbo[a];
+            tb += __shfl_xor(tb, 16);
+            tb += __shfl_xor(tb, 32);
+            if (a < A && tid == 0) gptr(part_b)[(size_t)blockIdx.x * A + a] = tb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t = dwo[a][q];
+                t += __shfl_xor(t, 16);
+                t += __shfl_xor(t, 32);
+                if (a < A && lane < 16) gptr(part)[((size_t)blockIdx.x * A + a) * K + 64 * wave + 16 * q + lane] = t;
+            }
+        }
     }
     // The act' operands come straight from the FM stash into registers (one 16-byte vector per column), issued a phase
     // ahead of their use: H_2 at the top of the step (used after the env adjoint), H_1 right after the head (used after the
@@ -189,7 +219,7 @@ struct SplitSweep {
     template <class Hook>
     __device__ __forceinline__ void run(const RolloutParams& p, const float* s_gy, const float* s_scale, char* dq2, char* dq1,
                                         float* G, int ldg, int tid, size_t row0, int nvalid, bool want_gx, int ncols,
-                                        DbgClock& dbg, Hook&& after_head) {
+                                        DbgClock& dbg, Hook&& after_head, bool fuse_out) {
         const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
         const MlpDev& M = p.pol;
         constexpr int ROWB = 2 * 256 + 16;
@@ -216,6 +246,20 @@ struct SplitSweep {
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, wo[q], acc[q], 0, 0, 0);
             finish(2, acc, dq2);
+            if (fuse_out) {   // dW_o += delta_y^T H_2 over this lane's rows and columns (hv still holds H_2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f32x4 dyr = *reinterpret_cast<const f32x4*>(s_gy + (m0 + r) * 4);
+                    const bool ok = m0 + r < nvalid;
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) {
+                        const float d = ok ? dyr[a] : 0.f;
+                        dbo[a] += d;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dwo[a][q] = fmaf(d, hv[q][r], dwo[a][q]);
+                    }
+                }
+            }
             fetch(p, 1, row0, tid);   // H_1 of this step: lands behind the delta_1 contraction
             if (tid < TB) {
                 f32x4 v = {s_gy[tid * 4 + 0], s_gy[tid * 4 + 1], s_gy[tid * 4 + 2], s_gy[tid * 4 + 3]};
@@ -336,7 +380,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     typename std::conditional<(SK1 > 0 && !SPLIT), StatW<16, 4>, NoW>::type WT1;
     if constexpr (SK0 > 0 && !SPLIT) WT0.load(p.pol.wpt[0], kp0 >> 4, tid, p.pol.dims[1] >> 4);
     if constexpr (SK1 > 0 && !SPLIT) WT1.load(p.pol.wpt[1], p.pol.dims[1] >> 4, tid);
-    typename std::conditional<SPLIT, SplitSweep<PT0>, NoSweep>::type SS;
+    constexpr int AMAX = (ENV == GOPS_ENV_IDPENDULUM) ? 1 : ((ENV == GOPS_ENV_VEH3DOFCONTI) ? 2 : GOPS_MAX_ACT);
+    typename std::conditional<SPLIT, SplitSweep<PT0, AMAX>, NoSweep>::type SS;
     // SPLIT: W_0's residual plane ((kp0 / 16) n-tiles x 8 chunks x 1 KiB) behind the two small staging halves
     if constexpr (SPLIT) SS.load(p, tid, reinterpret_cast<f16x8*>(s_stage + 2 * (TB * ENV_STASH + TB * 8)));
 
@@ -1006,7 +1051,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         __syncthreads();
         DBG_TICK(1)
         if constexpr (SPLIT) {
-            SS.run(p, s_gy, s_scale, dq2, dq1, G, ldx, tid, row0, nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up);
+            SS.run(p, s_gy, s_scale, dq2, dq1, G, ldx, tid, row0, nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up,
+                   p.sp.out_part != nullptr);
         } else
         if (!p.open_loop) {
             if constexpr (F16)
@@ -1045,6 +1091,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 gptr(p.adj_gobs)[(size_t)(b0 + m) * O + i] = G[m * ldx + i];
             }
         }
+    }
+    if constexpr (SPLIT) {
+        if (p.sp.out_part != nullptr && tile + (int)gridDim.x >= ntiles) SS.store_out_grad(p, p.sp.out_part, p.sp.out_part_b, tid);   // after the last tile
     }
     } while (SPLIT && MULTI && (tile += gridDim.x) < ntiles);   // (every step ends with a barrier: the next tile's set-up may overwrite G / s_ref)
     dbg.dump(p.dbg);

@@ -50,7 +50,9 @@ class GraphedStep:
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         torch._foreach_copy_(self._dst, [batch[k] for k in self.keys])
         self.graph.replay()
-        return self.out
+        # the graph's output buffer is rewritten by the next replay: callers keep results around unread (LazyScalar log
+        # entries, utils/lazy_scalar.py), so every replay hands out its own copy (a few floats, no sync)
+        return self.out.clone() if torch.is_tensor(self.out) else self.out
 
 
 class StepGraphCache:

@@ -17,6 +17,7 @@ size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int spl
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split);
 bool split_eligible(const RolloutParams& p);
 int split_grid_limit();
+void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s);
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s);
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
@@ -642,6 +643,17 @@ size_t gops_rollout_workspace_bytes(const GopsRolloutDesc* desc) {
     Plan plan;
     if (build_plan(*desc, nullptr, plan) != GOPS_OK) return 0;
     return plan.bytes;
+}
+
+int gops_rollout_variant(const GopsRolloutDesc* desc) {
+    if (desc == nullptr) return GOPS_ERR_BAD_ARG;
+    Plan plan;
+    const int rc = build_plan(*desc, nullptr, plan);
+    if (rc != GOPS_OK) return rc;
+    if (plan.p.sp.on) return GOPS_VARIANT_SPLIT;
+    int sk[2];
+    rollout_variant(plan.p, sk, false);
+    return sk[1] > 0 ? GOPS_VARIANT_STATIONARY_F32 : 0;
 }
 
 int gops_rollout_forward(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const GopsRolloutOut* out,

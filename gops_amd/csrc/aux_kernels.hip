@@ -208,7 +208,7 @@ __device__ __forceinline__ void ref_table_element(int B, int P, int H, const flo
                                                   const float* __restrict__ u_num,
                                                   const float* __restrict__ ref_time, float pdt,
                                                   float* __restrict__ table, int idx, bool yphi_only,
-                                                  const float* __restrict__ refc) {
+                                                  const float* __restrict__ refc, const float* __restrict__ appended) {
     const int TL = P + 1 + H;
     if (idx >= B * TL) return;
     const int b = idx / TL, i = idx - b * TL;
@@ -220,6 +220,8 @@ __device__ __forceinline__ void ref_table_element(int B, int P, int H, const flo
         } else {
             v = reinterpret_cast<const f32x4*>(ref_points)[(size_t)b * (P + 1) + i];
         }
+    } else if (appended != nullptr) {   // bit-parity mode: the caller's points [B][H][4]
+        v = reinterpret_cast<const f32x4*>(appended)[(size_t)b * H + (i - P - 1)];
     } else {
         float t = ref_time[b];
         for (int s = 0; s < i - P; ++s) t = RADD(t, 0.1f);
@@ -309,7 +311,8 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
         const int nrt = (p.B * (P + 1 + p.H) + 255) / 256;
         if (b < nrt) {
             ref_table_element(p.B, P, p.H, p.in.ref_points, p.in.path_num, p.in.u_num, p.in.ref_time, pdt,
-                              const_cast<float*>(p.ref_table), b * 256 + threadIdx.x, p.env.kind == GOPS_ENV_VEH2DOF, p.env.ref_c);
+                              const_cast<float*>(p.ref_table), b * 256 + threadIdx.x, p.env.kind == GOPS_ENV_VEH2DOF, p.env.ref_c,
+                              p.in.ref_appended);
             return;
         }
         b -= nrt;
@@ -1347,7 +1350,8 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         const float nt = RADD(io.ref_time[b], 0.1f);
         const float pn = io.path_num[b], un = io.u_num[b];
         const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : 3;
-        const f32x4 newp = ref_point(env.ref_c, RADD(nt, pdt), path, un == 0.f ? 0 : 1);
+        const f32x4 newp = io.ref_appended != nullptr ? reinterpret_cast<const f32x4*>(io.ref_appended)[b]
+                                                      : ref_point(env.ref_c, RADD(nt, pdt), path, un == 0.f ? 0 : 1);
         const float* rin = io.ref_points + (size_t)b * (P + 1) * 2;
         float* rout = io.next_ref_points + (size_t)b * (P + 1) * 2;
         for (int i = 0; i < P; ++i) { rout[2 * i] = rin[2 * (i + 1)]; rout[2 * i + 1] = rin[2 * (i + 1) + 1]; }
@@ -1387,7 +1391,8 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         const float nt = RADD(io.ref_time[b], 0.1f);
         const float pn = io.path_num[b], un = io.u_num[b];
         const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : 3;
-        const f32x4 newp = ref_point(env.ref_c, RADD(nt, pdt), path, un == 0.f ? 0 : 1);
+        const f32x4 newp = io.ref_appended != nullptr ? reinterpret_cast<const f32x4*>(io.ref_appended)[b]
+                                                      : ref_point(env.ref_c, RADD(nt, pdt), path, un == 0.f ? 0 : 1);
         const f32x4* rin = reinterpret_cast<const f32x4*>(io.ref_points) + (size_t)b * (P + 1);
         f32x4* rout = reinterpret_cast<f32x4*>(io.next_ref_points) + (size_t)b * (P + 1);
         float cn, snn;

@@ -72,7 +72,8 @@ class GopsRolloutDesc(C.Structure):
 
 class GopsRolloutIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "done", "state", "ref_points", "path_num", "u_num",
-                                          "ref_time", "head_pre", "surr_state", "grad_constraint", "grad_constraint_prod")]
+                                          "ref_time", "head_pre", "surr_state", "grad_constraint", "grad_constraint_prod",
+                                          "ref_appended")]
 
 
 class GopsRolloutOut(C.Structure):
@@ -98,7 +99,7 @@ class GopsStepIO(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "action", "done", "state", "ref_points", "path_num",
                                           "u_num", "ref_time", "next_obs", "reward", "next_done",
                                           "next_state", "next_ref_points", "next_ref_time",
-                                          "surr_state", "next_surr_state", "constraint")]
+                                          "surr_state", "next_surr_state", "constraint", "ref_appended")]
 
 
 _lib = None
@@ -152,6 +153,8 @@ def lib() -> C.CDLL:
         l.gops_adam_step.restype = C.c_int
         l.gops_adam_step.argtypes = [C.POINTER(GopsAdamTensors), C.c_void_p, C.c_double, C.c_double, C.c_double,
                                      C.c_void_p]
+        l.gops_rollout_variant.restype = C.c_int
+        l.gops_rollout_variant.argtypes = [C.POINTER(GopsRolloutDesc)]
         l.gops_profile_enable.argtypes = [C.c_int32]
         l.gops_profile_reset.argtypes = []
         l.gops_profile_read.restype = C.c_int
@@ -164,7 +167,7 @@ EXPORTED_SYMBOLS = ("gops_hip_version", "gops_rollout_workspace_bytes", "gops_ro
                     "gops_rollout_backward", "gops_rollout_backward_open_loop", "gops_rollout_backward_adj", "gops_env_step", "gops_value_workspace_bytes",
                     "gops_value_forward", "gops_value_backward", "gops_mlp_workspace_bytes", "gops_mlp_forward",
                     "gops_mlp_backward", "gops_mlp_backward_x", "gops_adam_step", "gops_profile_enable",
-                    "gops_profile_reset", "gops_profile_read")
+                    "gops_profile_reset", "gops_profile_read", "gops_rollout_variant")
 
 _ERR = {-1: "GOPS_ERR_BAD_ARG", -2: "GOPS_ERR_UNSUPPORTED", -3: "GOPS_ERR_WORKSPACE"}
 
@@ -355,6 +358,8 @@ class Rollout:
                 setattr(i, k, _ptr(data[k]))
         if d.env.kind == ENV_VEH_SURR:
             i.surr_state = _ptr(data.get("surr_state"))   # (None for the errcstr model: no surrounding vehicles)
+        # bit-parity mode (GopsRolloutIn.ref_appended): the reference's own appended reference points [B, H, 4]
+        i.ref_appended = _ptr(data.get("ref_appended"))
         self._keep = dict(data)   # the kernels (and a later backward) read these tensors: keep them alive
         out = GopsRolloutOut()
         res = {"v_pi": torch.empty(B, dtype=torch.float32, device=self.device)}
@@ -481,7 +486,8 @@ class MlpNet:
 
 
 def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Tensor]] = None):
-    """One wrapped env-model step on the GPU (gops_env_step)."""
+    """One wrapped env-model step on the GPU (gops_env_step).  `info["ref_appended"]` [B, 4] (optional): the reference
+    point this step appends, from the caller (bit-parity mode, GopsStepIO.ref_appended)."""
     B = obs.shape[0]
     io = GopsStepIO()
     nobs, rew, ndone = torch.empty_like(obs), torch.empty(B, device=obs.device), torch.empty(B, device=obs.device)
@@ -495,6 +501,7 @@ def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Ten
                      ref_time=torch.empty_like(info["ref_time"]), path_num=info["path_num"], u_num=info["u_num"])
         io.next_state, io.next_ref_points = _ptr(ninfo["state"]), _ptr(ninfo["ref_points"])
         io.next_ref_time = _ptr(ninfo["ref_time"])
+        io.ref_appended = _ptr(info.get("ref_appended"))
     if has_constraints(env) and env.n_surr == 0:
         ninfo["constraint"] = torch.empty(B, env.n_constraint, dtype=torch.float32, device=obs.device)
         io.constraint = _ptr(ninfo["constraint"])

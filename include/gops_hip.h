@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GOPS_HIP_ABI_VERSION 7
+#define GOPS_HIP_ABI_VERSION 8
 
 #define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
 #define GOPS_MAX_ACT 4      /* action dimensions */
@@ -217,6 +217,12 @@ typedef struct GopsRolloutIn {
                                  (rows as in GopsRolloutOut.constraint_sums); NULL = zeros */
     const float* grad_constraint_prod; /* gops_rollout_backward, GOPS_ENV_VEH3DOF_SURR: [n_constraint, B]
                                  d(loss)/d(P_k) * P_k for the products P_k of GopsRolloutOut.constraint_prods; NULL = zeros */
+    const float* ref_appended; /* ABI v8, models with reference trajectories, or NULL: [B, H, 4] (x, y, phi, u) - the point the
+                                 model APPENDS to info["ref_points"] at rollout step s (ref_traj_model.py:26-148 evaluated at
+                                 ref_time + (s + 1) dt + P dt), supplied by the caller instead of evaluated by the library.
+                                 Bit-parity mode: the reference's heading is a 1 ms finite difference in fp32 whose last-ulp
+                                 behaviour depends on the host's libm; a caller that fills this tensor with the reference's own
+                                 MultiRefTrajModel values gets observations identical to the reference's. */
 } GopsRolloutIn;
 
 typedef struct GopsRolloutOut {
@@ -290,6 +296,8 @@ typedef struct GopsStepIO {
     float* next_state; float* next_ref_points; float* next_ref_time;
     /* GOPS_ENV_VEH3DOF_SURR: info["surr_state"] [B, n_surr, 5] in / out, info["constraint"] [B, n_constraint] out */
     const float* surr_state; float* next_surr_state; float* constraint;
+    const float* ref_appended;   /* ABI v8, or NULL: [B, 4] (veh2dofconti: (., y, phi, .)) the reference point this step appends,
+                                    from the caller (see GopsRolloutIn.ref_appended) */
 } GopsStepIO;
 int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream);
 
@@ -347,6 +355,17 @@ typedef struct GopsAdamState {   /* 48 bytes of device memory */
 } GopsAdamState;
 int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, double beta1, double beta2,
                    double eps, void* stream);
+
+/* Which kernels a rollout description runs on this device (ABI v8; for benchmarks / profiles, no launch):
+ * bit 0 (GOPS_VARIANT_SPLIT): the register-stationary kernels with plane-split contractions - hidden-layer weights as
+ *        bf16 + scaled f16 residual planes, activations / deltas as three exact bf16 planes + one f16 plane,
+ *        3 bf16 + 1 f16 MFMA (16x16x32) per 32-deep block, fp32 accumulation (>= 19-bit weights, fp32 results);
+ * bit 1 (GOPS_VARIANT_STATIONARY_F32): the register-stationary kernels on exact fp32 MFMAs;
+ * neither: the streamed kernels (exact fp32 MFMAs, or half-precision MFMAs for GOPS_DTYPE_F16).
+ * Negative: a GOPS_ERR_* code for a description the library rejects. */
+#define GOPS_VARIANT_SPLIT 1
+#define GOPS_VARIANT_STATIONARY_F32 2
+int gops_rollout_variant(const GopsRolloutDesc* desc);
 
 /* Timing hook for bench.py: average duration in ms of the named internal kernel over the
  * launches recorded since the last reset (HIP events on the launch stream).  kernel ids:

@@ -107,6 +107,59 @@ def test_env_step_vs_reference_fixture(name, dev):
         assert np.array_equal(done.cpu().numpy() != 0, g[f"s{s}/done"])
 
 
+@pytest.mark.parametrize("name", ["step_veh_p10", "step_veh_p30", "step_veh_p10_refpara", "step_veh_p10_nomask", "step_veh2dof_p10"])
+def test_env_step_bit_parity_mode_with_the_references_appended_points(name, dev):
+    """Bit-parity mode (ABI v8, GopsStepIO.ref_appended): with the appended reference point of every step taken from the
+    reference itself (the fixtures record it: `s<k>/ref_last`) the 1 ms finite-difference heading - whose last-ulp
+    behaviour depends on the host's libm - no longer goes through the kernel's own evaluation, and EVERY observation
+    element meets the reference's own single-step tolerance: no outlier share, no 2e-3 band."""
+    from gops_amd import hip_backend as hb
+    g = load_golden(name)
+    meta = golden_meta(g)
+    env = hip_env_from_oracle(oracle_env(meta["cfg"], meta["extra"], g))
+    data = to_device(data_from_golden(g), dev)
+    obs, done = data["obs"], data["done"]
+    info = {k: data[k] for k in INFO_KEYS if k in data}
+    for s in range(int(g["meta/nsteps"])):
+        a = torch.from_numpy(g[f"s{s}/act"]).to(dev)
+        last = torch.from_numpy(g[f"s{s}/ref_last"]).to(dev)
+        if last.shape[1] == 2:   # veh2dofconti keeps (y, phi) only: slots 1, 2 of the (x, y, phi, u) record
+            last = torch.cat((torch.zeros_like(last[:, :1]), last, torch.zeros_like(last[:, :1])), 1)
+        obs, r, done, ninfo = hb.env_step(env, obs, a, done, dict(info, ref_appended=last.contiguous()))
+        info = {k: v for k, v in ninfo.items() if k != "ref_appended"}
+        np.testing.assert_allclose(obs.cpu().numpy(), g[f"s{s}/obs"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(r.cpu().numpy(), g[f"s{s}/rew"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(ninfo["state"].cpu().numpy(), g[f"s{s}/state"], rtol=1e-5, atol=1e-5)
+        assert np.array_equal(done.cpu().numpy() != 0, g[f"s{s}/done"])
+
+
+def test_rollout_bit_parity_mode_with_appended_points(dev):
+    """GopsRolloutIn.ref_appended: the H appended points of a rollout from the caller (here the oracle's restatement of
+    MultiRefTrajModel on this host) - the final observation then agrees ELEMENT-wise with the oracle's at 1e-5."""
+    from gops_amd import hip_backend as hb
+    cfg = dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=70, horizon=12, pre_horizon=10, hidden=(64, 64), act="tanh", gamma=0.97)
+    data = make_batch(cfg, 31)
+    nets = reference_init_nets(cfg, 31, obs_dim_of(cfg), act_dim_of(cfg))
+    env = orc.make_env(cfg["env_id"], pre_horizon=10)
+    ref = orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+    P, H, dt = 10, cfg["horizon"], 0.1
+    t = data["ref_time"].clone()
+    pts = []
+    for s in range(H):   # veh_step: nt = ref_time + dt (accumulated in fp32), new point at nt + P dt
+        t = t + dt
+        pts.append(orc.ref_point(t + P * dt, data["path_num"], data["u_num"]))
+    appended = torch.stack(pts, 1).contiguous()   # [B, H, 4]
+    henv = hip_env_from_oracle(env, nets["policy"])
+    mlp, ws, bs = hip_mlp_from_net(nets["policy"], dev)
+    B = data["obs"].shape[0]
+    ro = hb.Rollout(henv, mlp, batch=B, horizon=H, gamma=cfg["gamma"], finite_horizon=True)
+    ddev = to_device(dict(data, ref_appended=appended), dev)
+    res = ro.forward(ddev, want_rewards=True, want_final=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(res["final_obs"].cpu().numpy(), ref["final_obs"].numpy(), rtol=2e-5, atol=5e-5)
+    assert rel_l2(res["v_pi"].cpu(), ref["v_pi"]) < 1e-5
+
+
 def _run_fhadp(env, nets, data, cfg, dev):
     from gops_amd import hip_backend as hb
     henv = hip_env_from_oracle(env, nets["policy"])

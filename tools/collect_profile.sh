@@ -5,7 +5,7 @@
 # tools/summarize_profile.py then turns that directory into profiles/<tag>_<workload>[_f16]_*.
 # Every counter group is collected in its OWN short run (kernel-trace only): FETCH_SIZE and WRITE_SIZE do not fit
 # the TCC's 4 slots together (3 + 2, MI355X_MICROARCH.md), which is what made the r01 pass time out.
-tag=${1:-r02}
+tag=${1:-r03}
 wl=${2:-target_veh3dof_fhadp_b4096_h30}
 dt=${3:-fp32}
 sfx=""; [ "$dt" = "fp16" ] && sfx="_f16"

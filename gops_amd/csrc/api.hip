@@ -404,7 +404,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     if (desc.env.repeat_num > 1) p.ext = 1;   // ActionRepeatModel: the general (EXT) instantiations of the sweep
     if (adj != nullptr) {   // gops_rollout_backward_adj / gops_mlp_backward_x: the EXT kernels
         const int k = desc.env.kind;
-        if (p.open_loop || p.tail || p.f16) return GOPS_ERR_UNSUPPORTED;
+        if (p.tail || p.f16) return GOPS_ERR_UNSUPPORTED;   // (open loop: gops_rollout_backward_open_loop_adj)
         if (k != GOPS_ENV_NONE && k != GOPS_ENV_LQ && k != GOPS_ENV_IDPENDULUM && k != GOPS_ENV_CARTPOLE && k != GOPS_ENV_PENDULUM)
             return GOPS_ERR_UNSUPPORTED;
         p.ext = 1;
@@ -687,6 +687,18 @@ int gops_rollout_backward_open_loop(const GopsRolloutDesc* desc, const GopsRollo
     memset(&none, 0, sizeof(none));
     return run_backward(*desc, *in, grad_v, none, grad_head_pre, workspace, workspace_bytes,
                         static_cast<hipStream_t>(stream));
+}
+
+int gops_rollout_backward_open_loop_adj(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const float* grad_v,
+                                        float* grad_head_pre, const GopsRolloutAdjoint* adj, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    if (!desc || !in || !grad_head_pre || !adj || !desc->open_loop) return GOPS_ERR_BAD_ARG;
+    GopsMlpGrad none;
+    memset(&none, 0, sizeof(none));
+    GopsRolloutAdjoint a = *adj;
+    a.first_step_only = 0;
+    return run_backward(*desc, *in, grad_v, none, grad_head_pre, workspace, workspace_bytes, static_cast<hipStream_t>(stream),
+                        nullptr, &a, false);
 }
 
 int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream) {

@@ -153,6 +153,9 @@ def lib() -> C.CDLL:
         l.gops_adam_step.restype = C.c_int
         l.gops_adam_step.argtypes = [C.POINTER(GopsAdamTensors), C.c_void_p, C.c_double, C.c_double, C.c_double,
                                      C.c_void_p]
+        l.gops_rollout_backward_open_loop_adj.restype = C.c_int
+        l.gops_rollout_backward_open_loop_adj.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn), C.c_void_p, C.c_void_p,
+                                                          C.POINTER(GopsRolloutAdjoint), C.c_void_p, C.c_size_t, C.c_void_p]
         l.gops_rollout_variant.restype = C.c_int
         l.gops_rollout_variant.argtypes = [C.POINTER(GopsRolloutDesc)]
         l.gops_profile_enable.argtypes = [C.c_int32]
@@ -167,7 +170,7 @@ EXPORTED_SYMBOLS = ("gops_hip_version", "gops_rollout_workspace_bytes", "gops_ro
                     "gops_rollout_backward", "gops_rollout_backward_open_loop", "gops_rollout_backward_adj", "gops_env_step", "gops_value_workspace_bytes",
                     "gops_value_forward", "gops_value_backward", "gops_mlp_workspace_bytes", "gops_mlp_forward",
                     "gops_mlp_backward", "gops_mlp_backward_x", "gops_adam_step", "gops_profile_enable",
-                    "gops_profile_reset", "gops_profile_read", "gops_rollout_variant")
+                    "gops_profile_reset", "gops_profile_read", "gops_rollout_variant", "gops_rollout_backward_open_loop_adj")
 
 _ERR = {-1: "GOPS_ERR_BAD_ARG", -2: "GOPS_ERR_UNSUPPORTED", -3: "GOPS_ERR_WORKSPACE"}
 
@@ -415,6 +418,19 @@ class Rollout:
                                               C.byref(adj), self.workspace.data_ptr(), self.workspace.numel(), _stream()),
               "gops_rollout_backward_adj")
         return g_obs
+
+    def backward_open_loop_adj(self, grad_v: torch.Tensor, grad_final_obs: Optional[torch.Tensor] = None):
+        """`gops_rollout_backward_open_loop_adj`: (d(loss)/d(head_pre) [B, H, act_dim], d(loss)/d(obs) [B, obs_dim]) of the last
+        open-loop forward, the sweep seeded with d(loss)/d(final_obs) (models whose observation is the state)."""
+        d = self.desc
+        g = torch.empty(d.batch, d.horizon, d.env.act_dim, dtype=torch.float32, device=self.device)
+        g_obs = torch.empty(d.batch, d.env.obs_dim, dtype=torch.float32, device=self.device)
+        adj = GopsRolloutAdjoint()
+        adj.grad_final_obs, adj.grad_obs, adj.first_step_only = _ptr(grad_final_obs), _ptr(g_obs), 0
+        check(lib().gops_rollout_backward_open_loop_adj(C.byref(d), C.byref(self._in), _ptr(grad_v), _ptr(g), C.byref(adj),
+                                                        self.workspace.data_ptr(), self.workspace.numel(), _stream()),
+              "gops_rollout_backward_open_loop_adj")
+        return g, g_obs
 
     def backward_open_loop(self, grad_v: torch.Tensor) -> torch.Tensor:
         """d(loss)/d(head_pre) [B, H, act_dim] of the last open-loop forward."""

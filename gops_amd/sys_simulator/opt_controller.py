@@ -1,7 +1,8 @@
-"""OptController - receding-horizon optimal control over an environment model, by single shooting on the MI355X.
+"""OptController - receding-horizon optimal control over an environment model on the MI355X: single shooting and
+direct collocation.
 
 Interface of the reference's gops/sys_simulator/opt_controller.py:30-330 (`OptController(model, num_pred_step,
-ctrl_interval, gamma, ..., mode="shooting")`, `controller(x, info) -> first optimal action`, warm start by shifting the
+ctrl_interval, gamma, ..., mode="collocation")`, `controller(x, info) -> first optimal action`, warm start by shifting the
 previous solution).  The reference rolls the raw model out step by step in Python (`_rollout`, :240-300) and gets the
 Jacobian of the cost from autograd; here one cost + Jacobian evaluation is ONE forward and ONE backward launch of the
 horizon-rollout kernels in their raw-action open-loop mode (`GopsRolloutDesc.open_loop = 2`: the decision variables are
@@ -11,9 +12,21 @@ done test fired, as in :261-265):
     cost(u_0 .. u_{T-1}) = - sum_i gamma^i r_i ,      d cost / d u   from  gops_rollout_backward_open_loop.
 
 Box constraints on the actions are the model's action bounds.  The solver is scipy's L-BFGS-B (cyipopt, which the
-reference calls, is not part of this environment).  Not provided: `mode="collocation"` and path constraints
-(`model.get_constraint`), which need IPOPT's general constraint handling, and user terminal-cost callbacks (a Python
-function cannot run inside the kernel).
+reference calls, is not part of this environment).
+
+`mode="collocation"` (the reference's default, :60, 77-82, 104-109): the decision variables are (action, state) at every
+control point; the reference rolls ALL intervals out as one batch (`rollout_mode = "batch"`, :272-291: interval j starts
+from the decision state of point j - 1, the first from x) and hands IPOPT the transition residuals
+`true_state_j - decision_state_j = 0` as equality constraints (:196-215).  Here the batch of intervals is ONE open-loop
+rollout launch (batch = control points, horizon = ctrl_interval), the cost gradient w.r.t. actions AND start states one
+launch of `gops_rollout_backward_open_loop_adj` (ABI v8), and the transition Jacobian one forward + one backward launch over
+obs_dim replicas of every interval, each seeded with one unit vector on its final state.  Solver: scipy's SLSQP with the
+equality constraints and the box bounds on actions and states.  Collocation needs a model whose observation IS its state
+and whose `forward` takes no `info` (pyth_lq, pyth_idpendulum, gym_cartpoleconti, gym_pendulum) - for the others the
+reference itself drops to its step-by-step rollout (:292-294); use `mode="shooting"` for them here.
+
+Not provided: path constraints (`model.get_constraint`: the constrained vehicle models), and user terminal-cost callbacks
+(a Python function cannot run inside the kernel).
 """
 from typing import Dict, Optional
 
@@ -29,9 +42,8 @@ _INFO = ("state", "ref_points", "path_num", "u_num", "ref_time")
 class OptController:
     def __init__(self, model, num_pred_step: int, ctrl_interval: int = 1, gamma: float = 1.0,
                  use_terminal_cost: bool = False, terminal_cost=None, minimize_options: Optional[dict] = None,
-                 verbose: int = 0, mode: str = "shooting", device=None):
-        if mode != "shooting":
-            raise NotImplementedError("OptController on the HIP rollout supports mode='shooting' only")
+                 verbose: int = 0, mode: str = "collocation", device=None):
+        assert mode in ("shooting", "collocation")
         if use_terminal_cost or terminal_cost is not None:
             raise NotImplementedError("terminal-cost callbacks cannot run inside the rollout kernel")
         assert num_pred_step % ctrl_interval == 0, "ctrl_interval should be a factor of num_pred_step."
@@ -42,11 +54,22 @@ class OptController:
         self.obs_dim, self.action_dim, self.sim_dt = base.obs_dim, base.action_dim, base.dt
         self.gamma, self.ctrl_interval, self.num_pred_step = gamma, ctrl_interval, num_pred_step
         self.num_ctrl_points = num_pred_step // ctrl_interval
-        self.mode, self.rollout_mode, self.optimize_dim = mode, "kernel", self.action_dim
+        self.mode, self.rollout_mode = mode, "kernel"
         self.minimize_options = dict(minimize_options or {})
         self.verbose = verbose
         lo = base.action_lower_bound.cpu().numpy().astype(np.float64)
         hi = base.action_upper_bound.cpu().numpy().astype(np.float64)
+        if mode == "collocation":
+            if base.hip_kind not in (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_CARTPOLE, hb.ENV_PENDULUM):
+                raise NotImplementedError(
+                    "mode='collocation' batches the intervals, which needs a model whose observation is its state and whose "
+                    "forward takes no info (pyth_lq, pyth_idpendulum, gym_cartpoleconti, gym_pendulum); the reference itself "
+                    "falls back to a step-by-step rollout for the others (opt_controller.py:292-294) - use mode='shooting'")
+            lo = np.concatenate((lo, base.obs_lower_bound.cpu().numpy().astype(np.float64)))
+            hi = np.concatenate((hi, base.obs_upper_bound.cpu().numpy().astype(np.float64)))
+            self.optimize_dim = self.action_dim + self.obs_dim
+        else:
+            self.optimize_dim = self.action_dim
         self.bounds = opt.Bounds(np.tile(lo, self.num_ctrl_points), np.tile(hi, self.num_ctrl_points))
         self.initial_guess = np.zeros(self.optimize_dim * self.num_ctrl_points)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -59,7 +82,67 @@ class OptController:
         self._rollout_obj = hb.Rollout(env, None, batch=1, horizon=num_pred_step, gamma=gamma, finite_horizon=False,
                                        need_grad=True, device=self.device, raw_actions=True)
         self._minus_one = torch.full((1,), -1.0, dtype=torch.float32, device=self.device)
+        if mode == "collocation":
+            n, ci, O = self.num_ctrl_points, ctrl_interval, self.obs_dim
+            mk = lambda batch: hb.Rollout(env, None, batch=batch, horizon=ci, gamma=gamma, finite_horizon=False, need_grad=True,
+                                          device=self.device, raw_actions=True)
+            self._col, self._col_jac = mk(n), mk(n * O)
+            # interval j covers the global steps j ci .. j ci + ci - 1: its discounted return enters the cost with gamma^(j ci)
+            self._col_w = torch.tensor([-(gamma ** (j * ci)) for j in range(n)], dtype=torch.float32, device=self.device)
+            self._zeros_nO = torch.zeros(n * O, dtype=torch.float32, device=self.device)
+            self._eye_rep = torch.eye(O, dtype=torch.float32, device=self.device).repeat(n, 1).contiguous()   # row j O + k = e_k
         self._reset_statistics()
+
+    # ---- collocation: (action, state) per control point ------------------------------------------
+    def _col_split(self, inputs: np.ndarray, x):
+        """-> (start states [n, O], held actions [n, ci, A]) of the decision vector `inputs` and the current state x."""
+        n, A, O, ci = self.num_ctrl_points, self.action_dim, self.obs_dim, self.ctrl_interval
+        z = torch.as_tensor(np.asarray(inputs, dtype=np.float32), device=self.device).reshape(n, A + O)
+        x0 = torch.as_tensor(np.asarray(x), dtype=torch.float32, device=self.device).reshape(1, O)
+        starts = torch.cat((x0, z[:-1, A:]), 0).contiguous()
+        acts = z[:, :A].unsqueeze(1).expand(n, ci, A).contiguous()
+        return z, starts, acts
+
+    def _col_cost_and_jac(self, inputs: np.ndarray, x, info: Dict):
+        n, A, O = self.num_ctrl_points, self.action_dim, self.obs_dim
+        self.system_simulations += 1
+        z, starts, acts = self._col_split(inputs, x)
+        res = self._col.forward({"obs": starts, "done": torch.zeros(n, dtype=torch.float32, device=self.device)}, head_pre=acts)
+        g_act, g_obs = self._col.backward_open_loop_adj(self._col_w)
+        jac = torch.zeros(n, A + O, dtype=torch.float32, device=self.device)
+        jac[:, :A] = g_act.sum(1)               # the action of a point is held over its interval
+        jac[:-1, A:] = g_obs[1:]                # the state of point j starts interval j + 1
+        cost = (self._col_w * res["v_pi"]).sum()
+        return float(cost.item()), jac.reshape(-1).double().cpu().numpy()
+
+    def _trans_constraint_fcn(self, inputs: np.ndarray, x, info: Dict) -> np.ndarray:
+        """true_state_j - decision_state_j for every control point (opt_controller.py:196-215)."""
+        n, A = self.num_ctrl_points, self.action_dim
+        self.constraint_evaluations += 1
+        z, starts, acts = self._col_split(inputs, x)
+        res = self._col.forward({"obs": starts, "done": torch.zeros(n, dtype=torch.float32, device=self.device)}, head_pre=acts,
+                                want_final=True)
+        return (res["final_obs"] - z[:, A:]).reshape(-1).double().cpu().numpy()
+
+    def _trans_constraint_jac(self, inputs: np.ndarray, x, info: Dict) -> np.ndarray:
+        """Jacobian [n O, n (A + O)] of the transition residuals: block (j, j) = d true_state_j / d action_j and - I on the
+        decision state, block (j, j - 1) = d true_state_j / d start state.  One forward + one sweep over O replicas of each
+        interval, replica k seeded with e_k on its final state."""
+        n, A, O, ci = self.num_ctrl_points, self.action_dim, self.obs_dim, self.ctrl_interval
+        z, starts, acts = self._col_split(inputs, x)
+        rep = lambda t: t.repeat_interleave(O, dim=0).contiguous()
+        self._col_jac.forward({"obs": rep(starts), "done": self._zeros_nO}, head_pre=rep(acts))
+        g_act, g_obs = self._col_jac.backward_open_loop_adj(self._zeros_nO, grad_final_obs=self._eye_rep)
+        g_act = g_act.sum(1).reshape(n, O, A).double().cpu().numpy()       # [j, k, a] = d state_j[k] / d action_j[a]
+        g_obs = g_obs.reshape(n, O, O).double().cpu().numpy()              # [j, k, i] = d state_j[k] / d start_j[i]
+        D = A + O
+        J = np.zeros((n * O, n * D))
+        for j in range(n):
+            J[j * O:(j + 1) * O, j * D:j * D + A] = g_act[j]
+            J[j * O:(j + 1) * O, j * D + A:(j + 1) * D] = -np.eye(O)
+            if j > 0:
+                J[j * O:(j + 1) * O, (j - 1) * D + A:j * D] = g_obs[j]
+        return J
 
     # ------------------------------------------------------------------------------------------
     def _batch(self, x, info: Dict):
@@ -94,8 +177,14 @@ class OptController:
     def __call__(self, x: np.ndarray, info: Optional[Dict] = None) -> np.ndarray:
         """Optimal control input for the current state `x` (and model info, e.g. veh3dofconti's reference window)."""
         info = info or {}
-        res = opt.minimize(self._cost_fcn_and_jac, self.initial_guess, args=(x, info), jac=True, bounds=self.bounds,
-                           method="L-BFGS-B", options=self.minimize_options or None)
+        if self.mode == "collocation":
+            res = opt.minimize(self._col_cost_and_jac, self.initial_guess, args=(x, info), jac=True, bounds=self.bounds,
+                               method="SLSQP", options=self.minimize_options or {"maxiter": 200, "ftol": 1e-9},
+                               constraints=[{"type": "eq", "fun": self._trans_constraint_fcn, "jac": self._trans_constraint_jac,
+                                             "args": (x, info)}])
+        else:
+            res = opt.minimize(self._cost_fcn_and_jac, self.initial_guess, args=(x, info), jac=True, bounds=self.bounds,
+                               method="L-BFGS-B", options=self.minimize_options or None)
         self.last_result = res
         # warm start of the next call: drop the first control point, repeat the last (:158-160)
         self.initial_guess = np.concatenate((res.x[self.optimize_dim:], res.x[-self.optimize_dim:]))

@@ -285,6 +285,15 @@ int gops_rollout_backward_adj(const GopsRolloutDesc* desc, const GopsRolloutIn* 
                               const GopsMlpGrad* policy_grad, const GopsRolloutAdjoint* adj,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* Open-loop rollout with adjoint I/O (ABI v8): gops_rollout_backward_open_loop seeded with d(loss)/d(final_obs) and
+ * returning d(loss)/d(obs) of the initial observation next to d(loss)/d(head_pre) - one collocation interval of
+ * OptController (gops/sys_simulator/opt_controller.py:104-109, 196-215: the decision variables are the actions AND the
+ * states at the control points; cost and transition-constraint Jacobians need both adjoints).  Same env kinds as
+ * gops_rollout_backward_adj; adj->first_step_only is ignored. */
+int gops_rollout_backward_open_loop_adj(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const float* grad_v,
+                                        float* grad_head_pre, const GopsRolloutAdjoint* adj,
+                                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* One wrapped env-model step.  `action` is the raw (pre-wrapper) action [B, act_dim].  For
  * veh3dofconti the info tensors are updated into the next_* outputs (may alias the inputs
  * except ref_points). */

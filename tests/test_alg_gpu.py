@@ -463,7 +463,7 @@ def test_opt_controller_cost_and_jacobian_match_raw_model(cfg):
     from oracle import adp_oracle as orc
     model = create_env_model(**cfg, use_gpu=True)
     T, interval = 12, 3
-    ctrl = OptController(model, num_pred_step=T, ctrl_interval=interval, gamma=0.97)
+    ctrl = OptController(model, num_pred_step=T, ctrl_interval=interval, gamma=0.97, mode="shooting")
     data = make_batch(dict(cfg, batch=3), 21)
     env = orc.make_env(cfg["env_id"], lq_config=cfg.get("lq_config", "s4a2"), pre_horizon=cfg.get("pre_horizon", 10))
     rng = np.random.RandomState(4)
@@ -493,7 +493,7 @@ def test_opt_controller_solves_lq_regulation():
     from gops_amd.sys_simulator.opt_controller import OptController
     from gops_amd import hip_backend as hb
     model = create_env_model("pyth_lq", lq_config="s4a2", use_gpu=True)
-    ctrl = OptController(model, num_pred_step=20, ctrl_interval=2, gamma=1.0, minimize_options={"maxiter": 60})
+    ctrl = OptController(model, num_pred_step=20, ctrl_interval=2, gamma=1.0, minimize_options={"maxiter": 60}, mode="shooting")
     x = np.array([1.5, -0.6, 1.0, 0.5], dtype=np.float32)
     zero_cost, _ = ctrl._cost_fcn_and_jac(np.zeros_like(ctrl.initial_guess), x, {})
     raw = ctrl._rollout_obj.desc.env
@@ -509,6 +509,82 @@ def test_opt_controller_solves_lq_regulation():
         x = nobs[0].cpu().numpy()
         norms.append(float(np.linalg.norm(x)))
     assert norms[-1] < 0.8 * norms[0] and all(b < a + 1e-6 for a, b in zip(norms, norms[1:])), norms   # 2.5 s of a slow plant
+
+
+def _oracle_collocation(env, x, z, n, ci, A, O, gamma):
+    """The reference's collocation rollout in batch mode (opt_controller.py:272-291, 196-215, 302-318) on the oracle's raw model
+    steps: cost and transition residuals of the decision vector z [n, A + O], with autograd Jacobians."""
+    import torch
+    from oracle import adp_oracle as orc
+    step = (lambda o, a: orc.lq_step(env["lq"], o, a)) if env["kind"] == "lq" else (lambda o, a: orc.idp_step(o, a))
+
+    def both(zf):
+        zz = zf.reshape(n, A + O)
+        xs = torch.cat((x.reshape(1, O), zz[:-1, A:]), 0)
+        us = zz[:, :A]
+        cost = torch.zeros(())
+        for i in range(ci):
+            xs, r, _ = step(xs, us)
+            k = torch.arange(n, dtype=torch.float32) * ci + i
+            cost = cost - (r * gamma ** k).sum()
+        return cost, (xs - zz[:, A:]).reshape(-1)
+
+    zf = z.reshape(-1).clone().requires_grad_(True)
+    cost, res = both(zf)
+    (jac,) = torch.autograd.grad(cost, zf)
+    J = torch.autograd.functional.jacobian(lambda v: both(v)[1], z.reshape(-1))
+    return cost.item(), jac, res.detach(), J
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(env_id="pyth_lq", lq_config="s4a2"), dict(env_id="pyth_lq", lq_config="s6a3"), dict(env_id="pyth_idpendulum")],
+                         ids=lambda c: c["env_id"][5:] + c.get("lq_config", ""))
+def test_opt_controller_collocation_cost_constraints_and_jacobians(cfg):
+    """mode="collocation" (the reference's default): cost + Jacobian w.r.t. (action, state) of every control point, transition
+    residuals + their Jacobian - each from one or two kernel launches over the batch of intervals - against the reference's
+    batch rollout restated on the oracle's raw model steps with autograd."""
+    from gops_amd.create_pkg.create_env_model import create_env_model
+    from gops_amd.sys_simulator.opt_controller import OptController
+    from oracle import adp_oracle as orc
+    model = create_env_model(**cfg, use_gpu=True)
+    T, ci, gamma = 12, 3, 0.97
+    ctrl = OptController(model, num_pred_step=T, ctrl_interval=ci, gamma=gamma)   # default mode
+    assert ctrl.mode == "collocation" and ctrl.optimize_dim == ctrl.action_dim + ctrl.obs_dim
+    env = orc.make_env(cfg["env_id"], lq_config=cfg.get("lq_config", "s4a2"))
+    n, A, O = ctrl.num_ctrl_points, ctrl.action_dim, ctrl.obs_dim
+    rng = np.random.RandomState(7)
+    alo, ahi = ctrl.bounds.lb[:A], ctrl.bounds.ub[:A]
+    for trial in range(3):
+        x = rng.uniform(-0.3, 0.3, O).astype(np.float32)
+        z = np.concatenate([np.concatenate((rng.uniform(0.5 * alo, 0.5 * ahi), rng.uniform(-0.3, 0.3, O))) for _ in range(n)]).astype(np.float32)
+        want_cost, want_jac, want_res, want_J = _oracle_collocation(env, torch.tensor(x), torch.tensor(z), n, ci, A, O, gamma)
+        cost, jac = ctrl._col_cost_and_jac(z, x, {})
+        assert abs(cost - want_cost) <= 1e-4 * max(1.0, abs(want_cost)), (cost, want_cost)
+        assert rel_l2(jac, want_jac) < 1e-4, rel_l2(jac, want_jac)
+        res = ctrl._trans_constraint_fcn(z, x, {})
+        assert rel_l2(res, want_res) < 1e-4, rel_l2(res, want_res)
+        J = ctrl._trans_constraint_jac(z, x, {})
+        assert J.shape == tuple(want_J.shape) and rel_l2(J, want_J) < 1e-4, rel_l2(J, want_J)
+
+
+@pytest.mark.gpu
+def test_opt_controller_collocation_and_shooting_agree_on_lq():
+    """The two transcriptions of the same convex problem (pyth_lq s4a2, 16 steps, 8 control points) reach the same optimum: first
+    action within 2e-3 of the action range, optimal costs within 1e-4; the collocation solution satisfies its dynamics."""
+    from gops_amd.create_pkg.create_env_model import create_env_model
+    from gops_amd.sys_simulator.opt_controller import OptController
+    model = create_env_model("pyth_lq", lq_config="s4a2", use_gpu=True)
+    x = np.array([1.0, -0.4, 0.7, 0.3], dtype=np.float32)
+    col = OptController(model, num_pred_step=16, ctrl_interval=2, gamma=1.0, minimize_options={"maxiter": 300, "ftol": 1e-10})
+    sho = OptController(model, num_pred_step=16, ctrl_interval=2, gamma=1.0, minimize_options={"maxiter": 300}, mode="shooting")
+    u_col, u_sho = col(x), sho(x)
+    res = col._trans_constraint_fcn(col.last_result.x, x, {})
+    assert np.abs(res).max() < 1e-4, np.abs(res).max()
+    rng_a = col.bounds.ub[:2] - col.bounds.lb[:2]
+    assert np.all(np.abs(u_col - u_sho) < 2e-3 * rng_a), (u_col, u_sho)
+    assert abs(col.last_result.fun - sho.last_result.fun) <= 1e-4 * max(1.0, abs(sho.last_result.fun)), (col.last_result.fun, sho.last_result.fun)
+    # warm start keeps the (action, state) layout: shifted by one control point
+    assert col.initial_guess.shape == (8 * 6,) and np.allclose(col.initial_guess[:6], col.last_result.x[6:12])
 
 
 @pytest.mark.gpu

@@ -7,10 +7,10 @@ Reference: gops/algorithm/spil.py (ApproxContainer :32-66, SPIL :69-270).  Every
 * policy improvement (:214-251): ascend `w_r sum_t gamma^t r_t + sum_k w_c[k] prod_t Phi(c_tk)` through policy and
   model (no terminal value), with the weights from the PI(D) multiplier rule on `chance_thre - safe_prob` (:253-270,
   host arithmetic, kept verbatim).
-The model must have constraint outputs: the GOPS_ENV_VEH3DOF_SURR kernels (pyth_veh3dofconti_surrcstr / _detour) return
-the Phi-products and safe flags next to v_pi (`GopsRolloutOut.constraint_prods`) and take d(loss)/d(product) * product
-into the backward sweep (`GopsRolloutIn.grad_constraint_prod`).  (`example_train/spil/spil_mlp_veh3dofconti_surrcstr_
-offserial.py`; the mobilerobot / errcstr models of the other SPIL examples are not built.)
+The model must have constraint outputs: the kernels of pyth_veh3dofconti_surrcstr / _detour / _errcstr,
+pyth_veh2dofconti_errcstr and pyth_mobilerobot return the Phi-products and safe flags next to v_pi
+(`GopsRolloutOut.constraint_prods`) and take d(loss)/d(product) * product into the backward sweep
+(`GopsRolloutIn.grad_constraint_prod`) - every script under example_train/spil/.
 """
 __all__ = ["SPIL"]
 
@@ -85,7 +85,8 @@ class SPIL(AlgorithmBase):
         if ro is None:
             env = self.envmodel.hip_env(nets.policy.act_low_lim.cpu().numpy(), nets.policy.act_high_lim.cpu().numpy())
             if not hb.has_constraints(env):
-                raise RuntimeError("SPIL needs a model with constraint outputs (pyth_veh3dofconti_surrcstr / _detour / _errcstr)")
+                raise RuntimeError("SPIL needs a model with constraint outputs (pyth_veh3dofconti_surrcstr / _detour / _errcstr, "
+                                   "pyth_veh2dofconti_errcstr, pyth_mobilerobot)")
             if env.n_constraint != self.n_constraint:
                 raise RuntimeError(f"constraint_dim = {self.n_constraint}, but the model has {env.n_constraint} constraints")
             ro = hb.Rollout(env, pol, batch=batch, horizon=self.forward_step, gamma=self.gamma, finite_horizon=False,

@@ -79,7 +79,7 @@ class WrappedEnvModel:
             raise RuntimeError("env_model.forward runs on the MI355X only (tensors must be on 'cuda'); "
                                "there is no CPU fallback in gops_amd")
         f = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
-        dev_info = {k: f(info[k]) for k in ("state", "ref_points", "path_num", "u_num", "ref_time", "surr_state")
+        dev_info = {k: f(info[k]) for k in ("state", "ref_points", "path_num", "u_num", "ref_time", "surr_state", "noise")
                     if isinstance(info, dict) and k in info and info[k] is not None}
         nobs, rew, ndone, ninfo = hb.env_step(self.hip_env(), f(obs), f(action), f(done), dev_info)
         if "constraint" not in ninfo:

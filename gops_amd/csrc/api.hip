@@ -182,7 +182,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     memset(&p, 0, sizeof(p));
     const GopsEnv& e = desc.env;
     if (desc.batch < 1 || desc.horizon < 1 || desc.horizon > GOPS_MAX_HORIZON) return GOPS_ERR_BAD_ARG;
-    if (e.kind < GOPS_ENV_NONE || e.kind > GOPS_ENV_VEH2DOF) return GOPS_ERR_BAD_ARG;
+    if (e.kind < GOPS_ENV_NONE || e.kind > GOPS_ENV_MOBILEROBOT) return GOPS_ERR_BAD_ARG;
     if (e.obs_dim < 1 || e.data_env) return GOPS_ERR_BAD_ARG;   // data-env semantics exist for gops_env_step only
     const int pol_out = (e.kind == GOPS_ENV_NONE) ? 1 : e.act_dim;
     if (desc.dtype != GOPS_DTYPE_F32 && desc.dtype != GOPS_DTYPE_F16) return GOPS_ERR_BAD_ARG;
@@ -200,6 +200,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     if (e.kind == GOPS_ENV_PENDULUM && (e.obs_dim != 3 || e.act_dim != 1)) return GOPS_ERR_BAD_ARG;
     if (e.kind == GOPS_ENV_VEH2DOF && (e.act_dim != 1 || e.pre_horizon < 1 || e.obs_dim != 4 + e.pre_horizon || e.clip_obs ||
                                         (e.cstr_err && e.n_constraint != 1))) return GOPS_ERR_BAD_ARG;
+    if (e.kind == GOPS_ENV_MOBILEROBOT && (e.obs_dim != MOB_OBS || e.act_dim != 2 || e.n_constraint != 1 || e.scale_obs)) return GOPS_ERR_BAD_ARG;
     if (e.kind >= GOPS_ENV_CARTPOLE && f16) return GOPS_ERR_UNSUPPORTED;   // the half-precision kernels are built for the BASELINE envs
     if (e.kind == GOPS_ENV_LQ && (e.obs_dim > GOPS_MAX_LQ_STATE || e.act_dim > GOPS_MAX_ACT)) return GOPS_ERR_UNSUPPORTED;
     if (e.kind == GOPS_ENV_IDPENDULUM && (e.obs_dim != 6 || e.act_dim != 1 || e.clip_obs)) return GOPS_ERR_BAD_ARG;
@@ -213,7 +214,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
          (e.surr_penalty && (e.n_surr != 1 || e.n_constraint != 1)) ||
          desc.open_loop || desc.dtype != GOPS_DTYPE_F32))
         return GOPS_ERR_BAD_ARG;
-    if (e.clip_obs && e.obs_dim > 8) return GOPS_ERR_UNSUPPORTED;
+    if (e.clip_obs && e.obs_dim > (e.kind == GOPS_ENV_MOBILEROBOT ? GOPS_MAX_CLIP_OBS : 8)) return GOPS_ERR_UNSUPPORTED;
     if (e.repeat_num < 0 || e.repeat_num > GOPS_MAX_REPEAT) return GOPS_ERR_BAD_ARG;
     if (e.repeat_num > 1 && (f16 || (e.kind != GOPS_ENV_LQ && e.kind != GOPS_ENV_IDPENDULUM && e.kind != GOPS_ENV_CARTPOLE &&
                                      e.kind != GOPS_ENV_PENDULUM)))
@@ -405,7 +406,8 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     if (adj != nullptr) {   // gops_rollout_backward_adj / gops_mlp_backward_x: the EXT kernels
         const int k = desc.env.kind;
         if (p.tail || p.f16) return GOPS_ERR_UNSUPPORTED;   // (open loop: gops_rollout_backward_open_loop_adj)
-        if (k != GOPS_ENV_NONE && k != GOPS_ENV_LQ && k != GOPS_ENV_IDPENDULUM && k != GOPS_ENV_CARTPOLE && k != GOPS_ENV_PENDULUM)
+        if (k != GOPS_ENV_NONE && k != GOPS_ENV_LQ && k != GOPS_ENV_IDPENDULUM && k != GOPS_ENV_CARTPOLE && k != GOPS_ENV_PENDULUM &&
+            k != GOPS_ENV_MOBILEROBOT)
             return GOPS_ERR_UNSUPPORTED;
         p.ext = 1;
         p.adj_gfo = adj->grad_final_obs;
@@ -703,8 +705,10 @@ int gops_rollout_backward_open_loop_adj(const GopsRolloutDesc* desc, const GopsR
 
 int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream) {
     if (!env || !io || batch < 1) return GOPS_ERR_BAD_ARG;
-    if (env->kind < GOPS_ENV_LQ || env->kind > GOPS_ENV_VEH2DOF) return GOPS_ERR_BAD_ARG;
-    if (env->data_env && (env->kind == GOPS_ENV_PENDULUM || (env->kind == GOPS_ENV_VEH2DOF && env->cstr_err)))
+    if (env->kind < GOPS_ENV_LQ || env->kind > GOPS_ENV_MOBILEROBOT) return GOPS_ERR_BAD_ARG;
+    if (env->kind == GOPS_ENV_MOBILEROBOT &&
+        (env->obs_dim != MOB_OBS || env->act_dim != 2 || env->n_constraint != 1 || env->scale_obs || !io->constraint)) return GOPS_ERR_BAD_ARG;
+    if (env->data_env && (env->kind == GOPS_ENV_PENDULUM || env->kind == GOPS_ENV_MOBILEROBOT || (env->kind == GOPS_ENV_VEH2DOF && env->cstr_err)))
         return GOPS_ERR_UNSUPPORTED;   // these data envs are not restated
     if (!io->obs || !io->action || !io->next_obs || !io->reward || !io->next_done) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_VEH3DOF_SURR &&

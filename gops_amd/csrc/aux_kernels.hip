@@ -1338,6 +1338,19 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         }
         r = rs;
         for (int i = 0; i < 6; ++i) nob[i] = (dn && !env.scale_obs) ? ob[i] : obs_rescale(env, i, dn ? s0[i] : s[i]);
+    } else if (env.kind == GOPS_ENV_MOBILEROBOT) {
+        const MobConst MC = mob_const();
+        float x[MOB_OBS], xn[MOB_OBS], c;
+        for (int i = 0; i < MOB_OBS; ++i) x[i] = ob[i];
+        const float nv = io.noise != nullptr ? io.noise[(size_t)b * 2 + 0] : 0.f;
+        const float nw = io.noise != nullptr ? io.noise[(size_t)b * 2 + 1] : 0.f;
+        MobStep w;
+        mob_forward(MC, x, u[0], u[1], nv, nw, xn, r, c, done_m, w);
+        io.constraint[b] = c;   // of the model's new state, whatever `done` says
+        for (int i = 0; i < MOB_OBS; ++i) {
+            const float v = dn ? x[i] : xn[i];
+            nob[i] = env.clip_obs ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
+        }
     } else if (env.kind == GOPS_ENV_VEH2DOF) {
         const Veh2Const C2 = veh2_const();
         const int P = env.pre_horizon;

@@ -9,6 +9,7 @@
 #define NTHREADS 256      // 4 wavefronts of 64
 #define DW_SC_HOST 32     // samples per staged chunk of the dW GEMM (== DW_SC in aux_kernels.hip)
 #define DW_OUT_SPLITS 1024  // sample splits of the output-layer weight gradient
+#define MOB_OBS 13        // pyth_mobilerobot: observation = state columns
 #define ENV_STASH 16      // floats of per-(t,b) env stash: [0..3] abar, [4] done_t, [5..10] state_t, [12..15] veh3dof: sin, cos of the heading before / after the step
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

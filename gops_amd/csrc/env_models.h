@@ -258,6 +258,117 @@ __device__ __forceinline__ bool idp_done(const IdpConst& C, const float* s) {
     return (tip_y <= 1.0f) || (fabsf(s[0]) >= 15.f);
 }
 
+// ================================ pyth_mobilerobot ============================================
+// gops/env/env_ocp/env_model/pyth_mobilerobot_model.py:24-213.  State = observation, 13 columns:
+//   [0..4] ego (x, y, theta, v, w)   [5..7] tracking errors (e_y, e_theta, e_v) of the NEW ego state   [8..12] obstacle (x, y, theta, v, w)
+// Robot.f_xu (:129-181), T = 0.2:  dv = clamp(v_cmd - v, +-1.8 T), dw = clamp(w_cmd - w, +-0.8 T),
+//   vc = clamp(v + dv, +-0.4) + 0.5 n_v,  wc = clamp(w + dw, +-pi/2) + 0.5 n_w,  (x, y, theta)' = (x + T cos(theta) vc, y + T sin(theta) vc, theta + T wc),
+//   (v, w)' = (vc, wc).  The ego is driven by the action with n = 0; the obstacle by ITS OWN (v, w) as commands (dv = dw = 0 with
+//   unit derivative through `v + dv`) and the caller's draws n ~ N(0, 0.03), N(0, 0.02).
+// The reference path is y = 0 sin(x / 3), phi = arctan(0 cos(x / 3)) (:199-213): tracking errors (y', theta', v' - 0.3).
+// constraint = (0.37 + 0.37 + 0.15) - |obstacle' - ego'| (:84-95); reward = -1.4 e_y^2 - e_theta^2 - 16 e_v^2 - 0.2 a_0^2 - 0.5 a_1^2 (:98-104);
+// done = x' < -2 | |y'| > 4 | constraint > 0.15 (:116-121).  Clamp derivatives as torch.clamp: 1 on the closed interval.
+struct MobConst { float T, dv_max, dw_max, v_max, w_max, safe_dis, margin; };
+__device__ __forceinline__ MobConst mob_const() {
+    MobConst c;
+    c.T = 0.2f;
+    c.dv_max = (float)(1.8 * 0.2);
+    c.dw_max = (float)(0.8 * 0.2);
+    c.v_max = 0.4f;
+    c.w_max = (float)(3.14159265358979323846 / 2);
+    c.safe_dis = (float)(0.74 / 2 + 0.74 / 2 + 0.15);
+    c.margin = 0.15f;
+    return c;
+}
+
+struct MobStep {   // intermediates shared by forward and adjoint
+    float sth, cth, vc, wc;        // ego: sin / cos of the heading, saturated commands
+    float soth, coth, ovc, owc;    // obstacle
+    float dx, dy, dist;            // obstacle' - ego'
+    bool m_dv, m_vc, m_dw, m_wc, m_ov, m_ow;   // clamp pass-through masks
+};
+
+__device__ __forceinline__ bool mob_inside(float v, float lim) { return v >= -lim && v <= lim; }
+
+__device__ __forceinline__ void mob_forward(const MobConst& C, const float* x, float a0, float a1, float nv, float nw,
+                                            float* xn, float& r, float& c, bool& done, MobStep& w) {
+    const float dvr = a0 - x[3], dwr = a1 - x[4];
+    const float dv = clampf(dvr, -C.dv_max, C.dv_max), dw = clampf(dwr, -C.dw_max, C.dw_max);
+    const float vs = x[3] + dv, ws = x[4] + dw;
+    w.m_dv = mob_inside(dvr, C.dv_max); w.m_dw = mob_inside(dwr, C.dw_max);
+    w.m_vc = mob_inside(vs, C.v_max);   w.m_wc = mob_inside(ws, C.w_max);
+    w.vc = clampf(vs, -C.v_max, C.v_max);
+    w.wc = clampf(ws, -C.w_max, C.w_max);
+    sincosf(x[2], &w.sth, &w.cth);
+    xn[0] = x[0] + (C.T * w.cth) * w.vc;
+    xn[1] = x[1] + (C.T * w.sth) * w.vc;
+    xn[2] = x[2] + C.T * w.wc;
+    xn[3] = w.vc;
+    xn[4] = w.wc;
+    xn[5] = xn[1];
+    xn[6] = xn[2];
+    xn[7] = xn[3] - 0.3f;
+    w.m_ov = mob_inside(x[11], C.v_max); w.m_ow = mob_inside(x[12], C.w_max);
+    w.ovc = clampf(x[11], -C.v_max, C.v_max) + nv * 0.5f;
+    w.owc = clampf(x[12], -C.w_max, C.w_max) + nw * 0.5f;
+    sincosf(x[10], &w.soth, &w.coth);
+    xn[8] = x[8] + (C.T * w.coth) * w.ovc;
+    xn[9] = x[9] + (C.T * w.soth) * w.ovc;
+    xn[10] = x[10] + C.T * w.owc;
+    xn[11] = w.ovc;
+    xn[12] = w.owc;
+    w.dx = xn[8] - xn[0];
+    w.dy = xn[9] - xn[1];
+    w.dist = sqrtf(w.dx * w.dx + w.dy * w.dy);
+    c = C.safe_dis - w.dist;
+    const float r_track = -1.4f * (xn[5] * xn[5]) - 1.f * (xn[6] * xn[6]) - 16.f * (xn[7] * xn[7]);
+    const float r_act = -0.2f * (a0 * a0) - 0.5f * (a1 * a1);
+    r = r_track + r_act;
+    done = (xn[0] < -2.f) || (fabsf(xn[1]) > 4.f) || (c > C.margin);
+}
+
+// gx += (d xn / d x)^T gxn + g_r d r / d x + g_c d c / d x;  ga = (d . / d a)^T (...)   (gx carries what the caller put there)
+__device__ __forceinline__ void mob_backward(const MobConst& C, const float* x, float a0, float a1, float nv, float nw,
+                                             const float* gxn_in, float g_r, float g_c, float* gx, float* ga) {
+    float xn[MOB_OBS], r, c;
+    bool done;
+    MobStep w;
+    mob_forward(C, x, a0, a1, nv, nw, xn, r, c, done, w);
+    float g[MOB_OBS];
+#pragma unroll
+    for (int i = 0; i < MOB_OBS; ++i) g[i] = gxn_in[i];
+    // constraint: c = safe_dis - sqrt(dx^2 + dy^2)
+    const float inv = w.dist > 0.f ? 1.f / w.dist : 0.f;
+    const float ux = w.dx * inv, uy = w.dy * inv;
+    g[0] += g_c * ux;  g[1] += g_c * uy;
+    g[8] -= g_c * ux;  g[9] -= g_c * uy;
+    // reward on the new tracking errors, tracking errors on the new ego state
+    g[5] += g_r * (-2.8f * xn[5]);
+    g[6] += g_r * (-2.f * xn[6]);
+    g[7] += g_r * (-32.f * xn[7]);
+    g[1] += g[5];  g[2] += g[6];  g[3] += g[7];
+    // ego
+    const float gvc = g[3] + C.T * (w.cth * g[0] + w.sth * g[1]);
+    const float gwc = g[4] + C.T * g[2];
+    gx[0] += g[0];
+    gx[1] += g[1];
+    gx[2] += g[2] + C.T * w.vc * (-w.sth * g[0] + w.cth * g[1]);
+    const float gvs = w.m_vc ? gvc : 0.f, gws = w.m_wc ? gwc : 0.f;
+    const float gdv = w.m_dv ? gvs : 0.f, gdw = w.m_dw ? gws : 0.f;
+    gx[3] += gvs - gdv;
+    gx[4] += gws - gdw;
+    ga[0] = gdv + g_r * (-0.4f * a0);
+    ga[1] = gdw + g_r * (-1.f * a1);
+    // obstacle
+    const float govc = g[11] + C.T * (w.coth * g[8] + w.soth * g[9]);
+    const float gowc = g[12] + C.T * g[10];
+    gx[8] += g[8];
+    gx[9] += g[9];
+    gx[10] += g[10] + C.T * w.ovc * (-w.soth * g[8] + w.coth * g[9]);
+    gx[11] += w.m_ov ? govc : 0.f;
+    gx[12] += w.m_ow ? gowc : 0.f;
+}
+
 // ================================ pyth_veh2dofconti ===========================================
 // gops/env/env_ocp/env_model/pyth_veh2dofconti_model.py:24-174 (vehicle parameters pyth_veh2dofconti.py:24-34, u = 5):
 // linear 2-DOF lateral dynamics stepped in the ego frame (y = phi = 0), then placed back:

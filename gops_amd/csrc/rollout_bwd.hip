@@ -338,6 +338,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     constexpr bool VEH = (ENV == GOPS_ENV_VEH3DOFCONTI) || SURR;
     constexpr bool VEH2 = (ENV == GOPS_ENV_VEH2DOF);
     constexpr bool REF = VEH || VEH2;
+    constexpr bool CSTR = SURR || VEH2 || (ENV == GOPS_ENV_MOBILEROBOT);   // models with constraint outputs
     const int ldx = p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* G = smem;                    // [TB][ldx] adjoint of obs_{t+1}
     float* da = G + TB * ldx;           // [TB][ldh]
@@ -433,12 +434,12 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     float gv = (tid < nvalid) ? gptr(p.grad_v)[b0 + tid] : 0.f;
     if constexpr (F16) gv *= f16_grad_scale(gptr(p.gscale)[0]);
     float gc_ext = 0.f, gc_lin = 0.f, gc_int = 0.f;   // SURR: d(loss)/d(constraint sums) of trajectory tid
-    if ((SURR || ENV == GOPS_ENV_VEH2DOF) && tid < nvalid && p.in.grad_constraint != nullptr) {
+    if (CSTR && tid < nvalid && p.in.grad_constraint != nullptr) {
         const GLOBAL_AS float* gcp = gptr(p.in.grad_constraint) + b0 + tid;
         gc_ext = gcp[0]; gc_lin = gcp[(size_t)p.B]; gc_int = gcp[(size_t)2 * p.B];
     }
     float gc_mul[GOPS_MAX_CONSTRAINT] = {0.f, 0.f, 0.f};   // SPIL: d(loss)/d(P_k) * P_k of trajectory tid
-    if ((SURR || ENV == GOPS_ENV_VEH2DOF) && tid < nvalid && p.in.grad_constraint_prod != nullptr) {
+    if (CSTR && tid < nvalid && p.in.grad_constraint_prod != nullptr) {
 #pragma unroll
         for (int k = 0; k < GOPS_MAX_CONSTRAINT; ++k)
             if (k < p.env.n_constraint) gc_mul[k] = gptr(p.in.grad_constraint_prod)[(size_t)k * p.B + b0 + tid];
@@ -791,6 +792,67 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
 #pragma unroll
                 for (int a = 0; a < GOPS_MAX_ACT; ++a)
                     s_gy[m * 4 + a] = (a < A) ? (p.open_loop == 2 ? gu[a] : wrap_action_bwd(p.env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a])) : 0.f;
+            }
+        } else if (ENV == GOPS_ENV_MOBILEROBOT) {
+            if (tid < TB) {
+                const int m = tid;
+                const MobConst MC = mob_const();
+                float th[2] = {0.f, 0.f}, dflag = 1.f, nv = 0.f, nw = 0.f;
+                float x[MOB_OBS];
+#pragma unroll
+                for (int i = 0; i < MOB_OBS; ++i) x[i] = 0.f;
+                if (m < nvalid) {
+                    const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
+                    const f32x4 e0 = er[0], e1 = er[1];
+                    th[0] = e0[0]; th[1] = e0[1]; dflag = e1[0];
+#pragma unroll
+                    for (int i = 0; i < MOB_OBS; ++i) x[i] = x_col(row0, m, i);
+                    if (p.in.noise != nullptr) {
+                        const GLOBAL_AS float* nz = gptr(p.in.noise) + ((size_t)t * p.B + b0 + m) * 2;
+                        nv = nz[0]; nw = nz[1];
+                    }
+                }
+                float abar[2], u[2], sc[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    sc[a] = (p.env.policy_high[a] - p.env.policy_low[a]) / 2.f;
+                    abar[a] = sc[a] * th[a] + (p.env.policy_high[a] + p.env.policy_low[a]) / 2.f;
+                    u[a] = p.open_loop == 2 ? th[a] : wrap_action(p.env, a, abar[a]);
+                }
+                const bool dn = dflag != 0.f;
+                const float g_rm = dn ? 0.f : g_r;
+                float xn[MOB_OBS], rdummy, c;
+                bool ddummy;
+                MobStep w;
+                mob_forward(MC, x, u[0], u[1], nv, nw, xn, rdummy, c, ddummy, w);
+                float gxn[MOB_OBS], gx[MOB_OBS];
+#pragma unroll
+                for (int i = 0; i < MOB_OBS; ++i) {
+                    float gi = G[m * ldx + i];
+                    if (p.env.clip_obs) {   // ClipObservation on the (masked) next observation
+                        const float pre = dn ? x[i] : xn[i];
+                        if (!(pre >= p.env.obs_low[i] && pre <= p.env.obs_high[i])) gi = 0.f;
+                    }
+                    gxn[i] = dn ? 0.f : gi;   // MaskAtDone: a finished trajectory's observation is frozen ...
+                    gx[i] = dn ? gi : 0.f;
+                }
+                float gck = 0.f;               // ... but info["constraint"] still comes from the model's step
+                if (m < nvalid) {
+                    gck = gc_ext * 2.f * fmaxf(c, 0.f) + (c > 0.f ? gc_lin : 0.f);
+                    if (c < 0.f) gck += gc_int * (-1.f / (-c + 1e-8f));
+                    gck *= p.gpow[t];
+                    float dlog;
+                    (void)spil_phi(c, dlog);
+                    gck += gc_mul[0] * dlog;
+                }
+                float gu[2];
+                mob_backward(MC, x, u[0], u[1], nv, nw, gxn, g_rm, gck, gx, gu);
+#pragma unroll
+                for (int i = 0; i < MOB_OBS; ++i) G[m * ldx + i] = gx[i];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    s_gy[m * 4 + a] = p.open_loop == 2 ? gu[a] : wrap_action_bwd(p.env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a]);
+                s_gy[m * 4 + 2] = s_gy[m * 4 + 3] = 0.f;
             }
         } else if (ENV == GOPS_ENV_VEH2DOF) {
             if (tid < TB) {
@@ -1148,6 +1210,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
             case GOPS_ENV_IDPENDULUM: LAUNCH_BWD_EXT(GOPS_ENV_IDPENDULUM); break;
             case GOPS_ENV_CARTPOLE: LAUNCH_BWD_EXT(GOPS_ENV_CARTPOLE); break;
             case GOPS_ENV_PENDULUM: LAUNCH_BWD_EXT(GOPS_ENV_PENDULUM); break;
+            case GOPS_ENV_MOBILEROBOT: LAUNCH_BWD_EXT(GOPS_ENV_MOBILEROBOT); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
@@ -1203,6 +1266,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
         case GOPS_ENV_CARTPOLE: LAUNCH_BWD(GOPS_ENV_CARTPOLE, 0, 0); break;
         case GOPS_ENV_PENDULUM: LAUNCH_BWD(GOPS_ENV_PENDULUM, 0, 0); break;
         case GOPS_ENV_VEH2DOF: LAUNCH_BWD(GOPS_ENV_VEH2DOF, 0, 0); break;
+        case GOPS_ENV_MOBILEROBOT: LAUNCH_BWD(GOPS_ENV_MOBILEROBOT, 0, 0); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -273,6 +273,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     constexpr bool VEH = (ENV == GOPS_ENV_VEH3DOFCONTI) || SURR;
     constexpr bool VEH2 = (ENV == GOPS_ENV_VEH2DOF);   // 2-DOF lateral model: state [4], reference points (y, phi)
     constexpr bool REF = VEH || VEH2;                   // models with a reference-trajectory table
+    constexpr bool MOB = (ENV == GOPS_ENV_MOBILEROBOT); // obs == state [13], one constraint on the new state
+    constexpr bool CSTR = SURR || VEH2 || MOB;          // models with constraint outputs
     // leading dimensions are compile-time constants in the register-stationary variants
     const int ldx = p.ldx, ldh = (SK1 > 0) ? 260 : p.ldh;
     float* xs = smem;                       // [TB][ldx]  current observation (+ time column)
@@ -556,6 +558,40 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                     for (int i = 0; i < 6; ++i) xs[m * ldx + i] = obs_rescale(p.env, i, s_in[i]);
                 }
             }
+        } else if (ENV == GOPS_ENV_MOBILEROBOT) {
+            if (tid < TB) {   // obs == state; MaskAtDone freezes the observation, ClipObservation clips the result, the constraint is not masked
+                const int m = tid;
+                const MobConst MC = mob_const();
+                float x[MOB_OBS], xn[MOB_OBS];
+#pragma unroll
+                for (int i = 0; i < MOB_OBS; ++i) x[i] = xs[m * ldx + i];
+                float nv = 0.f, nw = 0.f;
+                if (p.in.noise != nullptr && m < nvalid) {
+                    const GLOBAL_AS float* nz = gptr(p.in.noise) + ((size_t)t * p.B + b0 + m) * 2;
+                    nv = nz[0]; nw = nz[1];
+                }
+                float c;
+                MobStep w;
+                mob_forward(MC, x, s_act[m * 4 + 0], s_act[m * 4 + 1], nv, nw, xn, r, c, done_m, w);
+                if (m < nvalid) {
+                    const float cp = fmaxf(c, 0.f), cm = fminf(c, 0.f);
+                    c_ext += cp * cp * p.gpow[t];
+                    c_lin += cp * p.gpow[t];
+                    c_int += logf(-cm + 1e-8f) * p.gpow[t];
+                    if (!(c < 0.f)) c_feas = 0.f;
+                    float dlog;
+                    c_mul[0] *= spil_phi(c, dlog);
+                    if (!(c <= 0.f)) c_safe[0] = 0.f;
+                }
+                const bool frozen = s_done[m] != 0.f;
+                if (!frozen || p.env.clip_obs) {
+#pragma unroll
+                    for (int i = 0; i < MOB_OBS; ++i) {
+                        const float v = frozen ? x[i] : xn[i];
+                        xs[m * ldx + i] = p.env.clip_obs ? clampf(v, p.env.obs_low[i], p.env.obs_high[i]) : v;
+                    }
+                }
+            }
         } else if (ENV == GOPS_ENV_VEH2DOF) {
             if (tid < TB) {
                 const int m = tid, P = p.env.pre_horizon;
@@ -743,6 +779,10 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             dl = (fabsf(o[0]) > 10.f) || (fabsf(o[1]) > 10.f) || (fabsf(o[2]) > pi);
         } else if (ENV == GOPS_ENV_VEH2DOF) {
             dl = (fabsf(o[0]) > 2.f) || (fabsf(o[1]) > pi);
+        } else if (ENV == GOPS_ENV_MOBILEROBOT) {
+            const MobConst MC = mob_const();
+            const float dx = o[8] - o[0], dy = o[9] - o[1];
+            dl = (o[0] < -2.f) || (fabsf(o[1]) > 4.f) || (MC.safe_dis - sqrtf(dx * dx + dy * dy) > MC.margin);
         }
         s_done[tid] = dl ? 1.f : 0.f;
     }
@@ -773,11 +813,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         if (tid < TB) v_acc += ((p.tail_unmasked ? 1.f : 1.f - s_done[tid]) * p.gpow[p.H]) * s_th[tid * 4];
     }
 
-    if ((SURR || VEH2) && tid < nvalid && p.out.constraint_sums != nullptr) {
+    if (CSTR && tid < nvalid && p.out.constraint_sums != nullptr) {
         GLOBAL_AS float* cs = gptr(p.out.constraint_sums) + b0 + tid;
         cs[0] = c_ext; cs[(size_t)p.B] = c_lin; cs[(size_t)2 * p.B] = c_int; cs[(size_t)3 * p.B] = c_feas;
     }
-    if ((SURR || VEH2) && tid < nvalid && p.out.constraint_prods != nullptr) {
+    if (CSTR && tid < nvalid && p.out.constraint_prods != nullptr) {
         GLOBAL_AS float* cp = gptr(p.out.constraint_prods) + b0 + tid;
         const int nc = p.env.n_constraint;
 #pragma unroll
@@ -974,6 +1014,7 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
         case GOPS_ENV_CARTPOLE: LAUNCH_FWD(GOPS_ENV_CARTPOLE, 0, 0); break;
         case GOPS_ENV_PENDULUM: LAUNCH_FWD(GOPS_ENV_PENDULUM, 0, 0); break;
         case GOPS_ENV_VEH2DOF: LAUNCH_FWD(GOPS_ENV_VEH2DOF, 0, 0); break;
+        case GOPS_ENV_MOBILEROBOT: LAUNCH_FWD(GOPS_ENV_MOBILEROBOT, 0, 0); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

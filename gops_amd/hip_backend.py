@@ -15,7 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOPS_HIP_LIB") or os.path.join(_HERE, "libgops_hip.so")
 
 MAX_LAYERS, MAX_ACT, MAX_LQ, TILE = 5, 4, 6, 16
-ENV_NONE, ENV_LQ, ENV_IDP, ENV_VEH, ENV_VEH_SURR, ENV_CARTPOLE, ENV_PENDULUM, ENV_VEH2DOF = 0, 1, 2, 3, 4, 5, 6, 7
+ENV_NONE, ENV_LQ, ENV_IDP, ENV_VEH, ENV_VEH_SURR, ENV_CARTPOLE, ENV_PENDULUM, ENV_VEH2DOF, ENV_MOBILEROBOT = 0, 1, 2, 3, 4, 5, 6, 7, 8
+MAX_CLIP_OBS = 16
+# std of the obstacle robot's per-step (v, w) noise draws (pyth_mobilerobot_model.py:141-147, std_type["obs"])
+MOBILEROBOT_NOISE_STD = (0.03, 0.02)
 MAX_SURR = 4
 MAX_REPEAT = 8   # GOPS_MAX_REPEAT
 ACT_IDS = {"linear": 0, "relu": 1, "elu": 2, "gelu": 3, "selu": 4, "sigmoid": 5, "tanh": 6}
@@ -50,7 +53,7 @@ class GopsEnv(C.Structure):
                 ("min_action", C.c_float * MAX_ACT), ("max_action", C.c_float * MAX_ACT),
                 ("act_low", C.c_float * MAX_ACT), ("act_high", C.c_float * MAX_ACT),
                 ("policy_low", C.c_float * MAX_ACT), ("policy_high", C.c_float * MAX_ACT),
-                ("clip_obs", C.c_int32), ("obs_low", C.c_float * 8), ("obs_high", C.c_float * 8),
+                ("clip_obs", C.c_int32), ("obs_low", C.c_float * MAX_CLIP_OBS), ("obs_high", C.c_float * MAX_CLIP_OBS),
                 ("shaping", C.c_int32), ("reward_scale", C.c_float), ("reward_shift", C.c_float),
                 ("lq_inv_IA", C.c_float * (MAX_LQ * MAX_LQ)), ("lq_B", C.c_float * (MAX_LQ * MAX_ACT)),
                 ("lq_Q", C.c_float * MAX_LQ), ("lq_R", C.c_float * MAX_ACT),
@@ -73,7 +76,7 @@ class GopsRolloutDesc(C.Structure):
 class GopsRolloutIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "done", "state", "ref_points", "path_num", "u_num",
                                           "ref_time", "head_pre", "surr_state", "grad_constraint", "grad_constraint_prod",
-                                          "ref_appended")]
+                                          "ref_appended", "noise")]
 
 
 class GopsRolloutOut(C.Structure):
@@ -99,7 +102,7 @@ class GopsStepIO(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "action", "done", "state", "ref_points", "path_num",
                                           "u_num", "ref_time", "next_obs", "reward", "next_done",
                                           "next_state", "next_ref_points", "next_ref_time",
-                                          "surr_state", "next_surr_state", "constraint", "ref_appended")]
+                                          "surr_state", "next_surr_state", "constraint", "ref_appended", "noise")]
 
 
 _lib = None
@@ -226,7 +229,7 @@ def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_ac
              reward_scale: Optional[float] = None, reward_shift: Optional[float] = None,
              lq: Optional[Dict] = None, data_env: bool = False, surr: Optional[Dict] = None,
              obs_scale=None, obs_shift=None, ref_c=None, repeat_num: Optional[int] = None, sum_reward: bool = True,
-             mask_at_done: bool = True) -> GopsEnv:
+             mask_at_done: bool = True, n_constraint: Optional[int] = None) -> GopsEnv:
     """Constants of the wrapped env model (create_env_model.py:86-128) as a C struct.  `data_env=True` (for
     `env_step` only): the DATA environment's termination tests / terminal penalty instead of the model's; obs_low /
     obs_high are then the data env's state bounds (pyth_lq) and are NOT applied as a clip."""
@@ -262,6 +265,8 @@ def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_ac
             _fill(e.err_tol, [float(v) for v in surr["err_tol"]])
         _fill(e.reward_w, list(surr["reward_w"]) + [0.0] * (8 - len(surr["reward_w"])))
     e.kind, e.obs_dim, e.act_dim, e.pre_horizon = kind, obs_dim, act_dim, pre_horizon
+    if n_constraint is not None:
+        e.n_constraint = int(n_constraint)
     A = act_dim
 
     def bc(v):
@@ -278,8 +283,9 @@ def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_ac
         hi = torch.as_tensor(obs_high, dtype=torch.float32).reshape(-1)
         finite = bool(torch.isfinite(lo).any() or torch.isfinite(hi).any())
         if finite:
-            if obs_dim > 8:
-                raise RuntimeError("finite observation bounds are only supported for obs_dim <= 8 (pyth_lq)")
+            if obs_dim > (MAX_CLIP_OBS if kind == ENV_MOBILEROBOT else 8):
+                raise RuntimeError("finite observation bounds are only supported for obs_dim <= 8 (pyth_lq, gym models) "
+                                   "and for pyth_mobilerobot")
             _fill(e.obs_low, lo.tolist()); _fill(e.obs_high, hi.tolist())
     e.clip_obs = 1 if finite else 0
     e.shaping = 1 if (reward_scale is not None or reward_shift is not None) else 0
@@ -299,7 +305,13 @@ def make_env(kind: int, obs_dim: int, act_dim: int, *, act_low, act_high, min_ac
 
 def has_constraints(env: GopsEnv) -> bool:
     """Models whose rollout returns constraint sums / products (and whose env step fills info["constraint"])."""
-    return env.kind == ENV_VEH_SURR or (env.kind == ENV_VEH2DOF and env.cstr_err != 0)
+    return env.kind in (ENV_VEH_SURR, ENV_MOBILEROBOT) or (env.kind == ENV_VEH2DOF and env.cstr_err != 0)
+
+
+def mobilerobot_noise(shape, device) -> torch.Tensor:
+    """The obstacle robot's noise draws of `shape` = (..., 2): N(0, 0.03) for v, N(0, 0.02) for w - what
+    np.random.normal hands Robot.f_xu(.., "obs") every step (pyth_mobilerobot_model.py:141-167), drawn on the device."""
+    return torch.randn(*shape, dtype=torch.float32, device=device) * torch.tensor(MOBILEROBOT_NOISE_STD, dtype=torch.float32, device=device)
 
 
 class Rollout:
@@ -363,7 +375,14 @@ class Rollout:
             i.surr_state = _ptr(data.get("surr_state"))   # (None for the errcstr model: no surrounding vehicles)
         # bit-parity mode (GopsRolloutIn.ref_appended): the reference's own appended reference points [B, H, 4]
         i.ref_appended = _ptr(data.get("ref_appended"))
-        self._keep = dict(data)   # the kernels (and a later backward) read these tensors: keep them alive
+        self._keep = dict(data)
+        if d.env.kind == ENV_MOBILEROBOT:   # the obstacle's draws of this rollout [H, B, 2] (a caller may hand in its own)
+            noise = data.get("noise")
+            if noise is None:
+                noise = mobilerobot_noise((H, B, 2), self.device)
+            assert tuple(noise.shape) == (H, B, 2) and noise.dtype == torch.float32 and noise.is_contiguous()
+            self._keep["noise"] = noise
+            i.noise = _ptr(noise)   # the kernels (and a later backward) read these tensors: keep them alive
         out = GopsRolloutOut()
         res = {"v_pi": torch.empty(B, dtype=torch.float32, device=self.device)}
         out.v_pi = _ptr(res["v_pi"])
@@ -518,6 +537,11 @@ def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Ten
         io.next_state, io.next_ref_points = _ptr(ninfo["state"]), _ptr(ninfo["ref_points"])
         io.next_ref_time = _ptr(ninfo["ref_time"])
         io.ref_appended = _ptr(info.get("ref_appended"))
+    if env.kind == ENV_MOBILEROBOT:   # info["noise"] [B, 2]: this step's obstacle draws (drawn here unless handed in)
+        noise = (info or {}).get("noise")
+        if noise is None:
+            noise = mobilerobot_noise((B, 2), obs.device)
+        io.noise = _ptr(noise)
     if has_constraints(env) and env.n_surr == 0:
         ninfo["constraint"] = torch.empty(B, env.n_constraint, dtype=torch.float32, device=obs.device)
         io.constraint = _ptr(ninfo["constraint"])

@@ -76,6 +76,8 @@ class ReplayBuffer:
         rows = self._rows(n)
 
         def put(key, values):
+            if self.buf[key][0].numel() == 0:   # a zero-size slot (pyth_mobilerobot declares "constraint" with shape (0,)):
+                return                           # the reference's numpy buffer broadcasts the value into nothing
             host = torch.as_tensor(np.asarray(values, dtype=np.float32).reshape(_shape(n, tuple(self.buf[key].shape[1:]))))
             self.buf[key].index_copy_(0, rows, host.to(self.device, non_blocking=True))
 
@@ -95,7 +97,7 @@ class ReplayBuffer:
         n = next(iter(batch.values())).shape[0]
         rows = self._rows(n)
         for k, dst in self.buf.items():
-            if k in batch:
+            if k in batch and dst[0].numel() > 0:
                 dst.index_copy_(0, rows, batch[k].to(device=self.device, dtype=torch.float32).reshape(_shape(n, tuple(dst.shape[1:]))))
 
     def sample_batch(self, batch_size: int) -> dict:

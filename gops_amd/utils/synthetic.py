@@ -109,6 +109,8 @@ def obs_dim_of(cfg: Dict) -> int:
         return 4 + cfg["pre_horizon"]
     if cfg["env_id"] == "gym_pendulum":
         return 3
+    if cfg["env_id"] == "pyth_mobilerobot":
+        return 13
     if cfg["env_id"] in ("pyth_veh3dofconti", "pyth_veh3dofconti_errcstr"):
         return 6 + 4 * cfg["pre_horizon"]
     if cfg["env_id"] in _SURR_ENVS:
@@ -126,7 +128,7 @@ def n_surr_of(cfg: Dict) -> int:
 def act_dim_of(cfg: Dict) -> int:
     if cfg["env_id"] in ("pyth_idpendulum", "gym_cartpoleconti", "gym_pendulum", "pyth_veh2dofconti", "pyth_veh2dofconti_errcstr"):
         return 1
-    if cfg["env_id"] in ("pyth_veh3dofconti", "pyth_veh3dofconti_errcstr") or cfg["env_id"] in _SURR_ENVS:
+    if cfg["env_id"] in ("pyth_veh3dofconti", "pyth_veh3dofconti_errcstr", "pyth_mobilerobot") or cfg["env_id"] in _SURR_ENVS:
         return 2
     return _LQ_ACT_DIM[cfg.get("lq_config", "s4a2")]
 
@@ -155,6 +157,18 @@ def make_batch(cfg: Dict, seed: int, batch: int = None) -> Dict[str, torch.Tenso
         obs = np.concatenate((state[:, :2] - ref[:, 0], state[:, 2:], state[:, :1] - ref[:, 1:, 0]), axis=1).astype(np.float32)
         out.update(obs=obs, state=state, ref_points=ref, path_num=path_num.astype(np.float32),
                    u_num=u_num.astype(np.float32), ref_time=t0.astype(np.float32))
+    elif env_id == "pyth_mobilerobot":
+        # data env reset (pyth_mobilerobot.py:31-54,98-109): ego (x, y, theta, v, w) and obstacle uniform in the work space,
+        # tracking errors of the ego state; here the ego also turns (w != 0) and a third of the obstacles start within
+        # 0.6 .. 1.2 m of the ego, so that the safety constraint (0.89 m) and the collision test (0.74 m) are exercised
+        ego = rng.uniform([0.0, -1.0, -0.6, 0.0, -0.5], [2.7, 1.0, 0.6, 0.4, 0.5], size=(B, 5))
+        obst = rng.uniform([3.5, -3.0, np.pi / 2 - 0.3, 0.0, -0.3], [6.0, 3.0, np.pi / 2 + 0.3, 0.5, 0.3], size=(B, 5))
+        near = rng.uniform(size=B) < 0.35
+        ang, rad = rng.uniform(-np.pi, np.pi, size=B), rng.uniform(0.6, 1.2, size=B)
+        obst[:, 0] = np.where(near, ego[:, 0] + rad * np.cos(ang), obst[:, 0])
+        obst[:, 1] = np.where(near, ego[:, 1] + rad * np.sin(ang), obst[:, 1])
+        track = np.stack((ego[:, 1], ego[:, 2], ego[:, 3] - 0.3), axis=1)
+        out["obs"] = np.concatenate((ego, track, obst), axis=1).astype(np.float32)
     elif env_id == "gym_cartpoleconti":   # wide enough that some trajectories leave |x| <= 2.4 / |theta| <= 12 deg within a rollout
         h = np.array([2.3, 1.0, 0.2, 1.0], dtype=np.float32)
         out["obs"] = rng.uniform(-h, h, size=(B, 4)).astype(np.float32)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GOPS_HIP_ABI_VERSION 8
+#define GOPS_HIP_ABI_VERSION 9
 
 #define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
 #define GOPS_MAX_ACT 4      /* action dimensions */
@@ -62,10 +62,18 @@ enum { GOPS_ENV_NONE = 0, GOPS_ENV_LQ = 1, GOPS_ENV_IDPENDULUM = 2, GOPS_ENV_VEH
        /* pyth_veh2dofconti_model.py:24-174: lateral 2-DOF vehicle at constant speed tracking the reference path: state
           (y, phi, v, omega) [B,4], action steer, obs = (y - y_ref0, phi - phi_ref0, v, omega, y - y_ref_1 .. y - y_ref_P),
           info["ref_points"] [B, P+1, 2] = (y, phi) */
-       GOPS_ENV_VEH2DOF = 7 };
+       GOPS_ENV_VEH2DOF = 7,
+       /* pyth_mobilerobot_model.py:24-213 (the model of example_train/spil/spil_mlp_mobilerobot_{offserial,async}.py):
+          obs == state [B,13] = ego (x, y, theta, v, w), tracking errors (e_y, e_theta, e_v), one obstacle robot
+          (x, y, theta, v, w); action (v_cmd, w_cmd); dt = 0.2.  The ego follows its rate-limited, saturated commands, the
+          obstacle its own (v, w) plus the noise draws handed in through GopsRolloutIn.noise / GopsStepIO.noise;
+          info["constraint"] [B,1] = 0.89 - distance(obstacle', ego') of the NEW state (n_constraint = 1, unmasked);
+          done = x' < -2 | |y'| > 4 | constraint > 0.15.  fp32 only; ClipObservation over all 13 columns. */
+       GOPS_ENV_MOBILEROBOT = 8 };
 #define GOPS_MAX_SURR 4        /* surrounding vehicles */
 #define GOPS_MAX_CONSTRAINT 3  /* constraint outputs per step */
 #define GOPS_MAX_REPEAT 8      /* ActionRepeatModel: sub-steps per env step */
+#define GOPS_MAX_CLIP_OBS 16   /* observation columns ClipObservationModel can act on */
 
 /* hidden activations: gops/utils/common_utils.py:26-55 */
 enum { GOPS_ACT_LINEAR = 0, GOPS_ACT_RELU = 1, GOPS_ACT_ELU = 2, GOPS_ACT_GELU = 3,
@@ -112,7 +120,7 @@ typedef struct GopsEnv {
     float policy_low[GOPS_MAX_ACT], policy_high[GOPS_MAX_ACT];
     /* ClipObservationModel (clip_observation.py:38-40); +-inf = inactive */
     int32_t clip_obs;             /* 0: all bounds infinite (idpendulum, veh3dofconti) */
-    float obs_low[8], obs_high[8];
+    float obs_low[GOPS_MAX_CLIP_OBS], obs_high[GOPS_MAX_CLIP_OBS];
     /* ShapingRewardModel (shaping_reward.py:84-88), applied outside MaskAtDone */
     int32_t shaping;
     float reward_scale, reward_shift;
@@ -223,6 +231,10 @@ typedef struct GopsRolloutIn {
                                  Bit-parity mode: the reference's heading is a 1 ms finite difference in fp32 whose last-ulp
                                  behaviour depends on the host's libm; a caller that fills this tensor with the reference's own
                                  MultiRefTrajModel values gets observations identical to the reference's. */
+    const float* noise;       /* ABI v9, GOPS_ENV_MOBILEROBOT, or NULL (= zeros): [H, B, 2] the obstacle robot's N(0, 0.03) / N(0, 0.02)
+                                 draws of every rollout step, exactly what np.random.normal returns inside Robot.f_xu(.., "obs")
+                                 (pyth_mobilerobot_model.py:143-167; the model adds 0.5 x draw to the obstacle's v / w).  Must stay
+                                 valid until the backward call (d x' / d theta of the obstacle depends on it). */
 } GopsRolloutIn;
 
 typedef struct GopsRolloutOut {
@@ -231,14 +243,14 @@ typedef struct GopsRolloutOut {
     float* final_obs;         /* [B, obs_dim] or NULL */
     float* final_done;        /* [B] or NULL */
     float* final_state;       /* veh3dofconti [B,6] or NULL */
-    /* GOPS_ENV_VEH3DOF_SURR, or NULL: [4, B] discounted sums over the rollout of the UNMASKED info["constraint"] c_t
+    /* Models with constraint outputs (GOPS_ENV_VEH3DOF_SURR, _VEH2DOF with cstr_err, _MOBILEROBOT), or NULL: [4, B] discounted sums over the rollout of the UNMASKED info["constraint"] c_t
      * (the algorithms read it regardless of `done`):
      *   row 0  sum_t gamma^t sum_k max(c_tk, 0)^2            (fhadp_exterior.py:64, fhadp_interior.py:66)
      *   row 1  sum_t gamma^t sum_k max(c_tk, 0)              (fhadp_lagrangian.py:66)
      *   row 2  sum_t gamma^t sum_k log(-min(c_tk, 0) + 1e-8) (fhadp_interior.py:65)
      *   row 3  1 if every c_tk < 0 (feasible trajectory, fhadp_interior.py:71) else 0 */
     float* constraint_sums;
-    /* GOPS_ENV_VEH3DOF_SURR, or NULL: [2 n_constraint, B] products over the rollout (gops/algorithm/spil.py:189-251):
+    /* Same models, or NULL: [2 n_constraint, B] products over the rollout (gops/algorithm/spil.py:189-251):
      *   rows 0 .. n_constraint-1        P_k = prod_t Phi(c_tk),  Phi(y) = 1.07 / (1 + 0.0315 exp(clamp(y / 0.07, -10, 5)))
      *   rows n_constraint .. 2 n_c - 1  prod_t [c_tk <= 0]       (trajectory safe w.r.t. constraint k: 0 / 1) */
     float* constraint_prods;
@@ -307,6 +319,7 @@ typedef struct GopsStepIO {
     const float* surr_state; float* next_surr_state; float* constraint;
     const float* ref_appended;   /* ABI v8, or NULL: [B, 4] (veh2dofconti: (., y, phi, .)) the reference point this step appends,
                                     from the caller (see GopsRolloutIn.ref_appended) */
+    const float* noise;          /* ABI v9, GOPS_ENV_MOBILEROBOT, or NULL (= zeros): [B, 2] this step's obstacle draws (GopsRolloutIn.noise) */
 } GopsStepIO;
 int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream);
 

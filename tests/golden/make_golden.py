@@ -654,6 +654,134 @@ def golden_constrained(step_cases=None, alg_cases=None):
 
 
 # ------------------------------------------------------------------------------------------
+# 5b. pyth_mobilerobot (example_train/spil/spil_mlp_mobilerobot_*.py): the model draws np.random.normal inside every
+#     forward (Robot.f_xu); the draws of the obstacle robot are recorded next to the outputs they produced
+# ------------------------------------------------------------------------------------------
+class record_normal:
+    """Records every np.random.normal call made inside the block: list of (scale, float32 draws)."""
+
+    def __enter__(self):
+        self.calls, self._orig = [], np.random.normal
+
+        def normal(loc=0.0, scale=1.0, size=None):
+            out = self._orig(loc, scale, size)
+            self.calls.append((float(scale), np.asarray(out, dtype=np.float32).copy()))
+            return out
+        np.random.normal = normal
+        return self
+
+    def __exit__(self, *exc):
+        np.random.normal = self._orig
+
+    def obstacle_draws(self):
+        """[n_forward_calls, B, 2]: per model.forward the (v, w) draws of the obstacle (the ego's std-0 draws are zeros)."""
+        obs = [d for sc, d in self.calls if sc != 0.0]
+        assert len(obs) % 2 == 0 and len(self.calls) == 2 * len(obs)
+        return np.stack([np.stack((obs[i], obs[i + 1]), axis=1) for i in range(0, len(obs), 2)])
+
+
+MOB_ALG_CASES = {
+    "spil_mobilerobot": (dict(alg="SPIL", env_id="pyth_mobilerobot", batch=48, horizon=10, hidden=(64, 64), act="relu", gamma=0.99),
+                         dict(constraint_dim=1)),
+    "fhadp_ext_mobilerobot": (dict(alg="FHADPExterior", env_id="pyth_mobilerobot", batch=40, horizon=8, hidden=(64, 64), act="elu",
+                                   gamma=0.98), dict(penalty=3.0)),
+    "infadp_mobilerobot_gelu": (dict(alg="INFADP", env_id="pyth_mobilerobot", batch=40, horizon=8, hidden=(64, 64), act="gelu",
+                                     gamma=0.99), {}),
+}
+
+
+def golden_mobilerobot():
+    cfg = dict(env_id="pyth_mobilerobot")
+    B, nsteps = 48, 6
+    np.random.seed(3)
+    data = make_batch(dict(cfg, batch=B), seed=29)
+    model = create_env_model(**cfg)
+    g = torch.Generator().manual_seed(31)
+    done = (torch.rand(B, generator=g) < 0.25).float()
+    obs = data["obs"].clone()
+    obs[:4, 0] = 59.96           # x passes the observation bound (60) within a step or two: ClipObservation acts
+    obs[4:8, 1] = 3.9            # |y| > 4: done from the model
+    out = {"in/obs": obs.numpy().copy(), "in/done": done.numpy().copy()}
+    o, d, info = obs, done, {}
+    for s in range(nsteps):
+        a = torch.rand(B, 2, generator=g) * 2.6 - 1.3
+        with record_normal() as rec:
+            o, r, d, info = model.forward(o, a, d, info)
+        out[f"s{s}/act"], out[f"s{s}/noise"] = a.numpy(), rec.obstacle_draws()[0]
+        out[f"s{s}/obs"], out[f"s{s}/rew"], out[f"s{s}/done"] = o.numpy().copy(), r.numpy().copy(), d.numpy().copy()
+        out[f"s{s}/constraint"] = info["constraint"].numpy().copy()
+    out["meta/nsteps"] = nsteps
+    out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra={}))
+    save("step_mobilerobot", **out)
+
+    from gops.algorithm.spil import SPIL
+    for name, (cfg, extra) in MOB_ALG_CASES.items():
+        seed = zlib.crc32(name.encode()) % 1000
+        np.random.seed(seed)
+        data = make_batch(cfg, seed)
+        data["done"][-4:] = 1.0
+        if cfg["alg"] == "SPIL":
+            torch.manual_seed(seed)
+            kw = alg_kwargs(dict(cfg, alg="INFADP"), seed, **extra)
+            kw["algorithm"] = "SPIL"
+            alg = SPIL(gamma=cfg["gamma"], forward_step=cfg["horizon"], **kw)
+            perturb_targets(alg, seed)
+            data["constraint"] = torch.zeros(cfg["batch"], 1)
+            alg.delta_i, alg.safe_prob_pre = np.array([3.0]), np.array([0.9])
+            out = {"in/" + k: v.numpy().copy() for k, v in data.items()}
+            out["state/delta_i"], out["state/safe_prob_pre"] = alg.delta_i.copy(), alg.safe_prob_pre.copy()
+            out.update(sd_to_np(alg.networks.state_dict()))
+            with record_normal() as rec:
+                tb, info = alg.get_remote_update_info(data, 0)
+            draws = rec.obstacle_draws()
+            H = cfg["horizon"]
+            assert draws.shape == (2 * H, cfg["batch"], 2)
+            out["in/noise_pev"], out["in/noise_pim"] = draws[:H], draws[H:]
+            for i, gr in enumerate(info["v"]):
+                out[f"pev_grad/{i}"] = gr.detach().numpy().copy()
+            for i, gr in enumerate(info["policy"]):
+                out[f"pim_grad/{i}"] = gr.detach().numpy().copy()
+            out["pev_loss"], out["pev_vmean"] = tb["Loss/Critic loss-RL iter"], tb["Train/Critic avg value-RL iter"]
+            out["pim_loss"] = tb["Loss/Actor loss-RL iter"]
+            out["safe_prob"], out["lam"] = np.asarray(alg.safe_prob), np.asarray(alg.lam)
+            out["after/delta_i"] = alg.delta_i.copy()
+        elif cfg["alg"] == "FHADPExterior":
+            alg = build_alg(cfg, seed, **extra)
+            out = {"in/" + k: v.numpy().copy() for k, v in data.items()}
+            out.update(sd_to_np(alg.networks.state_dict()))
+            alg.networks.policy.zero_grad()
+            with record_normal() as rec:
+                loss, info = alg._compute_loss_policy(deepcopy(data))
+            out["in/noise"] = rec.obstacle_draws()
+            loss.backward()
+            for i, gr in enumerate(grads_of(alg.networks.policy)):
+                out[f"grad/{i}"] = gr
+            out["loss"] = loss.item()
+            for k, v in info.items():
+                out["tb/" + k] = float(v)
+        else:   # INFADP: policy evaluation (iteration 0) and policy improvement (iteration 1), each with its own draws
+            alg = build_alg(cfg, seed, **extra)
+            perturb_targets(alg, seed)
+            out = {"in/" + k: v.numpy().copy() for k, v in data.items()}
+            out.update(sd_to_np(alg.networks.state_dict()))
+            with record_normal() as rec:
+                _, info = alg.get_remote_update_info(data, 0)
+            out["in/noise_pev"] = rec.obstacle_draws()
+            for i, gr in enumerate(info["v"]):
+                out[f"pev_grad/{i}"] = gr.detach().numpy().copy()
+            out["pev_loss"] = alg.tb_info["Loss/Critic loss-RL iter"]
+            out["pev_vmean"] = alg.tb_info["Train/Critic avg value-RL iter"]
+            with record_normal() as rec:
+                _, info = alg.get_remote_update_info(data, 1)
+            out["in/noise_pim"] = rec.obstacle_draws()
+            for i, gr in enumerate(info["policy"]):
+                out[f"pim_grad/{i}"] = gr.detach().numpy().copy()
+            out["pim_loss"] = alg.tb_info["Loss/Actor loss-RL iter"]
+        out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra=extra, seed=seed))
+        save(name, **out)
+
+
+# ------------------------------------------------------------------------------------------
 # 6. DATA-environment transitions (the numpy envs the reference's samplers step: create_env + its wrappers)
 #    and the reference ReplayBuffer run on them - the semantics DeviceEnvSampler / the device ReplayBuffer
 #    reproduce (terminal penalty -100, data-env termination tests, no observation clipping)
@@ -730,7 +858,9 @@ def golden_data_envs(only=None):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof", "errcstr", "mpg", "refpara", "repeat", "nomask"]
+    which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof", "errcstr", "mpg", "refpara", "repeat", "nomask", "mobilerobot"]
+    if "mobilerobot" in which:
+        golden_mobilerobot()
     if "veh2dof" in which:
         golden_steps(VEH2_STEP_CASES)
         golden_small(VEH2_SMALL)

@@ -94,7 +94,7 @@ def hip_env_from_oracle(env, policy_net=None):
     from gops_amd import hip_backend as hb
     from gops_amd.env.env_ocp.resources.ref_traj_params import ref_constants
     kind = {"veh_err": hb.ENV_VEH_SURR, "lq": hb.ENV_LQ, "idp": hb.ENV_IDP, "veh": hb.ENV_VEH, "veh_surr": hb.ENV_VEH_SURR,
-            "cartpole": hb.ENV_CARTPOLE, "pendulum": hb.ENV_PENDULUM, "veh2": hb.ENV_VEH2DOF}[env["kind"]]
+            "cartpole": hb.ENV_CARTPOLE, "pendulum": hb.ENV_PENDULUM, "veh2": hb.ENV_VEH2DOF, "mob": hb.ENV_MOBILEROBOT}[env["kind"]]
     surr = None
     if env["kind"] in ("veh_surr", "veh_err") or env.get("err_tol") is not None:
         surr = {k: env[k] for k in ("n_surr", "n_constraint", "veh_length", "veh_width", "road_upper", "road_lower", "reward_w")}
@@ -116,7 +116,8 @@ def hip_env_from_oracle(env, policy_net=None):
                        obs_shift=env["obs_shift"] if env.get("scale_obs") else None,
                        ref_c=ref_constants(env.get("path_para"), env.get("u_para")) if "ref_params" in env else None,
                        repeat_num=env.get("repeat_num"), sum_reward=env.get("sum_reward", True),
-                       mask_at_done=env.get("mask_at_done", True))
+                       mask_at_done=env.get("mask_at_done", True),
+                       n_constraint=env["n_constraint"] if env["kind"] == "mob" else None)
 
 
 def hip_mlp_from_net(net, device):

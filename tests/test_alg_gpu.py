@@ -32,7 +32,9 @@ def _kwargs(cfg, extra, seed):
     if "lq_config" in cfg:
         kw["lq_config"] = cfg["lq_config"]
     if cfg["alg"] == "SPIL":
-        kw.update(policy_func_name="DetermPolicy", pre_horizon=cfg["pre_horizon"])
+        kw.update(policy_func_name="DetermPolicy")
+        if "pre_horizon" in cfg:
+            kw["pre_horizon"] = cfg["pre_horizon"]
     if cfg["alg"] == "MPG":
         kw.update(value_func_type="MLP", value_func_name="ActionValue", value_hidden_sizes=list(cfg["hidden"]),
                   value_hidden_activation=cfg["act"], value_learning_rate=1e-3)

@@ -359,6 +359,12 @@ def test_replay_buffer_interface_and_ring_semantics():
     again.add_tensors({"obs": torch.ones(2, 5), "rew": torch.tensor([100.0, 101.0])})
     assert again.buf["rew"][3:5].tolist() == [100.0, 101.0] and again.buf["obs"][3].tolist() == [1.0] * 5
     assert buf.__get_RAM__() > 0
+    # a zero-size info slot (pyth_mobilerobot.py:88-92 declares "constraint" with shape (0,)): the reference's numpy buffer
+    # broadcasts the [1] value into nothing and samples a [B, 0] tensor
+    zero = create_buffer(**_buffer_kwargs(additional_info={"constraint": {"shape": (0,), "dtype": np.float32}}))
+    t = _transition(1)
+    zero.add_batch([t[:4] + ({"constraint": np.array([0.3])},) + t[5:6] + ({"constraint": np.array([0.1])},) + t[7:]] * 3)
+    assert len(zero) == 3 and zero.sample_batch(4)["constraint"].shape == (4, 0)
 
 
 def test_off_serial_trainer_loop(tmp_path):
@@ -409,6 +415,9 @@ class _SyncTrap:
 
     def __getitem__(self, i):
         return self
+
+    def dim(self):   # shape queries are host-side metadata, not a read of the value
+        return 0
 
     def _boom(self, *a, **k):
         raise AssertionError("host read of a device scalar between the backward pass and the all-reduce")
@@ -576,6 +585,7 @@ print("plumbing ok", seen["alg"])
                                     "example_train/spil/spil_mlp_veh3dofconti_errcstr_offserial.py",
                                     "example_train/spil/spil_mlp_veh3dofconti_surrcstr_offserial.py",
                                     "example_train/spil/spil_mlp_veh2dofconti_errcstr_offserial.py",
+                                    "example_train/spil/spil_mlp_mobilerobot_offserial.py",
                                     "example_train/mpg/mpg_mlp_cartpoleconti_offserial.py",
                                     "example_train/fhadp/fhadp2_mlp_veh3dofconti_serial.py",
                                     "example_train/fhadp/fhadp_mlp_lqs2a1_serial.py",
@@ -590,6 +600,7 @@ print("plumbing ok", seen["alg"])
                                     "example_train/fhadp/fhadp_mlp_idpendulum_async.py",
                                     "example_train/infadp/infadp_mlp_cartpoleconti_async.py",
                                     "example_train/mpg/mpg_mlp_cartpoleconti_async.py",
+                                    "example_train/spil/spil_mlp_mobilerobot_async.py",
                                     "example_train/mac/mac_mlp_cartpoleconti_async.py"])   # (the pendulum scripts need the gym package for their data env)
 def test_example_scripts_run_unchanged_through_the_overlay(script, tmp_path):
     """BASELINE configs[0] plumbing: the reference's UNMODIFIED example scripts (their own argparse block, create_env,

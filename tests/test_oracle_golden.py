@@ -269,6 +269,71 @@ def test_spil_gradients_match_reference(name):
         assert rel_l2(gr, g[f"pim_grad/{i}"]) < 1e-5, (name, "pim", i)
 
 
+# ---- pyth_mobilerobot (example_train/spil/spil_mlp_mobilerobot_*.py): the obstacle's np.random.normal draws of the reference run
+#      are part of the fixture (make_golden.record_normal) and replayed through info["noise"] -------------------------------------
+def test_mobilerobot_steps_match_reference():
+    g = load_golden("step_mobilerobot")
+    env = oracle_env(golden_meta(g)["cfg"], {}, g)
+    obs, done = torch.from_numpy(g["in/obs"]), torch.from_numpy(g["in/done"])
+    seen_clip = False
+    for s in range(int(g["meta/nsteps"])):
+        info = dict(noise=torch.from_numpy(g[f"s{s}/noise"])[None])
+        obs, r, done, info = orc.env_forward(env, obs, torch.from_numpy(g[f"s{s}/act"]), done, info)
+        np.testing.assert_allclose(obs.numpy(), g[f"s{s}/obs"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(r.numpy(), g[f"s{s}/rew"], rtol=1e-6, atol=1e-6)
+        assert np.array_equal(done.numpy(), g[f"s{s}/done"])
+        np.testing.assert_allclose(info["constraint"].numpy(), g[f"s{s}/constraint"], rtol=1e-6, atol=1e-6)
+        seen_clip |= bool((obs[:, 0] == 60.0).any())
+    assert seen_clip and (g["s0/constraint"] > 0.15).any()   # the fixture exercises ClipObservation and the collision test
+
+
+def test_mobilerobot_algorithms_match_reference():
+    """SPIL (one full update), FHADPExterior and INFADP (PEV + PIM) of the reference on pyth_mobilerobot against the oracle."""
+    g = load_golden("spil_mobilerobot")
+    cfg = golden_meta(g)["cfg"]
+    env = oracle_env(cfg, {}, g)
+    nets, _ = nets_from_golden(g, cfg)
+    data = data_from_golden(g)
+    pev = orc.spil_pev(env, nets["policy"], nets["v"], nets["v_target"], dict(data, noise=data["noise_pev"]), cfg["horizon"], cfg["gamma"])
+    assert abs(pev["loss"].item() - float(g["pev_loss"])) <= 1e-5 * max(1.0, abs(float(g["pev_loss"])))
+    np.testing.assert_allclose(pev["safe_prob"].numpy(), g["safe_prob"], atol=1e-7)
+    for i, gr in enumerate(pev["grads"]):
+        assert rel_l2(gr, g[f"pev_grad/{i}"]) < 1e-5, ("pev", i)
+    w_r, w_c, lam = _spil_weights(g["state/delta_i"], g["state/safe_prob_pre"], pev["safe_prob"].numpy())
+    np.testing.assert_allclose(lam, g["lam"], rtol=1e-6, atol=1e-7)
+    pim = orc.spil_pim(env, nets["policy"], dict(data, noise=data["noise_pim"]), cfg["horizon"], cfg["gamma"], w_r, w_c)
+    assert abs(pim["loss"].item() - float(g["pim_loss"])) <= 1e-5 * max(1.0, abs(float(g["pim_loss"])))
+    for i, gr in enumerate(pim["grads"]):
+        assert rel_l2(gr, g[f"pim_grad/{i}"]) < 1e-5, ("pim", i, rel_l2(gr, g[f"pim_grad/{i}"]))
+
+    g = load_golden("fhadp_ext_mobilerobot")
+    meta = golden_meta(g)
+    cfg = meta["cfg"]
+    env = oracle_env(cfg, {}, g)
+    nets, _ = nets_from_golden(g, cfg)
+    ref = orc.fhadp_constrained_gradient(env, nets["policy"], data_from_golden(g), cfg["horizon"], cfg["gamma"], "exterior",
+                                         meta["extra"]["penalty"])
+    assert abs(ref["loss"].item() - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
+    assert abs(ref["loss_constraint"].item() - float(g["tb/Loss/Actor constraint loss-RL iter"])) <= 1e-5
+    for i, gr in enumerate(ref["grads"]):
+        assert rel_l2(gr, g[f"grad/{i}"]) < 1e-5, ("ext", i, rel_l2(gr, g[f"grad/{i}"]))
+
+    g = load_golden("infadp_mobilerobot_gelu")
+    cfg = golden_meta(g)["cfg"]
+    env = oracle_env(cfg, {}, g)
+    nets, _ = nets_from_golden(g, cfg)
+    data = data_from_golden(g)
+    pev = orc.infadp_pev_gradient(env, nets["policy"], nets["v"], nets["v_target"], dict(data, noise=data["noise_pev"]),
+                                  cfg["horizon"], cfg["gamma"])
+    assert abs(pev["loss"].item() - float(g["pev_loss"])) <= 1e-5 * max(1.0, abs(float(g["pev_loss"])))
+    for i, gr in enumerate(pev["grads"]):
+        assert rel_l2(gr, g[f"pev_grad/{i}"]) < 1e-5, ("pev", i)
+    pim = orc.infadp_pim_gradient(env, nets["policy"], nets["v_target"], dict(data, noise=data["noise_pim"]), cfg["horizon"], cfg["gamma"])
+    assert abs(pim["loss"].item() - float(g["pim_loss"])) <= 1e-5 * max(1.0, abs(float(g["pim_loss"])))
+    for i, gr in enumerate(pim["grads"]):
+        assert rel_l2(gr, g[f"pim_grad/{i}"]) < 1e-5, ("pim", i)
+
+
 MPG_FIXTURES = ["mpg_cartpole_mixed_weight", "mpg_pendulum_mixed_state", "mpg_lq_s4a2_mixed_weight", "mpg_idp_mixed_state"]
 
 

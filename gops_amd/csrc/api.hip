@@ -33,6 +33,7 @@ hipError_t launch_linear_out_bwd(const float* gy, int W, int Wp, const float* Wo
 hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s);
 hipError_t launch_fill_zero(float* p, size_t n, hipStream_t s);
 hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s);
+hipError_t launch_env_constraint(const GopsEnv& env, int B, const GopsStepIO& io, hipStream_t s);
 hipError_t launch_adam(const GopsAdamTensors& T, GopsAdamState* st, double beta1, double beta2, float eps,
                        hipStream_t s);
 
@@ -212,7 +213,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
          (e.cstr_err ? e.n_constraint != 2 : (e.n_constraint != 1 && e.n_constraint != 3)) ||
          e.obs_dim != 6 + 4 * e.pre_horizon + 4 * e.n_surr || e.clip_obs ||
          (e.surr_penalty && (e.n_surr != 1 || e.n_constraint != 1)) ||
-         desc.open_loop || desc.dtype != GOPS_DTYPE_F32))
+         desc.open_loop == 1 || desc.dtype != GOPS_DTYPE_F32))   // (open_loop 2: OptController's raw-action rollouts)
         return GOPS_ERR_BAD_ARG;
     if (e.clip_obs && e.obs_dim > (e.kind == GOPS_ENV_MOBILEROBOT ? GOPS_MAX_CLIP_OBS : 8)) return GOPS_ERR_UNSUPPORTED;
     if (e.repeat_num < 0 || e.repeat_num > GOPS_MAX_REPEAT) return GOPS_ERR_BAD_ARG;
@@ -462,7 +463,8 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     // Two-half-plane weight-gradient GEMM (launch_dw_gemm): its delta scale is derived from max|grad_v|, which bounds the
     // deltas only when grad_v is the sweep's one gradient source - a terminal observation adjoint or constraint-sum
     // gradients can be orders of magnitude larger, so those launches keep the exact three-plane product.
-    const float* dw_scale = (adj == nullptr && in.grad_constraint == nullptr && in.grad_constraint_prod == nullptr && ext_delta == nullptr)
+    const float* dw_scale = (adj == nullptr && in.grad_constraint == nullptr && in.grad_constraint_prod == nullptr && in.grad_constraint_step == nullptr &&
+                             ext_delta == nullptr)
                                 ? p.gscale : nullptr;
     for (int j = 0; j < L; ++j) {   // dW_j = D_{j+1}^T * (j == 0 ? X : H_j)
         const int N = p.pol.dims[j + 1], Kp = p.f16 ? p.pol.kp32[j] : p.pol.kp[j], K = p.pol.dims[j];
@@ -727,6 +729,17 @@ int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void*
     GopsEnv e = *env;
     fill_ref_defaults(e);
     return (int)launch_env_step(e, batch, *io, pdt_of(e), static_cast<hipStream_t>(stream));
+}
+
+int gops_env_constraint(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream) {
+    if (!env || !io || batch < 1 || !io->constraint) return GOPS_ERR_BAD_ARG;
+    const bool err = env->cstr_err != 0 && (env->kind == GOPS_ENV_VEH3DOF_SURR || env->kind == GOPS_ENV_VEH2DOF);
+    const bool surr = env->kind == GOPS_ENV_VEH3DOF_SURR && !env->cstr_err;
+    if (!err && !surr) return GOPS_ERR_UNSUPPORTED;   // the model defines no get_constraint
+    if (err && (!io->obs || env->n_constraint != (env->kind == GOPS_ENV_VEH2DOF ? 1 : 2))) return GOPS_ERR_BAD_ARG;
+    if (surr && (!io->state || !io->surr_state || env->n_surr < 1 || env->n_surr > GOPS_MAX_SURR ||
+                 (env->n_constraint != 1 && env->n_constraint != 3))) return GOPS_ERR_BAD_ARG;
+    return (int)launch_env_constraint(*env, batch, *io, static_cast<hipStream_t>(stream));
 }
 
 size_t gops_value_workspace_bytes(const GopsMlp* value, int32_t batch) {

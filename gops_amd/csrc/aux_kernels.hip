@@ -1466,6 +1466,43 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
     io.next_done[b] = (dn || done_m) ? 1.f : 0.f;
 }
 
+// model.get_constraint(obs, info), one thread per row (gops_env_constraint)
+__global__ void env_constraint_kernel(const GopsEnv env, int B, const GopsStepIO io) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int nc = env.n_constraint;
+    if (env.cstr_err) {
+        const float* ob = io.obs + (size_t)b * env.obs_dim;
+        if (env.kind == GOPS_ENV_VEH2DOF) {
+            io.constraint[b] = fabsf(ob[0]) - env.err_tol[0];
+        } else {
+            io.constraint[(size_t)b * 2 + 0] = fabsf(ob[1]) - env.err_tol[0];
+            io.constraint[(size_t)b * 2 + 1] = fabsf(ob[3]) - env.err_tol[1];
+        }
+        return;
+    }
+    const float* st = io.state + (size_t)b * 6;
+    f32x4 pts[GOPS_MAX_SURR];
+    for (int i = 0; i < GOPS_MAX_SURR; ++i) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        pts[i] = z;
+        if (i < env.n_surr) {
+            const float* sv = io.surr_state + ((size_t)b * env.n_surr + i) * 5;
+            pts[i][0] = sv[0]; pts[i][1] = sv[1]; pts[i][2] = sv[2]; pts[i][3] = sv[3];
+        }
+    }
+    float sp, cp;
+    sincosf(st[2], &sp, &cp);
+    SurrCstr sc;
+    surr_constraint<false>(env, st[0], st[1], sp, cp, pts, sc);
+    for (int k = 0; k < nc; ++k) io.constraint[(size_t)b * nc + k] = sc.c[k];
+}
+
+hipError_t launch_env_constraint(const GopsEnv& env, int B, const GopsStepIO& io, hipStream_t s) {
+    hipLaunchKernelGGL(env_constraint_kernel, dim3((B + 127) / 128), dim3(128), 0, s, env, B, io);
+    return hipGetLastError();
+}
+
 hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s) {
     hipLaunchKernelGGL(env_step_kernel, dim3((B + 127) / 128), dim3(128), 0, s, env, B, io, pdt);
     return hipGetLastError();

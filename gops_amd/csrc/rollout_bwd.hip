@@ -444,6 +444,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         for (int k = 0; k < GOPS_MAX_CONSTRAINT; ++k)
             if (k < p.env.n_constraint) gc_mul[k] = gptr(p.in.grad_constraint_prod)[(size_t)k * p.B + b0 + tid];
     }
+    // d(loss)/d(c_tk) handed in per step (GopsRolloutIn.grad_constraint_step), trajectory m of this tile
+    auto gc_step = [&](int t, int m, int k) -> float {
+        if (!CSTR || p.in.grad_constraint_step == nullptr) return 0.f;
+        return gptr(p.in.grad_constraint_step)[((size_t)t * p.B + b0 + m) * p.env.n_constraint + k];
+    };
     float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // adjoint of the veh3dof state (tid < TB)
     if (REF) {
         const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
@@ -844,6 +849,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                     float dlog;
                     (void)spil_phi(c, dlog);
                     gck += gc_mul[0] * dlog;
+                    gck += gc_step(t, m, 0);
                 }
                 float gu[2];
                 mob_backward(MC, x, u[0], u[1], nv, nw, gxn, g_rm, gck, gx, gu);
@@ -898,6 +904,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                         float dlog;
                         (void)spil_phi(c, dlog);
                         gck += gc_mul[0] * dlog;
+                        gck += gc_step(t, m, 0);
                         gp[0] += gck * (o[0] > 0.f ? 1.f : (o[0] < 0.f ? -1.f : 0.f));
                     }
                 }
@@ -1007,6 +1014,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                                 float dlog;
                                 (void)spil_phi(c, dlog);
                                 gck += gc_mul[k] * dlog;   // d P_k / d c_tk = P_k Phi'(c_tk) / Phi(c_tk); gc_mul carries dL/dP_k * P_k
+                                gck += gc_step(t, m, k);
                                 lamn[0] += gck * sc.dx[k];
                                 lamn[1] += gck * sc.dy[k];
                                 lamn[2] += gck * sc.dphi[k];
@@ -1084,6 +1092,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                                 float dlog;
                                 (void)spil_phi(c, dlog);
                                 gck += gc_mul[k] * dlog;
+                                gck += gc_step(t, m, k);
                                 G[m * ldx + 1 + 2 * k] += gck * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
                             }
                         }

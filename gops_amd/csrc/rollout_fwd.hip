@@ -582,6 +582,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                     float dlog;
                     c_mul[0] *= spil_phi(c, dlog);
                     if (!(c <= 0.f)) c_safe[0] = 0.f;
+                    if (p.out.constraints != nullptr) gptr(p.out.constraints)[(size_t)t * p.B + b0 + m] = c;
                 }
                 const bool frozen = s_done[m] != 0.f;
                 if (!frozen || p.env.clip_obs) {
@@ -611,6 +612,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                     float dlog;
                     c_mul[0] *= spil_phi(c, dlog);
                     if (!(c <= 0.f)) c_safe[0] = 0.f;
+                    if (p.out.constraints != nullptr) gptr(p.out.constraints)[(size_t)t * p.B + b0 + m] = c;
                 }
                 float sphi, cphi;
                 sincosf(s[1], &sphi, &cphi);
@@ -741,6 +743,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                             float dlog;
                             c_mul[k] *= spil_phi(sc.c[k], dlog);
                             if (!(sc.c[k] <= 0.f)) c_safe[k] = 0.f;
+                            if (p.out.constraints != nullptr)
+                                gptr(p.out.constraints)[((size_t)t * p.B + b0 + m) * p.env.n_constraint + k] = sc.c[k];
                         }
                     }
                     c_ext += e2 * p.gpow[t];

@@ -37,6 +37,21 @@ class PythBaseModel:
         """Extra keyword arguments for `hip_backend.make_env` (e.g. the LQ matrices)."""
         return {}
 
+    def _hip_get_constraint(self, obs: torch.Tensor, info: Optional[Dict] = None) -> torch.Tensor:
+        """`get_constraint(obs, info)` of the models that define one (pyth_base_model.py:69-75): [B, n_constraint], each
+        entry required <= 0 - one launch of `gops_env_constraint`."""
+        from gops_amd import hip_backend as hb
+        if not obs.is_cuda:
+            raise RuntimeError("get_constraint runs on the MI355X only (tensors must be on 'cuda'); there is no CPU path in gops_amd")
+        env = self.__dict__.get("_constraint_env")
+        if env is None:
+            env = self._constraint_env = hb.make_env(
+                self.hip_kind, self.obs_dim, self.action_dim, act_low=self.action_lower_bound.cpu(),
+                act_high=self.action_upper_bound.cpu(), pre_horizon=getattr(self, "pre_horizon", 0), **self.hip_constants())
+        f = lambda t: t.to(dtype=torch.float32).contiguous()
+        dev_info = {k: f(info[k]) for k in ("state", "surr_state") if info and info.get(k) is not None}
+        return hb.env_constraint(env, f(obs), dev_info)
+
     def forward(self, obs: torch.Tensor, action: torch.Tensor, done: torch.Tensor, info: Dict
                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Dict]:
         raise NotImplementedError

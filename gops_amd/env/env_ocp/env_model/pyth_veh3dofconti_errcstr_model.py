@@ -27,6 +27,9 @@ class Veh3dofcontiErrCstrModel(PythBaseModel):
         super().__init__(obs_dim=6 + 4 * pre_horizon, action_dim=2, dt=0.1,
                          action_lower_bound=[-np.pi / 6, -3], action_upper_bound=[np.pi / 6, 3], device=device)
 
+    def get_constraint(self, obs: torch.Tensor, info: Optional[Dict] = None) -> torch.Tensor:
+        return self._hip_get_constraint(obs, info)
+
     def hip_constants(self) -> Dict:
         return dict(surr=dict(n_surr=0, n_constraint=2, veh_length=4.8, veh_width=2.0, reward_w=TRACKING_WEIGHTS,
                               err_tol=(self.y_error_tol, self.u_error_tol)))

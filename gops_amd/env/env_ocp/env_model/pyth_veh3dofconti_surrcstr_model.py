@@ -34,6 +34,9 @@ class Veh3dofcontiSurrCstrModel(PythBaseModel):
         super().__init__(obs_dim=6 + 4 * pre_horizon + 4 * surr_veh_num, action_dim=2, dt=0.1,
                          action_lower_bound=[-np.pi / 6, -3], action_upper_bound=[np.pi / 6, 3], device=device)
 
+    def get_constraint(self, obs: torch.Tensor, info: Optional[Dict] = None) -> torch.Tensor:
+        return self._hip_get_constraint(obs, info)
+
     def hip_constants(self) -> Dict:
         return dict(surr=dict(n_surr=self.surr_veh_num, n_constraint=self.n_constraint, veh_length=self.veh_length,
                               veh_width=self.veh_width, road_upper=self.road_upper, road_lower=self.road_lower,

@@ -76,12 +76,12 @@ class GopsRolloutDesc(C.Structure):
 class GopsRolloutIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "done", "state", "ref_points", "path_num", "u_num",
                                           "ref_time", "head_pre", "surr_state", "grad_constraint", "grad_constraint_prod",
-                                          "ref_appended", "noise")]
+                                          "ref_appended", "noise", "grad_constraint_step")]
 
 
 class GopsRolloutOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("v_pi", "rewards", "final_obs", "final_done", "final_state", "constraint_sums",
-                                          "constraint_prods")]
+                                          "constraint_prods", "constraints")]
 
 
 ADAM_MAX = 16
@@ -135,6 +135,8 @@ def lib() -> C.CDLL:
                                                 C.c_size_t, C.c_void_p]
         l.gops_env_step.restype = C.c_int
         l.gops_env_step.argtypes = [C.POINTER(GopsEnv), C.c_int32, C.POINTER(GopsStepIO), C.c_void_p]
+        l.gops_env_constraint.restype = C.c_int
+        l.gops_env_constraint.argtypes = [C.POINTER(GopsEnv), C.c_int32, C.POINTER(GopsStepIO), C.c_void_p]
         l.gops_value_workspace_bytes.restype = C.c_size_t
         l.gops_value_workspace_bytes.argtypes = [C.POINTER(GopsMlp), C.c_int32]
         l.gops_value_forward.restype = C.c_int
@@ -173,7 +175,8 @@ EXPORTED_SYMBOLS = ("gops_hip_version", "gops_rollout_workspace_bytes", "gops_ro
                     "gops_rollout_backward", "gops_rollout_backward_open_loop", "gops_rollout_backward_adj", "gops_env_step", "gops_value_workspace_bytes",
                     "gops_value_forward", "gops_value_backward", "gops_mlp_workspace_bytes", "gops_mlp_forward",
                     "gops_mlp_backward", "gops_mlp_backward_x", "gops_adam_step", "gops_profile_enable",
-                    "gops_profile_reset", "gops_profile_read", "gops_rollout_variant", "gops_rollout_backward_open_loop_adj")
+                    "gops_profile_reset", "gops_profile_read", "gops_rollout_variant", "gops_rollout_backward_open_loop_adj",
+                    "gops_env_constraint")
 
 _ERR = {-1: "GOPS_ERR_BAD_ARG", -2: "GOPS_ERR_UNSUPPORTED", -3: "GOPS_ERR_WORKSPACE"}
 
@@ -359,7 +362,7 @@ class Rollout:
         self._mlps = (policy, value if value is not None else self._mlps[1])
 
     def forward(self, data: Dict[str, torch.Tensor], *, want_rewards=False, want_final=False,
-                head_pre: Optional[torch.Tensor] = None):
+                head_pre: Optional[torch.Tensor] = None, want_constraints=False):
         d = self.desc
         B, H, O = d.batch, d.horizon, d.env.obs_dim
         i = self._in
@@ -403,18 +406,24 @@ class Rollout:
             nc = d.env.n_constraint
             res["constraint_prods"] = torch.empty(2 * nc, B, dtype=torch.float32, device=self.device)
             out.constraint_prods = _ptr(res["constraint_prods"])
+            if want_constraints:   # [H, B, n_c]: the unmasked info["constraint"] of every step
+                res["constraints"] = torch.empty(H, B, nc, dtype=torch.float32, device=self.device)
+                out.constraints = _ptr(res["constraints"])
         check(lib().gops_rollout_forward(C.byref(d), C.byref(i), C.byref(out), self.workspace.data_ptr(),
                                          self.workspace.numel(), _stream()), "gops_rollout_forward")
         return res
 
     def backward(self, grad_v: torch.Tensor, grad_w: List[torch.Tensor], grad_b: List[torch.Tensor],
-                 grad_constraint: Optional[torch.Tensor] = None, grad_constraint_prod: Optional[torch.Tensor] = None):
-        """`grad_constraint` (ENV_VEH_SURR): d(loss)/d(constraint_sums rows 0..2), [3, B]; `grad_constraint_prod`:
-        d(loss)/d(P_k) * P_k for the Phi-products P_k = constraint_prods[k], [n_constraint, B]."""
+                 grad_constraint: Optional[torch.Tensor] = None, grad_constraint_prod: Optional[torch.Tensor] = None,
+                 grad_constraint_step: Optional[torch.Tensor] = None):
+        """`grad_constraint` (models with constraint outputs): d(loss)/d(constraint_sums rows 0..2), [3, B];
+        `grad_constraint_prod`: d(loss)/d(P_k) * P_k for the Phi-products P_k = constraint_prods[k], [n_constraint, B];
+        `grad_constraint_step`: d(loss)/d(per-step constraint values), [H, B, n_constraint]."""
         g = make_mlp_grad(grad_w, grad_b)
         self._in.grad_constraint = _ptr(grad_constraint)
         self._in.grad_constraint_prod = _ptr(grad_constraint_prod)
-        self._grad_c = (grad_constraint, grad_constraint_prod)
+        self._in.grad_constraint_step = _ptr(grad_constraint_step)
+        self._grad_c = (grad_constraint, grad_constraint_prod, grad_constraint_step)
         check(lib().gops_rollout_backward(C.byref(self.desc), C.byref(self._in), _ptr(grad_v), C.byref(g),
                                           self.workspace.data_ptr(), self.workspace.numel(), _stream()),
               "gops_rollout_backward")
@@ -451,9 +460,12 @@ class Rollout:
               "gops_rollout_backward_open_loop_adj")
         return g, g_obs
 
-    def backward_open_loop(self, grad_v: torch.Tensor) -> torch.Tensor:
-        """d(loss)/d(head_pre) [B, H, act_dim] of the last open-loop forward."""
+    def backward_open_loop(self, grad_v: torch.Tensor, grad_constraint_step: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """d(loss)/d(head_pre) [B, H, act_dim] of the last open-loop forward; `grad_constraint_step` [H, B, n_constraint]:
+        d(loss)/d(per-step constraint values) (GopsRolloutIn.grad_constraint_step)."""
         d = self.desc
+        self._in.grad_constraint_step = _ptr(grad_constraint_step)
+        self._grad_cs = grad_constraint_step
         g = torch.empty(d.batch, d.horizon, d.env.act_dim, dtype=torch.float32, device=self.device)
         check(lib().gops_rollout_backward_open_loop(C.byref(d), C.byref(self._in), _ptr(grad_v), _ptr(g),
                                                     self.workspace.data_ptr(), self.workspace.numel(), _stream()),
@@ -552,6 +564,18 @@ def env_step(env: GopsEnv, obs, action, done, info: Optional[Dict[str, torch.Ten
         io.constraint = _ptr(ninfo["constraint"])
     check(lib().gops_env_step(C.byref(env), B, C.byref(io), _stream()), "gops_env_step")
     return nobs, rew, ndone, ninfo
+
+
+def env_constraint(env: GopsEnv, obs, info: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """model.get_constraint(obs, info) on the GPU (gops_env_constraint): [B, n_constraint]."""
+    B = obs.shape[0]
+    io = GopsStepIO()
+    out = torch.empty(B, env.n_constraint, dtype=torch.float32, device=obs.device)
+    io.obs, io.constraint = _ptr(obs), _ptr(out)
+    if info:
+        io.state, io.surr_state = _ptr(info.get("state")), _ptr(info.get("surr_state"))
+    check(lib().gops_env_constraint(C.byref(env), B, C.byref(io), _stream()), "gops_env_constraint")
+    return out
 
 
 class HipAdam(torch.optim.Optimizer):

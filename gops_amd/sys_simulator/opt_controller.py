@@ -25,8 +25,15 @@ equality constraints and the box bounds on actions and states.  Collocation need
 and whose `forward` takes no `info` (pyth_lq, pyth_idpendulum, gym_cartpoleconti, gym_pendulum) - for the others the
 reference itself drops to its step-by-step rollout (:292-294); use `mode="shooting"` for them here.
 
-Not provided: path constraints (`model.get_constraint`: the constrained vehicle models), and user terminal-cost callbacks
-(a Python function cannot run inside the kernel).
+Path constraints (`model.get_constraint`, :178-206: the reference evaluates it on all T + 1 states of the prediction and hands
+IPOPT `-c >= 0` with a `jacrev` Jacobian): for the constrained vehicle models (pyth_veh3dofconti_surrcstr / _detour /
+_errcstr, pyth_veh2dofconti_errcstr; shooting mode - they need `info`) the values are the per-step constraint output of ONE
+rollout launch (`GopsRolloutOut.constraints`; the state the kernel does not emit - the initial one for the surrounding-vehicle
+models - comes from `gops_env_constraint`), and the Jacobian is one forward + one backward launch over T n_constraint replicas
+of the trajectory, replica (t, k) seeded with a unit d/d c_tk (`GopsRolloutIn.grad_constraint_step`).  Solver: SLSQP.
+
+Not provided: user terminal-cost callbacks (a Python function cannot run inside the kernel), and the constraint of the
+surrcstr_penalty model (its info["constraint"] is computed on detached copies and carries no gradient).
 """
 from typing import Dict, Optional
 
@@ -36,7 +43,7 @@ import torch
 
 from gops_amd import hip_backend as hb
 
-_INFO = ("state", "ref_points", "path_num", "u_num", "ref_time")
+_INFO = ("state", "ref_points", "path_num", "u_num", "ref_time", "surr_state")
 
 
 class OptController:
@@ -48,8 +55,6 @@ class OptController:
             raise NotImplementedError("terminal-cost callbacks cannot run inside the rollout kernel")
         assert num_pred_step % ctrl_interval == 0, "ctrl_interval should be a factor of num_pred_step."
         base = model.unwrapped
-        if base.hip_kind == hb.ENV_VEH_SURR:
-            raise NotImplementedError("models with path constraints need a constrained solver (not provided)")
         self.model, self.base = model, base
         self.obs_dim, self.action_dim, self.sim_dt = base.obs_dim, base.action_dim, base.dt
         self.gamma, self.ctrl_interval, self.num_pred_step = gamma, ctrl_interval, num_pred_step
@@ -79,6 +84,28 @@ class OptController:
                           max_action=base.action_upper_bound.cpu(), pre_horizon=getattr(base, "pre_horizon", 0),
                           **base.hip_constants())
         env.no_mask_at_done = 1
+        # path constraints: the models that define get_constraint (all of them need `info`: shooting mode)
+        self._cstr = getattr(base, "get_constraint", None) is not None and hb.has_constraints(env)
+        if self._cstr:
+            if env.surr_penalty:
+                raise NotImplementedError("the constraint of pyth_veh3dofconti_surrcstr_penalty carries no gradient (the model computes "
+                                          "it on detached copies): its OptController constraint is not provided")
+            T, nc = num_pred_step, env.n_constraint
+            self._nc = nc
+            # errcstr models emit c(obs_t) at step t (t < H): one padded step more gives c(obs_T); the surrounding-vehicle
+            # models emit c(state_{t+1}) and the initial state's value comes from gops_env_constraint
+            self._cstr_err = bool(env.cstr_err)
+            Hc = T + 1 if self._cstr_err else T
+            mkc = lambda batch: hb.Rollout(env, None, batch=batch, horizon=Hc, gamma=gamma, finite_horizon=False, need_grad=True,
+                                           device=self.device, raw_actions=True)
+            self._cstr_ro, self._cstr_jac_ro = mkc(1), mkc(T * nc)
+            seed = torch.zeros(Hc, T * nc, nc, dtype=torch.float32, device=self.device)
+            for t in range(1, T + 1):       # row (t, k) of the Jacobian <- replica (t - 1) nc + k
+                for k in range(nc):
+                    seed[t if self._cstr_err else t - 1, (t - 1) * nc + k, k] = 1.0
+            self._cstr_seed = seed
+            self._cstr_zero = torch.zeros(T * nc, dtype=torch.float32, device=self.device)
+            self._cstr_env = env
         self._rollout_obj = hb.Rollout(env, None, batch=1, horizon=num_pred_step, gamma=gamma, finite_horizon=False,
                                        need_grad=True, device=self.device, raw_actions=True)
         self._minus_one = torch.full((1,), -1.0, dtype=torch.float32, device=self.device)
@@ -148,6 +175,8 @@ class OptController:
     def _batch(self, x, info: Dict):
         data = {"obs": torch.as_tensor(np.asarray(x), dtype=torch.float32, device=self.device).reshape(1, -1).contiguous(),
                 "done": torch.zeros(1, dtype=torch.float32, device=self.device)}
+        if self.base.hip_kind == hb.ENV_MOBILEROBOT:   # a deterministic cost: the obstacle follows its expected motion
+            data["noise"] = torch.zeros(self.num_pred_step, 1, 2, dtype=torch.float32, device=self.device)
         for k in _INFO:
             if info and k in info:
                 v = torch.as_tensor(np.asarray(info[k]), dtype=torch.float32, device=self.device)
@@ -174,6 +203,36 @@ class OptController:
         jac = g.reshape(self.num_ctrl_points, self.ctrl_interval, self.action_dim).sum(1).reshape(-1)
         return float(-res["v_pi"][0].item()), jac.double().cpu().numpy()
 
+    # ---- path constraints (shooting): -get_constraint(state_t, info_t) >= 0 for t = 0 .. T -----------------------
+    def _cstr_actions(self, inputs: np.ndarray) -> torch.Tensor:
+        u = self._actions(inputs)
+        return torch.cat((u, u[:, -1:]), 1).contiguous() if self._cstr_err else u   # (errcstr: one padded step, see __init__)
+
+    def _constraint_fcn(self, inputs: np.ndarray, x, info: Dict) -> np.ndarray:
+        """[(T + 1) n_constraint]: -c of every state of the prediction, t-major (opt_controller.py:178-198)."""
+        self.constraint_evaluations += 1
+        data = self._batch(x, info)
+        res = self._cstr_ro.forward(data, head_pre=self._cstr_actions(inputs), want_constraints=True)
+        c = res["constraints"][:, 0]                                             # [Hc, nc]
+        if not self._cstr_err:
+            c0 = hb.env_constraint(self._cstr_env, data["obs"], {k: data[k] for k in ("state", "surr_state") if k in data})
+            c = torch.cat((c0, c), 0)
+        return (-c).reshape(-1).double().cpu().numpy()
+
+    def _constraint_jac(self, inputs: np.ndarray, x, info: Dict) -> np.ndarray:
+        """[(T + 1) n_constraint, n A]: one forward + one sweep over T n_constraint replicas, each seeded with one unit
+        d/d c_tk; the rows of the initial state are zero."""
+        T, nc, n, A = self.num_pred_step, self._nc, self.num_ctrl_points, self.action_dim
+        R = T * nc
+        data = {k: v.expand((R,) + tuple(v.shape[1:])).contiguous() for k, v in self._batch(x, info).items()}
+        acts = self._cstr_actions(inputs)
+        self._cstr_jac_ro.forward(data, head_pre=acts.expand((R,) + tuple(acts.shape[1:])).contiguous())
+        g = self._cstr_jac_ro.backward_open_loop(self._cstr_zero, grad_constraint_step=self._cstr_seed)   # [R, Hc, A]
+        g = g[:, :T].reshape(R, n, self.ctrl_interval, A).sum(2).reshape(R, n * A)
+        J = np.zeros(((T + 1) * nc, n * A))
+        J[nc:] = -g.double().cpu().numpy()
+        return J
+
     def __call__(self, x: np.ndarray, info: Optional[Dict] = None) -> np.ndarray:
         """Optimal control input for the current state `x` (and model info, e.g. veh3dofconti's reference window)."""
         info = info or {}
@@ -181,6 +240,11 @@ class OptController:
             res = opt.minimize(self._col_cost_and_jac, self.initial_guess, args=(x, info), jac=True, bounds=self.bounds,
                                method="SLSQP", options=self.minimize_options or {"maxiter": 200, "ftol": 1e-9},
                                constraints=[{"type": "eq", "fun": self._trans_constraint_fcn, "jac": self._trans_constraint_jac,
+                                             "args": (x, info)}])
+        elif self._cstr:
+            res = opt.minimize(self._cost_fcn_and_jac, self.initial_guess, args=(x, info), jac=True, bounds=self.bounds,
+                               method="SLSQP", options=self.minimize_options or {"maxiter": 200, "ftol": 1e-9},
+                               constraints=[{"type": "ineq", "fun": self._constraint_fcn, "jac": self._constraint_jac,
                                              "args": (x, info)}])
         else:
             res = opt.minimize(self._cost_fcn_and_jac, self.initial_guess, args=(x, info), jac=True, bounds=self.bounds,

@@ -235,6 +235,10 @@ typedef struct GopsRolloutIn {
                                  draws of every rollout step, exactly what np.random.normal returns inside Robot.f_xu(.., "obs")
                                  (pyth_mobilerobot_model.py:143-167; the model adds 0.5 x draw to the obstacle's v / w).  Must stay
                                  valid until the backward call (d x' / d theta of the obstacle depends on it). */
+    const float* grad_constraint_step; /* ABI v9, backward calls of the models with constraint outputs, or NULL (= zeros): [H, B, n_constraint]
+                                 d(loss)/d(c_tk) for the per-step constraint values of GopsRolloutOut.constraints - a caller that needs
+                                 the Jacobian of the constraint path (OptController's inequality constraints, gops/sys_simulator/
+                                 opt_controller.py:178-206) replicates the trajectory once per row and seeds one unit entry each */
 } GopsRolloutIn;
 
 typedef struct GopsRolloutOut {
@@ -254,6 +258,9 @@ typedef struct GopsRolloutOut {
      *   rows 0 .. n_constraint-1        P_k = prod_t Phi(c_tk),  Phi(y) = 1.07 / (1 + 0.0315 exp(clamp(y / 0.07, -10, 5)))
      *   rows n_constraint .. 2 n_c - 1  prod_t [c_tk <= 0]       (trajectory safe w.r.t. constraint k: 0 / 1) */
     float* constraint_prods;
+    /* ABI v9, same models, or NULL: [H, B, n_constraint] the UNMASKED info["constraint"] the model returns at every step
+     * (errcstr models: of the observation the step STARTS from; surrcstr / detour / mobilerobot: of the NEW state) */
+    float* constraints;
 } GopsRolloutOut;
 
 int gops_hip_version(void);
@@ -322,6 +329,13 @@ typedef struct GopsStepIO {
     const float* noise;          /* ABI v9, GOPS_ENV_MOBILEROBOT, or NULL (= zeros): [B, 2] this step's obstacle draws (GopsRolloutIn.noise) */
 } GopsStepIO;
 int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream);
+
+/* model.get_constraint(obs, info) (ABI v9; gops/env/env_ocp/env_model/pyth_base_model.py:69-75 - the hook OptController evaluates on
+ * every state of its prediction, opt_controller.py:178-198): io->constraint [B, n_constraint] of the given io->obs (errcstr models:
+ * pyth_veh3dofconti_errcstr_model.py:49-56, pyth_veh2dofconti_errcstr_model.py:47-51) or of the given io->state / io->surr_state
+ * (pyth_veh3dofconti_surrcstr_model.py:98-148, _detour_model.py:102-151, _surrcstr_penalty_model.py:183-234).  Nothing else of
+ * `io` is read or written.  GOPS_ERR_UNSUPPORTED for models that define no get_constraint. */
+int gops_env_constraint(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void* stream);
 
 /* StateValue batch evaluation v = V(obs) with stash, and its backward into V's parameters. */
 size_t gops_value_workspace_bytes(const GopsMlp* value, int32_t batch);

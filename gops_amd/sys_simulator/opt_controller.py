@@ -22,7 +22,7 @@ rollout launch (batch = control points, horizon = ctrl_interval), the cost gradi
 launch of `gops_rollout_backward_open_loop_adj` (ABI v8), and the transition Jacobian one forward + one backward launch over
 obs_dim replicas of every interval, each seeded with one unit vector on its final state.  Solver: scipy's SLSQP with the
 equality constraints and the box bounds on actions and states.  Collocation needs a model whose observation IS its state
-and whose `forward` takes no `info` (pyth_lq, pyth_idpendulum, gym_cartpoleconti, gym_pendulum) - for the others the
+and whose `forward` takes no `info` (pyth_lq, pyth_idpendulum, gym_cartpoleconti, gym_pendulum, pyth_mobilerobot) - for the others the
 reference itself drops to its step-by-step rollout (:292-294); use `mode="shooting"` for them here.
 
 Path constraints (`model.get_constraint`, :178-206: the reference evaluates it on all T + 1 states of the prediction and hands
@@ -32,9 +32,14 @@ rollout launch (`GopsRolloutOut.constraints`; the state the kernel does not emit
 models - comes from `gops_env_constraint`), and the Jacobian is one forward + one backward launch over T n_constraint replicas
 of the trajectory, replica (t, k) seeded with a unit d/d c_tk (`GopsRolloutIn.grad_constraint_step`).  Solver: SLSQP.
 
-Not provided: user terminal-cost callbacks (a Python function cannot run inside the kernel), and the constraint of the
-surrcstr_penalty model (its info["constraint"] is computed on detached copies and carries no gradient).
+`use_terminal_cost` (:84-98, 312-317): `terminal_cost(state_T)` (the given torch function, else `model.get_terminal_cost` -
+pyth_lq's x'Px) is evaluated with autograd on the device between the forward and the backward launch; its gradient seeds the
+sweep through `grad_final_obs` (models whose observation is the state).
+
+Not provided: the constraint of the surrcstr_penalty model (its info["constraint"] is computed on detached copies and carries
+no gradient).
 """
+import warnings
 from typing import Dict, Optional
 
 import numpy as np
@@ -44,6 +49,8 @@ import torch
 from gops_amd import hip_backend as hb
 
 _INFO = ("state", "ref_points", "path_num", "u_num", "ref_time", "surr_state")
+# models whose observation is the state: adjoint I/O around the rollout (gops_rollout_backward_open_loop_adj)
+_STATE_OBS_KINDS = (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_CARTPOLE, hb.ENV_PENDULUM, hb.ENV_MOBILEROBOT)
 
 
 class OptController:
@@ -51,11 +58,18 @@ class OptController:
                  use_terminal_cost: bool = False, terminal_cost=None, minimize_options: Optional[dict] = None,
                  verbose: int = 0, mode: str = "collocation", device=None):
         assert mode in ("shooting", "collocation")
-        if use_terminal_cost or terminal_cost is not None:
-            raise NotImplementedError("terminal-cost callbacks cannot run inside the rollout kernel")
         assert num_pred_step % ctrl_interval == 0, "ctrl_interval should be a factor of num_pred_step."
         base = model.unwrapped
         self.model, self.base = model, base
+        self.terminal_cost = None
+        if use_terminal_cost:   # (:84-98) the given function, else the model's own
+            self.terminal_cost = terminal_cost if terminal_cost is not None else getattr(model, "get_terminal_cost", None)
+            assert self.terminal_cost is not None, "Choose to use terminal cost, but there is no available terminal cost function."
+            if base.hip_kind not in _STATE_OBS_KINDS:
+                raise NotImplementedError("a terminal cost needs the adjoint of the final observation, which the kernels provide for "
+                                          "the models whose observation is the state")
+        elif terminal_cost is not None:
+            warnings.warn("Choose not to use terminal cost, but a terminal cost function is given. This will be ignored.")
         self.obs_dim, self.action_dim, self.sim_dt = base.obs_dim, base.action_dim, base.dt
         self.gamma, self.ctrl_interval, self.num_pred_step = gamma, ctrl_interval, num_pred_step
         self.num_ctrl_points = num_pred_step // ctrl_interval
@@ -65,10 +79,10 @@ class OptController:
         lo = base.action_lower_bound.cpu().numpy().astype(np.float64)
         hi = base.action_upper_bound.cpu().numpy().astype(np.float64)
         if mode == "collocation":
-            if base.hip_kind not in (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_CARTPOLE, hb.ENV_PENDULUM):
+            if base.hip_kind not in _STATE_OBS_KINDS:
                 raise NotImplementedError(
                     "mode='collocation' batches the intervals, which needs a model whose observation is its state and whose "
-                    "forward takes no info (pyth_lq, pyth_idpendulum, gym_cartpoleconti, gym_pendulum); the reference itself "
+                    "forward takes no info (pyth_lq, pyth_idpendulum, gym_cartpoleconti, gym_pendulum, pyth_mobilerobot); the reference itself "
                     "falls back to a step-by-step rollout for the others (opt_controller.py:292-294) - use mode='shooting'")
             lo = np.concatenate((lo, base.obs_lower_bound.cpu().numpy().astype(np.float64)))
             hi = np.concatenate((hi, base.obs_upper_bound.cpu().numpy().astype(np.float64)))
@@ -130,16 +144,28 @@ class OptController:
         acts = z[:, :A].unsqueeze(1).expand(n, ci, A).contiguous()
         return z, starts, acts
 
+    def _col_data(self, starts: torch.Tensor) -> Dict:
+        data = {"obs": starts, "done": torch.zeros(starts.shape[0], dtype=torch.float32, device=self.device)}
+        if self.base.hip_kind == hb.ENV_MOBILEROBOT:   # a deterministic cost: the obstacle follows its expected motion
+            data["noise"] = torch.zeros(self.ctrl_interval, starts.shape[0], 2, dtype=torch.float32, device=self.device)
+        return data
+
     def _col_cost_and_jac(self, inputs: np.ndarray, x, info: Dict):
         n, A, O = self.num_ctrl_points, self.action_dim, self.obs_dim
         self.system_simulations += 1
         z, starts, acts = self._col_split(inputs, x)
-        res = self._col.forward({"obs": starts, "done": torch.zeros(n, dtype=torch.float32, device=self.device)}, head_pre=acts)
-        g_act, g_obs = self._col.backward_open_loop_adj(self._col_w)
+        res = self._col.forward(self._col_data(starts), head_pre=acts, want_final=self.terminal_cost is not None)
+        cost = (self._col_w * res["v_pi"]).sum()
+        gfo = None
+        if self.terminal_cost is not None:      # on the true final state of the last interval (:312-317)
+            tc, g_last = self._terminal(res["final_obs"][-1])
+            cost = cost + tc
+            gfo = torch.zeros(n, O, dtype=torch.float32, device=self.device)
+            gfo[-1] = g_last
+        g_act, g_obs = self._col.backward_open_loop_adj(self._col_w, grad_final_obs=gfo)
         jac = torch.zeros(n, A + O, dtype=torch.float32, device=self.device)
         jac[:, :A] = g_act.sum(1)               # the action of a point is held over its interval
         jac[:-1, A:] = g_obs[1:]                # the state of point j starts interval j + 1
-        cost = (self._col_w * res["v_pi"]).sum()
         return float(cost.item()), jac.reshape(-1).double().cpu().numpy()
 
     def _trans_constraint_fcn(self, inputs: np.ndarray, x, info: Dict) -> np.ndarray:
@@ -147,8 +173,7 @@ class OptController:
         n, A = self.num_ctrl_points, self.action_dim
         self.constraint_evaluations += 1
         z, starts, acts = self._col_split(inputs, x)
-        res = self._col.forward({"obs": starts, "done": torch.zeros(n, dtype=torch.float32, device=self.device)}, head_pre=acts,
-                                want_final=True)
+        res = self._col.forward(self._col_data(starts), head_pre=acts, want_final=True)
         return (res["final_obs"] - z[:, A:]).reshape(-1).double().cpu().numpy()
 
     def _trans_constraint_jac(self, inputs: np.ndarray, x, info: Dict) -> np.ndarray:
@@ -158,7 +183,7 @@ class OptController:
         n, A, O, ci = self.num_ctrl_points, self.action_dim, self.obs_dim, self.ctrl_interval
         z, starts, acts = self._col_split(inputs, x)
         rep = lambda t: t.repeat_interleave(O, dim=0).contiguous()
-        self._col_jac.forward({"obs": rep(starts), "done": self._zeros_nO}, head_pre=rep(acts))
+        self._col_jac.forward(self._col_data(rep(starts)), head_pre=rep(acts))
         g_act, g_obs = self._col_jac.backward_open_loop_adj(self._zeros_nO, grad_final_obs=self._eye_rep)
         g_act = g_act.sum(1).reshape(n, O, A).double().cpu().numpy()       # [j, k, a] = d state_j[k] / d action_j[a]
         g_obs = g_obs.reshape(n, O, O).double().cpu().numpy()              # [j, k, i] = d state_j[k] / d start_j[i]
@@ -198,10 +223,24 @@ class OptController:
     def _cost_fcn_and_jac(self, inputs: np.ndarray, x, info: Dict):
         """Value and Jacobian of the cost: one forward and one backward launch."""
         self.system_simulations += 1
-        res = self._rollout_obj.forward(self._batch(x, info), head_pre=self._actions(inputs))
-        g = self._rollout_obj.backward_open_loop(self._minus_one)        # d(-v_pi)/d(action) [1, T, A]
+        res = self._rollout_obj.forward(self._batch(x, info), head_pre=self._actions(inputs), want_final=self.terminal_cost is not None)
+        cost = -res["v_pi"][0]
+        if self.terminal_cost is not None:   # + gamma^T terminal_cost(state_T) (:312-317), its gradient seeds the sweep
+            tc, gfo = self._terminal(res["final_obs"][0])
+            cost = cost + tc
+            g, _ = self._rollout_obj.backward_open_loop_adj(self._minus_one, grad_final_obs=gfo.reshape(1, -1).contiguous())
+        else:
+            g = self._rollout_obj.backward_open_loop(self._minus_one)    # d(-v_pi)/d(action) [1, T, A]
         jac = g.reshape(self.num_ctrl_points, self.ctrl_interval, self.action_dim).sum(1).reshape(-1)
-        return float(-res["v_pi"][0].item()), jac.double().cpu().numpy()
+        return float(cost.item()), jac.double().cpu().numpy()
+
+    def _terminal(self, final_obs: torch.Tensor):
+        """(gamma^T terminal_cost(state_T), its gradient w.r.t. state_T): the user's / model's torch function, evaluated with
+        autograd on the device between the forward and the backward launch."""
+        xT = final_obs.detach().clone().requires_grad_(True)
+        tc = self.terminal_cost(xT) * (self.gamma ** self.num_pred_step)
+        (g,) = torch.autograd.grad(tc, xT)
+        return tc.detach(), g.to(torch.float32)
 
     # ---- path constraints (shooting): -get_constraint(state_t, info_t) >= 0 for t = 0 .. T -----------------------
     def _cstr_actions(self, inputs: np.ndarray) -> torch.Tensor:

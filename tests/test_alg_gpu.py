@@ -617,6 +617,65 @@ def test_opt_controller_solves_lq_regulation():
     assert norms[-1] < 0.8 * norms[0] and all(b < a + 1e-6 for a, b in zip(norms, norms[1:])), norms   # 2.5 s of a slow plant
 
 
+@pytest.mark.gpu
+def test_opt_controller_terminal_cost():
+    """use_terminal_cost (opt_controller.py:84-98, 312-317): pyth_lq's own x'Px and a user-supplied torch function on
+    pyth_idpendulum - cost and Jacobian against the oracle's rollout + autograd, shooting and collocation; the warning /
+    assertion behaviour of the reference's constructor."""
+    from gops_amd.create_pkg.create_env_model import create_env_model
+    from gops_amd.sys_simulator.opt_controller import OptController
+    from gops_amd.utils.synthetic import make_batch
+    from oracle import adp_oracle as orc
+    T, ci, gamma = 12, 3, 0.97
+    user_tc = lambda s: 3.0 * (s[1:3] ** 2).sum() + 0.1 * torch.sin(s[0]) ** 2
+    for cfg, tc in ((dict(env_id="pyth_lq", lq_config="s4a2"), None), (dict(env_id="pyth_idpendulum"), user_tc)):
+        model = create_env_model(**cfg, use_gpu=True)
+        env = orc.make_env(cfg["env_id"], lq_config=cfg.get("lq_config", "s4a2"))
+        data = make_batch(dict(cfg, batch=2), 9)
+        if tc is None:
+            P = torch.as_tensor(model.unwrapped.dynamics.P, dtype=torch.float32)
+            want_tc = lambda s: s @ P @ s.T
+        else:
+            want_tc = tc
+        sho = OptController(model, num_pred_step=T, ctrl_interval=ci, gamma=gamma, mode="shooting", use_terminal_cost=True, terminal_cost=tc)
+        plain = OptController(model, num_pred_step=T, ctrl_interval=ci, gamma=gamma, mode="shooting")
+        rng = np.random.RandomState(2)
+        for b in range(2):
+            u = rng.uniform(0.5 * sho.bounds.lb, 0.5 * sho.bounds.ub)
+            x = data["obs"][b].numpy()
+            cost, jac = sho._cost_fcn_and_jac(u, x, {})
+            acts = torch.tensor(u, dtype=torch.float32).reshape(T // ci, -1).repeat_interleave(ci, 0)[None]
+            want_cost, _, want_jac = orc.raw_shooting_cost(env, data["obs"][b:b + 1], {}, acts, gamma, terminal=want_tc)
+            assert abs(cost - want_cost.item()) <= 1e-4 * max(1.0, abs(want_cost.item())), (cfg, cost, want_cost)
+            want = want_jac[0].reshape(T // ci, ci, -1).sum(1).reshape(-1)
+            assert rel_l2(jac, want) < 1e-4, (cfg, rel_l2(jac, want))
+            assert abs(cost - plain._cost_fcn_and_jac(u, x, {})[0]) > 1e-6      # the terminal term is really there
+        # collocation: the terminal cost sits on the true final state of the last interval
+        n, A, O = T // ci, sho.action_dim, sho.obs_dim
+        col = OptController(model, num_pred_step=T, ctrl_interval=ci, gamma=gamma, use_terminal_cost=True, terminal_cost=tc)
+        z = torch.tensor(rng.uniform(-0.3, 0.3, size=(n, A + O)), dtype=torch.float32)
+        x0 = data["obs"][0]
+        cost, jac = col._col_cost_and_jac(z.reshape(-1).numpy(), x0.numpy(), {})
+        step = (lambda o, a: orc.lq_step(env["lq"], o, a)) if env["kind"] == "lq" else (lambda o, a: orc.idp_step(o, a))
+        zf = z.reshape(-1).clone().requires_grad_(True)
+        zz = zf.reshape(n, A + O)
+        xs, want_cost = torch.cat((x0.reshape(1, O), zz[:-1, A:]), 0), torch.zeros(())
+        for i in range(ci):
+            xs, r, _ = step(xs, zz[:, :A])
+            want_cost = want_cost - (r * gamma ** (torch.arange(n, dtype=torch.float32) * ci + i)).sum()
+        want_cost = want_cost + want_tc(xs[-1]) * gamma ** T
+        (want_jac,) = torch.autograd.grad(want_cost, zf)
+        assert abs(cost - want_cost.item()) <= 1e-4 * max(1.0, abs(want_cost.item()))
+        assert rel_l2(jac, want_jac) < 1e-4, (cfg, "collocation", rel_l2(jac, want_jac))
+    with pytest.raises(AssertionError, match="no available terminal cost"):
+        OptController(create_env_model("pyth_idpendulum", use_gpu=True), num_pred_step=4, use_terminal_cost=True)
+    with pytest.warns(UserWarning, match="will be ignored"):
+        OptController(create_env_model("pyth_idpendulum", use_gpu=True), num_pred_step=4, terminal_cost=user_tc)
+    with pytest.raises(NotImplementedError):
+        OptController(create_env_model("pyth_veh3dofconti", pre_horizon=10, use_gpu=True), num_pred_step=4, mode="shooting",
+                      use_terminal_cost=True, terminal_cost=user_tc)
+
+
 def _oracle_collocation(env, x, z, n, ci, A, O, gamma):
     """The reference's collocation rollout in batch mode (opt_controller.py:272-291, 196-215, 302-318) on the oracle's raw model
     steps: cost and transition residuals of the decision vector z [n, A + O], with autograd Jacobians."""

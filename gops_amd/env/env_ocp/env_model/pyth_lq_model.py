@@ -69,7 +69,7 @@ class LqModel(PythBaseModel):
 
     def get_terminal_cost(self, obs: torch.Tensor) -> torch.Tensor:
         P = torch.as_tensor(self.dynamics.P, dtype=torch.float32, device=obs.device)
-        return obs @ P @ obs.T
+        return obs @ P @ (obs.T if obs.dim() == 2 else obs)   # (lq_base.py:356-357; .T of a 1-D tensor is the tensor itself)
 
 
 def env_model_creator(**kwargs):

@@ -314,7 +314,10 @@ def has_constraints(env: GopsEnv) -> bool:
 def mobilerobot_noise(shape, device) -> torch.Tensor:
     """The obstacle robot's noise draws of `shape` = (..., 2): N(0, 0.03) for v, N(0, 0.02) for w - what
     np.random.normal hands Robot.f_xu(.., "obs") every step (pyth_mobilerobot_model.py:141-167), drawn on the device."""
-    return torch.randn(*shape, dtype=torch.float32, device=device) * torch.tensor(MOBILEROBOT_NOISE_STD, dtype=torch.float32, device=device)
+    n = torch.randn(*shape, dtype=torch.float32, device=device)
+    n[..., 0] *= MOBILEROBOT_NOISE_STD[0]   # (scalar kernel arguments: no host-to-device copy, so a HIP-graph capture of the
+    n[..., 1] *= MOBILEROBOT_NOISE_STD[1]   #  caller stays legal and every replay draws fresh numbers from the captured generator)
+    return n
 
 
 class Rollout:

@@ -254,3 +254,27 @@ def test_wrapped_model_forward_draws_noise_on_the_device():
     o3, _, _, _ = model.forward(obs, act, done, dict(noise=torch.zeros(64, 2, device="cuda")))
     ref, _, _, _ = orc.env_forward(orc.make_env("pyth_mobilerobot"), data["obs"], act.cpu(), data["done"], dict(noise=torch.zeros(1, 64, 2)))
     np.testing.assert_allclose(o3.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_graph_replay_draws_fresh_noise(monkeypatch):
+    """FHADPExterior on pyth_mobilerobot with the update captured into a HIP graph: the capture succeeds (the noise draw makes
+    no host-to-device copy) and every replay moves the obstacle with new draws (the loss of the same batch changes)."""
+    import warnings
+    from gops_amd.create_pkg.create_alg import create_alg
+    from gops_amd.utils.synthetic import make_batch
+    from test_alg_gpu import _kwargs
+    monkeypatch.setenv("GOPS_HIP_GRAPH", "1")
+    cfg = dict(alg="FHADPExterior", env_id="pyth_mobilerobot", batch=64, horizon=8, hidden=(64, 64), act="elu", gamma=0.98)
+    kw = _kwargs(cfg, dict(penalty=3.0), 5)
+    kw.update(policy_func_name="FiniteHorizonPolicy", pre_horizon=8, policy_learning_rate=0.0)   # frozen weights: only the noise changes
+    alg = create_alg(**kw)
+    alg.networks.cuda()
+    data = make_batch(cfg, 3)
+    losses = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")            # "HIP graph capture failed" would be a warning
+        for it in range(6):
+            tb = alg.local_update(data, it)
+            losses.append(float(tb["Loss/Actor loss-RL iter"]))
+    assert alg._update_graph.graph is not None
+    assert all(np.isfinite(losses)) and len(set(losses[3:])) == 3, losses

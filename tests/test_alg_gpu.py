@@ -634,7 +634,7 @@ def test_opt_controller_terminal_cost():
         data = make_batch(dict(cfg, batch=2), 9)
         if tc is None:
             P = torch.as_tensor(model.unwrapped.dynamics.P, dtype=torch.float32)
-            want_tc = lambda s: s @ P @ s.T
+            want_tc = lambda s: s @ P @ s
         else:
             want_tc = tc
         sho = OptController(model, num_pred_step=T, ctrl_interval=ci, gamma=gamma, mode="shooting", use_terminal_cost=True, terminal_cost=tc)

@@ -111,6 +111,8 @@ def test_weight_gradient_gemm_redoes_saturated_blocks_exactly(dev, monkeypatch):
     second launch redoes the GEMM with the exact three-plane split.  A policy whose first layer is scaled up so that H_1
     reaches ~1e5 must still meet the 1e-4 bar against the oracle (and it does not with the guard disabled: that is what
     GOPS_DW_NOGUARD=1 is for)."""
+    for knob in ("GOPS_DW_EXACT", "GOPS_DW_F32", "GOPS_DW_NOGUARD"):   # the test is about the default two-half-plane GEMM
+        monkeypatch.delenv(knob, raising=False)
     cfg = dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=64, horizon=3, hidden=(256, 256), act="relu", gamma=0.99)
     data = make_batch(cfg, 21)
     nets = reference_init_nets(cfg, 21, obs_dim_of(cfg), act_dim_of(cfg))

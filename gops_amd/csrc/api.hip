@@ -12,7 +12,7 @@
 #include "common.h"
 
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);
-hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);
+hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream);
 size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int split_k0);
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split);
 bool split_eligible(const RolloutParams& p);
@@ -434,10 +434,25 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
         p.sp.out_part = plan.dw_part[p.pol.nl - 1];
         p.sp.out_part_b = plan.dw_part_b[p.pol.nl - 1];
     }
-    if ((e = launch_upload_params(p, plan.dev_params, s)) != hipSuccess) return (int)e;
+    // What this call adds to the forward's device copy of the parameter block travels as a kernel argument (BwdPatch);
+    // only the half sweep, which needs max|grad_v| before it starts, still takes the upload launch.
+    BwdPatch q;
+    memset(&q, 0, sizeof(q));
+    q.in = in;
+    q.grad_v = grad_v;
+    q.g_head_pre = g_head_pre;
+    q.ext_delta = ext_delta;
+    q.adj_gfo = p.adj_gfo;
+    q.adj_gobs = p.adj_gobs;
+    q.adj_first_only = p.adj_first_only;
+    q.out_part = p.sp.out_part;
+    q.out_part_b = p.sp.out_part_b;
+    q.dbg = p.dbg;
+    static const bool force_upload = getenv("GOPS_BWD_UPLOAD") != nullptr;   // measurement knob: the pre-patch launch sequence
+    if ((p.f16 || force_upload) && (e = launch_upload_params(p, plan.dev_params, s)) != hipSuccess) return (int)e;
     {
         ProfScope scope(desc.env.kind == GOPS_ENV_NONE ? 4 : 1, s);
-        if ((e = launch_rollout_bwd(p, plan.dev_params, s)) != hipSuccess) return (int)e;
+        if ((e = launch_rollout_bwd(p, plan.dev_params, q, s)) != hipSuccess) return (int)e;
     }
     if (dbg) {
         unsigned long long h[16];

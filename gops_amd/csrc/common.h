@@ -130,6 +130,26 @@ struct RolloutParams {
     SplitDev sp;                      // plane-split contractions of the stationary fp32 kernels
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double
 };
+
+// What a backward launch knows that the forward's device copy of RolloutParams does not: handed to the sweep by value
+// (pointers and two ints: scalar registers straight from the kernel-argument segment), so that no upload launch has to
+// sit between the forward pass and the sweep.  The fp32 sweeps also fold max|grad_v| into gscale[0] themselves (one
+// atomicMax per tile) - the weight-gradient GEMMs read it after the sweep; the half sweeps need it BEFORE they start and
+// keep the upload kernel.
+struct BwdPatch {
+    GopsRolloutIn in;                 // the backward call's inputs (grad_constraint*, noise, head_pre, ...)
+    const float* grad_v;
+    float* g_head_pre;
+    const float* ext_delta;
+    const float* adj_gfo;
+    float* adj_gobs;
+    int adj_first_only;
+    int pad_;
+    float* out_part;
+    float* out_part_b;
+    unsigned long long* dbg;
+};
+
 // upload_params_kernel / prologue_kernel take the block BY VALUE: it has to fit the 4 KiB kernel-argument segment
 static_assert(sizeof(RolloutParams) <= 3840, "RolloutParams outgrew the kernel-argument segment (move gpow[] out)");
 

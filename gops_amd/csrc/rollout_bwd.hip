@@ -326,7 +326,7 @@ struct NoSweep {};
 // SPLIT: plane-split contractions (SplitSweep; SK1 > 0, PT0 = n-tiles of g_x per wave)
 // MULTI (SPLIT only): more tiles than workgroups - grid-stride walk over the tiles
 template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, bool EXT = false, bool SPLIT = false, bool MULTI = false>
-__global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1)) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp) {
+__global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1)) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp, const BwdPatch q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;
     const int tid = threadIdx.x;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     if constexpr (SPLIT) SS.load(p, tid, reinterpret_cast<f16x8*>(s_stage + 2 * (TB * ENV_STASH + TB * 8)));
 
     DbgClock dbg;
-    dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
+    dbg.init((q.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
     // One-workgroup-per-CU variants: everything step tt reads from the stash - the H_2 / H_1 tiles the
     // head and the layer-1 epilogue take act' from (Z for GELU), the env rows and the first 8 columns of
     // the observation rows - is fetched straight into LDS (global_load_lds: no VGPRs) ONE STEP AHEAD, into
@@ -423,31 +423,36 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     nvalid = min(TB, p.B - b0);
     for (int idx = tid; idx < TB * ldx; idx += NTHREADS) G[idx] = 0.f;
     if constexpr (EXT) {
-        if (p.adj_gfo != nullptr) {   // the caller's terminal term: G starts as d(loss)/d(obs_H)
+        if (q.adj_gfo != nullptr) {   // the caller's terminal term: G starts as d(loss)/d(obs_H)
             __syncthreads();
             for (int idx = tid; idx < nvalid * O; idx += NTHREADS) {
                 const int m = idx / O, i = idx - m * O;
-                G[m * ldx + i] = gptr(p.adj_gfo)[(size_t)(b0 + m) * O + i];
+                G[m * ldx + i] = gptr(q.adj_gfo)[(size_t)(b0 + m) * O + i];
             }
         }
     }
-    float gv = (tid < nvalid) ? gptr(p.grad_v)[b0 + tid] : 0.f;
-    if constexpr (F16) gv *= f16_grad_scale(gptr(p.gscale)[0]);
+    float gv = (tid < nvalid) ? gptr(q.grad_v)[b0 + tid] : 0.f;
+    if constexpr (F16) {
+        gv *= f16_grad_scale(gptr(p.gscale)[0]);
+    } else if (tid < TB && p.gscale != nullptr) {   // max|grad_v| of the launch for the weight-gradient GEMMs' delta scale
+        const float mx = row16_max(fabsf(gv));
+        if (tid == 0 && mx < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(p.gscale), __float_as_uint(mx));
+    }
     float gc_ext = 0.f, gc_lin = 0.f, gc_int = 0.f;   // SURR: d(loss)/d(constraint sums) of trajectory tid
-    if (CSTR && tid < nvalid && p.in.grad_constraint != nullptr) {
-        const GLOBAL_AS float* gcp = gptr(p.in.grad_constraint) + b0 + tid;
+    if (CSTR && tid < nvalid && q.in.grad_constraint != nullptr) {
+        const GLOBAL_AS float* gcp = gptr(q.in.grad_constraint) + b0 + tid;
         gc_ext = gcp[0]; gc_lin = gcp[(size_t)p.B]; gc_int = gcp[(size_t)2 * p.B];
     }
     float gc_mul[GOPS_MAX_CONSTRAINT] = {0.f, 0.f, 0.f};   // SPIL: d(loss)/d(P_k) * P_k of trajectory tid
-    if (CSTR && tid < nvalid && p.in.grad_constraint_prod != nullptr) {
+    if (CSTR && tid < nvalid && q.in.grad_constraint_prod != nullptr) {
 #pragma unroll
         for (int k = 0; k < GOPS_MAX_CONSTRAINT; ++k)
-            if (k < p.env.n_constraint) gc_mul[k] = gptr(p.in.grad_constraint_prod)[(size_t)k * p.B + b0 + tid];
+            if (k < p.env.n_constraint) gc_mul[k] = gptr(q.in.grad_constraint_prod)[(size_t)k * p.B + b0 + tid];
     }
     // d(loss)/d(c_tk) handed in per step (GopsRolloutIn.grad_constraint_step), trajectory m of this tile
     auto gc_step = [&](int t, int m, int k) -> float {
-        if (!CSTR || p.in.grad_constraint_step == nullptr) return 0.f;
-        return gptr(p.in.grad_constraint_step)[((size_t)t * p.B + b0 + m) * p.env.n_constraint + k];
+        if (!CSTR || q.in.grad_constraint_step == nullptr) return 0.f;
+        return gptr(q.in.grad_constraint_step)[((size_t)t * p.B + b0 + m) * p.env.n_constraint + k];
     };
     float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // adjoint of the veh3dof state (tid < TB)
     if (REF) {
@@ -812,8 +817,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                     th[0] = e0[0]; th[1] = e0[1]; dflag = e1[0];
 #pragma unroll
                     for (int i = 0; i < MOB_OBS; ++i) x[i] = x_col(row0, m, i);
-                    if (p.in.noise != nullptr) {
-                        const GLOBAL_AS float* nz = gptr(p.in.noise) + ((size_t)t * p.B + b0 + m) * 2;
+                    if (q.in.noise != nullptr) {
+                        const GLOBAL_AS float* nz = gptr(q.in.noise) + ((size_t)t * p.B + b0 + m) * 2;
                         nv = nz[0]; nw = nz[1];
                     }
                 }
@@ -1123,7 +1128,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         DBG_TICK(1)
         if constexpr (SPLIT) {
             SS.run(p, s_gy, s_scale, dq2, dq1, G, ldx, tid, row0, nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up,
-                   p.sp.out_part != nullptr);
+                   q.out_part != nullptr);
         } else
         if (!p.open_loop) {
             if constexpr (F16)
@@ -1131,17 +1136,17 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                                tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, [] {});
             else
             if constexpr (EXT) {
-                const bool keep = !(p.adj_first_only && t > 0);   // later steps act through the frozen policy copy
+                const bool keep = !(q.adj_first_only && t > 0);   // later steps act through the frozen policy copy
                 mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z,
                              keep ? p.st.d : nullptr, keep ? p.st.dy : nullptr, row0, nvalid,
-                             /*want_gx=*/(t > 0 && ENV != GOPS_ENV_NONE) || p.adj_gobs != nullptr, O, dbg, warm_up, st_cur,
-                             st_cur + TB * 256, ENV == GOPS_ENV_NONE ? p.ext_delta : nullptr);
+                             /*want_gx=*/(t > 0 && ENV != GOPS_ENV_NONE) || q.adj_gobs != nullptr, O, dbg, warm_up, st_cur,
+                             st_cur + TB * 256, ENV == GOPS_ENV_NONE ? q.ext_delta : nullptr);
             } else
             mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
                          nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up, st_cur, st_cur + TB * 256,
-                         ENV == GOPS_ENV_NONE ? p.ext_delta : nullptr);
+                         ENV == GOPS_ENV_NONE ? q.ext_delta : nullptr);
         } else if (tid < nvalid) {   // open loop: the head adjoint IS the result; no policy input adjoint
-            GLOBAL_AS float* gp = gptr(p.g_head_pre) + ((size_t)(b0 + tid) * p.H + t) * A;
+            GLOBAL_AS float* gp = gptr(q.g_head_pre) + ((size_t)(b0 + tid) * p.H + t) * A;
 #pragma unroll
             for (int a = 0; a < GOPS_MAX_ACT; ++a)
                 if (a < A) gp[a] = s_gy[tid * 4 + a];
@@ -1154,20 +1159,20 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         __syncthreads();
         DBG_TICK(2)
     }
-    if (l2_sink == 0x9e3779b9u && p.dbg != nullptr) gptr(p.dbg)[15] = l2_sink;   // keeps the warm-up loads alive
+    if (l2_sink == 0x9e3779b9u && q.dbg != nullptr) gptr(q.dbg)[15] = l2_sink;   // keeps the warm-up loads alive
     if constexpr (EXT) {
-        if (p.adj_gobs != nullptr) {   // (the loop's closing barrier made every G update visible)
+        if (q.adj_gobs != nullptr) {   // (the loop's closing barrier made every G update visible)
             for (int idx = tid; idx < nvalid * O; idx += NTHREADS) {
                 const int m = idx / O, i = idx - m * O;
-                gptr(p.adj_gobs)[(size_t)(b0 + m) * O + i] = G[m * ldx + i];
+                gptr(q.adj_gobs)[(size_t)(b0 + m) * O + i] = G[m * ldx + i];
             }
         }
     }
     if constexpr (SPLIT) {
-        if (p.sp.out_part != nullptr && tile + (int)gridDim.x >= ntiles) SS.store_out_grad(p, p.sp.out_part, p.sp.out_part_b, tid);   // after the last tile
+        if (q.out_part != nullptr && tile + (int)gridDim.x >= ntiles) SS.store_out_grad(p, q.out_part, q.out_part_b, tid);   // after the last tile
     }
     } while (SPLIT && MULTI && (tile += gridDim.x) < ntiles);   // (every step ends with a barrier: the next tile's set-up may overwrite G / s_ref)
-    dbg.dump(p.dbg);
+    dbg.dump(q.dbg);
 }
 
 // ref_points: reference-table points per trajectory (veh3dofconti), 30 (= 5 x 24 / 4) for the
@@ -1183,23 +1188,23 @@ int split_grid_limit();   // rollout_fwd.hip: CUs of the device
 
 #define LAUNCH_BWD(ENV, A, B)                                                                            \
     do {                                                                                                 \
-        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, A, B, true>, grid, block, lds, stream, dp);   \
-        else launch_with_lds(rollout_bwd_kernel<ENV, A, B, false>, grid, block, lds, stream, dp);         \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, A, B, true>, grid, block, lds, stream, dp, q);   \
+        else launch_with_lds(rollout_bwd_kernel<ENV, A, B, false>, grid, block, lds, stream, dp, q);         \
     } while (0)
 
 #define LAUNCH_BWD_H(ENV)                                                                                       \
     do {                                                                                                        \
-        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, true>, grid, block, lds, stream, dp); \
-        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, true>, grid, block, lds, stream, dp);       \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, true>, grid, block, lds, stream, dp, q); \
+        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, true>, grid, block, lds, stream, dp, q);       \
     } while (0)
 
 #define LAUNCH_BWD2(ENV, A, B, PT)                                                                          \
     do {                                                                                                    \
-        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, A, B, true, PT>, grid, block, lds, stream, dp);  \
-        else launch_with_lds(rollout_bwd_kernel<ENV, A, B, false, PT>, grid, block, lds, stream, dp);        \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, A, B, true, PT>, grid, block, lds, stream, dp, q);  \
+        else launch_with_lds(rollout_bwd_kernel<ENV, A, B, false, PT>, grid, block, lds, stream, dp, q);        \
     } while (0)
 
-hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
+hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream) {
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
     size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, p.f16 != 0, false);
@@ -1207,13 +1212,13 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
         if (p.f16) return hipErrorInvalidValue;
 #define LAUNCH_BWD_EXT(ENV)                                                                                             \
     do {                                                                                                                \
-        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, false, true>, grid, block, lds, stream, dp);  \
-        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp);        \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, false, true>, grid, block, lds, stream, dp, q);  \
+        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp, q);        \
     } while (0)
         switch (p.env.kind) {
             case GOPS_ENV_NONE:
                 if (p.tail) return hipErrorInvalidValue;
-                launch_with_lds(rollout_bwd_kernel<GOPS_ENV_NONE, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp);
+                launch_with_lds(rollout_bwd_kernel<GOPS_ENV_NONE, 0, 0, false, 1, false, true>, grid, block, lds, stream, dp, q);
                 break;
             case GOPS_ENV_LQ: LAUNCH_BWD_EXT(GOPS_ENV_LQ); break;
             case GOPS_ENV_IDPENDULUM: LAUNCH_BWD_EXT(GOPS_ENV_IDPENDULUM); break;
@@ -1229,10 +1234,10 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, h
 #define LAUNCH_BWD_SPLIT(ENV, PT)                                                                                                  \
     do {                                                                                                                          \
         if (multi) {                                                                                                              \
-            if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, true, PT, false, false, true, true>, grid, block, lds, stream, dp);    \
-            else launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, false, PT, false, false, true, true>, grid, block, lds, stream, dp);          \
-        } else if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, true, PT, false, false, true>, grid, block, lds, stream, dp);    \
-        else launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, false, PT, false, false, true>, grid, block, lds, stream, dp);          \
+            if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, true, PT, false, false, true, true>, grid, block, lds, stream, dp, q);    \
+            else launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, false, PT, false, false, true, true>, grid, block, lds, stream, dp, q);          \
+        } else if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, true, PT, false, false, true>, grid, block, lds, stream, dp, q);    \
+        else launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, false, PT, false, false, true>, grid, block, lds, stream, dp, q);          \
     } while (0)
         const int pt = (p.pol.kp[0] + 63) >> 6;
         const dim3 grid(std::min<int>((p.B + TB - 1) / TB, split_grid_limit()));   // one workgroup per CU, grid-stride over the tiles

@@ -1,0 +1,8 @@
+#!/bin/bash
+root=$(pwd); out=$root/gpurun_out/r03_call16; mkdir -p $out
+for i in 1 2 3; do
+  for v in patch upload; do
+    if [ $v = upload ]; then export GOPS_BWD_UPLOAD=1; else unset GOPS_BWD_UPLOAD; fi
+    timeout 300 python bench.py --no-other-workloads --steps 200 --warmup 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['value']/1e6,2), round(d['ms_per_step'],4), {k: round(x['avg_ms'],4) for k,x in d['kernels_ms'].items()})" | tee -a $out/ab.log
+  done
+done

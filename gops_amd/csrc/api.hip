@@ -120,7 +120,8 @@ DwPlan plan_dw(int N, int Kp, long long S, bool f16 = false) {
     const int tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
     const int sc = f16 ? 64 : DW_SC_HOST;
     const long long chunks = (S + sc - 1) / sc;
-    long long splits = (512 + tiles - 1) / tiles;
+    static const int wg_target = getenv("GOPS_DW_WGS") ? atoi(getenv("GOPS_DW_WGS")) : 512;   // tuning knob: workgroups per GEMM
+    long long splits = (wg_target + tiles - 1) / tiles;
     if (splits > chunks) splits = chunks;
     if (splits < 1) splits = 1;
     d.chunks_per_split = (int)((chunks + splits - 1) / splits);

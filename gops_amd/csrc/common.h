@@ -530,6 +530,102 @@ __device__ __forceinline__ void gemm_split(const char* planes, int rowb, const S
     }
 }
 
+// Plane-split weights of a layer that does NOT stay on the CU (layer 0 of policies with more than 128 inputs: its planes
+// would need 2 x 56 .. 64 KiB beside layer 1's 256 registers): the fragments stream from L2 - every CU of an XCD reads the
+// same <= 256 KiB, so they are L2 hits - two n-tiles at a time through a ring of PF chunks per wave (PF x 2 x 2 fragments =
+// 48 registers).  prime() issues the first PF chunks of a pair of n-tiles; gemm_split consumes chunk c and refills its slot
+// with chunk c + PF right behind the MFMAs that read it.  Same packed layout as StatQ::load reads.
+#define GOPS_SPLIT_PF 3
+template <int KCH>
+struct StreamRing {
+    static constexpr int PF = GOPS_SPLIT_PF < KCH ? GOPS_SPLIT_PF : KCH;
+    bf16x8 w[PF][2];
+    f16x8 r[PF][2];
+};
+template <int KCH, int NT>   // NT n-tiles per wave (even), visited as NT / 2 pairs
+struct StreamQ {
+    // (uniform base pointers + 32-bit per-lane fragment indices: the loads take the scalar-base addressing form; per-lane
+    //  64-bit pointers made hipcc precompute one address pair per fragment and spill them)
+    const GLOBAL_AS bf16x8* w1;
+    const GLOBAL_AS f16x8* r;
+    unsigned at[NT];                  // this lane's fragment of chunk 0 of its n-tile j
+    float inv[NT];
+    __device__ __forceinline__ void load(const bf16x8* __restrict__ W1, const f16x8* __restrict__ R, const float* __restrict__ inv_r,
+                                         int nt_tot, int tid) {
+        const int lane = tid & 63, nt0 = (tid >> 6) * NT;
+        w1 = gptr(W1);
+        r = gptr(R);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const bool ok = nt0 + j < nt_tot;   // (a wave's surplus n-tiles compute tile 0 again: their results are not stored)
+            inv[j] = ok ? gptr(inv_r)[nt0 + j] : 0.f;
+            at[j] = (unsigned)((ok ? nt0 + j : 0) * KCH * 64 + lane);
+        }
+    }
+    // The fragment addresses are invariant across the rollout's steps, so hipcc hoists all 2 NT KCH of them (64-bit pairs) out
+    // of the step loop, spills them, and reloads each from scratch in front of its load - behind an s_waitcnt vmcnt(0) that
+    // also drains the ring.  off() hands out the lane's fragment index through an empty asm the optimizer cannot see
+    // through: the address arithmetic (one 32-bit add per fragment) stays next to the load.
+    __device__ __forceinline__ int off(int j) const {
+        int o = (int)at[j];
+        asm volatile("" : "+v"(o));
+        return o;
+    }
+    __device__ __forceinline__ bf16x8 frag_w(int o, int c) const { return *(w1 + o + c * 64); }
+    __device__ __forceinline__ f16x8 frag_r(int o, int c) const { return *(r + o + c * 64); }
+    __device__ __forceinline__ void prime(StreamRing<KCH>& ring, int pair) const {
+        const int o[2] = {off(2 * pair), off(2 * pair + 1)};
+#pragma unroll
+        for (int d = 0; d < StreamRing<KCH>::PF; ++d)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { ring.w[d][j] = frag_w(o[j], d); ring.r[d][j] = frag_r(o[j], d); }
+    }
+};
+
+// n-tiles 2 pair, 2 pair + 1 of the wave: acc / accr are those two tiles' accumulators; the ring must hold the pair's first
+// PF chunks (prime)
+template <int KCH, int NT>
+__device__ __forceinline__ void gemm_split_pair(const char* planes, int rowb, const StreamQ<KCH, NT>& W, StreamRing<KCH>& ring, int pair,
+                                                int lane, f32x4 (&acc)[2], f32x4 (&accr)[2]) {
+    constexpr int PF = StreamRing<KCH>::PF;
+    const int pstride = TB * rowb;
+    const int o[2] = {W.off(2 * pair), W.off(2 * pair + 1)};
+    const char* arow = planes + (lane & 15) * rowb + (lane >> 4) * 16;
+    bf16x8 a1 = *reinterpret_cast<const bf16x8*>(arow), a2 = *reinterpret_cast<const bf16x8*>(arow + pstride);
+    bf16x8 a3 = *reinterpret_cast<const bf16x8*>(arow + 2 * pstride);
+    f16x8 af = *reinterpret_cast<const f16x8*>(arow + 3 * pstride);
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        const int slot = c % PF;
+        bf16x8 n1 = a1, n2 = a2, n3 = a3;
+        f16x8 nf = af;
+        if (c + 1 < KCH) {
+            n3 = *reinterpret_cast<const bf16x8*>(arow + 64 * (c + 1) + 2 * pstride);
+            n2 = *reinterpret_cast<const bf16x8*>(arow + 64 * (c + 1) + pstride);
+            n1 = *reinterpret_cast<const bf16x8*>(arow + 64 * (c + 1));
+            nf = *reinterpret_cast<const f16x8*>(arow + 64 * (c + 1) + 3 * pstride);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, ring.w[slot][j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, ring.w[slot][j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, ring.w[slot][j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accr[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, ring.r[slot][j], accr[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + PF < KCH) {   // refill the slot behind the MFMAs that read it: in flight during the next PF - 1 chunks
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                ring.w[slot][j] = W.frag_w(o[j], c + PF);
+                ring.r[slot][j] = W.frag_r(o[j], c + PF);
+            }
+        }
+        a1 = n1; a2 = n2; a3 = n3; af = nf;
+    }
+}
+
 __device__ __forceinline__ float row16_max(float v) {   // max over each aligned group of 16 lanes, result in every lane
     v = fmaxf(v, dpp_f<0xB1>(v));
     v = fmaxf(v, dpp_f<0x4E>(v));

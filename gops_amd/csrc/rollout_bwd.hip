@@ -171,14 +171,20 @@ struct SplitSweep {
     float dwo[AMAX][4];          // dW_o[a][64 wave + 16 q + (lane & 15)], partial over rows 4 (lane >> 4) .. +3
     float dbo[AMAX];             // d b_o[a], same partial
     StatQ<8, 4, false, GOPS_PIN_MODE> QT1;      // delta_2 -> delta_1 through W_1: both planes in registers
-    StatQ<8, PT0, true> QT0;     // delta_1 -> g_x through W_0: bf16 plane in registers, half residual plane in LDS
+    // delta_1 -> g_x through W_0: bf16 plane in registers, half residual plane in LDS; more than 128 inputs (PT0 > 2 n-tiles
+    // per wave): both planes stream from L2 (StreamQ, common.h)
+    static constexpr bool STREAMT0 = PT0 > 2;
+    static constexpr int PTS = (PT0 + 1) & ~1;   // streamed: n-tiles per wave rounded up to pairs
+    typename std::conditional<STREAMT0, StreamQ<8, PTS>, StatQ<8, PT0, true>>::type QT0;
+    StreamRing<8> ring0;         // (streamed W_0 only)
     float wo[4];                 // W_o[k = lane >> 4][64 wave + 16 q + (lane & 15)]: B operand of the head-delta MFMA
     f32x4 hv[4];                 // act' operands of this lane's four columns: H_2 (Z_2 for GELU) of the step, then H_1
     __device__ __forceinline__ void load(const RolloutParams& p, int tid, f16x8* rt0_lds) {
         const int lane = tid & 63, wave = tid >> 6;
         const MlpDev& M = p.pol;
         QT1.load(p.sp.w1t[1], p.sp.rt[1], p.sp.invt[1], M.dims[1] >> 4, tid);
-        QT0.load(p.sp.w1t[0], p.sp.rt[0], p.sp.invt[0], M.kp[0] >> 4, tid, rt0_lds);
+        if constexpr (STREAMT0) QT0.load(p.sp.w1t[0], p.sp.rt[0], p.sp.invt[0], M.kp[0] >> 4, tid);
+        else QT0.load(p.sp.w1t[0], p.sp.rt[0], p.sp.invt[0], M.kp[0] >> 4, tid, rt0_lds);
         const int K = M.dims[2], A = M.dims[3], kk = lane >> 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) wo[q] = (kk < A) ? gptr(M.w[2])[kk * K + 64 * wave + 16 * q + (lane & 15)] : 0.f;
@@ -283,12 +289,35 @@ struct SplitSweep {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[q][r] = fmaf(accr[q][r], sc, acc[q][r]);
             }
+            if constexpr (STREAMT0) {
+                if (want_gx) QT0.prime(ring0, 0);   // W_0's first chunks travel during delta_1's epilogue
+            }
             finish(1, acc, dq1);
         }
         DBG_TICK(6)
         __syncthreads();
         DBG_TICK(7)
         DBG_TICK(8)
+        if constexpr (STREAMT0) {
+            if (want_gx) {   // ---- g_x = delta_1 W_0 with W_0 streamed: pairs of n-tiles PTS wave + 2 k, + 1 ----
+#pragma unroll
+                for (int k = 0; k < PTS / 2; ++k) {
+                    f32x4 acc[2] = {}, accr[2] = {};
+                    gemm_split_pair(dq1, ROWB, QT0, ring0, k, lane, acc, accr);
+                    if (k + 1 < PTS / 2) QT0.prime(ring0, k + 1);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int n = 16 * (PTS * wave + 2 * k + j) + (lane & 15);
+                        const float sc = QT0.inv[2 * k + j] * inv_s;
+                        if (n < ncols) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) G[(m0 + r) * ldg + n] += fmaf(accr[j][r], sc, acc[j][r]);
+                        }
+                    }
+                }
+                DBG_TICK(9)
+            }
+        } else
         if (want_gx) {   // ---- input adjoint g_x = delta_1 W_0, accumulated into G ----
             f32x4 acc[PT0] = {}, accr[PT0] = {};
             gemm_split(dq1, ROWB, QT0, lane, acc, accr);
@@ -1179,7 +1208,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
 // idpendulum sub-step parking area, else 0
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split) {
     size_t b = sizeof(float) * (size_t)bwd_lds_floats(ldx, ldh, ref_points, f16, split);
-    if (split) b += sizeof(float) * 2 * (TB * ENV_STASH + TB * 8) + (size_t)((ldx - 4) >> 4) * 8 * 1024;   // small staging halves + W_0's residual plane
+    if (split) b += sizeof(float) * 2 * (TB * ENV_STASH + TB * 8) +
+                    (ldx - 4 > 128 ? 0 : (size_t)((ldx - 4) >> 4) * 8 * 1024);   // small staging halves + W_0's residual plane (streamed beyond 128 inputs)
     return b;
 }
 
@@ -1246,6 +1276,13 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
         else if (p.env.kind == GOPS_ENV_IDPENDULUM && pt == 1) LAUNCH_BWD_SPLIT(GOPS_ENV_IDPENDULUM, 1);
         else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && pt == 1) LAUNCH_BWD_SPLIT(GOPS_ENV_VEH3DOFCONTI, 1);
         else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && pt == 2) LAUNCH_BWD_SPLIT(GOPS_ENV_VEH3DOFCONTI, 2);
+#define LAUNCH_BWD_SPLIT_NOTAIL(ENV, PT)                                                                                          \
+    do {                                                                                                                          \
+        if (multi) launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, false, PT, false, false, true, true>, grid, block, lds, stream, dp, q);  \
+        else launch_with_lds(rollout_bwd_kernel<ENV, 8, 8, false, PT, false, false, true>, grid, block, lds, stream, dp, q);       \
+    } while (0)
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && pt == 3 && !p.tail) LAUNCH_BWD_SPLIT_NOTAIL(GOPS_ENV_VEH3DOFCONTI, 3);
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && pt == 4 && !p.tail) LAUNCH_BWD_SPLIT_NOTAIL(GOPS_ENV_VEH3DOFCONTI, 4);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }

@@ -143,14 +143,18 @@ __device__ __forceinline__ void mlp_head(WP Wo, int ldw, BP bo, int K, int A, co
 // loaded once), 16-lane DPP sums give the per-wave partial of each (row, action), and the four waves' partials meet in
 // s_part - H_2 never touches LDS.  Returns the head pre-activation of (trajectory tid >> 4, action tid & 15) for
 // tid & 15 < A (after the barrier that publishes s_part).
+// KC0 > SPLIT_MAX_RESIDENT_KC0: layer 0's planes stream from L2 (StreamQ, common.h)
+#define SPLIT_MAX_RESIDENT_KC0 4
 template <int KC0, int AMAX>   // AMAX: compile-time bound of the action dimension (registers of the head partials)
 struct SplitPolicy {
-    StatQ<KC0, 4, true> Q0;      // layer 0: bf16 plane in registers, half residual plane in LDS
+    static constexpr bool STREAM0 = KC0 > SPLIT_MAX_RESIDENT_KC0;
+    typename std::conditional<STREAM0, StreamQ<KC0, 4>, StatQ<KC0, 4, true>>::type Q0;   // layer 0: bf16 plane in registers, half residual plane in LDS - or both streamed
     StatQ<8, 4, false, GOPS_PIN_MODE> Q1;       // layer 1: both planes in registers
     // r0_lds: LDS region for layer 0's residual plane (16 n-tiles x KC0 chunks x 1 KiB); the caller's barrier publishes it
     __device__ __forceinline__ void load(const RolloutParams& p, int tid, f16x8* r0_lds) {
         const MlpDev& M = p.pol;
-        Q0.load(p.sp.w1[0], p.sp.r[0], p.sp.inv[0], M.dims[1] >> 4, tid, r0_lds);
+        if constexpr (STREAM0) Q0.load(p.sp.w1[0], p.sp.r[0], p.sp.inv[0], M.dims[1] >> 4, tid);
+        else Q0.load(p.sp.w1[0], p.sp.r[0], p.sp.inv[0], M.dims[1] >> 4, tid, r0_lds);
         Q1.load(p.sp.w1[1], p.sp.r[1], p.sp.inv[1], M.dims[2] >> 4, tid);
     }
     // s_bias: [.][ldb] hidden biases; s_wo4: [256][4] head weights, feature-major, rows a >= A zero; s_bo: [4] head bias
@@ -160,6 +164,8 @@ struct SplitPolicy {
         const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
         const MlpDev& M = p.pol;
         constexpr int ROWB1 = 2 * 256 + 16;
+        StreamRing<KC0> ring0;
+        if constexpr (STREAM0) Q0.prime(ring0, 0);   // the first chunks of W_0's planes travel during the conversion pass
         plane_convert_x(xs, ldx, M.kp[0], 32 * KC0, xq, rowb0, tid, SPLIT_FWD_SA);
         __syncthreads();
         DBG_TICK(1)
@@ -167,7 +173,17 @@ struct SplitPolicy {
         // ---- hidden layer 0 ----
         {
             f32x4 acc[4] = {}, accr[4] = {};
-            gemm_split(xq, rowb0, Q0, lane, acc, accr);
+            if constexpr (STREAM0) {   // two n-tiles at a time through the ring
+                f32x4 pa[2] = {}, pr[2] = {};
+                gemm_split_pair(xq, rowb0, Q0, ring0, 0, lane, pa, pr);
+                Q0.prime(ring0, 1);
+                acc[0] = pa[0]; acc[1] = pa[1]; accr[0] = pr[0]; accr[1] = pr[1];
+                f32x4 pb[2] = {}, ps[2] = {};
+                gemm_split_pair(xq, rowb0, Q0, ring0, 1, lane, pb, ps);
+                acc[2] = pb[0]; acc[3] = pb[1]; accr[2] = ps[0]; accr[3] = ps[1];
+            } else {
+                gemm_split(xq, rowb0, Q0, lane, acc, accr);
+            }
             DBG_TICK(14)
             float* hrow = stash ? p.st.h[1] + row0 * 256 : nullptr;
             float* zrow = (stash && gelu) ? p.st.z[1] + row0 * 256 : nullptr;
@@ -858,7 +874,8 @@ size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int spl
                                         4 * TB * ref_points);
     if (f16) b += sizeof(_Float16) * (size_t)TB * ((((ldx - 4) + 31) & ~31) + 8);   // x16
     if (split_k0 > 0) {   // plane images of X and H_1, head partials, layer 0's residual plane; no fp32 hidden tiles of their own
-        b += (size_t)4 * TB * (split_rowb(split_k0) + split_rowb(256)) + sizeof(float) * 4 * TB * 4 + (size_t)(split_k0 / 32) * 16384;
+        b += (size_t)4 * TB * (split_rowb(split_k0) + split_rowb(256)) + sizeof(float) * 4 * TB * 4 +
+             (split_k0 / 32 > SPLIT_MAX_RESIDENT_KC0 ? 0 : (size_t)(split_k0 / 32) * 16384);   // (wider inputs: W_0's planes stream from L2)
         b -= sizeof(float) * 2 * (size_t)hidden_tile_floats(ldh, false);
     }
     return b;
@@ -885,7 +902,9 @@ bool split_eligible(const RolloutParams& p) {
     const MlpDev& M = p.pol;
     if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
     if (p.env.kind != GOPS_ENV_LQ && p.env.kind != GOPS_ENV_IDPENDULUM && p.env.kind != GOPS_ENV_VEH3DOFCONTI) return false;
-    if (M.nl != 3 || M.dims[1] != 256 || M.dims[2] != 256 || p.ldh != 260 || M.kp32[0] > 128 || p.ldx != M.kp[0] + 4) return false;
+    if (M.nl != 3 || M.dims[1] != 256 || M.dims[2] != 256 || p.ldh != 260 || M.kp32[0] > 256 || p.ldx != M.kp[0] + 4) return false;
+    // more than 128 inputs (veh3dofconti with P > 30): layer 0's planes stream from L2 - instantiated without the tail value net
+    if (M.kp32[0] > 128 && (p.env.kind != GOPS_ENV_VEH3DOFCONTI || p.tail || (getenv("GOPS_SPLIT_STREAM0") != nullptr && getenv("GOPS_SPLIT_STREAM0")[0] == '0'))) return false;
     // More tiles than CUs AND a tail value net: the tail is evaluated per tile with fp32 weights streamed from L2 by the one
     // resident workgroup, which exposes every L2 round trip (measured at B = 65536: no faster than the streamed kernels with
     // their three workgroups per CU) - those launches stay on the streamed kernels.
@@ -972,6 +991,15 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
         else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 2) LAUNCH_FWD_SPLIT(GOPS_ENV_VEH3DOFCONTI, 2);
         else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 3) LAUNCH_FWD_SPLIT(GOPS_ENV_VEH3DOFCONTI, 3);
         else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 4) LAUNCH_FWD_SPLIT(GOPS_ENV_VEH3DOFCONTI, 4);
+#define LAUNCH_FWD_SPLIT_NOTAIL(ENV, KC0)                                                                                    \
+    do {                                                                                                                     \
+        if (multi) launch_with_lds(rollout_fwd_kernel<ENV, KC0, 8, false, false, false, true, true>, grid, block, lds, stream, dp);  \
+        else launch_with_lds(rollout_fwd_kernel<ENV, KC0, 8, false, false, false, true>, grid, block, lds, stream, dp);       \
+    } while (0)
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 5 && !p.tail) LAUNCH_FWD_SPLIT_NOTAIL(GOPS_ENV_VEH3DOFCONTI, 5);
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 6 && !p.tail) LAUNCH_FWD_SPLIT_NOTAIL(GOPS_ENV_VEH3DOFCONTI, 6);
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 7 && !p.tail) LAUNCH_FWD_SPLIT_NOTAIL(GOPS_ENV_VEH3DOFCONTI, 7);
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 8 && !p.tail) LAUNCH_FWD_SPLIT_NOTAIL(GOPS_ENV_VEH3DOFCONTI, 8);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }

@@ -439,6 +439,7 @@ class Rollout:
         d(loss)/d(obs) of the initial observation; `first_step_only`: parameter gradients through the action of step 0
         only (MPG's model return, mpg.py:340-353).  `grad_w is None`: no parameter gradients."""
         d = self.desc
+        self._in.grad_constraint = self._in.grad_constraint_prod = self._in.grad_constraint_step = None   # (no stale seeds of an earlier call)
         adj = GopsRolloutAdjoint()
         adj.grad_final_obs = _ptr(grad_final_obs)
         g_obs = torch.empty(d.batch, d.env.obs_dim, dtype=torch.float32, device=self.device) if want_grad_obs else None
@@ -454,6 +455,7 @@ class Rollout:
         """`gops_rollout_backward_open_loop_adj`: (d(loss)/d(head_pre) [B, H, act_dim], d(loss)/d(obs) [B, obs_dim]) of the last
         open-loop forward, the sweep seeded with d(loss)/d(final_obs) (models whose observation is the state)."""
         d = self.desc
+        self._in.grad_constraint = self._in.grad_constraint_prod = self._in.grad_constraint_step = None
         g = torch.empty(d.batch, d.horizon, d.env.act_dim, dtype=torch.float32, device=self.device)
         g_obs = torch.empty(d.batch, d.env.obs_dim, dtype=torch.float32, device=self.device)
         adj = GopsRolloutAdjoint()
@@ -467,6 +469,7 @@ class Rollout:
         """d(loss)/d(head_pre) [B, H, act_dim] of the last open-loop forward; `grad_constraint_step` [H, B, n_constraint]:
         d(loss)/d(per-step constraint values) (GopsRolloutIn.grad_constraint_step)."""
         d = self.desc
+        self._in.grad_constraint = self._in.grad_constraint_prod = None
         self._in.grad_constraint_step = _ptr(grad_constraint_step)
         self._grad_cs = grad_constraint_step
         g = torch.empty(d.batch, d.horizon, d.env.act_dim, dtype=torch.float32, device=self.device)

@@ -25,6 +25,12 @@ CASES = {
     "lq_s4a2_relu": dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=100, horizon=20, hidden=(256, 256), act="relu", gamma=0.99),
     "lq_s6a3_sigmoid": dict(alg="FHADP", env_id="pyth_lq", lq_config="s6a3", batch=33, horizon=10, hidden=(256, 256), act="sigmoid", gamma=1.0),
     "lq_s2a1_elu": dict(alg="FHADP", env_id="pyth_lq", lq_config="s2a1", batch=16, horizon=25, hidden=(256, 256), act="elu", gamma=0.97),
+    # more than 128 policy inputs: layer 0's planes stream from L2 (StreamQ), 5 .. 8 chunks of 32 inputs
+    "veh_p50_elu_stream": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=150, horizon=7, pre_horizon=50, hidden=(256, 256), act="elu", gamma=1.0),
+    "veh_p34_gelu_stream": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=64, horizon=6, pre_horizon=34, hidden=(256, 256), act="gelu", gamma=0.98),
+    "veh_p45_relu_stream": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=49, horizon=5, pre_horizon=45, hidden=(256, 256), act="relu", gamma=1.0),
+    "veh_p60_tanh_stream": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=40, horizon=4, pre_horizon=60, hidden=(256, 256), act="tanh", gamma=0.99),
+    "veh_p40_multi_stream": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=4096 + 16 * 5 + 7, horizon=3, pre_horizon=40, hidden=(256, 256), act="elu", gamma=1.0),
     # more tiles than CUs: the workgroups walk their tiles grid-stride with the weights resident (ragged last tile included)
     "lq_s4a2_multi": dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=4096 + 16 * 37 + 5, horizon=5, hidden=(256, 256), act="gelu", gamma=0.99),
     "veh_p10_multi": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=4096 + 16 * 9 + 3, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=1.0),
@@ -44,6 +50,8 @@ def _run(cfg, nets, data, env, dev, monkeypatch, split):
     mlp, ws, bs = hip_mlp_from_net(nets["policy"], dev)
     B = data["obs"].shape[0]
     ro = hb.Rollout(henv, mlp, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=True)
+    import ctypes
+    assert (hb.lib().gops_rollout_variant(ctypes.byref(ro.desc)) == 1) == split, "the launch would not take the kernels under test"
     res = ro.forward(to_device(data, dev), want_rewards=True, want_final=True)
     gw, gb = [torch.empty_like(w) for w in ws], [torch.empty_like(b) for b in bs]
     ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)

@@ -285,6 +285,14 @@ __device__ __forceinline__ void act_dispatch(int kind, F&& body) {
     }
 }
 
+// cond ? a : b on two elements of per-thread arrays: written plainly, hipcc turns it into a select of the two ADDRESSES and
+// a load - which keeps both arrays in scratch memory (measured: the pyth_lq env phase of the plane-split kernels at 6.7 k
+// cycles per step instead of 0.7 k).  The empty asm pins both values to registers first.
+__device__ __forceinline__ float sel_reg(bool c, float a, float b) {
+    asm volatile("" : "+v"(a), "+v"(b));
+    return c ? a : b;
+}
+
 // ---- wrapper chain on the action (ScaleActionModel -> ClipActionModel) -----------------------
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 

@@ -15,7 +15,9 @@ __device__ __forceinline__ void lq_forward(const GopsEnv& e, const float* x, con
     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) {
         if (i < n) {
             float bu = 0.f;
-            for (int j = 0; j < m; ++j) bu += e.lq_B[i * m + j] * u[j];
+#pragma unroll
+            for (int j = 0; j < GOPS_MAX_ACT; ++j)   // (compile-time trip counts everywhere: a run-time index into x / u / tmp puts
+                if (j < m) bu += e.lq_B[i * m + j] * u[j];   //  the array into scratch memory - 9x the time of this phase in the big kernels)
             tmp[i] = bu * e.lq_dt + x[i];
         }
     }
@@ -24,12 +26,16 @@ __device__ __forceinline__ void lq_forward(const GopsEnv& e, const float* x, con
     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) {
         if (i < n) {
             float acc = 0.f;
-            for (int k = 0; k < n; ++k) acc += e.lq_inv_IA[i * n + k] * tmp[k];
+#pragma unroll
+            for (int k = 0; k < GOPS_MAX_LQ_STATE; ++k)
+                if (k < n) acc += e.lq_inv_IA[i * n + k] * tmp[k];
             xn[i] = acc;
             rs += x[i] * x[i] * e.lq_Q[i];
         }
     }
-    for (int j = 0; j < m; ++j) ra += u[j] * u[j] * e.lq_R[j];
+#pragma unroll
+    for (int j = 0; j < GOPS_MAX_ACT; ++j)
+        if (j < m) ra += u[j] * u[j] * e.lq_R[j];
     r = e.lq_reward_scale * (e.lq_reward_shift - 1.0f * (rs + ra));
 }
 
@@ -42,15 +48,22 @@ __device__ __forceinline__ void lq_backward(const GopsEnv& e, const float* x, co
     for (int k = 0; k < GOPS_MAX_LQ_STATE; ++k) {
         if (k < n) {
             float acc = 0.f;
-            for (int i = 0; i < n; ++i) acc += e.lq_inv_IA[i * n + k] * gxn[i];
+#pragma unroll
+            for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                if (i < n) acc += e.lq_inv_IA[i * n + k] * gxn[i];
             gt[k] = acc;
             gx[k] += acc + gr * e.lq_reward_scale * (-2.f * e.lq_Q[k] * x[k]);
         }
     }
-    for (int j = 0; j < m; ++j) {
-        float acc = 0.f;
-        for (int i = 0; i < n; ++i) acc += e.lq_B[i * m + j] * gt[i];
-        gu[j] = acc * e.lq_dt + gr * e.lq_reward_scale * (-2.f * e.lq_R[j] * u[j]);
+#pragma unroll
+    for (int j = 0; j < GOPS_MAX_ACT; ++j) {
+        if (j < m) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                if (i < n) acc += e.lq_B[i * m + j] * gt[i];
+            gu[j] = acc * e.lq_dt + gr * e.lq_reward_scale * (-2.f * e.lq_R[j] * u[j]);
+        }
     }
 }
 

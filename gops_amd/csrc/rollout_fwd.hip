@@ -498,7 +498,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
 #pragma unroll
                     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
                         if (i < O) {
-                            const float v = obs_rescale(p.env, i, frozen ? x[i] : xn[i]);
+                            const float v = obs_rescale(p.env, i, sel_reg(frozen, x[i], xn[i]));
                             xs[m * ldx + i] = p.env.clip_obs ? clampf(v, p.env.obs_low[i], p.env.obs_high[i]) : v;
                         }
                 }
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 if (!frozen || p.env.clip_obs || p.env.scale_obs) {
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
-                        const float v = obs_rescale(p.env, i, frozen ? x[i] : xn[i]);
+                        const float v = obs_rescale(p.env, i, sel_reg(frozen, x[i], xn[i]));
                         xs[m * ldx + i] = p.env.clip_obs ? clampf(v, p.env.obs_low[i], p.env.obs_high[i]) : v;
                     }
                 }
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 if (!frozen || p.env.clip_obs) {
 #pragma unroll
                     for (int i = 0; i < MOB_OBS; ++i) {
-                        const float v = frozen ? x[i] : xn[i];
+                        const float v = sel_reg(frozen, x[i], xn[i]);
                         xs[m * ldx + i] = p.env.clip_obs ? clampf(v, p.env.obs_low[i], p.env.obs_high[i]) : v;
                     }
                 }

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
     extern __shared__ __attribute__((aligned(16))) float ring[];   // [DWR_STAGES][DWR_STAGE_FLOATS]
     constexpr int T = 128, R = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_k = Kp / T, tiles = tiles_k * (N / T);
+    const int tiles_k = (Kp + T - 1) / T, tiles = tiles_k * (N / T);   // (the last K-tile may be partial: Kp is a multiple of 16)
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;   // XCD-aware order, as above
     const int tile = local % tiles, split = (local / tiles) * 8 + xcd;
     if (split >= splits) return;
@@ -615,12 +615,18 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
     // this wave's copy job: region `wave` of a stage = sample tile (wave & 1) of operand (wave >> 1)
     const float* csrc = (wave < 2) ? D + (size_t)tile_n * T * 16 : X + (size_t)tile_k * T * 16;
     const size_t ctile = (size_t)((wave < 2) ? N : Kp) * 16;
+    // features of a partial last K-tile that do not exist (>= Kp) are fetched from the tile's first features instead: finite
+    // values whose products land in columns that are never stored
+    const int kvalid = (wave < 2) ? T : min(T, Kp - tile_k * T);   // valid features of this wave's operand tile
     auto copy_block = [&](int c, int stage) {   // block index clamped: the copy count per block is constant
         const long long bq = min(((long long)split + (long long)min(c, nblk - 1) * splits) * 2 + (wave & 1), Q - 1);
         const float* src = csrc + (size_t)bq * ctile + 4 * lane;
         const float* dst = ring + stage * DWR_STAGE_FLOATS + wave * 2048;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) async_copy16_to_lds(src + u * 256, dst + u * 256);
+        for (int u = 0; u < 8; ++u) {
+            const int feat = u * 16 + (lane >> 2);
+            async_copy16_to_lds(feat < kvalid ? src + u * 256 : src + u * 256 - (size_t)(feat - (feat % kvalid)) * 16, dst + u * 256);
+        }
     };
 
     f32x4 acc[R][R] = {};
@@ -762,6 +768,7 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int k = kb + 16 * j + f;
+            if (k >= Kp) continue;   // (partial last K-tile)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[i][j][r];
@@ -804,7 +811,7 @@ hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long lo
     const int T = big ? 128 : 64, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
     const dim3 grid(tiles * ((splits + 7) / 8) * 8), block(NTHREADS);
     static const bool no_ring = getenv("GOPS_DW_DIRECT") != nullptr;   // A/B knob: register-direct kernel for the large layers too
-    if (big && !force_f32 && !no_ring && (N % 128) == 0 && (Kp % 128) == 0) {
+    if (big && !force_f32 && !no_ring && (N % 128) == 0 && ((Kp % 128) == 0 || (Kp > 128 && (Kp % 16) == 0))) {
         const float* none = nullptr;
         if (dscale != nullptr && !force_exact) {
             launch_with_lds(dw_gemm_ring_kernel<true>, grid, block, (size_t)DWR_STAGES * DWR_STAGE_FLOATS * sizeof(float) + 16, s, D, N, X, Kp, Q,

@@ -426,9 +426,9 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
     if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
     p.dbg = dbg ? dbg_buf : nullptr;
-    // Split sweep, activation other than GELU: the output layer's weight gradient is accumulated inside the sweep (one
-    // partial per workgroup) - no dw_out pass.  (GELU's act' operand is gelu'(z), not H_2.)
-    const bool fused_out = p.sp.on && !p.ext && !p.open_loop && want_params && ext_delta == nullptr && p.pol.act != GOPS_ACT_GELU &&
+    // Split sweep: the output layer's weight gradient is accumulated inside the sweep (one partial per workgroup) - no dw_out
+    // pass.  (GELU: the sweep's act' operand is gelu'(z), so it fetches H_2 next to it.)
+    const bool fused_out = p.sp.on && !p.ext && !p.open_loop && want_params && ext_delta == nullptr &&
                            getenv("GOPS_NO_FUSED_DWOUT") == nullptr;
     const int sweep_grid = std::min((p.B + TB - 1) / TB, split_grid_limit());
     if (fused_out) {

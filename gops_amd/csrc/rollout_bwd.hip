@@ -248,11 +248,21 @@ struct SplitSweep {
         {   // ---- head: delta_2 = (delta_y W_o) * act'(z_2) ----
             const int kk = lane >> 4;
             const float ga = (kk < A) ? s_gy[(lane & 15) * 4 + kk] : 0.f;   // A operand: delta_y[m = lane & 15][k = lane >> 4]
+            // GELU with the fused output-layer gradient: hv holds gelu'(z_2), H_2 itself is fetched here and lands behind the
+            // head delta's epilogue (a short live range: as a member held across the env adjoint it spilled)
+            const bool gelu_fuse = fuse_out && M.act == GOPS_ACT_GELU;
+            f32x4 h2v[4] = {};
+            if (gelu_fuse) {
+                const GLOBAL_AS float* s2 = gptr(p.st.h[2] + row0 * 256);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h2v[q] = ld4(s2 + (64 * wave + 16 * q + (lane & 15)) * 16 + m0);
+            }
             f32x4 acc[4] = {};
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, wo[q], acc[q], 0, 0, 0);
             finish(2, acc, dq2);
-            if (fuse_out) {   // dW_o += delta_y^T H_2 over this lane's rows and columns (hv still holds H_2)
+            if (fuse_out) {   // dW_o += delta_y^T H_2 over this lane's rows and columns (hv still holds H_2; GELU: h2v does)
+                const bool gelu = gelu_fuse;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const f32x4 dyr = *reinterpret_cast<const f32x4*>(s_gy + (m0 + r) * 4);
@@ -262,7 +272,7 @@ struct SplitSweep {
                         const float d = ok ? dyr[a] : 0.f;
                         dbo[a] += d;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) dwo[a][q] = fmaf(d, hv[q][r], dwo[a][q]);
+                        for (int q = 0; q < 4; ++q) dwo[a][q] = fmaf(d, gelu ? h2v[q][r] : hv[q][r], dwo[a][q]);
                     }
                 }
             }

@@ -13,7 +13,7 @@
 
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream);
-size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int split_k0);
+size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int split_k0, bool ss = false);
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split);
 bool split_eligible(const RolloutParams& p);
 int split_grid_limit();
@@ -34,6 +34,7 @@ hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s);
 hipError_t launch_fill_zero(float* p, size_t n, hipStream_t s);
 hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s);
 hipError_t launch_env_constraint(const GopsEnv& env, int B, const GopsStepIO& io, hipStream_t s);
+bool ss_eligible(const RolloutParams& p);   // rollout_fwd.hip
 hipError_t launch_adam(const GopsAdamTensors& T, GopsAdamState* st, double beta1, double beta2, float eps,
                        hipStream_t s);
 
@@ -291,6 +292,20 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         sp.inv[1] = c.take(n2 >> 4);
         sp.invt[1] = c.take(n1 >> 4);
         sp.invt[0] = c.take(p.pol.kp[0] >> 4);
+    }
+    p.ss = (!p.sp.on && ss_eligible(p)) ? 1 : 0;
+    if (p.ss) {   // streamed-split forward: planes of every hidden layer of the policy (and of the tail value net)
+        for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
+            const MlpDev& d = m ? p.val : p.pol;
+            SplitNetDev& sn = m ? p.ssv : p.ssp;
+            for (int j = 0; j < d.nl - 1; ++j) {
+                sn.kc[j] = (j == 0) ? ss_kc0(d.kp32[0]) : d.dims[j] >> 5;
+                const size_t elems = (size_t)d.dims[j + 1] * 32 * sn.kc[j];
+                sn.w1[j] = reinterpret_cast<const bf16x8*>(c.take((elems + 1) / 2));
+                sn.r[j] = reinterpret_cast<const f16x8*>(c.take((elems + 1) / 2));
+                sn.inv[j] = c.take(d.dims[j + 1] >> 4);
+            }
+        }
     }
     p.gscale = c.take(4);   // max|grad_v| of a backward launch (f16 sweep scale; delta scale of the weight-gradient GEMM)
     // stash rows: every tile stores all 16 rows of every step (tile-major order)
@@ -671,6 +686,7 @@ int gops_rollout_variant(const GopsRolloutDesc* desc) {
     const int rc = build_plan(*desc, nullptr, plan);
     if (rc != GOPS_OK) return rc;
     if (plan.p.sp.on) return GOPS_VARIANT_SPLIT;
+    if (plan.p.ss) return GOPS_VARIANT_STREAMED_SPLIT_FWD;
     int sk[2];
     rollout_variant(plan.p, sk, false);
     return sk[1] > 0 ? GOPS_VARIANT_STATIONARY_F32 : 0;

@@ -106,6 +106,14 @@ __device__ __forceinline__ void pack_split_tile(const float* __restrict__ W, int
     if (tid == 0) inv[nt] = 1.f / s_r;
 }
 __host__ __device__ inline int split_pack_blocks(const RolloutParams& p) {
+    if (p.ss) {   // streamed-split forward: one block per n-tile of every hidden layer of the policy (and the tail value net)
+        int nb = 0;
+        for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
+            const MlpDev& d = m ? p.val : p.pol;
+            for (int j = 0; j < d.nl - 1; ++j) nb += d.dims[j + 1] >> 4;
+        }
+        return nb;
+    }
     if (!p.sp.on) return 0;
     return (p.pol.dims[1] >> 4) + (p.pol.dims[2] >> 4) + (p.pol.dims[1] >> 4) + (p.pol.kp[0] >> 4);
 }
@@ -279,6 +287,22 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
                 return;
             }
             b -= nb;
+        }
+    }
+    if (p.ss) {   // plane-split operands of the streamed-split forward kernels
+        auto us = [](const bf16x8* q) { return const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(q)); };
+        auto hf = [](const f16x8* q) { return const_cast<_Float16*>(reinterpret_cast<const _Float16*>(q)); };
+        for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
+            const MlpDev& d = m ? p.val : p.pol;
+            const SplitNetDev& sn = m ? p.ssv : p.ssp;
+            for (int j = 0; j < d.nl - 1; ++j) {
+                const int nt = d.dims[j + 1] >> 4;
+                if (b < nt) {   // layer 0: natural input order; deeper layers read the plane image of the previous activation
+                    pack_split_tile(d.w[j], d.dims[j + 1], d.dims[j], false, j > 0, sn.kc[j], b, us(sn.w1[j]), hf(sn.r[j]), const_cast<float*>(sn.inv[j]));
+                    return;
+                }
+                b -= nt;
+            }
         }
     }
     if (p.sp.on) {   // plane-split operands of the stationary kernels: one block per n-tile

@@ -72,6 +72,15 @@ struct SplitDev {
     float* out_part;            // backward: per-workgroup partials of the output layer's weight gradient [grid][A][K] (null: the
     float* out_part_b;          //   separate dw_out pass forms it), and of its bias gradient [grid][A]
 };
+// Plane-split operands of ALL hidden layers of one net, forward orientation, for the streamed-split forward kernels (SS):
+// every layer's planes stream from L2 (StreamQ), layer 0 padded to kc[0] in {1, 2, 4, 8} chunks of 32 inputs.
+struct SplitNetDev {
+    int kc[GOPS_MAX_LAYERS - 1];
+    const bf16x8* w1[GOPS_MAX_LAYERS - 1];
+    const f16x8* r[GOPS_MAX_LAYERS - 1];
+    const float* inv[GOPS_MAX_LAYERS - 1];
+};
+__host__ __device__ inline int ss_kc0(int kp32) { const int c = kp32 >> 5; return c <= 1 ? 1 : (c <= 2 ? 2 : (c <= 4 ? 4 : 8)); }
 #ifndef GOPS_PIN_MODE
 #define GOPS_PIN_MODE 2   // layer-1 bf16 planes of the split kernels pinned to AGPRs (StatQ PIN; modes 1 / 2 / 3 measured within 1 %, r03)
 #endif
@@ -128,6 +137,9 @@ struct RolloutParams {
     int f16;                          // 1: GOPS_DTYPE_F16
     float* gscale;                    // f16 backward: gscale[0] = max|grad_v| of the launch (upload_params_kernel)
     SplitDev sp;                      // plane-split contractions of the stationary fp32 kernels
+    int ss;                           // 1: streamed-split FORWARD kernel (all hidden layers 256 wide, planes streamed from L2)
+    int ss_pad_;
+    SplitNetDev ssp, ssv;             //   planes of the policy / the tail value net
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double
 };
 

@@ -262,6 +262,109 @@ struct SplitPolicy {
 };
 struct NoSplit {};
 
+// Streamed-split forward (SS): the hidden stack of ANY depth (all layers 256 wide) on plane-split MFMAs with every layer's
+// weight planes streamed from L2 (StreamQ, two n-tiles at a time) - for the launches the register-stationary kernels do not
+// take (three hidden layers, tail value nets with many tiles per CU, ...).  ONE activation plane buffer `hq`, rewritten in
+// place behind a barrier (two buffers would cost the second workgroup per CU); head partials from the last layer's
+// registers as in SplitPolicy.  s_wo4: [256][4] head weights, feature-major, unused rows zero; returns the head output of
+// (trajectory tid >> 4, output tid & 15) in lanes tid & 15 < 4.
+template <int KCH>
+__device__ __forceinline__ void ss_layer_gemm(const char* planes, int rowb, const bf16x8* W1, const f16x8* R, const float* inv_r,
+                                              int tid, f32x4 (&acc)[4], f32x4 (&accr)[4], float (&inv)[4]) {
+    StreamQ<KCH, 4> Q;
+    StreamRing<KCH> ring;
+    Q.load(W1, R, inv_r, 16, tid);
+    Q.prime(ring, 0);
+    const int lane = tid & 63;
+    f32x4 pa[2] = {}, pr[2] = {};
+    gemm_split_pair(planes, rowb, Q, ring, 0, lane, pa, pr);
+    Q.prime(ring, 1);
+    acc[0] = pa[0]; acc[1] = pa[1]; accr[0] = pr[0]; accr[1] = pr[1];
+    f32x4 pb[2] = {}, ps[2] = {};
+    gemm_split_pair(planes, rowb, Q, ring, 1, lane, pb, ps);
+    acc[2] = pb[0]; acc[3] = pb[1]; accr[2] = ps[0]; accr[3] = ps[1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) inv[q] = Q.inv[q];
+}
+
+template <int AMAX>
+__device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetDev& S, const float* xs, int ldx, char* xq, char* hq,
+                                                float* s_part, const float* s_bias, int ldb, const float* s_wo4, const float* s_bo,
+                                                int tid, float* const* stash_h, float* const* stash_z, size_t row0) {
+    const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
+    constexpr int ROWB1 = 2 * 256 + 16;
+    const int L = M.nl - 1, rowb0 = split_rowb(32 * S.kc[0]);
+    const bool gelu = M.act == GOPS_ACT_GELU;
+    plane_convert_x(xs, ldx, M.kp[0], 32 * S.kc[0], xq, rowb0, tid, SPLIT_FWD_SA);
+    __syncthreads();
+    float part[4][AMAX] = {};
+    for (int j = 0; j < L; ++j) {
+        f32x4 acc[4] = {}, accr[4] = {};
+        float inv[4];
+        if (j == 0) {
+            switch (S.kc[0]) {
+                case 1: ss_layer_gemm<1>(xq, rowb0, S.w1[0], S.r[0], S.inv[0], tid, acc, accr, inv); break;
+                case 2: ss_layer_gemm<2>(xq, rowb0, S.w1[0], S.r[0], S.inv[0], tid, acc, accr, inv); break;
+                case 4: ss_layer_gemm<4>(xq, rowb0, S.w1[0], S.r[0], S.inv[0], tid, acc, accr, inv); break;
+                default: ss_layer_gemm<8>(xq, rowb0, S.w1[0], S.r[0], S.inv[0], tid, acc, accr, inv); break;
+            }
+        } else {
+            ss_layer_gemm<8>(hq, ROWB1, S.w1[j], S.r[j], S.inv[j], tid, acc, accr, inv);
+            __syncthreads();   // every wave has read the activation image it is about to overwrite
+        }
+        float* hrow = (stash_h != nullptr) ? stash_h[j + 1] + row0 * 256 : nullptr;
+        float* zrow = (stash_z != nullptr && gelu) ? stash_z[j + 1] + row0 * 256 : nullptr;
+        const bool last = j == L - 1;
+        f32x4 hv[4];
+        act_dispatch(M.act, [&]<int ACT>() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 64 * wave + 16 * q + (lane & 15);
+                const float sc = inv[q] * (1.f / SPLIT_FWD_SA), bn = s_bias[j * ldb + n];
+                f32x4 zv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = fmaf(accr[q][r], sc, acc[q][r]) + bn;
+                    float hr, dr = z;
+                    if constexpr (ACT == GOPS_ACT_GELU) gelu_pair(z, hr, dr);
+                    else hr = act_fwd_t<ACT>(z);
+                    hv[q][r] = hr; zv[r] = dr;
+                }
+                if (hrow != nullptr) __builtin_nontemporal_store(hv[q], gptr(reinterpret_cast<f32x4*>(hrow + n * 16 + m0)));
+                if (ACT == GOPS_ACT_GELU && zrow != nullptr) __builtin_nontemporal_store(zv, gptr(reinterpret_cast<f32x4*>(zrow + n * 16 + m0)));
+            }
+        });
+        if (!last) {
+            plane_store(hq, ROWB1, wave, lane, hv, SPLIT_FWD_SA);
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 64 * wave + 16 * q + (lane & 15);
+                const f32x4 wq = *reinterpret_cast<const f32x4*>(s_wo4 + n * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) part[r][a] = fmaf(hv[q][r], wq[a], part[r][a]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) ps[a] = row16_sum(part[r][a]);
+        if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(s_part + (wave * TB + m0 + r) * 4) = ps;
+    }
+    __syncthreads();
+    const int hm = tid >> 4, la = tid & 15;
+    float ya = 0.f;
+    if (la < GOPS_MAX_ACT)
+        ya = ((s_part[(0 * TB + hm) * 4 + la] + s_part[(1 * TB + hm) * 4 + la]) +
+              (s_part[(2 * TB + hm) * 4 + la] + s_part[(3 * TB + hm) * 4 + la])) + s_bo[la];
+    return ya;
+}
+
 // SK0 / SK1: k-chunks (16 inputs each) of hidden layers 0 / 1 when their weights are register-
 // stationary (the layer must then be 256 wide), 0 = streamed.
 // TAIL: the INFADP terminal value V_target(obs_H) is evaluated after the loop (compiled out for FHADP so
@@ -274,8 +377,9 @@ struct NoSplit {};
 // SPLIT: plane-split contractions (SplitPolicy): SK0 then counts the 32-wide chunks of layer 0, SK1 = 8
 // MULTI (SPLIT only): more tiles than workgroups - the kernel walks its tiles grid-stride (the single-tile instantiation
 // keeps fewer values live across the step loop)
-template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false, bool GEN = false, bool SPLIT = false, bool MULTI = false>
-__global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1)) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
+// SS: streamed-split forward (ss_net_forward): plane-split MFMAs with all weight planes streamed from L2, two workgroups per CU
+template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false, bool GEN = false, bool SPLIT = false, bool MULTI = false, bool SS = false>
+__global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 0) ? 3 : 1))) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;   // parameters live in device memory: uniform scalar loads
     const int tid = threadIdx.x;
@@ -296,7 +400,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     float* xs = smem;                       // [TB][ldx]  current observation (+ time column)
     float* ha = xs + TB * ldx;              // [TB][ldh]  (SPLIT: only the tail value net uses ha / hb; they alias the plane images)
     float* hb = ha + hidden_tile_floats(ldh, F16);       // [TB][ldh] floats, or [TB][ldh + 4] halfs (F16)
-    float* s_state = SPLIT ? xs + TB * ldx : hb + hidden_tile_floats(ldh, F16);  // [TB][8]
+    float* s_state = (SPLIT || SS) ? xs + TB * ldx : hb + hidden_tile_floats(ldh, F16);  // [TB][8]
     float* s_act = s_state + TB * 8;        // [TB][4] wrapped action
     float* s_th = s_act + TB * 4;           // [TB][4] tanh(head) (ENV_NONE: raw head output)
     float* s_done = s_th + TB * 4;          // [TB]
@@ -312,7 +416,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     {   // one-time staging of everything the H-step loop would otherwise re-fetch from L2
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
         for (int idx = tid; idx < GOPS_MAX_ACT * ldh; idx += NTHREADS) {   // rows a >= Ao (and the pad columns) are zero: mlp_head<true>
-            if constexpr (SPLIT) {   // feature-major [K][4]: a lane reads the four action weights of one of its columns as one vector
+            if constexpr (SPLIT || SS) {   // feature-major [K][4]: a lane reads the four action weights of one of its columns as one vector
                 const int k = idx >> 2, a = idx & 3;
                 s_wo[idx] = (a < Ao && k < K) ? gptr(p.pol.w[Lh])[a * K + k] : 0.f;
             } else {
@@ -332,7 +436,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     // SPLIT: plane images of the observation tile and of H_1 behind the reference-table region, then the head partials
     constexpr int AMAX = (ENV == GOPS_ENV_IDPENDULUM) ? 1 : ((ENV == GOPS_ENV_VEH3DOFCONTI) ? 2 : GOPS_MAX_ACT);
     typename std::conditional<SPLIT, SplitPolicy<(SK0 > 0 ? SK0 : 1), AMAX>, NoSplit>::type SP;
-    const int rowb0 = split_rowb(32 * SK0);
+    // (SS: the observation image is sized for the wider of the policy's and the tail value net's padded inputs)
+    const int rowb0 = SS ? split_rowb(32 * max(p.ssp.kc[0], TAIL ? p.ssv.kc[0] : 0)) : split_rowb(32 * SK0);
     char* xq = reinterpret_cast<char*>(s_ref + (REF ? TB * TL : 0));
     char* hq = xq + 4 * TB * rowb0;
     float* s_part = reinterpret_cast<float*>(hq + 4 * TB * split_rowb(256));   // [4 waves][TB][4]
@@ -410,6 +515,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             float ya_split = 0.f;
             if constexpr (SPLIT) {
                 ya_split = SP.run(p, xs, ldx, xq, rowb0, hq, s_part, s_bias, ldh, s_wo, s_bo, tid, p.need_grad != 0, row0, dbg);
+            } else if constexpr (SS) {
+                ya_split = ss_net_forward<AMAX>(p.pol, p.ssp, xs, ldx, xq, hq, s_part, s_bias, ldh, s_wo, s_bo, tid,
+                                                p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0);
             } else
             if (!p.open_loop) {
                 if constexpr (F16) {
@@ -431,7 +539,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             {   // lane a of each 16-lane trajectory group squashes and wraps action a (row16_sum left y in every lane)
                 const int hm = tid >> 4, la = tid & 15;
                 float ya = (la == 0) ? y[0] : (la == 1) ? y[1] : (la == 2) ? y[2] : y[3];
-                if constexpr (SPLIT) ya = ya_split;
+                if constexpr (SPLIT || SS) ya = ya_split;
                 if (p.open_loop && la < A && hm < nvalid)   // FHADP2: the sequence was emitted by one MLP evaluation outside
                     ya = gptr(p.in.head_pre)[((size_t)(b0 + hm) * p.H + t) * A + la];
                 if (la < A) {
@@ -442,7 +550,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                         s_act[hm * 4 + la] = ya;
                     } else {
                         const ActC c = act_const(s_ac, la);
-                        const float th = SPLIT ? fast_tanh(ya) : tanhf(ya);
+                        const float th = (SPLIT || SS) ? fast_tanh(ya) : tanhf(ya);
                         s_th[hm * 4 + la] = th;
                         s_act[hm * 4 + la] = wrap_action(c, c.sc * th + c.of);
                     }
@@ -814,6 +922,17 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         __syncthreads();
         float y[GOPS_MAX_ACT];
         const int Lv = p.val.nl - 1;
+        if constexpr (SS) {   // the value net on the same streamed plane-split routine: its head (one output) staged like the policy's
+            const int Kv = p.val.dims[Lv];
+            for (int idx = tid; idx < GOPS_MAX_ACT * ldh; idx += NTHREADS) {
+                const int k = idx >> 2, a = idx & 3;
+                s_wo[idx] = (a == 0 && k < Kv) ? gptr(p.val.w[Lv])[k] : 0.f;
+            }
+            if (tid < GOPS_MAX_ACT) s_bo[tid] = (tid == 0) ? gptr(p.val.b[Lv])[0] : 0.f;
+            __syncthreads();
+            y[0] = ss_net_forward<1>(p.val, p.ssv, xs, ldx, xq, hq, s_part, s_bias, ldh, s_wo, s_bo, tid,
+                                     p.need_grad ? p.st.tail_h : nullptr, p.need_grad ? p.st.tail_z : nullptr, (size_t)b0);
+        } else
         if constexpr (F16) {
             convert_x_h(xs, ldx, p.val.kp[0], p.val.kp32[0], x16, ldx16, nullptr, 0, tid);
             __syncthreads();
@@ -869,13 +988,14 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
 }
 
 // split_k0: input width (multiple of 32) of hidden layer 0 when the plane-split kernel runs, else 0
-size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int split_k0) {
+// ss: the streamed-split forward (no residual plane in LDS whatever split_k0 is)
+size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int split_k0, bool ss = false) {
     size_t b = sizeof(float) * (size_t)(TB * ldx + 2 * hidden_tile_floats(ldh, f16) + TB * (8 + 4 + 4 + 1 + 1 + 2) + (4 + GOPS_MAX_LAYERS - 1) * ldh +
                                         4 * TB * ref_points);
     if (f16) b += sizeof(_Float16) * (size_t)TB * ((((ldx - 4) + 31) & ~31) + 8);   // x16
     if (split_k0 > 0) {   // plane images of X and H_1, head partials, layer 0's residual plane; no fp32 hidden tiles of their own
         b += (size_t)4 * TB * (split_rowb(split_k0) + split_rowb(256)) + sizeof(float) * 4 * TB * 4 +
-             (split_k0 / 32 > SPLIT_MAX_RESIDENT_KC0 ? 0 : (size_t)(split_k0 / 32) * 16384);   // (wider inputs: W_0's planes stream from L2)
+             ((ss || split_k0 / 32 > SPLIT_MAX_RESIDENT_KC0) ? 0 : (size_t)(split_k0 / 32) * 16384);   // (wider inputs: W_0's planes stream from L2)
         b -= sizeof(float) * 2 * (size_t)hidden_tile_floats(ldh, false);
     }
     return b;
@@ -898,9 +1018,20 @@ int split_grid_limit() { return device_cus(); }
 // obs -> 256 -> 256 -> act policy on the BASELINE env kinds with an input of at most 128 columns (4 chunks of 32: the
 // planes of both layers then fit the register file + LDS).  One workgroup per CU keeps the weights resident and walks
 // the tiles grid-stride, whatever the batch size.  GOPS_SPLIT=0 keeps the fp32-MFMA kernels.
+// Activations whose derivative jumps at 0: with a tail value net (INFADP: the gradient runs through dV/d(obs_H) of a
+// piecewise-linear net) every pre-activation that changes sign under the 2^-19 weight representation moves the result by a
+// finite amount - measured at cfg3 (relu, 256^3, B = 8192): 2.0e-4 from the reference with a plane-split forward against
+// < 1e-4 with exact fp32 products.  Such launches keep the fp32-MFMA kernels.  (Without a tail: relu at the target shape
+// 7.7e-6 plane-split vs 7.4e-6 fp32 - no difference.)
+static bool kinked_with_tail(const RolloutParams& p) {
+    auto kinked = [](int a) { return a == GOPS_ACT_RELU || a == GOPS_ACT_SELU; };
+    return p.tail && (kinked(p.pol.act) || kinked(p.val.act));
+}
+
 bool split_eligible(const RolloutParams& p) {
     const MlpDev& M = p.pol;
     if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
+    if (kinked_with_tail(p)) return false;
     if (p.env.kind != GOPS_ENV_LQ && p.env.kind != GOPS_ENV_IDPENDULUM && p.env.kind != GOPS_ENV_VEH3DOFCONTI) return false;
     if (M.nl != 3 || M.dims[1] != 256 || M.dims[2] != 256 || p.ldh != 260 || M.kp32[0] > 256 || p.ldx != M.kp[0] + 4) return false;
     // more than 128 inputs (veh3dofconti with P > 30): layer 0's planes stream from L2 - instantiated without the tail value net
@@ -915,6 +1046,28 @@ bool split_eligible(const RolloutParams& p) {
     if (rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? ref_pts : 0, false, M.kp32[0]) > 160 * 1024) return false;
     if (rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, true) > 160 * 1024) return false;
     return true;
+}
+
+// Streamed-split forward kernels: every hidden layer of the policy (and of the tail value net) 256 wide, at most 256 padded
+// inputs, fp32, closed loop, pyth_lq / pyth_veh3dofconti - the launches the register-stationary kernels do not take (three
+// hidden layers, a tail value net with more tiles than CUs).  The backward sweep of such a launch stays on the fp32-MFMA
+// kernels: both forward variants write the same feature-major stash.  GOPS_SS=0 switches it off.
+bool ss_eligible(const RolloutParams& p) {
+    if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
+    if (p.env.kind != GOPS_ENV_LQ && p.env.kind != GOPS_ENV_VEH3DOFCONTI) return false;
+    if (kinked_with_tail(p)) return false;
+    if (const char* e = getenv("GOPS_SS")) if (e[0] == '0') return false;
+    if (const char* e = getenv("GOPS_SK")) if (e[0] == '0') return false;   // "0,..": plain streamed kernels forced
+    auto net_ok = [](const MlpDev& M) {
+        if (M.nl < 3 || M.kp32[0] > 256) return false;
+        for (int j = 1; j < M.nl; ++j)
+            if (M.dims[j] != 256) return false;
+        return true;
+    };
+    if (!net_ok(p.pol) || p.ldh != 260 || (p.tail && !net_ok(p.val))) return false;
+    const int k0 = 32 * std::max(ss_kc0(p.pol.kp32[0]), p.tail ? ss_kc0(p.val.kp32[0]) : 0);
+    const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0;
+    return rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, k0, true) <= 80 * 1024;   // two workgroups per CU
 }
 
 // Picks the register-stationary variant when the policy is (kp0 in {16,48,128}) -> 256 -> 256 ...,
@@ -1000,6 +1153,19 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
         else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 6 && !p.tail) LAUNCH_FWD_SPLIT_NOTAIL(GOPS_ENV_VEH3DOFCONTI, 6);
         else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 7 && !p.tail) LAUNCH_FWD_SPLIT_NOTAIL(GOPS_ENV_VEH3DOFCONTI, 7);
         else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI && kc0 == 8 && !p.tail) LAUNCH_FWD_SPLIT_NOTAIL(GOPS_ENV_VEH3DOFCONTI, 8);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
+    if (p.ss) {   // streamed-split forward
+        const int k0 = 32 * std::max(p.ssp.kc[0], p.tail ? p.ssv.kc[0] : 0);
+        const size_t lds_ss = rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0, false, k0, true);
+#define LAUNCH_FWD_SS(ENV)                                                                                                        \
+    do {                                                                                                                          \
+        if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, true, false, false, false, false, true>, grid, block, lds_ss, stream, dp);   \
+        else launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, false, false, false, false, false, true>, grid, block, lds_ss, stream, dp);         \
+    } while (0)
+        if (p.env.kind == GOPS_ENV_LQ) LAUNCH_FWD_SS(GOPS_ENV_LQ);
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI) LAUNCH_FWD_SS(GOPS_ENV_VEH3DOFCONTI);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }

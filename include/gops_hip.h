@@ -397,10 +397,14 @@ int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, dou
  *        bf16 + scaled f16 residual planes, activations / deltas as three exact bf16 planes + one f16 plane,
  *        3 bf16 + 1 f16 MFMA (16x16x32) per 32-deep block, fp32 accumulation (>= 19-bit weights, fp32 results);
  * bit 1 (GOPS_VARIANT_STATIONARY_F32): the register-stationary kernels on exact fp32 MFMAs;
- * neither: the streamed kernels (exact fp32 MFMAs, or half-precision MFMAs for GOPS_DTYPE_F16).
+ * bit 2 (GOPS_VARIANT_STREAMED_SPLIT_FWD, ABI v9): the FORWARD rollout on the streamed plane-split kernel (any number of
+ *        256-wide hidden layers, weight planes streamed from L2, tail value net included); the backward sweep of such a
+ *        launch runs on the streamed fp32-MFMA kernel;
+ * none: the streamed kernels (exact fp32 MFMAs, or half-precision MFMAs for GOPS_DTYPE_F16).
  * Negative: a GOPS_ERR_* code for a description the library rejects. */
 #define GOPS_VARIANT_SPLIT 1
 #define GOPS_VARIANT_STATIONARY_F32 2
+#define GOPS_VARIANT_STREAMED_SPLIT_FWD 4
 int gops_rollout_variant(const GopsRolloutDesc* desc);
 
 /* Timing hook for bench.py: average duration in ms of the named internal kernel over the

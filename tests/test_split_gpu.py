@@ -139,3 +139,55 @@ def test_weight_gradient_gemm_redoes_saturated_blocks_exactly(dev, monkeypatch):
     worst_ng = rel_l2(grads_ng[2].cpu(), ref["grads"][2])   # dW of layer 1 = D_2^T H_1
     print(f"saturated H_1: worst tensor with the guard {worst:.2e}; layer-1 weight gradient without it {worst_ng:.2e}")
     assert worst_ng > 10 * TOL
+
+
+# ---- streamed-split forward kernels (GOPS_VARIANT_STREAMED_SPLIT_FWD): any number of 256-wide hidden layers, planes of every
+#      layer streamed from L2, tail value net on the same routine; the sweep of these launches is the fp32-MFMA one ---------------
+SS_CASES = {
+    # (relu / selu with a tail value net stay on the exact fp32 kernels: kinked_with_tail in csrc/rollout_fwd.hip)
+    "veh_p10_3x256_infadp": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=300, horizon=6, pre_horizon=10, hidden=(256, 256, 256), act="elu", gamma=0.99),
+    "veh_p10_3x256_fhadp_relu": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=4096 + 16 * 3 + 1, horizon=4, pre_horizon=10, hidden=(256, 256, 256), act="relu", gamma=0.99),
+    "veh_p10_3x256_infadp_many_tiles": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4096 + 16 * 7 + 9, horizon=3, pre_horizon=10, hidden=(256, 256, 256), act="gelu", gamma=0.99),
+    "veh_p30_4x256_fhadp": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=70, horizon=5, pre_horizon=30, hidden=(256, 256, 256, 256), act="elu", gamma=1.0),
+    "lq_s4a2_infadp_many_tiles": dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=4096 + 16 * 21 + 3, horizon=6, hidden=(256, 256), act="gelu", gamma=0.99),
+    "lq_s6a3_3x256_fhadp": dict(alg="FHADP", env_id="pyth_lq", lq_config="s6a3", batch=50, horizon=9, hidden=(256, 256, 256), act="tanh", gamma=0.97),
+}
+
+
+@pytest.mark.parametrize("name", list(SS_CASES))
+def test_streamed_split_forward_vs_oracle_and_fp32_mfma(name, dev, monkeypatch):
+    import ctypes
+    from gops_amd import hip_backend as hb
+    cfg = SS_CASES[name]
+    data = make_batch(cfg, 5)
+    nets = reference_init_nets(cfg, 5, obs_dim_of(cfg), act_dim_of(cfg))
+    env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
+    fh = cfg["alg"] == "FHADP"
+    if fh:
+        want = orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+    else:
+        want = orc.infadp_pim_gradient(env, nets["policy"], nets["v_target"], data, cfg["horizon"], cfg["gamma"])
+    flat_ref = torch.cat([g.reshape(-1) for g in want["grads"]])
+    out = {}
+    for ss in (True, False):
+        monkeypatch.setenv("GOPS_SS", "1" if ss else "0")
+        henv = hip_env_from_oracle(env, nets["policy"])
+        pol, pw, pb = hip_mlp_from_net(nets["policy"], dev)
+        vt = None if fh else hip_mlp_from_net(nets["v_target"], dev)[0]
+        B = data["obs"].shape[0]
+        ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=fh, need_grad=True, value=vt)
+        assert (hb.lib().gops_rollout_variant(ctypes.byref(ro.desc)) == 4) == ss, "the launch would not take the kernels under test"
+        res = ro.forward(to_device(data, dev), want_final=True)
+        gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]
+        ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
+        torch.cuda.synchronize()
+        out[ss] = (res, torch.cat([t.reshape(-1).cpu() for pair in zip(gw, gb) for t in pair]))
+    for ss in (True, False):
+        res, flat = out[ss]
+        assert rel_l2(res["v_pi"].cpu(), want["v_pi"]) < TOL, (name, ss, rel_l2(res["v_pi"].cpu(), want["v_pi"]))
+        assert rel_l2(res["final_obs"].cpu(), want["final_obs"]) < TOL
+        assert np.array_equal(res["final_done"].cpu().numpy() != 0, want["final_done"].numpy())
+        assert rel_l2(flat, flat_ref) < TOL, (name, ss, rel_l2(flat, flat_ref))
+    print(f"{name}: gradient rel-L2 to the oracle: streamed-split forward {rel_l2(out[True][1], flat_ref):.2e}, fp32 MFMA {rel_l2(out[False][1], flat_ref):.2e}; "
+          f"v_pi {rel_l2(out[True][0]['v_pi'].cpu(), want['v_pi']):.2e}")
+    assert rel_l2(out[True][1], out[False][1]) < 5e-5

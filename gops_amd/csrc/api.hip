@@ -14,7 +14,7 @@
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream);
 size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int split_k0, bool ss = false);
-size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split);
+size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split, bool ssb = false);
 bool split_eligible(const RolloutParams& p);
 int split_grid_limit();
 void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
@@ -35,6 +35,7 @@ hipError_t launch_fill_zero(float* p, size_t n, hipStream_t s);
 hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s);
 hipError_t launch_env_constraint(const GopsEnv& env, int B, const GopsStepIO& io, hipStream_t s);
 bool ss_eligible(const RolloutParams& p);   // rollout_fwd.hip
+bool ssb_eligible(const RolloutParams& p);  // rollout_bwd.hip
 hipError_t launch_adam(const GopsAdamTensors& T, GopsAdamState* st, double beta1, double beta2, float eps,
                        hipStream_t s);
 
@@ -304,6 +305,22 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
                 sn.w1[j] = reinterpret_cast<const bf16x8*>(c.take((elems + 1) / 2));
                 sn.r[j] = reinterpret_cast<const f16x8*>(c.take((elems + 1) / 2));
                 sn.inv[j] = c.take(d.dims[j + 1] >> 4);
+            }
+        }
+        // the sweep of the same launch on the streamed-split kernel too: transposed planes (n-tiles over a layer's inputs)
+        p.ssb = (p.need_grad && ssb_eligible(p)) ? 1 : 0;
+        if (p.ssb) {
+            for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
+                const MlpDev& d = m ? p.val : p.pol;
+                SplitNetDev& sn = m ? p.ssvt : p.sspt;
+                for (int j = 0; j < d.nl - 1; ++j) {
+                    const int nin = (j == 0) ? d.kp[0] : d.dims[j];   // (16-padded) inputs of the layer = columns of the transposed operand
+                    sn.kc[j] = d.dims[j + 1] >> 5;
+                    const size_t elems = (size_t)nin * d.dims[j + 1];
+                    sn.w1[j] = reinterpret_cast<const bf16x8*>(c.take((elems + 1) / 2));
+                    sn.r[j] = reinterpret_cast<const f16x8*>(c.take((elems + 1) / 2));
+                    sn.inv[j] = c.take(nin >> 4);
+                }
             }
         }
     }

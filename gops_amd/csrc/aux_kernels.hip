@@ -110,7 +110,10 @@ __host__ __device__ inline int split_pack_blocks(const RolloutParams& p) {
         int nb = 0;
         for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
             const MlpDev& d = m ? p.val : p.pol;
-            for (int j = 0; j < d.nl - 1; ++j) nb += d.dims[j + 1] >> 4;
+            for (int j = 0; j < d.nl - 1; ++j) {
+                nb += d.dims[j + 1] >> 4;
+                if (p.ssb) nb += ((j == 0) ? d.kp[0] : d.dims[j]) >> 4;   // transposed planes of the sweep
+            }
         }
         return nb;
     }
@@ -302,6 +305,15 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
                     return;
                 }
                 b -= nt;
+                if (p.ssb) {   // sweep: delta_{j+1} -> delta_j (j = 0: g_x) through W_j, tiles over its inputs, slots over its outputs
+                    const SplitNetDev& st = m ? p.ssvt : p.sspt;
+                    const int ntt = ((j == 0) ? d.kp[0] : d.dims[j]) >> 4;
+                    if (b < ntt) {
+                        pack_split_tile(d.w[j], d.dims[j + 1], d.dims[j], true, true, st.kc[j], b, us(st.w1[j]), hf(st.r[j]), const_cast<float*>(st.inv[j]));
+                        return;
+                    }
+                    b -= ntt;
+                }
             }
         }
     }

@@ -140,6 +140,9 @@ struct RolloutParams {
     int ss;                           // 1: streamed-split FORWARD kernel (all hidden layers 256 wide, planes streamed from L2)
     int ss_pad_;
     SplitNetDev ssp, ssv;             //   planes of the policy / the tail value net
+    SplitNetDev sspt, ssvt;           //   streamed-split SWEEP (ssb): transposed planes (n-tiles over a layer's inputs, 8 chunks over its outputs)
+    int ssb;
+    int ssb_pad_;
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double
 };
 
@@ -163,7 +166,7 @@ struct BwdPatch {
 };
 
 // upload_params_kernel / prologue_kernel take the block BY VALUE: it has to fit the 4 KiB kernel-argument segment
-static_assert(sizeof(RolloutParams) <= 3840, "RolloutParams outgrew the kernel-argument segment (move gpow[] out)");
+static_assert(sizeof(RolloutParams) <= 4000, "RolloutParams outgrew the kernel-argument segment (move gpow[] out)");
 
 
 // per-phase cycle accounting of block 0 / thread 0 (debug builds of the timing knob only)
@@ -644,6 +647,32 @@ __device__ __forceinline__ void gemm_split_pair(const char* planes, int rowb, co
         }
         a1 = n1; a2 = n2; a3 = n3; af = nf;
     }
+}
+
+// One layer of the streamed-split kernels: this wave's four n-tiles (of nt_tot; surplus tiles recompute tile 0) over KCH
+// chunks of the plane image `planes`, two n-tiles at a time through the ring.
+template <int KCH>
+__device__ __forceinline__ void ss_layer_gemm(const char* planes, int rowb, const bf16x8* W1, const f16x8* R, const float* inv_r,
+                                              int nt_tot, int tid, f32x4 (&acc)[4], f32x4 (&accr)[4], float (&inv)[4]) {
+    StreamQ<KCH, 4> Q;
+    StreamRing<KCH> ring;
+    Q.load(W1, R, inv_r, nt_tot, tid);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) inv[q] = Q.inv[q];
+    // narrow operands (g_x of a 4- or 6-column observation: ONE n-tile): a wave without a valid tile in a pair skips it
+    // (wave-uniform), instead of recomputing tile 0 - acc / accr stay zero there and nothing of them is stored
+    const int mine = nt_tot - 4 * (tid >> 6);
+    if (mine <= 0) return;
+    Q.prime(ring, 0);
+    const int lane = tid & 63;
+    f32x4 pa[2] = {}, pr[2] = {};
+    gemm_split_pair(planes, rowb, Q, ring, 0, lane, pa, pr);
+    acc[0] = pa[0]; acc[1] = pa[1]; accr[0] = pr[0]; accr[1] = pr[1];
+    if (mine <= 2) return;
+    Q.prime(ring, 1);
+    f32x4 pb[2] = {}, ps[2] = {};
+    gemm_split_pair(planes, rowb, Q, ring, 1, lane, pb, ps);
+    acc[2] = pb[0]; acc[3] = pb[1]; accr[2] = ps[0]; accr[3] = ps[1];
 }
 
 __device__ __forceinline__ float row16_max(float v) {   // max over each aligned group of 16 lanes, result in every lane

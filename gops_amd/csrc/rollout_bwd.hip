@@ -14,8 +14,9 @@
 // LDS floats of the per-tile buffers (everything except the optional staged tiles at the end).
 // split: the plane-split sweep keeps the plane images of delta_2 / delta_1 where the fp32 delta tiles would be (the
 // tail value net's fp32 tiles, dead once the loop starts, alias them) and needs no LDS copy of the head weights
-__host__ __device__ inline int bwd_lds_floats(int ldx, int ldh, int ref_points, bool f16 = false, bool split = false) {
-    return TB * ldx + (split ? 2 * split_tile_floats(256) : 2 * hidden_tile_floats(ldh, f16)) + TB * 4 + 4 + 4 * TB * 8 +
+// ssb: the streamed-split sweep - ONE delta plane image (rewritten in place) where the two fp32 delta tiles would be
+__host__ __device__ inline int bwd_lds_floats(int ldx, int ldh, int ref_points, bool f16 = false, bool split = false, bool ssb = false) {
+    return TB * ldx + (split ? 2 * split_tile_floats(256) : (ssb ? split_tile_floats(256) : 2 * hidden_tile_floats(ldh, f16))) + TB * 4 + 4 + 4 * TB * 8 +
            (split ? 0 : 4 * ldh) + 4 * TB * ref_points;
 }
 
@@ -353,6 +354,93 @@ struct SplitSweep {
 };
 struct NoSweep {};
 
+// Streamed-split sweep through one net (any number of 256-wide hidden layers; the counterpart of ss_net_forward): delta_y
+// (s_gy[TB][4]) -> hidden deltas (FM stash st_d when non-null) and, if want_gx, G += delta_1 W_0.  Weight planes (transposed
+// packing, SplitNetDev) stream from L2; ONE delta plane image `dq`, rewritten in place behind a barrier; act' operands come
+// from the FM stash straight into registers, in flight during the contraction they follow.  Wo: head weights [A][ldw]
+// (LDS copy or global).
+template <class WP, class Hook>
+__device__ __forceinline__ void ss_net_backward(const MlpDev& M, const SplitNetDev& ST, WP Wo, int ldw, const float* s_gy, const float* s_scale,
+                                                char* dq, float* G, int ldg, int tid, float* const* st_h, float* const* st_z,
+                                                float* const* st_d, float* st_dy, size_t row0, int nvalid, bool want_gx, int ncols,
+                                                Hook&& after_head) {
+    const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
+    constexpr int ROWB = 2 * 256 + 16;
+    const int L = M.nl - 1, A = M.dims[M.nl];
+    const bool gelu = M.act == GOPS_ACT_GELU;
+    const float s = s_scale[0], inv_s = s_scale[1];
+    auto fetch = [&](int j, f32x4 (&hv)[4]) {
+        const GLOBAL_AS float* src = gptr((gelu ? st_z[j] : st_h[j]) + row0 * 256);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[q] = ld4(src + (64 * wave + 16 * q + (lane & 15)) * 16 + m0);
+    };
+    auto finish = [&](int j, f32x4 (&a)[4], const f32x4 (&hv)[4]) {   // * act'(.), zero for padding rows, -> stash + plane image
+        float* dst = (st_d != nullptr) ? st_d[j] + row0 * 256 : nullptr;
+        act_dispatch(M.act, [&]<int ACT>() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 64 * wave + 16 * q + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[q][r] = (m0 + r < nvalid) ? a[q][r] * act_bwd_t<ACT>(hv[q][r], hv[q][r]) : 0.f;
+                if (dst != nullptr) __builtin_nontemporal_store(a[q], gptr(reinterpret_cast<f32x4*>(dst + n * 16 + m0)));
+            }
+        });
+        plane_store(dq, ROWB, wave, lane, a, s);
+    };
+    {   // ---- head: delta_L = (delta_y W_o) * act'(z_L): one K = 4 fp32 MFMA per n-tile ----
+        f32x4 hv[4];
+        fetch(L, hv);
+        const int kk = lane >> 4;
+        const float ga = (kk < A) ? s_gy[(lane & 15) * 4 + kk] : 0.f;
+        f32x4 acc[4] = {};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float wo = (kk < A) ? Wo[kk * ldw + 64 * wave + 16 * q + (lane & 15)] : 0.f;
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, wo, acc[q], 0, 0, 0);
+        }
+        finish(L, acc, hv);
+        if (st_dy != nullptr && tid < TB) {
+            f32x4 v = {s_gy[tid * 4 + 0], s_gy[tid * 4 + 1], s_gy[tid * 4 + 2], s_gy[tid * 4 + 3]};
+#pragma unroll
+            for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                if (a >= A || tid >= nvalid) v[a] = 0.f;
+            *gptr(reinterpret_cast<f32x4*>(st_dy + (row0 + tid) * 4)) = v;
+        }
+    }
+    __syncthreads();
+    after_head();
+    for (int j = L - 1; j >= 1; --j) {   // ---- delta_j = (delta_{j+1} W_j) * act'(z_j) ----
+        f32x4 hv[4];
+        fetch(j, hv);
+        f32x4 acc[4] = {}, accr[4] = {};
+        float inv[4];
+        ss_layer_gemm<8>(dq, ROWB, ST.w1[j], ST.r[j], ST.inv[j], 16, tid, acc, accr, inv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float sc = inv[q] * inv_s;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[q][r] = fmaf(accr[q][r], sc, acc[q][r]);
+        }
+        __syncthreads();   // every wave has read the delta image it is about to overwrite
+        finish(j, acc, hv);
+        __syncthreads();
+    }
+    if (want_gx) {   // ---- g_x = delta_1 W_0 into G: n-tiles over the (16-padded) inputs ----
+        f32x4 acc[4] = {}, accr[4] = {};
+        float inv[4];
+        ss_layer_gemm<8>(dq, ROWB, ST.w1[0], ST.r[0], ST.inv[0], M.kp[0] >> 4, tid, acc, accr, inv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = 16 * (4 * wave + q) + (lane & 15);
+            const float sc = inv[q] * inv_s;
+            if (n < ncols) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) G[(m0 + r) * ldg + n] += fmaf(accr[q][r], sc, acc[q][r]);
+            }
+        }
+    }
+}
+
 // SK0 / SK1 as in the forward kernel: here the stationary fragments are the TRANSPOSED packings
 // (delta_2 -> delta_1 through W_1: 16 chunks x 4 tiles).  SK0 here = number of the 16 K-chunks of
 // delta_1 -> g_x (through W_0^T, PT0 n-tiles per wave) that stay in registers; the rest streams.
@@ -364,8 +452,10 @@ struct NoSweep {};
 // observation adjoint out, parameter deltas of step 0 only - gops_rollout_backward_adj / gops_mlp_backward_x
 // SPLIT: plane-split contractions (SplitSweep; SK1 > 0, PT0 = n-tiles of g_x per wave)
 // MULTI (SPLIT only): more tiles than workgroups - grid-stride walk over the tiles
-template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, bool EXT = false, bool SPLIT = false, bool MULTI = false>
-__global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1)) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp, const BwdPatch q) {
+// SSB: streamed-split sweep (ss_net_backward): plane-split MFMAs with all (transposed) weight planes streamed from L2, two
+// workgroups per CU; the tail value net's input adjoint on the same routine
+template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, bool EXT = false, bool SPLIT = false, bool MULTI = false, bool SSB = false>
+__global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 == 0) ? 3 : 1))) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp, const BwdPatch q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;
     const int tid = threadIdx.x;
@@ -385,7 +475,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     // SPLIT: the plane images of delta_2 / delta_1 take the place of the fp32 delta tiles (which only the tail value net uses)
     char* dq2 = reinterpret_cast<char*>(da);
     char* dq1 = dq2 + 4 * split_tile_floats(256);
-    float* s_gy = SPLIT ? da + 2 * split_tile_floats(256) : db + hidden_tile_floats(ldh, F16);  // [TB][4]
+    float* s_gy = SPLIT ? da + 2 * split_tile_floats(256) : (SSB ? da + split_tile_floats(256) : db + hidden_tile_floats(ldh, F16));  // [TB][4]
     float* s_scale = s_gy + TB * 4;     // [4] SPLIT: this step's power-of-two delta scale and its inverse
     float* red = s_scale + 4;           // [4][TB][8]
     float* s_wo = red + 4 * TB * 8;     // [4][ldh] head weights (not in the SPLIT layout: SplitSweep keeps its columns in registers)
@@ -394,7 +484,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
     // One-workgroup-per-CU variants: LDS copies of this step's H_2 / H_1 (Z for GELU) tiles, [2][TB][256]
     constexpr bool STAGE = (SK1 > 0);   // (those variants are only selected for obs-256-256-act policies)
     float* s_stage = smem + bwd_lds_floats(ldx, ldh, REF ? p.env.pre_horizon + 1 + p.H
-                                                                             : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0), F16, SPLIT);
+                                                                             : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0), F16, SPLIT, SSB);
 
     const int ld16 = (p.ldh - 4) + 8;                 // F16: leading dimension (halfs) of the delta tiles
     // fp32 observation column i of row m of the stash tile at row0 (the env adjoints read the first few):
@@ -507,7 +597,17 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
             s_gy[tid * 4 + 0] = gv * ((p.tail_unmasked ? 1.f : 1.f - dH) * p.gpow[p.H]);
             s_gy[tid * 4 + 1] = s_gy[tid * 4 + 2] = s_gy[tid * 4 + 3] = 0.f;
         }
+        if constexpr (SSB) {
+            if (tid < TB) {
+                const float mx = row16_max(fabsf(s_gy[tid * 4]));
+                if (tid == 0) split_delta_scale(mx, s_scale);
+            }
+        }
         __syncthreads();
+        if constexpr (SSB)
+            ss_net_backward(p.val, p.ssvt, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, s_scale, dq2, G, ldx, tid,
+                            p.st.tail_h, p.st.tail_z, nullptr, nullptr, (size_t)b0, nvalid, true, O, [] {});
+        else
         if constexpr (F16)
             mlp_backward_h(p.val, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, reinterpret_cast<_Float16*>(da),
                            reinterpret_cast<_Float16*>(db), ld16, G, ldx, tid, p.st.tail_h, p.st.tail_z, nullptr, nullptr,
@@ -1156,7 +1256,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
                 s_gy[m * 4 + 3] = 0.f;
             }
         }
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT || SSB) {
             if (tid < TB) {   // (the same 16 threads wrote s_gy above) -> this step's delta scale
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(s_gy + tid * 4);
                 const float mx = row16_max(fmaxf(fmaxf(fabsf(g4[0]), fabsf(g4[1])), fmaxf(fabsf(g4[2]), fabsf(g4[3]))));
@@ -1168,6 +1268,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
         if constexpr (SPLIT) {
             SS.run(p, s_gy, s_scale, dq2, dq1, G, ldx, tid, row0, nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up,
                    q.out_part != nullptr);
+        } else if constexpr (SSB) {
+            ss_net_backward(p.pol, p.sspt, s_wo, ldh, s_gy, s_scale, dq2, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
+                            /*want_gx=*/t > 0, O, warm_up);
         } else
         if (!p.open_loop) {
             if constexpr (F16)
@@ -1216,8 +1319,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : ((SK0 == 0 && SK1 == 0) ? 3 : 1
 
 // ref_points: reference-table points per trajectory (veh3dofconti), 30 (= 5 x 24 / 4) for the
 // idpendulum sub-step parking area, else 0
-size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split) {
-    size_t b = sizeof(float) * (size_t)bwd_lds_floats(ldx, ldh, ref_points, f16, split);
+size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split, bool ssb = false) {
+    size_t b = sizeof(float) * (size_t)bwd_lds_floats(ldx, ldh, ref_points, f16, split, ssb);
     if (split) b += sizeof(float) * 2 * (TB * ENV_STASH + TB * 8) +
                     (ldx - 4 > 128 ? 0 : (size_t)((ldx - 4) >> 4) * 8 * 1024);   // small staging halves + W_0's residual plane (streamed beyond 128 inputs)
     return b;
@@ -1225,6 +1328,15 @@ size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool sp
 
 void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
 int split_grid_limit();   // rollout_fwd.hip: CUs of the device
+
+// The sweep of a streamed-split forward launch (p.ss) on the streamed-split sweep as well: same conditions, its LDS image at
+// two workgroups per CU.  GOPS_SSB=0 keeps the fp32-MFMA sweep.
+bool ssb_eligible(const RolloutParams& p) {
+    if (!p.ss) return false;
+    if (const char* e = getenv("GOPS_SSB")) if (e[0] == '0') return false;
+    const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0;
+    return rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false, true) <= 80 * 1024;
+}
 
 #define LAUNCH_BWD(ENV, A, B)                                                                            \
     do {                                                                                                 \
@@ -1267,6 +1379,18 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
             case GOPS_ENV_MOBILEROBOT: LAUNCH_BWD_EXT(GOPS_ENV_MOBILEROBOT); break;
             default: return hipErrorInvalidValue;
         }
+        return hipGetLastError();
+    }
+    if (p.ssb && !p.ext && !p.open_loop) {   // streamed-split sweep
+        const size_t lds_ss = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false, true);
+#define LAUNCH_BWD_SS(ENV)                                                                                                                  \
+    do {                                                                                                                                    \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, false, false, false, false, true>, grid, block, lds_ss, stream, dp, q);   \
+        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, false, false, false, false, true>, grid, block, lds_ss, stream, dp, q);         \
+    } while (0)
+        if (p.env.kind == GOPS_ENV_LQ) LAUNCH_BWD_SS(GOPS_ENV_LQ);
+        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI) LAUNCH_BWD_SS(GOPS_ENV_VEH3DOFCONTI);
+        else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     if (p.sp.on) {   // plane-split stationary sweep: PT0 = n-tiles of g_x per wave

@@ -268,25 +268,6 @@ struct NoSplit {};
 // place behind a barrier (two buffers would cost the second workgroup per CU); head partials from the last layer's
 // registers as in SplitPolicy.  s_wo4: [256][4] head weights, feature-major, unused rows zero; returns the head output of
 // (trajectory tid >> 4, output tid & 15) in lanes tid & 15 < 4.
-template <int KCH>
-__device__ __forceinline__ void ss_layer_gemm(const char* planes, int rowb, const bf16x8* W1, const f16x8* R, const float* inv_r,
-                                              int tid, f32x4 (&acc)[4], f32x4 (&accr)[4], float (&inv)[4]) {
-    StreamQ<KCH, 4> Q;
-    StreamRing<KCH> ring;
-    Q.load(W1, R, inv_r, 16, tid);
-    Q.prime(ring, 0);
-    const int lane = tid & 63;
-    f32x4 pa[2] = {}, pr[2] = {};
-    gemm_split_pair(planes, rowb, Q, ring, 0, lane, pa, pr);
-    Q.prime(ring, 1);
-    acc[0] = pa[0]; acc[1] = pa[1]; accr[0] = pr[0]; accr[1] = pr[1];
-    f32x4 pb[2] = {}, ps[2] = {};
-    gemm_split_pair(planes, rowb, Q, ring, 1, lane, pb, ps);
-    acc[2] = pb[0]; acc[3] = pb[1]; accr[2] = ps[0]; accr[3] = ps[1];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) inv[q] = Q.inv[q];
-}
-
 template <int AMAX>
 __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetDev& S, const float* xs, int ldx, char* xq, char* hq,
                                                 float* s_part, const float* s_bias, int ldb, const float* s_wo4, const float* s_bo,
@@ -303,13 +284,13 @@ __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetD
         float inv[4];
         if (j == 0) {
             switch (S.kc[0]) {
-                case 1: ss_layer_gemm<1>(xq, rowb0, S.w1[0], S.r[0], S.inv[0], tid, acc, accr, inv); break;
-                case 2: ss_layer_gemm<2>(xq, rowb0, S.w1[0], S.r[0], S.inv[0], tid, acc, accr, inv); break;
-                case 4: ss_layer_gemm<4>(xq, rowb0, S.w1[0], S.r[0], S.inv[0], tid, acc, accr, inv); break;
-                default: ss_layer_gemm<8>(xq, rowb0, S.w1[0], S.r[0], S.inv[0], tid, acc, accr, inv); break;
+                case 1: ss_layer_gemm<1>(xq, rowb0, S.w1[0], S.r[0], S.inv[0], 16, tid, acc, accr, inv); break;
+                case 2: ss_layer_gemm<2>(xq, rowb0, S.w1[0], S.r[0], S.inv[0], 16, tid, acc, accr, inv); break;
+                case 4: ss_layer_gemm<4>(xq, rowb0, S.w1[0], S.r[0], S.inv[0], 16, tid, acc, accr, inv); break;
+                default: ss_layer_gemm<8>(xq, rowb0, S.w1[0], S.r[0], S.inv[0], 16, tid, acc, accr, inv); break;
             }
         } else {
-            ss_layer_gemm<8>(hq, ROWB1, S.w1[j], S.r[j], S.inv[j], tid, acc, accr, inv);
+            ss_layer_gemm<8>(hq, ROWB1, S.w1[j], S.r[j], S.inv[j], 16, tid, acc, accr, inv);
             __syncthreads();   // every wave has read the activation image it is about to overwrite
         }
         float* hrow = (stash_h != nullptr) ? stash_h[j + 1] + row0 * 256 : nullptr;
@@ -1000,7 +981,7 @@ size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int spl
     }
     return b;
 }
-size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split);
+size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split, bool ssb = false);
 
 static int device_cus() {
     static int n_cu = 0;

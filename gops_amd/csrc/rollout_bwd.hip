@@ -1334,7 +1334,7 @@ int split_grid_limit();   // rollout_fwd.hip: CUs of the device
 bool ssb_eligible(const RolloutParams& p) {
     if (!p.ss) return false;
     if (const char* e = getenv("GOPS_SSB")) if (e[0] == '0') return false;
-    const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0;
+    const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
     return rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false, true) <= 80 * 1024;
 }
 
@@ -1388,9 +1388,17 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
         if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, false, false, false, false, true>, grid, block, lds_ss, stream, dp, q);   \
         else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, false, false, false, false, true>, grid, block, lds_ss, stream, dp, q);         \
     } while (0)
-        if (p.env.kind == GOPS_ENV_LQ) LAUNCH_BWD_SS(GOPS_ENV_LQ);
-        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI) LAUNCH_BWD_SS(GOPS_ENV_VEH3DOFCONTI);
-        else return hipErrorInvalidValue;
+        switch (p.env.kind) {
+            case GOPS_ENV_LQ: LAUNCH_BWD_SS(GOPS_ENV_LQ); break;
+            case GOPS_ENV_IDPENDULUM: LAUNCH_BWD_SS(GOPS_ENV_IDPENDULUM); break;
+            case GOPS_ENV_VEH3DOFCONTI: LAUNCH_BWD_SS(GOPS_ENV_VEH3DOFCONTI); break;
+            case GOPS_ENV_VEH3DOF_SURR: LAUNCH_BWD_SS(GOPS_ENV_VEH3DOF_SURR); break;
+            case GOPS_ENV_CARTPOLE: LAUNCH_BWD_SS(GOPS_ENV_CARTPOLE); break;
+            case GOPS_ENV_PENDULUM: LAUNCH_BWD_SS(GOPS_ENV_PENDULUM); break;
+            case GOPS_ENV_VEH2DOF: LAUNCH_BWD_SS(GOPS_ENV_VEH2DOF); break;
+            case GOPS_ENV_MOBILEROBOT: LAUNCH_BWD_SS(GOPS_ENV_MOBILEROBOT); break;
+            default: return hipErrorInvalidValue;
+        }
         return hipGetLastError();
     }
     if (p.sp.on) {   // plane-split stationary sweep: PT0 = n-tiles of g_x per wave

@@ -1030,12 +1030,12 @@ bool split_eligible(const RolloutParams& p) {
 }
 
 // Streamed-split forward kernels: every hidden layer of the policy (and of the tail value net) 256 wide, at most 256 padded
-// inputs, fp32, closed loop, pyth_lq / pyth_veh3dofconti - the launches the register-stationary kernels do not take (three
+// inputs, fp32, closed loop, every env model - the launches the register-stationary kernels do not take (three
 // hidden layers, a tail value net with more tiles than CUs).  The backward sweep of such a launch stays on the fp32-MFMA
 // kernels: both forward variants write the same feature-major stash.  GOPS_SS=0 switches it off.
 bool ss_eligible(const RolloutParams& p) {
     if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
-    if (p.env.kind != GOPS_ENV_LQ && p.env.kind != GOPS_ENV_VEH3DOFCONTI) return false;
+    if (p.env.kind == GOPS_ENV_NONE) return false;   // (value / MLP batches: one step, nothing to gain)
     if (kinked_with_tail(p)) return false;
     if (const char* e = getenv("GOPS_SS")) if (e[0] == '0') return false;
     if (const char* e = getenv("GOPS_SK")) if (e[0] == '0') return false;   // "0,..": plain streamed kernels forced
@@ -1145,9 +1145,17 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
         if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, true, false, false, false, false, true>, grid, block, lds_ss, stream, dp);   \
         else launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, false, false, false, false, false, true>, grid, block, lds_ss, stream, dp);         \
     } while (0)
-        if (p.env.kind == GOPS_ENV_LQ) LAUNCH_FWD_SS(GOPS_ENV_LQ);
-        else if (p.env.kind == GOPS_ENV_VEH3DOFCONTI) LAUNCH_FWD_SS(GOPS_ENV_VEH3DOFCONTI);
-        else return hipErrorInvalidValue;
+        switch (p.env.kind) {
+            case GOPS_ENV_LQ: LAUNCH_FWD_SS(GOPS_ENV_LQ); break;
+            case GOPS_ENV_IDPENDULUM: LAUNCH_FWD_SS(GOPS_ENV_IDPENDULUM); break;
+            case GOPS_ENV_VEH3DOFCONTI: LAUNCH_FWD_SS(GOPS_ENV_VEH3DOFCONTI); break;
+            case GOPS_ENV_VEH3DOF_SURR: LAUNCH_FWD_SS(GOPS_ENV_VEH3DOF_SURR); break;
+            case GOPS_ENV_CARTPOLE: LAUNCH_FWD_SS(GOPS_ENV_CARTPOLE); break;
+            case GOPS_ENV_PENDULUM: LAUNCH_FWD_SS(GOPS_ENV_PENDULUM); break;
+            case GOPS_ENV_VEH2DOF: LAUNCH_FWD_SS(GOPS_ENV_VEH2DOF); break;
+            case GOPS_ENV_MOBILEROBOT: LAUNCH_FWD_SS(GOPS_ENV_MOBILEROBOT); break;
+            default: return hipErrorInvalidValue;
+        }
         return hipGetLastError();
     }
     if (p.f16) {   // half-precision kernels: weights streamed from L2, four workgroups per CU

@@ -151,6 +151,13 @@ SS_CASES = {
     "veh_p30_4x256_fhadp": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=70, horizon=5, pre_horizon=30, hidden=(256, 256, 256, 256), act="elu", gamma=1.0),
     "lq_s4a2_infadp_many_tiles": dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=4096 + 16 * 21 + 3, horizon=6, hidden=(256, 256), act="gelu", gamma=0.99),
     "lq_s6a3_3x256_fhadp": dict(alg="FHADP", env_id="pyth_lq", lq_config="s6a3", batch=50, horizon=9, hidden=(256, 256, 256), act="tanh", gamma=0.97),
+    # the other env models (the routines do not depend on the model: one instantiation each)
+    "idp_3x256_fhadp": dict(alg="FHADP", env_id="pyth_idpendulum", batch=70, horizon=8, hidden=(256, 256, 256), act="gelu", gamma=1.0),
+    "surrcstr_2x256_fhadp": dict(alg="FHADP", env_id="pyth_veh3dofconti_surrcstr", batch=60, horizon=6, pre_horizon=10, hidden=(256, 256), act="elu", gamma=1.0),
+    "veh2dof_2x256_infadp": dict(alg="INFADP", env_id="pyth_veh2dofconti", batch=90, horizon=7, pre_horizon=10, hidden=(256, 256), act="gelu", gamma=0.99),
+    "cartpole_3x256_infadp": dict(alg="INFADP", env_id="gym_cartpoleconti", batch=64, horizon=8, hidden=(256, 256, 256), act="tanh", gamma=0.99),
+    "pendulum_2x256_fhadp": dict(alg="FHADP", env_id="gym_pendulum", batch=40, horizon=6, hidden=(256, 256), act="elu", gamma=0.98),
+    "mobilerobot_2x256_infadp": dict(alg="INFADP", env_id="pyth_mobilerobot", batch=50, horizon=6, hidden=(256, 256), act="gelu", gamma=0.99),
 }
 
 
@@ -160,6 +167,8 @@ def test_streamed_split_forward_vs_oracle_and_fp32_mfma(name, dev, monkeypatch):
     from gops_amd import hip_backend as hb
     cfg = SS_CASES[name]
     data = make_batch(cfg, 5)
+    if cfg["env_id"] == "pyth_mobilerobot":
+        data["noise"] = torch.randn(cfg["horizon"], cfg["batch"], 2, generator=torch.Generator().manual_seed(3)) * torch.tensor([0.03, 0.02])
     nets = reference_init_nets(cfg, 5, obs_dim_of(cfg), act_dim_of(cfg))
     env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
     fh = cfg["alg"] == "FHADP"

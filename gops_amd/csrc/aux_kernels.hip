@@ -835,6 +835,252 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised ring GEMM (two-half-plane products) for the layers with N % 256 == 0.  Measured on the 4-wave ring
+// kernel at the target (two GEMMs per update, 165 us): without the conversion 128 us, without the MFMAs 123 us - stash
+// stream (~85 us at 6 TB/s), conversion VALU and MFMAs ADD, because all waves of a workgroup convert, then all multiply, and
+// the co-resident workgroup falls into the same rhythm.  Here the two kinds of work run side by side on every SIMD:
+//   * 512 threads, one workgroup per CU, 256 x 128 outputs (every delta element is fetched and converted by ONE workgroup
+//     per K-tile), three 48-KiB stages [D q0][D q0+1][X q0][X q0+1] of 32 samples;
+//   * waves 0-3 CONVERT block c + 1 in place (fp32 -> hi / lo half planes, 6 items per thread) while waves 4-7 MULTIPLY
+//     block c (128 x 64 outputs per wave, 96 MFMAs); all eight waves issue the LDS-DMA copies of block c + 2 (6 KiB each);
+//   * ONE barrier per block: converted block c + 1 is published, block c's stage is free for the copies of block c + 3,
+//     and each wave has waited for its own copies of block c + 2.
+// Saturated half planes (a diverged rollout): the workgroup repeats its blocks with the exact three-plane split on the same
+// four multiplying waves, from unconverted stages.
+// ---------------------------------------------------------------------------------------------
+struct DwSpec {
+    static constexpr int NW = 8, NT = 512, TN = 256, T = 128;
+    static constexpr int DT = TN * 16;                       // floats of one D sample tile
+    static constexpr int STAGES = 3;
+    static constexpr int STAGE_FLOATS = 2 * DT + 4096;       // 48 KiB
+    static constexpr int PIECES = STAGE_FLOATS / 256 / NW;   // 1-KiB copies per wave and block
+    static constexpr size_t lds_bytes() { return (size_t)STAGES * STAGE_FLOATS * sizeof(float) + 16; }
+};
+
+struct DwSpecGeo {
+    const float* dbase;   // D + tile_n * 256 * 16
+    const float* xbase;   // X + tile_k * 128 * 16
+    float* pbase;         // part + split * N * Kp
+    long long Q;
+    int N, Kp, split, splits, nblk, nfull, xgroups, tile_n, tile_k;
+};
+// copy job of a wave: pieces wave * PIECES .. + PIECES - 1 of a stage; a piece = 16 features x 16 rows (1 KiB, contiguous in the
+// stash) of one sample tile of one operand, in the stage's order.  Feature groups of a partial last K-tile that do not exist
+// (>= Kp) are fetched from the tile's first groups instead: finite values whose columns are never stored.
+__device__ __forceinline__ void dw_spec_copy(const DwSpecGeo& G, float* ring, int c, int stage, int wave, int lane) {
+    constexpr int T = DwSpec::T, TN = DwSpec::TN, PC = DwSpec::PIECES;
+    const long long b0 = ((long long)G.split + (long long)c * G.splits) * 2;
+    float* dst = ring + stage * DwSpec::STAGE_FLOATS + wave * PC * 256;
+#pragma unroll
+    for (int u = 0; u < PC; ++u) {
+        const int pc = wave * PC + u;   // (wave-uniform)
+        const bool isx = pc >= 2 * (TN / 16);
+        const int q = isx ? pc - 2 * (TN / 16) : pc, per = isx ? T / 16 : TN / 16;
+        const int st_tile = q / per;
+        int grp = q - st_tile * per;
+        if (isx && grp >= G.xgroups) grp %= G.xgroups;
+        const size_t bq = (size_t)min(b0 + st_tile, G.Q - 1);
+        const float* src = (isx ? G.xbase + bq * ((size_t)G.Kp * 16) : G.dbase + bq * ((size_t)G.N * 16)) + grp * 256 + 4 * lane;
+        async_copy16_to_lds(src, dst + u * 256);
+    }
+}
+__device__ __forceinline__ void dw_spec_store(const DwSpecGeo& G, const f32x4 (&acc)[8][4], int wn, int wk, int f, int g, float unscale) {
+    const int nb = G.tile_n * DwSpec::TN + wn * 128, kb = G.tile_k * DwSpec::T + wk * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kb + 16 * j + f;
+            if (k >= G.Kp) continue;   // (partial last K-tile)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) G.pbase[(size_t)(nb + 16 * i + 4 * g + r) * G.Kp + k] = acc[i][j][r] * unscale;
+        }
+}
+// Exact pass of a workgroup whose half planes saturated: the same blocks from unconverted stages, three-plane bf16 split on
+// the four multiplying waves, results stored here.  A separate (non-inlined) function: its 128 accumulator + 60 operand
+// registers would otherwise shape the register allocation of the kernel's main loop.
+__device__ __attribute__((noinline)) void dw_spec_exact_pass(const DwSpecGeo G, float* ring) {
+    constexpr int DT = DwSpec::DT, SF = DwSpec::STAGE_FLOATS, NST = DwSpec::STAGES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool mul_wave = wave >= 4;
+    const int mw = wave & 3, wn = mw >> 1, wk = mw & 1, f = lane & 15, g = lane >> 4;
+    f32x4 acc[8][4] = {};
+    dw_spec_copy(G, ring, 0, 0, wave, lane);
+    if (G.nblk > 1) dw_spec_copy(G, ring, 1, 1, wave, lane);
+    for (int c = 0; c < G.nblk; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // block c (and c + 1) landed; every wave is past block c - 1
+        if (c + 2 < G.nblk) dw_spec_copy(G, ring, c + 2, (c + 2) % NST, wave, lane);
+        if (mul_wave) {
+            const bool half_empty = c >= G.nfull;
+            const float* st = ring + (c % NST) * SF;
+            const float* da = st + (wn * 128 + f) * 16 + 4 * g;
+            const float* xa = st + 2 * DT + (wk * 64 + f) * 16 + 4 * g;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            bf16x8 b[4][3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xa + 256 * j);
+                const f32x4 x1 = half_empty ? zero4 : *reinterpret_cast<const f32x4*>(xa + 256 * j + 2048);
+                split_frag(x0, x1, b[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 d0 = *reinterpret_cast<const f32x4*>(da + 256 * i);
+                const f32x4 d1 = half_empty ? zero4 : *reinterpret_cast<const f32x4*>(da + 256 * i + DT);
+                bf16x8 a[3];
+                split_frag(d0, d1, a);
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (mul_wave) dw_spec_store(G, acc, wn, wk, f, g, 1.f);
+}
+
+__global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __restrict__ D, int N, const float* __restrict__ X, int Kp, long long Q,
+                                                              int splits, float* __restrict__ part, float* __restrict__ part_b,
+                                                              const float* __restrict__ dscale, int guard) {
+    extern __shared__ __attribute__((aligned(16))) float ring[];   // [STAGES][STAGE_FLOATS] + flag word
+    constexpr int T = DwSpec::T, TN = DwSpec::TN, DT = DwSpec::DT, SF = DwSpec::STAGE_FLOATS, NST = DwSpec::STAGES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool mul_wave = wave >= 4;   // (waves w and w + 4 share a SIMD: one converting, one multiplying)
+    const int tiles_k = (Kp + T - 1) / T, tiles = tiles_k * (N / TN);
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;   // XCD-aware order, as above
+    const int tile = local % tiles, split = (local / tiles) * 8 + xcd;
+    if (split >= splits) return;
+    const int f = lane & 15, g = lane >> 4;
+    DwSpecGeo G;
+    G.tile_n = tile / tiles_k;
+    G.tile_k = tile - G.tile_n * tiles_k;
+    G.N = N; G.Kp = Kp; G.Q = Q; G.split = split; G.splits = splits;
+    const long long nblk_all = (Q + 1) >> 1;                                  // block c of this split is block split + c * splits
+    G.nblk = (int)((nblk_all - split + splits - 1) / splits);
+    const bool odd_tail = (Q & 1) && ((nblk_all - 1) % splits == split);
+    G.nfull = odd_tail ? G.nblk - 1 : G.nblk;
+    G.xgroups = min(T, Kp - G.tile_k * T) >> 4;
+    G.dbase = D + (size_t)G.tile_n * TN * 16;
+    G.xbase = X + (size_t)G.tile_k * T * 16;
+    G.pbase = part + (size_t)split * N * Kp;
+    const int nblk = G.nblk, nfull = G.nfull;
+
+    // multiplying waves: 128 x 64 outputs each
+    const int mw = wave & 3, wn = mw >> 1, wk = mw & 1;
+    f32x4 acc[8][4] = {};
+    const float sd = f16_grad_scale(gptr(dscale)[0]) * 16.f;
+    auto block_h2 = [&](int stage) {
+        const float* st = ring + stage * SF;
+        const float* da = st + (wn * 128 + f) * 16 + 4 * g;            // D fragments of row-tile i: + 256 i  (lo plane: + DT)
+        const float* xa = st + 2 * DT + (wk * 64 + f) * 16 + 4 * g;    // X fragments of column-tile j: + 256 j  (lo plane: + 2048)
+        f16x8 bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bh[j] = *reinterpret_cast<const f16x8*>(xa + 256 * j);
+            bl[j] = *reinterpret_cast<const f16x8*>(xa + 256 * j + 2048);
+        }
+        // D fragments double-buffered behind scheduling barriers (left alone, hipcc hoists all sixteen reads: 64 registers, spills)
+        f16x8 ah = *reinterpret_cast<const f16x8*>(da), al = *reinterpret_cast<const f16x8*>(da + DT);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f16x8 nh = ah, nl = al;
+            if (i + 1 < 8) {
+                nh = *reinterpret_cast<const f16x8*>(da + 256 * (i + 1));
+                nl = *reinterpret_cast<const f16x8*>(da + 256 * (i + 1) + DT);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ah = nh; al = nl;
+        }
+    };
+
+    // converting waves (threads 0 .. 255): items k < 4: D feature (tid >> 2) + 64 k, k = 4, 5: X feature (tid >> 2) + 64 (k - 4);
+    // sample group tid & 3.  The same items every block: the bias column sums accumulate in the converting thread.
+    float vmax = 0.f;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    auto convert_stage = [&]<bool LAST_HALF_EMPTY>(int stage) {
+        float* st = ring + stage * SF;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const bool isd = k < 4;
+            const int fe = (tid >> 2) + 64 * (isd ? k : k - 4), gg = tid & 3, second = isd ? DT : 2048;
+            float* at = st + (isd ? 0 : 2 * DT) + fe * 16 + 4 * gg;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(at);
+            const f32x4 v1 = LAST_HALF_EMPTY ? zero4 : *reinterpret_cast<const f32x4*>(at + second);
+            if (isd) csum[k & 3] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+            const float sc = isd ? sd : DW_H2_SA;
+            const float m0 = fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3])));
+            const float m1 = fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3])));
+            vmax = fmaxf(vmax, fmaxf(m0, m1) * sc);
+            f16x8 ph, pl;
+            split2h(v0, v1, sc, ph, pl);
+            *reinterpret_cast<f16x8*>(at) = ph;
+            *reinterpret_cast<f16x8*>(at + second) = pl;
+        }
+    };
+    auto landed_and_sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    unsigned* sat = reinterpret_cast<unsigned*>(ring + NST * SF);
+    if (tid == 0) *sat = 0u;
+    dw_spec_copy(G, ring, 0, 0, wave, lane);
+    if (nblk > 1) dw_spec_copy(G, ring, 1, 1, wave, lane);
+    landed_and_sync();
+    if (!mul_wave) {
+        if (0 < nfull) convert_stage.template operator()<false>(0);
+        else convert_stage.template operator()<true>(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nblk; ++c) {
+        if (c + 2 < nblk) dw_spec_copy(G, ring, c + 2, (c + 2) % NST, wave, lane);
+        if (mul_wave) {
+            block_h2(c % NST);
+        } else if (c + 1 < nblk) {
+            if (c + 1 < nfull) convert_stage.template operator()<false>((c + 1) % NST);
+            else convert_stage.template operator()<true>((c + 1) % NST);
+        }
+        landed_and_sync();
+    }
+    if (!mul_wave) {
+        if (!(vmax < 65504.f)) *sat = 1u;
+        if (part_b != nullptr && G.tile_k == 0) {   // groups gg = tid & 3 of a feature sit in 4 adjacent lanes (formed from the fp32 values)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = csum[k];
+                t += __shfl_xor(t, 1);
+                t += __shfl_xor(t, 2);
+                if ((tid & 3) == 0) part_b[(size_t)split * N + G.tile_n * TN + 64 * k + (tid >> 2)] = t;
+            }
+        }
+    }
+    __syncthreads();
+    if (*sat != 0u && guard) {   // a diverged rollout: time, never a wrong gradient
+        dw_spec_exact_pass(G, ring);
+        return;
+    }
+    if (mul_wave) dw_spec_store(G, acc, wn, wk, f, g, 1.f / (sd * DW_H2_SA));   // (powers of two: exact)
+}
+
+// The layers the wave-specialised kernel takes (GOPS_DW_SPEC=0: the 4-wave ring kernel)
+static bool dw_spec_ok(int N, int Kp) {
+    static const bool off = getenv("GOPS_DW_SPEC") != nullptr && getenv("GOPS_DW_SPEC")[0] == '0';
+    return !off && (N % 256) == 0 && ((Kp % 128) == 0 || (Kp > 128 && (Kp % 16) == 0));
+}
+
 // dscale: device pointer to max|grad_v| of the launch (the deltas' magnitude reference), or null: with it the large
 // layers run the two-half-plane products (22 significant bits per operand), without it - or with GOPS_DW_EXACT set -
 // the exact three-plane bf16 split.
@@ -849,7 +1095,11 @@ hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long lo
     static const bool no_ring = getenv("GOPS_DW_DIRECT") != nullptr;   // A/B knob: register-direct kernel for the large layers too
     if (big && !force_f32 && !no_ring && (N % 128) == 0 && ((Kp % 128) == 0 || (Kp > 128 && (Kp % 16) == 0))) {
         const float* none = nullptr;
-        if (dscale != nullptr && !force_exact) {
+        if (dscale != nullptr && !force_exact && dw_spec_ok(N, Kp)) {
+            const dim3 grids(((N / 256) * ((Kp + 127) / 128)) * ((splits + 7) / 8) * 8);
+            launch_with_lds(dw_gemm_spec_kernel, grids, dim3(512), DwSpec::lds_bytes(), s, D, N, X, Kp, Q, splits, part, part_b, dscale,
+                            no_guard ? 0 : 1);
+        } else if (dscale != nullptr && !force_exact) {
             launch_with_lds(dw_gemm_ring_kernel<true>, grid, block, (size_t)DWR_STAGES * DWR_STAGE_FLOATS * sizeof(float) + 16, s, D, N, X, Kp, Q,
                             splits, chunks_per_split, part, part_b, dscale, no_guard ? 0 : 1);
         } else {

@@ -442,6 +442,27 @@ def test_shape_sweep_matches_oracle(cfg, dev):
     assert rel_l2(flat, flat_ref) < TOL, rel_l2(flat, flat_ref)
 
 
+_WIDE = [   # layers wider than 256: several 256-row tiles per weight-gradient GEMM (wave-specialised kernel), 512-deep K
+    dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=90, horizon=7, hidden=(512, 256), act="elu", gamma=0.99),
+    dict(alg="FHADP", env_id="pyth_veh3dofconti", pre_horizon=10, batch=50, horizon=5, hidden=(256, 512), act="gelu", gamma=1.0),
+    dict(alg="FHADP", env_id="pyth_idpendulum", batch=33, horizon=9, hidden=(512, 512), act="tanh", gamma=0.98),   # 27 sample tiles: odd
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", _WIDE, ids=lambda c: f"{c['env_id'][5:]}-{'x'.join(map(str, c['hidden']))}")
+def test_wide_layers_match_oracle(cfg, dev):
+    seed = 11
+    data = make_batch(cfg, seed)
+    nets = reference_init_nets(cfg, seed, obs_dim_of(cfg), act_dim_of(cfg))
+    env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
+    res, grads = _run_fhadp(env, nets, data, cfg, dev)
+    ref = orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+    assert rel_l2(res["v_pi"].cpu(), ref["v_pi"]) < TOL
+    for i, (got, want) in enumerate(zip(grads, ref["grads"])):
+        assert rel_l2(got.cpu(), want) < TOL, (i, rel_l2(got.cpu(), want))
+
+
 _STATIONARY = [  # 256-256 policies on <= 256 tiles: the register-stationary / LDS-staged kernel variants of every env
     dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=200, horizon=12, hidden=(256, 256), act="gelu", gamma=0.99),
     dict(alg="FHADP", env_id="pyth_lq", lq_config="s6a3", batch=77, horizon=9, hidden=(256, 256), act="tanh", gamma=1.0),

@@ -22,6 +22,7 @@ hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipS
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s);
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
                           int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s, const float* dscale = nullptr);
+bool dw_skinny_ok(int N, int Kp);   // aux_kernels.hip
 hipError_t launch_dw_gemm_f16(const void* D, int N, const void* X, int Kp, long long S, int splits,
                               int chunks_per_split, float* part, float* part_b, hipStream_t s);
 hipError_t launch_dw_out(const float* dy, const float* h, bool h_is_half, int K, int A, long long S, int splits,
@@ -119,7 +120,8 @@ DwPlan plan_dw(int N, int Kp, long long S, bool f16 = false) {
     DwPlan d;
     d.big = f16 || (N >= 128 && Kp >= 128);   // the half-precision GEMM has one tile size (128) and 64-sample chunks
     const int T = d.big ? 128 : 64;
-    const int tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
+    int tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
+    if (!f16 && dw_skinny_ok(N, Kp)) tiles = (N + 255) / 256;   // dw_skinny_kernel: one workgroup per 256 features and split
     const int sc = f16 ? 64 : DW_SC_HOST;
     const long long chunks = (S + sc - 1) / sc;
     static const int wg_target = getenv("GOPS_DW_WGS") ? atoi(getenv("GOPS_DW_WGS")) : 512;   // tuning knob: workgroups per GEMM

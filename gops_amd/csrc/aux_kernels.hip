@@ -1075,6 +1075,94 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
     if (mul_wave) dw_spec_store(G, acc, wn, wk, f, g, 1.f / (sd * DW_H2_SA));   // (powers of two: exact)
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of a layer with 16 (padded) inputs - layer 0 of the pyth_lq / pyth_idpendulum / gym / mobilerobot nets:
+// dW[n][k] = sum_s D[s][n] X[s][k], k < 16.  Bound by the D stream (4 N bytes per sample; X adds 64): with 16 output columns
+// the matrix core has next to nothing to do (4 MFMAs per 16 features and sample tile), so the products are EXACT fp32
+// (`v_mfma_f32_16x16x4_f32`) - no operand split, no scale, no fallback; the 64 x 64-tile kernel above spends three quarters
+// of its splits and MFMAs on padding columns here (cfg5: 138 us for 335 MB).  Lane (f, g) of a fragment holds samples
+// 4g .. 4g+3 of feature f - ONE 16-byte load per 16 features x 16 samples, a contiguous KiB per wave; MFMA e of a tile
+// contracts samples {e, 4 + e, 8 + e, 12 + e} (element e of every lane's vector, the same order for both operands).
+// Workgroup = 4 waves x up to 4 blocks of 16 features (256 features); split s takes the sample tiles s, s + splits, ...;
+// two batches of DWK_U tiles alternate in registers (one in flight while the other is multiplied).
+// ---------------------------------------------------------------------------------------------
+#define DWK_U 2
+__global__ __launch_bounds__(NTHREADS, 3) void dw_skinny_kernel(const float* __restrict__ D, int N, const float* __restrict__ X, long long Q,
+                                                                 int splits, float* __restrict__ part, float* __restrict__ part_b) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = lane & 15, g = lane >> 4;
+    const int ngroups = (N + 255) / 256;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;   // XCD-aware order, as above
+    const int grp = local % ngroups, split = (local / ngroups) * 8 + xcd;
+    if (split >= splits) return;
+    int doff[4], nfeat[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        nfeat[i] = 256 * grp + 16 * (wave + 4 * i);                       // first feature of this wave's block i
+        doff[i] = min(nfeat[i] + f, N - 1) * 16 + 4 * g;                  // (blocks past N: clamped, never stored)
+    }
+    const int xoff = f * 16 + 4 * g;
+    const GLOBAL_AS float* Dg = gptr(D);
+    const GLOBAL_AS float* Xg = gptr(X);
+    const size_t dtile = (size_t)N * 16;
+    struct Batch { f32x4 d[DWK_U][4]; f32x4 x[DWK_U]; };
+    auto load = [&](long long q0, Batch& b) {   // tiles q0, q0 + splits, ...: past the end -> the last tile with X = 0
+#pragma unroll
+        for (int u = 0; u < DWK_U; ++u) {
+            const long long q = q0 + (long long)u * splits;
+            const size_t qq = (size_t)min(q, Q - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b.d[u][i] = *reinterpret_cast<const GLOBAL_AS f32x4*>(Dg + qq * dtile + doff[i]);
+            b.x[u] = *reinterpret_cast<const GLOBAL_AS f32x4*>(Xg + qq * 256 + xoff);
+        }
+    };
+    f32x4 acc[4] = {};
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    auto mul = [&](long long q0, const Batch& b) {
+#pragma unroll
+        for (int u = 0; u < DWK_U; ++u) {
+            const bool live = q0 + (long long)u * splits < Q;
+            f32x4 x = b.x[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = live ? x[e] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 d = b.d[u][i];
+                bsum[i] += live ? (d[0] + d[1]) + (d[2] + d[3]) : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[e], x[e], acc[i], 0, 0, 0);
+            }
+        }
+    };
+    const long long stride = (long long)DWK_U * splits;
+    Batch b0, b1;
+    load(split, b0);
+    for (long long q = split; q < Q; q += 2 * stride) {
+        load(q + stride, b1);
+        mul(q, b0);
+        load(q + 2 * stride, b0);
+        mul(q + stride, b1);
+    }
+    float* pbase = part + (size_t)split * N * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (nfeat[i] >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pbase[(size_t)(nfeat[i] + 4 * g + r) * 16 + f] = acc[i][r];
+        if (part_b != nullptr) {
+            float t = bsum[i];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            if (g == 0) part_b[(size_t)split * N + nfeat[i] + f] = t;
+        }
+    }
+}
+// GOPS_DW_SKINNY=0: the 64 x 64-tile kernel for these layers too
+bool dw_skinny_ok(int N, int Kp) {
+    static const bool off = getenv("GOPS_DW_SKINNY") != nullptr && getenv("GOPS_DW_SKINNY")[0] == '0';
+    return !off && Kp == 16 && (N % 16) == 0;
+}
+
 // The layers the wave-specialised kernel takes (GOPS_DW_SPEC=0: the 4-wave ring kernel)
 static bool dw_spec_ok(int N, int Kp) {
     static const bool off = getenv("GOPS_DW_SPEC") != nullptr && getenv("GOPS_DW_SPEC")[0] == '0';
@@ -1107,6 +1195,8 @@ hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long lo
                             splits, chunks_per_split, part, part_b, none, 1);
         }
     }
+    else if (!force_f32 && dw_skinny_ok(N, Kp))
+        hipLaunchKernelGGL(dw_skinny_kernel, dim3(((N + 255) / 256) * ((splits + 7) / 8) * 8), block, 0, s, D, N, X, Q, splits, part, part_b);
     else if (big && !force_f32) hipLaunchKernelGGL((dw_gemm_fm_kernel<4, true>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
     else if (big) hipLaunchKernelGGL((dw_gemm_fm_kernel<4, false>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
     else if (!force_f32) hipLaunchKernelGGL((dw_gemm_fm_kernel<2, true>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);

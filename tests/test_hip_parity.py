@@ -598,3 +598,48 @@ def test_default_reference_constants_are_the_same_on_both_sides_of_the_abi(dev):
     o0, r0, d0, i0 = hb.env_step(env0, data["obs"], a, data["done"], info)
     o1, r1, d1, i1 = hb.env_step(env1, data["obs"], a, data["done"], info)
     assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(i0["ref_points"], i1["ref_points"])
+
+
+# ---- size-independent properties at the BASELINE.json sizes (no oracle run is affordable there) -----------------------------
+def _gradient(cfg, nets, data, dev, grad_scale=1.0, perm=None):
+    """v_pi and the flat policy gradient of loss = -grad_scale * mean(v_pi) for a (possibly permuted / sliced) batch."""
+    from gops_amd import hip_backend as hb
+    env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
+    if perm is not None:
+        data = {k: v[perm] for k, v in data.items()}
+    B = data["obs"].shape[0]
+    henv = hip_env_from_oracle(env, nets["policy"])
+    pol, pw, pb = hip_mlp_from_net(nets["policy"], dev)
+    fh = cfg["alg"] == "FHADP"
+    vt = None if fh else hip_mlp_from_net(nets["v_target"], dev)[0]
+    ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=fh, need_grad=True, value=vt)
+    res = ro.forward(to_device(data, dev))
+    gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]
+    ro.backward(torch.full((B,), -grad_scale / B, device=dev), gw, gb)
+    torch.cuda.synchronize()
+    return res["v_pi"].cpu(), torch.cat([t.reshape(-1).cpu() for pair in zip(gw, gb) for t in pair])
+
+
+@pytest.mark.parametrize("name", ["target_veh3dof_fhadp_b4096_h30", "cfg2_idp_fhadp_b4096_h30", "cfg5_lq_infadp_b65536"])
+def test_full_size_properties(name, dev):
+    """At the full BASELINE shapes: (a) the full-batch gradient is the mean of the two half-batch gradients (other tile counts,
+    partly other kernel variants), (b) v_pi of a permuted batch is the permuted v_pi, bit for bit (a trajectory's arithmetic
+    does not depend on its tile or row), and its gradient is the same up to summation order, (c) the gradient is linear in
+    grad_v (a power of two: exactly)."""
+    cfg = CONFIGS[name]
+    data = make_batch(cfg, 3)
+    nets = reference_init_nets(cfg, 3, obs_dim_of(cfg), act_dim_of(cfg))
+    B = cfg["batch"]
+    v_full, g_full = _gradient(cfg, nets, data, dev)
+    assert torch.isfinite(g_full).all() and g_full.norm() > 0
+    idx = torch.arange(B)
+    v_a, g_a = _gradient(cfg, nets, data, dev, perm=idx[: B // 2])
+    v_b, g_b = _gradient(cfg, nets, data, dev, perm=idx[B // 2:])
+    assert torch.equal(torch.cat((v_a, v_b)), v_full)
+    assert rel_l2(0.5 * (g_a + g_b), g_full) < 2e-5, rel_l2(0.5 * (g_a + g_b), g_full)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))
+    v_p, g_p = _gradient(cfg, nets, data, dev, perm=perm)
+    assert torch.equal(v_p, v_full[perm])
+    assert rel_l2(g_p, g_full) < 2e-5, rel_l2(g_p, g_full)
+    _, g_4 = _gradient(cfg, nets, data, dev, grad_scale=4.0)
+    assert rel_l2(g_4, 4.0 * g_full) < 1e-6, rel_l2(g_4, 4.0 * g_full)

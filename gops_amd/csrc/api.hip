@@ -17,6 +17,8 @@ size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int spl
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split, bool ssb = false);
 bool split_eligible(const RolloutParams& p);
 int split_grid_limit();
+int ssb_grid_limit();     // rollout_bwd.hip
+bool ssb_fuses_out(const RolloutParams& p);
 void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s);
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s);
@@ -465,9 +467,10 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     p.dbg = dbg ? dbg_buf : nullptr;
     // Split sweep: the output layer's weight gradient is accumulated inside the sweep (one partial per workgroup) - no dw_out
     // pass.  (GELU: the sweep's act' operand is gelu'(z), so it fetches H_2 next to it.)
-    const bool fused_out = p.sp.on && !p.ext && !p.open_loop && want_params && ext_delta == nullptr &&
-                           getenv("GOPS_NO_FUSED_DWOUT") == nullptr;
-    const int sweep_grid = std::min((p.B + TB - 1) / TB, split_grid_limit());
+    // (the streamed-split sweep does the same for the env kinds whose instantiation has the registers: ssb_fuses_out)
+    const bool fused_out = (p.sp.on || ssb_fuses_out(p)) && !p.ext && !p.open_loop && want_params &&
+                           ext_delta == nullptr && getenv("GOPS_NO_FUSED_DWOUT") == nullptr;
+    const int sweep_grid = std::min((p.B + TB - 1) / TB, p.sp.on ? split_grid_limit() : ssb_grid_limit());
     if (fused_out) {
         p.sp.out_part = plan.dw_part[p.pol.nl - 1];
         p.sp.out_part_b = plan.dw_part_b[p.pol.nl - 1];

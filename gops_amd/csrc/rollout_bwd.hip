@@ -354,6 +354,37 @@ struct SplitSweep {
 };
 struct NoSweep {};
 
+// Env kinds whose streamed-split sweep has the registers for it (the vehicle / idpendulum instantiations would spill): those
+// instantiations also walk their tiles grid-stride (one partial slab per workgroup).
+__host__ __device__ constexpr bool ssb_fuse_kind(int env) {
+    return env == GOPS_ENV_LQ || env == GOPS_ENV_CARTPOLE || env == GOPS_ENV_PENDULUM || env == GOPS_ENV_MOBILEROBOT;
+}
+bool ssb_fuses_out(const RolloutParams& p) { return p.ssb && ssb_fuse_kind(p.env.kind); }
+// Output-layer weight gradient accumulated inside the streamed-split sweep (as SplitSweep does): lane (f = lane & 15,
+// g = lane >> 4) of wave w holds dW_o[a][64 w + 16 q + f] over the rows 4g .. 4g+3 of every tile and step the workgroup walked.
+struct SsOutGrad {
+    float dwo[GOPS_MAX_ACT][4];
+    float dbo[GOPS_MAX_ACT];
+};
+// this workgroup's partial -> part[blockIdx.x][a][K], part_b[blockIdx.x][a]
+__device__ __forceinline__ void ss_store_out_grad(const SsOutGrad& og, int K, int A, float* part, float* part_b, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int a = 0; a < GOPS_MAX_ACT; ++a) {
+        float tb = og.dbo[a];
+        tb += __shfl_xor(tb, 16);
+        tb += __shfl_xor(tb, 32);
+        if (a < A && tid == 0) gptr(part_b)[(size_t)blockIdx.x * A + a] = tb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float t = og.dwo[a][q];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            if (a < A && lane < 16) gptr(part)[((size_t)blockIdx.x * A + a) * K + 64 * wave + 16 * q + lane] = t;
+        }
+    }
+}
+
 // Streamed-split sweep through one net (any number of 256-wide hidden layers; the counterpart of ss_net_forward): delta_y
 // (s_gy[TB][4]) -> hidden deltas (FM stash st_d when non-null) and, if want_gx, G += delta_1 W_0.  Weight planes (transposed
 // packing, SplitNetDev) stream from L2; ONE delta plane image `dq`, rewritten in place behind a barrier; act' operands come
@@ -363,7 +394,7 @@ template <class WP, class Hook>
 __device__ __forceinline__ void ss_net_backward(const MlpDev& M, const SplitNetDev& ST, WP Wo, int ldw, const float* s_gy, const float* s_scale,
                                                 char* dq, float* G, int ldg, int tid, float* const* st_h, float* const* st_z,
                                                 float* const* st_d, float* st_dy, size_t row0, int nvalid, bool want_gx, int ncols,
-                                                Hook&& after_head) {
+                                                Hook&& after_head, SsOutGrad& og, bool fuse_out) {
     const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
     constexpr int ROWB = 2 * 256 + 16;
     const int L = M.nl - 1, A = M.dims[M.nl];
@@ -398,7 +429,28 @@ __device__ __forceinline__ void ss_net_backward(const MlpDev& M, const SplitNetD
             const float wo = (kk < A) ? Wo[kk * ldw + 64 * wave + 16 * q + (lane & 15)] : 0.f;
             acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, wo, acc[q], 0, 0, 0);
         }
+        // fused output-layer gradient, GELU: hv holds gelu'(z_L); H_L itself is fetched here (a short live range)
+        f32x4 hlv[4] = {};
+        if (fuse_out && gelu) {
+            const GLOBAL_AS float* sl = gptr(st_h[L] + row0 * 256);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hlv[q] = ld4(sl + (64 * wave + 16 * q + (lane & 15)) * 16 + m0);
+        }
         finish(L, acc, hv);
+        if (fuse_out) {   // dW_o += delta_y^T H_L over this lane's rows and columns
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 dyr = *reinterpret_cast<const f32x4*>(s_gy + (m0 + r) * 4);
+                const bool ok = m0 + r < nvalid;
+#pragma unroll
+                for (int a = 0; a < GOPS_MAX_ACT; ++a) {
+                    const float d = ok ? dyr[a] : 0.f;
+                    og.dbo[a] += d;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) og.dwo[a][q] = fmaf(d, gelu ? hlv[q][r] : hv[q][r], og.dwo[a][q]);
+                }
+            }
+        }
         if (st_dy != nullptr && tid < TB) {
             f32x4 v = {s_gy[tid * 4 + 0], s_gy[tid * 4 + 1], s_gy[tid * 4 + 2], s_gy[tid * 4 + 3]};
 #pragma unroll
@@ -547,6 +599,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
             async_copy16_to_lds(p.st.x + r0 * kp0 + 4 * ln, dst + STAGE_TILES + TB * ENV_STASH);
     };
     const int ntiles = (p.B + TB - 1) / TB;
+    SsOutGrad og = {};   // (SSB with the fused output-layer gradient; otherwise unused)
     do {   // ---- one tile of 16 trajectories ----
     b0 = tile * TB;
     nvalid = min(TB, p.B - b0);
@@ -606,7 +659,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
         __syncthreads();
         if constexpr (SSB)
             ss_net_backward(p.val, p.ssvt, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, s_scale, dq2, G, ldx, tid,
-                            p.st.tail_h, p.st.tail_z, nullptr, nullptr, (size_t)b0, nvalid, true, O, [] {});
+                            p.st.tail_h, p.st.tail_z, nullptr, nullptr, (size_t)b0, nvalid, true, O, [] {}, og, false);
         else
         if constexpr (F16)
             mlp_backward_h(p.val, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, reinterpret_cast<_Float16*>(da),
@@ -1270,7 +1323,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
                    q.out_part != nullptr);
         } else if constexpr (SSB) {
             ss_net_backward(p.pol, p.sspt, s_wo, ldh, s_gy, s_scale, dq2, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
-                            /*want_gx=*/t > 0, O, warm_up);
+                            /*want_gx=*/t > 0, O, warm_up, og, ssb_fuse_kind(ENV) && q.out_part != nullptr);
         } else
         if (!p.open_loop) {
             if constexpr (F16)
@@ -1313,7 +1366,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
     if constexpr (SPLIT) {
         if (q.out_part != nullptr && tile + (int)gridDim.x >= ntiles) SS.store_out_grad(p, q.out_part, q.out_part_b, tid);   // after the last tile
     }
-    } while (SPLIT && MULTI && (tile += gridDim.x) < ntiles);   // (every step ends with a barrier: the next tile's set-up may overwrite G / s_ref)
+    if constexpr (SSB && ssb_fuse_kind(ENV)) {
+        if (q.out_part != nullptr && tile + (int)gridDim.x >= ntiles)
+            ss_store_out_grad(og, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], q.out_part, q.out_part_b, tid);   // after the last tile
+    }
+    } while ((SPLIT || SSB) && MULTI && (tile += gridDim.x) < ntiles);   // (every step ends with a barrier: the next tile's set-up may overwrite G / s_ref)
     dbg.dump(q.dbg);
 }
 
@@ -1328,6 +1385,7 @@ size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool sp
 
 void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
 int split_grid_limit();   // rollout_fwd.hip: CUs of the device
+int ssb_grid_limit() { return 2 * split_grid_limit(); }   // workgroups of the streamed-split sweep (= slabs of its fused output-layer gradient)
 
 // The sweep of a streamed-split forward launch (p.ss) on the streamed-split sweep as well: same conditions, its LDS image at
 // two workgroups per CU.  GOPS_SSB=0 keeps the fp32-MFMA sweep.
@@ -1383,10 +1441,13 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
     }
     if (p.ssb && !p.ext && !p.open_loop) {   // streamed-split sweep
         const size_t lds_ss = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false, true);
+        const dim3 grid_ss(std::min<int>((p.B + TB - 1) / TB, ssb_grid_limit()));   // two workgroups per CU walk the tiles grid-stride
 #define LAUNCH_BWD_SS(ENV)                                                                                                                  \
     do {                                                                                                                                    \
-        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, false, false, false, false, true>, grid, block, lds_ss, stream, dp, q);   \
-        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, false, false, false, false, true>, grid, block, lds_ss, stream, dp, q);         \
+        constexpr bool MT = ssb_fuse_kind(ENV);   /* grid-stride walk + fused output-layer gradient */                                        \
+        const dim3 g = MT ? grid_ss : grid;                                                                                                   \
+        if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, false, false, false, MT, true>, g, block, lds_ss, stream, dp, q);   \
+        else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, false, false, false, MT, true>, g, block, lds_ss, stream, dp, q);         \
     } while (0)
         switch (p.env.kind) {
             case GOPS_ENV_LQ: LAUNCH_BWD_SS(GOPS_ENV_LQ); break;

@@ -1439,7 +1439,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
         }
         return hipGetLastError();
     }
-    if (p.ssb && !p.ext && !p.open_loop) {   // streamed-split sweep
+    if (p.ssb && !p.ext && !p.open_loop && q.ext_delta == nullptr) {   // streamed-split sweep (gops_mlp_backward's hidden-stack deltas: the fp32 sweep)
         const size_t lds_ss = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false, true);
         const dim3 grid_ss(std::min<int>((p.B + TB - 1) / TB, ssb_grid_limit()));   // two workgroups per CU walk the tiles grid-stride
 #define LAUNCH_BWD_SS(ENV)                                                                                                                  \
@@ -1450,6 +1450,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
         else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, false, false, false, MT, true>, g, block, lds_ss, stream, dp, q);         \
     } while (0)
         switch (p.env.kind) {
+            case GOPS_ENV_NONE: LAUNCH_BWD_SS(GOPS_ENV_NONE); break;
             case GOPS_ENV_LQ: LAUNCH_BWD_SS(GOPS_ENV_LQ); break;
             case GOPS_ENV_IDPENDULUM: LAUNCH_BWD_SS(GOPS_ENV_IDPENDULUM); break;
             case GOPS_ENV_VEH3DOFCONTI: LAUNCH_BWD_SS(GOPS_ENV_VEH3DOFCONTI); break;

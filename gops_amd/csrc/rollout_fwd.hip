@@ -1035,7 +1035,17 @@ bool split_eligible(const RolloutParams& p) {
 // kernels: both forward variants write the same feature-major stash.  GOPS_SS=0 switches it off.
 bool ss_eligible(const RolloutParams& p) {
     if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
-    if (p.env.kind == GOPS_ENV_NONE) return false;   // (value / MLP batches: one step, nothing to gain)
+    // OPEN ISSUE (round 3, tools/gpu/dbg_poison.py): with two of these workgroups on a CU the veh3dofconti instantiations are
+    // not run-to-run deterministic - whole tiles of v_pi move by up to 5e-4 relative between identical launches (first launch
+    // of a process against later ones, and by dispatch order); one workgroup per CU (LDS padding) is bit-stable, extra barriers
+    // around the net evaluation and at the step end change nothing, every other env kind is bit-stable in the forward.  Until
+    // that is understood these launches keep the fp32-MFMA kernels (GOPS_SS_VEH=1 re-enables them for the hunt).
+    if (p.env.kind == GOPS_ENV_VEH3DOFCONTI || p.env.kind == GOPS_ENV_VEH3DOF_SURR) {
+        const char* e = getenv("GOPS_SS_VEH");
+        if (e == nullptr || e[0] != '1') return false;
+    }
+    // (value / MLP batches, GOPS_ENV_NONE: one step - half the MFMA time of the fp32 kernels; GOPS_SS_VALUE=0 keeps those)
+    if (p.env.kind == GOPS_ENV_NONE) if (const char* e = getenv("GOPS_SS_VALUE")) if (e[0] == '0') return false;
     if (kinked_with_tail(p)) return false;
     if (const char* e = getenv("GOPS_SS")) if (e[0] == '0') return false;
     if (const char* e = getenv("GOPS_SK")) if (e[0] == '0') return false;   // "0,..": plain streamed kernels forced
@@ -1146,6 +1156,7 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
         else launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, false, false, false, false, false, true>, grid, block, lds_ss, stream, dp);         \
     } while (0)
         switch (p.env.kind) {
+            case GOPS_ENV_NONE: LAUNCH_FWD_SS(GOPS_ENV_NONE); break;
             case GOPS_ENV_LQ: LAUNCH_FWD_SS(GOPS_ENV_LQ); break;
             case GOPS_ENV_IDPENDULUM: LAUNCH_FWD_SS(GOPS_ENV_IDPENDULUM); break;
             case GOPS_ENV_VEH3DOFCONTI: LAUNCH_FWD_SS(GOPS_ENV_VEH3DOFCONTI); break;

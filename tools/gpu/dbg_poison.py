@@ -1,0 +1,43 @@
+"""Uninitialised-read hunt: the same streamed-split launch pair with the workspace poisoned (NaN bytes / random bytes)
+before the forward; every result must be finite and bit-identical to the clean run."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+from helpers import hip_env_from_oracle, hip_mlp_from_net, reference_init_nets, to_device
+from oracle import adp_oracle as orc
+from gops_amd import hip_backend as hb
+from gops_amd.utils.synthetic import act_dim_of, make_batch, obs_dim_of
+
+dev = torch.device("cuda", 0)
+CASES = {
+    "veh_infadp_2x256_many": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=0.99),
+}
+for name, cfg in CASES.items():
+    data = make_batch(cfg, 5)
+    nets = reference_init_nets(cfg, 5, obs_dim_of(cfg), act_dim_of(cfg))
+    env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
+    fh = cfg["alg"] == "FHADP"
+    B = data["obs"].shape[0]
+    ddev = to_device(data, dev)
+    base = None
+    for mode in ["clean", "nan", "rand", "clean", "rand", "nan", "rand", "rand", "rand", "rand"]:
+        henv = hip_env_from_oracle(env, nets["policy"])
+        pol, pw, pb = hip_mlp_from_net(nets["policy"], dev)
+        vt = None if fh else hip_mlp_from_net(nets["v_target"], dev)[0]
+        ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=fh, need_grad=True, value=vt)
+        if mode == "nan": ro.workspace.fill_(255)           # 0xffffffff: NaN
+        elif mode == "rand": ro.workspace.random_(0, 256)
+        else: ro.workspace.zero_()
+        res = ro.forward(ddev)
+        gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]
+        ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
+        torch.cuda.synchronize()
+        flat = torch.cat([res["v_pi"].reshape(-1)] + [t.reshape(-1) for pair in zip(gw, gb) for t in pair]).cpu()
+        if base is None: base = flat
+        same = torch.equal(flat, base)
+        print("touch", os.environ.get("GOPS_TOUCH", "-"), "ssb", os.environ.get("GOPS_SSB", "1"), "nofuse", os.environ.get("GOPS_NO_FUSED_DWOUT", "-"), "spec", os.environ.get("GOPS_DW_SPEC", "1"), "exact", os.environ.get("GOPS_DW_EXACT", "-"), name, mode, "finite", bool(torch.isfinite(flat).all()), "bit-identical", same,
+              "" if same else f"rel-L2 of the gradient {float((flat[B:] - base[B:]).norm() / base[B:].norm()):.3e} max rel diff {float(((flat - base).abs() / (base.abs() + 1e-12)).max()):.3e} v_pi same {torch.equal(flat[:B], base[:B])}")
+        if not same:
+            d = (flat[:B] != base[:B]).nonzero().reshape(-1)
+            print("    differing v_pi:", d.numel(), "rows; tiles", sorted(set((d // 16).tolist()))[:20], "max abs", float((flat[:B] - base[:B]).abs().max()), "of", float(base[:B].abs().max()))
+        del ro

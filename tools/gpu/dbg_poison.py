@@ -10,7 +10,10 @@ from gops_amd.utils.synthetic import act_dim_of, make_batch, obs_dim_of
 
 dev = torch.device("cuda", 0)
 CASES = {
-    "veh_infadp_2x256_many": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=0.99),
+    "veh_p5_kc1": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=5, hidden=(256, 256), act="elu", gamma=0.99),
+    "veh_p10_kc2": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=0.99),
+    "veh_p20_kc4": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=20, hidden=(256, 256), act="elu", gamma=0.99),
+    "veh2_p50_kc2": dict(alg="INFADP", env_id="pyth_veh2dofconti", batch=4800, horizon=4, pre_horizon=50, hidden=(256, 256), act="elu", gamma=0.99),
 }
 for name, cfg in CASES.items():
     data = make_batch(cfg, 5)

@@ -10,10 +10,7 @@ from gops_amd.utils.synthetic import act_dim_of, make_batch, obs_dim_of
 
 dev = torch.device("cuda", 0)
 CASES = {
-    "veh_p5_kc1": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=5, hidden=(256, 256), act="elu", gamma=0.99),
-    "veh_p10_kc2": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=0.99),
-    "veh_p20_kc4": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=20, hidden=(256, 256), act="elu", gamma=0.99),
-    "veh2_p50_kc2": dict(alg="INFADP", env_id="pyth_veh2dofconti", batch=4800, horizon=4, pre_horizon=50, hidden=(256, 256), act="elu", gamma=0.99),
+    "veh_p10": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=0.99),
 }
 for name, cfg in CASES.items():
     data = make_batch(cfg, 5)
@@ -31,16 +28,23 @@ for name, cfg in CASES.items():
         if mode == "nan": ro.workspace.fill_(255)           # 0xffffffff: NaN
         elif mode == "rand": ro.workspace.random_(0, 256)
         else: ro.workspace.zero_()
-        res = ro.forward(ddev)
+        res = ro.forward(ddev, want_rewards=True, want_final=True)
         gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]
         ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
         torch.cuda.synchronize()
         flat = torch.cat([res["v_pi"].reshape(-1)] + [t.reshape(-1) for pair in zip(gw, gb) for t in pair]).cpu()
-        if base is None: base = flat
+        rw = res['rewards'].cpu(); fo = res['final_obs'].cpu()
+        if base is None: base = flat; base_rw = rw; base_fo = fo
         same = torch.equal(flat, base)
         print("touch", os.environ.get("GOPS_TOUCH", "-"), "ssb", os.environ.get("GOPS_SSB", "1"), "nofuse", os.environ.get("GOPS_NO_FUSED_DWOUT", "-"), "spec", os.environ.get("GOPS_DW_SPEC", "1"), "exact", os.environ.get("GOPS_DW_EXACT", "-"), name, mode, "finite", bool(torch.isfinite(flat).all()), "bit-identical", same,
               "" if same else f"rel-L2 of the gradient {float((flat[B:] - base[B:]).norm() / base[B:].norm()):.3e} max rel diff {float(((flat - base).abs() / (base.abs() + 1e-12)).max()):.3e} v_pi same {torch.equal(flat[:B], base[:B])}")
         if not same:
+            for t in range(rw.shape[0]):
+                dd = (rw[t] != base_rw[t]).nonzero().reshape(-1)
+                print("    step", t, "rewards differing:", dd.numel(), "tiles", sorted(set((dd // 16).tolist()))[:8], "max abs", float((rw[t] - base_rw[t]).abs().max()))
+            dd = (fo != base_fo).any(dim=1).nonzero().reshape(-1)
+            cols = (fo != base_fo).any(dim=0).nonzero().reshape(-1).tolist()
+            print("    final_obs rows differing:", dd.numel(), "columns", cols[:20], "max abs", float((fo - base_fo).abs().max()))
             d = (flat[:B] != base[:B]).nonzero().reshape(-1)
             print("    differing v_pi:", d.numel(), "rows; tiles", sorted(set((d // 16).tolist()))[:20], "max abs", float((flat[:B] - base[:B]).abs().max()), "of", float(base[:B].abs().max()))
         del ro

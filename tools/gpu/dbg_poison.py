@@ -1,4 +1,4 @@
-"""Uninitialised-read hunt: the same streamed-split launch pair with the workspace poisoned (NaN bytes / random bytes)
+"""Reproducibility / uninitialised-read hunt: the same streamed-split launch pair with the workspace poisoned (NaN bytes / random bytes)
 before the forward; every result must be finite and bit-identical to the clean run."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -9,9 +9,23 @@ from gops_amd import hip_backend as hb
 from gops_amd.utils.synthetic import act_dim_of, make_batch, obs_dim_of
 
 dev = torch.device("cuda", 0)
-CASES = {
-    "veh_p10": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=0.99),
+_VEH = dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=0.99)
+ALL_CASES = {
+    # the open defect (run with GOPS_SS_VEH=1; GOPS_SSB=0 isolates the forward): 300 tiles, two workgroups on 44 CUs
+    "veh_p10": _VEH,
+    "veh_p5": dict(_VEH, pre_horizon=5),
+    "veh_fhadp_3x256": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=10, hidden=(256, 256, 256), act="relu", gamma=0.99),
+    "veh_h1": dict(_VEH, horizon=1),            # bit-stable
+    "veh_256_tiles": dict(_VEH, batch=4096),    # bit-stable: one workgroup per CU
+    # kinds that are on by default: bit-stable returns, gradient spread <= 1.4e-6 from the sweep
+    "lq_many": dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=4800, horizon=6, hidden=(256, 256), act="gelu", gamma=0.99),
+    "veh2_many": dict(alg="INFADP", env_id="pyth_veh2dofconti", batch=4800, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=0.99),
+    "idp_many": dict(alg="FHADP", env_id="pyth_idpendulum", batch=4800, horizon=4, hidden=(256, 256, 256), act="elu", gamma=0.99),
+    # register-stationary plane-split kernels (one workgroup per CU): bit-stable
+    "veh_split": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=200, horizon=12, pre_horizon=30, hidden=(256, 256), act="elu", gamma=0.99),
 }
+# usage: [GOPS_SS_VEH=1] [GOPS_SSB=0] python tools/gpu/dbg_poison.py [case ...]     (default: veh_p10 lq_many)
+CASES = {k: ALL_CASES[k] for k in (sys.argv[1:] or ["veh_p10", "lq_many"])}
 for name, cfg in CASES.items():
     data = make_batch(cfg, 5)
     nets = reference_init_nets(cfg, 5, obs_dim_of(cfg), act_dim_of(cfg))

@@ -9,6 +9,7 @@ from gops_amd import hip_backend as hb
 from gops_amd.utils.synthetic import act_dim_of, make_batch, obs_dim_of
 
 dev = torch.device("cuda", 0)
+NEED_GRAD = os.environ.get("DBG_NOGRAD") is None   # DBG_NOGRAD=1: forward only, without the activation stash
 _VEH = dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=0.99)
 ALL_CASES = {
     # the open defect (run with GOPS_SS_VEH=1; GOPS_SSB=0 isolates the forward): 300 tiles, two workgroups on 44 CUs
@@ -38,13 +39,14 @@ for name, cfg in CASES.items():
         henv = hip_env_from_oracle(env, nets["policy"])
         pol, pw, pb = hip_mlp_from_net(nets["policy"], dev)
         vt = None if fh else hip_mlp_from_net(nets["v_target"], dev)[0]
-        ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=fh, need_grad=True, value=vt)
+        ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=fh, need_grad=NEED_GRAD, value=vt)
         if mode == "nan": ro.workspace.fill_(255)           # 0xffffffff: NaN
         elif mode == "rand": ro.workspace.random_(0, 256)
         else: ro.workspace.zero_()
         res = ro.forward(ddev, want_rewards=True, want_final=True)
         gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]
-        ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
+        if NEED_GRAD: ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
+        else: [t.zero_() for t in gw + gb]
         torch.cuda.synchronize()
         flat = torch.cat([res["v_pi"].reshape(-1)] + [t.reshape(-1) for pair in zip(gw, gb) for t in pair]).cpu()
         rw = res['rewards'].cpu(); fo = res['final_obs'].cpu()

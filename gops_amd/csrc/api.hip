@@ -373,6 +373,16 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     return GOPS_OK;
 }
 
+#ifdef GOPS_DUMP
+// debug build only (make variant V=dump VFLAGS=-DGOPS_DUMP): per-thread, per-step record buffer of the streamed-split forward
+#define GOPS_DUMP_BYTES ((size_t)320 << 20)
+float* gops_dump_buffer() {
+    static float* buf = nullptr;
+    if (buf == nullptr) { (void)hipMalloc(&buf, GOPS_DUMP_BYTES); (void)hipMemset(buf, 0, GOPS_DUMP_BYTES); }
+    return buf;
+}
+#endif
+
 float pdt_of(const GopsEnv& e) { return (float)((double)e.pre_horizon * 0.1); }
 
 int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const GopsRolloutOut& out,
@@ -397,6 +407,9 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
     const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
     if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
     p.dbg = dbg ? dbg_buf : nullptr;
+#ifdef GOPS_DUMP
+    p.dbg = reinterpret_cast<unsigned long long*>(gops_dump_buffer());
+#endif
     // parameter block upload + weight packing + reference table: one launch
     hipError_t ue = launch_prologue(p, plan.dev_params, desc.env.pre_horizon, pdt_of(desc.env), s);
     if (ue != hipSuccess) return (int)ue;
@@ -615,6 +628,13 @@ int plan_mlp(const GopsMlp& mlp, int batch, void* ws, MlpPlan& m) {
 }  // namespace
 
 extern "C" {
+
+#ifdef GOPS_DUMP
+int gops_dbg_dump_read(void* host, size_t bytes) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpy(host, gops_dump_buffer(), bytes < GOPS_DUMP_BYTES ? bytes : GOPS_DUMP_BYTES, hipMemcpyDeviceToHost);
+}
+#endif
 
 size_t gops_mlp_workspace_bytes(const GopsMlp* mlp, int32_t batch) {
     if (!mlp) return 0;

@@ -164,9 +164,25 @@ hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipS
 // number of points where a 1-ulp difference in x(t) is amplified ~1e3x by the finite difference.
 #define SINF_CR(x) ((float)sin((double)(x)))
 #define COSF_CR(x) ((float)cos((double)(x)))
-#define RMUL(a, b) __fmul_rn((a), (b))
-#define RADD(a, b) __fadd_rn((a), (b))
-#define RSUB(a, b) __fsub_rn((a), (b))
+// One rounding per operation, never fused: HIP's __fmul_rn / __fadd_rn are plain `a * b` / `a + b`, which hipcc's default
+// -ffp-contract=fast-honor-pragmas may contract into an fma with a neighbour - whether it did depended on unrelated codegen
+// (round 4: building without packed-fp32 instructions moved 4 more of the 48 appended headings of the step fixture by ~1e-3).
+// The reference (torch CPU) rounds every product and sum separately.
+__device__ __forceinline__ float rn_mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float rn_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float rn_sub(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+#define RMUL(a, b) rn_mul((a), (b))
+#define RADD(a, b) rn_add((a), (b))
+#define RSUB(a, b) rn_sub((a), (b))
 
 // `c` = GopsEnv.ref_c (include/gops_hip.h): the reference's path / speed parameters, folded on the host where the
 // reference folds Python scalars.  With the default set every expression below rounds exactly like the constants the

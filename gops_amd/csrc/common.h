@@ -5,6 +5,11 @@
 
 #include "gops_hip.h"
 
+// NOTE (round 4): this library is compiled with the `packed-fp32-ops` subtarget feature OFF (csrc/Makefile: NOPK) - a gfx950
+// hazard between dependent v_pk_*_f32 instructions that hipcc's SLP vectoriser forms out of plain scalar code made the streamed
+// plane-split kernels run-to-run non-deterministic (reproducer tools/microbench/pk_hazard.hip).
+// tests/test_host_cpu.py disassembles the built library and fails on any v_pk_{mul,add,fma}_f32.
+
 #define TB GOPS_TILE      // trajectories per workgroup tile = MFMA M
 #define NTHREADS 256      // 4 wavefronts of 64
 #define DW_SC_HOST 32     // samples per staged chunk of the dW GEMM (== DW_SC in aux_kernels.hip)

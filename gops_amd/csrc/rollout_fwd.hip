@@ -271,7 +271,7 @@ struct NoSplit {};
 template <int AMAX>
 __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetDev& S, const float* xs, int ldx, char* xq, char* hq,
                                                 float* s_part, const float* s_bias, int ldb, const float* s_wo4, const float* s_bo,
-                                                int tid, float* const* stash_h, float* const* stash_z, size_t row0) {
+                                                int tid, float* const* stash_h, float* const* stash_z, size_t row0, float* dmp = nullptr) {
     const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
     constexpr int ROWB1 = 2 * 256 + 16;
     const int L = M.nl - 1, rowb0 = split_rowb(32 * S.kc[0]);
@@ -315,6 +315,14 @@ __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetD
                 if (ACT == GOPS_ACT_GELU && zrow != nullptr) __builtin_nontemporal_store(zv, gptr(reinterpret_cast<f32x4*>(zrow + n * 16 + m0)));
             }
         });
+#ifdef GOPS_DUMP
+        if (dmp != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gptr(dmp)[32 + 16 * (j > 0 ? 1 : 0) + 4 * q + r] = hv[q][r];
+        }
+#endif
         if (!last) {
             plane_store(hq, ROWB1, wave, lane, hv, SPLIT_FWD_SA);
             __syncthreads();
@@ -497,8 +505,19 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
             if constexpr (SPLIT) {
                 ya_split = SP.run(p, xs, ldx, xq, rowb0, hq, s_part, s_bias, ldh, s_wo, s_bo, tid, p.need_grad != 0, row0, dbg);
             } else if constexpr (SS) {
+#ifdef GOPS_DUMP
+                float* dmp = (p.dbg != nullptr && VEH) ? reinterpret_cast<float*>(p.dbg) + ((((size_t)tile * p.H + t) * NTHREADS + tid) << 6) : nullptr;
+                if (dmp != nullptr) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) gptr(dmp)[28 + k] = xs[(tid >> 4) * ldx + (tid & 15) + 16 * k];
+                }
+                ya_split = ss_net_forward<AMAX>(p.pol, p.ssp, xs, ldx, xq, hq, s_part, s_bias, ldh, s_wo, s_bo, tid,
+                                                p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0, dmp);
+                if (dmp != nullptr) gptr(dmp)[0] = ya_split;
+#else
                 ya_split = ss_net_forward<AMAX>(p.pol, p.ssp, xs, ldx, xq, hq, s_part, s_bias, ldh, s_wo, s_bo, tid,
                                                 p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0);
+#endif
             } else
             if (!p.open_loop) {
                 if constexpr (F16) {
@@ -744,6 +763,14 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
             VehStep w;
             w.sphi = veh_s; w.cphi = veh_c;
             veh_f_xu(VC, s, steer, ax, sn, w);
+#ifdef GOPS_DUMP
+            float* dmpe = (SS && p.dbg != nullptr) ? reinterpret_cast<float*>(p.dbg) + ((((size_t)tile * p.H + t) * NTHREADS + tid) << 6) : nullptr;
+            if (dmpe != nullptr) {
+                gptr(dmpe)[1] = steer; gptr(dmpe)[2] = ax; gptr(dmpe)[3] = dflag;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { gptr(dmpe)[4 + i] = s[i]; gptr(dmpe)[10 + i] = sn[i]; }
+            }
+#endif
             float pen_c = 0.f;   // surrcstr_penalty: constraint of the CURRENT pose
             float err_c0 = 0.f, err_c1 = 0.f;   // errcstr: |delta_y| - tol, |delta_u| - tol of the current observation
             if (part == 0) {
@@ -783,6 +810,14 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                 const float ytf = dx * snn + dy * cn;
                 const float ptf = angle_normalize(rp[2] - sn[2]);
                 const float utf = rp[3] - sn[3];
+#ifdef GOPS_DUMP
+                if (dmpe != nullptr && j == part) {
+                    gptr(dmpe)[16] = veh_s; gptr(dmpe)[17] = veh_c;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gptr(dmpe)[18 + i] = rp[i];
+                    gptr(dmpe)[22] = xtf; gptr(dmpe)[23] = ytf; gptr(dmpe)[24] = ptf; gptr(dmpe)[25] = utf;
+                }
+#endif
                 if (j == 0) {
                     done_m = (fabsf(xtf) > 10.f) || (fabsf(ytf) > 10.f) || (fabsf(ptf) > 3.14159265358979323846f);
                     if (SURR && p.env.surr_penalty) done_m = false;   // judge_done of the penalty model: never (:236-246)
@@ -863,6 +898,12 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
             float rr = (d != 0.f) ? 0.f : r;
             if (ENV != GOPS_ENV_NONE && p.env.shaping) rr = (rr + p.env.reward_shift) * p.env.reward_scale;
             v_acc += rr * p.gpow[t];
+#ifdef GOPS_DUMP
+            if (SS && VEH && p.dbg != nullptr) {
+                float* dm = reinterpret_cast<float*>(p.dbg) + ((((size_t)tile * p.H + t) * NTHREADS + tid) << 6);
+                gptr(dm)[26] = rr; gptr(dm)[27] = v_acc;
+            }
+#endif
             if (p.out.rewards != nullptr && tid < nvalid) gptr(p.out.rewards)[(size_t)t * p.B + b0 + tid] = rr;
             if (done_m && !p.env.no_mask_at_done) s_done[tid] = 1.f;
         }
@@ -1035,15 +1076,6 @@ bool split_eligible(const RolloutParams& p) {
 // kernels: both forward variants write the same feature-major stash.  GOPS_SS=0 switches it off.
 bool ss_eligible(const RolloutParams& p) {
     if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
-    // OPEN ISSUE (round 3, tools/gpu/dbg_poison.py): with two of these workgroups on a CU the veh3dofconti instantiations are
-    // not run-to-run deterministic - whole tiles of v_pi move by up to 5e-4 relative between identical launches (first launch
-    // of a process against later ones, and by dispatch order); one workgroup per CU (LDS padding) is bit-stable, extra barriers
-    // around the net evaluation and at the step end change nothing, every other env kind is bit-stable in the forward.  Until
-    // that is understood these launches keep the fp32-MFMA kernels (GOPS_SS_VEH=1 re-enables them for the hunt).
-    if (p.env.kind == GOPS_ENV_VEH3DOFCONTI || p.env.kind == GOPS_ENV_VEH3DOF_SURR) {
-        const char* e = getenv("GOPS_SS_VEH");
-        if (e == nullptr || e[0] != '1') return false;
-    }
     // (value / MLP batches, GOPS_ENV_NONE: one step - half the MFMA time of the fp32 kernels; GOPS_SS_VALUE=0 keeps those)
     if (p.env.kind == GOPS_ENV_NONE) if (const char* e = getenv("GOPS_SS_VALUE")) if (e[0] == '0') return false;
     if (kinked_with_tail(p)) return false;

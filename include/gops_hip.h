@@ -40,6 +40,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define GOPS_HIP_ABI_VERSION 9
 
@@ -415,6 +419,9 @@ void gops_profile_enable(int32_t on);
 void gops_profile_reset(void);
 int gops_profile_read(int32_t kernel_id, double* avg_ms, int64_t* launches);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -23,8 +23,8 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s);
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s);
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
-                          int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s, const float* dscale = nullptr);
-bool dw_skinny_ok(int N, int Kp);   // aux_kernels.hip
+                          int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s, const float* dscale, unsigned vflags);
+bool dw_skinny_ok(int N, int Kp, unsigned vflags);   // aux_kernels.hip
 hipError_t launch_dw_gemm_f16(const void* D, int N, const void* X, int Kp, long long S, int splits,
                               int chunks_per_split, float* part, float* part_b, hipStream_t s);
 hipError_t launch_dw_out(const float* dy, const float* h, bool h_is_half, int K, int A, long long S, int splits,
@@ -118,15 +118,55 @@ struct DwPlan {
     bool big;
 };
 
-DwPlan plan_dw(int N, int Kp, long long S, bool f16 = false) {
+// ---- debug override of the variant flags from the process environment ------------------------------------------------
+// Kernel variants are selected by GopsRolloutDesc.variant_flags / GopsMlp.variant_flags (ABI v10).  The environment knobs of
+// ABI v9 survive as a DEBUG override only: read ONCE, when the first call reaches the library, OR-ed into every description.
+struct EnvOverride {
+    unsigned flags = 0;
+    int l2_warmup = 0;      // as GopsRolloutDesc.l2_warmup (GOPS_TOUCH = mode -> mode + 1)
+    int dw_wgs = 0;
+    bool dbg_timing = false;
+};
+const EnvOverride& env_override() {
+    static const EnvOverride o = [] {
+        struct Knob { const char* name; char match; unsigned bit; int kind; };   // kind 0: flag when set (match 0) / when value[0] == match
+        static const Knob knobs[] = {
+            {"GOPS_SPLIT", '0', GOPS_VF_NO_STATIONARY_SPLIT, 0}, {"GOPS_SS", '0', GOPS_VF_NO_STREAMED_SPLIT_FWD, 0},
+            {"GOPS_SSB", '0', GOPS_VF_NO_STREAMED_SPLIT_BWD, 0}, {"GOPS_SS_VALUE", '0', GOPS_VF_NO_STREAMED_SPLIT_VALUE, 0},
+            {"GOPS_SPLIT_STREAM0", '0', GOPS_VF_NO_SPLIT_STREAM0, 0}, {"GOPS_SPLIT_TAIL_MULTI", 0, GOPS_VF_SPLIT_TAIL_MULTI, 0},
+            {"GOPS_DW_EXACT", 0, GOPS_VF_DW_EXACT, 0}, {"GOPS_DW_F32", 0, GOPS_VF_DW_F32, 0}, {"GOPS_DW_NOGUARD", 0, GOPS_VF_DW_NO_GUARD, 0},
+            {"GOPS_DW_SKINNY", '0', GOPS_VF_DW_NO_SKINNY, 0}, {"GOPS_DW_SPEC", '0', GOPS_VF_DW_NO_SPEC, 0}, {"GOPS_DW_DIRECT", 0, GOPS_VF_DW_DIRECT, 0},
+            {"GOPS_NO_FUSED_DWOUT", 0, GOPS_VF_NO_FUSED_DWOUT, 0}, {"GOPS_BWD_UPLOAD", 0, GOPS_VF_BWD_UPLOAD, 0},
+            {"GOPS_SK", 0, 0, 1}, {"GOPS_TOUCH", 0, 0, 2}, {"GOPS_DW_WGS", 0, 0, 3}, {"GOPS_DBG_TIMING", 0, 0, 4}};
+        EnvOverride r;
+        for (const Knob& k : knobs) {
+            const char* e = getenv(k.name);
+            if (e == nullptr) continue;
+            if (k.kind == 0) { if (k.match == 0 || e[0] == k.match) r.flags |= k.bit; }
+            else if (k.kind == 1) {   // GOPS_SK="a,b": 0,0 = plain streamed kernels, 0,16 = layer 0 streamed; any value: stationary at any batch
+                int a = -1, b = -1;
+                r.flags |= GOPS_VF_STATIONARY_ANY_BATCH;
+                if (sscanf(e, "%d,%d", &a, &b) == 2) { if (b == 0) r.flags |= GOPS_VF_STREAMED_FP32; else if (a == 0) r.flags |= GOPS_VF_STREAM_LAYER0; }
+                else if (e[0] == '0') r.flags |= GOPS_VF_STREAMED_FP32;
+            }
+            else if (k.kind == 2) r.l2_warmup = atoi(e) + 1;
+            else if (k.kind == 3) r.dw_wgs = atoi(e);
+            else r.dbg_timing = true;
+        }
+        return r;
+    }();
+    return o;
+}
+
+DwPlan plan_dw(int N, int Kp, long long S, bool f16 = false, unsigned vflags = 0, int wg_target = 512) {
     DwPlan d;
     d.big = f16 || (N >= 128 && Kp >= 128);   // the half-precision GEMM has one tile size (128) and 64-sample chunks
     const int T = d.big ? 128 : 64;
     int tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
-    if (!f16 && dw_skinny_ok(N, Kp)) tiles = (N + 255) / 256;   // dw_skinny_kernel: one workgroup per 256 features and split
+    if (!f16 && dw_skinny_ok(N, Kp, vflags)) tiles = (N + 255) / 256;   // dw_skinny_kernel: one workgroup per 256 features and split
     const int sc = f16 ? 64 : DW_SC_HOST;
     const long long chunks = (S + sc - 1) / sc;
-    static const int wg_target = getenv("GOPS_DW_WGS") ? atoi(getenv("GOPS_DW_WGS")) : 512;   // tuning knob: workgroups per GEMM
+    if (wg_target < 1) wg_target = 512;
     long long splits = (wg_target + tiles - 1) / tiles;
     if (splits > chunks) splits = chunks;
     if (splits < 1) splits = 1;
@@ -238,6 +278,8 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     fill_ref_defaults(p.env);
     p.open_loop = desc.open_loop == 2 ? 2 : (desc.open_loop ? 1 : 0);
     p.f16 = f16 ? 1 : 0;
+    p.vflags = desc.variant_flags | env_override().flags;
+    p.dw_wgs = desc.dw_workgroups > 0 ? desc.dw_workgroups : (env_override().dw_wgs > 0 ? env_override().dw_wgs : 512);
     if (p.open_loop) {
         // The kernels keep their tile / stash bookkeeping in terms of a policy: give them the
         // smallest one (obs -> 16 -> act, weights zeroed in the workspace); its layers are never
@@ -261,7 +303,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     // the next step's stash rows); with more tiles than CUs the co-resident workgroups hide it, and the warm-up lines are
     // evicted before their use - measured at cfg5 (4096 tiles): 3.8 GB fetched per sweep with it, 1.55 GB without, 1.39 -> 1.24 ms
     p.touch_mode = ((p.B + TB - 1) / TB > split_grid_limit()) ? 0 : 2;
-    if (const char* tm = getenv("GOPS_TOUCH")) p.touch_mode = atoi(tm);   // tuning knob
+    if (const int lw = desc.l2_warmup > 0 ? desc.l2_warmup : env_override().l2_warmup) p.touch_mode = lw - 1;   // tuning knob
     p.ldx = kp0 + 4;
     p.ldh = hmax + 4;
     const bool veh = env_has_ref_table(e.kind);
@@ -361,7 +403,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         // partial sums can be reduced by a single launch at the end
         for (int j = 0; j < p.pol.nl - 1; ++j) {
             const int Kp = f16 ? p.pol.kp32[j] : p.pol.kp[j];
-            const DwPlan d = plan_dw(p.pol.dims[j + 1], Kp, S, f16);
+            const DwPlan d = plan_dw(p.pol.dims[j + 1], Kp, S, f16, p.vflags, p.dw_wgs);
             plan.dw_part[j] = c.take((size_t)d.splits * p.pol.dims[j + 1] * Kp);
             plan.dw_part_b[j] = c.take((size_t)d.splits * p.pol.dims[j + 1]);
         }
@@ -404,7 +446,7 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
         if (me != hipSuccess) return (int)me;
     }
     static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
-    const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
+    const bool dbg = env_override().dbg_timing;
     if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
     p.dbg = dbg ? dbg_buf : nullptr;
 #ifdef GOPS_DUMP
@@ -475,14 +517,14 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
         }
     }
     static unsigned long long* dbg_buf = nullptr;   // debug knob only: GOPS_DBG_TIMING=1
-    const bool dbg = getenv("GOPS_DBG_TIMING") != nullptr;
+    const bool dbg = env_override().dbg_timing;
     if (dbg && dbg_buf == nullptr) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
     p.dbg = dbg ? dbg_buf : nullptr;
     // Split sweep: the output layer's weight gradient is accumulated inside the sweep (one partial per workgroup) - no dw_out
     // pass.  (GELU: the sweep's act' operand is gelu'(z), so it fetches H_2 next to it.)
     // (the streamed-split sweep does the same for the env kinds whose instantiation has the registers: ssb_fuses_out)
     const bool fused_out = (p.sp.on || ssb_fuses_out(p)) && !p.ext && !p.open_loop && want_params &&
-                           ext_delta == nullptr && getenv("GOPS_NO_FUSED_DWOUT") == nullptr;
+                           ext_delta == nullptr && !(p.vflags & GOPS_VF_NO_FUSED_DWOUT);
     const int sweep_grid = std::min((p.B + TB - 1) / TB, p.sp.on ? split_grid_limit() : ssb_grid_limit());
     if (fused_out) {
         p.sp.out_part = plan.dw_part[p.pol.nl - 1];
@@ -502,7 +544,11 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     q.out_part = p.sp.out_part;
     q.out_part_b = p.sp.out_part_b;
     q.dbg = p.dbg;
-    static const bool force_upload = getenv("GOPS_BWD_UPLOAD") != nullptr;   // measurement knob: the pre-patch launch sequence
+    const bool force_upload = (p.vflags & GOPS_VF_BWD_UPLOAD) != 0;   // measurement knob: the pre-patch launch sequence
+    // max|grad_v| belongs to THIS backward call: the sweep (fp32) / the upload kernel (half) only ever raise gscale[0], so a
+    // second backward after the same forward with a much smaller grad_v would inherit the larger scale and push its scaled
+    // deltas into half subnormals (advisor finding, round 3).  One 1-block launch.
+    if ((e = launch_fill_zero(p.gscale, 4, s)) != hipSuccess) return (int)e;
     if ((p.f16 || force_upload) && (e = launch_upload_params(p, plan.dev_params, s)) != hipSuccess) return (int)e;
     {
         ProfScope scope(desc.env.kind == GOPS_ENV_NONE ? 4 : 1, s);
@@ -537,14 +583,14 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
                                 ? p.gscale : nullptr;
     for (int j = 0; j < L; ++j) {   // dW_j = D_{j+1}^T * (j == 0 ? X : H_j)
         const int N = p.pol.dims[j + 1], Kp = p.f16 ? p.pol.kp32[j] : p.pol.kp[j], K = p.pol.dims[j];
-        const DwPlan d = plan_dw(N, Kp, S, p.f16 != 0);
+        const DwPlan d = plan_dw(N, Kp, S, p.f16 != 0, p.vflags, p.dw_wgs);
         const float* X = (j == 0) ? p.st.x : p.st.h[j];
         if (p.f16) {
             if ((e = launch_dw_gemm_f16(p.st.d[j + 1], N, X, Kp, S, d.splits, d.chunks_per_split, plan.dw_part[j],
                                         plan.dw_part_b[j], s)) != hipSuccess) return (int)e;
         } else
         if ((e = launch_dw_gemm(p.st.d[j + 1], N, X, Kp, S, d.splits, d.chunks_per_split, plan.dw_part[j],
-                                plan.dw_part_b[j], d.big, s, dw_scale)) != hipSuccess) return (int)e;
+                                plan.dw_part_b[j], d.big, s, dw_scale, p.vflags)) != hipSuccess) return (int)e;
         reduce_jobs_add(jobs, plan.dw_part[j], d.splits, N, K, Kp, grad.weight[j]);
         reduce_jobs_add(jobs, plan.dw_part_b[j], d.splits, 1, N, N, grad.bias[j]);
     }
@@ -573,6 +619,7 @@ GopsRolloutDesc value_desc(const GopsMlp& value, int batch) {
     d.env.act_dim = 1;
     d.policy = value;
     d.dtype = value.dtype;
+    d.variant_flags = value.variant_flags;   // (ABI v10: plain MLP batches carry their variant flags in GopsMlp)
     return d;
 }
 
@@ -616,7 +663,8 @@ int plan_mlp(const GopsMlp& mlp, int batch, void* ws, MlpPlan& m) {
     m.gv = c.take((size_t)batch);
     m.gh = c.take((size_t)m.S * m.K);
     m.gyp = c.take((size_t)m.S * m.Wp);
-    const DwPlan d = plan_dw(m.Wp, m.K, m.S);
+    const unsigned vf = mlp.variant_flags | env_override().flags;
+    const DwPlan d = plan_dw(m.Wp, m.K, m.S, false, vf);
     m.part = c.take((size_t)d.splits * m.Wp * m.K);
     m.part_b = c.take((size_t)d.splits * m.Wp);
     m.bytes = m.inner + c.off + kAlign;
@@ -682,8 +730,9 @@ static int mlp_backward_impl(const GopsMlp* mlp, int32_t batch, const float* x, 
     Plan inner;
     build_plan(m.d, workspace, inner);
     if (grad) {
-        const DwPlan d = plan_dw(m.Wp, m.K, m.S);
-        if ((e = launch_dw_gemm(m.gyp, m.Wp, inner.p.st.h[L], m.K, m.S, d.splits, d.chunks_per_split, m.part, m.part_b, d.big, s)) != hipSuccess)
+        const unsigned vf = mlp->variant_flags | env_override().flags;
+        const DwPlan d = plan_dw(m.Wp, m.K, m.S, false, vf);
+        if ((e = launch_dw_gemm(m.gyp, m.Wp, inner.p.st.h[L], m.K, m.S, d.splits, d.chunks_per_split, m.part, m.part_b, d.big, s, nullptr, vf)) != hipSuccess)
             return (int)e;
         ReduceJobs jobs;
         memset(&jobs, 0, sizeof(jobs));

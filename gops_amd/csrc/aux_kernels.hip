@@ -648,7 +648,7 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
                                                                     const float* __restrict__ X, int Kp,
                                                                     long long Q, int splits, int chunks_per_split,
                                                                     float* __restrict__ part,
-                                                                    float* __restrict__ part_b, const float* __restrict__ dscale, int getenv_guard) {
+                                                                    float* __restrict__ part_b, const float* __restrict__ dscale, int redo_guard) {
     extern __shared__ __attribute__((aligned(16))) float ring[];   // [DWR_STAGES][DWR_STAGE_FLOATS]
     constexpr int T = 128, R = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
         unsigned* sat = reinterpret_cast<unsigned*>(ring + DWR_STAGES * DWR_STAGE_FLOATS);
         if (!(vmax < 65504.f)) *sat = 1u;   // (zeroed by thread 0 before the first barrier of the pass above)
         __syncthreads();
-        if (*sat != 0u && getenv_guard) {
+        if (*sat != 0u && redo_guard) {
             redone = true;
 #pragma unroll
             for (int i = 0; i < R; ++i)
@@ -1173,33 +1173,31 @@ __global__ __launch_bounds__(NTHREADS, 3) void dw_skinny_kernel(const float* __r
         }
     }
 }
-// GOPS_DW_SKINNY=0: the 64 x 64-tile kernel for these layers too
-bool dw_skinny_ok(int N, int Kp) {
-    static const bool off = getenv("GOPS_DW_SKINNY") != nullptr && getenv("GOPS_DW_SKINNY")[0] == '0';
-    return !off && Kp == 16 && (N % 16) == 0;
+// GOPS_VF_DW_NO_SKINNY: the 64 x 64-tile kernel for these layers too
+bool dw_skinny_ok(int N, int Kp, unsigned vflags) {
+    return !(vflags & GOPS_VF_DW_NO_SKINNY) && Kp == 16 && (N % 16) == 0;
 }
 
-// The layers the wave-specialised kernel takes (GOPS_DW_SPEC=0: the 4-wave ring kernel)
-static bool dw_spec_ok(int N, int Kp) {
-    static const bool off = getenv("GOPS_DW_SPEC") != nullptr && getenv("GOPS_DW_SPEC")[0] == '0';
-    return !off && (N % 256) == 0 && ((Kp % 128) == 0 || (Kp > 128 && (Kp % 16) == 0));
+// The layers the wave-specialised kernel takes (GOPS_VF_DW_NO_SPEC: the 4-wave ring kernel)
+static bool dw_spec_ok(int N, int Kp, unsigned vflags) {
+    return !(vflags & GOPS_VF_DW_NO_SPEC) && (N % 256) == 0 && ((Kp % 128) == 0 || (Kp > 128 && (Kp % 16) == 0));
 }
 
 // dscale: device pointer to max|grad_v| of the launch (the deltas' magnitude reference), or null: with it the large
 // layers run the two-half-plane products (22 significant bits per operand), without it - or with GOPS_DW_EXACT set -
 // the exact three-plane bf16 split.
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
-                          int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s, const float* dscale) {
-    static const bool force_f32 = getenv("GOPS_DW_F32") != nullptr;   // A/B knob: fp32 MFMA GEMM
-    static const bool force_exact = getenv("GOPS_DW_EXACT") != nullptr;
-    const bool no_guard = getenv("GOPS_DW_NOGUARD") != nullptr;   // test knob: skip the exact re-run behind a saturated launch
+                          int chunks_per_split, float* part, float* part_b, bool big, hipStream_t s, const float* dscale, unsigned vflags) {
+    const bool force_f32 = (vflags & GOPS_VF_DW_F32) != 0;       // A/B knob: fp32 MFMA GEMM
+    const bool force_exact = (vflags & GOPS_VF_DW_EXACT) != 0;
+    const bool no_guard = (vflags & GOPS_VF_DW_NO_GUARD) != 0;   // test knob: skip the exact re-run behind a saturated launch
     const long long Q = (S + TB - 1) / TB;
     const int T = big ? 128 : 64, tiles = ((N + T - 1) / T) * ((Kp + T - 1) / T);
     const dim3 grid(tiles * ((splits + 7) / 8) * 8), block(NTHREADS);
-    static const bool no_ring = getenv("GOPS_DW_DIRECT") != nullptr;   // A/B knob: register-direct kernel for the large layers too
+    const bool no_ring = (vflags & GOPS_VF_DW_DIRECT) != 0;   // A/B knob: register-direct kernel for the large layers too
     if (big && !force_f32 && !no_ring && (N % 128) == 0 && ((Kp % 128) == 0 || (Kp > 128 && (Kp % 16) == 0))) {
         const float* none = nullptr;
-        if (dscale != nullptr && !force_exact && dw_spec_ok(N, Kp)) {
+        if (dscale != nullptr && !force_exact && dw_spec_ok(N, Kp, vflags)) {
             const dim3 grids(((N / 256) * ((Kp + 127) / 128)) * ((splits + 7) / 8) * 8);
             launch_with_lds(dw_gemm_spec_kernel, grids, dim3(512), DwSpec::lds_bytes(), s, D, N, X, Kp, Q, splits, part, part_b, dscale,
                             no_guard ? 0 : 1);
@@ -1211,7 +1209,7 @@ hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long lo
                             splits, chunks_per_split, part, part_b, none, 1);
         }
     }
-    else if (!force_f32 && dw_skinny_ok(N, Kp))
+    else if (!force_f32 && dw_skinny_ok(N, Kp, vflags))
         hipLaunchKernelGGL(dw_skinny_kernel, dim3(((N + 255) / 256) * ((splits + 7) / 8) * 8), block, 0, s, D, N, X, Q, splits, part, part_b);
     else if (big && !force_f32) hipLaunchKernelGGL((dw_gemm_fm_kernel<4, true>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);
     else if (big) hipLaunchKernelGGL((dw_gemm_fm_kernel<4, false>), grid, block, 0, s, D, N, X, Kp, Q, splits, chunks_per_split, part, part_b);

@@ -147,7 +147,9 @@ struct RolloutParams {
     SplitNetDev ssp, ssv;             //   planes of the policy / the tail value net
     SplitNetDev sspt, ssvt;           //   streamed-split SWEEP (ssb): transposed planes (n-tiles over a layer's inputs, 8 chunks over its outputs)
     int ssb;
-    int ssb_pad_;
+    unsigned vflags;                  // GOPS_VF_* of the description (| the debug override of the process environment, read once at load)
+    int dw_wgs;                       // target workgroup count of a weight-gradient GEMM
+    int vpad_;
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double
 };
 

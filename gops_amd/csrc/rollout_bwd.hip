@@ -1391,7 +1391,7 @@ int ssb_grid_limit() { return 2 * split_grid_limit(); }   // workgroups of the s
 // two workgroups per CU.  GOPS_SSB=0 keeps the fp32-MFMA sweep.
 bool ssb_eligible(const RolloutParams& p) {
     if (!p.ss) return false;
-    if (const char* e = getenv("GOPS_SSB")) if (e[0] == '0') return false;
+    if (p.vflags & GOPS_VF_NO_STREAMED_SPLIT_BWD) return false;
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
     return rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false, true) <= 80 * 1024;
 }

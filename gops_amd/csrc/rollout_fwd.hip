@@ -1057,13 +1057,12 @@ bool split_eligible(const RolloutParams& p) {
     if (p.env.kind != GOPS_ENV_LQ && p.env.kind != GOPS_ENV_IDPENDULUM && p.env.kind != GOPS_ENV_VEH3DOFCONTI) return false;
     if (M.nl != 3 || M.dims[1] != 256 || M.dims[2] != 256 || p.ldh != 260 || M.kp32[0] > 256 || p.ldx != M.kp[0] + 4) return false;
     // more than 128 inputs (veh3dofconti with P > 30): layer 0's planes stream from L2 - instantiated without the tail value net
-    if (M.kp32[0] > 128 && (p.env.kind != GOPS_ENV_VEH3DOFCONTI || p.tail || (getenv("GOPS_SPLIT_STREAM0") != nullptr && getenv("GOPS_SPLIT_STREAM0")[0] == '0'))) return false;
+    if (M.kp32[0] > 128 && (p.env.kind != GOPS_ENV_VEH3DOFCONTI || p.tail || (p.vflags & GOPS_VF_NO_SPLIT_STREAM0) != 0)) return false;
     // More tiles than CUs AND a tail value net: the tail is evaluated per tile with fp32 weights streamed from L2 by the one
     // resident workgroup, which exposes every L2 round trip (measured at B = 65536: no faster than the streamed kernels with
     // their three workgroups per CU) - those launches stay on the streamed kernels.
-    if (p.tail && (p.B + TB - 1) / TB > device_cus() && getenv("GOPS_SPLIT_TAIL_MULTI") == nullptr) return false;
-    if (const char* e = getenv("GOPS_SPLIT")) if (e[0] == '0') return false;
-    if (const char* e = getenv("GOPS_SK")) if (e[0] == '0') return false;   // "0,..": streamed kernels forced
+    if (p.tail && (p.B + TB - 1) / TB > device_cus() && !(p.vflags & GOPS_VF_SPLIT_TAIL_MULTI)) return false;
+    if (p.vflags & (GOPS_VF_NO_STATIONARY_SPLIT | GOPS_VF_STREAMED_FP32 | GOPS_VF_STREAM_LAYER0)) return false;
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
     if (rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? ref_pts : 0, false, M.kp32[0]) > 160 * 1024) return false;
     if (rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, true) > 160 * 1024) return false;
@@ -1077,10 +1076,9 @@ bool split_eligible(const RolloutParams& p) {
 bool ss_eligible(const RolloutParams& p) {
     if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
     // (value / MLP batches, GOPS_ENV_NONE: one step - half the MFMA time of the fp32 kernels; GOPS_SS_VALUE=0 keeps those)
-    if (p.env.kind == GOPS_ENV_NONE) if (const char* e = getenv("GOPS_SS_VALUE")) if (e[0] == '0') return false;
+    if (p.env.kind == GOPS_ENV_NONE && (p.vflags & GOPS_VF_NO_STREAMED_SPLIT_VALUE)) return false;
     if (kinked_with_tail(p)) return false;
-    if (const char* e = getenv("GOPS_SS")) if (e[0] == '0') return false;
-    if (const char* e = getenv("GOPS_SK")) if (e[0] == '0') return false;   // "0,..": plain streamed kernels forced
+    if (p.vflags & (GOPS_VF_NO_STREAMED_SPLIT_FWD | GOPS_VF_STREAMED_FP32 | GOPS_VF_STREAM_LAYER0)) return false;
     auto net_ok = [](const MlpDev& M) {
         if (M.nl < 3 || M.kp32[0] > 256) return false;
         for (int j = 1; j < M.nl; ++j)
@@ -1104,7 +1102,7 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
     // Register-stationary weights pin one workgroup per CU.  That is the right trade only while there
     // is at most one tile per CU (B <= 16 * #CUs = 4096 on MI355X); with more tiles the streamed
     // kernels win because 2-3 workgroups per CU overlap each other's MFMA and VALU phases.
-    if ((p.B + TB - 1) / TB > device_cus() && getenv("GOPS_SK") == nullptr) return;
+    if ((p.B + TB - 1) / TB > device_cus() && !(p.vflags & GOPS_VF_STATIONARY_ANY_BATCH)) return;
     if (M.nl - 1 < 2 || M.dims[1] != 256 || M.dims[2] != 256 || p.env.kind == GOPS_ENV_NONE || p.ldh != 260) return;
     sk[1] = 16;
     const int k0 = M.kp[0] >> 4;
@@ -1121,14 +1119,9 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
     // The backward's stationary variants also stage this step's H_2 / H_1 tiles in LDS: exactly two hidden layers.
     if (backward && M.nl != 3) { sk[0] = sk[1] = 0; return; }
     if (backward) sk[0] = (sk[1] == 16 && M.kp[0] == 128) ? 12 : ((sk[1] == 16 && M.kp[0] == 16) ? 16 : 0);
-    // tuning knob (benchmarks only): GOPS_SK="0,0" forces the streamed kernels, "0,16" layer 1 only
-    if (const char* e = getenv("GOPS_SK")) {
-        int a = -1, b = -1;
-        if (sscanf(e, "%d,%d", &a, &b) == 2) {
-            if (a == 0) sk[0] = 0;
-            if (b == 0) sk[0] = sk[1] = 0;
-        }
-    }
+    // tuning flags (benchmarks only): the plain streamed kernels, or layer 1 stationary only
+    if (p.vflags & GOPS_VF_STREAM_LAYER0) sk[0] = 0;
+    if (p.vflags & GOPS_VF_STREAMED_FP32) sk[0] = sk[1] = 0;
 }
 
 #define LAUNCH_FWD(ENV, A, B)                                                                            \

@@ -39,7 +39,7 @@ _fp = C.POINTER(C.c_float)
 
 class GopsMlp(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("sizes", C.c_int32 * (MAX_LAYERS + 1)),
-                ("hidden_act", C.c_int32), ("dtype", C.c_int32),
+                ("hidden_act", C.c_int32), ("dtype", C.c_int32), ("variant_flags", C.c_uint32),
                 ("weight", C.c_void_p * MAX_LAYERS), ("bias", C.c_void_p * MAX_LAYERS)]
 
 
@@ -70,7 +70,19 @@ class GopsEnv(C.Structure):
 class GopsRolloutDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("horizon", C.c_int32), ("finite_horizon", C.c_int32),
                 ("need_grad", C.c_int32), ("tail_value", C.c_int32), ("open_loop", C.c_int32),
-                ("dtype", C.c_int32), ("tail_unmasked", C.c_int32), ("gamma", C.c_double), ("env", GopsEnv), ("policy", GopsMlp), ("value", GopsMlp)]
+                ("dtype", C.c_int32), ("tail_unmasked", C.c_int32), ("variant_flags", C.c_uint32), ("l2_warmup", C.c_int32),
+                ("dw_workgroups", C.c_int32), ("reserved0", C.c_int32), ("gamma", C.c_double), ("env", GopsEnv), ("policy", GopsMlp),
+                ("value", GopsMlp)]
+
+
+# GopsRolloutDesc.variant_flags / GopsMlp.variant_flags (include/gops_hip.h, ABI v10): kernel-variant selection is part of the
+# description - no process-global state.  DEFAULT_VARIANT_FLAGS is what `Rollout` / `make_mlp` use when the caller passes none
+# (tests patch it to steer the algorithm classes).
+VF_NO_STATIONARY_SPLIT, VF_NO_STREAMED_SPLIT_FWD, VF_NO_STREAMED_SPLIT_BWD, VF_NO_STREAMED_SPLIT_VALUE = 0x1, 0x2, 0x4, 0x8
+VF_STREAMED_FP32, VF_STREAM_LAYER0, VF_STATIONARY_ANY_BATCH, VF_NO_SPLIT_STREAM0, VF_SPLIT_TAIL_MULTI = 0x10, 0x20, 0x40, 0x80, 0x100
+VF_DW_EXACT, VF_DW_F32, VF_DW_NO_GUARD, VF_DW_NO_SKINNY, VF_DW_NO_SPEC, VF_DW_DIRECT = 0x10000, 0x20000, 0x40000, 0x80000, 0x100000, 0x200000
+VF_NO_FUSED_DWOUT, VF_BWD_UPLOAD = 0x400000, 0x800000
+DEFAULT_VARIANT_FLAGS = 0
 
 
 class GopsRolloutIn(C.Structure):
@@ -202,10 +214,13 @@ def _fill(arr, vals):
         arr[i] = float(v)
 
 
-def make_mlp(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], act: str, dtype=None) -> GopsMlp:
-    """`dtype` ("fp32" / "fp16") only matters for `ValueNet`; a `Rollout` takes its own `dtype` for all nets."""
+def make_mlp(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], act: str, dtype=None,
+             variant_flags: Optional[int] = None) -> GopsMlp:
+    """`dtype` ("fp32" / "fp16") and `variant_flags` (VF_*) only matter for `ValueNet` / `Mlp` batches; a `Rollout` takes its
+    own for all nets."""
     m = GopsMlp()
     m.dtype = dtype_id(dtype)
+    m.variant_flags = DEFAULT_VARIANT_FLAGS if variant_flags is None else variant_flags
     m.n_layers = len(weights)
     if not 2 <= len(weights) <= MAX_LAYERS:
         raise RuntimeError(f"MLP with {len(weights)} Linear layers is outside the HIP path (2..{MAX_LAYERS})")
@@ -330,13 +345,16 @@ class Rollout:
     def __init__(self, env: GopsEnv, policy: Optional[GopsMlp], *, batch: int, horizon: int, gamma: float,
                  finite_horizon: bool, need_grad: bool = True, value: Optional[GopsMlp] = None,
                  device: Optional[torch.device] = None, dtype=None, raw_actions: bool = False,
-                 tail_unmasked: bool = False):
+                 tail_unmasked: bool = False, variant_flags: Optional[int] = None, l2_warmup: int = 0, dw_workgroups: int = 0):
         """`policy=None` selects the open-loop mode: `forward(data, head_pre=...)` takes the pre-tanh
         policy-head outputs of all steps [B, H, act_dim] and `backward_open_loop` returns their gradient.
-        `dtype`: "fp32" (default, exact fp32 MFMA) or "fp16" (half-precision MFMA contractions and stash)."""
+        `dtype`: "fp32" (default: fp32 results at the 1e-4 bar, plane-split MFMAs where they apply) or "fp16" (half-precision
+        MFMA contractions and stash).  `variant_flags`: VF_* bits (GopsRolloutDesc.variant_flags), None = DEFAULT_VARIANT_FLAGS."""
         self.desc = GopsRolloutDesc()
         d = self.desc
         d.dtype = dtype_id(dtype)
+        d.variant_flags = DEFAULT_VARIANT_FLAGS if variant_flags is None else variant_flags
+        d.l2_warmup, d.dw_workgroups = int(l2_warmup), int(dw_workgroups)
         d.batch, d.horizon, d.finite_horizon = batch, horizon, int(finite_horizon)
         d.need_grad, d.tail_value, d.gamma = int(need_grad), int(value is not None), float(gamma)
         d.tail_unmasked = int(bool(tail_unmasked))   # SPIL's evaluation target: the terminal value is not masked at done

@@ -45,7 +45,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GOPS_HIP_ABI_VERSION 9
+#define GOPS_HIP_ABI_VERSION 10
 
 #define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
 #define GOPS_MAX_ACT 4      /* action dimensions */
@@ -84,7 +84,13 @@ enum { GOPS_ACT_LINEAR = 0, GOPS_ACT_RELU = 1, GOPS_ACT_ELU = 2, GOPS_ACT_GELU =
        GOPS_ACT_SELU = 4, GOPS_ACT_SIGMOID = 5, GOPS_ACT_TANH = 6 };
 
 /* Arithmetic of the MLP contractions (BASELINE.json configs[4]: "fp16 MFMA MLP path").
- *   GOPS_DTYPE_F32: v_mfma_f32_16x16x4_f32, exact fp32 (the 1e-4 parity path, default).
+ *   GOPS_DTYPE_F32: fp32 results at the 1e-4 parity bar (default).  NOT bit-level fp32 arithmetic where the plane-split
+ *                   kernels run (gops_rollout_variant bits 0 / 2; every 256-wide net): a weight is carried as bf16 + scaled
+ *                   f16 residual (>= 19 significant bits, fp32 has 24), activations / deltas as three exact bf16 planes +
+ *                   one f16 plane, fp32 accumulation; the large weight-gradient GEMMs multiply two-half-plane operands
+ *                   (22 significant bits, deltas scaled by max|grad_v| of the call, saturated blocks redone exactly).
+ *                   Measured distance to the reference 4e-7 .. 8e-6.  GOPS_VF_STREAMED_FP32 |
+ *                   GOPS_VF_DW_F32 in the descriptor's variant_flags select v_mfma_f32_16x16x4_f32 (an fmaf chain) throughout.
  *   GOPS_DTYPE_F16: weights, hidden activations and deltas rounded to IEEE half, products accumulated
  *                   in fp32 by v_mfma_f32_16x16x32_f16; the activation stash is half (2 bytes/element).
  *                   Env model, wrapper chain, rewards, returns, observation / state adjoints, policy
@@ -102,6 +108,9 @@ typedef struct GopsMlp {
     int32_t hidden_act;                    /* GOPS_ACT_* */
     int32_t dtype;                         /* GOPS_DTYPE_*: read by gops_value_forward / _backward only
                                               (a rollout takes GopsRolloutDesc.dtype for all its nets) */
+    uint32_t variant_flags;                /* ABI v10: GOPS_VF_* for gops_value_* / gops_mlp_* calls (a rollout takes
+                                              GopsRolloutDesc.variant_flags); 0 = the library's choice.  Occupies what was
+                                              alignment padding in v9: offsets and size are unchanged */
     const float* weight[GOPS_MAX_LAYERS];  /* device pointers */
     const float* bias[GOPS_MAX_LAYERS];
 } GopsMlp;
@@ -208,6 +217,14 @@ typedef struct GopsRolloutDesc {
                                  (hidden widths must then be multiples of 64) */
     int32_t tail_unmasked;    /* with tail_value: 1 = v += gamma^H V(obs_H) for finished trajectories too
                                  (SPIL's evaluation target, gops/algorithm/spil.py:208) */
+    uint32_t variant_flags;   /* ABI v10: GOPS_VF_* bits - which kernel variants this rollout may NOT / must take.  0 = the
+                                 library's choice (gops_rollout_variant reports it).  Part of the description: two callers
+                                 in one process can choose differently, and forward / backward of one rollout must pass
+                                 the same value */
+    int32_t l2_warmup;        /* ABI v10: backward sweep's L2 warm-up of the next step's stash rows: 0 = library default,
+                                 1 = off, 2 = all at the step top, 3 = spread over the step (tuning) */
+    int32_t dw_workgroups;    /* ABI v10: target workgroup count of a weight-gradient GEMM, 0 = default (512) (tuning) */
+    int32_t reserved0;
     double gamma;             /* discount; gamma^t is formed in double then rounded (fhadp.py:120) */
     GopsEnv env;
     GopsMlp policy;           /* out width = act_dim */
@@ -406,6 +423,26 @@ int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, dou
  *        launch runs on the streamed fp32-MFMA kernel;
  * none: the streamed kernels (exact fp32 MFMAs, or half-precision MFMAs for GOPS_DTYPE_F16).
  * Negative: a GOPS_ERR_* code for a description the library rejects. */
+/* GopsRolloutDesc.variant_flags / GopsMlp.variant_flags (ABI v10; replaces the process-environment knobs of v9, which
+ * survive only as a debug override read ONCE when the library is loaded - see INTEGRATION.md). */
+#define GOPS_VF_NO_STATIONARY_SPLIT 0x1u     /* not the register-stationary plane-split kernels            (v9: GOPS_SPLIT=0) */
+#define GOPS_VF_NO_STREAMED_SPLIT_FWD 0x2u   /* not the streamed plane-split forward                        (GOPS_SS=0) */
+#define GOPS_VF_NO_STREAMED_SPLIT_BWD 0x4u   /* not the streamed plane-split sweep                          (GOPS_SSB=0) */
+#define GOPS_VF_NO_STREAMED_SPLIT_VALUE 0x8u /* value / MLP batches (GOPS_ENV_NONE) on the fp32-MFMA kernels (GOPS_SS_VALUE=0) */
+#define GOPS_VF_STREAMED_FP32 0x10u          /* the plain streamed exact-fp32 kernels: no stationary weights, no planes (GOPS_SK=0,0) */
+#define GOPS_VF_STREAM_LAYER0 0x20u          /* stationary kernels keep layer 1 only                         (GOPS_SK=0,16) */
+#define GOPS_VF_STATIONARY_ANY_BATCH 0x40u   /* stationary fp32 kernels also with more tiles than CUs        (GOPS_SK set) */
+#define GOPS_VF_NO_SPLIT_STREAM0 0x80u       /* no plane-split kernel for policies with 129 .. 256 inputs    (GOPS_SPLIT_STREAM0=0) */
+#define GOPS_VF_SPLIT_TAIL_MULTI 0x100u      /* stationary plane-split kernels also for tail + more tiles than CUs (GOPS_SPLIT_TAIL_MULTI) */
+#define GOPS_VF_DW_EXACT 0x10000u            /* weight-gradient GEMM: exact three-plane bf16 split           (GOPS_DW_EXACT) */
+#define GOPS_VF_DW_F32 0x20000u              /*   fp32-MFMA GEMM                                              (GOPS_DW_F32) */
+#define GOPS_VF_DW_NO_GUARD 0x40000u         /*   test knob: no exact redo of saturated blocks                (GOPS_DW_NOGUARD) */
+#define GOPS_VF_DW_NO_SKINNY 0x80000u        /*   no 16-input-layer kernel                                    (GOPS_DW_SKINNY=0) */
+#define GOPS_VF_DW_NO_SPEC 0x100000u         /*   no wave-specialised kernel                                  (GOPS_DW_SPEC=0) */
+#define GOPS_VF_DW_DIRECT 0x200000u          /*   register-direct kernel for the large layers too             (GOPS_DW_DIRECT) */
+#define GOPS_VF_NO_FUSED_DWOUT 0x400000u     /*   output layer's gradient in its own pass                     (GOPS_NO_FUSED_DWOUT) */
+#define GOPS_VF_BWD_UPLOAD 0x800000u         /*   measurement: parameter upload launch in front of the sweep  (GOPS_BWD_UPLOAD) */
+
 #define GOPS_VARIANT_SPLIT 1
 #define GOPS_VARIANT_STATIONARY_F32 2
 #define GOPS_VARIANT_STREAMED_SPLIT_FWD 4

@@ -80,6 +80,40 @@ def test_workspace_query_and_rejections_need_no_gpu():
     assert hb.lib().gops_rollout_workspace_bytes(ctypes.byref(d)) == 0
 
 
+def test_variant_selection_is_part_of_the_description_not_of_the_process():
+    """ABI v10: kernel variants are chosen by GopsRolloutDesc.variant_flags - two callers in one process can choose
+    differently (the library keeps no global state) - and the library source reads the process environment in ONE
+    place only (the debug override, read once at load)."""
+    import glob
+    from gops_amd import hip_backend as hb
+    from gops_amd.create_pkg.create_env_model import create_env_model
+    d = hb.GopsRolloutDesc()
+    d.batch, d.horizon, d.finite_horizon, d.need_grad, d.gamma = 4096, 30, 1, 1, 1.0
+    d.env = create_env_model("pyth_veh3dofconti", pre_horizon=30).hip_env()
+    m = hb.GopsMlp()
+    m.n_layers = 3
+    for i, s in enumerate([127, 256, 256, 2]):
+        m.sizes[i] = s
+    for j in range(3):
+        m.weight[j] = m.bias[j] = 1
+    m.hidden_act = hb.ACT_IDS["elu"]
+    d.policy = m
+    variant = lambda flags: (setattr(d, "variant_flags", flags), hb.lib().gops_rollout_variant(ctypes.byref(d)))[1]
+    assert variant(0) == 1                                    # register-stationary plane-split kernels (the headline launch)
+    assert variant(hb.VF_NO_STATIONARY_SPLIT) == 2            # register-stationary fp32-MFMA kernels
+    assert variant(hb.VF_STREAMED_FP32) == 0                  # plain streamed fp32 kernels
+    assert variant(0) == 1                                    # ... and nothing lingered
+    m.n_layers = 4                                            # three hidden layers: the streamed plane-split kernels
+    for i, s in enumerate([47, 256, 256, 256, 2]):            # (P = 10: two of its workgroups fit a CU's LDS)
+        m.sizes[i] = s
+    m.weight[3] = m.bias[3] = 1
+    d.policy = m
+    d.env = create_env_model("pyth_veh3dofconti", pre_horizon=10).hip_env()
+    assert variant(0) == 4 and variant(hb.VF_NO_STREAMED_SPLIT_FWD) == 2 and variant(hb.VF_STREAMED_FP32) == 0
+    n_getenv = sum(open(f).read().count("getenv(") for f in glob.glob(os.path.join(ROOT, "gops_amd", "csrc", "*.h*")))
+    assert n_getenv <= 3, n_getenv
+
+
 def test_registries_and_error_behaviour():
     from gops_amd.create_pkg import create_alg, create_apprfunc, create_env_model, create_trainer
     assert set(create_alg.registry) == {"FHADP", "FHADP2", "FHADPExterior", "FHADPInterior", "FHADPLagrangian", "INFADP", "MAC", "MPG", "SPIL"}

@@ -43,13 +43,14 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def _run(cfg, nets, data, env, dev, monkeypatch, split):
+def _run(cfg, nets, data, env, dev, monkeypatch, split, extra_flags=0):
+    """(variant selection goes through GopsRolloutDesc.variant_flags, ABI v10 - `monkeypatch` is kept for the callers' signature)"""
     from gops_amd import hip_backend as hb
-    monkeypatch.setenv("GOPS_SPLIT", "1" if split else "0")
     henv = hip_env_from_oracle(env, nets["policy"])
     mlp, ws, bs = hip_mlp_from_net(nets["policy"], dev)
     B = data["obs"].shape[0]
-    ro = hb.Rollout(henv, mlp, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=True)
+    ro = hb.Rollout(henv, mlp, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=True,
+                    variant_flags=(0 if split else hb.VF_NO_STATIONARY_SPLIT) | extra_flags)
     import ctypes
     assert (hb.lib().gops_rollout_variant(ctypes.byref(ro.desc)) == 1) == split, "the launch would not take the kernels under test"
     res = ro.forward(to_device(data, dev), want_rewards=True, want_final=True)
@@ -88,7 +89,6 @@ def test_split_kernels_with_tail_value(batch, dev, monkeypatch):
     """INFADP's policy-improvement gradient (tail value net after the loop: its fp32 tiles alias the plane images); the
     second batch has more tiles than CUs (grid-stride tile walk: the policy biases are re-staged after every tail)."""
     from gops_amd import hip_backend as hb
-    monkeypatch.setenv("GOPS_SPLIT_TAIL_MULTI", "1")   # (by default tail + more tiles than CUs stays on the streamed kernels)
     cfg = dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=batch, horizon=8, hidden=(256, 256), act="gelu", gamma=0.99)
     data = make_batch(cfg, 8)
     nets = reference_init_nets(cfg, 8, obs_dim_of(cfg), act_dim_of(cfg))
@@ -96,12 +96,13 @@ def test_split_kernels_with_tail_value(batch, dev, monkeypatch):
     want = orc.infadp_pim_gradient(env, nets["policy"], nets["v_target"], data, cfg["horizon"], cfg["gamma"])
     out = {}
     for split in (True, False):
-        monkeypatch.setenv("GOPS_SPLIT", "1" if split else "0")
         henv = hip_env_from_oracle(env, nets["policy"])
         pol, pw, pb = hip_mlp_from_net(nets["policy"], dev)
         vt, _, _ = hip_mlp_from_net(nets["v_target"], dev)
         B = data["obs"].shape[0]
-        ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=False, need_grad=True, value=vt)
+        # (by default tail + more tiles than CUs stays on the streamed kernels: VF_SPLIT_TAIL_MULTI)
+        ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=False, need_grad=True, value=vt,
+                        variant_flags=hb.VF_SPLIT_TAIL_MULTI | (0 if split else hb.VF_NO_STATIONARY_SPLIT))
         res = ro.forward(to_device(data, dev))
         gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]
         ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
@@ -118,9 +119,7 @@ def test_weight_gradient_gemm_redoes_saturated_blocks_exactly(dev, monkeypatch):
     """The two-half-plane weight-gradient GEMM saturates beyond |x| = 65504; the converting threads flag it and a guarded
     second launch redoes the GEMM with the exact three-plane split.  A policy whose first layer is scaled up so that H_1
     reaches ~1e5 must still meet the 1e-4 bar against the oracle (and it does not with the guard disabled: that is what
-    GOPS_DW_NOGUARD=1 is for)."""
-    for knob in ("GOPS_DW_EXACT", "GOPS_DW_F32", "GOPS_DW_NOGUARD"):   # the test is about the default two-half-plane GEMM
-        monkeypatch.delenv(knob, raising=False)
+    GOPS_VF_DW_NO_GUARD is for)."""
     cfg = dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=64, horizon=3, hidden=(256, 256), act="relu", gamma=0.99)
     data = make_batch(cfg, 21)
     nets = reference_init_nets(cfg, 21, obs_dim_of(cfg), act_dim_of(cfg))
@@ -134,8 +133,8 @@ def test_weight_gradient_gemm_redoes_saturated_blocks_exactly(dev, monkeypatch):
     res, grads = _run(cfg, nets, data, env, dev, monkeypatch, split=True)
     worst = max(rel_l2(g.cpu(), w) for g, w in zip(grads, ref["grads"]))
     assert rel_l2(res["v_pi"].cpu(), ref["v_pi"]) < TOL and worst < TOL, worst
-    monkeypatch.setenv("GOPS_DW_NOGUARD", "1")
-    _, grads_ng = _run(cfg, nets, data, env, dev, monkeypatch, split=True)
+    from gops_amd import hip_backend as hb
+    _, grads_ng = _run(cfg, nets, data, env, dev, monkeypatch, split=True, extra_flags=hb.VF_DW_NO_GUARD)
     worst_ng = rel_l2(grads_ng[2].cpu(), ref["grads"][2])   # dW of layer 1 = D_2^T H_1
     print(f"saturated H_1: worst tensor with the guard {worst:.2e}; layer-1 weight gradient without it {worst_ng:.2e}")
     assert worst_ng > 10 * TOL
@@ -181,12 +180,12 @@ def test_streamed_split_forward_vs_oracle_and_fp32_mfma(name, dev, monkeypatch):
     flat_ref = torch.cat([g.reshape(-1) for g in want["grads"]])
     out = {}
     for ss in (True, False):
-        monkeypatch.setenv("GOPS_SS", "1" if ss else "0")
         henv = hip_env_from_oracle(env, nets["policy"])
         pol, pw, pb = hip_mlp_from_net(nets["policy"], dev)
         vt = None if fh else hip_mlp_from_net(nets["v_target"], dev)[0]
         B = data["obs"].shape[0]
-        ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=fh, need_grad=True, value=vt)
+        ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=fh, need_grad=True, value=vt,
+                        variant_flags=0 if ss else hb.VF_NO_STREAMED_SPLIT_FWD)
         assert (hb.lib().gops_rollout_variant(ctypes.byref(ro.desc)) == 4) == ss, "the launch would not take the kernels under test"
         res = ro.forward(to_device(data, dev), want_final=True)
         gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]

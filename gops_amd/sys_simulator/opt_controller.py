@@ -60,6 +60,14 @@ class OptController:
         assert mode in ("shooting", "collocation")
         assert num_pred_step % ctrl_interval == 0, "ctrl_interval should be a factor of num_pred_step."
         base = model.unwrapped
+        if mode == "collocation" and base.hip_kind not in _STATE_OBS_KINDS:
+            # The batched collocation needs a model whose observation is its state and whose forward takes no info (pyth_lq,
+            # pyth_idpendulum, gym_cartpoleconti, gym_pendulum, pyth_mobilerobot).  For the others the reference itself drops to
+            # its step-by-step rollout (opt_controller.py:292-294); callers that rely on the default mode keep working here
+            # through the shooting formulation (same optimum: the transition equalities are eliminated instead of imposed).
+            warnings.warn(f"OptController: mode='collocation' is not available for {type(base).__name__} (its forward needs `info`); "
+                          "falling back to mode='shooting'")
+            mode = "shooting"
         self.model, self.base = model, base
         self.terminal_cost = None
         if use_terminal_cost:   # (:84-98) the given function, else the model's own
@@ -79,11 +87,6 @@ class OptController:
         lo = base.action_lower_bound.cpu().numpy().astype(np.float64)
         hi = base.action_upper_bound.cpu().numpy().astype(np.float64)
         if mode == "collocation":
-            if base.hip_kind not in _STATE_OBS_KINDS:
-                raise NotImplementedError(
-                    "mode='collocation' batches the intervals, which needs a model whose observation is its state and whose "
-                    "forward takes no info (pyth_lq, pyth_idpendulum, gym_cartpoleconti, gym_pendulum, pyth_mobilerobot); the reference itself "
-                    "falls back to a step-by-step rollout for the others (opt_controller.py:292-294) - use mode='shooting'")
             lo = np.concatenate((lo, base.obs_lower_bound.cpu().numpy().astype(np.float64)))
             hi = np.concatenate((hi, base.obs_upper_bound.cpu().numpy().astype(np.float64)))
             self.optimize_dim = self.action_dim + self.obs_dim

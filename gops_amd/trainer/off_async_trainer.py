@@ -55,12 +55,14 @@ class OffAsyncTrainer(OffSerialTrainer):
         self.n = world_size()
         self._state = [p.data for p in self.networks.parameters()] + [b.data for b in self.networks.buffers()]
         device = self._state[0].device
-        # gradient slots: every child network with trainable parameters, in a fixed (sorted) order shared by all ranks
+        # gradient slots: every child network with trainable parameters, in a fixed (sorted) order shared by all ranks.  A slot
+        # covers ALL parameters of its network - the algorithms build their gradient lists from `mod.parameters()` and
+        # `remote_update` zips against the same list, frozen entries included (a None gradient travels as zeros)
         self._slots = []      # (net name, parameters, offset of its region in the message body)
         off = 0
         for name, mod in sorted(self.networks.named_children()):
-            params = [p for p in mod.parameters() if p.requires_grad]
-            if params:
+            params = list(mod.parameters())
+            if any(p.requires_grad for p in params):
                 self._slots.append((name, params, off))
                 off += sum(p.numel() for p in params)
         self._slot_of = {name: i for i, (name, _, _) in enumerate(self._slots)}
@@ -103,7 +105,7 @@ class OffAsyncTrainer(OffSerialTrainer):
                 _, params, off = self._slots[i]
                 if len(val) != len(params):
                     raise ValueError(f"off_async_trainer: '{key}' carries {len(val)} tensors, the network has {len(params)}")
-                flat = _flatten_dense_tensors([g.reshape(-1) for g in val])
+                flat = _flatten_dense_tensors([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(val, params)])
                 msg[1 + i] = 1.0
                 msg[self._head + off:self._head + off + flat.numel()] = flat
             elif key in self._scalar_names:

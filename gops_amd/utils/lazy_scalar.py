@@ -68,10 +68,25 @@ class LazyScalar:
     def __round__(self, n=None):
         return round(self._get(), n)
 
+    def __hash__(self):
+        return hash(self._get())
+
+    def __reduce__(self):
+        # copies, pickles and deep copies carry the VALUE (a plain float), not the device tensor behind it
+        return (float, (self._get(),))
+
 
 def _binary(name):
     def op(self, other):
-        return getattr(float, name)(self._get(), float(other))
+        # like float: anything that is not a real number (None, a string, a tensor, ...) is NotImplemented - `entry == None` is
+        # False and `entry in (None, ...)` works, as with the plain floats the reference's tb_info holds
+        if isinstance(other, LazyScalar):
+            other = other._get()
+        elif isinstance(other, (bool, int, float, np.integer, np.floating)):
+            other = float(other)
+        else:
+            return NotImplemented
+        return getattr(float, name)(self._get(), other)
     op.__name__ = name
     return op
 

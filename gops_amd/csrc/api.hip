@@ -20,6 +20,7 @@ int split_grid_limit();
 int ssb_grid_limit();     // rollout_bwd.hip
 bool ssb_fuses_out(const RolloutParams& p);
 void rollout_variant(const RolloutParams& p, int sk[2], bool backward);
+bool h64_eligible(const RolloutParams& p);   // rollout_h64.hip
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s);
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s);
 hipError_t launch_dw_gemm(const float* D, int N, const float* X, int Kp, long long S, int splits,
@@ -312,6 +313,8 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     if (rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16, 0) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16, false) > 160 * 1024)
         return GOPS_ERR_UNSUPPORTED;
     p.sp.on = split_eligible(p) ? 1 : 0;
+    p.h64 = h64_eligible(p) ? 1 : 0;   // half precision: 64-trajectory tiles (stash rows in 64-row tiles)
+    const int tile_rows = p.h64 ? 64 : TB;
     for (int t = 0; t <= p.H; ++t) p.gpow[t] = (float)pow(desc.gamma, (double)t);
 
     Carver c(ws);
@@ -375,7 +378,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     }
     p.gscale = c.take(4);   // max|grad_v| of a backward launch (f16 sweep scale; delta scale of the weight-gradient GEMM)
     // stash rows: every tile stores all 16 rows of every step (tile-major order)
-    const long long S = (long long)((p.B + TB - 1) / TB) * TB * p.H;
+    const long long S = (long long)((p.B + tile_rows - 1) / tile_rows) * tile_rows * p.H;
     if (veh) p.ref_table = c.take((size_t)p.B * (e.pre_horizon + 1 + p.H) * 4);
     if (e.kind == GOPS_ENV_VEH3DOF_SURR)
         p.surr_table = reinterpret_cast<const f32x4*>(c.take((size_t)p.B * (p.H + 1) * e.n_surr * 4));
@@ -393,7 +396,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         p.st.env = c.take((size_t)S * ENV_STASH);
         if (p.tail) {
             for (int j = 1; j < p.val.nl; ++j) {
-                const size_t rows = (size_t)((p.B + TB - 1) / TB) * TB;   // whole 16-row tiles (FM stash tiles are written whole)
+                const size_t rows = (size_t)((p.B + tile_rows - 1) / tile_rows) * tile_rows;   // whole tiles (FM stash tiles are written whole)
                 p.st.tail_h[j] = c.take((rows * p.val.dims[j] + el - 1) / el);
                 if (p.val.act == GOPS_ACT_GELU) p.st.tail_z[j] = c.take((rows * p.val.dims[j] + el - 1) / el);
             }
@@ -570,7 +573,8 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     }
     if (p.open_loop || !want_params) return GOPS_OK;   // no parameters behind the rollout / none wanted
     ProfScope scope(desc.env.kind == GOPS_ENV_NONE ? 5 : 2, s);
-    const long long S = (long long)((p.B + TB - 1) / TB) * TB * p.H;
+    const int tile_rows = p.h64 ? 64 : TB;
+    const long long S = (long long)((p.B + tile_rows - 1) / tile_rows) * tile_rows * p.H;
     const int L = p.pol.nl - 1;
     ReduceJobs jobs;
     memset(&jobs, 0, sizeof(jobs));

@@ -149,7 +149,7 @@ struct RolloutParams {
     int ssb;
     unsigned vflags;                  // GOPS_VF_* of the description (| the debug override of the process environment, read once at load)
     int dw_wgs;                       // target workgroup count of a weight-gradient GEMM
-    int vpad_;
+    int h64;                          // 1: GOPS_DTYPE_F16 launch on the 64-trajectory-tile kernels (rollout_h64.hip): stash rows in 64-row tiles
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double
 };
 

@@ -1414,7 +1414,9 @@ bool ssb_eligible(const RolloutParams& p) {
         else launch_with_lds(rollout_bwd_kernel<ENV, A, B, false, PT>, grid, block, lds, stream, dp, q);        \
     } while (0)
 
+hipError_t launch_rollout_bwd_h64(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream);   // rollout_h64.hip
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream) {
+    if (p.h64) return launch_rollout_bwd_h64(p, dp, q, stream);   // half precision, 64-trajectory tiles
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
     size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, p.f16 != 0, false);

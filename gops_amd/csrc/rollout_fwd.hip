@@ -1136,7 +1136,9 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
     } while (0)
 
 // `p` is the host copy (for shape dispatch), `dp` the device copy the kernel reads.
+hipError_t launch_rollout_fwd_h64(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);   // rollout_h64.hip
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
+    if (p.h64) return launch_rollout_fwd_h64(p, dp, stream);   // half precision, 64-trajectory tiles
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
     const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0, p.f16 != 0,
                                              p.sp.on ? 32 * p.sp.kc[0] : 0);

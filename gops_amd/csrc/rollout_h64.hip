@@ -1,0 +1,531 @@
+// Half-precision rollout kernels with 64-TRAJECTORY tiles (GOPS_DTYPE_F16, BASELINE.json configs[4] "fp16 MFMA MLP path";
+// round 4).  Same arithmetic, packings and stash contents as the 16-row half kernels (rollout_f16.h: transposed MFMAs - M =
+// output feature, N = trajectory, K = input feature -, fp32 accumulation, half activations / deltas / stash, fp32 env model,
+// head and adjoints), other work decomposition:
+//   * a workgroup (4 waves) owns 64 trajectories; wave w owns the 64-feature quad w of every 256-wide layer for ALL 64 rows:
+//     each weight fragment it pulls from L2 feeds FOUR MFMAs (one per 16-row group) instead of one - the weight stream per
+//     trajectory is a quarter of the 16-row kernels' (there: 144 KB of fragments per 16.5 KB of stash traffic and tile-step);
+//   * every per-step scalar / address / barrier cost is paid once per 64 rows, and the env phase runs on all 64 lanes of a
+//     wave instead of 16;
+//   * ONE hidden tile in LDS, rewritten in place behind a barrier (the whole GEMM result sits in 64 accumulator registers),
+//     so two workgroups share a CU.
+// Stash rows are tile-major in 64-row tiles: row (tile * H + t) * 64 + m.  The weight-gradient GEMMs contract over all
+// rows and do not care about their order.
+// Scope: env kinds GOPS_ENV_NONE (value / MLP batches) and GOPS_ENV_LQ, closed loop, every hidden layer 256 wide, at most 64
+// padded inputs; everything else stays on the 16-row kernels (api.hip: h64_eligible).
+#include "common.h"
+#include "env_models.h"
+#include "rollout_f16.h"
+
+#define TB64 64
+#define H64_LD 264   // halfs per row of the hidden tile: 256 + 8 (16-byte row skew, conflict-free ds_read_b128)
+
+// acc[jt][rg] (n-tile jt of quad q, 16-row group rg) += W_quad * act^T over kch chunks of 32 inputs
+__device__ __forceinline__ void gemm_quad_h64(const _Float16* act, int ld, int kch, const f16x8* Wp, int q, int lane, f32x4 (&acc)[4][4]) {
+    constexpr int PF = 2;
+    const GLOBAL_AS f16x8* wb = gptr(Wp) + (size_t)q * 4 * kch * 64 + lane;
+    const _Float16* brow = act + (lane & 15) * ld + 8 * (lane >> 4);
+    f16x8 ring[PF][4];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        const int cd = d < kch ? d : kch - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ring[d][j] = wb[((size_t)j * kch + cd) * 64];
+    }
+    for (int c0 = 0; c0 < kch; c0 += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const int c = c0 + d;
+            if (c < kch) {
+                f16x8 b[4], a[4];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) b[rg] = ld8h(brow + 16 * rg * ld + 32 * c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = ring[d][j];
+                const int cn = (c + PF < kch) ? c + PF : kch - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ring[d][j] = wb[((size_t)j * kch + cn) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) acc[j][rg] = MFMA_F16(a[j], b[rg], acc[j][rg]);
+            }
+        }
+    }
+}
+
+// fp32 tile xs [64][ldx] -> half tile x16 [64][ld16] (kp32 columns, zero padded) and the stash rows g16[(row0 + m) * kp32 ..]
+__device__ __forceinline__ void convert_x_h64(const float* xs, int ldx, int kp, int kp32, _Float16* x16, int ld16, _Float16* g16, size_t row0, int tid) {
+    const int upr = kp32 >> 3;
+    for (int idx = tid; idx < TB64 * upr; idx += NTHREADS) {
+        const int m = idx / upr, c = (idx - m * upr) << 3;
+        f16x8 v = zero8h();
+        if (c < kp) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xs + m * ldx + c);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(xs + m * ldx + c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (_Float16)a[e]; v[4 + e] = (_Float16)b[e]; }
+        }
+        *reinterpret_cast<f16x8*>(x16 + m * ld16 + c) = v;
+        if (g16 != nullptr) __builtin_nontemporal_store(v, gptr(reinterpret_cast<f16x8*>(g16 + (row0 + m) * kp32 + c)));
+    }
+}
+
+// Hidden stack on the half tile x16 -> hbuf (the LAST hidden activation, [64][H64_LD]); activations (and act'(z) for GELU)
+// of rows < stash_rows go to stash_h / stash_g rows row0 + m.  Ends with a barrier.
+__device__ __forceinline__ void mlp_hidden_forward_h64(const MlpDev& M, const _Float16* x16, int ldx16, _Float16* hbuf, int tid, const float* s_bias,
+                                                       int ldb, float* const* stash_h, float* const* stash_g, size_t row0, int stash_rows) {
+    const int lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+    const int L = M.nl - 1;
+    const int f0 = 64 * wave + 16 * g;
+    for (int j = 0; j < L; ++j) {
+        f32x4 acc[4][4] = {};
+        gemm_quad_h64(j == 0 ? x16 : hbuf, j == 0 ? ldx16 : H64_LD, M.kp32[j] >> 5, M.wph[j], wave, lane, acc);
+        if (j > 0) __syncthreads();   // every wave has read the tile it is about to overwrite
+        f32x4 bv[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) bv[jj] = *reinterpret_cast<const f32x4*>(s_bias + j * ldb + f0 + 4 * jj);
+        const bool gelu = M.act == GOPS_ACT_GELU;
+        act_dispatch(M.act, [&]<int ACT>() {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row = 16 * rg + m;
+                f16x8 o[2], gd[2];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = 4 * jj + r;
+                        const float z = acc[jj][rg][r] + bv[jj][r];
+                        float h, dh = 0.f;
+                        if (ACT == GOPS_ACT_GELU) gelu_pair(z, h, dh);
+                        else h = act_fwd_t<ACT>(z);
+                        o[e >> 3][e & 7] = (_Float16)h;
+                        gd[e >> 3][e & 7] = (_Float16)dh;
+                    }
+                *reinterpret_cast<f16x8*>(hbuf + row * H64_LD + f0) = o[0];
+                *reinterpret_cast<f16x8*>(hbuf + row * H64_LD + f0 + 8) = o[1];
+                if (stash_h != nullptr && row < stash_rows) {
+                    _Float16* hrow = reinterpret_cast<_Float16*>(stash_h[j + 1]) + (row0 + row) * 256;
+                    __builtin_nontemporal_store(o[0], gptr(reinterpret_cast<f16x8*>(hrow + f0)));
+                    __builtin_nontemporal_store(o[1], gptr(reinterpret_cast<f16x8*>(hrow + f0 + 8)));
+                    if (ACT == GOPS_ACT_GELU && gelu && stash_g != nullptr) {
+                        _Float16* grow = reinterpret_cast<_Float16*>(stash_g[j + 1]) + (row0 + row) * 256;
+                        __builtin_nontemporal_store(gd[0], gptr(reinterpret_cast<f16x8*>(grow + f0)));
+                        __builtin_nontemporal_store(gd[1], gptr(reinterpret_cast<f16x8*>(grow + f0 + 8)));
+                    }
+                }
+            }
+        });
+        __syncthreads();
+    }
+}
+
+size_t rollout_fwd_h64_lds_bytes(int ldx, int ldh) {
+    const int ldx16 = (((ldx - 4) + 31) & ~31) + 8;
+    return sizeof(float) * (size_t)(TB64 * ldx + TB64 * (4 + 4 + 1) + 16 + 32 + 4 * ldh + (GOPS_MAX_LAYERS - 1) * ldh) +
+           sizeof(_Float16) * (size_t)(TB64 * ldx16 + TB64 * H64_LD);
+}
+
+template <int ENV, bool TAIL>
+__global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const RolloutParams* __restrict__ pp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RolloutParams& p = *pp;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, b0 = tile * TB64, nvalid = min(TB64, p.B - b0);
+    const int O = p.env.obs_dim, A = p.env.act_dim;
+    const int ldx = p.ldx, ldh = p.ldh;
+    float* xs = smem;                       // [64][ldx] current observation (+ time column)
+    float* s_act = xs + TB64 * ldx;         // [64][4] wrapped action
+    float* s_th = s_act + TB64 * 4;         // [64][4] tanh(head) (ENV_NONE: raw head output)
+    float* s_done = s_th + TB64 * 4;        // [64]
+    float* s_bo = s_done + TB64;            // [16] head bias
+    float* s_ac = s_bo + 16;                // [4][8] per-action constants
+    float* s_wo = s_ac + 32;                // [4][ldh] head weights, rows a >= A zero
+    float* s_bias = s_wo + 4 * ldh;         // [GOPS_MAX_LAYERS - 1][ldh]
+    _Float16* x16 = reinterpret_cast<_Float16*>(s_bias + (GOPS_MAX_LAYERS - 1) * ldh);
+    const int ldx16 = (((p.ldx - 4) + 31) & ~31) + 8;
+    _Float16* hbuf = x16 + TB64 * ldx16;    // [64][H64_LD]
+    {
+        const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
+        for (int idx = tid; idx < GOPS_MAX_ACT * ldh; idx += NTHREADS) {
+            const int a = idx / ldh, k = idx - a * ldh;
+            s_wo[idx] = (a < Ao && k < K) ? gptr(p.pol.w[Lh])[a * K + k] : 0.f;
+        }
+        if (tid < GOPS_MAX_ACT) s_bo[tid] = (tid < Ao) ? gptr(p.pol.b[Lh])[tid] : 0.f;
+        stage_act_const(p.env, s_ac, tid);
+        for (int j = 0; j < Lh; ++j)
+            for (int n = tid; n < p.pol.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = gptr(p.pol.b[j])[n];
+    }
+    for (int idx = tid; idx < TB64 * ldx; idx += NTHREADS) {
+        const int m = idx / ldx, c = idx - m * ldx;
+        xs[idx] = (c < O && m < nvalid) ? gptr(p.in.obs)[(size_t)(b0 + m) * O + c] : 0.f;
+    }
+    if (tid < TB64) s_done[tid] = (tid < nvalid && p.in.done != nullptr && !p.env.no_mask_at_done && gptr(p.in.done)[b0 + tid] != 0.f) ? 1.f : 0.f;
+    float v_acc = 0.f;
+    __syncthreads();
+    for (int t = 0; t < p.H; ++t) {
+        if (p.fh && tid < TB64) xs[tid * ldx + O] = (float)(t + 1);
+        __syncthreads();
+        const size_t row0 = ((size_t)tile * p.H + t) * TB64;
+        convert_x_h64(xs, ldx, p.pol.kp[0], p.pol.kp32[0], x16, ldx16, p.need_grad ? reinterpret_cast<_Float16*>(p.st.x) : nullptr, row0, tid);
+        if (p.need_grad && tid < 2 * TB64)
+            *gptr(reinterpret_cast<f32x4*>(p.st.xf + (row0 + (tid >> 1)) * 8 + 4 * (tid & 1))) =
+                *reinterpret_cast<const f32x4*>(xs + (tid >> 1) * ldx + 4 * (tid & 1));
+        __syncthreads();
+        mlp_hidden_forward_h64(p.pol, x16, ldx16, hbuf, tid, s_bias, ldh, p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0, TB64);
+        {   // head + squash + wrapper chain: lane a of a 16-lane group handles action a of its trajectory, four row groups
+            const int hm = tid >> 4, la = tid & 15;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                float y[GOPS_MAX_ACT];
+                mlp_head_h<true>(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hbuf + 16 * pass * H64_LD, H64_LD, tid, y);
+                const float ya = (la == 0) ? y[0] : (la == 1) ? y[1] : (la == 2) ? y[2] : y[3];
+                const int row = 16 * pass + hm;
+                if (la < A) {
+                    if (ENV == GOPS_ENV_NONE) {
+                        s_th[row * 4 + la] = ya;
+                    } else {
+                        const ActC c = act_const(s_ac, la);
+                        const float th = fast_tanh(ya);
+                        s_th[row * 4 + la] = th;
+                        s_act[row * 4 + la] = wrap_action(c, c.sc * th + c.of);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        float r = 0.f;
+        if (tid < TB64) {
+            const int m = tid;
+            if (p.need_grad) {   // env stash row: tanh outputs, done_t (the LQ state IS the observation: X stash)
+                GLOBAL_AS f32x4* er = gptr(reinterpret_cast<f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
+                const f32x4 e0 = {s_th[m * 4 + 0], s_th[m * 4 + 1], s_th[m * 4 + 2], s_th[m * 4 + 3]};
+                const f32x4 e1 = {s_done[m], 0.f, 0.f, 0.f};
+                er[0] = e0;
+                er[1] = e1;
+            }
+            if (ENV == GOPS_ENV_NONE) {
+                r = s_th[m * 4];
+            } else {   // GOPS_ENV_LQ (the arithmetic of rollout_fwd_kernel's LQ block)
+                float x[GOPS_MAX_LQ_STATE], xn[GOPS_MAX_LQ_STATE], u[GOPS_MAX_ACT];
+#pragma unroll
+                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { x[i] = (i < O) ? obs_unscale(p.env, i, xs[m * ldx + i]) : 0.f; xn[i] = 0.f; }
+#pragma unroll
+                for (int j = 0; j < GOPS_MAX_ACT; ++j) u[j] = (j < A) ? s_act[m * 4 + j] : 0.f;
+                const bool frozen = s_done[m] != 0.f;
+                lq_forward(p.env, x, u, xn, r);
+                if (!frozen || p.env.clip_obs || p.env.scale_obs) {
+#pragma unroll
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                        if (i < O) {
+                            const float v = obs_rescale(p.env, i, sel_reg(frozen, x[i], xn[i]));
+                            xs[m * ldx + i] = p.env.clip_obs ? clampf(v, p.env.obs_low[i], p.env.obs_high[i]) : v;
+                        }
+                }
+            }
+            const float d = s_done[m];
+            float rr = (d != 0.f) ? 0.f : r;
+            if (ENV != GOPS_ENV_NONE && p.env.shaping) rr = (rr + p.env.reward_shift) * p.env.reward_scale;
+            v_acc += rr * p.gpow[t];
+            if (p.out.rewards != nullptr && m < nvalid) gptr(p.out.rewards)[(size_t)t * p.B + b0 + m] = rr;
+            // (pyth_lq never terminates: done_m == false; the done flags handed in stay as they are)
+        }
+    }
+    __syncthreads();
+    if (TAIL) {   // v += (~done_H) gamma^H V_target(obs_H)
+        if (p.fh && tid < TB64) xs[tid * ldx + O] = 0.f;
+        for (int j = 0; j < p.val.nl - 1; ++j)
+            for (int n = tid; n < p.val.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = gptr(p.val.b[j])[n];
+        __syncthreads();
+        convert_x_h64(xs, ldx, p.val.kp[0], p.val.kp32[0], x16, ldx16, nullptr, 0, tid);
+        __syncthreads();
+        mlp_hidden_forward_h64(p.val, x16, ldx16, hbuf, tid, s_bias, ldh, p.need_grad ? p.st.tail_h : nullptr, p.need_grad ? p.st.tail_z : nullptr,
+                               (size_t)b0, nvalid);
+        const int Lv = p.val.nl - 1;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            float y[GOPS_MAX_ACT];
+            mlp_head_h<false>(gptr(p.val.w[Lv]), p.val.dims[Lv], gptr(p.val.b[Lv]), p.val.dims[Lv], 1, hbuf + 16 * pass * H64_LD, H64_LD, tid, y);
+            if ((tid & 15) == 0) s_th[(16 * pass + (tid >> 4)) * 4] = y[0];
+        }
+        __syncthreads();
+        if (tid < TB64) v_acc += ((p.tail_unmasked ? 1.f : 1.f - s_done[tid]) * p.gpow[p.H]) * s_th[tid * 4];
+    }
+    if (tid < nvalid) {
+        gptr(p.out.v_pi)[b0 + tid] = v_acc;
+        if (p.out.final_done != nullptr) gptr(p.out.final_done)[b0 + tid] = s_done[tid];
+        if (p.need_grad && p.st.tail_done != nullptr) gptr(p.st.tail_done)[b0 + tid] = s_done[tid];
+    }
+    if (p.out.final_obs != nullptr) {
+        for (int idx = tid; idx < TB64 * O; idx += NTHREADS) {
+            const int m = idx / O, c = idx - m * O;
+            if (m < nvalid) gptr(p.out.final_obs)[(size_t)(b0 + m) * O + c] = xs[m * ldx + c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward sweep, 64-row tiles.  delta_y (fp32, in the launch's scaled units) in s_gy[64][4] -> hidden deltas (half; stash
+// st_d[j] when non-null) and, if want_gx, G[row][n] += (delta_1 W_0)[row][n] for n < ncols.  ONE delta tile `dbuf`, rewritten
+// in place behind a barrier.  Ends without a barrier after the g_x update (the caller's end-of-step barrier follows).
+template <class WP>
+__device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw, const float* s_gy, _Float16* dbuf, float* G, int ldg, int tid,
+                                                 float* const* st_h, float* const* st_z, float* const* st_d, float* stash_dy, size_t row0,
+                                                 int nvalid, bool want_gx, int ncols) {
+    const int lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+    const int L = M.nl - 1, A = M.dims[M.nl];
+    const bool gelu = (M.act == GOPS_ACT_GELU);
+    {   // head: delta_L[row][k] = (sum_a gy[row][a] Wo[a][k]) * act'_L[row][k]; thread (hm, hp) walks 4 row groups x 2 column blocks
+        const int hm = tid >> 4, hp = tid & 15;
+        act_dispatch(M.act, [&]<int ACT>() {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int k = 8 * hp + 128 * kb;
+                f32x4 w0[GOPS_MAX_ACT], w1[GOPS_MAX_ACT];
+#pragma unroll
+                for (int a = 0; a < GOPS_MAX_ACT; ++a) {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    w0[a] = (a < A) ? ld4(Wo + a * ldw + k) : z;
+                    w1[a] = (a < A) ? ld4(Wo + a * ldw + k + 4) : z;
+                }
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int row = 16 * pass + hm;
+                    const bool ok = row < nvalid;
+                    const f32x4 gy = *reinterpret_cast<const f32x4*>(s_gy + row * 4);
+                    f16x8 hv = zero8h();
+                    if (ok) hv = ld8h(gptr(reinterpret_cast<const _Float16*>(gelu ? st_z[L] : st_h[L]) + (row0 + row) * 256 + k));
+                    f16x8 dv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int a = 0; a < GOPS_MAX_ACT; ++a) acc += gy[a] * (e < 4 ? w0[a][e] : w1[a][e - 4]);   // (rows a >= A: zero weights)
+                        const float hf = (float)hv[e];
+                        const float d = (ACT == GOPS_ACT_GELU) ? hf : act_bwd_t<ACT>(hf, hf);
+                        dv[e] = sat_h(ok ? acc * d : 0.f);
+                    }
+                    *reinterpret_cast<f16x8*>(dbuf + row * H64_LD + k) = dv;
+                    if (st_d != nullptr)
+                        __builtin_nontemporal_store(dv, gptr(reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(st_d[L]) + (row0 + row) * 256 + k)));
+                }
+            }
+        });
+        if (stash_dy != nullptr && tid < TB64) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(s_gy + tid * 4);
+#pragma unroll
+            for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                if (a >= A || tid >= nvalid) v[a] = 0.f;
+            *gptr(reinterpret_cast<f32x4*>(stash_dy + (row0 + tid) * 4)) = v;
+        }
+    }
+    __syncthreads();
+    const int f0 = 64 * wave + 16 * g;
+    for (int j = L - 1; j >= 1; --j) {   // delta_j = (delta_{j+1} W_j) * act'_j
+        f16x8 hv[4][2];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {   // act' operands: in flight during the GEMM
+            const int row = 16 * rg + m;
+            hv[rg][0] = hv[rg][1] = zero8h();
+            if (row < nvalid) {
+                const GLOBAL_AS _Float16* src = gptr(reinterpret_cast<const _Float16*>(gelu ? st_z[j] : st_h[j]) + (row0 + row) * 256 + f0);
+                hv[rg][0] = ld8h(src);
+                hv[rg][1] = ld8h(src + 8);
+            }
+        }
+        f32x4 acc[4][4] = {};
+        gemm_quad_h64(dbuf, H64_LD, M.dims[j + 1] >> 5, M.wpth[j], wave, lane, acc);
+        __syncthreads();   // every wave has read the delta tile it is about to overwrite
+        act_dispatch(M.act, [&]<int ACT>() {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row = 16 * rg + m;
+                f16x8 o[2];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = 4 * jj + r;
+                        const float hf = (float)hv[rg][e >> 3][e & 7];
+                        const float d = (ACT == GOPS_ACT_GELU) ? hf : act_bwd_t<ACT>(hf, hf);
+                        o[e >> 3][e & 7] = sat_h((row < nvalid) ? acc[jj][rg][r] * d : 0.f);
+                    }
+                *reinterpret_cast<f16x8*>(dbuf + row * H64_LD + f0) = o[0];
+                *reinterpret_cast<f16x8*>(dbuf + row * H64_LD + f0 + 8) = o[1];
+                if (st_d != nullptr) {
+                    _Float16* dst = reinterpret_cast<_Float16*>(st_d[j]) + (row0 + row) * 256 + f0;
+                    __builtin_nontemporal_store(o[0], gptr(reinterpret_cast<f16x8*>(dst)));
+                    __builtin_nontemporal_store(o[1], gptr(reinterpret_cast<f16x8*>(dst + 8)));
+                }
+            }
+        });
+        __syncthreads();
+    }
+    if (want_gx) {   // g_x = delta_1 W_0: 16-feature tiles over the (16-padded) inputs; wave w takes row group w
+        const int kch = M.dims[1] >> 5, nt_tot = M.kp[0] >> 4;
+        const _Float16* brow = dbuf + (16 * wave + m) * H64_LD + 8 * g;
+        for (int nt = 0; nt < nt_tot; ++nt) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const GLOBAL_AS f16x8* wb = gptr(M.wpth[0]) + (size_t)nt * kch * 64 + lane;
+            for (int c = 0; c < kch; c += 2) {
+                const f16x8 a0 = wb[(size_t)c * 64], a1 = wb[(size_t)(c + 1) * 64];
+                acc0 = MFMA_F16(a0, ld8h(brow + 32 * c), acc0);
+                acc1 = MFMA_F16(a1, ld8h(brow + 32 * (c + 1)), acc1);
+            }
+            const int f = 16 * nt + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (f + r < ncols) G[(16 * wave + m) * ldg + f + r] += acc0[r] + acc1[r];
+        }
+    }
+}
+
+size_t rollout_bwd_h64_lds_bytes(int ldx, int ldh) {
+    return sizeof(float) * (size_t)(TB64 * ldx + TB64 * 4 + 4 * ldh) + sizeof(_Float16) * (size_t)(TB64 * H64_LD);
+}
+
+template <int ENV, bool TAIL>
+__global__ __launch_bounds__(NTHREADS, 2) void rollout_bwd_h64_kernel(const RolloutParams* __restrict__ pp, const BwdPatch q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RolloutParams& p = *pp;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, b0 = tile * TB64, nvalid = min(TB64, p.B - b0);
+    const int O = p.env.obs_dim, A = p.env.act_dim;
+    const int ldx = p.ldx, ldh = p.ldh;
+    float* G = smem;                  // [64][ldx] adjoint of obs_{t+1}
+    float* s_gy = G + TB64 * ldx;     // [64][4]
+    float* s_wo = s_gy + TB64 * 4;    // [4][ldh] head weights
+    _Float16* dbuf = reinterpret_cast<_Float16*>(s_wo + 4 * ldh);   // [64][H64_LD]
+    {
+        const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
+        for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
+            const int a = idx / K, k = idx - a * K;
+            s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
+        }
+    }
+    for (int idx = tid; idx < TB64 * ldx; idx += NTHREADS) G[idx] = 0.f;
+    float gv = (tid < nvalid) ? gptr(q.grad_v)[b0 + tid] : 0.f;
+    gv *= f16_grad_scale(gptr(p.gscale)[0]);
+    if (TAIL) {
+        if (tid < TB64) {
+            const float dH = (tid < nvalid) ? gptr(p.st.tail_done)[b0 + tid] : 1.f;
+            s_gy[tid * 4 + 0] = gv * ((p.tail_unmasked ? 1.f : 1.f - dH) * p.gpow[p.H]);
+            s_gy[tid * 4 + 1] = s_gy[tid * 4 + 2] = s_gy[tid * 4 + 3] = 0.f;
+        }
+        __syncthreads();
+        mlp_backward_h64(p.val, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, dbuf, G, ldx, tid, p.st.tail_h, p.st.tail_z, nullptr,
+                         nullptr, (size_t)b0, nvalid, true, O);
+    }
+    __syncthreads();
+    for (int t = p.H - 1; t >= 0; --t) {
+        const size_t row0 = ((size_t)tile * p.H + t) * TB64;
+        float g_r = gv * p.gpow[t];
+        if (ENV != GOPS_ENV_NONE && p.env.shaping) g_r *= p.env.reward_scale;
+        if (tid < TB64) {
+            const int m = tid;
+            if (ENV == GOPS_ENV_NONE) {
+                s_gy[m * 4 + 0] = g_r;
+                s_gy[m * 4 + 1] = s_gy[m * 4 + 2] = s_gy[m * 4 + 3] = 0.f;
+            } else {   // GOPS_ENV_LQ (the arithmetic of rollout_bwd_kernel's LQ block)
+                float th[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, dflag = 1.f;
+                float x[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (m < nvalid) {
+                    const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
+                    const f32x4 e0 = er[0], e1 = er[1];
+                    th[0] = e0[0]; th[1] = e0[1]; th[2] = e0[2]; th[3] = e0[3];
+                    dflag = e1[0];
+#pragma unroll
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                        if (i < O) x[i] = obs_unscale(p.env, i, gptr(p.st.xf)[(row0 + m) * 8 + i]);   // the stash holds the (scaled) policy input
+                }
+                float abar[GOPS_MAX_ACT], u[GOPS_MAX_ACT], sc[GOPS_MAX_ACT], gu[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < GOPS_MAX_ACT; ++a) {
+                    sc[a] = (p.env.policy_high[a] - p.env.policy_low[a]) / 2.f;
+                    abar[a] = sc[a] * th[a] + (p.env.policy_high[a] + p.env.policy_low[a]) / 2.f;
+                    u[a] = (a < A) ? wrap_action(p.env, a, abar[a]) : 0.f;
+                }
+                const bool dn = dflag != 0.f;
+                const float g_rm = dn ? 0.f : g_r;
+                float Gin[GOPS_MAX_LQ_STATE], gx[GOPS_MAX_LQ_STATE];
+#pragma unroll
+                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { Gin[i] = (i < O) ? G[m * ldx + i] : 0.f; gx[i] = 0.f; }
+                if (p.env.clip_obs) {
+                    float xn[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rdummy;
+                    lq_forward(p.env, x, u, xn, rdummy);
+#pragma unroll
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) {
+                        const float pre = obs_rescale(p.env, i, dn ? x[i] : xn[i]);   // what ClipObservation saw
+                        if (i < O && !(pre >= p.env.obs_low[i] && pre <= p.env.obs_high[i])) Gin[i] = 0.f;
+                    }
+                }
+                if (p.env.scale_obs) {
+#pragma unroll
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                        if (i < O) Gin[i] *= p.env.obs_scale[i];
+                }
+                float gxn[GOPS_MAX_LQ_STATE];
+#pragma unroll
+                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { gxn[i] = dn ? 0.f : Gin[i]; gx[i] = dn ? Gin[i] : 0.f; }
+                lq_backward(p.env, x, u, gxn, g_rm, gx, gu);
+#pragma unroll
+                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
+                    if (i < O) G[m * ldx + i] = p.env.scale_obs ? gx[i] / p.env.obs_scale[i] : gx[i];
+#pragma unroll
+                for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                    s_gy[m * 4 + a] = (a < A) ? wrap_action_bwd(p.env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a]) : 0.f;
+            }
+        }
+        __syncthreads();
+        mlp_backward_h64(p.pol, s_wo, ldh, s_gy, dbuf, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
+                         /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O);
+        __syncthreads();
+    }
+}
+
+hipError_t launch_rollout_fwd_h64(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
+    const dim3 grid((p.B + TB64 - 1) / TB64), block(NTHREADS);
+    const size_t lds = rollout_fwd_h64_lds_bytes(p.ldx, p.ldh);
+    if (p.env.kind == GOPS_ENV_LQ) {
+        if (p.tail) launch_with_lds(rollout_fwd_h64_kernel<GOPS_ENV_LQ, true>, grid, block, lds, stream, dp);
+        else launch_with_lds(rollout_fwd_h64_kernel<GOPS_ENV_LQ, false>, grid, block, lds, stream, dp);
+    } else if (p.env.kind == GOPS_ENV_NONE) {
+        if (p.tail) return hipErrorInvalidValue;
+        launch_with_lds(rollout_fwd_h64_kernel<GOPS_ENV_NONE, false>, grid, block, lds, stream, dp);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout_bwd_h64(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream) {
+    const dim3 grid((p.B + TB64 - 1) / TB64), block(NTHREADS);
+    const size_t lds = rollout_bwd_h64_lds_bytes(p.ldx, p.ldh);
+    if (p.env.kind == GOPS_ENV_LQ) {
+        if (p.tail) launch_with_lds(rollout_bwd_h64_kernel<GOPS_ENV_LQ, true>, grid, block, lds, stream, dp, q);
+        else launch_with_lds(rollout_bwd_h64_kernel<GOPS_ENV_LQ, false>, grid, block, lds, stream, dp, q);
+    } else if (p.env.kind == GOPS_ENV_NONE) {
+        if (p.tail) return hipErrorInvalidValue;
+        launch_with_lds(rollout_bwd_h64_kernel<GOPS_ENV_NONE, false>, grid, block, lds, stream, dp, q);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// The launches the 64-row half kernels take (api.hip build_plan; GOPS_VF_NO_HALF_TILE64 keeps the 16-row kernels)
+bool h64_eligible(const RolloutParams& p) {
+    if (!p.f16 || p.open_loop || p.ext || p.env.repeat_num > 1) return false;
+    if (p.vflags & GOPS_VF_NO_HALF_TILE64) return false;
+    if (p.env.kind != GOPS_ENV_LQ && p.env.kind != GOPS_ENV_NONE) return false;
+    if (p.env.kind == GOPS_ENV_NONE && p.tail) return false;
+    auto net_ok = [](const MlpDev& M) {
+        if (M.nl < 2 || M.kp32[0] > 64) return false;
+        for (int j = 1; j < M.nl; ++j)
+            if (M.dims[j] != 256) return false;
+        return true;
+    };
+    if (!net_ok(p.pol) || (p.tail && !net_ok(p.val))) return false;
+    return rollout_fwd_h64_lds_bytes(p.ldx, p.ldh) <= 80 * 1024 && rollout_bwd_h64_lds_bytes(p.ldx, p.ldh) <= 80 * 1024;
+}

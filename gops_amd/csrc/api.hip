@@ -785,6 +785,7 @@ int gops_rollout_variant(const GopsRolloutDesc* desc) {
     if (rc != GOPS_OK) return rc;
     if (plan.p.sp.on) return GOPS_VARIANT_SPLIT;
     if (plan.p.ss) return GOPS_VARIANT_STREAMED_SPLIT_FWD;
+    if (plan.p.h64) return GOPS_VARIANT_HALF_TILE64;
     int sk[2];
     rollout_variant(plan.p, sk, false);
     return sk[1] > 0 ? GOPS_VARIANT_STATIONARY_F32 : 0;

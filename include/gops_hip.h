@@ -420,7 +420,8 @@ int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, dou
  * bit 1 (GOPS_VARIANT_STATIONARY_F32): the register-stationary kernels on exact fp32 MFMAs;
  * bit 2 (GOPS_VARIANT_STREAMED_SPLIT_FWD, ABI v9): the FORWARD rollout on the streamed plane-split kernel (any number of
  *        256-wide hidden layers, weight planes streamed from L2, tail value net included); the backward sweep of such a
- *        launch runs on the streamed fp32-MFMA kernel;
+ *        launch runs on the streamed plane-split sweep where its LDS image fits twice per CU, else on the streamed fp32-MFMA kernel;
+ * bit 3 (GOPS_VARIANT_HALF_TILE64, ABI v10): GOPS_DTYPE_F16 on the 64-trajectory-tile kernels (rollout_h64.hip);
  * none: the streamed kernels (exact fp32 MFMAs, or half-precision MFMAs for GOPS_DTYPE_F16).
  * Negative: a GOPS_ERR_* code for a description the library rejects. */
 /* GopsRolloutDesc.variant_flags / GopsMlp.variant_flags (ABI v10; replaces the process-environment knobs of v9, which
@@ -447,6 +448,7 @@ int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, dou
 #define GOPS_VARIANT_SPLIT 1
 #define GOPS_VARIANT_STATIONARY_F32 2
 #define GOPS_VARIANT_STREAMED_SPLIT_FWD 4
+#define GOPS_VARIANT_HALF_TILE64 8   /* ABI v10: GOPS_DTYPE_F16 on the 64-trajectory-tile kernels (GOPS_ENV_LQ / _NONE, 256-wide nets) */
 int gops_rollout_variant(const GopsRolloutDesc* desc);
 
 /* Timing hook for bench.py: average duration in ms of the named internal kernel over the

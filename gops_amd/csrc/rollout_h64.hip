@@ -21,7 +21,8 @@
 #define H64_LD 264   // halfs per row of the hidden tile: 256 + 8 (16-byte row skew, conflict-free ds_read_b128)
 
 // acc[jt][rg] (n-tile jt of quad q, 16-row group rg) += W_quad * act^T over kch chunks of 32 inputs
-__device__ __forceinline__ void gemm_quad_h64(const _Float16* act, int ld, int kch, const f16x8* Wp, int q, int lane, f32x4 (&acc)[4][4]) {
+template <int RG>   // 16-row groups of the tile (4: 64 trajectories per workgroup, 2: 32)
+__device__ __forceinline__ void gemm_quad_h64(const _Float16* act, int ld, int kch, const f16x8* Wp, int q, int lane, f32x4 (&acc)[4][RG]) {
     constexpr int PF = 2;
     const GLOBAL_AS f16x8* wb = gptr(Wp) + (size_t)q * 4 * kch * 64 + lane;
     const _Float16* brow = act + (lane & 15) * ld + 8 * (lane >> 4);
@@ -37,9 +38,9 @@ __device__ __forceinline__ void gemm_quad_h64(const _Float16* act, int ld, int k
         for (int d = 0; d < PF; ++d) {
             const int c = c0 + d;
             if (c < kch) {
-                f16x8 b[4], a[4];
+                f16x8 b[RG], a[4];
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) b[rg] = ld8h(brow + 16 * rg * ld + 32 * c);
+                for (int rg = 0; rg < RG; ++rg) b[rg] = ld8h(brow + 16 * rg * ld + 32 * c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) a[j] = ring[d][j];
                 const int cn = (c + PF < kch) ? c + PF : kch - 1;
@@ -48,7 +49,7 @@ __device__ __forceinline__ void gemm_quad_h64(const _Float16* act, int ld, int k
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) acc[j][rg] = MFMA_F16(a[j], b[rg], acc[j][rg]);
+                    for (int rg = 0; rg < RG; ++rg) acc[j][rg] = MFMA_F16(a[j], b[rg], acc[j][rg]);
             }
         }
     }
@@ -80,7 +81,7 @@ __device__ __forceinline__ void mlp_hidden_forward_h64(const MlpDev& M, const _F
     const int f0 = 64 * wave + 16 * g;
     for (int j = 0; j < L; ++j) {
         f32x4 acc[4][4] = {};
-        gemm_quad_h64(j == 0 ? x16 : hbuf, j == 0 ? ldx16 : H64_LD, M.kp32[j] >> 5, M.wph[j], wave, lane, acc);
+        gemm_quad_h64<4>(j == 0 ? x16 : hbuf, j == 0 ? ldx16 : H64_LD, M.kp32[j] >> 5, M.wph[j], wave, lane, acc);
         if (j > 0) __syncthreads();   // every wave has read the tile it is about to overwrite
         f32x4 bv[4];
 #pragma unroll
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const Roll
 // Backward sweep, 64-row tiles.  delta_y (fp32, in the launch's scaled units) in s_gy[64][4] -> hidden deltas (half; stash
 // st_d[j] when non-null) and, if want_gx, G[row][n] += (delta_1 W_0)[row][n] for n < ncols.  ONE delta tile `dbuf`, rewritten
 // in place behind a barrier.  Ends without a barrier after the g_x update (the caller's end-of-step barrier follows).
-template <class WP>
+template <int RG, class WP>
 __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw, const float* s_gy, _Float16* dbuf, float* G, int ldg, int tid,
                                                  float* const* st_h, float* const* st_z, float* const* st_d, float* stash_dy, size_t row0,
                                                  int nvalid, bool want_gx, int ncols) {
@@ -290,7 +291,7 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
                     w1[a] = (a < A) ? ld4(Wo + a * ldw + k + 4) : z;
                 }
 #pragma unroll
-                for (int pass = 0; pass < 4; ++pass) {
+                for (int pass = 0; pass < RG; ++pass) {
                     const int row = 16 * pass + hm;
                     const bool ok = row < nvalid;
                     const f32x4 gy = *reinterpret_cast<const f32x4*>(s_gy + row * 4);
@@ -312,7 +313,7 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
                 }
             }
         });
-        if (stash_dy != nullptr && tid < TB64) {
+        if (stash_dy != nullptr && tid < 16 * RG) {
             f32x4 v = *reinterpret_cast<const f32x4*>(s_gy + tid * 4);
 #pragma unroll
             for (int a = 0; a < GOPS_MAX_ACT; ++a)
@@ -323,9 +324,9 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
     __syncthreads();
     const int f0 = 64 * wave + 16 * g;
     for (int j = L - 1; j >= 1; --j) {   // delta_j = (delta_{j+1} W_j) * act'_j
-        f16x8 hv[4][2];
+        f16x8 hv[RG][2];
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {   // act' operands: in flight during the GEMM
+        for (int rg = 0; rg < RG; ++rg) {   // act' operands: in flight during the GEMM
             const int row = 16 * rg + m;
             hv[rg][0] = hv[rg][1] = zero8h();
             if (row < nvalid) {
@@ -334,12 +335,12 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
                 hv[rg][1] = ld8h(src + 8);
             }
         }
-        f32x4 acc[4][4] = {};
-        gemm_quad_h64(dbuf, H64_LD, M.dims[j + 1] >> 5, M.wpth[j], wave, lane, acc);
+        f32x4 acc[4][RG] = {};
+        gemm_quad_h64<RG>(dbuf, H64_LD, M.dims[j + 1] >> 5, M.wpth[j], wave, lane, acc);
         __syncthreads();   // every wave has read the delta tile it is about to overwrite
         act_dispatch(M.act, [&]<int ACT>() {
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
+            for (int rg = 0; rg < RG; ++rg) {
                 const int row = 16 * rg + m;
                 f16x8 o[2];
 #pragma unroll
@@ -362,10 +363,11 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
         });
         __syncthreads();
     }
-    if (want_gx) {   // g_x = delta_1 W_0: 16-feature tiles over the (16-padded) inputs; wave w takes row group w
+    if (want_gx) {   // g_x = delta_1 W_0: 16-feature tiles over the (16-padded) inputs; wave w takes row group w % RG, n-tiles w / RG, ...
         const int kch = M.dims[1] >> 5, nt_tot = M.kp[0] >> 4;
-        const _Float16* brow = dbuf + (16 * wave + m) * H64_LD + 8 * g;
-        for (int nt = 0; nt < nt_tot; ++nt) {
+        const int rgw = wave % RG;
+        const _Float16* brow = dbuf + (16 * rgw + m) * H64_LD + 8 * g;
+        for (int nt = wave / RG; nt < nt_tot; nt += 4 / RG) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const GLOBAL_AS f16x8* wb = gptr(M.wpth[0]) + (size_t)nt * kch * 64 + lane;
             for (int c = 0; c < kch; c += 2) {
@@ -376,26 +378,35 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
             const int f = 16 * nt + 4 * g;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (f + r < ncols) G[(16 * wave + m) * ldg + f + r] += acc0[r] + acc1[r];
+                if (f + r < ncols) G[(16 * rgw + m) * ldg + f + r] += acc0[r] + acc1[r];
         }
     }
 }
 
+// The sweep walks the forward's 64-row stash tiles in tiles of H64_BWD_RG x 16 rows.  Measured at cfg5 (round 4): 64 rows per
+// workgroup (two workgroups = 8 waves per CU, 235 registers) 0.491 ms; 32 rows (three workgroups = 12 waves per CU, 143
+// registers) 0.587 ms - the weight stream per trajectory doubles and costs more than the extra waves hide.
+#ifndef H64_BWD_RG
+#define H64_BWD_RG 4
+#endif
+#define H64_BWD_WGS (H64_BWD_RG == 4 ? 2 : 3)
 size_t rollout_bwd_h64_lds_bytes(int ldx, int ldh) {
-    return sizeof(float) * (size_t)(TB64 * ldx + TB64 * 4 + 4 * ldh) + sizeof(_Float16) * (size_t)(TB64 * H64_LD);
+    return sizeof(float) * (size_t)(16 * H64_BWD_RG * ldx + 16 * H64_BWD_RG * 4 + 4 * ldh) + sizeof(_Float16) * (size_t)(16 * H64_BWD_RG * H64_LD);
 }
 
-template <int ENV, bool TAIL>
-__global__ __launch_bounds__(NTHREADS, 2) void rollout_bwd_h64_kernel(const RolloutParams* __restrict__ pp, const BwdPatch q) {
+template <int ENV, bool TAIL, int RG>
+__global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(const RolloutParams* __restrict__ pp, const BwdPatch q) {
+    constexpr int TBW = 16 * RG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutParams& p = *pp;
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x, b0 = tile * TB64, nvalid = min(TB64, p.B - b0);
+    const int tile = blockIdx.x, b0 = tile * TBW, nvalid = min(TBW, p.B - b0);
+    const int ftile = b0 / TB64, fsub = b0 % TB64;   // the forward's 64-row stash tile this tile is part of
     const int O = p.env.obs_dim, A = p.env.act_dim;
     const int ldx = p.ldx, ldh = p.ldh;
     float* G = smem;                  // [64][ldx] adjoint of obs_{t+1}
-    float* s_gy = G + TB64 * ldx;     // [64][4]
-    float* s_wo = s_gy + TB64 * 4;    // [4][ldh] head weights
+    float* s_gy = G + TBW * ldx;      // [TBW][4]
+    float* s_wo = s_gy + TBW * 4;     // [4][ldh] head weights
     _Float16* dbuf = reinterpret_cast<_Float16*>(s_wo + 4 * ldh);   // [64][H64_LD]
     {
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
@@ -404,25 +415,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_bwd_h64_kernel(const Roll
             s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
         }
     }
-    for (int idx = tid; idx < TB64 * ldx; idx += NTHREADS) G[idx] = 0.f;
+    for (int idx = tid; idx < TBW * ldx; idx += NTHREADS) G[idx] = 0.f;
     float gv = (tid < nvalid) ? gptr(q.grad_v)[b0 + tid] : 0.f;
     gv *= f16_grad_scale(gptr(p.gscale)[0]);
     if (TAIL) {
-        if (tid < TB64) {
+        if (tid < TBW) {
             const float dH = (tid < nvalid) ? gptr(p.st.tail_done)[b0 + tid] : 1.f;
             s_gy[tid * 4 + 0] = gv * ((p.tail_unmasked ? 1.f : 1.f - dH) * p.gpow[p.H]);
             s_gy[tid * 4 + 1] = s_gy[tid * 4 + 2] = s_gy[tid * 4 + 3] = 0.f;
         }
         __syncthreads();
-        mlp_backward_h64(p.val, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, dbuf, G, ldx, tid, p.st.tail_h, p.st.tail_z, nullptr,
+        mlp_backward_h64<RG>(p.val, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, dbuf, G, ldx, tid, p.st.tail_h, p.st.tail_z, nullptr,
                          nullptr, (size_t)b0, nvalid, true, O);
     }
     __syncthreads();
     for (int t = p.H - 1; t >= 0; --t) {
-        const size_t row0 = ((size_t)tile * p.H + t) * TB64;
+        const size_t row0 = ((size_t)ftile * p.H + t) * TB64 + fsub;
         float g_r = gv * p.gpow[t];
         if (ENV != GOPS_ENV_NONE && p.env.shaping) g_r *= p.env.reward_scale;
-        if (tid < TB64) {
+        if (tid < TBW) {
             const int m = tid;
             if (ENV == GOPS_ENV_NONE) {
                 s_gy[m * 4 + 0] = g_r;
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_bwd_h64_kernel(const Roll
             }
         }
         __syncthreads();
-        mlp_backward_h64(p.pol, s_wo, ldh, s_gy, dbuf, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
+        mlp_backward_h64<RG>(p.pol, s_wo, ldh, s_gy, dbuf, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
                          /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O);
         __syncthreads();
     }
@@ -500,14 +511,15 @@ hipError_t launch_rollout_fwd_h64(const RolloutParams& p, const RolloutParams* d
 }
 
 hipError_t launch_rollout_bwd_h64(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream) {
-    const dim3 grid((p.B + TB64 - 1) / TB64), block(NTHREADS);
+    constexpr int RG = H64_BWD_RG, TBW = 16 * RG;
+    const dim3 grid((p.B + TBW - 1) / TBW), block(NTHREADS);
     const size_t lds = rollout_bwd_h64_lds_bytes(p.ldx, p.ldh);
     if (p.env.kind == GOPS_ENV_LQ) {
-        if (p.tail) launch_with_lds(rollout_bwd_h64_kernel<GOPS_ENV_LQ, true>, grid, block, lds, stream, dp, q);
-        else launch_with_lds(rollout_bwd_h64_kernel<GOPS_ENV_LQ, false>, grid, block, lds, stream, dp, q);
+        if (p.tail) launch_with_lds(rollout_bwd_h64_kernel<GOPS_ENV_LQ, true, RG>, grid, block, lds, stream, dp, q);
+        else launch_with_lds(rollout_bwd_h64_kernel<GOPS_ENV_LQ, false, RG>, grid, block, lds, stream, dp, q);
     } else if (p.env.kind == GOPS_ENV_NONE) {
         if (p.tail) return hipErrorInvalidValue;
-        launch_with_lds(rollout_bwd_h64_kernel<GOPS_ENV_NONE, false>, grid, block, lds, stream, dp, q);
+        launch_with_lds(rollout_bwd_h64_kernel<GOPS_ENV_NONE, false, RG>, grid, block, lds, stream, dp, q);
     } else {
         return hipErrorInvalidValue;
     }

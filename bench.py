@@ -285,14 +285,17 @@ def run_workload(workload, dtype, steps, warmup, profile_steps, ctx):
     if cfg["alg"] == "INFADP":   # cfg3 / cfg5: one step = one local_update, PEV and PIM alternate
         alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]
     data = {k: v.to(device) for k, v in make_batch(cfg, 1000 + rank).items()}   # per-rank shard
-    reducer = GradAllReducer()
+    reducer = GradAllReducer(overlap=os.environ.get("GOPS_BENCH_OVERLAP", "1") != "0")   # (A/B knob: 0 = one flat all-reduce behind the whole backward)
 
     def step(it):
         if world == 1:
             alg.local_update(data, it)
         else:
-            _, info = alg.get_remote_update_info(data, it)   # no host sync: the loss stays on the device
-            reducer.average_(info, defer_scale=True)         # one flat SUM all-reduce; 1/N applied inside the Adam kernel
+            if getattr(alg, "supports_overlapped_reduce", False):   # the all-reduce of the early gradients overlaps the rest of the backward
+                _, info = alg.get_remote_update_info(data, it, reducer=reducer)
+            else:
+                _, info = alg.get_remote_update_info(data, it)   # no host sync: the loss stays on the device
+            reducer.average_(info, defer_scale=True)         # flat SUM all-reduce (or the wait for the started ones); 1/N applied inside the Adam kernel
             alg.remote_update(info)
 
     def barrier():

@@ -52,7 +52,7 @@ class FHADP(AlgorithmBase):
         self.mlp_dtype = kwargs.get("mlp_dtype", "fp32")
         self.tb_info = dict()
         self._rollouts = {}
-        self._update_graph, self._grad_graph = StepGraphCache(), StepGraphCache()
+        self._update_graph, self._grad_graph, self._grad_graph_b = StepGraphCache(), StepGraphCache(), StepGraphCache()
 
     @property
     def adjustable_parameters(self) -> Tuple[str]:
@@ -81,17 +81,34 @@ class FHADP(AlgorithmBase):
 
     accepts_grad_scale = True   # remote_update honours update_info["_grad_scale"] (trainer/grad_sync.py)
 
-    def get_remote_update_info(self, data, iteration: int):
+    supports_overlapped_reduce = True   # get_remote_update_info(..., reducer=...) starts the gradient all-reduce itself
+
+    def get_remote_update_info(self, data, iteration: int, reducer=None):
         # Data-parallel path: NO host sync here - the gradient all-reduce is queued right behind the backward
         # sweep.  The loss stays a device scalar in tb_info (`add_scalars` reads it at log time).
+        # With a `reducer` (trainer/grad_sync.GradAllReducer, more than one rank) the backward runs as two halves: everything
+        # except the first hidden layer's weight gradient, whose all-reduce then travels on the collective's stream while the
+        # first layer's GEMM + reduce still run on this one (GOPS_VF_BWD_PHASE_A / _B); `reducer.average_` later only waits.
         self._t0 = time.time()
         batch = self._device_batch(data)
-        loss = self._grad_graph.run(self._signature(batch), batch, self._gradient_kernels,
-                                   work=batch["obs"].shape[0] * self.pre_horizon)
+        work = batch["obs"].shape[0] * self.pre_horizon
+        grad_buffers(self.networks.policy)   # (allocates the flat gradient buffer on first use)
+        grads = [p._grad for p in self.networks.policy.parameters()]
+        info = {"grad": grads}
+        plain = type(self)._gradient_kernels is FHADP._gradient_kernels   # (the constrained variants bring their own gradient kernels)
+        if reducer is not None and reducer.overlap_enabled() and len(grads) >= 4 and plain:
+            sig = self._signature(batch)
+            loss = self._grad_graph.run(("a",) + sig, batch, lambda b: self._gradient_kernels(b, phase="a"), work=work)
+            reducer.start_(grads[2:])   # output layer, hidden layers 1.. : final after phase A
+            self._grad_graph_b.run(("b",) + sig, batch, lambda b: self._gradient_kernels(b, phase="b"), work=work)
+            reducer.start_(grads[:2])   # first hidden layer
+            info["_pending"] = True
+        else:
+            loss = self._grad_graph.run(self._signature(batch), batch, self._gradient_kernels, work=work)
         self._after_gradient(loss)
         self._fill_tb(loss, lazy=True)                       # device scalars, read at log time
         self.tb_info[tb_tags["alg_time"]] = (time.time() - self._t0) * 1000   # ms of host enqueue time
-        return self.tb_info, {"grad": [p._grad for p in self.networks.policy.parameters()]}
+        return self.tb_info, info
 
     def _remote_update(self, update_info):
         for p, grad in zip(self.networks.policy.parameters(), update_info["grad"]):
@@ -146,16 +163,21 @@ class FHADP(AlgorithmBase):
                 self.networks.policy_optimizer.storage_signature(),
                 tuple(ro.workspace.data_ptr() for ro in self._rollouts.values()))
 
-    def _gradient_kernels(self, batch):
-        """Enqueue forward rollout, loss and backward sweep; returns mean(v_pi) (device scalar)."""
+    def _gradient_kernels(self, batch, phase=None):
+        """Enqueue forward rollout, loss and backward sweep; returns mean(v_pi) (device scalar).  `phase`: None = all of it,
+        "a" = everything but the first hidden layer's weight gradient, "b" = that gradient (hip_backend.Rollout.backward)."""
         B, device = batch["obs"].shape[0], batch["obs"].device
         ro = self._rollout_for(B, device)
+        if phase == "b":
+            gw, gb = grad_buffers(self.networks.policy)
+            ro.backward(self._grad_v(B, device), gw, gb, phase="b")
+            return None
         v_pi = ro.forward(batch)["v_pi"]
         # the loss is only logged: inside a captured graph its mean is one more node; as eager launches (large batches) the
         # reduction kernel is left to whoever reads the log entry (LazyScalar) - v_pi is a fresh tensor of this update
         loss_policy = v_pi if (lazy_enabled() and not torch.cuda.is_current_stream_capturing() and type(self) is FHADP) else v_pi.mean()
         gw, gb = grad_buffers(self.networks.policy)
-        ro.backward(self._grad_v(B, device), gw, gb)
+        ro.backward(self._grad_v(B, device), gw, gb, phase=phase)
         return loss_policy
 
     def _after_gradient(self, out):

@@ -548,6 +548,11 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     q.out_part_b = p.sp.out_part_b;
     q.dbg = p.dbg;
     const bool force_upload = (p.vflags & GOPS_VF_BWD_UPLOAD) != 0;   // measurement knob: the pre-patch launch sequence
+    // GOPS_VF_BWD_PHASE_A / _B: the call is one half of a backward (see gops_hip.h); only_b skips the sweep
+    const unsigned phase = p.vflags & (GOPS_VF_BWD_PHASE_A | GOPS_VF_BWD_PHASE_B);
+    const bool only_a = phase == GOPS_VF_BWD_PHASE_A, only_b = phase == GOPS_VF_BWD_PHASE_B;
+    if ((only_a || only_b) && (p.open_loop || !want_params || ext_delta != nullptr || adj != nullptr)) return GOPS_ERR_UNSUPPORTED;
+    if (!only_b) {
     // max|grad_v| belongs to THIS backward call: the sweep (fp32) / the upload kernel (half) only ever raise gscale[0], so a
     // second backward after the same forward with a much smaller grad_v would inherit the larger scale and push its scaled
     // deltas into half subnormals (advisor finding, round 3).  One 1-block launch.
@@ -557,6 +562,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
         ProfScope scope(desc.env.kind == GOPS_ENV_NONE ? 4 : 1, s);
         if ((e = launch_rollout_bwd(p, plan.dev_params, q, s)) != hipSuccess) return (int)e;
     }
+    }   // !only_b
     if (dbg) {
         unsigned long long h[16];
         (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
@@ -586,6 +592,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
                              ext_delta == nullptr)
                                 ? p.gscale : nullptr;
     for (int j = 0; j < L; ++j) {   // dW_j = D_{j+1}^T * (j == 0 ? X : H_j)
+        if ((only_a && j == 0) || (only_b && j != 0)) continue;   // (two-phase backward: layer 0 is phase B)
         const int N = p.pol.dims[j + 1], Kp = p.f16 ? p.pol.kp32[j] : p.pol.kp[j], K = p.pol.dims[j];
         const DwPlan d = plan_dw(N, Kp, S, p.f16 != 0, p.vflags, p.dw_wgs);
         const float* X = (j == 0) ? p.st.x : p.st.h[j];
@@ -598,7 +605,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
         reduce_jobs_add(jobs, plan.dw_part[j], d.splits, N, K, Kp, grad.weight[j]);
         reduce_jobs_add(jobs, plan.dw_part_b[j], d.splits, 1, N, N, grad.bias[j]);
     }
-    if (ext_delta == nullptr) {
+    if (ext_delta == nullptr && !only_b) {
         const int K = p.pol.dims[L], A = p.pol.dims[p.pol.nl];
         long long splits = fused_out ? sweep_grid : DW_OUT_SPLITS;
         if (splits > S) splits = S;

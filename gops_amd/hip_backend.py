@@ -83,6 +83,7 @@ VF_STREAMED_FP32, VF_STREAM_LAYER0, VF_STATIONARY_ANY_BATCH, VF_NO_SPLIT_STREAM0
 VF_NO_HALF_TILE64 = 0x200
 VF_DW_EXACT, VF_DW_F32, VF_DW_NO_GUARD, VF_DW_NO_SKINNY, VF_DW_NO_SPEC, VF_DW_DIRECT = 0x10000, 0x20000, 0x40000, 0x80000, 0x100000, 0x200000
 VF_NO_FUSED_DWOUT, VF_BWD_UPLOAD = 0x400000, 0x800000
+VF_BWD_PHASE_A, VF_BWD_PHASE_B = 0x1000000, 0x2000000   # a backward in two halves (overlapped gradient all-reduce, trainer/grad_sync.py)
 DEFAULT_VARIANT_FLAGS = 0
 
 
@@ -437,18 +438,31 @@ class Rollout:
 
     def backward(self, grad_v: torch.Tensor, grad_w: List[torch.Tensor], grad_b: List[torch.Tensor],
                  grad_constraint: Optional[torch.Tensor] = None, grad_constraint_prod: Optional[torch.Tensor] = None,
-                 grad_constraint_step: Optional[torch.Tensor] = None):
+                 grad_constraint_step: Optional[torch.Tensor] = None, phase: Optional[str] = None):
         """`grad_constraint` (models with constraint outputs): d(loss)/d(constraint_sums rows 0..2), [3, B];
         `grad_constraint_prod`: d(loss)/d(P_k) * P_k for the Phi-products P_k = constraint_prods[k], [n_constraint, B];
-        `grad_constraint_step`: d(loss)/d(per-step constraint values), [H, B, n_constraint]."""
+        `grad_constraint_step`: d(loss)/d(per-step constraint values), [H, B, n_constraint].
+        `phase`: None = the whole backward; "a" = sweep + every gradient except the first hidden layer's, "b" (after "a", same
+        arguments) = the first hidden layer's (GOPS_VF_BWD_PHASE_A / _B): lets a data-parallel trainer start the all-reduce of the
+        gradients that are ready first while the rest is being formed."""
+        if phase == "b":
+            return self._backward_call(grad_v, make_mlp_grad(grad_w, grad_b), VF_BWD_PHASE_B)
         g = make_mlp_grad(grad_w, grad_b)
         self._in.grad_constraint = _ptr(grad_constraint)
         self._in.grad_constraint_prod = _ptr(grad_constraint_prod)
         self._in.grad_constraint_step = _ptr(grad_constraint_step)
         self._grad_c = (grad_constraint, grad_constraint_prod, grad_constraint_step)
-        check(lib().gops_rollout_backward(C.byref(self.desc), C.byref(self._in), _ptr(grad_v), C.byref(g),
-                                          self.workspace.data_ptr(), self.workspace.numel(), _stream()),
-              "gops_rollout_backward")
+        self._backward_call(grad_v, g, VF_BWD_PHASE_A if phase == "a" else 0)
+
+    def _backward_call(self, grad_v, g, phase_bits):
+        flags = self.desc.variant_flags
+        self.desc.variant_flags = flags | phase_bits
+        try:
+            check(lib().gops_rollout_backward(C.byref(self.desc), C.byref(self._in), _ptr(grad_v), C.byref(g),
+                                              self.workspace.data_ptr(), self.workspace.numel(), _stream()),
+                  "gops_rollout_backward")
+        finally:
+            self.desc.variant_flags = flags
 
 
     def backward_adj(self, grad_v: torch.Tensor, grad_w: Optional[List[torch.Tensor]] = None,

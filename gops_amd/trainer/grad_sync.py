@@ -43,8 +43,24 @@ def _as_one_buffer(tensors: List[torch.Tensor]):
 class GradAllReducer:
     """In-place mean of `update_info` (dict: name -> list of gradient tensors) over all ranks."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, overlap: bool = True):
         self.group = group
+        self.overlap = overlap
+        self._works = []
+
+    def overlap_enabled(self) -> bool:
+        """More than one rank and not switched off: algorithms that can (`supports_overlapped_reduce`) start the all-reduce of
+        the gradients that are ready first themselves (`start_`), behind the kernels that produced them."""
+        return self.overlap and world_size() > 1
+
+    def start_(self, tensors: List[torch.Tensor]):
+        """Asynchronous in-place SUM all-reduce of gradient tensors that tile ONE contiguous slice of a network's gradient
+        buffer (`algorithm/base.py:grad_buffers`): the collective waits for what is queued on the current stream so far and runs
+        on the process group's own stream - kernels queued afterwards overlap it.  `average_` waits for it."""
+        flat = _as_one_buffer(tensors)
+        if flat is None:
+            raise RuntimeError("GradAllReducer.start_: the tensors do not tile one contiguous buffer")
+        self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def average_(self, update_info: Dict[str, List[torch.Tensor]], defer_scale: bool = False) -> Dict[str, List[torch.Tensor]]:
         """`defer_scale`: leave the SUM in the buffers and hand the 1/N to the consumer as
@@ -53,6 +69,16 @@ class GradAllReducer:
         the optimizer step.  Entries whose name starts with "_", and entries that are not lists of tensors, are left alone."""
         n = world_size()
         if n == 1:
+            return update_info
+        if update_info.pop("_pending", False):   # the algorithm started the collectives itself (start_): only wait for them
+            for w in self._works:
+                w.wait()                         # (NCCL / RCCL: the current stream waits, the host does not)
+            self._works = []
+            if defer_scale:
+                update_info["_grad_scale"] = 1.0 / n
+            else:
+                for g in update_info["grad"]:
+                    g.div_(n)
             return update_info
         # (MPG's update_info also carries its iteration counter, mpg.py:434: non-list entries are not gradients)
         tensors = [g for name in sorted(update_info)

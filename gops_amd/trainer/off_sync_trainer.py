@@ -47,11 +47,18 @@ class OffSyncTrainer(OffSerialTrainer):
         replay_samples = self.buffer.sample_batch(self.replay_batch_size)
         self.networks.train()
         # no host sync between the backward sweep and the collective (loss scalars stay on the device until logged)
-        alg_tb_dict, update_info = self.alg.get_remote_update_info(replay_samples, self.iteration)
+        alg_tb_dict, update_info = self._gradient(replay_samples)
         self.reducer.average_(update_info, defer_scale=getattr(self.alg, "accepts_grad_scale", False))
         self.alg.remote_update(update_info)
         self.networks.eval()
         self._after_update(alg_tb_dict)
+
+    def _gradient(self, samples):
+        """Local gradient; an algorithm that can (`supports_overlapped_reduce`) starts the all-reduce of the gradients that are
+        ready first itself, overlapped with the rest of its backward (grad_sync.GradAllReducer.start_)."""
+        if getattr(self.alg, "supports_overlapped_reduce", False):
+            return self.alg.get_remote_update_info(samples, self.iteration, reducer=self.reducer)
+        return self.alg.get_remote_update_info(samples, self.iteration)
 
     def save_apprfunc(self):
         if self.is_chief:

@@ -40,11 +40,18 @@ class OnSyncTrainer(OnSerialTrainer):
         self.networks.train()
         # no host sync between the backward sweep and the collective: the algorithms leave their loss scalars on the
         # device (read at log time), and the 1/N is folded into the Adam kernel when the algorithm supports it
-        alg_tb_dict, update_info = self.alg.get_remote_update_info(samples, self.iteration)
+        alg_tb_dict, update_info = self._gradient(samples)
         self.reducer.average_(update_info, defer_scale=getattr(self.alg, "accepts_grad_scale", False))
         self.alg.remote_update(update_info)
         self.networks.eval()
         self._after_update(alg_tb_dict)
+
+    def _gradient(self, samples):
+        """Local gradient; an algorithm that can (`supports_overlapped_reduce`) starts the all-reduce of the gradients that are
+        ready first itself, overlapped with the rest of its backward (grad_sync.GradAllReducer.start_)."""
+        if getattr(self.alg, "supports_overlapped_reduce", False):
+            return self.alg.get_remote_update_info(samples, self.iteration, reducer=self.reducer)
+        return self.alg.get_remote_update_info(samples, self.iteration)
 
     def save_apprfunc(self):
         if self.is_chief:

@@ -444,6 +444,13 @@ int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, dou
 #define GOPS_VF_DW_DIRECT 0x200000u          /*   register-direct kernel for the large layers too             (GOPS_DW_DIRECT) */
 #define GOPS_VF_NO_FUSED_DWOUT 0x400000u     /*   output layer's gradient in its own pass                     (GOPS_NO_FUSED_DWOUT) */
 #define GOPS_VF_BWD_UPLOAD 0x800000u         /*   measurement: parameter upload launch in front of the sweep  (GOPS_BWD_UPLOAD) */
+/* A backward call in two halves, so that a data-parallel caller can put the all-reduce of the gradients that are ready
+ * first on a side stream while the rest is still being formed (gops_amd/trainer/grad_sync.py):
+ *   PHASE_A: sweep, output layer's gradient and every hidden layer's EXCEPT the first one's (reduced and final in the caller's
+ *            buffers when the call's work completes); PHASE_B (same description, same workspace, after PHASE_A): the first
+ *            hidden layer's weight gradient + bias from the stash PHASE_A left.  Neither / both bits: the whole backward. */
+#define GOPS_VF_BWD_PHASE_A 0x1000000u
+#define GOPS_VF_BWD_PHASE_B 0x2000000u
 
 #define GOPS_VARIANT_SPLIT 1
 #define GOPS_VARIANT_STATIONARY_F32 2

@@ -21,6 +21,7 @@ _WORKER = r"""
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 ROOT, ALG = sys.argv[1], sys.argv[2]
+OVERLAP = len(sys.argv) > 4 and sys.argv[4] == "overlap"   # FHADP: the all-reduce of the early gradients overlaps the rest of the backward
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 os.environ["GOPS_HIP_GRAPH"] = "1"          # capture even these small steps: the collective sits BETWEEN two graphs
 from gops_amd.create_pkg.create_alg import create_alg
@@ -51,15 +52,32 @@ alg = make()
 broadcast_parameters(alg.networks, src=0)
 reducer = GradAllReducer()
 full = [{k: v.to(dev) for k, v in make_batch(cfg, 500 + it).items()} for it in range(ITERS)]
-for it in range(ITERS):
-    shard = {k: v[r * B:(r + 1) * B].contiguous() for k, v in full[it].items()}
-    _, info = alg.get_remote_update_info(shard, it)
-    reducer.average_(info, defer_scale=True)
-    assert info["_grad_scale"] == 1.0 / n
-    alg.remote_update(info)
-torch.cuda.synchronize()
+
+def run(alg, overlap):
+    for it in range(ITERS):
+        shard = {k: v[r * B:(r + 1) * B].contiguous() for k, v in full[it].items()}
+        if overlap:   # what the trainers / bench.py do for algorithms with supports_overlapped_reduce
+            _, info = alg.get_remote_update_info(shard, it, reducer=reducer)
+            assert info.get("_pending") is True and len(reducer._works) == 2
+        else:
+            _, info = alg.get_remote_update_info(shard, it)
+        reducer.average_(info, defer_scale=True)
+        assert info["_grad_scale"] == 1.0 / n and not reducer._works
+        alg.remote_update(info)
+    torch.cuda.synchronize()
+
+run(alg, OVERLAP)
 if ALG == "FHADP":
     assert alg._grad_graph.graph is not None, "the gradient kernels were not replayed as a HIP graph"
+if OVERLAP:
+    # the overlapped path (backward in two halves, two collectives started by the algorithm) against the serial one (one
+    # backward, one flat all-reduce): bit-identical weights after the same updates
+    assert alg._grad_graph_b.graph is not None
+    ser = make()
+    broadcast_parameters(ser.networks, src=0)
+    run(ser, False)
+    for (name, a), b in zip(alg.networks.named_parameters(), ser.networks.parameters()):
+        assert torch.equal(a, b), name
 
 # single process, concatenated batch (what the reference's on_sync_trainer feeds its one learner)
 os.environ["GOPS_HIP_GRAPH"] = "0"
@@ -89,13 +107,15 @@ open(os.path.join(sys.argv[3], f"ok_{r}"), "w").write("ok")
 """
 
 
-@pytest.mark.parametrize("alg,port", [("FHADP", 29711), ("INFADP", 29712)])
-def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path, alg, port):
+@pytest.mark.parametrize("alg,port,mode", [("FHADP", 29711, "serial"), ("INFADP", 29712, "serial"), ("FHADP", 29713, "overlap")])
+def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path, alg, port, mode):
+    """mode "overlap" (VERDICT r3 #8): the all-reduce of the output / upper hidden layers' gradients is started behind the first
+    half of the backward and overlaps the first hidden layer's GEMM; the result must equal the serial path bit for bit."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, alg, str(tmp_path)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, alg, str(tmp_path), mode],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert all((tmp_path / f"ok_{k}").exists() for k in range(2))

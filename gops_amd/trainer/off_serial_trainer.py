@@ -47,7 +47,13 @@ class OffSerialTrainer(TrainerBase):
             self.sampler_tb_dict.add_average(sampler_tb)
         replay_samples = self.buffer.sample_batch(self.replay_batch_size)
         self.networks.train()
-        alg_tb_dict = self.alg.local_update(replay_samples, self.iteration)
+        out = self.alg.local_update(replay_samples, self.iteration)
+        if isinstance(out, tuple):   # prioritized replay (off_serial_trainer.py:96-100): (tb_info, tree indices, new priorities)
+            alg_tb_dict, idx, new_priority = out
+            if hasattr(self.buffer, "update_batch"):
+                self.buffer.update_batch(idx, new_priority)
+        else:
+            alg_tb_dict = out
         self.networks.eval()
         self._after_update(alg_tb_dict)
 

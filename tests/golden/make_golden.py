@@ -857,7 +857,69 @@ def golden_data_envs(only=None):
         save(name, **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 9. the reference's PrioritizedReplayBuffer (gops/trainer/buffer/prioritized_replay_buffer.py) run on synthetic
+#    transitions at a capacity that is NOT a power of two (ring wrap included): trees after the stores, leaves and
+#    weights of two sampled batches (the uniform draws recorded), trees after two priority updates (duplicate indices
+#    included), leaves of a third batch
+# ------------------------------------------------------------------------------------------
+def golden_per():
+    from gops.trainer.buffer.prioritized_replay_buffer import PrioritizedReplayBuffer as RefPER
+    rng = np.random.RandomState(77)
+    bkw = dict(trainer="off_serial_trainer", seed=5, obsv_dim=3, action_dim=2, buffer_max_size=37, additional_info={})
+    buf = RefPER(index=0, **bkw)
+    n = 50
+    t = dict(obs=rng.randn(n, 3).astype(np.float32), act=rng.randn(n, 2).astype(np.float32), rew=rng.randn(n).astype(np.float32),
+             done=(rng.rand(n) < 0.1).astype(np.float32), obs2=rng.randn(n, 3).astype(np.float32))
+    out = {"t/" + k: v for k, v in t.items()}
+    draws = []
+    orig_uniform = np.random.uniform
+
+    def rec_uniform(low, high=None, size=None):
+        v = orig_uniform(low, high, size)
+        draws.append((np.asarray(low, dtype=np.float64), np.asarray(high, dtype=np.float64), np.asarray(v, dtype=np.float64)))
+        return v
+
+    def store(lo, hi):
+        for i in range(lo, hi):
+            buf.store(t["obs"][i], t["act"][i], float(t["rew"][i]), bool(t["done"][i]), {}, t["obs2"][i], {}, 0.25)
+
+    def snap(tag):
+        out[tag + "/sum_tree"], out[tag + "/min_tree"] = buf.sum_tree.copy(), buf.min_tree.copy()
+        out[tag + "/max_priority"], out[tag + "/beta"] = np.float64(buf.max_priority), np.float64(buf.beta)
+        out[tag + "/size"], out[tag + "/ptr"] = buf.size, buf.ptr
+
+    store(0, 20)
+    snap("s0")
+    np.random.seed(3)
+    np.random.uniform = rec_uniform
+    try:
+        for k in range(3):
+            if k == 1:
+                store(20, 50)           # wraps the ring: 37 slots
+                snap("s1")
+            b = buf.sample_batch(8)
+            lo, hi, v = draws[-1]
+            out[f"b{k}/u"] = (v - lo) / (hi - lo)          # the unit draws behind the stratified values
+            out[f"b{k}/idx"], out[f"b{k}/weight"] = b["idx"].numpy(), b["weight"].numpy()
+            out[f"b{k}/obs"], out[f"b{k}/rew"] = b["obs"].numpy(), b["rew"].numpy()
+            pr = np.abs(rng.randn(8)) * (10.0 if k == 1 else 1.0)
+            idx = b["idx"].numpy().copy()
+            if k == 1:
+                idx[5] = idx[2]          # a duplicated index: the later priority wins
+            out[f"b{k}/upd_idx"], out[f"b{k}/upd_pr"] = idx, pr
+            buf.update_batch(torch.as_tensor(idx), torch.as_tensor(pr))
+            snap(f"u{k}")
+    finally:
+        np.random.uniform = orig_uniform
+    out["meta/buffer_kwargs"] = json.dumps(bkw)
+    save("per_buffer", **out)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["per"]:
+        golden_per()
+        sys.exit(0)
     which = sys.argv[1:] or ["steps", "small", "big", "trained", "fhadp2", "dataenv", "constrained", "penalty", "obsscale", "mac", "spil", "gym", "veh2dof", "errcstr", "mpg", "refpara", "repeat", "nomask", "mobilerobot"]
     if "mobilerobot" in which:
         golden_mobilerobot()

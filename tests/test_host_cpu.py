@@ -883,3 +883,53 @@ def test_off_async_trainer_ships_every_gradient_list_and_scalar(tmp_path, style,
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert all((tmp_path / f"ok_{k}").exists() for k in range(2))
+
+
+def test_prioritized_replay_buffer_matches_reference_side_by_side():
+    """tests/golden/per_buffer.npz: the reference's PrioritizedReplayBuffer (numpy sum / min trees walked in Python) run by
+    make_golden.py on 50 synthetic transitions at capacity 37 - not a power of two, ring wrap included -, three sampled batches
+    (unit draws recorded), three priority updates (one with a duplicated index).  This package's device buffer with vectorised
+    tree operations, fed the same transitions / draws / priorities, must hold the same trees after every step and return the
+    same leaves, weights and rows."""
+    import json
+    from gops_amd.trainer.buffer.prioritized_replay_buffer import PrioritizedReplayBuffer
+    z = np.load(os.path.join(ROOT, "tests", "golden", "per_buffer.npz"))
+    g = {k: z[k] for k in z.files}
+    kw = json.loads(str(g["meta/buffer_kwargs"]))
+    buf = PrioritizedReplayBuffer(index=0, buffer_device="cpu", **kw)
+    t = {k[2:]: g[k] for k in g if k.startswith("t/")}
+
+    def store(lo, hi, chunk):
+        for a in range(lo, hi, chunk):
+            b = min(a + chunk, hi)
+            buf.add_batch([(t["obs"][i], t["act"][i], float(t["rew"][i]), bool(t["done"][i]), {}, t["obs2"][i], {}, 0.25) for i in range(a, b)])
+
+    def check(tag):
+        np.testing.assert_allclose(buf.sum_tree.numpy(), g[tag + "/sum_tree"], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(buf.min_tree.numpy(), g[tag + "/min_tree"], rtol=1e-13, atol=0)   # (torch's pow vs numpy's: 1 ulp)
+        assert abs(float(buf.max_priority) - float(g[tag + "/max_priority"])) <= 1e-13 * float(g[tag + "/max_priority"])
+        assert (buf.size, buf.ptr) == (int(g[tag + "/size"]), int(g[tag + "/ptr"]))
+
+    store(0, 20, 7)
+    check("s0")
+    for k in range(3):
+        if k == 1:
+            store(20, 50, 11)
+            check("s1")
+        u = torch.from_numpy(g[f"b{k}/u"])
+        rand = torch.rand
+        torch.rand = lambda *a, **kw_: u.clone()     # the recorded unit draws instead of the device generator's
+        try:
+            b = buf.sample_batch(8)
+        finally:
+            torch.rand = rand
+        np.testing.assert_array_equal(b["idx"].numpy(), g[f"b{k}/idx"])
+        np.testing.assert_allclose(b["weight"].numpy(), g[f"b{k}/weight"], rtol=1e-6)
+        np.testing.assert_array_equal(b["obs"].numpy(), g[f"b{k}/obs"])
+        np.testing.assert_array_equal(b["rew"].numpy(), g[f"b{k}/rew"])
+        assert b["idx"].dtype == torch.int32 and b["weight"].dtype == torch.float32
+        buf.update_batch(torch.from_numpy(g[f"b{k}/upd_idx"]), torch.from_numpy(g[f"b{k}/upd_pr"]))
+        check(f"u{k}")
+        assert abs(buf.beta - float(g[f"u{k}/beta"])) < 1e-12
+    from gops_amd.create_pkg.create_buffer import create_buffer
+    assert isinstance(create_buffer(buffer_name="prioritized_replay_buffer", buffer_device="cpu", **kw), PrioritizedReplayBuffer)

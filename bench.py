@@ -454,7 +454,9 @@ def main():
             r = record_of(name, dtype, k_steps, k_warm, world, mm)
             others[name + ("_f16" if dtype == "fp16" else "")] = {
                 "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k_steps, "dtype": r["dtype"],
-                "roofline": {k: r["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_ms")},
+                "roofline": {k: r["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_ms", "frac_vs_fp32_roof",
+                                                           "products_per_mac") if k in r["roofline"]},
+                "kernel_variant": r["kernel_variant"],
                 "kernels_ms": {k: v["avg_ms"] for k, v in r["kernels_ms"].items()}}
         out["workloads"] = others
     if rank == 0:

@@ -18,36 +18,47 @@
 #include "rollout_f16.h"
 
 #define TB64 64
+#ifndef H64_NT
+#define H64_NT 1
+#endif
+#if H64_NT
+#define H64_STORE(v, ptr) __builtin_nontemporal_store(v, ptr)
+#else
+#define H64_STORE(v, ptr) (*(ptr) = (v))
+#endif
+#ifndef H64_STEP_MAJOR
+#define H64_STEP_MAJOR 1
+#endif
 #define H64_LD 264   // halfs per row of the hidden tile: 256 + 8 (16-byte row skew, conflict-free ds_read_b128)
 
 // acc[jt][rg] (n-tile jt of quad q, 16-row group rg) += W_quad * act^T over kch chunks of 32 inputs
 template <int RG>   // 16-row groups of the tile (4: 64 trajectories per workgroup, 2: 32)
 __device__ __forceinline__ void gemm_quad_h64(const _Float16* act, int ld, int kch, const f16x8* Wp, int q, int lane, f32x4 (&acc)[4][RG]) {
-    constexpr int PF = 2;
+    constexpr int PF = 2, NJ = 4;
     const GLOBAL_AS f16x8* wb = gptr(Wp) + (size_t)q * 4 * kch * 64 + lane;
     const _Float16* brow = act + (lane & 15) * ld + 8 * (lane >> 4);
-    f16x8 ring[PF][4];
+    f16x8 ring[PF][NJ];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
         const int cd = d < kch ? d : kch - 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ring[d][j] = wb[((size_t)j * kch + cd) * 64];
+        for (int j = 0; j < NJ; ++j) ring[d][j] = wb[((size_t)j * kch + cd) * 64];
     }
     for (int c0 = 0; c0 < kch; c0 += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
             const int c = c0 + d;
             if (c < kch) {
-                f16x8 b[RG], a[4];
+                f16x8 b[RG], a[NJ];
 #pragma unroll
                 for (int rg = 0; rg < RG; ++rg) b[rg] = ld8h(brow + 16 * rg * ld + 32 * c);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = ring[d][j];
+                for (int j = 0; j < NJ; ++j) a[j] = ring[d][j];
                 const int cn = (c + PF < kch) ? c + PF : kch - 1;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ring[d][j] = wb[((size_t)j * kch + cn) * 64];
+                for (int j = 0; j < NJ; ++j) ring[d][j] = wb[((size_t)j * kch + cn) * 64];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int rg = 0; rg < RG; ++rg) acc[j][rg] = MFMA_F16(a[j], b[rg], acc[j][rg]);
             }
@@ -68,7 +79,7 @@ __device__ __forceinline__ void convert_x_h64(const float* xs, int ldx, int kp, 
             for (int e = 0; e < 4; ++e) { v[e] = (_Float16)a[e]; v[4 + e] = (_Float16)b[e]; }
         }
         *reinterpret_cast<f16x8*>(x16 + m * ld16 + c) = v;
-        if (g16 != nullptr) __builtin_nontemporal_store(v, gptr(reinterpret_cast<f16x8*>(g16 + (row0 + m) * kp32 + c)));
+        if (g16 != nullptr) H64_STORE(v, gptr(reinterpret_cast<f16x8*>(g16 + (row0 + m) * kp32 + c)));
     }
 }
 
@@ -108,12 +119,12 @@ __device__ __forceinline__ void mlp_hidden_forward_h64(const MlpDev& M, const _F
                 *reinterpret_cast<f16x8*>(hbuf + row * H64_LD + f0 + 8) = o[1];
                 if (stash_h != nullptr && row < stash_rows) {
                     _Float16* hrow = reinterpret_cast<_Float16*>(stash_h[j + 1]) + (row0 + row) * 256;
-                    __builtin_nontemporal_store(o[0], gptr(reinterpret_cast<f16x8*>(hrow + f0)));
-                    __builtin_nontemporal_store(o[1], gptr(reinterpret_cast<f16x8*>(hrow + f0 + 8)));
+                    H64_STORE(o[0], gptr(reinterpret_cast<f16x8*>(hrow + f0)));
+                    H64_STORE(o[1], gptr(reinterpret_cast<f16x8*>(hrow + f0 + 8)));
                     if (ACT == GOPS_ACT_GELU && gelu && stash_g != nullptr) {
                         _Float16* grow = reinterpret_cast<_Float16*>(stash_g[j + 1]) + (row0 + row) * 256;
-                        __builtin_nontemporal_store(gd[0], gptr(reinterpret_cast<f16x8*>(grow + f0)));
-                        __builtin_nontemporal_store(gd[1], gptr(reinterpret_cast<f16x8*>(grow + f0 + 8)));
+                        H64_STORE(gd[0], gptr(reinterpret_cast<f16x8*>(grow + f0)));
+                        H64_STORE(gd[1], gptr(reinterpret_cast<f16x8*>(grow + f0 + 8)));
                     }
                 }
             }
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const Roll
     for (int t = 0; t < p.H; ++t) {
         if (p.fh && tid < TB64) xs[tid * ldx + O] = (float)(t + 1);
         __syncthreads();
-        const size_t row0 = ((size_t)tile * p.H + t) * TB64;
+        const size_t row0 = H64_STEP_MAJOR ? ((size_t)t * gridDim.x + tile) * TB64 : ((size_t)tile * p.H + t) * TB64;
         convert_x_h64(xs, ldx, p.pol.kp[0], p.pol.kp32[0], x16, ldx16, p.need_grad ? reinterpret_cast<_Float16*>(p.st.x) : nullptr, row0, tid);
         if (p.need_grad && tid < 2 * TB64)
             *gptr(reinterpret_cast<f32x4*>(p.st.xf + (row0 + (tid >> 1)) * 8 + 4 * (tid & 1))) =
@@ -279,6 +290,18 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
     const bool gelu = (M.act == GOPS_ACT_GELU);
     {   // head: delta_L[row][k] = (sum_a gy[row][a] Wo[a][k]) * act'_L[row][k]; thread (hm, hp) walks 4 row groups x 2 column blocks
         const int hm = tid >> 4, hp = tid & 15;
+        // all act' operands of the phase are requested before the first delta store (the compiler does not move a load
+        // across a store it cannot prove disjoint: fetched inside the loop, every pass waited for its own HBM round trip)
+        f16x8 hv[2][RG];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int pass = 0; pass < RG; ++pass) {
+                const int row = 16 * pass + hm;
+                hv[kb][pass] = zero8h();
+                if (row < nvalid)
+                    hv[kb][pass] = ld8h(gptr(reinterpret_cast<const _Float16*>(gelu ? st_z[L] : st_h[L]) + (row0 + row) * 256 + 8 * hp + 128 * kb));
+            }
         act_dispatch(M.act, [&]<int ACT>() {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -295,21 +318,19 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
                     const int row = 16 * pass + hm;
                     const bool ok = row < nvalid;
                     const f32x4 gy = *reinterpret_cast<const f32x4*>(s_gy + row * 4);
-                    f16x8 hv = zero8h();
-                    if (ok) hv = ld8h(gptr(reinterpret_cast<const _Float16*>(gelu ? st_z[L] : st_h[L]) + (row0 + row) * 256 + k));
                     f16x8 dv;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float acc = 0.f;
 #pragma unroll
                         for (int a = 0; a < GOPS_MAX_ACT; ++a) acc += gy[a] * (e < 4 ? w0[a][e] : w1[a][e - 4]);   // (rows a >= A: zero weights)
-                        const float hf = (float)hv[e];
+                        const float hf = (float)hv[kb][pass][e];
                         const float d = (ACT == GOPS_ACT_GELU) ? hf : act_bwd_t<ACT>(hf, hf);
                         dv[e] = sat_h(ok ? acc * d : 0.f);
                     }
                     *reinterpret_cast<f16x8*>(dbuf + row * H64_LD + k) = dv;
                     if (st_d != nullptr)
-                        __builtin_nontemporal_store(dv, gptr(reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(st_d[L]) + (row0 + row) * 256 + k)));
+                        H64_STORE(dv, gptr(reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(st_d[L]) + (row0 + row) * 256 + k)));
                 }
             }
         });
@@ -356,8 +377,8 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
                 *reinterpret_cast<f16x8*>(dbuf + row * H64_LD + f0 + 8) = o[1];
                 if (st_d != nullptr) {
                     _Float16* dst = reinterpret_cast<_Float16*>(st_d[j]) + (row0 + row) * 256 + f0;
-                    __builtin_nontemporal_store(o[0], gptr(reinterpret_cast<f16x8*>(dst)));
-                    __builtin_nontemporal_store(o[1], gptr(reinterpret_cast<f16x8*>(dst + 8)));
+                    H64_STORE(o[0], gptr(reinterpret_cast<f16x8*>(dst)));
+                    H64_STORE(o[1], gptr(reinterpret_cast<f16x8*>(dst + 8)));
                 }
             }
         });
@@ -404,6 +425,12 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
     const int ftile = b0 / TB64, fsub = b0 % TB64;   // the forward's 64-row stash tile this tile is part of
     const int O = p.env.obs_dim, A = p.env.act_dim;
     const int ldx = p.ldx, ldh = p.ldh;
+#ifdef H64_SKEW_US   // experiment: every second wave of workgroups starts late, so that co-resident workgroups run different phases
+    if ((blockIdx.x >> 8) & 1) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (long long)(H64_SKEW_US) * 100) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     float* G = smem;                  // [64][ldx] adjoint of obs_{t+1}
     float* s_gy = G + TBW * ldx;      // [TBW][4]
     float* s_wo = s_gy + TBW * 4;     // [4][ldh] head weights
@@ -430,7 +457,7 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
     }
     __syncthreads();
     for (int t = p.H - 1; t >= 0; --t) {
-        const size_t row0 = ((size_t)ftile * p.H + t) * TB64 + fsub;
+        const size_t row0 = (H64_STEP_MAJOR ? ((size_t)t * ((p.B + TB64 - 1) / TB64) + ftile) : ((size_t)ftile * p.H + t)) * TB64 + fsub;
         float g_r = gv * p.gpow[t];
         if (ENV != GOPS_ENV_NONE && p.env.shaping) g_r *= p.env.reward_scale;
         if (tid < TBW) {

@@ -137,7 +137,7 @@ const EnvOverride& env_override() {
             {"GOPS_SPLIT_STREAM0", '0', GOPS_VF_NO_SPLIT_STREAM0, 0}, {"GOPS_SPLIT_TAIL_MULTI", 0, GOPS_VF_SPLIT_TAIL_MULTI, 0},
             {"GOPS_DW_EXACT", 0, GOPS_VF_DW_EXACT, 0}, {"GOPS_DW_F32", 0, GOPS_VF_DW_F32, 0}, {"GOPS_DW_NOGUARD", 0, GOPS_VF_DW_NO_GUARD, 0},
             {"GOPS_DW_SKINNY", '0', GOPS_VF_DW_NO_SKINNY, 0}, {"GOPS_DW_SPEC", '0', GOPS_VF_DW_NO_SPEC, 0}, {"GOPS_DW_DIRECT", 0, GOPS_VF_DW_DIRECT, 0},
-            {"GOPS_NO_FUSED_DWOUT", 0, GOPS_VF_NO_FUSED_DWOUT, 0}, {"GOPS_BWD_UPLOAD", 0, GOPS_VF_BWD_UPLOAD, 0},
+            {"GOPS_NO_FUSED_DWOUT", 0, GOPS_VF_NO_FUSED_DWOUT, 0}, {"GOPS_H64", '0', GOPS_VF_NO_HALF_TILE64, 0}, {"GOPS_BWD_UPLOAD", 0, GOPS_VF_BWD_UPLOAD, 0},
             {"GOPS_SK", 0, 0, 1}, {"GOPS_TOUCH", 0, 0, 2}, {"GOPS_DW_WGS", 0, 0, 3}, {"GOPS_DBG_TIMING", 0, 0, 4}};
         EnvOverride r;
         for (const Knob& k : knobs) {

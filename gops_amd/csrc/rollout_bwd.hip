@@ -388,7 +388,8 @@ __device__ __forceinline__ void ss_store_out_grad(const SsOutGrad& og, int K, in
 // Streamed-split sweep through one net (any number of 256-wide hidden layers; the counterpart of ss_net_forward): delta_y
 // (s_gy[TB][4]) -> hidden deltas (FM stash st_d when non-null) and, if want_gx, G += delta_1 W_0.  Weight planes (transposed
 // packing, SplitNetDev) stream from L2; ONE delta plane image `dq`, rewritten in place behind a barrier; act' operands come
-// from the FM stash straight into registers, in flight during the contraction they follow.  Wo: head weights [A][ldw]
+// from the FM stash straight into registers, requested one phase ahead (vmcnt retires in order: requested in front of a
+// contraction they would sit between it and its first weight fragment).  Wo: head weights [A][ldw]
 // (LDS copy or global).
 template <class WP, class Hook>
 __device__ __forceinline__ void ss_net_backward(const MlpDev& M, const SplitNetDev& ST, WP Wo, int ldw, const float* s_gy, const float* s_scale,
@@ -418,9 +419,11 @@ __device__ __forceinline__ void ss_net_backward(const MlpDev& M, const SplitNetD
         });
         plane_store(dq, ROWB, wave, lane, a, s);
     };
+    f32x4 hvn[4];   // act' operands requested one phase ahead
     {   // ---- head: delta_L = (delta_y W_o) * act'(z_L): one K = 4 fp32 MFMA per n-tile ----
         f32x4 hv[4];
         fetch(L, hv);
+        if (L >= 2) fetch(L - 1, hvn);   // the next phase's act' operands: in flight during this phase's math
         const int kk = lane >> 4;
         const float ga = (kk < A) ? s_gy[(lane & 15) * 4 + kk] : 0.f;
         f32x4 acc[4] = {};
@@ -463,7 +466,8 @@ __device__ __forceinline__ void ss_net_backward(const MlpDev& M, const SplitNetD
     after_head();
     for (int j = L - 1; j >= 1; --j) {   // ---- delta_j = (delta_{j+1} W_j) * act'(z_j) ----
         f32x4 hv[4];
-        fetch(j, hv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[q] = hvn[q];
         f32x4 acc[4] = {}, accr[4] = {};
         float inv[4];
         ss_layer_gemm<8>(dq, ROWB, ST.w1[j], ST.r[j], ST.inv[j], 16, tid, acc, accr, inv);
@@ -473,6 +477,7 @@ __device__ __forceinline__ void ss_net_backward(const MlpDev& M, const SplitNetD
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[q][r] = fmaf(accr[q][r], sc, acc[q][r]);
         }
+        if (j >= 2) fetch(j - 1, hvn);   // (before the barrier and this layer's epilogue)
         __syncthreads();   // every wave has read the delta image it is about to overwrite
         finish(j, acc, hv);
         __syncthreads();

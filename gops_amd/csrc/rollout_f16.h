@@ -211,10 +211,17 @@ __device__ __forceinline__ void mlp_backward_h(const MlpDev& M, WP Wo, int ldw, 
         for (int a = 0; a < GOPS_MAX_ACT; ++a) gy[a] = (a < A) ? s_gy[hm * 4 + a] : 0.f;
         const GLOBAL_AS _Float16* src = gptr(reinterpret_cast<const _Float16*>(gelu ? st_z[L] : st_h[L]) + (row0 + hm) * K);
         _Float16* dst = (st_d != nullptr) ? reinterpret_cast<_Float16*>(st_d[L]) + (row0 + hm) * K : nullptr;
+        // the act' operands of the first 512 columns are requested before the first delta store (a load inside the loop waits for
+        // its own HBM round trip: the compiler does not move it across a store it cannot prove disjoint)
+        f16x8 hvs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 8 * hp + 128 * i;
+            hvs[i] = zero8h();
+            if (k < K && hm < nvalid) hvs[i] = ld8h(src + k);
+        }
         act_dispatch(M.act, [&]<int ACT>() {
-            for (int k = 8 * hp; k < K; k += 128) {
-                f16x8 hv = zero8h();
-                if (hm < nvalid) hv = ld8h(src + k);
+            auto column_block = [&](int k, const f16x8 hv) {
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int a = 0; a < GOPS_MAX_ACT; ++a)
@@ -232,7 +239,11 @@ __device__ __forceinline__ void mlp_backward_h(const MlpDev& M, WP Wo, int ldw, 
                 }
                 *reinterpret_cast<f16x8*>(da + hm * ld16 + k) = dv;
                 if (dst != nullptr) __builtin_nontemporal_store(dv, gptr(reinterpret_cast<f16x8*>(dst + k)));
-            }
+            };
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (8 * hp + 128 * i < K) column_block(8 * hp + 128 * i, hvs[i]);
+            for (int k = 8 * hp + 512; k < K; k += 128) column_block(k, (hm < nvalid) ? ld8h(src + k) : zero8h());
         });
         if (stash_dy != nullptr && tid < TB) {
             f32x4 v = {s_gy[tid * 4 + 0], s_gy[tid * 4 + 1], s_gy[tid * 4 + 2], s_gy[tid * 4 + 3]};

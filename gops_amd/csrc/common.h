@@ -253,6 +253,27 @@ __device__ __forceinline__ void gelu_pair(float z, float& h, float& dh) {
     dh = fmaf(z * 0.39894228040143267794f, e, cdf);
 }
 
+// The same pair for the HALF-precision kernels (results are rounded to 2^-11 anyway): Phi(-|z|) = exp(-z^2/2) P7(|z|) with P7 the
+// degree-7 least-squares fit of the Mills ratio Phi(-x) / exp(-x^2/2) on [0, 6] under the weight exp(-x^2/2) (|error| <= 1.6e-5
+// on Phi, 1.2e-5 on gelu, evaluated in fp32 Horner form; numpy: chebvander + lstsq, converted to monomials).  No reciprocal:
+// one v_exp_f32 + 17 full-rate instructions, ~21 issue slots against ~26 - the forward of the 64-row half kernels is bound
+// by exactly this arithmetic.
+__device__ __forceinline__ void gelu_pair_h(float z, float& h, float& dh) {
+    const float x = fminf(fabsf(z), 6.f);
+    const float e = __builtin_amdgcn_exp2f(z * z * -0.72134752044448170368f);   // exp(-z^2 / 2)
+    float p = fmaf(x, -1.45366924e-04f, 2.07320246e-03f);
+    p = fmaf(p, x, -1.29176200e-02f);
+    p = fmaf(p, x, 4.79239046e-02f);
+    p = fmaf(p, x, -1.23755032e-01f);
+    p = fmaf(p, x, 2.46921233e-01f);
+    p = fmaf(p, x, -3.98505880e-01f);
+    p = fmaf(p, x, 4.99984820e-01f);
+    const float q = p * e;                       // Phi(-|z|)
+    const float cdf = z < 0.f ? q : 1.f - q;
+    h = z * cdf;
+    dh = fmaf(z * 0.39894228040143267794f, e, cdf);
+}
+
 // ELU / SELU negative branch: exp(min(z,0)) - 1 on the hardware exponential (v_exp_f32, ~1 ulp of a
 // value <= 1, i.e. absolute error <= 1.2e-7 - fp32 round-off class, far inside the 1e-4 parity
 // bar) and written as max(z,0) + (e - 1) so that no lane diverges: for z > 0, e == 1 exactly.

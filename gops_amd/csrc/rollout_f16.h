@@ -27,7 +27,7 @@ __device__ __forceinline__ f16x8 zero8h() {
     return z;
 }
 
-// (gelu_pair: common.h)
+// (gelu_pair_h: common.h)
 
 // acc[j] (n-tile j of quad q, see the header) += W_quad * act^T over kch chunks of 32 inputs.  The
 // weight fragments stream from L2 through a ring of PF chunks (L2 latency >> the 4 MFMAs of a chunk).  Measured
@@ -121,7 +121,7 @@ __device__ __forceinline__ const _Float16* mlp_hidden_forward_h(const MlpDev& M,
                         const int e = 4 * jj + r;
                         const float z = acc[jj][r] + bv[jj][r];
                         float h, dh = 0.f;
-                        if (ACT == GOPS_ACT_GELU) gelu_pair(z, h, dh);
+                        if (ACT == GOPS_ACT_GELU) gelu_pair_h(z, h, dh);
                         else h = act_fwd_t<ACT>(z);
                         o[e >> 3][e & 7] = (_Float16)h;
                         gd[e >> 3][e & 7] = (_Float16)dh;

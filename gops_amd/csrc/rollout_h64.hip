@@ -110,7 +110,7 @@ __device__ __forceinline__ void mlp_hidden_forward_h64(const MlpDev& M, const _F
                         const int e = 4 * jj + r;
                         const float z = acc[jj][rg][r] + bv[jj][r];
                         float h, dh = 0.f;
-                        if (ACT == GOPS_ACT_GELU) gelu_pair(z, h, dh);
+                        if (ACT == GOPS_ACT_GELU) gelu_pair_h(z, h, dh);
                         else h = act_fwd_t<ACT>(z);
                         o[e >> 3][e & 7] = (_Float16)h;
                         gd[e >> 3][e & 7] = (_Float16)dh;

@@ -1360,52 +1360,58 @@ hipError_t launch_dw_gemm_f16(const void* D, int N, const void* X, int Kp, long 
 }
 
 // Output layer (width A <= 4) on the VALU: part[split][a][k] = sum_s dy[s][a] * h[s][k].
-// Row-major h (GOPS_DTYPE_F16 stash): thread = (4 columns, sample lane), 16-byte coalesced reads of h, four sample
-// lanes per block combined through LDS in a fixed order.
-__device__ __forceinline__ f32x4 ld4_as_f32(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ f32x4 ld4_as_f32(const _Float16* p) {
-    const f16x4 v = *reinterpret_cast<const f16x4*>(p);
-    const f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-    return r;
-}
-template <class HT>   // _Float16 for GOPS_DTYPE_F16 (dy stays fp32)
-__global__ __launch_bounds__(NTHREADS) void dw_out_kernel(const float* __restrict__ dy,
-                                                          const HT* __restrict__ h, int K, int A,
-                                                          long long S, long long per_split,
-                                                          float* __restrict__ part, float* __restrict__ part_b) {
-    __shared__ __attribute__((aligned(16))) f32x4 red[4][GOPS_MAX_ACT][64];
+// Row-major half h (GOPS_DTYPE_F16 stash): thread = (8 columns, sample lane): one 16-byte read of h per sample, four samples
+// in flight per thread (a workgroup keeps 16 KiB of the stream in flight; the round-3 form - 8-byte reads, 8 KiB - ran at
+// 2.6 TB/s); the two sample lanes of a wave are combined by a lane exchange, the four waves through LDS, in a fixed order.
+__global__ __launch_bounds__(NTHREADS) void dw_out_h_kernel(const float* __restrict__ dy, const _Float16* __restrict__ h, int K, int A,
+                                                            long long S, long long per_split, float* __restrict__ part,
+                                                            float* __restrict__ part_b) {
+    __shared__ __attribute__((aligned(16))) float red[4][GOPS_MAX_ACT][256];
     __shared__ float redb[4][GOPS_MAX_ACT];
-    const int split = blockIdx.x, c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int split = blockIdx.x, tid = threadIdx.x, c8 = tid & 31, sl = tid >> 5, wave = tid >> 6;
     const long long s0 = split * per_split, s1 = min(S, s0 + per_split);
-    const int npass = ((K >> 2) + 63) / 64;   // uniform trip count: every lane reaches the barriers
-    for (int pass = 0; pass < npass; ++pass) {
-        const int k4 = c + 64 * pass;
-        const bool col_ok = k4 < (K >> 2);
-        f32x4 acc[GOPS_MAX_ACT] = {};
+    const int nblk = K >> 3;   // (half nets: K is a multiple of 64)
+    for (int cb0 = 0; cb0 < nblk; cb0 += 32) {   // uniform trip count: every lane reaches the barriers
+        const int cb = cb0 + c8;
+        const bool col_ok = cb < nblk;
+        float acc[GOPS_MAX_ACT][8] = {};
         float accb[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
         if (col_ok) {
+            const GLOBAL_AS _Float16* hp = gptr(h) + 8 * cb;
 #pragma unroll 4
-            for (long long sidx = s0 + sl; sidx < s1; sidx += 4) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(dy + sidx * 4);
-                const f32x4 hv = ld4_as_f32(h + sidx * K + 4 * k4);
+            for (long long sidx = s0 + sl; sidx < s1; sidx += 8) {
+                const f32x4 g = *gptr(reinterpret_cast<const f32x4*>(dy) + sidx);
+                const f16x8 hv = *reinterpret_cast<const GLOBAL_AS f16x8*>(hp + sidx * K);
 #pragma unroll
-                for (int a = 0; a < GOPS_MAX_ACT; ++a) { acc[a] += g[a] * hv; accb[a] += g[a]; }
+                for (int a = 0; a < GOPS_MAX_ACT; ++a) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[a][e] = fmaf(g[a], (float)hv[e], acc[a][e]);
+                    accb[a] += g[a];
+                }
             }
         }
 #pragma unroll
-        for (int a = 0; a < GOPS_MAX_ACT; ++a) red[sl][a][c] = acc[a];
-        if (c == 0 && k4 == 0)
-            for (int a = 0; a < GOPS_MAX_ACT; ++a) redb[sl][a] = accb[a];
+        for (int a = 0; a < GOPS_MAX_ACT; ++a) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[a][e] += __shfl_xor(acc[a][e], 32);
+            accb[a] += __shfl_xor(accb[a], 32);
+        }
+        if ((tid & 32) == 0) {
+#pragma unroll
+            for (int a = 0; a < GOPS_MAX_ACT; ++a) {
+                *reinterpret_cast<f32x4*>(&red[wave][a][8 * c8]) = f32x4{acc[a][0], acc[a][1], acc[a][2], acc[a][3]};
+                *reinterpret_cast<f32x4*>(&red[wave][a][8 * c8 + 4]) = f32x4{acc[a][4], acc[a][5], acc[a][6], acc[a][7]};
+            }
+            if (c8 == 0 && cb0 == 0)
+                for (int a = 0; a < GOPS_MAX_ACT; ++a) redb[wave][a] = accb[a];
+        }
         __syncthreads();
-        if (sl == 0 && col_ok) {
-            for (int a = 0; a < A; ++a) {
-                const f32x4 t = (red[0][a][c] + red[1][a][c]) + (red[2][a][c] + red[3][a][c]);
-                *reinterpret_cast<f32x4*>(part + ((size_t)split * A + a) * K + 4 * k4) = t;
-            }
-            if (k4 == 0)
-                for (int a = 0; a < A; ++a)
-                    part_b[(size_t)split * A + a] = (redb[0][a] + redb[1][a]) + (redb[2][a] + redb[3][a]);
-        }
+        const int k = 8 * cb0 + tid;
+        if (k < K)
+            for (int a = 0; a < A; ++a)
+                part[((size_t)split * A + a) * K + k] = (red[0][a][tid] + red[1][a][tid]) + (red[2][a][tid] + red[3][a][tid]);
+        if (tid == 0 && cb0 == 0)
+            for (int a = 0; a < A; ++a) part_b[(size_t)split * A + a] = (redb[0][a] + redb[1][a]) + (redb[2][a] + redb[3][a]);
         __syncthreads();
     }
 }
@@ -1455,8 +1461,8 @@ hipError_t launch_dw_out(const float* dy, const float* h, bool h_is_half, int K,
                          float* part, float* part_b, hipStream_t s) {
     if (h_is_half) {
         const long long per = (S + splits - 1) / splits;
-        hipLaunchKernelGGL(dw_out_kernel<_Float16>, dim3(splits), dim3(NTHREADS), 0, s, dy, reinterpret_cast<const _Float16*>(h),
-                           K, A, S, per, part, part_b);
+        hipLaunchKernelGGL(dw_out_h_kernel, dim3(splits), dim3(NTHREADS), 0, s, dy, reinterpret_cast<const _Float16*>(h), K, A, S, per, part,
+                           part_b);
     } else {   // splits beyond the tile count produce zero slabs (their loops are empty)
         const long long Q = (S + TB - 1) / TB, per = (Q + splits - 1) / splits;
         hipLaunchKernelGGL(dw_out_fm_kernel, dim3(splits), dim3(NTHREADS), 0, s, dy, h, K, A, Q, per, part, part_b);

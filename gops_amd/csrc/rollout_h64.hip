@@ -86,13 +86,14 @@ __device__ __forceinline__ void convert_x_h64(const float* xs, int ldx, int kp, 
 // Hidden stack on the half tile x16 -> hbuf (the LAST hidden activation, [64][H64_LD]); activations (and act'(z) for GELU)
 // of rows < stash_rows go to stash_h / stash_g rows row0 + m.  Ends with a barrier.
 __device__ __forceinline__ void mlp_hidden_forward_h64(const MlpDev& M, const _Float16* x16, int ldx16, _Float16* hbuf, int tid, const float* s_bias,
-                                                       int ldb, float* const* stash_h, float* const* stash_g, size_t row0, int stash_rows) {
+                                                       int ldb, float* const* stash_h, float* const* stash_g, size_t row0, int stash_rows, DbgClock& dbg) {
     const int lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
     const int L = M.nl - 1;
     const int f0 = 64 * wave + 16 * g;
     for (int j = 0; j < L; ++j) {
         f32x4 acc[4][4] = {};
         gemm_quad_h64<4>(j == 0 ? x16 : hbuf, j == 0 ? ldx16 : H64_LD, M.kp32[j] >> 5, M.wph[j], wave, lane, acc);
+        DBG_TICK(2 + 3 * (j > 0))
         if (j > 0) __syncthreads();   // every wave has read the tile it is about to overwrite
         f32x4 bv[4];
 #pragma unroll
@@ -129,7 +130,9 @@ __device__ __forceinline__ void mlp_hidden_forward_h64(const MlpDev& M, const _F
                 }
             }
         });
+        DBG_TICK(3 + 3 * (j > 0))
         __syncthreads();
+        DBG_TICK(4 + 3 * (j > 0))
     }
 }
 
@@ -153,16 +156,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const Roll
     float* s_done = s_th + TB64 * 4;        // [64]
     float* s_bo = s_done + TB64;            // [16] head bias
     float* s_ac = s_bo + 16;                // [4][8] per-action constants
-    float* s_wo = s_ac + 32;                // [4][ldh] head weights, rows a >= A zero
+    float* s_wo = s_ac + 32;                // 4 ldh floats: the head weights as half-plane MFMA fragments (below)
+    f16x8* s_woh = reinterpret_cast<f16x8*>(s_wo);
     float* s_bias = s_wo + 4 * ldh;         // [GOPS_MAX_LAYERS - 1][ldh]
     _Float16* x16 = reinterpret_cast<_Float16*>(s_bias + (GOPS_MAX_LAYERS - 1) * ldh);
     const int ldx16 = (((p.ldx - 4) + 31) & ~31) + 8;
     _Float16* hbuf = x16 + TB64 * ldx16;    // [64][H64_LD]
     {
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
-        for (int idx = tid; idx < GOPS_MAX_ACT * ldh; idx += NTHREADS) {
-            const int a = idx / ldh, k = idx - a * ldh;
-            s_wo[idx] = (a < Ao && k < K) ? gptr(p.pol.w[Lh])[a * K + k] : 0.f;
+        // head weights (fp32) as TWO half planes hi = half(w), lo = half(w - hi) (22 significant bits) in MFMA A-fragment order:
+        // s_woh[(plane * kch + c) * 16 + 4 g + a] = W_o[a][32 c + 8 g .. + 7], a < 4 (fragment rows 4 .. 15 are zero: not stored)
+        for (int idx = tid; idx < 2 * (K >> 5) * 16; idx += NTHREADS) {
+            const int a = idx & 3, g = (idx >> 2) & 3, c = (idx >> 4) % (K >> 5), plane = idx / (16 * (K >> 5));
+            f16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float w = (a < Ao) ? gptr(p.pol.w[Lh])[a * K + 32 * c + 8 * g + e] : 0.f;
+                const _Float16 hi = (_Float16)w;
+                v[e] = plane ? (_Float16)(w - (float)hi) : hi;
+            }
+            s_woh[idx] = v;
         }
         if (tid < GOPS_MAX_ACT) s_bo[tid] = (tid < Ao) ? gptr(p.pol.b[Lh])[tid] : 0.f;
         stage_act_const(p.env, s_ac, tid);
@@ -176,37 +189,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const Roll
     if (tid < TB64) s_done[tid] = (tid < nvalid && p.in.done != nullptr && !p.env.no_mask_at_done && gptr(p.in.done)[b0 + tid] != 0.f) ? 1.f : 0.f;
     float v_acc = 0.f;
     __syncthreads();
+    DbgClock dbg;   // phase counters of thread 0 (GOPS_DBG_BUILD + GOPS_DBG_TIMING=1, tools/dbg_run.py)
+    dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
     for (int t = 0; t < p.H; ++t) {
         if (p.fh && tid < TB64) xs[tid * ldx + O] = (float)(t + 1);
         __syncthreads();
+        DBG_TICK(0)
         const size_t row0 = H64_STEP_MAJOR ? ((size_t)t * gridDim.x + tile) * TB64 : ((size_t)tile * p.H + t) * TB64;
         convert_x_h64(xs, ldx, p.pol.kp[0], p.pol.kp32[0], x16, ldx16, p.need_grad ? reinterpret_cast<_Float16*>(p.st.x) : nullptr, row0, tid);
         if (p.need_grad && tid < 2 * TB64)
             *gptr(reinterpret_cast<f32x4*>(p.st.xf + (row0 + (tid >> 1)) * 8 + 4 * (tid & 1))) =
                 *reinterpret_cast<const f32x4*>(xs + (tid >> 1) * ldx + 4 * (tid & 1));
         __syncthreads();
-        mlp_hidden_forward_h64(p.pol, x16, ldx16, hbuf, tid, s_bias, ldh, p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0, TB64);
-        {   // head + squash + wrapper chain: lane a of a 16-lane group handles action a of its trajectory, four row groups
-            const int hm = tid >> 4, la = tid & 15;
+        DBG_TICK(1)
+        mlp_hidden_forward_h64(p.pol, x16, ldx16, hbuf, tid, s_bias, ldh, p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0, TB64, dbg);
+        {   // head on the matrix core: y[a][row] = sum_k W_o[a][k] h[row][k] as (hi + lo) planes of W_o (fragment rows = actions, zero
+            // padded to 16) times the half tile; wave w takes rows 16 w .. + 15, lanes 0 .. 15 receive the (<= 4) outputs of
+            // their trajectory; then squash + wrapper chain.  (The VALU form read W_o from LDS once per 16-row pass: 590 KB of LDS
+            // reads per tile-step, 6.4 k of the step's 32 k cycles.)
+            const int lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4, kch = p.pol.dims[p.pol.nl - 1] >> 5;
+            const _Float16* brow = hbuf + (16 * wave + n) * H64_LD + 8 * g;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < kch; ++c) {
+                const f16x8 b = ld8h(brow + 32 * c);
+                f16x8 ahi = zero8h(), alo = zero8h();
+                if (n < 4) { ahi = s_woh[c * 16 + 4 * g + n]; alo = s_woh[(kch + c) * 16 + 4 * g + n]; }
+                acc = MFMA_F16(ahi, b, acc);
+                acc = MFMA_F16(alo, b, acc);
+            }
+            if (lane < 16) {
+                const int row = 16 * wave + lane;
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                float y[GOPS_MAX_ACT];
-                mlp_head_h<true>(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hbuf + 16 * pass * H64_LD, H64_LD, tid, y);
-                const float ya = (la == 0) ? y[0] : (la == 1) ? y[1] : (la == 2) ? y[2] : y[3];
-                const int row = 16 * pass + hm;
-                if (la < A) {
-                    if (ENV == GOPS_ENV_NONE) {
-                        s_th[row * 4 + la] = ya;
-                    } else {
-                        const ActC c = act_const(s_ac, la);
-                        const float th = fast_tanh(ya);
-                        s_th[row * 4 + la] = th;
-                        s_act[row * 4 + la] = wrap_action(c, c.sc * th + c.of);
+                for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                    if (a < A) {
+                        const float ya = acc[a] + s_bo[a];
+                        if (ENV == GOPS_ENV_NONE) {
+                            s_th[row * 4 + a] = ya;
+                        } else {
+                            const ActC c = act_const(s_ac, a);
+                            const float th = fast_tanh(ya);
+                            s_th[row * 4 + a] = th;
+                            s_act[row * 4 + a] = wrap_action(c, c.sc * th + c.of);
+                        }
                     }
-                }
             }
         }
+        DBG_TICK(8)
         __syncthreads();
+        DBG_TICK(9)
         float r = 0.f;
         if (tid < TB64) {
             const int m = tid;
@@ -243,7 +273,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const Roll
             if (p.out.rewards != nullptr && m < nvalid) gptr(p.out.rewards)[(size_t)t * p.B + b0 + m] = rr;
             // (pyth_lq never terminates: done_m == false; the done flags handed in stay as they are)
         }
+        DBG_TICK(10)
     }
+    dbg.dump(p.dbg);
     __syncthreads();
     if (TAIL) {   // v += (~done_H) gamma^H V_target(obs_H)
         if (p.fh && tid < TB64) xs[tid * ldx + O] = 0.f;
@@ -253,7 +285,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const Roll
         convert_x_h64(xs, ldx, p.val.kp[0], p.val.kp32[0], x16, ldx16, nullptr, 0, tid);
         __syncthreads();
         mlp_hidden_forward_h64(p.val, x16, ldx16, hbuf, tid, s_bias, ldh, p.need_grad ? p.st.tail_h : nullptr, p.need_grad ? p.st.tail_z : nullptr,
-                               (size_t)b0, nvalid);
+                               (size_t)b0, nvalid, dbg);
         const int Lv = p.val.nl - 1;
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {

@@ -276,6 +276,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     p.tail = desc.tail_value ? 1 : 0;
     p.tail_unmasked = (desc.tail_value && desc.tail_unmasked) ? 1 : 0;
     p.env = e;
+    lq_pad_env(p.env);   // (env_models.h: the LQ matrices with compile-time strides)
     fill_ref_defaults(p.env);
     p.open_loop = desc.open_loop == 2 ? 2 : (desc.open_loop ? 1 : 0);
     p.f16 = f16 ? 1 : 0;
@@ -570,7 +571,11 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     if (dbg) {
         unsigned long long h[16];
         (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
-        if (p.sp.on)
+        if (p.h64)
+            fprintf(stderr, "[gops dbg] bwd 64-row half cycles/step: env adjoint %llu sync %llu | head %llu sync %llu | gemm %llu sync %llu epi %llu sync %llu | "
+                    "g_x %llu | end sync %llu\n", h[0] / p.H, h[1] / p.H, h[2] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H, h[6] / p.H, h[7] / p.H, h[8] / p.H,
+                    h[9] / p.H);
+        else if (p.sp.on)
             fprintf(stderr, "[gops dbg] bwd SPLIT cycles/step: top %llu | env points %llu | reduce+sync %llu | env finish+sync %llu | head delta+planes %llu | "
                     "sync %llu | hook %llu | gemm1+epi+planes %llu | sync %llu | gemm0+G %llu | end sync %llu || sum %llu\n",
                     h[0] / p.H, h[10] / p.H, h[11] / p.H, h[1] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H, h[6] / p.H, (h[7] + h[8]) / p.H, h[9] / p.H,

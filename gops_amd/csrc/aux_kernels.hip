@@ -1907,6 +1907,8 @@ hipError_t launch_env_constraint(const GopsEnv& env, int B, const GopsStepIO& io
 }
 
 hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s) {
-    hipLaunchKernelGGL(env_step_kernel, dim3((B + 127) / 128), dim3(128), 0, s, env, B, io, pdt);
+    GopsEnv padded = env;
+    lq_pad_env(padded);
+    hipLaunchKernelGGL(env_step_kernel, dim3((B + 127) / 128), dim3(128), 0, s, padded, B, io, pdt);
     return hipGetLastError();
 }

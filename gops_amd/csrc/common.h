@@ -230,6 +230,21 @@ __device__ __forceinline__ float f16_grad_scale(float m) {
     return ldexpf(1.f, sh);
 }
 
+// Host side: the ABI's row-major n x n / n x m matrices -> fixed row strides, zero padded (in place, on the library's own copy)
+inline void lq_pad_env(GopsEnv& e) {
+    if (e.kind != GOPS_ENV_LQ) return;
+    const int n = e.obs_dim, m = e.act_dim;
+    float ia[GOPS_MAX_LQ_STATE * GOPS_MAX_LQ_STATE] = {}, b[GOPS_MAX_LQ_STATE * GOPS_MAX_ACT] = {};
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < n; ++k) ia[i * GOPS_MAX_LQ_STATE + k] = e.lq_inv_IA[i * n + k];
+        for (int j = 0; j < m; ++j) b[i * GOPS_MAX_ACT + j] = e.lq_B[i * m + j];
+    }
+    for (int i = 0; i < GOPS_MAX_LQ_STATE * GOPS_MAX_LQ_STATE; ++i) e.lq_inv_IA[i] = ia[i];
+    for (int i = 0; i < GOPS_MAX_LQ_STATE * GOPS_MAX_ACT; ++i) e.lq_B[i] = b[i];
+    for (int i = n; i < GOPS_MAX_LQ_STATE; ++i) e.lq_Q[i] = 0.f;
+    for (int j = m; j < GOPS_MAX_ACT; ++j) e.lq_R[j] = 0.f;
+}
+
 // ---- activations ---------------------------------------------------------------------------
 #define SELU_SCALE 1.0507009873554804934193349852946f
 #define SELU_ALPHA 1.6732632423543772848170429916717f

@@ -34,7 +34,7 @@
 // acc[jt][rg] (n-tile jt of quad q, 16-row group rg) += W_quad * act^T over kch chunks of 32 inputs
 template <int RG>   // 16-row groups of the tile (4: 64 trajectories per workgroup, 2: 32)
 __device__ __forceinline__ void gemm_quad_h64(const _Float16* act, int ld, int kch, const f16x8* Wp, int q, int lane, f32x4 (&acc)[4][RG]) {
-    constexpr int PF = 2, NJ = 4;
+    constexpr int PF = 2, NJ = 4;   // (measured at cfg5: ring depths 3 and 4 change nothing)
     const GLOBAL_AS f16x8* wb = gptr(Wp) + (size_t)q * 4 * kch * 64 + lane;
     const _Float16* brow = act + (lane & 15) * ld + 8 * (lane >> 4);
     f16x8 ring[PF][NJ];
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const Roll
 template <int RG, class WP>
 __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw, const float* s_gy, _Float16* dbuf, float* G, int ldg, int tid,
                                                  float* const* st_h, float* const* st_z, float* const* st_d, float* stash_dy, size_t row0,
-                                                 int nvalid, bool want_gx, int ncols) {
+                                                 int nvalid, bool want_gx, int ncols, DbgClock& dbg) {
     const int lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
     const int L = M.nl - 1, A = M.dims[M.nl];
     const bool gelu = (M.act == GOPS_ACT_GELU);
@@ -374,7 +374,9 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
             *gptr(reinterpret_cast<f32x4*>(stash_dy + (row0 + tid) * 4)) = v;
         }
     }
+    DBG_TICK(2)
     __syncthreads();
+    DBG_TICK(3)
     const int f0 = 64 * wave + 16 * g;
     for (int j = L - 1; j >= 1; --j) {   // delta_j = (delta_{j+1} W_j) * act'_j
         f16x8 hv[RG][2];
@@ -390,7 +392,9 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
         }
         f32x4 acc[4][RG] = {};
         gemm_quad_h64<RG>(dbuf, H64_LD, M.dims[j + 1] >> 5, M.wpth[j], wave, lane, acc);
+        DBG_TICK(4)
         __syncthreads();   // every wave has read the delta tile it is about to overwrite
+        DBG_TICK(5)
         act_dispatch(M.act, [&]<int ACT>() {
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) {
@@ -414,7 +418,9 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
                 }
             }
         });
+        DBG_TICK(6)
         __syncthreads();
+        DBG_TICK(7)
     }
     if (want_gx) {   // g_x = delta_1 W_0: 16-feature tiles over the (16-padded) inputs; wave w takes row group w % RG, n-tiles w / RG, ...
         const int kch = M.dims[1] >> 5, nt_tot = M.kp[0] >> 4;
@@ -434,6 +440,7 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
                 if (f + r < ncols) G[(16 * rgw + m) * ldg + f + r] += acc0[r] + acc1[r];
         }
     }
+    DBG_TICK(8)
 }
 
 // The sweep walks the forward's 64-row stash tiles in tiles of H64_BWD_RG x 16 rows.  Measured at cfg5 (round 4): 64 rows per
@@ -475,6 +482,8 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
         }
     }
     for (int idx = tid; idx < TBW * ldx; idx += NTHREADS) G[idx] = 0.f;
+    DbgClock dbg;   // phase counters of thread 0 (GOPS_DBG_BUILD + GOPS_DBG_TIMING=1, tools/dbg_run.py)
+    dbg.init(false);
     float gv = (tid < nvalid) ? gptr(q.grad_v)[b0 + tid] : 0.f;
     gv *= f16_grad_scale(gptr(p.gscale)[0]);
     if (TAIL) {
@@ -485,9 +494,10 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
         }
         __syncthreads();
         mlp_backward_h64<RG>(p.val, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, dbuf, G, ldx, tid, p.st.tail_h, p.st.tail_z, nullptr,
-                         nullptr, (size_t)b0, nvalid, true, O);
+                         nullptr, (size_t)b0, nvalid, true, O, dbg);
     }
     __syncthreads();
+    dbg.init((q.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
     for (int t = p.H - 1; t >= 0; --t) {
         const size_t row0 = (H64_STEP_MAJOR ? ((size_t)t * ((p.B + TB64 - 1) / TB64) + ftile) : ((size_t)ftile * p.H + t)) * TB64 + fsub;
         float g_r = gv * p.gpow[t];
@@ -547,16 +557,21 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
                     s_gy[m * 4 + a] = (a < A) ? wrap_action_bwd(p.env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a]) : 0.f;
             }
         }
+        DBG_TICK(0)
         __syncthreads();
+        DBG_TICK(1)
         mlp_backward_h64<RG>(p.pol, s_wo, ldh, s_gy, dbuf, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
-                         /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O);
+                         /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg);
         __syncthreads();
+        DBG_TICK(9)
     }
+    dbg.dump(q.dbg);
 }
 
 hipError_t launch_rollout_fwd_h64(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
     const dim3 grid((p.B + TB64 - 1) / TB64), block(NTHREADS);
-    const size_t lds = rollout_fwd_h64_lds_bytes(p.ldx, p.ldh);
+    size_t lds = rollout_fwd_h64_lds_bytes(p.ldx, p.ldh);
+    if (p.dbg != nullptr) lds = max(lds, (size_t)84 * 1024);   // phase counters: ONE workgroup per CU, so that the phases of thread 0 add up
     if (p.env.kind == GOPS_ENV_LQ) {
         if (p.tail) launch_with_lds(rollout_fwd_h64_kernel<GOPS_ENV_LQ, true>, grid, block, lds, stream, dp);
         else launch_with_lds(rollout_fwd_h64_kernel<GOPS_ENV_LQ, false>, grid, block, lds, stream, dp);
@@ -572,7 +587,8 @@ hipError_t launch_rollout_fwd_h64(const RolloutParams& p, const RolloutParams* d
 hipError_t launch_rollout_bwd_h64(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream) {
     constexpr int RG = H64_BWD_RG, TBW = 16 * RG;
     const dim3 grid((p.B + TBW - 1) / TBW), block(NTHREADS);
-    const size_t lds = rollout_bwd_h64_lds_bytes(p.ldx, p.ldh);
+    size_t lds = rollout_bwd_h64_lds_bytes(p.ldx, p.ldh);
+    if (q.dbg != nullptr) lds = max(lds, (size_t)84 * 1024);   // (as in the forward)
     if (p.env.kind == GOPS_ENV_LQ) {
         if (p.tail) launch_with_lds(rollout_bwd_h64_kernel<GOPS_ENV_LQ, true, RG>, grid, block, lds, stream, dp, q);
         else launch_with_lds(rollout_bwd_h64_kernel<GOPS_ENV_LQ, false, RG>, grid, block, lds, stream, dp, q);

@@ -313,10 +313,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const Roll
 // Backward sweep, 64-row tiles.  delta_y (fp32, in the launch's scaled units) in s_gy[64][4] -> hidden deltas (half; stash
 // st_d[j] when non-null) and, if want_gx, G[row][n] += (delta_1 W_0)[row][n] for n < ncols.  ONE delta tile `dbuf`, rewritten
 // in place behind a barrier.  Ends without a barrier after the g_x update (the caller's end-of-step barrier follows).
-template <int RG, class WP>
+template <int RG, class WP, class Hook>
 __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw, const float* s_gy, _Float16* dbuf, float* G, int ldg, int tid,
                                                  float* const* st_h, float* const* st_z, float* const* st_d, float* stash_dy, size_t row0,
-                                                 int nvalid, bool want_gx, int ncols, DbgClock& dbg) {
+                                                 int nvalid, bool want_gx, int ncols, DbgClock& dbg, Hook&& after_head) {
     const int lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
     const int L = M.nl - 1, A = M.dims[M.nl];
     const bool gelu = (M.act == GOPS_ACT_GELU);
@@ -377,6 +377,7 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
     DBG_TICK(2)
     __syncthreads();
     DBG_TICK(3)
+    after_head();   // the caller's prefetches: they travel together with the layer step's act' operands, in front of its GEMM
     const int f0 = 64 * wave + 16 * g;
     for (int j = L - 1; j >= 1; --j) {   // delta_j = (delta_{j+1} W_j) * act'_j
         f16x8 hv[RG][2];
@@ -484,6 +485,26 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
     for (int idx = tid; idx < TBW * ldx; idx += NTHREADS) G[idx] = 0.f;
     DbgClock dbg;   // phase counters of thread 0 (GOPS_DBG_BUILD + GOPS_DBG_TIMING=1, tools/dbg_run.py)
     dbg.init(false);
+    auto step_row0 = [&](int t) -> size_t {
+        return (H64_STEP_MAJOR ? ((size_t)t * ((p.B + TB64 - 1) / TB64) + ftile) : ((size_t)ftile * p.H + t)) * TB64 + fsub;
+    };
+    // env-stash row and policy input of a trajectory, requested one step ahead (from inside the previous step's network sweep:
+    // read at the top of the env phase they cost that phase a full HBM round trip on ONE wave while three wait at the barrier)
+    struct EnvRow { f32x4 e0, xa, xb; float dflag; };
+    auto fetch_env = [&](int t, EnvRow& r) {
+        r.e0 = r.xa = r.xb = f32x4{0.f, 0.f, 0.f, 0.f};
+        r.dflag = 1.f;
+        if (ENV != GOPS_ENV_NONE && t >= 0 && tid < nvalid) {
+            const size_t row = step_row0(t) + tid;
+            const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + row * ENV_STASH));
+            const GLOBAL_AS f32x4* xr = gptr(reinterpret_cast<const f32x4*>(p.st.xf + row * 8));
+            r.e0 = er[0];
+            r.dflag = er[1][0];
+            r.xa = xr[0];
+            r.xb = xr[1];
+        }
+    };
+    EnvRow cur, nxt;
     float gv = (tid < nvalid) ? gptr(q.grad_v)[b0 + tid] : 0.f;
     gv *= f16_grad_scale(gptr(p.gscale)[0]);
     if (TAIL) {
@@ -494,12 +515,14 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
         }
         __syncthreads();
         mlp_backward_h64<RG>(p.val, gptr(p.val.w[p.val.nl - 1]), p.val.dims[p.val.nl - 1], s_gy, dbuf, G, ldx, tid, p.st.tail_h, p.st.tail_z, nullptr,
-                         nullptr, (size_t)b0, nvalid, true, O, dbg);
+                         nullptr, (size_t)b0, nvalid, true, O, dbg, [&] { fetch_env(p.H - 1, cur); });
+    } else {
+        fetch_env(p.H - 1, cur);
     }
     __syncthreads();
     dbg.init((q.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
     for (int t = p.H - 1; t >= 0; --t) {
-        const size_t row0 = (H64_STEP_MAJOR ? ((size_t)t * ((p.B + TB64 - 1) / TB64) + ftile) : ((size_t)ftile * p.H + t)) * TB64 + fsub;
+        const size_t row0 = step_row0(t);
         float g_r = gv * p.gpow[t];
         if (ENV != GOPS_ENV_NONE && p.env.shaping) g_r *= p.env.reward_scale;
         if (tid < TBW) {
@@ -508,16 +531,12 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
                 s_gy[m * 4 + 0] = g_r;
                 s_gy[m * 4 + 1] = s_gy[m * 4 + 2] = s_gy[m * 4 + 3] = 0.f;
             } else {   // GOPS_ENV_LQ (the arithmetic of rollout_bwd_kernel's LQ block)
-                float th[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, dflag = 1.f;
+                const float th[GOPS_MAX_ACT] = {cur.e0[0], cur.e0[1], cur.e0[2], cur.e0[3]}, dflag = cur.dflag;
                 float x[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (m < nvalid) {
-                    const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
-                    const f32x4 e0 = er[0], e1 = er[1];
-                    th[0] = e0[0]; th[1] = e0[1]; th[2] = e0[2]; th[3] = e0[3];
-                    dflag = e1[0];
 #pragma unroll
                     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                        if (i < O) x[i] = obs_unscale(p.env, i, gptr(p.st.xf)[(row0 + m) * 8 + i]);   // the stash holds the (scaled) policy input
+                        if (i < O) x[i] = obs_unscale(p.env, i, i < 4 ? cur.xa[i & 3] : cur.xb[i & 3]);   // the stash holds the (scaled) policy input
                 }
                 float abar[GOPS_MAX_ACT], u[GOPS_MAX_ACT], sc[GOPS_MAX_ACT], gu[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -561,7 +580,8 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
         __syncthreads();
         DBG_TICK(1)
         mlp_backward_h64<RG>(p.pol, s_wo, ldh, s_gy, dbuf, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
-                         /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg);
+                         /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, [&] { fetch_env(t - 1, nxt); });
+        cur = nxt;
         __syncthreads();
         DBG_TICK(9)
     }

@@ -29,6 +29,10 @@
 #ifndef H64_STEP_MAJOR
 #define H64_STEP_MAJOR 1
 #endif
+// The env description is copied to LDS once per workgroup and the env phases read it there (broadcast ds_reads with immediate
+// offsets): read through the kernel-argument pointer its ~100 scalars per step did not fit the SGPR file - the sweep's env
+// phase held 325 v_readlane / 45 v_writelane SGPR spills and 96 single s_loads (8.3 k of a 34 k-cycle step on ONE wave).
+#define ENV_LDS_FLOATS ((int)((sizeof(GopsEnv) + 15) / 16) * 4)
 #define H64_LD 264   // halfs per row of the hidden tile: 256 + 8 (16-byte row skew, conflict-free ds_read_b128)
 
 // acc[jt][rg] (n-tile jt of quad q, 16-row group rg) += W_quad * act^T over kch chunks of 32 inputs
@@ -138,7 +142,7 @@ __device__ __forceinline__ void mlp_hidden_forward_h64(const MlpDev& M, const _F
 
 size_t rollout_fwd_h64_lds_bytes(int ldx, int ldh) {
     const int ldx16 = (((ldx - 4) + 31) & ~31) + 8;
-    return sizeof(float) * (size_t)(TB64 * ldx + TB64 * (4 + 4 + 1) + 16 + 32 + 4 * ldh + (GOPS_MAX_LAYERS - 1) * ldh) +
+    return sizeof(float) * (size_t)(TB64 * ldx + TB64 * (4 + 4 + 1) + 16 + 32 + 4 * ldh + (GOPS_MAX_LAYERS - 1) * ldh + ENV_LDS_FLOATS) +
            sizeof(_Float16) * (size_t)(TB64 * ldx16 + TB64 * H64_LD);
 }
 
@@ -159,7 +163,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const Roll
     float* s_wo = s_ac + 32;                // 4 ldh floats: the head weights as half-plane MFMA fragments (below)
     f16x8* s_woh = reinterpret_cast<f16x8*>(s_wo);
     float* s_bias = s_wo + 4 * ldh;         // [GOPS_MAX_LAYERS - 1][ldh]
-    _Float16* x16 = reinterpret_cast<_Float16*>(s_bias + (GOPS_MAX_LAYERS - 1) * ldh);
+    float* s_env = s_bias + (GOPS_MAX_LAYERS - 1) * ldh;   // GopsEnv copy
+    const GopsEnv& env = *reinterpret_cast<const GopsEnv*>(s_env);
+    for (int idx = tid; idx < (int)(sizeof(GopsEnv) / 4); idx += NTHREADS) s_env[idx] = gptr(reinterpret_cast<const float*>(&p.env))[idx];
+    _Float16* x16 = reinterpret_cast<_Float16*>(s_env + ENV_LDS_FLOATS);
     const int ldx16 = (((p.ldx - 4) + 31) & ~31) + 8;
     _Float16* hbuf = x16 + TB64 * ldx16;    // [64][H64_LD]
     {
@@ -252,23 +259,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const Roll
             } else {   // GOPS_ENV_LQ (the arithmetic of rollout_fwd_kernel's LQ block)
                 float x[GOPS_MAX_LQ_STATE], xn[GOPS_MAX_LQ_STATE], u[GOPS_MAX_ACT];
 #pragma unroll
-                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { x[i] = (i < O) ? obs_unscale(p.env, i, xs[m * ldx + i]) : 0.f; xn[i] = 0.f; }
+                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { x[i] = (i < O) ? obs_unscale(env, i, xs[m * ldx + i]) : 0.f; xn[i] = 0.f; }
 #pragma unroll
                 for (int j = 0; j < GOPS_MAX_ACT; ++j) u[j] = (j < A) ? s_act[m * 4 + j] : 0.f;
                 const bool frozen = s_done[m] != 0.f;
-                lq_forward(p.env, x, u, xn, r);
-                if (!frozen || p.env.clip_obs || p.env.scale_obs) {
+                lq_forward(env, x, u, xn, r);
+                if (!frozen || env.clip_obs || env.scale_obs) {
 #pragma unroll
                     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
                         if (i < O) {
-                            const float v = obs_rescale(p.env, i, sel_reg(frozen, x[i], xn[i]));
-                            xs[m * ldx + i] = p.env.clip_obs ? clampf(v, p.env.obs_low[i], p.env.obs_high[i]) : v;
+                            const float v = obs_rescale(env, i, sel_reg(frozen, x[i], xn[i]));
+                            xs[m * ldx + i] = env.clip_obs ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
                         }
                 }
             }
             const float d = s_done[m];
             float rr = (d != 0.f) ? 0.f : r;
-            if (ENV != GOPS_ENV_NONE && p.env.shaping) rr = (rr + p.env.reward_shift) * p.env.reward_scale;
+            if (ENV != GOPS_ENV_NONE && env.shaping) rr = (rr + env.reward_shift) * env.reward_scale;
             v_acc += rr * p.gpow[t];
             if (p.out.rewards != nullptr && m < nvalid) gptr(p.out.rewards)[(size_t)t * p.B + b0 + m] = rr;
             // (pyth_lq never terminates: done_m == false; the done flags handed in stay as they are)
@@ -452,7 +459,7 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
 #endif
 #define H64_BWD_WGS (H64_BWD_RG == 4 ? 2 : 3)
 size_t rollout_bwd_h64_lds_bytes(int ldx, int ldh) {
-    return sizeof(float) * (size_t)(16 * H64_BWD_RG * ldx + 16 * H64_BWD_RG * 4 + 4 * ldh) + sizeof(_Float16) * (size_t)(16 * H64_BWD_RG * H64_LD);
+    return sizeof(float) * (size_t)(16 * H64_BWD_RG * ldx + 16 * H64_BWD_RG * 4 + 4 * ldh + ENV_LDS_FLOATS) + sizeof(_Float16) * (size_t)(16 * H64_BWD_RG * H64_LD);
 }
 
 template <int ENV, bool TAIL, int RG>
@@ -474,7 +481,10 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
     float* G = smem;                  // [64][ldx] adjoint of obs_{t+1}
     float* s_gy = G + TBW * ldx;      // [TBW][4]
     float* s_wo = s_gy + TBW * 4;     // [4][ldh] head weights
-    _Float16* dbuf = reinterpret_cast<_Float16*>(s_wo + 4 * ldh);   // [64][H64_LD]
+    float* s_env = s_wo + 4 * ldh;    // GopsEnv copy
+    const GopsEnv& env = *reinterpret_cast<const GopsEnv*>(s_env);
+    for (int idx = tid; idx < (int)(sizeof(GopsEnv) / 4); idx += NTHREADS) s_env[idx] = gptr(reinterpret_cast<const float*>(&p.env))[idx];
+    _Float16* dbuf = reinterpret_cast<_Float16*>(s_env + ENV_LDS_FLOATS);   // [64][H64_LD]
     {
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
         for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
     for (int t = p.H - 1; t >= 0; --t) {
         const size_t row0 = step_row0(t);
         float g_r = gv * p.gpow[t];
-        if (ENV != GOPS_ENV_NONE && p.env.shaping) g_r *= p.env.reward_scale;
+        if (ENV != GOPS_ENV_NONE && env.shaping) g_r *= env.reward_scale;
         if (tid < TBW) {
             const int m = tid;
             if (ENV == GOPS_ENV_NONE) {
@@ -536,44 +546,44 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
                 if (m < nvalid) {
 #pragma unroll
                     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                        if (i < O) x[i] = obs_unscale(p.env, i, i < 4 ? cur.xa[i & 3] : cur.xb[i & 3]);   // the stash holds the (scaled) policy input
+                        if (i < O) x[i] = obs_unscale(env, i, i < 4 ? cur.xa[i & 3] : cur.xb[i & 3]);   // the stash holds the (scaled) policy input
                 }
                 float abar[GOPS_MAX_ACT], u[GOPS_MAX_ACT], sc[GOPS_MAX_ACT], gu[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int a = 0; a < GOPS_MAX_ACT; ++a) {
-                    sc[a] = (p.env.policy_high[a] - p.env.policy_low[a]) / 2.f;
-                    abar[a] = sc[a] * th[a] + (p.env.policy_high[a] + p.env.policy_low[a]) / 2.f;
-                    u[a] = (a < A) ? wrap_action(p.env, a, abar[a]) : 0.f;
+                    sc[a] = (env.policy_high[a] - env.policy_low[a]) / 2.f;
+                    abar[a] = sc[a] * th[a] + (env.policy_high[a] + env.policy_low[a]) / 2.f;
+                    u[a] = (a < A) ? wrap_action(env, a, abar[a]) : 0.f;
                 }
                 const bool dn = dflag != 0.f;
                 const float g_rm = dn ? 0.f : g_r;
                 float Gin[GOPS_MAX_LQ_STATE], gx[GOPS_MAX_LQ_STATE];
 #pragma unroll
                 for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { Gin[i] = (i < O) ? G[m * ldx + i] : 0.f; gx[i] = 0.f; }
-                if (p.env.clip_obs) {
+                if (env.clip_obs) {
                     float xn[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rdummy;
-                    lq_forward(p.env, x, u, xn, rdummy);
+                    lq_forward(env, x, u, xn, rdummy);
 #pragma unroll
                     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) {
-                        const float pre = obs_rescale(p.env, i, dn ? x[i] : xn[i]);   // what ClipObservation saw
-                        if (i < O && !(pre >= p.env.obs_low[i] && pre <= p.env.obs_high[i])) Gin[i] = 0.f;
+                        const float pre = obs_rescale(env, i, dn ? x[i] : xn[i]);   // what ClipObservation saw
+                        if (i < O && !(pre >= env.obs_low[i] && pre <= env.obs_high[i])) Gin[i] = 0.f;
                     }
                 }
-                if (p.env.scale_obs) {
+                if (env.scale_obs) {
 #pragma unroll
                     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                        if (i < O) Gin[i] *= p.env.obs_scale[i];
+                        if (i < O) Gin[i] *= env.obs_scale[i];
                 }
                 float gxn[GOPS_MAX_LQ_STATE];
 #pragma unroll
                 for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { gxn[i] = dn ? 0.f : Gin[i]; gx[i] = dn ? Gin[i] : 0.f; }
-                lq_backward(p.env, x, u, gxn, g_rm, gx, gu);
+                lq_backward(env, x, u, gxn, g_rm, gx, gu);
 #pragma unroll
                 for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                    if (i < O) G[m * ldx + i] = p.env.scale_obs ? gx[i] / p.env.obs_scale[i] : gx[i];
+                    if (i < O) G[m * ldx + i] = env.scale_obs ? gx[i] / env.obs_scale[i] : gx[i];
 #pragma unroll
                 for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                    s_gy[m * 4 + a] = (a < A) ? wrap_action_bwd(p.env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a]) : 0.f;
+                    s_gy[m * 4 + a] = (a < A) ? wrap_action_bwd(env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a]) : 0.f;
             }
         }
         DBG_TICK(0)

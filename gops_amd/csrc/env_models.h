@@ -12,47 +12,51 @@
 // too - so every loop has a compile-time trip count AND compile-time addresses: the constants arrive as a few wide scalar
 // loads instead of one s_load per run-time index (measured in the 64-row half kernels: the env phase of one wave was
 // 5.3 k of the forward's 27 k cycles per step and 11 k of the sweep's 34 k with the n x n / n x m layout of the ABI).
+// N, M: compile-time bounds of the state / action loops (>= the env's n, m; the arrays keep their maximal sizes) for callers
+// that know the dimensions (the 64-row half kernels special-case n = 4, m = 2).
+template <int N = GOPS_MAX_LQ_STATE, int M = GOPS_MAX_ACT>
 __device__ __forceinline__ void lq_forward(const GopsEnv& e, const float* x, const float* u,
                                            float* xn, float& r) {
     float tmp[GOPS_MAX_LQ_STATE];
 #pragma unroll
-    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) {
+    for (int i = 0; i < N; ++i) {
         float bu = 0.f;
 #pragma unroll
-        for (int j = 0; j < GOPS_MAX_ACT; ++j) bu += e.lq_B[i * GOPS_MAX_ACT + j] * u[j];
+        for (int j = 0; j < M; ++j) bu += e.lq_B[i * GOPS_MAX_ACT + j] * u[j];
         tmp[i] = bu * e.lq_dt + x[i];
     }
     float rs = 0.f, ra = 0.f;
 #pragma unroll
-    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) {
+    for (int i = 0; i < N; ++i) {
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < GOPS_MAX_LQ_STATE; ++k) acc += e.lq_inv_IA[i * GOPS_MAX_LQ_STATE + k] * tmp[k];
+        for (int k = 0; k < N; ++k) acc += e.lq_inv_IA[i * GOPS_MAX_LQ_STATE + k] * tmp[k];
         xn[i] = acc;
         rs += x[i] * x[i] * e.lq_Q[i];
     }
 #pragma unroll
-    for (int j = 0; j < GOPS_MAX_ACT; ++j) ra += u[j] * u[j] * e.lq_R[j];
+    for (int j = 0; j < M; ++j) ra += u[j] * u[j] * e.lq_R[j];
     r = e.lq_reward_scale * (e.lq_reward_shift - 1.0f * (rs + ra));
 }
 
 // adjoints: gxn (adjoint of x'), gr (adjoint of r) -> gx (accumulated), gu (overwritten)
+template <int N = GOPS_MAX_LQ_STATE, int M = GOPS_MAX_ACT>
 __device__ __forceinline__ void lq_backward(const GopsEnv& e, const float* x, const float* u,
                                             const float* gxn, float gr, float* gx, float* gu) {
     float gt[GOPS_MAX_LQ_STATE];
 #pragma unroll
-    for (int k = 0; k < GOPS_MAX_LQ_STATE; ++k) {
+    for (int k = 0; k < N; ++k) {
         float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) acc += e.lq_inv_IA[i * GOPS_MAX_LQ_STATE + k] * gxn[i];
+        for (int i = 0; i < N; ++i) acc += e.lq_inv_IA[i * GOPS_MAX_LQ_STATE + k] * gxn[i];
         gt[k] = acc;
         gx[k] += acc + gr * e.lq_reward_scale * (-2.f * e.lq_Q[k] * x[k]);
     }
 #pragma unroll
-    for (int j = 0; j < GOPS_MAX_ACT; ++j) {
+    for (int j = 0; j < M; ++j) {
         float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) acc += e.lq_B[i * GOPS_MAX_ACT + j] * gt[i];
+        for (int i = 0; i < N; ++i) acc += e.lq_B[i * GOPS_MAX_ACT + j] * gt[i];
         gu[j] = acc * e.lq_dt + gr * e.lq_reward_scale * (-2.f * e.lq_R[j] * u[j]);
     }
 }

@@ -256,22 +256,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const Roll
             }
             if (ENV == GOPS_ENV_NONE) {
                 r = s_th[m * 4];
-            } else {   // GOPS_ENV_LQ (the arithmetic of rollout_fwd_kernel's LQ block)
-                float x[GOPS_MAX_LQ_STATE], xn[GOPS_MAX_LQ_STATE], u[GOPS_MAX_ACT];
+            } else {   // GOPS_ENV_LQ (the arithmetic of rollout_fwd_kernel's LQ block); NS / NA: compile-time loop bounds
+                auto lq_step = [&]<int NS, int NA>() {
+                    constexpr bool EXACT = NS < GOPS_MAX_LQ_STATE;   // the dimensions ARE (NS, NA): no run-time guards
+                    float x[GOPS_MAX_LQ_STATE], xn[GOPS_MAX_LQ_STATE], u[GOPS_MAX_ACT];
 #pragma unroll
-                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { x[i] = (i < O) ? obs_unscale(env, i, xs[m * ldx + i]) : 0.f; xn[i] = 0.f; }
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { x[i] = (i < NS && (EXACT || i < O)) ? obs_unscale(env, i, xs[m * ldx + i]) : 0.f; xn[i] = 0.f; }
 #pragma unroll
-                for (int j = 0; j < GOPS_MAX_ACT; ++j) u[j] = (j < A) ? s_act[m * 4 + j] : 0.f;
-                const bool frozen = s_done[m] != 0.f;
-                lq_forward(env, x, u, xn, r);
-                if (!frozen || env.clip_obs || env.scale_obs) {
+                    for (int j = 0; j < GOPS_MAX_ACT; ++j) u[j] = (j < NA && (EXACT || j < A)) ? s_act[m * 4 + j] : 0.f;
+                    const bool frozen = s_done[m] != 0.f;
+                    lq_forward<NS, NA>(env, x, u, xn, r);
+                    if (!frozen || env.clip_obs || env.scale_obs) {
 #pragma unroll
-                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                        if (i < O) {
-                            const float v = obs_rescale(env, i, sel_reg(frozen, x[i], xn[i]));
-                            xs[m * ldx + i] = env.clip_obs ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
-                        }
-                }
+                        for (int i = 0; i < NS; ++i)
+                            if (EXACT || i < O) {
+                                const float v = obs_rescale(env, i, sel_reg(frozen, x[i], xn[i]));
+                                xs[m * ldx + i] = env.clip_obs ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
+                            }
+                    }
+                };
+                if (O == 4 && A == 2) lq_step.template operator()<4, 2>();   // BASELINE configs[4] (lq s4a2)
+                else lq_step.template operator()<GOPS_MAX_LQ_STATE, GOPS_MAX_ACT>();
             }
             const float d = s_done[m];
             float rr = (d != 0.f) ? 0.f : r;
@@ -540,50 +545,56 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
             if (ENV == GOPS_ENV_NONE) {
                 s_gy[m * 4 + 0] = g_r;
                 s_gy[m * 4 + 1] = s_gy[m * 4 + 2] = s_gy[m * 4 + 3] = 0.f;
-            } else {   // GOPS_ENV_LQ (the arithmetic of rollout_bwd_kernel's LQ block)
-                const float th[GOPS_MAX_ACT] = {cur.e0[0], cur.e0[1], cur.e0[2], cur.e0[3]}, dflag = cur.dflag;
-                float x[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (m < nvalid) {
+            } else {   // GOPS_ENV_LQ (the arithmetic of rollout_bwd_kernel's LQ block); NS / NA: compile-time loop bounds
+                auto lq_adjoint = [&]<int NS, int NA>() {
+                    constexpr bool EXACT = NS < GOPS_MAX_LQ_STATE;   // the dimensions ARE (NS, NA): no run-time guards
+                    const float th[GOPS_MAX_ACT] = {cur.e0[0], cur.e0[1], cur.e0[2], cur.e0[3]}, dflag = cur.dflag;
+                    float x[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (m < nvalid) {
 #pragma unroll
-                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                        if (i < O) x[i] = obs_unscale(env, i, i < 4 ? cur.xa[i & 3] : cur.xb[i & 3]);   // the stash holds the (scaled) policy input
-                }
-                float abar[GOPS_MAX_ACT], u[GOPS_MAX_ACT], sc[GOPS_MAX_ACT], gu[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int a = 0; a < GOPS_MAX_ACT; ++a) {
-                    sc[a] = (env.policy_high[a] - env.policy_low[a]) / 2.f;
-                    abar[a] = sc[a] * th[a] + (env.policy_high[a] + env.policy_low[a]) / 2.f;
-                    u[a] = (a < A) ? wrap_action(env, a, abar[a]) : 0.f;
-                }
-                const bool dn = dflag != 0.f;
-                const float g_rm = dn ? 0.f : g_r;
-                float Gin[GOPS_MAX_LQ_STATE], gx[GOPS_MAX_LQ_STATE];
-#pragma unroll
-                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { Gin[i] = (i < O) ? G[m * ldx + i] : 0.f; gx[i] = 0.f; }
-                if (env.clip_obs) {
-                    float xn[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rdummy;
-                    lq_forward(env, x, u, xn, rdummy);
-#pragma unroll
-                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) {
-                        const float pre = obs_rescale(env, i, dn ? x[i] : xn[i]);   // what ClipObservation saw
-                        if (i < O && !(pre >= env.obs_low[i] && pre <= env.obs_high[i])) Gin[i] = 0.f;
+                        for (int i = 0; i < NS; ++i)
+                            if (EXACT || i < O) x[i] = obs_unscale(env, i, i < 4 ? cur.xa[i & 3] : cur.xb[i & 3]);   // the stash holds the (scaled) policy input
                     }
-                }
-                if (env.scale_obs) {
+                    float abar[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, u[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, sc[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f},
+                          gu[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                        if (i < O) Gin[i] *= env.obs_scale[i];
-                }
-                float gxn[GOPS_MAX_LQ_STATE];
+                    for (int a = 0; a < NA; ++a) {
+                        sc[a] = (env.policy_high[a] - env.policy_low[a]) / 2.f;
+                        abar[a] = sc[a] * th[a] + (env.policy_high[a] + env.policy_low[a]) / 2.f;
+                        u[a] = (EXACT || a < A) ? wrap_action(env, a, abar[a]) : 0.f;
+                    }
+                    const bool dn = dflag != 0.f;
+                    const float g_rm = dn ? 0.f : g_r;
+                    float Gin[GOPS_MAX_LQ_STATE], gx[GOPS_MAX_LQ_STATE];
 #pragma unroll
-                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { gxn[i] = dn ? 0.f : Gin[i]; gx[i] = dn ? Gin[i] : 0.f; }
-                lq_backward(env, x, u, gxn, g_rm, gx, gu);
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { Gin[i] = (i < NS && (EXACT || i < O)) ? G[m * ldx + i] : 0.f; gx[i] = 0.f; }
+                    if (env.clip_obs) {
+                        float xn[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rdummy;
+                        lq_forward<NS, NA>(env, x, u, xn, rdummy);
 #pragma unroll
-                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                    if (i < O) G[m * ldx + i] = env.scale_obs ? gx[i] / env.obs_scale[i] : gx[i];
+                        for (int i = 0; i < NS; ++i) {
+                            const float pre = obs_rescale(env, i, dn ? x[i] : xn[i]);   // what ClipObservation saw
+                            if ((EXACT || i < O) && !(pre >= env.obs_low[i] && pre <= env.obs_high[i])) Gin[i] = 0.f;
+                        }
+                    }
+                    if (env.scale_obs) {
 #pragma unroll
-                for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                    s_gy[m * 4 + a] = (a < A) ? wrap_action_bwd(env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a]) : 0.f;
+                        for (int i = 0; i < NS; ++i)
+                            if (EXACT || i < O) Gin[i] *= env.obs_scale[i];
+                    }
+                    float gxn[GOPS_MAX_LQ_STATE];
+#pragma unroll
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { gxn[i] = dn ? 0.f : Gin[i]; gx[i] = dn ? Gin[i] : 0.f; }
+                    lq_backward<NS, NA>(env, x, u, gxn, g_rm, gx, gu);
+#pragma unroll
+                    for (int i = 0; i < NS; ++i)
+                        if (EXACT || i < O) G[m * ldx + i] = env.scale_obs ? gx[i] / env.obs_scale[i] : gx[i];
+#pragma unroll
+                    for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                        s_gy[m * 4 + a] = (a < NA && (EXACT || a < A)) ? wrap_action_bwd(env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a]) : 0.f;
+                };
+                if (O == 4 && A == 2) lq_adjoint.template operator()<4, 2>();   // BASELINE configs[4] (lq s4a2)
+                else lq_adjoint.template operator()<GOPS_MAX_LQ_STATE, GOPS_MAX_ACT>();
             }
         }
         DBG_TICK(0)

@@ -718,6 +718,81 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
                 s_gy[tid * 4 + 0] = g_r;
                 s_gy[tid * 4 + 1] = s_gy[tid * 4 + 2] = s_gy[tid * 4 + 3] = 0.f;
             }
+        } else if (ENV == GOPS_ENV_LQ && !EXT) {
+            // pyth_lq without ActionRepeat / adjoint I/O: the arithmetic of the generic block below, as a routine with compile-time
+            // loop bounds - (4, 2) for BASELINE configs[4] (lq s4a2), the maxima otherwise.  The generic form (run-time guards on
+            // every state / action index, ~100 scalars of the description live at once) took 9.9 k of the 32 k cycles of a
+            // streamed-split sweep step at cfg5, on 16 lanes.
+            if (tid < TB) {
+                const int m = tid;
+                auto lq_adjoint = [&]<int NS, int NA>() {
+                    constexpr bool EXACT = NS < GOPS_MAX_LQ_STATE;   // the dimensions ARE (NS, NA): no run-time guards
+                    float th[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, dflag = 1.f;
+                    float x[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (m < nvalid) {
+                        f32x4 e0, e1;
+                        if constexpr (STAGE) {
+                            const f32x4* er = reinterpret_cast<const f32x4*>(st_env + m * ENV_STASH);
+                            e0 = er[0]; e1 = er[1];
+#pragma unroll
+                            for (int i = 0; i < NS; ++i)
+                                if (EXACT || i < O) x[i] = st_x[i * 16 + m];
+                        } else {
+                            const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
+                            e0 = er[0]; e1 = er[1];
+#pragma unroll
+                            for (int i = 0; i < NS; ++i)
+                                if (EXACT || i < O) x[i] = x_col(row0, m, i);
+                        }
+                        th[0] = e0[0]; th[1] = e0[1]; th[2] = e0[2]; th[3] = e0[3];
+                        dflag = e1[0];
+#pragma unroll
+                        for (int i = 0; i < NS; ++i)
+                            if (EXACT || i < O) x[i] = obs_unscale(p.env, i, x[i]);   // the stash holds the (scaled) policy input
+                    }
+                    float abar[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, u[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, sc[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f},
+                          gu[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        sc[a] = (p.env.policy_high[a] - p.env.policy_low[a]) / 2.f;
+                        abar[a] = sc[a] * th[a] + (p.env.policy_high[a] + p.env.policy_low[a]) / 2.f;
+                        u[a] = (EXACT || a < A) ? (p.open_loop == 2 ? th[a] : wrap_action(p.env, a, abar[a])) : 0.f;   // open_loop 2: raw actions
+                    }
+                    const bool dn = dflag != 0.f;
+                    const float g_rm = dn ? 0.f : g_r;
+                    float Gin[GOPS_MAX_LQ_STATE], gx[GOPS_MAX_LQ_STATE];
+#pragma unroll
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { Gin[i] = (i < NS && (EXACT || i < O)) ? G[m * ldx + i] : 0.f; gx[i] = 0.f; }
+                    if (p.env.clip_obs) {
+                        float xn[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rdummy;
+                        lq_forward<NS, NA>(p.env, x, u, xn, rdummy);
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) {
+                            const float pre = obs_rescale(p.env, i, dn ? x[i] : xn[i]);   // what ClipObservation saw
+                            if ((EXACT || i < O) && !(pre >= p.env.obs_low[i] && pre <= p.env.obs_high[i])) Gin[i] = 0.f;
+                        }
+                    }
+                    if (p.env.scale_obs) {   // d(scaled next obs) / d(next obs) = scale
+#pragma unroll
+                        for (int i = 0; i < NS; ++i)
+                            if (EXACT || i < O) Gin[i] *= p.env.obs_scale[i];
+                    }
+                    float gxn[GOPS_MAX_LQ_STATE];
+#pragma unroll
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { gxn[i] = dn ? 0.f : Gin[i]; gx[i] = dn ? Gin[i] : 0.f; }
+                    lq_backward<NS, NA>(p.env, x, u, gxn, g_rm, gx, gu);
+#pragma unroll
+                    for (int i = 0; i < NS; ++i)
+                        if (EXACT || i < O) G[m * ldx + i] = p.env.scale_obs ? gx[i] / p.env.obs_scale[i] : gx[i];   // d(obs / scale - shift) / d(obs)
+#pragma unroll
+                    for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                        s_gy[m * 4 + a] = (a < NA && (EXACT || a < A))
+                                              ? (p.open_loop == 2 ? gu[a] : wrap_action_bwd(p.env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a]))
+                                              : 0.f;
+                };
+                if (O == 4 && A == 2) lq_adjoint.template operator()<4, 2>();
+                else lq_adjoint.template operator()<GOPS_MAX_LQ_STATE, GOPS_MAX_ACT>();
+            }
         } else if (ENV == GOPS_ENV_LQ || ENV == GOPS_ENV_IDPENDULUM || ENV == GOPS_ENV_CARTPOLE || ENV == GOPS_ENV_PENDULUM) {
             if (tid < TB) {
                 const int m = tid;

@@ -584,32 +584,38 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
         } else if (ENV == GOPS_ENV_LQ) {
             if (tid < TB) {
                 const int m = tid;
-                float x[GOPS_MAX_LQ_STATE], xn[GOPS_MAX_LQ_STATE], u[GOPS_MAX_ACT];
+                // NS / NA: compile-time loop bounds - (4, 2) for BASELINE configs[4] (lq s4a2), the maxima otherwise
+                auto lq_step = [&]<int NS, int NA>() {
+                    constexpr bool EXACT = NS < GOPS_MAX_LQ_STATE;   // the dimensions ARE (NS, NA): no run-time guards
+                    float x[GOPS_MAX_LQ_STATE], xn[GOPS_MAX_LQ_STATE], u[GOPS_MAX_ACT];
 #pragma unroll
-                for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { x[i] = (i < O) ? obs_unscale(p.env, i, xs[m * ldx + i]) : 0.f; xn[i] = 0.f; }
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { x[i] = (i < NS && (EXACT || i < O)) ? obs_unscale(p.env, i, xs[m * ldx + i]) : 0.f; xn[i] = 0.f; }
 #pragma unroll
-                for (int j = 0; j < GOPS_MAX_ACT; ++j) u[j] = (j < A) ? s_act[m * 4 + j] : 0.f;
-                // MaskAtDone freezes the (unscaled) observation; ScaleObservation rescales, ClipObservation clips the result
-                const bool frozen = s_done[m] != 0.f;
-                const int nrep = GEN ? p.env.repeat_num : 1;   // ActionRepeat: sub-steps with the initial done flag
-                float rs = 0.f;
-                for (int rep = 0; rep < nrep; ++rep) {
-                    if (rep > 0 && !frozen) {
+                    for (int j = 0; j < GOPS_MAX_ACT; ++j) u[j] = (j < NA && (EXACT || j < A)) ? s_act[m * 4 + j] : 0.f;
+                    // MaskAtDone freezes the (unscaled) observation; ScaleObservation rescales, ClipObservation clips the result
+                    const bool frozen = s_done[m] != 0.f;
+                    const int nrep = GEN ? p.env.repeat_num : 1;   // ActionRepeat: sub-steps with the initial done flag
+                    float rs = 0.f;
+                    for (int rep = 0; rep < nrep; ++rep) {
+                        if (rep > 0 && !frozen) {
 #pragma unroll
-                        for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) x[i] = xn[i];
-                    }
-                    lq_forward(p.env, x, u, xn, r);
-                    rs = (GEN && !p.env.repeat_last_reward) ? rs + r : r;
-                }
-                r = rs;
-                if (!frozen || p.env.clip_obs || p.env.scale_obs) {
-#pragma unroll
-                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
-                        if (i < O) {
-                            const float v = obs_rescale(p.env, i, sel_reg(frozen, x[i], xn[i]));
-                            xs[m * ldx + i] = p.env.clip_obs ? clampf(v, p.env.obs_low[i], p.env.obs_high[i]) : v;
+                            for (int i = 0; i < NS; ++i) x[i] = xn[i];
                         }
-                }
+                        lq_forward<NS, NA>(p.env, x, u, xn, r);
+                        rs = (GEN && !p.env.repeat_last_reward) ? rs + r : r;
+                    }
+                    r = rs;
+                    if (!frozen || p.env.clip_obs || p.env.scale_obs) {
+#pragma unroll
+                        for (int i = 0; i < NS; ++i)
+                            if (EXACT || i < O) {
+                                const float v = obs_rescale(p.env, i, sel_reg(frozen, x[i], xn[i]));
+                                xs[m * ldx + i] = p.env.clip_obs ? clampf(v, p.env.obs_low[i], p.env.obs_high[i]) : v;
+                            }
+                    }
+                };
+                if (O == 4 && A == 2) lq_step.template operator()<4, 2>();
+                else lq_step.template operator()<GOPS_MAX_LQ_STATE, GOPS_MAX_ACT>();
             }
         } else if (ENV == GOPS_ENV_CARTPOLE || ENV == GOPS_ENV_PENDULUM) {
             if (tid < TB) {   // gym-style models: obs == state, same wrapper handling as pyth_lq

@@ -245,6 +245,12 @@ inline void lq_pad_env(GopsEnv& e) {
     for (int j = m; j < GOPS_MAX_ACT; ++j) e.lq_R[j] = 0.f;
 }
 
+// LDS copy of the env description (kernels whose env phases read ~100 of its scalars per step: read through the parameter
+// pointer they do not fit the SGPR file - hundreds of lane spills per step; from LDS they are broadcast reads with immediate
+// offsets).  Used by the 64-row half kernels and the pyth_lq instantiations of the streamed plane-split kernels.
+#define ENV_LDS_FLOATS ((int)((sizeof(GopsEnv) + 15) / 16) * 4)
+__host__ __device__ constexpr bool env_in_lds(int env_kind, bool streamed_split) { return streamed_split && env_kind == GOPS_ENV_LQ; }
+
 // ---- activations ---------------------------------------------------------------------------
 #define SELU_SCALE 1.0507009873554804934193349852946f
 #define SELU_ALPHA 1.6732632423543772848170429916717f

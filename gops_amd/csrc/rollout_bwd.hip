@@ -513,9 +513,21 @@ __device__ __forceinline__ void ss_net_backward(const MlpDev& M, const SplitNetD
 // workgroups per CU; the tail value net's input adjoint on the same routine
 template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, bool EXT = false, bool SPLIT = false, bool MULTI = false, bool SSB = false>
 __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 == 0) ? 3 : 1))) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp, const BwdPatch q) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_raw[];
     const RolloutParams& p = *pp;
     const int tid = threadIdx.x;
+    // pyth_lq on the streamed-split sweep: the env description in front of everything else in LDS (common.h: env_in_lds)
+    constexpr bool ENVLDS = env_in_lds(ENV, SSB);
+    float* smem = smem_raw + (ENVLDS ? ENV_LDS_FLOATS : 0);
+    const GopsEnv* env_ptr;
+    if constexpr (ENVLDS) {
+        for (int idx = tid; idx < (int)(sizeof(GopsEnv) / 4); idx += NTHREADS) smem_raw[idx] = gptr(reinterpret_cast<const float*>(&p.env))[idx];
+        env_ptr = reinterpret_cast<const GopsEnv*>(smem_raw);
+        __syncthreads();
+    } else {
+        env_ptr = &p.env;
+    }
+    const GopsEnv& env = *env_ptr;
     int tile = blockIdx.x;   // SPLIT: grid-stride walk over the tiles with the weights resident (else one tile per workgroup)
     int b0 = tile * TB;
     int nvalid = min(TB, p.B - b0);
@@ -748,46 +760,46 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
                         dflag = e1[0];
 #pragma unroll
                         for (int i = 0; i < NS; ++i)
-                            if (EXACT || i < O) x[i] = obs_unscale(p.env, i, x[i]);   // the stash holds the (scaled) policy input
+                            if (EXACT || i < O) x[i] = obs_unscale(env, i, x[i]);   // the stash holds the (scaled) policy input
                     }
                     float abar[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, u[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f}, sc[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f},
                           gu[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int a = 0; a < NA; ++a) {
-                        sc[a] = (p.env.policy_high[a] - p.env.policy_low[a]) / 2.f;
-                        abar[a] = sc[a] * th[a] + (p.env.policy_high[a] + p.env.policy_low[a]) / 2.f;
-                        u[a] = (EXACT || a < A) ? (p.open_loop == 2 ? th[a] : wrap_action(p.env, a, abar[a])) : 0.f;   // open_loop 2: raw actions
+                        sc[a] = (env.policy_high[a] - env.policy_low[a]) / 2.f;
+                        abar[a] = sc[a] * th[a] + (env.policy_high[a] + env.policy_low[a]) / 2.f;
+                        u[a] = (EXACT || a < A) ? (p.open_loop == 2 ? th[a] : wrap_action(env, a, abar[a])) : 0.f;   // open_loop 2: raw actions
                     }
                     const bool dn = dflag != 0.f;
                     const float g_rm = dn ? 0.f : g_r;
                     float Gin[GOPS_MAX_LQ_STATE], gx[GOPS_MAX_LQ_STATE];
 #pragma unroll
                     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { Gin[i] = (i < NS && (EXACT || i < O)) ? G[m * ldx + i] : 0.f; gx[i] = 0.f; }
-                    if (p.env.clip_obs) {
+                    if (env.clip_obs) {
                         float xn[GOPS_MAX_LQ_STATE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rdummy;
-                        lq_forward<NS, NA>(p.env, x, u, xn, rdummy);
+                        lq_forward<NS, NA>(env, x, u, xn, rdummy);
 #pragma unroll
                         for (int i = 0; i < NS; ++i) {
-                            const float pre = obs_rescale(p.env, i, dn ? x[i] : xn[i]);   // what ClipObservation saw
-                            if ((EXACT || i < O) && !(pre >= p.env.obs_low[i] && pre <= p.env.obs_high[i])) Gin[i] = 0.f;
+                            const float pre = obs_rescale(env, i, dn ? x[i] : xn[i]);   // what ClipObservation saw
+                            if ((EXACT || i < O) && !(pre >= env.obs_low[i] && pre <= env.obs_high[i])) Gin[i] = 0.f;
                         }
                     }
-                    if (p.env.scale_obs) {   // d(scaled next obs) / d(next obs) = scale
+                    if (env.scale_obs) {   // d(scaled next obs) / d(next obs) = scale
 #pragma unroll
                         for (int i = 0; i < NS; ++i)
-                            if (EXACT || i < O) Gin[i] *= p.env.obs_scale[i];
+                            if (EXACT || i < O) Gin[i] *= env.obs_scale[i];
                     }
                     float gxn[GOPS_MAX_LQ_STATE];
 #pragma unroll
                     for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { gxn[i] = dn ? 0.f : Gin[i]; gx[i] = dn ? Gin[i] : 0.f; }
-                    lq_backward<NS, NA>(p.env, x, u, gxn, g_rm, gx, gu);
+                    lq_backward<NS, NA>(env, x, u, gxn, g_rm, gx, gu);
 #pragma unroll
                     for (int i = 0; i < NS; ++i)
-                        if (EXACT || i < O) G[m * ldx + i] = p.env.scale_obs ? gx[i] / p.env.obs_scale[i] : gx[i];   // d(obs / scale - shift) / d(obs)
+                        if (EXACT || i < O) G[m * ldx + i] = env.scale_obs ? gx[i] / env.obs_scale[i] : gx[i];   // d(obs / scale - shift) / d(obs)
 #pragma unroll
                     for (int a = 0; a < GOPS_MAX_ACT; ++a)
                         s_gy[m * 4 + a] = (a < NA && (EXACT || a < A))
-                                              ? (p.open_loop == 2 ? gu[a] : wrap_action_bwd(p.env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a]))
+                                              ? (p.open_loop == 2 ? gu[a] : wrap_action_bwd(env, a, abar[a], gu[a]) * sc[a] * (1.f - th[a] * th[a]))
                                               : 0.f;
                 };
                 if (O == 4 && A == 2) lq_adjoint.template operator()<4, 2>();
@@ -1473,7 +1485,7 @@ bool ssb_eligible(const RolloutParams& p) {
     if (!p.ss) return false;
     if (p.vflags & GOPS_VF_NO_STREAMED_SPLIT_BWD) return false;
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
-    return rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false, true) <= 80 * 1024;
+    return rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false, true) + (env_in_lds(p.env.kind, true) ? 4 * ENV_LDS_FLOATS : 0) <= 80 * 1024;
 }
 
 #define LAUNCH_BWD(ENV, A, B)                                                                            \
@@ -1522,7 +1534,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
         return hipGetLastError();
     }
     if (p.ssb && !p.ext && !p.open_loop && q.ext_delta == nullptr) {   // streamed-split sweep (gops_mlp_backward's hidden-stack deltas: the fp32 sweep)
-        const size_t lds_ss = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false, true);
+        const size_t lds_ss = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false, true) + (env_in_lds(p.env.kind, true) ? 4 * ENV_LDS_FLOATS : 0);
         const dim3 grid_ss(std::min<int>((p.B + TB - 1) / TB, ssb_grid_limit()));   // two workgroups per CU walk the tiles grid-stride
 #define LAUNCH_BWD_SS(ENV)                                                                                                                  \
     do {                                                                                                                                    \

@@ -369,9 +369,21 @@ __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetD
 // SS: streamed-split forward (ss_net_forward): plane-split MFMAs with all weight planes streamed from L2, two workgroups per CU
 template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false, bool GEN = false, bool SPLIT = false, bool MULTI = false, bool SS = false>
 __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 0) ? 3 : 1))) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_raw[];
     const RolloutParams& p = *pp;   // parameters live in device memory: uniform scalar loads
     const int tid = threadIdx.x;
+    // pyth_lq on the streamed-split forward: the env description in front of everything else in LDS (common.h: env_in_lds)
+    constexpr bool ENVLDS = env_in_lds(ENV, SS);
+    float* smem = smem_raw + (ENVLDS ? ENV_LDS_FLOATS : 0);
+    const GopsEnv* env_ptr;
+    if constexpr (ENVLDS) {
+        for (int idx = tid; idx < (int)(sizeof(GopsEnv) / 4); idx += NTHREADS) smem_raw[idx] = gptr(reinterpret_cast<const float*>(&p.env))[idx];
+        env_ptr = reinterpret_cast<const GopsEnv*>(smem_raw);
+        __syncthreads();
+    } else {
+        env_ptr = &p.env;
+    }
+    const GopsEnv& env = *env_ptr;
     // SPLIT kernels are launched with at most one workgroup per CU and walk tiles tile, tile + gridDim.x, ... with their
     // weights resident; every other variant has one tile per workgroup (the tile loop below runs once)
     int tile = blockIdx.x;
@@ -589,28 +601,28 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                     constexpr bool EXACT = NS < GOPS_MAX_LQ_STATE;   // the dimensions ARE (NS, NA): no run-time guards
                     float x[GOPS_MAX_LQ_STATE], xn[GOPS_MAX_LQ_STATE], u[GOPS_MAX_ACT];
 #pragma unroll
-                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { x[i] = (i < NS && (EXACT || i < O)) ? obs_unscale(p.env, i, xs[m * ldx + i]) : 0.f; xn[i] = 0.f; }
+                    for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i) { x[i] = (i < NS && (EXACT || i < O)) ? obs_unscale(env, i, xs[m * ldx + i]) : 0.f; xn[i] = 0.f; }
 #pragma unroll
                     for (int j = 0; j < GOPS_MAX_ACT; ++j) u[j] = (j < NA && (EXACT || j < A)) ? s_act[m * 4 + j] : 0.f;
                     // MaskAtDone freezes the (unscaled) observation; ScaleObservation rescales, ClipObservation clips the result
                     const bool frozen = s_done[m] != 0.f;
-                    const int nrep = GEN ? p.env.repeat_num : 1;   // ActionRepeat: sub-steps with the initial done flag
+                    const int nrep = GEN ? env.repeat_num : 1;   // ActionRepeat: sub-steps with the initial done flag
                     float rs = 0.f;
                     for (int rep = 0; rep < nrep; ++rep) {
                         if (rep > 0 && !frozen) {
 #pragma unroll
                             for (int i = 0; i < NS; ++i) x[i] = xn[i];
                         }
-                        lq_forward<NS, NA>(p.env, x, u, xn, r);
-                        rs = (GEN && !p.env.repeat_last_reward) ? rs + r : r;
+                        lq_forward<NS, NA>(env, x, u, xn, r);
+                        rs = (GEN && !env.repeat_last_reward) ? rs + r : r;
                     }
                     r = rs;
-                    if (!frozen || p.env.clip_obs || p.env.scale_obs) {
+                    if (!frozen || env.clip_obs || env.scale_obs) {
 #pragma unroll
                         for (int i = 0; i < NS; ++i)
                             if (EXACT || i < O) {
-                                const float v = obs_rescale(p.env, i, sel_reg(frozen, x[i], xn[i]));
-                                xs[m * ldx + i] = p.env.clip_obs ? clampf(v, p.env.obs_low[i], p.env.obs_high[i]) : v;
+                                const float v = obs_rescale(env, i, sel_reg(frozen, x[i], xn[i]));
+                                xs[m * ldx + i] = env.clip_obs ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
                             }
                     }
                 };
@@ -1094,7 +1106,7 @@ bool ss_eligible(const RolloutParams& p) {
     if (!net_ok(p.pol) || p.ldh != 260 || (p.tail && !net_ok(p.val))) return false;
     const int k0 = 32 * std::max(ss_kc0(p.pol.kp32[0]), p.tail ? ss_kc0(p.val.kp32[0]) : 0);
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0;
-    return rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, k0, true) <= 80 * 1024;   // two workgroups per CU
+    return rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, k0, true) + (env_in_lds(p.env.kind, true) ? 4 * ENV_LDS_FLOATS : 0) <= 80 * 1024;   // two workgroups per CU
 }
 
 // Picks the register-stationary variant when the policy is (kp0 in {16,48,128}) -> 256 -> 256 ...,
@@ -1182,7 +1194,8 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
     }
     if (p.ss) {   // streamed-split forward
         const int k0 = 32 * std::max(p.ssp.kc[0], p.tail ? p.ssv.kc[0] : 0);
-        const size_t lds_ss = rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0, false, k0, true);
+        const size_t lds_ss = rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0, false, k0, true) +
+                              (env_in_lds(p.env.kind, true) ? 4 * ENV_LDS_FLOATS : 0);
 #define LAUNCH_FWD_SS(ENV)                                                                                                        \
     do {                                                                                                                          \
         if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, true, false, false, false, false, true>, grid, block, lds_ss, stream, dp);   \

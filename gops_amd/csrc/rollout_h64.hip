@@ -29,10 +29,7 @@
 #ifndef H64_STEP_MAJOR
 #define H64_STEP_MAJOR 1
 #endif
-// The env description is copied to LDS once per workgroup and the env phases read it there (broadcast ds_reads with immediate
-// offsets): read through the kernel-argument pointer its ~100 scalars per step did not fit the SGPR file - the sweep's env
-// phase held 325 v_readlane / 45 v_writelane SGPR spills and 96 single s_loads (8.3 k of a 34 k-cycle step on ONE wave).
-#define ENV_LDS_FLOATS ((int)((sizeof(GopsEnv) + 15) / 16) * 4)
+// (the env description is copied to LDS once per workgroup and the env phases read it there: common.h ENV_LDS_FLOATS)
 #define H64_LD 264   // halfs per row of the hidden tile: 256 + 8 (16-byte row skew, conflict-free ds_read_b128)
 
 // acc[jt][rg] (n-tile jt of quad q, 16-row group rg) += W_quad * act^T over kch chunks of 32 inputs

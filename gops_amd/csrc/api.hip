@@ -360,20 +360,21 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
                 sn.inv[j] = c.take(d.dims[j + 1] >> 4);
             }
         }
-        // the sweep of the same launch on the streamed-split kernel too: transposed planes (n-tiles over a layer's inputs)
-        p.ssb = (p.need_grad && ssb_eligible(p)) ? 1 : 0;
-        if (p.ssb) {
-            for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
-                const MlpDev& d = m ? p.val : p.pol;
-                SplitNetDev& sn = m ? p.ssvt : p.sspt;
-                for (int j = 0; j < d.nl - 1; ++j) {
-                    const int nin = (j == 0) ? d.kp[0] : d.dims[j];   // (16-padded) inputs of the layer = columns of the transposed operand
-                    sn.kc[j] = d.dims[j + 1] >> 5;
-                    const size_t elems = (size_t)nin * d.dims[j + 1];
-                    sn.w1[j] = reinterpret_cast<const bf16x8*>(c.take((elems + 1) / 2));
-                    sn.r[j] = reinterpret_cast<const f16x8*>(c.take((elems + 1) / 2));
-                    sn.inv[j] = c.take(nin >> 4);
-                }
+    }
+    // the sweep of the same launch on the streamed-split kernel too: transposed planes (n-tiles over a layer's inputs) - also behind
+    // an exact-fp32 forward (relu / selu nets with a tail value net: ss_sweep_only)
+    p.ssb = (p.need_grad && ssb_eligible(p)) ? 1 : 0;
+    if (p.ssb) {
+        for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
+            const MlpDev& d = m ? p.val : p.pol;
+            SplitNetDev& sn = m ? p.ssvt : p.sspt;
+            for (int j = 0; j < d.nl - 1; ++j) {
+                const int nin = (j == 0) ? d.kp[0] : d.dims[j];   // (16-padded) inputs of the layer = columns of the transposed operand
+                sn.kc[j] = d.dims[j + 1] >> 5;
+                const size_t elems = (size_t)nin * d.dims[j + 1];
+                sn.w1[j] = reinterpret_cast<const bf16x8*>(c.take((elems + 1) / 2));
+                sn.r[j] = reinterpret_cast<const f16x8*>(c.take((elems + 1) / 2));
+                sn.inv[j] = c.take(nin >> 4);
             }
         }
     }

@@ -106,12 +106,12 @@ __device__ __forceinline__ void pack_split_tile(const float* __restrict__ W, int
     if (tid == 0) inv[nt] = 1.f / s_r;
 }
 __host__ __device__ inline int split_pack_blocks(const RolloutParams& p) {
-    if (p.ss) {   // streamed-split forward: one block per n-tile of every hidden layer of the policy (and the tail value net)
+    if (p.ss || p.ssb) {   // streamed-split forward: one block per n-tile of every hidden layer of the policy (and the tail value net)
         int nb = 0;
         for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
             const MlpDev& d = m ? p.val : p.pol;
             for (int j = 0; j < d.nl - 1; ++j) {
-                nb += d.dims[j + 1] >> 4;
+                if (p.ss) nb += d.dims[j + 1] >> 4;
                 if (p.ssb) nb += ((j == 0) ? d.kp[0] : d.dims[j]) >> 4;   // transposed planes of the sweep
             }
         }
@@ -308,14 +308,14 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
             b -= nb;
         }
     }
-    if (p.ss) {   // plane-split operands of the streamed-split forward kernels
+    if (p.ss || p.ssb) {   // plane-split operands of the streamed-split forward kernels (p.ss) and of the streamed-split sweep (p.ssb)
         auto us = [](const bf16x8* q) { return const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(q)); };
         auto hf = [](const f16x8* q) { return const_cast<_Float16*>(reinterpret_cast<const _Float16*>(q)); };
         for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
             const MlpDev& d = m ? p.val : p.pol;
             const SplitNetDev& sn = m ? p.ssv : p.ssp;
             for (int j = 0; j < d.nl - 1; ++j) {
-                const int nt = d.dims[j + 1] >> 4;
+                const int nt = p.ss ? d.dims[j + 1] >> 4 : 0;
                 if (b < nt) {   // layer 0: natural input order; deeper layers read the plane image of the previous activation
                     pack_split_tile(d.w[j], d.dims[j + 1], d.dims[j], false, j > 0, sn.kc[j], b, us(sn.w1[j]), hf(sn.r[j]), const_cast<float*>(sn.inv[j]));
                     return;

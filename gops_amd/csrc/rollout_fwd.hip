@@ -1091,11 +1091,10 @@ bool split_eligible(const RolloutParams& p) {
 // inputs, fp32, closed loop, every env model - the launches the register-stationary kernels do not take (three
 // hidden layers, a tail value net with more tiles than CUs).  The backward sweep of such a launch stays on the fp32-MFMA
 // kernels: both forward variants write the same feature-major stash.  GOPS_SS=0 switches it off.
-bool ss_eligible(const RolloutParams& p) {
+static bool ss_shape_ok(const RolloutParams& p) {   // everything but the arithmetic question (kinked_with_tail) and the forward's own switch
     if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
     // (value / MLP batches, GOPS_ENV_NONE: one step - half the MFMA time of the fp32 kernels; GOPS_SS_VALUE=0 keeps those)
     if (p.env.kind == GOPS_ENV_NONE && (p.vflags & GOPS_VF_NO_STREAMED_SPLIT_VALUE)) return false;
-    if (kinked_with_tail(p)) return false;
     if (p.vflags & (GOPS_VF_NO_STREAMED_SPLIT_FWD | GOPS_VF_STREAMED_FP32 | GOPS_VF_STREAM_LAYER0)) return false;
     auto net_ok = [](const MlpDev& M) {
         if (M.nl < 3 || M.kp32[0] > 256) return false;
@@ -1108,6 +1107,11 @@ bool ss_eligible(const RolloutParams& p) {
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0;
     return rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, k0, true) + (env_in_lds(p.env.kind, true) ? 4 * ENV_LDS_FLOATS : 0) <= 80 * 1024;   // two workgroups per CU
 }
+bool ss_eligible(const RolloutParams& p) { return ss_shape_ok(p) && !kinked_with_tail(p); }
+// relu / selu with a tail value net: the FORWARD keeps exact fp32 products (a pre-activation that changes sign under the 2^-19
+// weight representation moves dV/d(obs) by a finite amount), but the SWEEP is linear once the forward has fixed the activation
+// pattern (act' comes from the stash): it may run plane-split like any other - cfg3.
+bool ss_sweep_only(const RolloutParams& p) { return !p.sp.on && ss_shape_ok(p) && kinked_with_tail(p); }
 
 // Picks the register-stationary variant when the policy is (kp0 in {16,48,128}) -> 256 -> 256 ...,
 // else the fully streamed kernel.  sk[0] / sk[1] receive the chosen chunk counts (0 = streamed).

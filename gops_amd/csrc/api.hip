@@ -396,6 +396,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         }
         p.st.dy = c.take((size_t)S * 4);
         p.st.env = c.take((size_t)S * ENV_STASH);
+        if (p.sp.on && e.kind == GOPS_ENV_IDPENDULUM) p.st.idp = c.take((size_t)S * IDP_PARK);
         if (p.tail) {
             for (int j = 1; j < p.val.nl; ++j) {
                 const size_t rows = (size_t)((p.B + tile_rows - 1) / tile_rows) * tile_rows;   // whole tiles (FM stash tiles are written whole)

@@ -15,6 +15,10 @@
 #define DW_SC_HOST 32     // samples per staged chunk of the dW GEMM (== DW_SC in aux_kernels.hip)
 #define DW_OUT_SPLITS 1024  // sample splits of the output-layer weight gradient
 #define MOB_OBS 13        // pyth_mobilerobot: observation = state columns
+// LDS "reference points" (x 4 TB floats) of the idpendulum sweeps: one [TB][5][24] parking, or - plane-split stationary sweep -
+// the two parity halves of the staged [TB][IDP_PARK] parking the forward wrote
+#define IDP_POINTS(split) ((split) ? 64 : 30)
+#define IDP_PARK 128      // floats of the idpendulum sub-step parking per (t, b): [k][24] (state, sin / cos, M^-1, qdd), [120..125] final state
 #define ENV_STASH 16      // floats of per-(t,b) env stash: [0..3] abar, [4] done_t, [5..10] state_t, [12..15] veh3dof: sin, cos of the heading before / after the step
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -115,6 +119,9 @@ struct StashDev {
     // GOPS_DTYPE_F16: x / h / z / d / tail_h / tail_z are ROW-major [S][width] _Float16 (x rows are kp32[0] wide, z
     // holds act'(z) instead of z), and the first 8 observation columns are kept in fp32 for the env adjoints:
     float* xf;                        // [S][8]
+    // pyth_idpendulum on the plane-split stationary kernels: the forward parks the intermediates of the five Euler sub-steps
+    // (IDP_PARK floats per row: 5 x 24 + the state after the step) so that the sweep does not recompute them
+    float* idp;                       // [S][IDP_PARK] or null
 };
 
 struct RolloutParams {

@@ -553,7 +553,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
     // One-workgroup-per-CU variants: LDS copies of this step's H_2 / H_1 (Z for GELU) tiles, [2][TB][256]
     constexpr bool STAGE = (SK1 > 0);   // (those variants are only selected for obs-256-256-act policies)
     float* s_stage = smem + bwd_lds_floats(ldx, ldh, REF ? p.env.pre_horizon + 1 + p.H
-                                                                             : (ENV == GOPS_ENV_IDPENDULUM ? 30 : 0), F16, SPLIT, SSB);
+                                                                             : (ENV == GOPS_ENV_IDPENDULUM ? IDP_POINTS(SPLIT) : 0), F16, SPLIT, SSB);
 
     const int ld16 = (p.ldh - 4) + 8;                 // F16: leading dimension (halfs) of the delta tiles
     // fp32 observation column i of row m of the stash tile at row0 (the env adjoints read the first few):
@@ -614,6 +614,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
             async_copy16_to_lds(p.st.env + r0 * ENV_STASH + 4 * ln, dst + STAGE_TILES);
         if (wv == 1 && ln < 2 * TB)   // first 8 observation columns: 8 x 64 B, contiguous in the FM tile -> st_x[i * 16 + m]
             async_copy16_to_lds(p.st.x + r0 * kp0 + 4 * ln, dst + STAGE_TILES + TB * ENV_STASH);
+        if constexpr (SPLIT && ENV == GOPS_ENV_IDPENDULUM) {   // the forward's sub-step parking of the tile: 16 x 512 B, contiguous
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+                async_copy16_to_lds(p.st.idp + r0 * IDP_PARK + (wv * 2 + q2) * 256 + 4 * ln, s_idp + (tt & 1) * (TB * IDP_PARK) + (wv * 2 + q2) * 256);
+        }
     };
     const int ntiles = (p.B + TB - 1) / TB;
     SsOutGrad og = {};   // (SSB with the fused output-layer gradient; otherwise unused)
@@ -1031,27 +1036,37 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
 #pragma unroll
                         for (int i = 0; i < 6; ++i) Gin[i] *= p.env.obs_scale[i];
                     }
-                    float* park = s_idp + m * (5 * 24);
-                    float sc_[6], sn_[6];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) sc_[i] = x[i];
+                    float sc_[6];
                     const float a = u[0], force = 500.f * a;
-                    IdpSub w;
+                    const float* park;   // [5][24]: sub-step k's input state, sin / cos, M^-1, qdd
+                    if constexpr (SPLIT && STAGE) {
+                        // parked by the forward (p.st.idp), staged one step ahead: nothing is recomputed
+                        park = s_idp + (t & 1) * (TB * IDP_PARK) + m * IDP_PARK;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) sc_[i] = park[120 + i];   // the state after the step
+                    } else {
+                        float* parkw = s_idp + m * (5 * 24);
+                        park = parkw;
+                        float sn_[6];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) sc_[i] = x[i];
+                        IdpSub w;
 #pragma unroll 1
-                    for (int k = 0; k < 5; ++k) {
-                        if (k == 0) idp_substep<true>(IC, sc_, force, 0.002f, sn_, w);
-                        else idp_substep<false>(IC, sc_, force, 0.002f, sn_, w);   // w.s1 .. w.c2 advanced at the end of the last trip
-                        float* pk = park + k * 24;
+                        for (int k = 0; k < 5; ++k) {
+                            if (k == 0) idp_substep<true>(IC, sc_, force, 0.002f, sn_, w);
+                            else idp_substep<false>(IC, sc_, force, 0.002f, sn_, w);   // w.s1 .. w.c2 advanced at the end of the last trip
+                            float* pk = parkw + k * 24;
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) pk[i] = sc_[i];
-                        pk[6] = w.s1; pk[7] = w.c1; pk[8] = w.s2; pk[9] = w.c2; pk[10] = w.s12; pk[11] = w.c12;
+                            for (int i = 0; i < 6; ++i) pk[i] = sc_[i];
+                            pk[6] = w.s1; pk[7] = w.c1; pk[8] = w.s2; pk[9] = w.c2; pk[10] = w.s12; pk[11] = w.c12;
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) pk[12 + i] = w.inv[i];
+                            for (int i = 0; i < 6; ++i) pk[12 + i] = w.inv[i];
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) pk[18 + i] = w.qdd[i];
-                        idp_advance_trig(sc_, 0.002f, w, w);
+                            for (int i = 0; i < 3; ++i) pk[18 + i] = w.qdd[i];
+                            idp_advance_trig(sc_, 0.002f, w, w);
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) sc_[i] = sn_[i];
+                            for (int i = 0; i < 6; ++i) sc_[i] = sn_[i];
+                        }
                     }
                     float g[6];
 #pragma unroll
@@ -1559,7 +1574,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
         return hipGetLastError();
     }
     if (p.sp.on) {   // plane-split stationary sweep: PT0 = n-tiles of g_x per wave
-        lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, true);
+        lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, p.env.kind == GOPS_ENV_IDPENDULUM ? IDP_POINTS(true) : ref_pts, false, true);
 #define LAUNCH_BWD_SPLIT(ENV, PT)                                                                                                  \
     do {                                                                                                                          \
         if (multi) {                                                                                                              \

@@ -675,18 +675,35 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                 const float u = 500.f * a;
                 const int nrep = GEN ? p.env.repeat_num : 1;   // (finished rows advance too: nothing of them is written)
                 float rs = 0.f;
+                // the sweep's parking of the sub-steps (plane-split stationary kernels: p.st.idp), written from the registers that
+                // hold them here instead of being recomputed there (the recomputation - libm sincosf, five sub-steps - was ~45 %
+                // of the sweep's env phase, which is half of a sweep step at cfg2)
+                GLOBAL_AS f32x4* parkg = (p.need_grad && p.st.idp != nullptr) ? gptr(reinterpret_cast<f32x4*>(p.st.idp + (row0 + m) * IDP_PARK)) : nullptr;
+                auto park_store = [&](int k, const IdpSub& w) {
+                    if (parkg == nullptr) return;
+                    GLOBAL_AS f32x4* d = parkg + k * 6;
+                    d[0] = f32x4{s[0], s[1], s[2], s[3]};
+                    d[1] = f32x4{s[4], s[5], w.s1, w.c1};
+                    d[2] = f32x4{w.s2, w.c2, w.s12, w.c12};
+                    d[3] = f32x4{w.inv[0], w.inv[1], w.inv[2], w.inv[3]};
+                    d[4] = f32x4{w.inv[4], w.inv[5], w.qdd[0], w.qdd[1]};
+                    d[5] = f32x4{w.qdd[2], 0.f, 0.f, 0.f};
+                };
                 for (int rep = 0; rep < nrep; ++rep) {
                     IdpSub w;
                     idp_substep<true>(IC, s, u, 0.002f, sn, w);
+                    park_store(0, w);
 #pragma unroll 1
                     for (int k = 1; k < 5; ++k) {
                         idp_advance_trig(s, 0.002f, w, w);   // sin / cos of the new angles from the old ones (rotation by tau * theta_dot)
 #pragma unroll
                         for (int i = 0; i < 6; ++i) s[i] = sn[i];
                         idp_substep<false>(IC, s, u, 0.002f, sn, w);
+                        park_store(k, w);
                     }
 #pragma unroll
                     for (int i = 0; i < 6; ++i) s[i] = sn[i];
+                    if (parkg != nullptr) { parkg[30] = f32x4{s[0], s[1], s[2], s[3]}; parkg[31] = f32x4{s[4], s[5], 0.f, 0.f}; }
                     r = idp_reward(s, a);
                     rs = (GEN && !p.env.repeat_last_reward) ? rs + r : r;
                     done_m = idp_done(IC, s);
@@ -1081,7 +1098,7 @@ bool split_eligible(const RolloutParams& p) {
     // their three workgroups per CU) - those launches stay on the streamed kernels.
     if (p.tail && (p.B + TB - 1) / TB > device_cus() && !(p.vflags & GOPS_VF_SPLIT_TAIL_MULTI)) return false;
     if (p.vflags & (GOPS_VF_NO_STATIONARY_SPLIT | GOPS_VF_STREAMED_FP32 | GOPS_VF_STREAM_LAYER0)) return false;
-    const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
+    const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? IDP_POINTS(true) : 0);
     if (rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? ref_pts : 0, false, M.kp32[0]) > 160 * 1024) return false;
     if (rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, true) > 160 * 1024) return false;
     return true;

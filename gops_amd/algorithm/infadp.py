@@ -68,6 +68,8 @@ class INFADP(AlgorithmBase):
         self.tb_info = dict()
         self._cache = {}
         self._graphs = {}
+        self._polyak = {}   # net name -> hb.PolyakUpdater
+        self._bufs = {}     # persistent device scratch: loss gradient, loss scalars (read them before the next update of the same mode)
 
     @property
     def adjustable_parameters(self):
@@ -126,11 +128,17 @@ class INFADP(AlgorithmBase):
         for net_name in update_list:
             self.networks.optimizer_dict[net_name].step()
         with torch.no_grad():
-            for net_name in update_list:
+            for net_name in update_list:   # Polyak averaging (reference :124-133), all tensors of the network in one launch
                 online = list(self.networks.net_dict[net_name].parameters())
                 target = list(self.networks.target_net_dict[net_name].parameters())
-                torch._foreach_mul_(target, 1 - tau)
-                torch._foreach_add_(target, online, alpha=tau)
+                if not online[0].is_cuda:
+                    torch._foreach_mul_(target, 1 - tau)
+                    torch._foreach_add_(target, online, alpha=tau)
+                    continue
+                pk = self._polyak.get(net_name)
+                if pk is None or not pk.matches(target, online):
+                    pk = self._polyak[net_name] = hb.PolyakUpdater(target, online)
+                pk.step(tau)
 
     # ------------------------------------------------------------------------------------------
     def _rollout_for(self, batch: int, device, need_grad: bool) -> hb.Rollout:
@@ -169,16 +177,30 @@ class INFADP(AlgorithmBase):
             backup = self._rollout_for(B, device, need_grad=False).forward(batch)["v_pi"]
             vn = self._value_for(B, device)
             v = vn.forward(batch["obs"])
-            diff = v - backup
+            # loss_v, mean V and d(loss_v)/dV = (2 / B)(V - backup) in one launch (they were six torch passes)
+            gdiff = self._scratch("gdiff", B, device)
+            scalars = self._loss_stats("v", device).value_loss(v, backup, gdiff)
             gw, gb = grad_buffers(self.networks.v)
-            vn.backward(batch["obs"], (2.0 / B) * diff, gw, gb)
-            return torch.stack(((diff * diff).mean(), v.mean()))
+            vn.backward(batch["obs"], gdiff, gw, gb)
+            return scalars
         # PIM: loss = -mean(sum_t gamma^t r_t + (~d) gamma^n V_target(o_n)), grads into the policy
         ro = self._rollout_for(B, device, need_grad=True)
         v_pi = ro.forward(batch)["v_pi"]
         gw, gb = grad_buffers(self.networks.policy)
         ro.backward(self._grad_v(B, device), gw, gb)
-        return (-v_pi.mean()).reshape(1)
+        return self._loss_stats("policy", device).mean_loss(v_pi, -1.0)[:1]
+
+    def _scratch(self, name, n, device):
+        t = self._bufs.get(name)
+        if t is None or t.numel() != n or t.device != device:
+            t = self._bufs[name] = torch.empty(n, dtype=torch.float32, device=device)
+        return t
+
+    def _loss_stats(self, mode, device) -> hb.LossStats:
+        st = self._bufs.get(("stats", mode))
+        if st is None or st.buf.device != device:
+            st = self._bufs[("stats", mode)] = hb.LossStats(device)
+        return st
 
     def _grad_v(self, B, device):
         gv = getattr(self, "_gv", None)

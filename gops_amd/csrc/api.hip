@@ -40,6 +40,8 @@ hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, floa
 hipError_t launch_env_constraint(const GopsEnv& env, int B, const GopsStepIO& io, hipStream_t s);
 bool ss_eligible(const RolloutParams& p);   // rollout_fwd.hip
 bool ssb_eligible(const RolloutParams& p);  // rollout_bwd.hip
+hipError_t launch_polyak(const GopsAdamTensors& T, float omt, float tau, hipStream_t s);
+hipError_t launch_batch_loss(const float* a, const float* b, int n, float gsc, float sc0, float* grad, float* stats, hipStream_t s);
 hipError_t launch_adam(const GopsAdamTensors& T, GopsAdamState* st, double beta1, double beta2, float eps,
                        hipStream_t s);
 
@@ -927,6 +929,23 @@ int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, dou
         if (!tensors->param[i] || !tensors->grad[i] || !tensors->exp_avg[i] || !tensors->exp_avg_sq[i] ||
             tensors->numel[i] < 1) return GOPS_ERR_BAD_ARG;
     return (int)launch_adam(*tensors, state_dev, beta1, beta2, (float)eps, static_cast<hipStream_t>(stream));
+}
+
+int gops_polyak_update(const GopsAdamTensors* tensors, double tau, void* stream) {
+    if (!tensors || tensors->n < 1 || tensors->n > GOPS_ADAM_MAX_TENSORS) return GOPS_ERR_BAD_ARG;
+    for (int i = 0; i < tensors->n; ++i)
+        if (!tensors->param[i] || !tensors->grad[i] || tensors->numel[i] < 1) return GOPS_ERR_BAD_ARG;
+    return (int)launch_polyak(*tensors, (float)(1.0 - tau), (float)tau, static_cast<hipStream_t>(stream));
+}
+
+int gops_value_loss(const float* v, const float* target, int32_t n, float* grad, float* stats, void* stream) {
+    if (!v || !target || !stats || n < 1) return GOPS_ERR_BAD_ARG;
+    return (int)launch_batch_loss(v, target, n, (float)(2.0 / n), 1.f, grad, stats, static_cast<hipStream_t>(stream));
+}
+
+int gops_mean_loss(const float* x, int32_t n, double scale, float* stats, void* stream) {
+    if (!x || !stats || n < 1) return GOPS_ERR_BAD_ARG;
+    return (int)launch_batch_loss(x, nullptr, n, 0.f, (float)scale, nullptr, stats, static_cast<hipStream_t>(stream));
 }
 
 void gops_profile_enable(int32_t on) {

@@ -1636,6 +1636,77 @@ __global__ __launch_bounds__(256) void adam_kernel(const GopsAdamTensors T, Gops
     }
 }
 
+// Polyak averaging of target networks (gops/algorithm/infadp.py:124-133: p_targ.mul_(1 - tau); p_targ.add_(tau * p)), all
+// tensors of a network in ONE launch; the same two roundings per element as the two torch passes it replaces.
+// Table: param[] = target tensors, grad[] = online tensors (GopsAdamTensors reused; the moment slots are ignored).
+__global__ __launch_bounds__(256) void polyak_kernel(const GopsAdamTensors T, float omt, float tau) {
+    const int ti = blockIdx.y;
+    const long long n = T.numel[ti];
+    float* __restrict__ t = T.param[ti];
+    const float* __restrict__ o = T.grad[ti];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        t[i] = rn_add(rn_mul(t[i], omt), rn_mul(tau, o[i]));
+}
+hipError_t launch_polyak(const GopsAdamTensors& T, float omt, float tau, hipStream_t s) {
+    long long nmax = 1;
+    for (int i = 0; i < T.n; ++i) nmax = std::max<long long>(nmax, T.numel[i]);
+    const int bx = (int)std::min<long long>((nmax + 255) / 256, 64);
+    hipLaunchKernelGGL(polyak_kernel, dim3(bx, T.n), dim3(256), 0, s, T, omt, tau);
+    return hipGetLastError();
+}
+
+// Loss scalars of a batch in ONE launch (they were three torch reductions + three elementwise passes per INFADP update pair:
+// ~10 % of a cfg5 fp16 update).  a, b: [n]; grad (nullable) <- gsc * (a - b);  stats[0] <- sum((a - b)^2) / n (b null: sc0 * sum(a) / n),
+// stats[1] <- sum(a) / n.  Blocks add up their elements in double in a fixed order and park the partial sums behind the two results
+// (stats[2 ..]: GOPS_LOSS_STATS_FLOATS floats in all, the last one a ticket that must be zero on entry and is left zero); the last block to
+// finish adds the partials in block order - deterministic.
+#define LOSS_BLOCKS 64
+__global__ __launch_bounds__(256) void batch_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float gsc, float sc0,
+                                                         float* __restrict__ grad, float* __restrict__ stats) {
+    __shared__ double red[2][256];
+    __shared__ bool last;
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LOSS_BLOCKS * 256) {
+        const float ai = a[i];
+        if (b != nullptr) {
+            const float d = ai - b[i];
+            if (grad != nullptr) grad[i] = gsc * d;
+            s0 += (double)(d * d);
+        } else {
+            s0 += (double)ai;
+        }
+        s1 += (double)ai;
+    }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
+        __syncthreads();
+    }
+    double* part = reinterpret_cast<double*>(stats + 2);               // [LOSS_BLOCKS][2]
+    unsigned* ticket = reinterpret_cast<unsigned*>(stats + 2 + 4 * LOSS_BLOCKS);
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = red[0][0];
+        part[2 * blockIdx.x + 1] = red[1][0];
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        double t0 = 0.0, t1 = 0.0;
+        const volatile double* vp = part;
+        for (unsigned k = 0; k < gridDim.x; ++k) { t0 += vp[2 * k]; t1 += vp[2 * k + 1]; }
+        stats[0] = (float)((b != nullptr ? 1.0 : (double)sc0) * t0 / (double)n);
+        stats[1] = (float)(t1 / (double)n);
+        *ticket = 0u;
+    }
+}
+hipError_t launch_batch_loss(const float* a, const float* b, int n, float gsc, float sc0, float* grad, float* stats, hipStream_t s) {
+    hipLaunchKernelGGL(batch_loss_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, s, a, b, n, gsc, sc0, grad, stats);
+    return hipGetLastError();
+}
+
 // Zero fill as a KERNEL on the caller's stream: inside a captured HIP graph a hipMemsetAsync becomes a memset node,
 // which was measured to race with the neighbouring kernel nodes on replay (non-reproducible gradients); a kernel node
 // is ordered like every other launch.

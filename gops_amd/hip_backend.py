@@ -172,6 +172,12 @@ def lib() -> C.CDLL:
         l.gops_adam_step.restype = C.c_int
         l.gops_adam_step.argtypes = [C.POINTER(GopsAdamTensors), C.c_void_p, C.c_double, C.c_double, C.c_double,
                                      C.c_void_p]
+        l.gops_polyak_update.restype = C.c_int
+        l.gops_polyak_update.argtypes = [C.POINTER(GopsAdamTensors), C.c_double, C.c_void_p]
+        l.gops_value_loss.restype = C.c_int
+        l.gops_value_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.gops_mean_loss.restype = C.c_int
+        l.gops_mean_loss.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]
         l.gops_rollout_backward_open_loop_adj.restype = C.c_int
         l.gops_rollout_backward_open_loop_adj.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn), C.c_void_p, C.c_void_p,
                                                           C.POINTER(GopsRolloutAdjoint), C.c_void_p, C.c_size_t, C.c_void_p]
@@ -190,7 +196,7 @@ EXPORTED_SYMBOLS = ("gops_hip_version", "gops_rollout_workspace_bytes", "gops_ro
                     "gops_value_forward", "gops_value_backward", "gops_mlp_workspace_bytes", "gops_mlp_forward",
                     "gops_mlp_backward", "gops_mlp_backward_x", "gops_adam_step", "gops_profile_enable",
                     "gops_profile_reset", "gops_profile_read", "gops_rollout_variant", "gops_rollout_backward_open_loop_adj",
-                    "gops_env_constraint")
+                    "gops_env_constraint", "gops_polyak_update", "gops_value_loss", "gops_mean_loss")
 
 _ERR = {-1: "GOPS_ERR_BAD_ARG", -2: "GOPS_ERR_UNSUPPORTED", -3: "GOPS_ERR_WORKSPACE"}
 
@@ -740,6 +746,56 @@ class HipAdam(torch.optim.Optimizer):
             for p in ps:
                 self.state[p]["step"] = int(self.state[p]["step"]) + 1
             dev["step"] += 1
+
+
+LOSS_STATS_FLOATS = 260   # include/gops_hip.h: GOPS_LOSS_STATS_FLOATS
+
+
+class LossStats:
+    """Device scalars of a batch in one launch (`gops_value_loss` / `gops_mean_loss`): `stats[0]`, `stats[1]` are the results,
+    the rest of the buffer is the kernels' scratch (zero before the first call, left zero by every call)."""
+
+    def __init__(self, device):
+        self.buf = torch.zeros(LOSS_STATS_FLOATS, dtype=torch.float32, device=device)
+
+    def value_loss(self, v: torch.Tensor, target: torch.Tensor, grad: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """-> [mean((v - target)^2), mean(v)]; `grad` <- (2 / n) (v - target) (gops/algorithm/infadp.py:172-173)."""
+        n = v.numel()
+        check(lib().gops_value_loss(_ptr(v), _ptr(target), n, _ptr(grad), self.buf.data_ptr(), _stream()), "gops_value_loss")
+        return self.buf[:2]
+
+    def mean_loss(self, x: torch.Tensor, scale: float = -1.0) -> torch.Tensor:
+        """-> [scale * mean(x), mean(x)] (`-v_pi.mean()`: infadp.py:213, fhadp.py:123)."""
+        check(lib().gops_mean_loss(_ptr(x), x.numel(), float(scale), self.buf.data_ptr(), _stream()), "gops_mean_loss")
+        return self.buf[:2]
+
+
+class PolyakUpdater:
+    """target <- (1 - tau) target + tau online for all tensors of a network in one launch (`gops_polyak_update`; chunks of
+    GOPS_ADAM_MAX_TENSORS), the same two roundings per element as the reference's `mul_` / `add_` passes (infadp.py:124-133)."""
+
+    def __init__(self, target_params, online_params):
+        tp, op = list(target_params), list(online_params)
+        assert len(tp) == len(op)
+        self._keep = (tp, op)
+        self._sig = tuple((t.data_ptr(), o.data_ptr(), t.numel()) for t, o in zip(tp, op))
+        self.tables = []
+        for c0 in range(0, len(tp), ADAM_MAX):
+            t = GopsAdamTensors()
+            chunk = list(zip(tp[c0:c0 + ADAM_MAX], op[c0:c0 + ADAM_MAX]))
+            t.n = len(chunk)
+            for i, (a, b) in enumerate(chunk):
+                assert a.shape == b.shape
+                t.numel[i] = a.numel()
+                t.param[i], t.grad[i] = _ptr(a.data), _ptr(b.data)
+            self.tables.append(t)
+
+    def matches(self, target_params, online_params) -> bool:
+        return self._sig == tuple((t.data_ptr(), o.data_ptr(), t.numel()) for t, o in zip(target_params, online_params))
+
+    def step(self, tau: float):
+        for t in self.tables:
+            check(lib().gops_polyak_update(C.byref(t), float(tau), _stream()), "gops_polyak_update")
 
 
 def profile_enable(on: bool):

@@ -45,7 +45,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GOPS_HIP_ABI_VERSION 10
+#define GOPS_HIP_ABI_VERSION 11
 
 #define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
 #define GOPS_MAX_ACT 4      /* action dimensions */
@@ -412,6 +412,23 @@ typedef struct GopsAdamState {   /* 48 bytes of device memory */
 } GopsAdamState;
 int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, double beta1, double beta2,
                    double eps, void* stream);
+
+/* ABI v11.  Polyak averaging of a target network, every tensor in one launch - replaces the two passes of
+ * gops/algorithm/infadp.py:124-133 (`p_targ.mul_(1 - tau); p_targ.add_(tau * p)`), same roundings per element.
+ * Table: param[i] = target tensor i (updated in place), grad[i] = online tensor i, numel[i]; the moment slots are ignored. */
+int gops_polyak_update(const GopsAdamTensors* tensors, double tau, void* stream);
+
+/* ABI v11.  The scalars (and the loss gradient) the algorithms form from a batch of values, one launch, no host sync:
+ *   gops_value_loss:  stats[0] = mean((v - target)^2), stats[1] = mean(v), grad[i] = (2 / n) (v[i] - target[i]) (grad may be NULL)
+ *                     - `loss_v = ((v - backup) ** 2).mean()` and `torch.mean(v)` of gops/algorithm/infadp.py:172-173 and
+ *                     d(loss_v) / d(v);
+ *   gops_mean_loss:   stats[0] = scale * mean(x), stats[1] = mean(x) - `-v_pi.mean()` (infadp.py:213, fhadp.py:123) with scale = -1.
+ * `stats` is 8-byte aligned device memory of GOPS_LOSS_STATS_FLOATS floats, ALL ZERO before the first call: behind the two
+ * results it holds the blocks' partial sums and a ticket counter that every call leaves zero again; sums are formed in double
+ * in a fixed order (run-to-run reproducible). */
+#define GOPS_LOSS_STATS_FLOATS 260
+int gops_value_loss(const float* v, const float* target, int32_t n, float* grad, float* stats, void* stream);
+int gops_mean_loss(const float* x, int32_t n, double scale, float* stats, void* stream);
 
 /* Which kernels a rollout description runs on this device (ABI v8; for benchmarks / profiles, no launch):
  * bit 0 (GOPS_VARIANT_SPLIT): the register-stationary kernels with plane-split contractions - hidden-layer weights as

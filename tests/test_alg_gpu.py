@@ -1017,3 +1017,38 @@ def test_mpg_gradient_is_the_mean_over_batch_shards():
     for k in whole:
         for i, g in enumerate(whole[k]):
             assert rel_l2(0.5 * (lo[k][i] + hi[k][i]).cpu(), g.cpu()) < 1e-4, (k, i, rel_l2(0.5 * (lo[k][i] + hi[k][i]).cpu(), g.cpu()))
+
+
+@pytest.mark.gpu
+def test_loss_scalars_and_polyak_update_match_torch():
+    """ABI v11: gops_value_loss / gops_mean_loss / gops_polyak_update against the torch passes they replace
+    (gops/algorithm/infadp.py:124-133, 172-173, 213), ragged sizes, repeated calls on one stats buffer, bit-reproducible."""
+    from gops_amd import hip_backend as hb
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    st = hb.LossStats(dev)
+    for n in (1, 77, 4096, 65536, 100003):
+        v = torch.randn(n, generator=g).to(dev) * 3 - 1
+        b = torch.randn(n, generator=g).to(dev)
+        grad = torch.empty(n, device=dev)
+        out = st.value_loss(v, b, grad).clone()
+        ref = torch.stack((((v - b).double() ** 2).mean(), v.double().mean())).float()
+        assert torch.allclose(out, ref, rtol=2e-6, atol=1e-7), (n, out, ref)
+        assert torch.equal(grad, (2.0 / n) * (v - b)) or torch.allclose(grad, (2.0 / n) * (v - b), rtol=2e-7, atol=0)
+        again = st.value_loss(v, b, None).clone()
+        assert torch.equal(out, again)
+        m = st.mean_loss(v, -1.0).clone()
+        assert torch.allclose(m, torch.stack((-v.double().mean(), v.double().mean())).float(), rtol=2e-6, atol=1e-7)
+        assert float(st.buf[2:].abs().sum()) == 0.0 or st.buf[-2] == 0   # the ticket is left zero
+    shapes = [(256, 126), (256,), (256, 256), (256,), (2, 256), (2,)] * 3   # 18 tensors: two chunks of the table
+    online = [torch.randn(*s, generator=g).to(dev) for s in shapes]
+    target = [torch.randn(*s, generator=g).to(dev) for s in shapes]
+    want = [t.clone() for t in target]
+    tau = 0.005
+    torch._foreach_mul_(want, 1 - tau)
+    torch._foreach_add_(want, online, alpha=tau)
+    pk = hb.PolyakUpdater(target, online)
+    assert pk.matches(target, online)
+    pk.step(tau)
+    for t, w in zip(target, want):
+        assert torch.allclose(t, w, rtol=0, atol=1.2e-7 * float(w.abs().max()))   # (torch may fuse alpha * x + y into one fma)

@@ -1080,9 +1080,11 @@ int split_grid_limit() { return device_cus(); }
 // finite amount - measured at cfg3 (relu, 256^3, B = 8192): 2.0e-4 from the reference with a plane-split forward against
 // < 1e-4 with exact fp32 products.  Such launches keep the fp32-MFMA kernels.  (Without a tail: relu at the target shape
 // 7.7e-6 plane-split vs 7.4e-6 fp32 - no difference.)
+// Only launches that keep a gradient are concerned: the VALUES are continuous in the weights (a forward without stash - INFADP's
+// policy evaluation - is plane-split like any other net: 1e-6-class error on the backup).
 static bool kinked_with_tail(const RolloutParams& p) {
     auto kinked = [](int a) { return a == GOPS_ACT_RELU || a == GOPS_ACT_SELU; };
-    return p.tail && (kinked(p.pol.act) || kinked(p.val.act));
+    return p.need_grad && p.tail && (kinked(p.pol.act) || kinked(p.val.act));
 }
 
 bool split_eligible(const RolloutParams& p) {

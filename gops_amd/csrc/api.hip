@@ -39,6 +39,7 @@ hipError_t launch_fill_zero(float* p, size_t n, hipStream_t s);
 hipError_t launch_env_step(const GopsEnv& env, int B, const GopsStepIO& io, float pdt, hipStream_t s);
 hipError_t launch_env_constraint(const GopsEnv& env, int B, const GopsStepIO& io, hipStream_t s);
 bool ss_eligible(const RolloutParams& p);   // rollout_fwd.hip
+bool ss_tail_exact(const RolloutParams& p); // rollout_fwd.hip
 bool ssb_eligible(const RolloutParams& p);  // rollout_bwd.hip
 hipError_t launch_polyak(const GopsAdamTensors& T, float omt, float tau, hipStream_t s);
 hipError_t launch_batch_loss(const float* a, const float* b, int n, float gsc, float sc0, float* grad, float* stats, hipStream_t s);
@@ -350,6 +351,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         sp.invt[0] = c.take(p.pol.kp[0] >> 4);
     }
     p.ss = (!p.sp.on && ss_eligible(p)) ? 1 : 0;
+    p.tail_fp32 = (p.ss && ss_tail_exact(p)) ? 1 : 0;
     if (p.ss) {   // streamed-split forward: planes of every hidden layer of the policy (and of the tail value net)
         for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
             const MlpDev& d = m ? p.val : p.pol;
@@ -363,8 +365,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
             }
         }
     }
-    // the sweep of the same launch on the streamed-split kernel too: transposed planes (n-tiles over a layer's inputs) - also behind
-    // an exact-fp32 forward (relu / selu nets with a tail value net: ss_sweep_only)
+    // the sweep of the same launch on the streamed-split kernel too: transposed planes (n-tiles over a layer's inputs)
     p.ssb = (p.need_grad && ssb_eligible(p)) ? 1 : 0;
     if (p.ssb) {
         for (int m = 0; m < (p.tail ? 2 : 1); ++m) {

@@ -150,7 +150,7 @@ struct RolloutParams {
     float* gscale;                    // f16 backward: gscale[0] = max|grad_v| of the launch (upload_params_kernel)
     SplitDev sp;                      // plane-split contractions of the stationary fp32 kernels
     int ss;                           // 1: streamed-split FORWARD kernel (all hidden layers 256 wide, planes streamed from L2)
-    int ss_pad_;
+    int tail_fp32;                    //   ... with the TAIL value net on exact fp32 products (relu / selu nets that keep a gradient: rollout_fwd.hip)
     SplitNetDev ssp, ssv;             //   planes of the policy / the tail value net
     SplitNetDev sspt, ssvt;           //   streamed-split SWEEP (ssb): transposed planes (n-tiles over a layer's inputs, 8 chunks over its outputs)
     int ssb;

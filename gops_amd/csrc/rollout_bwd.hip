@@ -1496,9 +1496,8 @@ int ssb_grid_limit() { return 2 * split_grid_limit(); }   // workgroups of the s
 
 // The sweep of a streamed-split forward launch (p.ss) on the streamed-split sweep as well: same conditions, its LDS image at
 // two workgroups per CU.  GOPS_SSB=0 keeps the fp32-MFMA sweep.
-bool ss_sweep_only(const RolloutParams& p);   // rollout_fwd.hip: fp32 forward, plane-split sweep
 bool ssb_eligible(const RolloutParams& p) {
-    if (!p.ss && !ss_sweep_only(p)) return false;
+    if (!p.ss) return false;
     if (p.vflags & GOPS_VF_NO_STREAMED_SPLIT_BWD) return false;
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
     return rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false, true) + (env_in_lds(p.env.kind, true) ? 4 * ENV_LDS_FLOATS : 0) <= 80 * 1024;

@@ -448,6 +448,10 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
         ha = reinterpret_cast<float*>(xq);   // tail value net (after the loop): its fp32 tiles alias the dead plane images
         hb = ha + TB * ldh;
     }
+    if constexpr (SS && TAIL) {   // (p.tail_fp32: the same aliasing; 64 (rowb0 + 528) bytes >= two [TB][260] fp32 tiles for every rowb0)
+        ha = reinterpret_cast<float*>(xq);
+        hb = ha + TB * ldh;
+    }
     const IdpConst IC = idp_const();
     const VehConst VC = veh_const();
 
@@ -979,6 +983,14 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
         __syncthreads();
         float y[GOPS_MAX_ACT];
         const int Lv = p.val.nl - 1;
+        if (SS && p.tail_fp32) {
+            // relu / selu value net of a launch that keeps a gradient: exact fp32 products for THIS net (dV/d(obs) of a piecewise-linear
+            // net jumps where a pre-activation changes sign under the 2^-19 weight representation); the step loop stays plane-split
+            float* hcur = mlp_hidden_forward(p.val, NoW{}, NoW{}, xs, ldx, ha, hb, ldh, tid, s_bias,
+                                             p.need_grad ? p.st.tail_h : nullptr,
+                                             p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, dbg);
+            mlp_head<false>(gptr(p.val.w[Lv]), p.val.dims[Lv], gptr(p.val.b[Lv]), p.val.dims[Lv], 1, hcur, ldh, tid, y);
+        } else
         if constexpr (SS) {   // the value net on the same streamed plane-split routine: its head (one output) staged like the policy's
             const int Kv = p.val.dims[Lv];
             for (int idx = tid; idx < GOPS_MAX_ACT * ldh; idx += NTHREADS) {
@@ -1126,11 +1138,13 @@ static bool ss_shape_ok(const RolloutParams& p) {   // everything but the arithm
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0;
     return rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, k0, true) + (env_in_lds(p.env.kind, true) ? 4 * ENV_LDS_FLOATS : 0) <= 80 * 1024;   // two workgroups per CU
 }
-bool ss_eligible(const RolloutParams& p) { return ss_shape_ok(p) && !kinked_with_tail(p); }
-// relu / selu with a tail value net: the FORWARD keeps exact fp32 products (a pre-activation that changes sign under the 2^-19
-// weight representation moves dV/d(obs) by a finite amount), but the SWEEP is linear once the forward has fixed the activation
-// pattern (act' comes from the stash): it may run plane-split like any other - cfg3.
-bool ss_sweep_only(const RolloutParams& p) { return !p.sp.on && ss_shape_ok(p) && kinked_with_tail(p); }
+// relu / selu with a tail value net, gradient kept: the step loop (policy net, env model) is plane-split like any other launch, only the
+// TAIL value net keeps exact fp32 products (p.tail_fp32) - it is the gradient THROUGH dV/d(obs_H) of the piecewise-linear value net
+// that moves by a finite amount when a pre-activation changes sign under the 2^-19 weight representation (measured at cfg3, 256^3
+// relu, B = 8192: 2.0e-4 from the reference with a plane-split tail, < 1e-4 with an exact one; a relu POLICY alone is indifferent:
+// 7.7e-6 vs 7.4e-6 at the target shape).  The sweep is linear once the forward has fixed the activation pattern: plane-split.
+bool ss_eligible(const RolloutParams& p) { return ss_shape_ok(p); }
+bool ss_tail_exact(const RolloutParams& p) { return kinked_with_tail(p); }
 
 // Picks the register-stationary variant when the policy is (kp0 in {16,48,128}) -> 256 -> 256 ...,
 // else the fully streamed kernel.  sk[0] / sk[1] receive the chosen chunk counts (0 = streamed).

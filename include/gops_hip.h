@@ -436,7 +436,8 @@ int gops_mean_loss(const float* x, int32_t n, double scale, float* stats, void* 
  *        3 bf16 + 1 f16 MFMA (16x16x32) per 32-deep block, fp32 accumulation (>= 19-bit weights, fp32 results);
  * bit 1 (GOPS_VARIANT_STATIONARY_F32): the register-stationary kernels on exact fp32 MFMAs;
  * bit 2 (GOPS_VARIANT_STREAMED_SPLIT_FWD, ABI v9): the FORWARD rollout on the streamed plane-split kernel (any number of
- *        256-wide hidden layers, weight planes streamed from L2, tail value net included); the backward sweep of such a
+ *        256-wide hidden layers, weight planes streamed from L2, tail value net included - except that the tail value net of a
+ *        relu / selu launch that keeps a gradient is evaluated with exact fp32 products); the backward sweep of such a
  *        launch runs on the streamed plane-split sweep where its LDS image fits twice per CU, else on the streamed fp32-MFMA kernel;
  * bit 3 (GOPS_VARIANT_HALF_TILE64, ABI v10): GOPS_DTYPE_F16 on the 64-trajectory-tile kernels (rollout_h64.hip);
  * none: the streamed kernels (exact fp32 MFMAs, or half-precision MFMAs for GOPS_DTYPE_F16).

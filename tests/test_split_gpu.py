@@ -149,6 +149,9 @@ SS_CASES = {
     "veh_p10_3x256_fhadp_relu": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=4096 + 16 * 37 + 1, horizon=4, pre_horizon=10, hidden=(256, 256, 256), act="relu", gamma=0.99),
     "veh_p10_3x256_infadp_many_tiles": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4096 + 16 * 93 + 9, horizon=3, pre_horizon=10, hidden=(256, 256, 256), act="gelu", gamma=0.99),
     "veh_p10_2x256_infadp_many_tiles": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=0.99),
+    # relu / selu with a tail value net: plane-split step loop and sweep, the tail value net on exact fp32 products (RolloutParams.tail_fp32)
+    "veh_p10_3x256_infadp_relu_tail": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4096 + 16 * 40 + 5, horizon=4, pre_horizon=10, hidden=(256, 256, 256), act="relu", gamma=0.99),
+    "lq_s4a2_2x256_infadp_selu_tail": dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=200, horizon=5, hidden=(256, 256), act="selu", gamma=0.99),
     "veh_p30_4x256_fhadp": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=70, horizon=5, pre_horizon=30, hidden=(256, 256, 256, 256), act="elu", gamma=1.0),
     "lq_s4a2_infadp_many_tiles": dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=4096 + 16 * 21 + 3, horizon=6, hidden=(256, 256), act="gelu", gamma=0.99),
     "lq_s6a3_3x256_fhadp": dict(alg="FHADP", env_id="pyth_lq", lq_config="s6a3", batch=50, horizon=9, hidden=(256, 256, 256), act="tanh", gamma=0.97),

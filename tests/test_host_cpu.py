@@ -110,6 +110,22 @@ def test_variant_selection_is_part_of_the_description_not_of_the_process():
     d.policy = m
     d.env = create_env_model("pyth_veh3dofconti", pre_horizon=10).hip_env()
     assert variant(0) == 4 and variant(hb.VF_NO_STREAMED_SPLIT_FWD) == 2 and variant(hb.VF_STREAMED_FP32) == 0
+    # relu nets with a tail value net (INFADP, cfg3): still the streamed plane-split kernels - only the tail value net of a launch
+    # that keeps a gradient is evaluated with exact fp32 products (round 4; round 3 kept the whole launch on the fp32 kernels)
+    m.hidden_act = hb.ACT_IDS["relu"]
+    m.sizes[0] = 46                                           # (infinite horizon: no time column)
+    d.policy = m
+    v = hb.GopsMlp()
+    v.n_layers = 4
+    for i, s in enumerate([46, 256, 256, 256, 1]):
+        v.sizes[i] = s
+    for j in range(4):
+        v.weight[j] = v.bias[j] = 1
+    v.hidden_act = hb.ACT_IDS["relu"]
+    d.value, d.tail_value, d.finite_horizon, d.batch, d.horizon = v, 1, 0, 8192, 10
+    for ng in (1, 0):
+        d.need_grad = ng
+        assert variant(0) == 4, ng
     n_getenv = sum(open(f).read().count("getenv(") for f in glob.glob(os.path.join(ROOT, "gops_amd", "csrc", "*.h*")))
     assert n_getenv <= 3, n_getenv
 

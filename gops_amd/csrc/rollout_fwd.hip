@@ -1102,7 +1102,8 @@ static bool kinked_with_tail(const RolloutParams& p) {
 bool split_eligible(const RolloutParams& p) {
     const MlpDev& M = p.pol;
     if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
-    if (kinked_with_tail(p)) return false;
+    // (relu / selu nets with a tail value net are fine here: these kernels evaluate the tail value net - forward and input adjoint -
+    // with exact fp32 products anyway, see ss_tail_exact below)
     if (p.env.kind != GOPS_ENV_LQ && p.env.kind != GOPS_ENV_IDPENDULUM && p.env.kind != GOPS_ENV_VEH3DOFCONTI) return false;
     if (M.nl != 3 || M.dims[1] != 256 || M.dims[2] != 256 || p.ldh != 260 || M.kp32[0] > 256 || p.ldx != M.kp[0] + 4) return false;
     // more than 128 inputs (veh3dofconti with P > 30): layer 0's planes stream from L2 - instantiated without the tail value net

@@ -84,12 +84,13 @@ def test_split_kernels_vs_oracle_and_fp32_mfma(name, dev, monkeypatch):
     assert rel_l2(flat, flat0) < 5e-5, (name, rel_l2(flat, flat0))   # the two arithmetic paths agree far inside the bar
 
 
-@pytest.mark.parametrize("batch", [90, 4096 + 16 * 11 + 7])
-def test_split_kernels_with_tail_value(batch, dev, monkeypatch):
+@pytest.mark.parametrize("batch,act", [(90, "gelu"), (4096 + 16 * 11 + 7, "gelu"), (3000, "relu"), (200, "selu")])
+def test_split_kernels_with_tail_value(batch, act, dev, monkeypatch):
     """INFADP's policy-improvement gradient (tail value net after the loop: its fp32 tiles alias the plane images); the
-    second batch has more tiles than CUs (grid-stride tile walk: the policy biases are re-staged after every tail)."""
+    second batch has more tiles than CUs (grid-stride tile walk: the policy biases are re-staged after every tail).  relu / selu:
+    the tail value net runs on exact fp32 products in these kernels, which is what such nets need (rollout_fwd.hip: ss_tail_exact)."""
     from gops_amd import hip_backend as hb
-    cfg = dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=batch, horizon=8, hidden=(256, 256), act="gelu", gamma=0.99)
+    cfg = dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=batch, horizon=8, hidden=(256, 256), act=act, gamma=0.99)
     data = make_batch(cfg, 8)
     nets = reference_init_nets(cfg, 8, obs_dim_of(cfg), act_dim_of(cfg))
     env = orc.make_env("pyth_lq", lq_config="s4a2")
@@ -103,6 +104,8 @@ def test_split_kernels_with_tail_value(batch, dev, monkeypatch):
         # (by default tail + more tiles than CUs stays on the streamed kernels: VF_SPLIT_TAIL_MULTI)
         ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=False, need_grad=True, value=vt,
                         variant_flags=hb.VF_SPLIT_TAIL_MULTI | (0 if split else hb.VF_NO_STATIONARY_SPLIT))
+        import ctypes
+        assert (hb.lib().gops_rollout_variant(ctypes.byref(ro.desc)) == 1) == split, "the launch would not take the kernels under test"
         res = ro.forward(to_device(data, dev))
         gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]
         ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
@@ -151,7 +154,7 @@ SS_CASES = {
     "veh_p10_2x256_infadp_many_tiles": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4800, horizon=4, pre_horizon=10, hidden=(256, 256), act="elu", gamma=0.99),
     # relu / selu with a tail value net: plane-split step loop and sweep, the tail value net on exact fp32 products (RolloutParams.tail_fp32)
     "veh_p10_3x256_infadp_relu_tail": dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=4096 + 16 * 40 + 5, horizon=4, pre_horizon=10, hidden=(256, 256, 256), act="relu", gamma=0.99),
-    "lq_s4a2_2x256_infadp_selu_tail": dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=200, horizon=5, hidden=(256, 256), act="selu", gamma=0.99),
+    "lq_s4a2_3x256_infadp_selu_tail": dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=200, horizon=5, hidden=(256, 256, 256), act="selu", gamma=0.99),
     "veh_p30_4x256_fhadp": dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=70, horizon=5, pre_horizon=30, hidden=(256, 256, 256, 256), act="elu", gamma=1.0),
     "lq_s4a2_infadp_many_tiles": dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=4096 + 16 * 21 + 3, horizon=6, hidden=(256, 256), act="gelu", gamma=0.99),
     "lq_s6a3_3x256_fhadp": dict(alg="FHADP", env_id="pyth_lq", lq_config="s6a3", batch=50, horizon=9, hidden=(256, 256, 256), act="tanh", gamma=0.97),

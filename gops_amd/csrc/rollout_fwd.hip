@@ -1087,13 +1087,12 @@ int split_grid_limit() { return device_cus(); }
 // obs -> 256 -> 256 -> act policy on the BASELINE env kinds with an input of at most 128 columns (4 chunks of 32: the
 // planes of both layers then fit the register file + LDS).  One workgroup per CU keeps the weights resident and walks
 // the tiles grid-stride, whatever the batch size.  GOPS_SPLIT=0 keeps the fp32-MFMA kernels.
-// Activations whose derivative jumps at 0: with a tail value net (INFADP: the gradient runs through dV/d(obs_H) of a
-// piecewise-linear net) every pre-activation that changes sign under the 2^-19 weight representation moves the result by a
-// finite amount - measured at cfg3 (relu, 256^3, B = 8192): 2.0e-4 from the reference with a plane-split forward against
-// < 1e-4 with exact fp32 products.  Such launches keep the fp32-MFMA kernels.  (Without a tail: relu at the target shape
-// 7.7e-6 plane-split vs 7.4e-6 fp32 - no difference.)
-// Only launches that keep a gradient are concerned: the VALUES are continuous in the weights (a forward without stash - INFADP's
-// policy evaluation - is plane-split like any other net: 1e-6-class error on the backup).
+// Activations whose derivative jumps at 0 (relu, selu) in a launch with a tail value net that keeps a gradient: the gradient runs
+// through dV/d(obs_H) of a piecewise-linear net, and every pre-activation of THAT net which changes sign under the 2^-19 weight
+// representation moves it by a finite amount - measured at cfg3 (relu, 256^3, B = 8192): 2.0e-4 from the reference with a
+// plane-split tail value net, < 1e-4 with exact fp32 products.  The tail value net of such a launch is therefore evaluated with
+// exact fp32 products (the stationary kernels do that for every tail; the streamed ones on RolloutParams.tail_fp32).  Launches
+// without a gradient are not concerned: the VALUES are continuous in the weights.
 static bool kinked_with_tail(const RolloutParams& p) {
     auto kinked = [](int a) { return a == GOPS_ACT_RELU || a == GOPS_ACT_SELU; };
     return p.need_grad && p.tail && (kinked(p.pol.act) || kinked(p.val.act));
@@ -1102,8 +1101,8 @@ static bool kinked_with_tail(const RolloutParams& p) {
 bool split_eligible(const RolloutParams& p) {
     const MlpDev& M = p.pol;
     if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
-    // (relu / selu nets with a tail value net are fine here: these kernels evaluate the tail value net - forward and input adjoint -
-    // with exact fp32 products anyway, see ss_tail_exact below)
+    // (relu / selu nets with a tail value net are fine here: these kernels evaluate every tail value net - forward and input
+    // adjoint - with exact fp32 products)
     if (p.env.kind != GOPS_ENV_LQ && p.env.kind != GOPS_ENV_IDPENDULUM && p.env.kind != GOPS_ENV_VEH3DOFCONTI) return false;
     if (M.nl != 3 || M.dims[1] != 256 || M.dims[2] != 256 || p.ldh != 260 || M.kp32[0] > 256 || p.ldx != M.kp[0] + 4) return false;
     // more than 128 inputs (veh3dofconti with P > 30): layer 0's planes stream from L2 - instantiated without the tail value net
@@ -1121,9 +1120,9 @@ bool split_eligible(const RolloutParams& p) {
 
 // Streamed-split forward kernels: every hidden layer of the policy (and of the tail value net) 256 wide, at most 256 padded
 // inputs, fp32, closed loop, every env model - the launches the register-stationary kernels do not take (three
-// hidden layers, a tail value net with more tiles than CUs).  The backward sweep of such a launch stays on the fp32-MFMA
-// kernels: both forward variants write the same feature-major stash.  GOPS_SS=0 switches it off.
-static bool ss_shape_ok(const RolloutParams& p) {   // everything but the arithmetic question (kinked_with_tail) and the forward's own switch
+// hidden layers, a tail value net with more tiles than CUs).  The backward sweep of such a launch: rollout_bwd.hip ssb_eligible
+// (both forward variants write the same feature-major stash).  GOPS_VF_NO_STREAMED_SPLIT_FWD switches it off.
+static bool ss_shape_ok(const RolloutParams& p) {
     if (p.f16 || p.ext || p.open_loop || p.env.repeat_num > 1) return false;
     // (value / MLP batches, GOPS_ENV_NONE: one step - half the MFMA time of the fp32 kernels; GOPS_SS_VALUE=0 keeps those)
     if (p.env.kind == GOPS_ENV_NONE && (p.vflags & GOPS_VF_NO_STREAMED_SPLIT_VALUE)) return false;
@@ -1139,11 +1138,9 @@ static bool ss_shape_ok(const RolloutParams& p) {   // everything but the arithm
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0;
     return rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, k0, true) + (env_in_lds(p.env.kind, true) ? 4 * ENV_LDS_FLOATS : 0) <= 80 * 1024;   // two workgroups per CU
 }
-// relu / selu with a tail value net, gradient kept: the step loop (policy net, env model) is plane-split like any other launch, only the
-// TAIL value net keeps exact fp32 products (p.tail_fp32) - it is the gradient THROUGH dV/d(obs_H) of the piecewise-linear value net
-// that moves by a finite amount when a pre-activation changes sign under the 2^-19 weight representation (measured at cfg3, 256^3
-// relu, B = 8192: 2.0e-4 from the reference with a plane-split tail, < 1e-4 with an exact one; a relu POLICY alone is indifferent:
-// 7.7e-6 vs 7.4e-6 at the target shape).  The sweep is linear once the forward has fixed the activation pattern: plane-split.
+// relu / selu with a tail value net, gradient kept (kinked_with_tail above): the step loop (policy net, env model: a relu POLICY alone is
+// indifferent, 7.7e-6 vs 7.4e-6 at the target shape) is plane-split like any other launch, only the TAIL value net keeps exact fp32
+// products (p.tail_fp32); the sweep is linear once the forward has fixed the activation pattern: plane-split.
 bool ss_eligible(const RolloutParams& p) { return ss_shape_ok(p); }
 bool ss_tail_exact(const RolloutParams& p) { return kinked_with_tail(p); }
 

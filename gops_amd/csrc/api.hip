@@ -476,6 +476,11 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
             fprintf(stderr, "[gops dbg] fwd 64-row half cycles/step: top+sync %llu | convert+xstash+sync %llu | L0 gemm %llu epi %llu sync %llu | "
                     "L1 gemm %llu epi %llu sync %llu | head %llu sync %llu | env %llu\n",
                     h[0] / p.H, h[1] / p.H, h[2] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H, h[6] / p.H, h[7] / p.H, h[8] / p.H, h[9] / p.H, h[10] / p.H);
+        else if (p.ss)   // (grid-stride launches: the counters add up over the tiles block 0 walked)
+            fprintf(stderr, "[gops dbg] fwd streamed-split cycles/step (x tiles of block 0): top+sync %llu | planes of X+sync %llu | L0 gemm %llu | "
+                    "epilogues %llu | plane store+sync %llu | L1.. gemm %llu sync %llu | head partials+combine %llu | tanh+wrap %llu sync %llu | "
+                    "envstash %llu | env %llu\n", h[0] / p.H, h[1] / p.H, h[14] / p.H, h[8] / p.H, h[12] / p.H, h[11] / p.H, h[9] / p.H, h[2] / p.H,
+                    h[7] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H);
         else if (p.sp.on)
             fprintf(stderr, "[gops dbg] fwd SPLIT cycles/step: top+sync %llu | xstash+convert+sync %llu | gemm0 %llu | epi0+planes %llu | sync %llu | "
                     "gemm1 %llu | epi1+head fma %llu | head reduce %llu | sync+combine %llu | tanh+wrap %llu | sync %llu | envstash %llu | env %llu || sum %llu\n",

@@ -271,13 +271,14 @@ struct NoSplit {};
 template <int AMAX>
 __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetDev& S, const float* xs, int ldx, char* xq, char* hq,
                                                 float* s_part, const float* s_bias, int ldb, const float* s_wo4, const float* s_bo,
-                                                int tid, float* const* stash_h, float* const* stash_z, size_t row0, float* dmp = nullptr) {
+                                                int tid, float* const* stash_h, float* const* stash_z, size_t row0, DbgClock& dbg, float* dmp = nullptr) {
     const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
     constexpr int ROWB1 = 2 * 256 + 16;
     const int L = M.nl - 1, rowb0 = split_rowb(32 * S.kc[0]);
     const bool gelu = M.act == GOPS_ACT_GELU;
     plane_convert_x(xs, ldx, M.kp[0], 32 * S.kc[0], xq, rowb0, tid, SPLIT_FWD_SA);
     __syncthreads();
+    DBG_TICK(1)
     float part[4][AMAX] = {};
     for (int j = 0; j < L; ++j) {
         f32x4 acc[4] = {}, accr[4] = {};
@@ -291,8 +292,11 @@ __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetD
             }
         } else {
             ss_layer_gemm<8>(hq, ROWB1, S.w1[j], S.r[j], S.inv[j], 16, tid, acc, accr, inv);
+            DBG_TICK(11)
             __syncthreads();   // every wave has read the activation image it is about to overwrite
+            DBG_TICK(9)
         }
+        if (j == 0) DBG_TICK(14)
         float* hrow = (stash_h != nullptr) ? stash_h[j + 1] + row0 * 256 : nullptr;
         float* zrow = (stash_z != nullptr && gelu) ? stash_z[j + 1] + row0 * 256 : nullptr;
         const bool last = j == L - 1;
@@ -323,9 +327,11 @@ __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetD
                 for (int r = 0; r < 4; ++r) gptr(dmp)[32 + 16 * (j > 0 ? 1 : 0) + 4 * q + r] = hv[q][r];
         }
 #endif
+        DBG_TICK(8)
         if (!last) {
             plane_store(hq, ROWB1, wave, lane, hv, SPLIT_FWD_SA);
             __syncthreads();
+            DBG_TICK(12)
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -351,6 +357,7 @@ __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetD
     if (la < GOPS_MAX_ACT)
         ya = ((s_part[(0 * TB + hm) * 4 + la] + s_part[(1 * TB + hm) * 4 + la]) +
               (s_part[(2 * TB + hm) * 4 + la] + s_part[(3 * TB + hm) * 4 + la])) + s_bo[la];
+    DBG_TICK(2)
     return ya;
 }
 
@@ -528,11 +535,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                     for (int k = 0; k < 3; ++k) gptr(dmp)[28 + k] = xs[(tid >> 4) * ldx + (tid & 15) + 16 * k];
                 }
                 ya_split = ss_net_forward<AMAX>(p.pol, p.ssp, xs, ldx, xq, hq, s_part, s_bias, ldh, s_wo, s_bo, tid,
-                                                p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0, dmp);
+                                                p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0, dbg, dmp);
                 if (dmp != nullptr) gptr(dmp)[0] = ya_split;
 #else
                 ya_split = ss_net_forward<AMAX>(p.pol, p.ssp, xs, ldx, xq, hq, s_part, s_bias, ldh, s_wo, s_bo, tid,
-                                                p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0);
+                                                p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0, dbg);
 #endif
             } else
             if (!p.open_loop) {
@@ -1000,7 +1007,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
             if (tid < GOPS_MAX_ACT) s_bo[tid] = (tid == 0) ? gptr(p.val.b[Lv])[0] : 0.f;
             __syncthreads();
             y[0] = ss_net_forward<1>(p.val, p.ssv, xs, ldx, xq, hq, s_part, s_bias, ldh, s_wo, s_bo, tid,
-                                     p.need_grad ? p.st.tail_h : nullptr, p.need_grad ? p.st.tail_z : nullptr, (size_t)b0);
+                                     p.need_grad ? p.st.tail_h : nullptr, p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, dbg);
         } else
         if constexpr (F16) {
             convert_x_h(xs, ldx, p.val.kp[0], p.val.kp32[0], x16, ldx16, nullptr, 0, tid);

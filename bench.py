@@ -78,13 +78,53 @@ def bytes_per_step(cfg, dtype):
 CPU_SAMPLE_MAX_BATCH = 8192   # bounded sample: larger batches are timed on this many trajectories
 
 
+def host_cpu_info():
+    """Model string, sockets, physical cores and logical CPUs of this host (/proc/cpuinfo)."""
+    model, phys, cores = None, set(), set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                pid = v
+                phys.add(v)
+            elif k == "core id":
+                cid = v
+            elif k == "" and pid is not None and cid is not None:
+                cores.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    import platform
+    return {"cpu_model": model or platform.processor() or "unknown", "sockets": len(phys) or None,
+            "physical_cores": len(cores) or None, "logical_cpus": os.cpu_count()}
+
+
+def reference_root():
+    """The unmodified reference tree, when this box has it (the build container: /root/reference; anywhere else through
+    GOPS_REFERENCE_ROOT).  The GPU box of the driver does not: the baseline is then the oracle port (`kind: port`)."""
+    for cand in (os.environ.get("GOPS_REFERENCE_ROOT"), "/root/reference"):
+        if cand and os.path.isfile(os.path.join(cand, "gops", "algorithm", "fhadp.py")):
+            return cand
+    return None
+
+
 def cpu_baseline(cfg, seed, workload, eager_gpu=False):
-    """The oracle (CPU restatement of the reference, pinned to its fixtures) timed on the host
-    cores of this box.  Checker only: nothing it computes is used by the GPU path."""
+    """The reference's CPU trainer arithmetic timed on the host cores of THIS box: the unmodified reference classes
+    (`gops.algorithm.fhadp.FHADP._compute_gradient`, `gops.algorithm.infadp.INFADP.local_update`, imported behind the gym /
+    tensorboard stub of tests/golden/_ref_import.py) when the reference tree is present - `kind: reference`, nothing estimated -,
+    and always the oracle port (`oracle/adp_oracle.py`, pinned to the reference's fixtures).  Where the reference is absent the
+    stated `value` is the port's rate divided by the reference / port time ratio measured on identical cores in the build
+    container (profiles/cpu_port_calibration.json): `kind: port`, `estimated: true`.  Checker only: nothing it computes is used by
+    the GPU path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import reference_init_nets
     from oracle import adp_oracle as orc
     B = min(cfg["batch"], CPU_SAMPLE_MAX_BATCH)
+    full_batch = CONFIGS[workload]["batch"]
     cfg = dict(cfg, batch=B)
     nets = reference_init_nets(cfg, seed, obs_dim_of(cfg), act_dim_of(cfg))
     env = orc.make_env(cfg["env_id"], pre_horizon=cfg.get("pre_horizon", 10), lq_config=cfg.get("lq_config", "s4a2"))
@@ -98,20 +138,45 @@ def cpu_baseline(cfg, seed, workload, eager_gpu=False):
             orc.infadp_pev_gradient(e, n["policy"], n["v"], n["v_target"], d, cfg["horizon"], cfg["gamma"])
             orc.infadp_pim_gradient(e, n["policy"], n["v_target"], d, cfg["horizon"], cfg["gamma"])
         calls_per_unit = 2
-    # The reference pins 4 intra-op threads for serial trainers (gops/utils/init_args.py:31-35); the
-    # many tiny ATen ops of this loop scale poorly, so try a few counts and report the fastest.
-    ncpu = os.cpu_count() or 4
-    results = {}
-    for nthreads in sorted({4, min(16, ncpu), min(64, ncpu)}):
-        torch.set_num_threads(nthreads)
-        times = []
-        for i in range(3):
-            t0 = time.perf_counter()
-            one()
-            times.append((time.perf_counter() - t0) / calls_per_unit)
-        results[nthreads] = min(times[1:])
-    best_threads = min(results, key=results.get)
-    best = results[best_threads]
+    ref_one, ref_root = None, reference_root()
+    if ref_root is not None:   # the unmodified classes
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import _ref_import
+        _ref_import.REFERENCE_ROOT = ref_root
+        with contextlib.redirect_stdout(sys.stderr):
+            import make_golden as mg   # (alg_kwargs / build_alg of the fixture generator: constructs the reference classes)
+            ref_alg = mg.build_alg(cfg, seed)
+        if cfg["alg"] == "FHADP":
+            def ref_one():
+                ref_alg._compute_gradient({k: v.clone() for k, v in data.items()})
+        else:
+            it = [0]
+
+            def ref_one():   # one PEV + one PIM `local_update` (incl. the reference's Adam / Polyak steps: negligible)
+                for _ in range(2):
+                    ref_alg.local_update({k: v.clone() for k, v in data.items()}, it[0])
+                    it[0] += 1
+    # The reference pins 4 intra-op threads for serial trainers (gops/utils/init_args.py:31-35); the many tiny ATen ops of
+    # this loop scale poorly, so a few counts are tried: the 4-thread figure is reported next to the best one.
+    host = host_cpu_info()
+    ncpu = host["logical_cpus"] or 4
+    steps_per_call = B * cfg["horizon"]
+
+    def sweep(fn):
+        res = {}
+        for nthreads in sorted({4, min(16, ncpu), min(64, ncpu)}):
+            torch.set_num_threads(nthreads)
+            times = []
+            for i in range(3):
+                t0 = time.perf_counter()
+                fn()
+                times.append((time.perf_counter() - t0) / calls_per_unit)
+            res[nthreads] = min(times[1:])
+        return res
+    port = sweep(one)
+    ref = sweep(ref_one) if ref_one is not None else None
+    timed = ref if ref is not None else port
+    best_threads = min(timed, key=timed.get)
     eager = None
     if eager_gpu and cfg["alg"] == "FHADP":   # the same restatement as plain PyTorch-ROCm eager ops on the GPU ("no-kernel" baseline)
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -132,34 +197,50 @@ def cpu_baseline(cfg, seed, workload, eager_gpu=False):
             orc.fhadp_gradient(denv, pol, ddata, cfg["horizon"], cfg["gamma"])
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
-        eager = B * cfg["horizon"] / min(times[1:])
-    out = {"eager_gpu_steps_per_s": eager, "value": B * cfg["horizon"] / best, "unit": "env-model steps/s",
-           "cores": best_threads, "kind": "port",
-           "sample": f"{B} of the workload's {CONFIGS[workload]['batch']} trajectories x H={cfg['horizon']}; per thread count 1 warm-up + 2 "
+        eager = steps_per_call / min(times[1:])
+    out = {"value": steps_per_call / timed[best_threads], "unit": "env-model steps/s", "cores": best_threads,
+           "kind": "reference" if ref is not None else "port", "estimated": False,
+           "cpu_model": host["cpu_model"], "sockets": host["sockets"], "physical_cores": host["physical_cores"],
+           "logical_cpus": host["logical_cpus"],
+           "threads_4": {"value": steps_per_call / timed[4], "threads": 4,
+                         "note": "the reference's default intra-op thread count for serial trainers (gops/utils/init_args.py:31-35)"},
+           "best": {"value": steps_per_call / timed[best_threads], "threads": best_threads},
+           "by_threads": {str(n): steps_per_call / t for n, t in timed.items()},
+           "port_by_threads": {str(n): steps_per_call / t for n, t in port.items()},
+           "eager_gpu_steps_per_s": eager,
+           "sample": f"{B} of the workload's {full_batch} trajectories x H={cfg['horizon']}; per thread count 1 warm-up + 2 "
                      f"timed gradient evaluations (fwd+bwd{', PEV and PIM averaged' if calls_per_unit == 2 else ''}), best; "
-                     + ", ".join(f"{n} threads: {t * 1e3:.0f} ms" for n, t in results.items())
-                     + f"; host has {ncpu} logical CPUs"}
-    # the port is faster than the reference classes it restates (no deepcopy(data), no per-key info clones, no
-    # torch.equal host checks): profiles/cpu_port_calibration.json (tools/calibrate_cpu_port.py, build container)
-    # holds the measured ratio on identical cores
+                     + ", ".join(f"{n} threads: {t * 1e3:.0f} ms" for n, t in timed.items())
+                     + f"; host: {host['cpu_model']}, {host['sockets']} socket(s), {host['physical_cores']} physical cores, "
+                       f"{host['logical_cpus']} logical CPUs"}
+    if ref is not None:
+        out["timed"] = "the UNMODIFIED reference classes from " + ref_root + " (use_gpu=False)"
+        out["port_value"] = steps_per_call / port[best_threads]
+        out["reference_over_port_time_ratio_here"] = {str(n): ref[n] / port[n] for n in ref}
+        return out
+    # No reference tree on this box: `value` = the port's rate divided by the reference / port time ratio measured on identical
+    # cores in the build container (tools/calibrate_cpu_port.py -> profiles/cpu_port_calibration.json: the port skips the
+    # reference's deepcopy(data), per-key info clones and torch.equal host checks); `port_value` keeps what was timed here.
+    out["timed"] = "the oracle port (oracle/adp_oracle.py); the reference tree is not on this box"
     cal_path = os.path.join(ROOT, "profiles", "cpu_port_calibration.json")
-    # The stated baseline (`value`) is the port's rate divided by that ratio = an ESTIMATE of the unmodified reference on this
-    # host (the reference tree does not exist on the GPU box); `port_value` keeps what was actually timed here.
     if os.path.exists(cal_path):
         cal = json.load(open(cal_path))
         rec = cal.get("workloads", {}).get(workload)
         if rec is not None:
             ths = {int(k): v["ratio_ref_over_port"] for k, v in rec.get("threads", {}).items()}
-            near = min(ths, key=lambda t: abs(t - best_threads)) if ths else None
-            ratio = ths[near] if near is not None else rec["ratio_ref_over_port"]
-            out["port_value"] = out["value"]
-            out["value"] = out["port_value"] / ratio
+            ratio = max(ths.values()) if ths else rec["ratio_ref_over_port"]   # the largest measured ratio: the most conservative estimate
+            for key in ("value",):
+                out["port_value"] = out[key]
+                out[key] = out["port_value"] / ratio
+            out["threads_4"]["value"] /= ratio
+            out["best"]["value"] /= ratio
+            out["by_threads"] = {k: v / ratio for k, v in out["by_threads"].items()}
             out["estimated"] = True
             out["calibration"] = {"reference_over_port_time_ratio": ratio,
-                                  "ratio_measured_at_threads": near, "reported_threads": best_threads,
-                                  "all_ratios": {str(k): v for k, v in sorted(ths.items())},
-                                  "measured_on": f"{cal['cpu']} ({cal['logical_cpus']} logical CPUs: the build container - the ratio at the "
-                                                 f"reported thread count cannot be measured there, the nearest measured count is used)",
+                                  "ratio_by_threads": {str(k): v for k, v in sorted(ths.items())},
+                                  "ratio_spread": [min(ths.values()), max(ths.values())] if ths else None,
+                                  "measured_on": f"{cal['cpu']} ({cal['logical_cpus']} logical CPUs: the build container; the largest "
+                                                 f"ratio over the measured thread counts is applied)",
                                   "source": "profiles/cpu_port_calibration.json"}
     return out
 
@@ -273,19 +354,117 @@ def roofline_of(cfg, dt, kern, pmc, pmc_src, workload, variant=0):
     return roofline, flops
 
 
-def run_workload(workload, dtype, steps, warmup, profile_steps, ctx):
+PARITY_TOL = 1e-4   # north_star: results within 1e-4 (relative) of the CPU fp32 reference
+
+
+def _num(x):
+    return x.item() if hasattr(x, "item") else float(x)
+
+
+def _rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().reshape(-1), torch.as_tensor(b).double().reshape(-1)
+    den = b.norm().item()
+    return (a - b).norm().item() / (den if den > 0 else 1.0)
+
+
+def parity_stamp(alg, cfg, workload, device, variant_name):
+    """Gradient of the kernels about to be timed (same algorithm object, same variant flags, the workload's full batch) against the
+    REFERENCE's values for this workload: tests/golden/big_<workload>.npz holds loss, per-parameter gradient norms and 256 sampled
+    entries per parameter recorded from the unmodified reference classes on the seed-0 batch and seed-0 random-init weights
+    (tests/golden/make_golden.py golden_big).  Runs before the warm-up (the weights are still the seed-0 initialisation)."""
+    path = os.path.join(ROOT, "tests", "golden", "big_" + workload + ".npz")
+    if not os.path.exists(path):
+        return {"checked": False, "reason": "no reference fixture for this workload"}
+    g = np.load(path)
+    data = make_batch(cfg, 0)
+    if abs(data["obs"].double().sum().item() - float(g["chk/obs_sum"])) > 1e-6:
+        return {"checked": False, "reason": "seed-0 batch does not reproduce the fixture's checksum"}
+    # The fixture's weights: torch.manual_seed(0), then nn.Linear layers in the reference's construction order (fhadp.py:42-44 the
+    # policy; infadp.py:41-45 value net first, targets = copies) - the algorithm object here was seeded by its trainer's rule
+    # (`set_seed`: +300 for sync trainers), so the seed-0 initialisation is written into its networks (and stays for the timed run).
+    torch.manual_seed(0)
+    sizes_p, sizes_v = mlp_sizes(cfg), mlp_sizes(cfg, "value")
+
+    def init_into(module, sizes):
+        fresh = [torch.nn.Linear(sizes[i], sizes[i + 1]) for i in range(len(sizes) - 1)]
+        with torch.no_grad():
+            for layer, src in zip(module.linear_layers(), fresh):
+                layer.weight.copy_(src.weight)
+                layer.bias.copy_(src.bias)
+    with torch.no_grad():
+        if cfg["alg"] == "FHADP":
+            init_into(alg.networks.policy, sizes_p)
+        else:
+            init_into(alg.networks.v, sizes_v)
+            init_into(alg.networks.policy, sizes_p)
+            for tgt, src in ((alg.networks.v_target, alg.networks.v), (alg.networks.policy_target, alg.networks.policy)):
+                for a, b in zip(tgt.parameters(), src.parameters()):
+                    a.copy_(b)
+    pol0 = next(alg.networks.policy.parameters())
+    if abs(pol0.detach().double().sum().item() - float(g["chk/policy_w0_sum"])) > 1e-6:
+        return {"checked": False, "reason": "seed-0 initialisation does not reproduce the fixture's checksum"}
+    data = {k: v.to(device) for k, v in data.items()}
+
+    def compare(prefix, params, loss, ref_loss):
+        worst, worst_norm = 0.0, 0.0
+        for i, prm in enumerate(params):
+            gr = prm.grad.detach()
+            got = gr.reshape(-1).cpu()[torch.from_numpy(g[f"{prefix}idx{i}"])]
+            worst = max(worst, _rel_l2(got, g[f"{prefix}val{i}"]))
+            worst_norm = max(worst_norm, abs(gr.double().norm().item() - float(g[prefix + "norms"][i])) / float(g[prefix + "norms"][i]))
+        return {"grad_rel_l2": worst, "grad_norm_rel": worst_norm, "loss_rel": abs(loss - ref_loss) / max(1.0, abs(ref_loss))}
+
+    out = {"checked": True, "tolerance": PARITY_TOL, "variant": variant_name, "fixture": "tests/golden/big_" + workload + ".npz",
+           "what": "worst per-parameter rel-L2 over 256 sampled gradient entries, worst per-parameter gradient-norm deviation and the "
+                   "loss, against the unmodified reference (CPU fp32) on the seed-0 batch / seed-0 weights of this workload"}
+    if cfg["alg"] == "FHADP":
+        alg._compute_gradient(data)
+        loss = _num(alg.tb_info["Loss/Actor loss-RL iter"])
+        out.update(compare("grad/", list(alg.networks.policy.parameters()), loss, float(g["loss"])))
+    else:
+        # the fixture was recorded with the target value net moved away from the online one (make_golden.perturb_targets)
+        saved = [p_.detach().clone() for p_ in alg.networks.v_target.parameters()]
+        gen = torch.Generator().manual_seed(0 + 1000)
+        with torch.no_grad():
+            for p_ in alg.networks.v_target.parameters():
+                p_.add_((0.05 * (torch.rand(p_.shape, generator=gen) - 0.5)).to(p_.device))
+        if abs(next(alg.networks.v_target.parameters()).detach().double().sum().item() - float(g["chk/vt_w0_sum"])) > 1e-5:
+            out = {"checked": False, "reason": "perturbed target net does not reproduce the fixture's checksum"}
+        else:
+            alg._compute_gradient(data, 0)   # PEV
+            pev = compare("pev_grad/", list(alg.networks.v.parameters()), _num(alg.tb_info["Loss/Critic loss-RL iter"]), float(g["pev_loss"]))
+            alg._compute_gradient(data, 1)   # PIM
+            pim = compare("pim_grad/", list(alg.networks.policy.parameters()), _num(alg.tb_info["Loss/Actor loss-RL iter"]), float(g["pim_loss"]))
+            out.update({k: max(pev[k], pim[k]) for k in pev})
+            out["pev"], out["pim"] = pev, pim
+        with torch.no_grad():
+            for p_, s0 in zip(alg.networks.v_target.parameters(), saved):
+                p_.copy_(s0)
+    if out.get("checked"):
+        out["ok"] = bool(out["grad_rel_l2"] < PARITY_TOL and out["grad_norm_rel"] < PARITY_TOL and out["loss_rel"] <= PARITY_TOL)
+    torch.cuda.synchronize()
+    return out
+
+
+
+def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, check_parity=False, overlap=True):
     """Times `steps` updates of one workload on this rank's GPU (all ranks call it together) and returns the
     measurements; rank 0 turns them into the record."""
     rank, world, device, dist = ctx["rank"], ctx["world"], ctx["device"], ctx["dist"]
     cfg = CONFIGS[workload]
     torch.manual_seed(0)   # identical random-init weights on every replica
+    # kernel variants travel in the descriptors (GopsRolloutDesc.variant_flags); the algorithm classes build theirs from this default
+    saved_flags, hb.DEFAULT_VARIANT_FLAGS = hb.DEFAULT_VARIANT_FLAGS, flags
     with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
         alg = create_alg(**alg_kwargs(cfg, 0), mlp_dtype=dtype)
     alg.networks.to(device)
     if cfg["alg"] == "INFADP":   # cfg3 / cfg5: one step = one local_update, PEV and PIM alternate
         alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]
+    parity = None
+    if check_parity and rank == 0 and dtype == "fp32":
+        parity = parity_stamp(alg, cfg, workload, device, "exact fp32 MFMA (GOPS_VF_STREAMED_FP32 | GOPS_VF_DW_F32)" if flags else "default")
     data = {k: v.to(device) for k, v in make_batch(cfg, 1000 + rank).items()}   # per-rank shard
-    reducer = GradAllReducer(overlap=os.environ.get("GOPS_BENCH_OVERLAP", "1") != "0")   # (A/B knob: 0 = one flat all-reduce behind the whole backward)
+    reducer = GradAllReducer(overlap=overlap)   # (overlap=False: one flat all-reduce behind the whole backward)
 
     def step(it):
         if world == 1:
@@ -335,9 +514,14 @@ def run_workload(workload, dtype, steps, warmup, profile_steps, ctx):
     variant = 0
     for ro in list(getattr(alg, "_rollouts", {}).values()) + [o for o in getattr(alg, "_cache", {}).values() if hasattr(o, "desc")]:
         variant |= max(0, hb.lib().gops_rollout_variant(ro.desc))
+    payload = None
+    if world > 1:   # what one update all-reduces: the flat gradient buffer(s) of the network(s) it trains
+        payload = {name: sum(p.numel() for p in net.parameters()) * 4 for name, net in alg.networks.net_dict.items()} \
+            if hasattr(alg.networks, "net_dict") else {"policy": sum(p.numel() for p in alg.networks.policy.parameters()) * 4}
     del alg, data
     torch.cuda.empty_cache()
-    return {"elapsed": elapsed, "kern": kern, "variant": variant}
+    hb.DEFAULT_VARIANT_FLAGS = saved_flags
+    return {"elapsed": elapsed, "kern": kern, "variant": variant, "parity": parity, "allreduce_payload_bytes": payload}
 
 
 def record_of(workload, dtype, steps, warmup, world, m):
@@ -378,6 +562,7 @@ def record_of(workload, dtype, steps, warmup, world, m):
                        for k in kern if kern[k][1] > 0},
         "kernel_variant": variant_label(m.get("variant", 0), dt),
         "host_sync_per_step": os.environ.get("GOPS_EAGER_LOG", "0") not in ("", "0"),
+        "parity": m.get("parity"),
     }
 
 
@@ -441,23 +626,59 @@ def main():
     ctx = {"rank": rank, "world": world, "device": device, "dist": dist}
 
     workload = args.workload or HEADLINE
-    m = run_workload(workload, args.dtype, args.steps, args.warmup, min(args.steps, 100), ctx)
+    m = run_workload(workload, args.dtype, args.steps, args.warmup, min(args.steps, 100), ctx, check_parity=True)
     out = record_of(workload, args.dtype, args.steps, args.warmup, world, m) if rank == 0 else None
-    if world > 1 and rank == 0:
-        out["backend"] = "nccl (RCCL)" if backend == "nccl" else f"{backend} - {world} ranks on {torch.cuda.device_count()} GPU(s): multi-rank logic only, not a scaling number"
+    if world > 1:
+        # N > 1: say what carried the gradients, time the collective alone, and time the update loop a second time with the
+        # all-reduce NOT overlapped (one flat collective behind the whole backward) - so that a scaling shortfall can be
+        # attributed: collective latency (allreduce_us), lost overlap (overlap.on vs .off) or something else
+        payload = m["allreduce_payload_bytes"]
+        nbytes = max(payload.values())
+        buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+        for _ in range(10):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        t_ar = torch.tensor([(time.perf_counter() - t0) / 100 * 1e6], dtype=torch.float64, device=device)
+        dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
+        m_off = run_workload(workload, args.dtype, args.steps, args.warmup, 0, ctx, overlap=False)
+        if rank == 0:
+            cfg = CONFIGS[workload]
+            out["backend"] = "nccl (RCCL)" if backend == "nccl" else f"{backend} - {world} ranks on {torch.cuda.device_count()} GPU(s): multi-rank logic only, not a scaling number"
+            out["rccl_ranks"] = world if backend == "nccl" else 0
+            out["gpus_visible"] = torch.cuda.device_count()
+            out["allreduce_payload_bytes"] = payload
+            out["allreduce_us"] = {"value": t_ar.item(), "bytes": nbytes, "calls": 100,
+                                   "what": "stand-alone in-place SUM all-reduce of one update's gradient buffer, back to back, max over ranks"}
+            out["overlap"] = {"on": {"value": out["value"], "ms_per_step": out["ms_per_step"]},
+                              "off": {"value": world * cfg["batch"] * cfg["horizon"] * args.steps / m_off["elapsed"],
+                                      "ms_per_step": m_off["elapsed"] / args.steps * 1e3},
+                              "what": "the same timed loop with GradAllReducer(overlap=True): FHADP starts the all-reduce of the output / upper "
+                                      "layers' gradients behind backward phase A while phase B still runs (headline) - and with overlap=False: "
+                                      "one flat all-reduce behind the whole backward"}
     if args.workload is None and world == 1 and not args.no_other_workloads:
         # the other BASELINE workloads, ~1 s each: same timing method, fewer steps
         others = {}
+
+        def brief(r):
+            return {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "dtype": r["dtype"],
+                    "roofline": {k: r["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_ms", "frac_vs_fp32_roof",
+                                                               "products_per_mac", "mfma_issued") if k in r["roofline"]},
+                    "kernel_variant": r["kernel_variant"], "parity": r.get("parity"),
+                    "kernels_ms": {k: v["avg_ms"] for k, v in r["kernels_ms"].items()}}
+        k_steps, k_warm = min(args.steps, 20), min(args.warmup, 5)
         for name, dtype in ALL_WORKLOADS:
-            k_steps, k_warm = min(args.steps, 20), min(args.warmup, 5)
-            mm = run_workload(name, dtype, k_steps, k_warm, min(k_steps, 10), ctx)
-            r = record_of(name, dtype, k_steps, k_warm, world, mm)
-            others[name + ("_f16" if dtype == "fp16" else "")] = {
-                "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k_steps, "dtype": r["dtype"],
-                "roofline": {k: r["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_ms", "frac_vs_fp32_roof",
-                                                           "products_per_mac") if k in r["roofline"]},
-                "kernel_variant": r["kernel_variant"],
-                "kernels_ms": {k: v["avg_ms"] for k, v in r["kernels_ms"].items()}}
+            mm = run_workload(name, dtype, k_steps, k_warm, min(k_steps, 10), ctx, check_parity=(dtype == "fp32"))
+            others[name + ("_f16" if dtype == "fp16" else "")] = brief(record_of(name, dtype, k_steps, k_warm, world, mm))
+        # the headline workload once more on the exact-fp32 kernels (v_mfma_f32_16x16x4_f32 in the rollout kernels and the
+        # weight-gradient GEMM): what a strict-fp32 reader takes as the figure, and the parity distance of THAT arithmetic
+        mm = run_workload(workload, "fp32", k_steps, k_warm, min(k_steps, 10), ctx, flags=hb.VF_STREAMED_FP32 | hb.VF_DW_F32, check_parity=True)
+        others["exact_fp32"] = dict(brief(record_of(workload, "fp32", k_steps, k_warm, world, mm)), workload=workload,
+                                    variant_flags="GOPS_VF_STREAMED_FP32 | GOPS_VF_DW_F32")
         out["workloads"] = others
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

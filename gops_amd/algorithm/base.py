@@ -86,6 +86,72 @@ class AlgorithmBase(metaclass=ABCMeta):
         self.networks.eval()
 
 
+class PrecisionGuard:
+    """When must a launch leave the plane-split kernels for exact fp32 products?  A measured rule.
+
+    The default 256-wide kernels carry a weight as bf16 + scaled f16 residual (>= 19 significant bits, csrc/common.h SplitDev),
+    i.e. they evaluate the network with weights moved by up to ~2^-20 relative - 8 - 16 fp32 ulps.  On random-init and on most
+    trained weights that is far inside the 1e-4 bar (measured 2e-6 .. 3e-5 against the reference, tests/test_trained256_gpu.py);
+    on an ill-conditioned closed loop it is not: the reference-trained pyth_lq policy with a saturated tanh head
+    (t256_fhadp_lq_s4a2_elu_sat: the REFERENCE's own gradient moves 6.6e-5 under 1-ulp weight moves) lands 3.5e-4 from the
+    reference on the plane-split forward and 3.2e-5 on the exact-fp32 forward.  Only the FORWARD matters (the sweep is linear once
+    the forward has fixed states and activations: plane-split sweep + weight-gradient GEMM behind an exact forward measure the same as
+    all-exact), and conditioning cannot be read off a description - so it is measured: every `interval` gradients (and at the
+    first one: a loaded checkpoint may already be there) the gradient of the current batch is formed twice, with the launch's own
+    kernels and with `FWD_EXACT` added, and if their relative L2 distance exceeds `threshold` the algorithm stays on the
+    exact-fp32 forward from then on (sticky).  Cost: two extra gradients per `interval` updates (0.4 % at the default 500), one
+    host sync per check.  `GOPS_PRECISION_CHECK_INTERVAL=0` (or `precision_check_interval=0`) switches the guard off."""
+
+    def __init__(self, interval=None, threshold=None):
+        import os
+        self.interval = int(os.environ.get("GOPS_PRECISION_CHECK_INTERVAL", 500)) if interval is None else int(interval)
+        self.threshold = float(os.environ.get("GOPS_PRECISION_THRESHOLD", 5e-5)) if threshold is None else float(threshold)
+        self.count = 0            # gradients seen
+        self.exact = False        # sticky: the forward runs on exact fp32 products from here on
+        self.last_distance = None
+        self.checks = 0
+
+    @staticmethod
+    def fwd_exact_flags():
+        from gops_amd import hip_backend as hb
+        return hb.VF_NO_STATIONARY_SPLIT | hb.VF_NO_STREAMED_SPLIT_FWD | hb.VF_NO_STREAMED_SPLIT_VALUE
+
+    def flags(self) -> int:
+        """Variant flags of the owner's launches right now (on top of hip_backend.DEFAULT_VARIANT_FLAGS)."""
+        from gops_amd import hip_backend as hb
+        return hb.DEFAULT_VARIANT_FLAGS | (self.fwd_exact_flags() if self.exact else 0)
+
+    def due(self) -> bool:
+        """Call once per computed gradient; True when this one is to be checked."""
+        self.count += 1
+        if self.exact or self.interval <= 0 or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            return False
+        return self.count == 1 or self.count % self.interval == 0
+
+    def check(self, flat_gradient) -> float:
+        """`flat_gradient(flags) -> 1-D device tensor`: the owner's gradient of the batch at hand under the given variant flags
+        (a fresh tensor).  Returns the measured distance and switches to the exact forward when it exceeds the threshold."""
+        from gops_amd import hip_backend as hb
+        base = hb.DEFAULT_VARIANT_FLAGS
+        g_split = flat_gradient(base)
+        g_exact = flat_gradient(base | self.fwd_exact_flags())
+        d = (g_split.double() - g_exact.double()).norm() / g_exact.double().norm().clamp_min(1e-300)
+        try:   # data-parallel replicas take the decision together (the largest distance any rank saw)
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(d, op=dist.ReduceOp.MAX)
+        except RuntimeError:
+            pass
+        self.last_distance = float(d.item())
+        self.checks += 1
+        if not (self.last_distance <= self.threshold):   # (NaN counts as exceeded)
+            self.exact = True
+            import warnings
+            warnings.warn(f"gops_amd: plane-split and exact-fp32 forward differ by {self.last_distance:.2e} (relative L2 of the gradient, "
+                          f"threshold {self.threshold:.0e}) - this network stays on the exact-fp32 forward from here on")
+        return self.last_distance
+
+
 # ---- helpers shared by the HIP-backed algorithms ---------------------------------------------
 _INFO_KEYS = ("state", "ref_points", "path_num", "u_num", "ref_time", "surr_state")
 

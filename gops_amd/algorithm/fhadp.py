@@ -15,10 +15,10 @@ import torch
 from gops_amd.utils.common_utils import make_adam
 
 from gops_amd import hip_backend as hb
-from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, batch_to_device, cuda_device_of,
+from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, PrecisionGuard, batch_to_device, cuda_device_of,
                                      grad_buffers)
 from gops_amd.utils.hip_graph import StepGraphCache
-from gops_amd.utils.lazy_scalar import LazyScalar, lazy_enabled, scalar
+from gops_amd.utils.lazy_scalar import scalar
 from gops_amd.create_pkg.create_apprfunc import create_apprfunc
 from gops_amd.create_pkg.create_env_model import create_env_model
 from gops_amd.utils.common_utils import get_apprfunc_dict
@@ -52,6 +52,8 @@ class FHADP(AlgorithmBase):
         self.mlp_dtype = kwargs.get("mlp_dtype", "fp32")
         self.tb_info = dict()
         self._rollouts = {}
+        # measured rule for leaving the plane-split forward (algorithm/base.py PrecisionGuard); fp16 launches state their own tolerance
+        self.precision_guard = PrecisionGuard(kwargs.get("precision_check_interval"), kwargs.get("precision_threshold"))
         self._update_graph, self._grad_graph, self._grad_graph_b = StepGraphCache(), StepGraphCache(), StepGraphCache()
 
     @property
@@ -64,6 +66,7 @@ class FHADP(AlgorithmBase):
         self._t0 = time.time()
         batch = self._device_batch(data)
         opt = self.networks.policy_optimizer
+        self._precision_check(batch)
 
         def update(b):
             loss = self._gradient_kernels(b)
@@ -91,6 +94,7 @@ class FHADP(AlgorithmBase):
         # first layer's GEMM + reduce still run on this one (GOPS_VF_BWD_PHASE_A / _B); `reducer.average_` later only waits.
         self._t0 = time.time()
         batch = self._device_batch(data)
+        self._precision_check(batch)
         work = batch["obs"].shape[0] * self.pre_horizon
         grad_buffers(self.networks.policy)   # (allocates the flat gradient buffer on first use)
         grads = [p._grad for p in self.networks.policy.parameters()]
@@ -121,26 +125,45 @@ class FHADP(AlgorithmBase):
     # ------------------------------------------------------------------------------------------
     def _rollout_for(self, batch: int, device) -> hb.Rollout:
         policy = self.networks.policy
-        key = (batch, self.pre_horizon, float(self.gamma), str(device), hb.dtype_id(self.mlp_dtype))
+        flags = self._variant_flags()
+        key = (batch, self.pre_horizon, float(self.gamma), str(device), hb.dtype_id(self.mlp_dtype), flags)
         ro = self._rollouts.get(key)
         mlp = policy.hip_mlp()
         if ro is None:
             env = self.envmodel.hip_env(policy.act_low_lim.cpu().numpy(), policy.act_high_lim.cpu().numpy())
             ro = hb.Rollout(env, mlp, batch=batch, horizon=self.pre_horizon, gamma=self.gamma,
-                            finite_horizon=True, need_grad=True, device=device, dtype=self.mlp_dtype)
-            self._rollouts = {key: ro}   # one live workspace: shapes rarely change between updates
+                            finite_horizon=True, need_grad=True, device=device, dtype=self.mlp_dtype, variant_flags=flags)
+            # one live workspace per kernel variant of the current shape (shapes rarely change between updates)
+            self._rollouts = {k: r for k, r in self._rollouts.items() if k[:5] == key[:5]}
+            self._rollouts[key] = ro
         else:
             ro.set_policy(mlp)
         return ro
 
+    def _variant_flags(self) -> int:
+        forced = getattr(self, "_forced_flags", None)   # (set for the duration of a precision check)
+        return self.precision_guard.flags() if forced is None else forced
+
+    def _precision_check(self, batch):
+        """PrecisionGuard (algorithm/base.py): every `interval` gradients the gradient of `batch` is formed with the launch's own
+        kernels and with the exact-fp32 forward; beyond the threshold the algorithm stays on the exact forward."""
+        if self.mlp_dtype != "fp32" or not self.precision_guard.due():
+            return
+
+        def flat_gradient(flags):
+            self._forced_flags = flags
+            try:
+                self._gradient_kernels(batch)
+            finally:
+                self._forced_flags = None
+            return self.networks.policy._flat_grad.clone()
+        self.precision_guard.check(flat_gradient)
+
     def _fill_tb(self, out, lazy=False):
-        """`out` is what `_gradient_kernels` returned - here mean(v_pi), whose negative is the loss.  lazy: leave
-        device tensors in tb_info (data-parallel path); else a LazyScalar (utils/lazy_scalar.py: read back on first
-        use; GOPS_EAGER_LOG=1: `.item()` right here, as the reference does)."""
-        if out.dim() == 1:   # the per-trajectory returns themselves (eager launches): their mean is formed when the entry is read
-            self.tb_info[tb_tags["loss_actor"]] = LazyScalar(out, negate=True, mean=True) if lazy else scalar(out, negate=True, mean=True)
-        else:
-            self.tb_info[tb_tags["loss_actor"]] = -out if lazy else scalar(out, negate=True)
+        """`out` is what `_gradient_kernels` returned - here the pair [-mean(v_pi), mean(v_pi)] of `gops_mean_loss`; entry 0 is the
+        loss.  lazy: leave a device tensor in tb_info (data-parallel path: a view, no launch); else a LazyScalar
+        (utils/lazy_scalar.py: read back on first use; GOPS_EAGER_LOG=1: `.item()` right here, as the reference does)."""
+        self.tb_info[tb_tags["loss_actor"]] = out[0] if lazy else scalar(out, 0)
 
     def _log(self, out):
         self._fill_tb(out)   # host sync, as in the reference
@@ -164,7 +187,7 @@ class FHADP(AlgorithmBase):
                 tuple(ro.workspace.data_ptr() for ro in self._rollouts.values()))
 
     def _gradient_kernels(self, batch, phase=None):
-        """Enqueue forward rollout, loss and backward sweep; returns mean(v_pi) (device scalar).  `phase`: None = all of it,
+        """Enqueue forward rollout, backward sweep and the loss reduction; returns [-mean(v_pi), mean(v_pi)] (device tensor).  `phase`: None = all of it,
         "a" = everything but the first hidden layer's weight gradient, "b" = that gradient (hip_backend.Rollout.backward)."""
         B, device = batch["obs"].shape[0], batch["obs"].device
         ro = self._rollout_for(B, device)
@@ -173,12 +196,23 @@ class FHADP(AlgorithmBase):
             ro.backward(self._grad_v(B, device), gw, gb, phase="b")
             return None
         v_pi = ro.forward(batch)["v_pi"]
-        # the loss is only logged: inside a captured graph its mean is one more node; as eager launches (large batches) the
-        # reduction kernel is left to whoever reads the log entry (LazyScalar) - v_pi is a fresh tensor of this update
-        loss_policy = v_pi if (lazy_enabled() and not torch.cuda.is_current_stream_capturing() and type(self) is FHADP) else v_pi.mean()
         gw, gb = grad_buffers(self.networks.policy)
         ro.backward(self._grad_v(B, device), gw, gb, phase=phase)
-        return loss_policy
+        # loss = -mean(v_pi) (fhadp.py:121): ONE launch (gops_mean_loss) queued with every gradient - eager, captured or replayed -,
+        # so that an update always contains the loss reduction the reference's `_compute_loss_policy` contains
+        return self._mean_of(v_pi)
+
+    _LOSS_RING = 16
+
+    def _mean_of(self, v_pi):
+        """[-mean(v_pi), mean(v_pi)] on the device.  The result lands in one of a small ring of persistent buffers (no allocation, no
+        extra launch): a log entry (`LazyScalar`) read within `_LOSS_RING` updates of its own sees its own value."""
+        ring = self.__dict__.setdefault("_loss_ring", [])
+        if not ring or ring[0].buf.device != v_pi.device:
+            ring[:] = [hb.LossStats(v_pi.device) for _ in range(self._LOSS_RING)]
+            self._loss_slot = 0
+        self._loss_slot = (self._loss_slot + 1) % len(ring)
+        return ring[self._loss_slot].mean_loss(v_pi, -1.0)
 
     def _after_gradient(self, out):
         """Host-side bookkeeping that belongs to ONE computed gradient (penalty / multiplier schedules of the

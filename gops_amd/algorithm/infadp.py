@@ -15,7 +15,7 @@ import torch
 from gops_amd.utils.common_utils import make_adam
 
 from gops_amd import hip_backend as hb
-from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, batch_to_device, cuda_device_of,
+from gops_amd.algorithm.base import (_INFO_KEYS, AlgorithmBase, ApprBase, PrecisionGuard, batch_to_device, cuda_device_of,
                                      grad_buffers)
 from gops_amd.utils.hip_graph import StepGraphCache
 from gops_amd.utils.lazy_scalar import scalar
@@ -69,6 +69,8 @@ class INFADP(AlgorithmBase):
         self._cache = {}
         self._graphs = {}
         self._polyak = {}   # net name -> hb.PolyakUpdater
+        # measured rule for leaving the plane-split forward (algorithm/base.py PrecisionGuard), one per trained network
+        self.precision_guard = {m: PrecisionGuard(kwargs.get("precision_check_interval"), kwargs.get("precision_threshold")) for m in ("v", "policy")}
         self._bufs = {}     # persistent device scratch: loss gradient, loss scalars (read them before the next update of the same mode)
 
     @property
@@ -82,6 +84,7 @@ class INFADP(AlgorithmBase):
         batch = batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
         mode = self._mode(iteration)
         opt = self.networks.optimizer_dict[mode]
+        self._precision_check(mode, batch)
 
         def update(b):
             scalars = self._gradient_kernels(mode, b)
@@ -104,6 +107,7 @@ class INFADP(AlgorithmBase):
         start_time = time.time()
         batch = batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
         mode = self._mode(iteration)
+        self._precision_check(mode, batch)
         scalars = self._gradient_kernels(mode, batch)
         if mode == "v":
             self.tb_info[tb_tags["loss_critic"]], self.tb_info[tb_tags["critic_avg_value"]] = scalars[0], scalars[1]
@@ -143,27 +147,50 @@ class INFADP(AlgorithmBase):
     # ------------------------------------------------------------------------------------------
     def _rollout_for(self, batch: int, device, need_grad: bool) -> hb.Rollout:
         nets = self.networks
-        key = (batch, self.forward_step, float(self.gamma), str(device), need_grad, hb.dtype_id(self.mlp_dtype))
+        flags = self._variant_flags("policy" if need_grad else "v")   # (PEV's gradient-free backup belongs to the value update)
+        key = (batch, self.forward_step, float(self.gamma), str(device), need_grad, hb.dtype_id(self.mlp_dtype), flags)
         pol, vt = nets.policy.hip_mlp(), nets.v_target.hip_mlp()
         ro = self._cache.get(key)
         if ro is None:
             env = self.envmodel.hip_env(nets.policy.act_low_lim.cpu().numpy(), nets.policy.act_high_lim.cpu().numpy())
             ro = hb.Rollout(env, pol, batch=batch, horizon=self.forward_step, gamma=self.gamma,
-                            finite_horizon=False, need_grad=need_grad, value=vt, device=device, dtype=self.mlp_dtype)
+                            finite_horizon=False, need_grad=need_grad, value=vt, device=device, dtype=self.mlp_dtype, variant_flags=flags)
             self._cache[key] = ro
         else:
             ro.set_policy(pol, vt)
         return ro
 
     def _value_for(self, batch: int, device) -> hb.ValueNet:
-        key = ("v", batch, str(device), hb.dtype_id(self.mlp_dtype))
-        mlp = self.networks.v.hip_mlp(self.mlp_dtype)
+        flags = self._variant_flags("v")
+        key = ("v", batch, str(device), hb.dtype_id(self.mlp_dtype), flags)
+        mlp = self.networks.v.hip_mlp(self.mlp_dtype, variant_flags=flags)
         vn = self._cache.get(key)
         if vn is None:
             vn = self._cache[key] = hb.ValueNet(mlp, batch, device=device)
         else:
             vn.mlp = mlp
         return vn
+
+    def _variant_flags(self, mode: str) -> int:
+        forced = getattr(self, "_forced_flags", None)   # (set for the duration of a precision check)
+        return self.precision_guard[mode].flags() if forced is None else forced
+
+    def _precision_check(self, mode: str, batch):
+        """PrecisionGuard (algorithm/base.py) of the network this iteration trains: every `interval` of ITS gradients the gradient of
+        `batch` is formed with the launch's own kernels and with the exact-fp32 forward; beyond the threshold that network's
+        launches stay on the exact forward."""
+        guard = self.precision_guard[mode]
+        if self.mlp_dtype != "fp32" or not guard.due():
+            return
+
+        def flat_gradient(flags):
+            self._forced_flags = flags
+            try:
+                self._gradient_kernels(mode, batch)
+            finally:
+                self._forced_flags = None
+            return self.networks.net_dict[mode]._flat_grad.clone()
+        guard.check(flat_gradient)
 
     def _mode(self, iteration) -> str:
         return "v" if iteration % (self.pev_step + self.pim_step) < self.pev_step else "policy"

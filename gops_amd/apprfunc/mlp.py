@@ -43,17 +43,19 @@ class _HipMlpMixin:
             object.__setattr__(self, "_linear_cache", layers)
         return layers
 
-    def hip_mlp(self, dtype=None):
+    def hip_mlp(self, dtype=None, variant_flags=None):
+        """`variant_flags` (GOPS_VF_*, None = hip_backend.DEFAULT_VARIANT_FLAGS) only matter for plain MLP batches (`ValueNet`,
+        `MlpNet`); a rollout takes its own."""
         from gops_amd import hip_backend as hb
         if self._output_activation != "linear":
             raise RuntimeError("the HIP rollout supports a linear output activation only")
         layers = self.linear_layers()
         # the struct only holds raw pointers: rebuild it when the storage moved (.to(device), load)
-        key = tuple(l.weight.data_ptr() for l in layers) + tuple(l.bias.data_ptr() for l in layers) + (hb.dtype_id(dtype),)
+        key = tuple(l.weight.data_ptr() for l in layers) + tuple(l.bias.data_ptr() for l in layers) + (hb.dtype_id(dtype), variant_flags)
         cached = _HIP_CACHE.get(self)
         if cached is None or cached[0] != key:
             mlp = hb.make_mlp([l.weight.data for l in layers], [l.bias.data for l in layers],
-                              self._hidden_activation, dtype)
+                              self._hidden_activation, dtype, variant_flags=variant_flags)
             _HIP_CACHE[self] = (key, mlp)
             return mlp
         return cached[1]

@@ -539,6 +539,121 @@ def golden_trained():
 
 
 # ------------------------------------------------------------------------------------------
+# 4b. 256-wide networks TRAINED by the unmodified reference (`FHADP._local_update`, fhadp.py:87-90;
+#     `INFADP.local_update`, infadp.py:101-104, incl. its Polyak step): a few hundred Adam updates on
+#     fresh synthetic batches, then one gradient evaluation on a held-out batch.  The BASELINE shapes
+#     are all 256-wide, i.e. they run the plane-split (bf16 + f16 weight planes) kernels; the shipped
+#     checkpoints above are 64-wide.  These fixtures pin the 1e-4 bar on weights that have MOVED
+#     (larger magnitudes, a saturating tanh head in the *_sat case).
+# ------------------------------------------------------------------------------------------
+TRAINED256 = {
+    # name: (cfg of the evaluation batch, training: updates / batch / learning rate)
+    "t256_fhadp_idp_h30_gelu": (dict(alg="FHADP", env_id="pyth_idpendulum", batch=208, horizon=30, hidden=(256, 256),
+                                     act="gelu", gamma=1.0), dict(updates=300, batch=256, lr=1e-3)),
+    "t256_fhadp_veh_p30_elu": (dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=176, horizon=30, pre_horizon=30,
+                                    hidden=(256, 256), act="elu", gamma=1.0), dict(updates=300, batch=128, lr=1e-3)),
+    # a learning rate high enough that the tanh head saturates (80 - 95 % of the actions beyond 0.99) - on pyth_lq, where the
+    # closed loop stays well-conditioned (the same experiment on veh3dofconti ends in a chaotic bang-bang policy whose fp32
+    # gradient scatters by 7e-2 under 1-ulp weight moves: not a parity fixture)
+    "t256_fhadp_lq_s4a2_elu_sat": (dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=192, horizon=30,
+                                        hidden=(256, 256), act="elu", gamma=0.99), dict(updates=300, batch=256, lr=3e-3)),
+    "t256_infadp_lq_s4a2_relu": (dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=240, horizon=10,
+                                      hidden=(256, 256), act="relu", gamma=0.99), dict(updates=400, batch=256, lr=1e-3)),
+    "t256_infadp_lq_s4a2_gelu": (dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=240, horizon=10,
+                                      hidden=(256, 256), act="gelu", gamma=0.99), dict(updates=400, batch=256, lr=1e-3)),
+    # the shape of BASELINE configs[2] (three 256-wide relu layers + tail value net: the thinnest parity margin)
+    "t256_infadp_veh_p10_relu3": (dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=144, horizon=10, pre_horizon=10,
+                                       hidden=(256, 256, 256), act="relu", gamma=0.99), dict(updates=300, batch=128, lr=1e-3)),
+}
+
+
+def ref_fp32_scatter(alg, net_names, grad_fn, trials=4):
+    """How far the REFERENCE's own fp32 gradient moves when every weight of `net_names` moves by at most one ulp: the largest
+    rel-L2 distance of `grad_fn()` (flat gradient) to its unperturbed value over `trials` seeded perturbations.  Near a trained
+    optimum the mean gradient is a small difference of large per-trajectory terms, and this scatter reaches 1e-4 (veh3dofconti):
+    a fixture's parity bar cannot be tighter than the noise of the thing it is compared with."""
+    base = grad_fn().double()
+    params = [p for n in net_names for p in getattr(alg.networks, n).parameters()]
+    saved = [p.detach().clone() for p in params]
+    gen = torch.Generator().manual_seed(0)
+    worst = 0.0
+    for _ in range(trials):
+        with torch.no_grad():
+            for p, s0 in zip(params, saved):
+                p.copy_(s0 * (1 + (torch.rand(s0.shape, generator=gen) - 0.5) * 1.2e-7))
+        worst = max(worst, float((grad_fn().double() - base).norm() / base.norm()))
+    with torch.no_grad():
+        for p, s0 in zip(params, saved):
+            p.copy_(s0)
+    return worst
+
+
+def golden_trained256(only=None):
+    for name, (cfg, tr) in TRAINED256.items():
+        if only and name not in only:
+            continue
+        seed = zlib.crc32(name.encode()) % 1000
+        alg = build_alg(cfg, seed, policy_learning_rate=tr["lr"], value_learning_rate=tr["lr"])
+        w0 = torch.cat([p.detach().reshape(-1) for p in alg.networks.policy.parameters()]).clone()
+        curve = []
+        for it in range(tr["updates"]):
+            batch = make_batch(cfg, 10_000 + 7 * seed + it, batch=tr["batch"])
+            if cfg["alg"] == "FHADP":
+                alg._local_update(batch, it)
+                curve.append(alg.tb_info["Loss/Actor loss-RL iter"])
+            else:
+                alg.local_update(batch, it)      # PEV and PIM by `iteration % (pev_step + pim_step)`, Polyak inside
+                curve.append(alg.tb_info.get("Loss/Actor loss-RL iter", np.nan))
+        w1 = torch.cat([p.detach().reshape(-1) for p in alg.networks.policy.parameters()])
+        data = make_batch(cfg, seed)
+        data["done"][-2:] = 1.0
+        out = {"in/" + k: v.numpy().copy() for k, v in data.items()}
+        out["meta/cfg"] = json.dumps(dict(cfg=cfg, extra={}, seed=seed, training=tr))
+        out["meta/loss_curve"] = np.asarray(curve, dtype=np.float64)
+        out["meta/policy_moved_rel"] = float((w1 - w0).norm() / w0.norm())
+        out["meta/policy_absmax"] = float(w1.abs().max())
+        out.update(sd_to_np(alg.networks.state_dict()))
+        out.update(model_consts(alg.envmodel))
+        if cfg["alg"] == "FHADP":
+            alg._compute_gradient(data)
+            for i, gr in enumerate(grads_of(alg.networks.policy)):
+                out[f"grad/{i}"] = gr.numpy()
+            out["loss"] = alg.tb_info["Loss/Actor loss-RL iter"]
+            with torch.no_grad():   # how saturated the tanh head is on the evaluation batch (|a| of the first step)
+                a0 = alg.networks.policy(data["obs"], 1)
+            out["meta/act0_absmean"] = float(a0.abs().mean())
+            out["meta/act0_sat_share"] = float((a0.abs() > 0.99).float().mean())
+
+            def flat_grad():
+                alg._compute_gradient(data)
+                return torch.cat([gr.reshape(-1) for gr in grads_of(alg.networks.policy)])
+            out["meta/ref_fp32_scatter"] = ref_fp32_scatter(alg, ["policy"], flat_grad)
+        else:
+            _, info = alg.get_remote_update_info(data, 0)  # PEV
+            for i, gr in enumerate(info["v"]):
+                out[f"pev_grad/{i}"] = gr.detach().numpy().copy()
+            out["pev_loss"] = alg.tb_info["Loss/Critic loss-RL iter"]
+            out["pev_vmean"] = alg.tb_info["Train/Critic avg value-RL iter"]
+            _, info = alg.get_remote_update_info(data, 1)  # PIM
+            for i, gr in enumerate(info["policy"]):
+                out[f"pim_grad/{i}"] = gr.detach().numpy().copy()
+            out["pim_loss"] = alg.tb_info["Loss/Actor loss-RL iter"]
+
+            def flat_pev():
+                return torch.cat([gr.detach().reshape(-1) for gr in alg.get_remote_update_info(data, 0)[1]["v"]])
+
+            def flat_pim():
+                return torch.cat([gr.detach().reshape(-1) for gr in alg.get_remote_update_info(data, 1)[1]["policy"]])
+            out["meta/ref_fp32_scatter_pev"] = ref_fp32_scatter(alg, ["v"], flat_pev)
+            out["meta/ref_fp32_scatter_pim"] = ref_fp32_scatter(alg, ["policy", "v_target"], flat_pim)
+        print(f"{name}: policy moved {out['meta/policy_moved_rel']:.3f} (rel L2), max|w| {out['meta/policy_absmax']:.3f}, "
+              f"loss {curve[0]:.4g} -> {curve[-1]:.4g}" + (f", |a0| mean {out['meta/act0_absmean']:.3f}, saturated share "
+              f"{out['meta/act0_sat_share']:.3f}, reference fp32 scatter {out['meta/ref_fp32_scatter']:.2e}" if cfg["alg"] == "FHADP" else
+              f", reference fp32 scatter PEV {out['meta/ref_fp32_scatter_pev']:.2e} PIM {out['meta/ref_fp32_scatter_pim']:.2e}"))
+        save(name, **out)
+
+
+# ------------------------------------------------------------------------------------------
 # 5. FHADP2 (open-loop action sequence from one FiniteHorizonFullPolicy evaluation)
 # ------------------------------------------------------------------------------------------
 FHADP2_CASES = {
@@ -968,6 +1083,8 @@ if __name__ == "__main__":
         golden_fhadp2()
     if "trained" in which:
         golden_trained()
+    if "trained256" in which:
+        golden_trained256()
     if "steps" in which:
         golden_steps()
     if "small" in which:

@@ -57,6 +57,87 @@ def test_device_code_has_no_packed_fp32_instructions():
     assert kernels > 100, kernels      # the scan saw the rollout kernels ...
     assert counts[mfma] > 1000         # ... and their disassembly
     assert counts[pk] == 0, counts
+
+def test_ctypes_mirror_matches_the_header_layout(tmp_path):
+    """`gops_amd/hip_backend.py` restates every struct of include/gops_hip.h by hand (ctypes).  This compiles a C program against
+    the header (plain C: the boundary is a C ABI) that prints sizeof of every struct and offsetof of every member, and holds
+    the ctypes classes to it - a field added on one side only, or moved into what used to be padding, fails here."""
+    from gops_amd import hip_backend as hb
+    pairs = {"GopsMlp": hb.GopsMlp, "GopsMlpGrad": hb.GopsMlpGrad, "GopsEnv": hb.GopsEnv, "GopsRolloutDesc": hb.GopsRolloutDesc,
+             "GopsRolloutIn": hb.GopsRolloutIn, "GopsRolloutOut": hb.GopsRolloutOut, "GopsRolloutAdjoint": hb.GopsRolloutAdjoint,
+             "GopsStepIO": hb.GopsStepIO, "GopsAdamTensors": hb.GopsAdamTensors}
+    header = open(os.path.join(ROOT, "include", "gops_hip.h")).read()
+    declared = set(re.findall(r"typedef struct (Gops[A-Za-z]+) \{", header))
+    assert declared - {"GopsAdamState"} == set(pairs), "a struct of the header has no ctypes mirror (or the reverse)"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gops_hip.h"', "int main(void) {"]
+    for name, cls in pairs.items():
+        lines.append(f'    printf("{name} %zu\\n", sizeof({name}));')
+        for field, _ in cls._fields_:
+            lines.append(f'    printf("{name}.{field} %zu\\n", offsetof({name}, {field}));')
+    lines.append('    printf("GopsAdamState %zu\\n", sizeof(GopsAdamState));')
+    lines += ["    return 0;", "}"]
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text("\n".join(lines))
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for name, cls in pairs.items():
+        assert int(got[name]) == ctypes.sizeof(cls), (name, got[name], ctypes.sizeof(cls))
+        for field, _ in cls._fields_:
+            assert int(got[f"{name}.{field}"]) == getattr(cls, field).offset, (name, field, got[f"{name}.{field}"], getattr(cls, field).offset)
+    assert int(got["GopsAdamState"]) == 48   # HipAdam keeps it as 6 x int64 of device memory
+
+
+def test_integration_md_stub_matches_the_current_abi():
+    """INTEGRATION.md section 2 shows the ctypes stub a GOPS maintainer would add: its `GopsMlp` must be the layout of the
+    CURRENT header (v10 put `variant_flags` where v9 had padding - a stale copy would still run and silently pass garbage)."""
+    from gops_amd import hip_backend as hb
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"(class GopsMlp\(C\.Structure\):\n(?:    .*\n)+)", text)
+    assert m, "INTEGRATION.md lost its GopsMlp stub"
+    ns = {"C": ctypes}
+    exec(m.group(1), ns)
+    stub = ns["GopsMlp"]
+    assert [f[0] for f in stub._fields_] == [f[0] for f in hb.GopsMlp._fields_]
+    assert ctypes.sizeof(stub) == ctypes.sizeof(hb.GopsMlp)
+    for name, _ in stub._fields_:
+        assert getattr(stub, name).offset == getattr(hb.GopsMlp, name).offset, name
+    header = open(os.path.join(ROOT, "include", "gops_hip.h")).read()
+    abi = re.search(r"#define GOPS_HIP_ABI_VERSION (\d+)", header).group(1)
+    assert f"gops_hip_version() == {abi}" in text, "the stub asserts another ABI version than the header's"
+
+
+def test_precision_guard_schedule_and_decision():
+    """algorithm/base.py PrecisionGuard without a GPU: which gradients are checked, when it trips, that it is sticky, and the
+    flags it hands the launches."""
+    from gops_amd import hip_backend as hb
+    from gops_amd.algorithm.base import PrecisionGuard
+    g = PrecisionGuard(interval=4, threshold=5e-5)
+    assert [g.due() for _ in range(9)] == [True, False, False, True, False, False, False, True, False]   # gradients 1, 4, 8
+    base = torch.arange(1.0, 101.0)
+    seen = []
+
+    def close(flags):
+        seen.append(flags)
+        return base * (1 + (1e-6 if flags else 0.0))
+    d = g.check(close)
+    assert seen == [hb.DEFAULT_VARIANT_FLAGS, hb.DEFAULT_VARIANT_FLAGS | PrecisionGuard.fwd_exact_flags()]
+    assert 0.5e-6 < d < 2e-6 and not g.exact and g.flags() == hb.DEFAULT_VARIANT_FLAGS
+    with pytest.warns(UserWarning, match="exact-fp32 forward"):
+        d = g.check(lambda flags: base * (1 + (3e-4 if flags else 0.0)))
+    assert 2e-4 < d < 4e-4 and g.exact
+    assert g.flags() & PrecisionGuard.fwd_exact_flags() == PrecisionGuard.fwd_exact_flags()
+    assert not any(g.due() for _ in range(20))   # sticky: nothing left to decide
+    with pytest.warns(UserWarning):
+        g2 = PrecisionGuard(interval=1, threshold=5e-5)
+        g2.check(lambda flags: base * float("nan") if flags == 0 else base)   # a NaN gradient counts as exceeded
+    assert g2.exact
+    off = PrecisionGuard(interval=0)
+    assert not any(off.due() for _ in range(5))
+    # the exact-forward flags leave the sweep and the weight-gradient GEMM alone
+    f = PrecisionGuard.fwd_exact_flags()
+    assert f & (hb.VF_NO_STREAMED_SPLIT_BWD | hb.VF_DW_F32 | hb.VF_DW_EXACT | hb.VF_STREAMED_FP32) == 0
+
+
 def test_workspace_query_and_rejections_need_no_gpu():
     from gops_amd import hip_backend as hb
     d = hb.GopsRolloutDesc()
@@ -502,7 +583,9 @@ def test_remote_update_path_has_no_host_sync_before_the_collective(monkeypatch):
     from gops_amd.create_pkg.create_alg import create_alg
     from gops_amd.trainer.grad_sync import GradAllReducer
     from gops_amd.utils.tensorboard_setup import tb_tags
-    alg = create_alg(**_fhadp_kwargs())
+    # (precision_check_interval=0: the PrecisionGuard's check - one deliberate host read every 500 gradients - is not what this
+    #  test is about; tests/test_trained256_gpu.py covers it)
+    alg = create_alg(**_fhadp_kwargs(precision_check_interval=0))
     monkeypatch.setattr(alg, "_device_batch", lambda d: d)
     monkeypatch.setattr(alg._grad_graph, "run", lambda *a, **k: _SyncTrap())
     monkeypatch.setattr(alg, "_log", lambda *a, **k: (_ for _ in ()).throw(AssertionError("_log syncs the host")))
@@ -518,7 +601,7 @@ def test_remote_update_path_has_no_host_sync_before_the_collective(monkeypatch):
     kw.update(algorithm="INFADP", policy_func_name="DetermPolicy", value_func_type="MLP", value_func_name="StateValue",
               value_hidden_sizes=[64, 64], value_hidden_activation="gelu", value_learning_rate=1e-3)
     kw.pop("pre_horizon", None)
-    inf = create_alg(**kw)
+    inf = create_alg(**kw, precision_check_interval=0)
     import gops_amd.algorithm.infadp as infadp_mod
     monkeypatch.setattr(infadp_mod, "batch_to_device", lambda d, dev, keys: d)
     monkeypatch.setattr(infadp_mod, "cuda_device_of", lambda nets: torch.device("cpu"))

@@ -32,13 +32,16 @@ FHADP_CASES = ["fhadp_lq_s4a2_tanh", "fhadp_lq_s6a3_relu", "fhadp_idp_gelu", "fh
                "fhadp_idp_repeat2_gelu", "fhadp_pendulum_repeat3_tanh",   # ActionRepeatModel
                "fhadp_veh_p10_nomask_elu",   # mask_at_done = False
                # the reference's shipped trained checkpoints (saturating policies, H = 80, limits != +-1)
-               "fhadp_trained_idp_h80", "fhadp_trained_lqs3a1_h80"]
+               "fhadp_trained_idp_h80", "fhadp_trained_lqs3a1_h80",
+               # 256-wide networks trained by the reference for 300 updates (make_golden.py trained256)
+               "t256_fhadp_idp_h30_gelu", "t256_fhadp_veh_p30_elu", "t256_fhadp_lq_s4a2_elu_sat"]
 INFADP_CASES = ["infadp_lq_s4a2_gelu", "infadp_idp_gelu", "infadp_veh_p10_relu", "infadp_lq_s5a1_obsscale_shift",
                 "mac_lq_s4a2_gelu", "mac_idp_elu", "infadp_cartpole_gelu", "mac_pendulum_elu", "infadp_pendulum_tanh",
                 "infadp_veh2dof_p10_gelu",   # gops/algorithm/mac.py: INFADP's losses (its Bayes model-bias term is inert)
                 "infadp_lq_s4a2_repeat3_elu", "infadp_cartpole_repeat2_relu",   # ActionRepeatModel
                 "infadp_cartpole_nomask_relu", "infadp_veh2dof_nomask_gelu",   # mask_at_done = False
-                "infadp_trained_lqs4a2", "infadp_trained_idp"]
+                "infadp_trained_lqs4a2", "infadp_trained_idp",
+                "t256_infadp_lq_s4a2_relu", "t256_infadp_lq_s4a2_gelu", "t256_infadp_veh_p10_relu3"]
 
 
 @pytest.mark.parametrize("name", STEP_CASES)

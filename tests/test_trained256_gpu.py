@@ -1,0 +1,296 @@
+"""GPU: the plane-split kernels (bf16 + f16 weight planes, >= 19-bit weights: what every BASELINE shape runs by default) on
+256-wide networks TRAINED by the unmodified reference (`tests/golden/make_golden.py trained256`: 300 - 400 `local_update`s of
+`gops/algorithm/fhadp.py:87-90` / `infadp.py:101-133`, then one gradient on a held-out batch).  Random-init weights are small
+and centred; trained ones have moved (and in the *_sat case saturate the tanh head), so this is where the 2^-20 weight
+representation has to hold the north_star bar (1e-4 relative L2) - and where it is compared with the exact-fp32 kernels of the
+same library on the same fixture.  Every case prints all distances; DESIGN.md section 2 quotes them.
+
+What round 5 measured here (MI355X):
+  * the error of the plane-split path is carried by the FORWARD alone: an exact-fp32 forward with the plane-split sweep and
+    weight-gradient GEMM behind it is as close to the reference as the all-exact launch (the sweep is linear once the forward
+    has fixed states and activations);
+  * five of the six fixtures sit at 3e-6 .. 3e-5 on the default kernels; the reference-trained pyth_lq policy with a saturated
+    tanh head (the REFERENCE's own gradient moves 6.6e-5 under 1-ulp weight moves) is at 3.5e-4 plane-split, 3.2e-5 with the exact
+    forward: `NEEDS_EXACT_FORWARD`, and the case the algorithm classes' `PrecisionGuard` (algorithm/base.py) has to catch;
+  * veh3dofconti: the appended reference headings (exemption 1: a 1 ms finite difference in fp32 whose last bit
+    depends on the host's libm) reach the GRADIENT of a trained policy - 1.6e-4 (INFADP 256^3 relu) / 4e-5 (FHADP P = 30) whatever
+    the arithmetic; with the reference's appended points handed in (`GopsRolloutIn.ref_appended`, here from the oracle's restatement
+    on this host) the same launches are at 3e-6 / 1e-5.  The 1e-4 assertions of the veh3dofconti fixtures run in that mode, the
+    kernel-evaluated headings are bounded by `VEH_HEADING_BOUND`."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_meta, load_golden, rel_l2
+from helpers import data_from_golden, hip_env_from_oracle, nets_from_golden, oracle_env, to_device
+from oracle import adp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+VEH_HEADING_BOUND = 5e-4
+NEEDS_EXACT_FORWARD = {"t256_fhadp_lq_s4a2_elu_sat"}
+
+FHADP_T256 = ["t256_fhadp_idp_h30_gelu", "t256_fhadp_veh_p30_elu", "t256_fhadp_lq_s4a2_elu_sat"]
+INFADP_T256 = ["t256_infadp_lq_s4a2_relu", "t256_infadp_lq_s4a2_gelu", "t256_infadp_veh_p10_relu3"]
+
+
+def bar_of(g, key="meta/ref_fp32_scatter"):
+    """1e-4 - unless the REFERENCE's own fp32 gradient of this fixture moves by more than half of that when its weights move by
+    one ulp (`make_golden.ref_fp32_scatter`, recorded with the fixture): then twice that scatter.  Of the six fixtures only the
+    saturated LQ policy (99.7 % of its first actions beyond 0.99: the gradient flows through the few that are not) is there,
+    at 6.6e-5."""
+    return max(TOL, 2.0 * float(g[key]))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+def _variants():
+    from gops_amd import hip_backend as hb
+    from gops_amd.algorithm.base import PrecisionGuard
+    return {
+        "default": 0,                                                  # what bench.py times: plane-split where eligible
+        "streamed_split": hb.VF_NO_STATIONARY_SPLIT,                   # the streamed plane-split kernels (B > 4096 takes these)
+        "exact_forward": PrecisionGuard.fwd_exact_flags(),             # the guard's fallback: exact forward, plane-split sweep / dW
+        "exact_fp32": hb.VF_STREAMED_FP32 | hb.VF_DW_F32,              # v_mfma_f32_16x16x4_f32 throughout
+    }
+
+
+def _mlp(net, dev, flags):
+    from gops_amd import hip_backend as hb
+    ws = [w.detach().to(dev).contiguous() for w in net["w"]]
+    bs = [b.detach().to(dev).contiguous() for b in net["b"]]
+    return hb.make_mlp(ws, bs, net["act"], variant_flags=flags), ws, bs
+
+
+def _flat(grads):
+    return torch.cat([g.reshape(-1).cpu() for g in grads])
+
+
+def _golden_flat(g, prefix, n):
+    return torch.cat([torch.from_numpy(g[f"{prefix}{i}"]).reshape(-1) for i in range(n)])
+
+
+def _appended_points(cfg, data):
+    """The H reference points a veh3dofconti rollout appends, from the oracle's restatement of MultiRefTrajModel on this host
+    (same libm as the reference run that recorded the fixture): [B, H, 4]."""
+    P, H, dt = cfg["pre_horizon"], cfg["horizon"], 0.1
+    t = data["ref_time"].clone()
+    pts = []
+    for _ in range(H):   # veh_step: nt = ref_time + dt (accumulated in fp32), new point at nt + P dt
+        t = t + dt
+        pts.append(orc.ref_point(t + P * dt, data["path_num"], data["u_num"]))
+    return torch.stack(pts, 1).contiguous()
+
+
+def _policy_gradient(henv, nets, cfg, ddev, dev, flags, tail):
+    from gops_amd import hip_backend as hb
+    B = ddev["obs"].shape[0]
+    pol, pw, pb = _mlp(nets["policy"], dev, flags)
+    vt = _mlp(nets["v_target"], dev, flags)[0] if tail else None
+    ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=not tail, need_grad=True,
+                    value=vt, variant_flags=flags)
+    variant = hb.lib().gops_rollout_variant(ctypes.byref(ro.desc))
+    res = ro.forward(ddev)
+    gw, gb = [torch.empty_like(w) for w in pw], [torch.empty_like(b) for b in pb]
+    ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
+    torch.cuda.synchronize()
+    return variant, -res["v_pi"].double().mean().item(), [t for pair in zip(gw, gb) for t in pair]
+
+
+def _check_table(name, report, bar, what=""):
+    for vname, (dl, err, worst) in report.items():
+        split = vname in ("default", "streamed_split")
+        assert dl <= TOL, (name, what, vname, dl)
+        if split and name in NEEDS_EXACT_FORWARD:
+            # the documented case that needs the exact forward: must still be beyond the bar on plane-split kernels, or the
+            # exemption (and the guard's reason to exist) has outlived its cause
+            assert err > bar, (name, vname, err, "no longer beyond the bar on the plane-split kernels: drop it from NEEDS_EXACT_FORWARD")
+        else:
+            assert err < bar and worst < bar, (name, what, vname, err, worst, bar)
+
+
+@pytest.mark.parametrize("name", FHADP_T256)
+def test_fhadp_trained_256_wide_vs_reference(name, dev):
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg = meta["cfg"]
+    env = oracle_env(cfg, meta["extra"], g)
+    nets, _ = nets_from_golden(g, cfg)
+    data = data_from_golden(g)
+    veh = cfg["env_id"] == "pyth_veh3dofconti"
+    henv = hip_env_from_oracle(env, nets["policy"])
+    modes = {"": data}
+    if veh:   # bit-parity mode for the 1e-4 assertions; the kernel's own headings are bounded separately
+        modes = {"ref_appended": dict(data, ref_appended=_appended_points(cfg, data)), "kernel_headings": data}
+    for mode, d in modes.items():
+        ddev = to_device(d, dev)
+        report = {}
+        for vname, flags in _variants().items():
+            variant, loss, grads = _policy_gradient(henv, nets, cfg, ddev, dev, flags, tail=False)
+            if vname == "default":
+                assert variant == 1, "256-wide FHADP launches of this size take the register-stationary plane-split kernels"
+            if vname == "streamed_split" and variant != 4:
+                continue   # (veh3dofconti with P = 30: the streamed plane-split kernel does not fit two workgroups' LDS - exact fp32 then)
+            if vname in ("exact_forward", "exact_fp32"):
+                assert variant not in (1, 4)
+            err = rel_l2(_flat(grads), _golden_flat(g, "grad/", len(grads)))
+            worst = max(rel_l2(t.cpu(), g[f"grad/{i}"]) for i, t in enumerate(grads))
+            report[vname] = (abs(loss - float(g["loss"])) / max(1.0, abs(float(g["loss"]))), err, worst)
+        print(f"{name}{' [' + mode + ']' if mode else ''} (policy moved {float(g['meta/policy_moved_rel']):.2f} rel. L2 from init, "
+              f"max|w| {float(g['meta/policy_absmax']):.2f}, saturated first actions {float(g['meta/act0_sat_share']):.2f}, reference fp32 "
+              f"scatter {float(g['meta/ref_fp32_scatter']):.1e}): "
+              + "; ".join(f"{k}: loss {v[0]:.1e} grad {v[1]:.2e} (worst tensor {v[2]:.2e})" for k, v in report.items()))
+        _check_table(name, report, VEH_HEADING_BOUND if mode == "kernel_headings" else bar_of(g), mode)
+
+
+@pytest.mark.parametrize("name", INFADP_T256)
+def test_infadp_trained_256_wide_vs_reference(name, dev):
+    from gops_amd import hip_backend as hb
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg = meta["cfg"]
+    env = oracle_env(cfg, meta["extra"], g)
+    nets, _ = nets_from_golden(g, cfg)
+    data = data_from_golden(g)
+    B = data["obs"].shape[0]
+    veh = cfg["env_id"] == "pyth_veh3dofconti"
+    henv = hip_env_from_oracle(env, nets["policy"])
+    modes = {"": data}
+    if veh:
+        modes = {"ref_appended": dict(data, ref_appended=_appended_points(cfg, data)), "kernel_headings": data}
+    for mode, d in modes.items():
+        ddev = to_device(d, dev)
+        pev_rep, pim_rep = {}, {}
+        for vname, flags in _variants().items():
+            if vname == "streamed_split" and len(cfg["hidden"]) != 2:
+                continue   # three hidden layers: the default IS the streamed plane-split kernel
+            vt = _mlp(nets["v_target"], dev, flags)[0]
+            v, vw, vb = _mlp(nets["v"], dev, flags)
+            pol = _mlp(nets["policy"], dev, flags)[0]
+            # PEV: backup from a gradient-free rollout with the tail value, V(o) regression through the value path
+            ro = hb.Rollout(henv, pol, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=False, need_grad=False,
+                            value=vt, variant_flags=flags)
+            backup = ro.forward(ddev)["v_pi"]
+            vn = hb.ValueNet(v, B)
+            vo = vn.forward(ddev["obs"])
+            gw, gb = [torch.empty_like(w) for w in vw], [torch.empty_like(b) for b in vb]
+            vn.backward(ddev["obs"], (2.0 / B) * (vo - backup), gw, gb)
+            torch.cuda.synchronize()
+            pev = [t for pair in zip(gw, gb) for t in pair]
+            pev_loss = ((vo - backup).double() ** 2).mean().item()
+            del ro, vn
+            # PIM: gradient through policy, model and the target value net's input
+            variant, pim_loss, pim = _policy_gradient(henv, nets, cfg, ddev, dev, flags, tail=True)
+            if vname in ("exact_forward", "exact_fp32"):
+                assert variant not in (1, 4)
+            else:
+                assert variant in (1, 4), "256-wide INFADP launches take plane-split kernels by default"
+            pev_rep[vname] = (abs(pev_loss - float(g["pev_loss"])) / max(1.0, abs(float(g["pev_loss"]))),
+                              rel_l2(_flat(pev), _golden_flat(g, "pev_grad/", len(pev))),
+                              max(rel_l2(t.cpu(), g[f"pev_grad/{i}"]) for i, t in enumerate(pev)))
+            pim_rep[vname] = (abs(pim_loss - float(g["pim_loss"])) / max(1.0, abs(float(g["pim_loss"]))),
+                              rel_l2(_flat(pim), _golden_flat(g, "pim_grad/", len(pim))),
+                              max(rel_l2(t.cpu(), g[f"pim_grad/{i}"]) for i, t in enumerate(pim)))
+        print(f"{name}{' [' + mode + ']' if mode else ''} (policy moved {float(g['meta/policy_moved_rel']):.2f} rel. L2 from init, "
+              f"max|w| {float(g['meta/policy_absmax']):.2f}, reference fp32 scatter PEV {float(g['meta/ref_fp32_scatter_pev']):.1e} / PIM "
+              f"{float(g['meta/ref_fp32_scatter_pim']):.1e}): "
+              + "; ".join(f"{k}: PEV grad {pev_rep[k][1]:.2e} (worst {pev_rep[k][2]:.2e}) PIM grad {pim_rep[k][1]:.2e} (worst {pim_rep[k][2]:.2e})"
+                          for k in pev_rep))
+        heading = mode == "kernel_headings"
+        _check_table(name, pev_rep, VEH_HEADING_BOUND if heading else bar_of(g, "meta/ref_fp32_scatter_pev"), mode + " PEV")
+        _check_table(name, pim_rep, VEH_HEADING_BOUND if heading else bar_of(g, "meta/ref_fp32_scatter_pim"), mode + " PIM")
+
+
+# ---- the algorithm classes: PrecisionGuard decides between the plane-split and the exact-fp32 forward ------------------------
+def _load_alg(name, **extra):
+    from test_alg_gpu import _kwargs
+    from gops_amd.create_pkg.create_alg import create_alg
+    g = load_golden(name)
+    meta = golden_meta(g)
+    cfg = meta["cfg"]
+    kw = _kwargs(cfg, meta["extra"], meta["seed"])
+    if cfg["alg"] == "FHADP":
+        kw["gamma"] = cfg["gamma"]
+    kw.update(extra)
+    alg = create_alg(**kw)
+    sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("sd/")}
+    alg.load_state_dict(sd)      # the reference's checkpoint layout loads unchanged
+    alg.networks.cuda()
+    if cfg["alg"] == "INFADP":
+        alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]
+    if "const/lq_inv_IA" in g:
+        # (I - A dt)^-1 comes out of LAPACK in fp32 with host-dependent last bits (lq_base.py:55-57); the fixture carries the value
+        # its outputs were recorded with, and one ulp of THIS constant - applied at every step of every trajectory - is worth
+        # ~1e-4 of gradient on these trained policies (measured: class 8e-5 / 1.2e-4 with this host's pinv, 2e-5 with the recorded one)
+        dyn = alg.envmodel.unwrapped.dynamics
+        dyn.inv_IA = torch.from_numpy(np.array(g["const/lq_inv_IA"])).to(dyn.inv_IA.device)
+    return alg, g, cfg
+
+
+@pytest.mark.parametrize("name", FHADP_T256)
+def test_precision_guard_fhadp(name, dev):
+    """The FHADP class on the trained fixtures: the first gradient is checked (a loaded checkpoint may already need the exact
+    forward).  The saturated LQ policy trips the guard - and the gradient the class then returns meets the bar; the others stay on
+    the plane-split kernels with their measured distance below the threshold."""
+    alg, g, cfg = _load_alg(name)
+    data = to_device(data_from_golden(g), dev)
+    guard = alg.precision_guard
+    with pytest.warns(UserWarning, match="exact-fp32 forward") if name in NEEDS_EXACT_FORWARD else _no_context():
+        _, info = alg.get_remote_update_info(data, 0)
+    torch.cuda.synchronize()
+    assert guard.checks == 1 and guard.last_distance is not None
+    grads = info["grad"]
+    err = rel_l2(_flat(grads), _golden_flat(g, "grad/", len(grads)))
+    print(f"{name}: guard distance {guard.last_distance:.2e} (threshold {guard.threshold:.0e}) -> exact forward: {guard.exact}; "
+          f"gradient of the class vs the reference {err:.2e}")
+    assert guard.exact == (name in NEEDS_EXACT_FORWARD), (name, guard.last_distance)
+    veh = cfg["env_id"] == "pyth_veh3dofconti"   # (the class evaluates the appended headings itself: exemption 1)
+    assert err < (VEH_HEADING_BOUND if veh else bar_of(g)), (name, err)
+    # sticky, and no further checks once exact; an unexceptional network is checked again only after `interval` gradients
+    for it in range(1, 4):
+        alg.get_remote_update_info(data, it)
+    assert guard.checks == 1 and guard.exact == (name in NEEDS_EXACT_FORWARD)
+    assert alg._rollout_for(data["obs"].shape[0], dev).desc.variant_flags == guard.flags()
+
+
+class _no_context:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def test_precision_guard_interval_and_switch_off(dev):
+    alg, g, cfg = _load_alg("t256_fhadp_idp_h30_gelu", precision_check_interval=3)
+    data = to_device(data_from_golden(g), dev)
+    for it in range(7):
+        alg.get_remote_update_info(data, it)
+    assert alg.precision_guard.checks == 3     # gradients 1, 3 and 6
+    assert not alg.precision_guard.exact
+    alg2, g2, _ = _load_alg("t256_fhadp_lq_s4a2_elu_sat", precision_check_interval=0)
+    data2 = to_device(data_from_golden(g2), dev)
+    alg2.get_remote_update_info(data2, 0)
+    assert alg2.precision_guard.checks == 0 and not alg2.precision_guard.exact   # switched off: the caller's responsibility
+
+
+@pytest.mark.parametrize("name", ["t256_infadp_lq_s4a2_relu", "t256_infadp_lq_s4a2_gelu"])
+def test_precision_guard_infadp(name, dev):
+    """INFADP keeps one guard per trained network; on these fixtures both stay on the plane-split kernels."""
+    alg, g, cfg = _load_alg(name)
+    data = to_device(data_from_golden(g), dev)
+    _, info_v = alg.get_remote_update_info(data, 0)     # PEV
+    pev = rel_l2(_flat(info_v["v"]), _golden_flat(g, "pev_grad/", len(info_v["v"])))
+    _, info_p = alg.get_remote_update_info(data, 1)     # PIM
+    pim = rel_l2(_flat(info_p["policy"]), _golden_flat(g, "pim_grad/", len(info_p["policy"])))
+    torch.cuda.synchronize()
+    gv, gp = alg.precision_guard["v"], alg.precision_guard["policy"]
+    print(f"{name}: guard distances PEV {gv.last_distance:.2e} PIM {gp.last_distance:.2e}; class vs reference PEV {pev:.2e} PIM {pim:.2e}")
+    assert gv.checks == 1 and gp.checks == 1 and not gv.exact and not gp.exact
+    assert pev < bar_of(g, "meta/ref_fp32_scatter_pev") and pim < bar_of(g, "meta/ref_fp32_scatter_pim")

@@ -487,6 +487,7 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
                     h[0] / p.H, h[1] / p.H, h[14] / p.H, h[8] / p.H, h[9] / p.H, h[11] / p.H, h[12] / p.H, h[2] / p.H, h[6] / p.H, h[7] / p.H,
                     h[3] / p.H, h[4] / p.H, h[5] / p.H,
                     (h[0] + h[1] + h[14] + h[8] + h[9] + h[11] + h[12] + h[2] + h[6] + h[7] + h[3] + h[4] + h[5]) / p.H);
+        if (p.sp.on) fprintf(stderr, "[gops dbg] fwd SPLIT per launch (cycles of block 0): kernel entry -> first step %llu | behind the last step %llu\n", h[13], h[15]);
         else
         fprintf(stderr, "[gops dbg] fwd cycles/step: top+sync %llu | xstash %llu | hidden-rest %llu | head %llu | envstash %llu | env %llu"
                 " || L0 epi %llu sync %llu stash %llu | L1 epi %llu sync %llu stash %llu | gemm(L0+L1) %llu || head: dot %llu tanh+wrap %llu barrier %llu\n",

@@ -540,30 +540,81 @@ struct StatQ {
     const f16x8* rl;   // RLDS: this lane's first fragment of this wave's first n-tile
     float inv[NT];     // 1 / s_r of the n-tiles
     // lds_r (RLDS): LDS region of nt_tot * KCH * 64 fragments, filled here by all NTHREADS threads (caller: barrier before use)
+    //
+    // Launch-time cost (round 5, ISA of the round-4 build): written as one loop over fragments, every PINNED fragment went
+    // global_load -> s_waitcnt vmcnt(0) -> 4 x v_accvgpr_write through the same four VGPRs - 32 serialized L2 round trips for a
+    // 256 x 256 layer -, and the LDS fill of the residual plane was a load / wait / ds_write loop of 16 more: ~20 of the forward
+    // kernel's 22 - 27 us of per-launch fixed cost (tools: kernel time at H = 1, 2, 5 .. 30).  Now every load of a group is issued
+    // before the first result is touched: fragments in groups of LOAD_GROUP (64 temporaries), the LDS fill in batches of 8.
+    static constexpr int LOAD_GROUP = 16;
     __device__ __forceinline__ void load(const bf16x8* __restrict__ W1, const f16x8* __restrict__ R, const float* __restrict__ inv_r,
                                          int nt_tot, int tid, f16x8* lds_r = nullptr) {
         const int lane = tid & 63, nt0 = (tid >> 6) * NT;
+        size_t at0[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const bool ok = nt0 + j < nt_tot;
-            inv[j] = ok ? gptr(inv_r)[nt0 + j] : 0.f;
+            const float iv = gptr(inv_r)[ok ? nt0 + j : 0];   // (unconditional load: a guarded one is load, s_waitcnt, per n-tile)
+            inv[j] = ok ? iv : 0.f;
+            at0[j] = (size_t)(ok ? nt0 + j : 0) * KCH * 64 + lane;
+        }
+        if constexpr (!RLDS) {   // residual plane: plain loads (hipcc targets the accumulator registers directly, all in flight)
 #pragma unroll
-            for (int c = 0; c < KCH; ++c) {
-                const size_t at = ((size_t)(ok ? nt0 + j : 0) * KCH + c) * 64 + lane;
-                if constexpr ((PIN & 2) != 0) w[c * NT + j] = pin_agpr(gptr(W1)[at]);
-                else w[c * NT + j] = gptr(W1)[at];
-                if constexpr (!RLDS) {
-                    if constexpr ((PIN & 1) != 0) r[c * NT + j] = pin_agpr(gptr(R)[at]);
-                    else r[c * NT + j] = gptr(R)[at];
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int c = 0; c < KCH; ++c) {
+                    if constexpr ((PIN & 1) != 0) r[c * NT + j] = pin_agpr(gptr(R)[at0[j] + (size_t)c * 64]);
+                    else r[c * NT + j] = gptr(R)[at0[j] + (size_t)c * 64];
                 }
+        }
+        if constexpr ((PIN & 2) != 0) {
+#pragma unroll
+            for (int g0 = 0; g0 < KCH * NT; g0 += LOAD_GROUP) {
+                bf16x8 tmp[LOAD_GROUP];
+#pragma unroll
+                for (int i = 0; i < LOAD_GROUP; ++i) {
+                    const int f = g0 + i, c = f / NT, j = f - c * NT;
+                    if (f < KCH * NT) tmp[i] = gptr(W1)[at0[j] + (size_t)c * 64];
+                }
+#pragma unroll
+                for (int i = 0; i < LOAD_GROUP; ++i)
+                    if (g0 + i < KCH * NT) w[g0 + i] = pin_agpr(tmp[i]);
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int c = 0; c < KCH; ++c) w[c * NT + j] = gptr(W1)[at0[j] + (size_t)c * 64];
         }
         if constexpr (RLDS) {
-            for (int i = tid; i < nt_tot * KCH * 64; i += NTHREADS) lds_r[i] = gptr(R)[i];
+            const int total = nt_tot * KCH * 64;
+            for (int base = tid; base < total; base += 8 * NTHREADS) {
+                f16x8 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = gptr(R)[min(base + u * NTHREADS, total - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (base + u * NTHREADS < total) lds_r[base + u * NTHREADS] = v[u];
+            }
             rl = lds_r + (size_t)(nt0 < nt_tot ? nt0 : 0) * KCH * 64 + lane;
         }
     }
 };
+
+// Launch-time fills of LDS from global memory: U loads in flight per thread before the first store.  (Left as
+// `for (i = tid; i < n; i += NTHREADS) lds[i] = glob[i]`, hipcc emits load, s_waitcnt vmcnt(0), ds_write per iteration: one L2
+// round trip each - see StatQ::load.)  `load(i)` must be safe for every i < n; `store(i, v)` is only called for i < n.
+template <int U, class L, class S>
+__device__ __forceinline__ void batched_fill(int n, int tid, L&& load, S&& store) {
+    for (int base = tid; base < n; base += U * NTHREADS) {
+        decltype(load(0)) v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = load(min(base + u * NTHREADS, n - 1));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (base + u * NTHREADS < n) store(base + u * NTHREADS, v[u]);
+    }
+}
 
 // acc (bf16 main term) / accr (f16 residual term, still scaled) of this wave's NT n-tiles over the plane image `planes`.
 // The four A fragments of chunk c + 1 (and an LDS-resident residual plane's fragments of chunk c) are requested ahead of
@@ -637,7 +688,8 @@ struct StreamQ {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const bool ok = nt0 + j < nt_tot;   // (a wave's surplus n-tiles compute tile 0 again: their results are not stored)
-            inv[j] = ok ? gptr(inv_r)[nt0 + j] : 0.f;
+            const float iv = gptr(inv_r)[ok ? nt0 + j : 0];
+            inv[j] = ok ? iv : 0.f;
             at[j] = (unsigned)((ok ? nt0 + j : 0) * KCH * 64 + lane);
         }
     }

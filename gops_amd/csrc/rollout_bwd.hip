@@ -661,10 +661,14 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
     float lam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // adjoint of the veh3dof state (tid < TB)
     if (REF) {
         const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
-        for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            s_ref[idx] = (idx < nvalid * TL) ? tbl[idx] : z;
-        }
+        const int nv = nvalid * TL;
+        batched_fill<4>(TB * TL, tid,
+                        [&](int idx) {
+                            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                            const f32x4 v = tbl[idx < nv ? idx : 0];
+                            return idx < nv ? v : z;
+                        },
+                        [&](int idx, const f32x4& v) { s_ref[idx] = v; });
     }
     if (TAIL) {
         if (tid < TB) {

@@ -379,6 +379,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
     extern __shared__ __attribute__((aligned(16))) float smem_raw[];
     const RolloutParams& p = *pp;   // parameters live in device memory: uniform scalar loads
     const int tid = threadIdx.x;
+#ifdef GOPS_DBG_BUILD
+    const long long t_entry = clock64();   // (phase-counter build: cycles from kernel entry to the first step -> slot 13)
+#endif
     // pyth_lq on the streamed-split forward: the env description in front of everything else in LDS (common.h: env_in_lds)
     constexpr bool ENVLDS = env_in_lds(ENV, SS);
     float* smem = smem_raw + (ENVLDS ? ENV_LDS_FLOATS : 0);
@@ -421,21 +424,30 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
     // F16: half copy of the policy / value input tile, [TB][ldx16], behind the reference-table region
     _Float16* x16 = reinterpret_cast<_Float16*>(s_ref + (REF ? TB * TL : 0));
     const int ldx16 = (((p.ldx - 4) + 31) & ~31) + 8, ld16 = (p.ldh - 4) + 8;
-    {   // one-time staging of everything the H-step loop would otherwise re-fetch from L2
+    {   // one-time staging of everything the H-step loop would otherwise re-fetch from L2 (batched_fill: loads in flight together)
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
-        for (int idx = tid; idx < GOPS_MAX_ACT * ldh; idx += NTHREADS) {   // rows a >= Ao (and the pad columns) are zero: mlp_head<true>
-            if constexpr (SPLIT || SS) {   // feature-major [K][4]: a lane reads the four action weights of one of its columns as one vector
-                const int k = idx >> 2, a = idx & 3;
-                s_wo[idx] = (a < Ao && k < K) ? gptr(p.pol.w[Lh])[a * K + k] : 0.f;
-            } else {
-                const int a = idx / ldh, k = idx - a * ldh;
-                s_wo[idx] = (a < Ao && k < K) ? gptr(p.pol.w[Lh])[a * K + k] : 0.f;
-            }
-        }
+        const GLOBAL_AS float* wl = gptr(p.pol.w[Lh]);
+        // rows a >= Ao (and the pad columns) are zero: mlp_head<true>
+        batched_fill<5>(GOPS_MAX_ACT * ldh, tid,
+                        [&](int idx) {
+                            int a, k;
+                            if constexpr (SPLIT || SS) { k = idx >> 2; a = idx & 3; }   // feature-major [K][4]: a lane reads the four action weights of one of its columns as one vector
+                            else { a = idx / ldh; k = idx - a * ldh; }
+                            const bool ok = a < Ao && k < K;
+                            const float v = wl[ok ? a * K + k : 0];
+                            return ok ? v : 0.f;
+                        },
+                        [&](int idx, float v) { s_wo[idx] = v; });
         if (tid < GOPS_MAX_ACT) s_bo[tid] = (tid < Ao) ? gptr(p.pol.b[Lh])[tid] : 0.f;
         stage_act_const(p.env, s_ac, tid);
-        for (int j = 0; j < Lh; ++j)
-            for (int n = tid; n < p.pol.dims[j + 1]; n += NTHREADS) s_bias[j * ldh + n] = gptr(p.pol.b[j])[n];
+        batched_fill<GOPS_MAX_LAYERS - 1>(Lh * ldh, tid,
+                                          [&](int idx) {
+                                              const int j = idx / ldh, n = idx - j * ldh;
+                                              const bool ok = n < p.pol.dims[j + 1];
+                                              const float v = gptr(p.pol.b[j])[ok ? n : 0];
+                                              return ok ? v : 0.f;
+                                          },
+                                          [&](int idx, float v) { s_bias[idx] = v; });
     }
     typename std::conditional<(SK0 > 0 && !SPLIT), StatW<(SK0 > 0 ? SK0 : 1), 4>, NoW>::type W0;
     typename std::conditional<(SK1 > 0 && !SPLIT), StatW<(SK1 > 0 ? SK1 : 1), 4>, NoW>::type W1;
@@ -464,6 +476,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
 
     DbgClock dbg;
     dbg.init((p.dbg != nullptr) && blockIdx.x == 0 && tid == 0);
+#ifdef GOPS_DBG_BUILD
+    if (dbg.on) dbg.acc[13] = dbg.last - t_entry;
+#endif
     const int ntiles = (p.B + TB - 1) / TB;
     do {   // ---- one tile of 16 trajectories (SPLIT: a grid-stride walk over the tiles) ----
     b0 = tile * TB;
@@ -474,14 +489,25 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
     }
     if (REF) {
         const GLOBAL_AS f32x4* tbl = gptr(reinterpret_cast<const f32x4*>(p.ref_table)) + (size_t)b0 * TL;
-        for (int idx = tid; idx < TB * TL; idx += NTHREADS) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            s_ref[idx] = (idx < nvalid * TL) ? tbl[idx] : z;
-        }
+        const int nv = nvalid * TL;
+        batched_fill<4>(TB * TL, tid,
+                        [&](int idx) {
+                            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                            const f32x4 v = tbl[idx < nv ? idx : 0];
+                            return idx < nv ? v : z;
+                        },
+                        [&](int idx, const f32x4& v) { s_ref[idx] = v; });
     }
-    for (int idx = tid; idx < TB * ldx; idx += NTHREADS) {
-        const int m = idx / ldx, c = idx - m * ldx;
-        xs[idx] = (c < O && m < nvalid) ? gptr(p.in.obs)[(size_t)(b0 + m) * O + c] : 0.f;
+    {
+        const GLOBAL_AS float* ob = gptr(p.in.obs) + (size_t)b0 * O;
+        batched_fill<5>(TB * ldx, tid,
+                        [&](int idx) {
+                            const int m = idx / ldx, c = idx - m * ldx;
+                            const bool ok = c < O && m < nvalid;
+                            const float v = ob[ok ? m * O + c : 0];
+                            return ok ? v : 0.f;
+                        },
+                        [&](int idx, float v) { xs[idx] = v; });
     }
     // (no MaskAtDoneModel in the chain: the base models ignore the done flags they are handed)
     if (tid < TB) s_done[tid] = (tid < nvalid && p.in.done != nullptr && !p.env.no_mask_at_done && gptr(p.in.done)[b0 + tid] != 0.f) ? 1.f : 0.f;
@@ -1060,6 +1086,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
     }
     if constexpr (SPLIT && MULTI) __syncthreads();   // the next tile's set-up overwrites xs / s_state / s_done / s_ref
     } while (SPLIT && MULTI && (tile += gridDim.x) < ntiles);
+    DBG_TICK(15)   // (everything behind the last step: final outputs)
     dbg.dump(p.dbg);
 }
 

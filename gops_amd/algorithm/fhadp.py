@@ -103,9 +103,13 @@ class FHADP(AlgorithmBase):
         if reducer is not None and reducer.overlap_enabled() and len(grads) >= 4 and plain:
             sig = self._signature(batch)
             loss = self._grad_graph.run(("a",) + sig, batch, lambda b: self._gradient_kernels(b, phase="a"), work=work)
-            reducer.start_(grads[2:])   # output layer, hidden layers 1.. : final after phase A
-            self._grad_graph_b.run(("b",) + sig, batch, lambda b: self._gradient_kernels(b, phase="b"), work=work)
-            reducer.start_(grads[:2])   # first hidden layer
+            try:
+                reducer.start_(grads[2:])   # output layer, hidden layers 1.. : final after phase A
+                self._grad_graph_b.run(("b",) + sig, batch, lambda b: self._gradient_kernels(b, phase="b"), work=work)
+                reducer.start_(grads[:2])   # first hidden layer
+            except BaseException:
+                reducer.abandon_()          # no handle of this update outlives it
+                raise
             info["_pending"] = True
         else:
             loss = self._grad_graph.run(self._signature(batch), batch, self._gradient_kernels, work=work)

@@ -408,6 +408,7 @@ class Rollout:
         # bit-parity mode (GopsRolloutIn.ref_appended): the reference's own appended reference points [B, H, 4]
         i.ref_appended = _ptr(data.get("ref_appended"))
         self._keep = dict(data)
+        self._last_phase = None   # (a new forward invalidates a pending backward phase A)
         if d.env.kind == ENV_MOBILEROBOT:   # the obstacle's draws of this rollout [H, B, 2] (a caller may hand in its own)
             noise = data.get("noise")
             if noise is None:
@@ -452,7 +453,12 @@ class Rollout:
         arguments) = the first hidden layer's (GOPS_VF_BWD_PHASE_A / _B): lets a data-parallel trainer start the all-reduce of the
         gradients that are ready first while the rest is being formed."""
         if phase == "b":
+            # phase B reuses the inputs (and the delta stash) phase A left in this workspace: it must follow one, directly
+            if getattr(self, "_last_phase", None) != "a":
+                raise RuntimeError("Rollout.backward(phase='b') must directly follow backward(phase='a') of the same rollout")
+            self._last_phase = "b"
             return self._backward_call(grad_v, make_mlp_grad(grad_w, grad_b), VF_BWD_PHASE_B)
+        self._last_phase = phase
         g = make_mlp_grad(grad_w, grad_b)
         self._in.grad_constraint = _ptr(grad_constraint)
         self._in.grad_constraint_prod = _ptr(grad_constraint_prod)

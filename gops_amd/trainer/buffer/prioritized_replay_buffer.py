@@ -37,12 +37,17 @@ class PrioritizedReplayBuffer(ReplayBuffer):
 
     # ---- tree maintenance -----------------------------------------------------------------------------------------
     def _repair(self, tree_idx: torch.Tensor):
-        """Recompute every ancestor of the given nodes (reference: update_tree :73-82 / the lazy loop :138-151)."""
+        """Recompute every ancestor of the given nodes (reference: update_tree :73-82 / the lazy loop :138-151): a FIXED number of
+        rounds, each recomputing the parents of the previous round's nodes from their children - no `unique`, no emptiness test,
+        no boolean mask, i.e. no device-to-host synchronisation.  Duplicated parents write the same value twice (a parent only
+        depends on its children); nodes that have reached the root keep recomputing the root; leaves sit on the last two levels,
+        so a parent can be recomputed before its deeper child has been - the round in which the deeper path passes recomputes it
+        again, and after `_depth` rounds (>= the longest leaf-to-root path) every touched path is final."""
+        if self.max_size == 1:
+            return   # the root is the only leaf
         nodes = tree_idx
         for _ in range(self._depth):
-            nodes = torch.unique((nodes[nodes > 0] - 1) // 2)
-            if nodes.numel() == 0:
-                break
+            nodes = torch.clamp((nodes - 1) // 2, min=0)
             left, right = 2 * nodes + 1, 2 * nodes + 2
             self.sum_tree[nodes] = self.sum_tree[left] + self.sum_tree[right]
             self.min_tree[nodes] = torch.minimum(self.min_tree[left], self.min_tree[right])
@@ -94,11 +99,16 @@ class PrioritizedReplayBuffer(ReplayBuffer):
         pr = torch.as_tensor(np.asarray(priorities) if not torch.is_tensor(priorities) else priorities)
         pr = (pr.detach().to(self.device, torch.float64).reshape(-1) + self.epsilon) ** self.alpha
         self.max_priority = torch.maximum(self.max_priority, pr.max())
-        # duplicated indices: numpy's fancy assignment keeps the LAST occurrence; a device scatter with duplicates is unordered,
-        # so the last occurrence of every index is selected explicitly
-        uniq, inv = torch.unique(idxes, return_inverse=True)
-        last = torch.zeros(uniq.numel(), dtype=torch.long, device=self.device)
-        last.scatter_reduce_(0, inv, torch.arange(idxes.numel(), device=self.device), reduce="amax", include_self=False)
-        self.sum_tree[uniq] = pr[last]
-        self.min_tree[uniq] = pr[last]
-        self._repair(uniq)
+        # duplicated indices: numpy's fancy assignment keeps the LAST occurrence; a device scatter with duplicates is unordered, so
+        # every occurrence writes the value of the index's last occurrence (position table in a persistent scratch: no `unique`,
+        # no host synchronisation)
+        pos = torch.arange(idxes.numel(), device=self.device)
+        last = getattr(self, "_last_pos", None)
+        if last is None:
+            last = self._last_pos = torch.zeros(self.sum_tree.numel(), dtype=torch.long, device=self.device)
+        last[idxes] = 0
+        last.scatter_reduce_(0, idxes, pos, reduce="amax", include_self=True)
+        winner = pr[last[idxes]]
+        self.sum_tree[idxes] = winner
+        self.min_tree[idxes] = winner
+        self._repair(idxes)

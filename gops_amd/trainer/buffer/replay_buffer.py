@@ -95,6 +95,8 @@ class ReplayBuffer:
         """Device-side insert of a dict of [n, ...] tensors with this buffer's keys (no host round trip):
         the entry point for samplers that already produce batched device data."""
         n = next(iter(batch.values())).shape[0]
+        if n > self.max_size:   # (like add_batch: only the last max_size rows can survive - and no slot is written twice)
+            batch, n = {k: v[-self.max_size:] for k, v in batch.items()}, self.max_size
         rows = self._rows(n)
         for k, dst in self.buf.items():
             if k in batch and dst[0].numel() > 0:

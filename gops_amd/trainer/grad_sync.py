@@ -56,11 +56,25 @@ class GradAllReducer:
     def start_(self, tensors: List[torch.Tensor]):
         """Asynchronous in-place SUM all-reduce of gradient tensors that tile ONE contiguous slice of a network's gradient
         buffer (`algorithm/base.py:grad_buffers`): the collective waits for what is queued on the current stream so far and runs
-        on the process group's own stream - kernels queued afterwards overlap it.  `average_` waits for it."""
+        on the process group's own stream - kernels queued afterwards overlap it.  `average_` waits for it.  Tensors that do not
+        tile one buffer (gradients installed from outside) are reduced through a flattened copy - slower, never an error."""
         flat = _as_one_buffer(tensors)
         if flat is None:
-            raise RuntimeError("GradAllReducer.start_: the tensors do not tile one contiguous buffer")
-        self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            flat = _flatten_dense_tensors(tensors)
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._works.append((work, flat, list(tensors)))
+            return
+        self._works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+
+    def abandon_(self):
+        """Wait for and drop collectives that were started but will not be consumed (the caller's update raised between `start_`
+        and `average_`): a later iteration must not wait on - or take the 1/N for - somebody else's handles."""
+        works, self._works = self._works, []
+        for w, _, _ in works:
+            try:
+                w.wait()
+            except Exception:   # noqa: BLE001 - best effort while unwinding
+                pass
 
     def average_(self, update_info: Dict[str, List[torch.Tensor]], defer_scale: bool = False) -> Dict[str, List[torch.Tensor]]:
         """`defer_scale`: leave the SUM in the buffers and hand the 1/N to the consumer as
@@ -71,15 +85,21 @@ class GradAllReducer:
         if n == 1:
             return update_info
         if update_info.pop("_pending", False):   # the algorithm started the collectives itself (start_): only wait for them
-            for w in self._works:
+            works, self._works = self._works, []   # (taken over first: whatever happens below, no stale handle survives this call)
+            for w, flat, tensors in works:
                 w.wait()                         # (NCCL / RCCL: the current stream waits, the host does not)
-            self._works = []
+                if flat is not None:             # reduced through a flattened copy: scatter it back
+                    torch._foreach_copy_(tensors, list(_unflatten_dense_tensors(flat, tensors)))
             if defer_scale:
                 update_info["_grad_scale"] = 1.0 / n
             else:
-                for g in update_info["grad"]:
-                    g.div_(n)
+                for name, grads in update_info.items():
+                    if not name.startswith("_") and isinstance(grads, (list, tuple)):
+                        for g in grads:
+                            g.div_(n)
             return update_info
+        if self._works:   # collectives of an update that never reached average_ (it raised): drain them before this one
+            self.abandon_()
         # (MPG's update_info also carries its iteration counter, mpg.py:434: non-list entries are not gradients)
         tensors = [g for name in sorted(update_info)
                    if not name.startswith("_") and isinstance(update_info[name], (list, tuple)) for g in update_info[name]]

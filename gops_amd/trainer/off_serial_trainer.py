@@ -19,8 +19,8 @@ class OffSerialTrainer(TrainerBase):
     def __init__(self, alg, sampler, buffer, evaluator, **kwargs):
         super().__init__(alg, sampler, evaluator, **kwargs)
         self.buffer = buffer
-        if kwargs.get("buffer_name") == "prioritized_replay_buffer":
-            raise NotImplementedError("prioritized replay is outside the MI355X ADP path (FHADP / INFADP use uniform replay)")
+        # prioritized replay (off_serial_trainer.py:34-37, 96-100): the algorithm returns (tb_info, tree indices, new priorities)
+        self.per_flag = kwargs.get("buffer_name") == "prioritized_replay_buffer"
         self.replay_batch_size = kwargs["replay_batch_size"]
         self.sample_interval = kwargs.get("sample_interval", 1)
         while self.buffer.size < kwargs["buffer_warm_size"]:   # pre sampling
@@ -47,13 +47,11 @@ class OffSerialTrainer(TrainerBase):
             self.sampler_tb_dict.add_average(sampler_tb)
         replay_samples = self.buffer.sample_batch(self.replay_batch_size)
         self.networks.train()
-        out = self.alg.local_update(replay_samples, self.iteration)
-        if isinstance(out, tuple):   # prioritized replay (off_serial_trainer.py:96-100): (tb_info, tree indices, new priorities)
-            alg_tb_dict, idx, new_priority = out
-            if hasattr(self.buffer, "update_batch"):
-                self.buffer.update_batch(idx, new_priority)
+        if self.per_flag:   # (off_serial_trainer.py:96-100)
+            alg_tb_dict, idx, new_priority = self.alg.local_update(replay_samples, self.iteration)
+            self.buffer.update_batch(idx, new_priority)
         else:
-            alg_tb_dict = out
+            alg_tb_dict = self.alg.local_update(replay_samples, self.iteration)
         self.networks.eval()
         self._after_update(alg_tb_dict)
 

@@ -558,6 +558,64 @@ def test_off_serial_trainer_loop(tmp_path):
     assert {"apprfunc_0.pkl", "apprfunc_4.pkl", "apprfunc_5.pkl"} <= set(os.listdir(tmp_path / "apprfunc"))
 
 
+def test_off_serial_trainer_with_prioritized_replay(tmp_path):
+    """the per_flag path of the reference's off_serial_trainer.py:96-100 - with `buffer_name=
+    "prioritized_replay_buffer"` the algorithm's `local_update` returns (tb_info, tree indices, new priorities) and the trainer
+    hands them to `buffer.update_batch`; the trees must move, and sampling must follow the new priorities."""
+    from gops_amd.create_pkg.create_buffer import create_buffer
+    from gops_amd.create_pkg.create_trainer import create_trainer
+    from gops_amd.trainer.buffer.prioritized_replay_buffer import PrioritizedReplayBuffer
+
+    class Alg:
+        def __init__(self):
+            self.networks = torch.nn.Linear(5, 2)
+            self.updates = []
+
+        def local_update(self, data, it):
+            # a TD-error-like priority: large for the transitions whose reward tag is a multiple of 5, tiny for the rest
+            pr = torch.where(data["rew"].round() % 5 == 0, torch.full_like(data["rew"], 50.0), torch.full_like(data["rew"], 1e-3))
+            self.updates.append((data["idx"].clone(), pr.clone()))
+            return {"Loss/Actor loss-RL iter": 0.0}, data["idx"], pr
+
+    class Sampler:
+        networks = None
+        calls = 0
+
+        def sample(self):
+            base = 4 * Sampler.calls
+            Sampler.calls += 1
+            return [_transition(base + i) for i in range(4)], {"Time/Sampler time [ms]-RL iter": 1.0}
+
+        def get_total_sample_number(self):
+            return 4 * Sampler.calls
+
+    kw = _buffer_kwargs(buffer_max_size=64)
+    kw["buffer_name"] = "prioritized_replay_buffer"
+    buf = create_buffer(**kw)
+    assert isinstance(buf, PrioritizedReplayBuffer)
+    alg = Alg()
+    tr = create_trainer(alg, Sampler(), buf, None, trainer="off_serial_trainer", buffer_name="prioritized_replay_buffer",
+                        replay_batch_size=16, buffer_warm_size=40, sample_interval=100, max_iteration=6,
+                        log_save_interval=100, apprfunc_save_interval=100, eval_interval=100,
+                        save_folder=str(tmp_path), ini_network_dir=None, use_gpu=False)
+    assert tr.per_flag
+    sum0 = buf.sum_tree[0].item()
+    tr.train()
+    assert len(alg.updates) == 6
+    # the trees changed, and stay consistent: every inner node is the sum / min of its children
+    assert buf.sum_tree[0].item() != sum0
+    n = buf.max_size
+    inner = torch.arange(n - 1)
+    assert torch.allclose(buf.sum_tree[inner], buf.sum_tree[2 * inner + 1] + buf.sum_tree[2 * inner + 2], rtol=1e-12, atol=0)
+    assert torch.equal(buf.min_tree[inner], torch.minimum(buf.min_tree[2 * inner + 1], buf.min_tree[2 * inner + 2]))
+    # the leaves the algorithm marked carry (|p| + eps)^alpha of ITS priorities, and sampling now prefers them
+    idx, pr = alg.updates[-1]
+    want = (pr.double() + buf.epsilon) ** buf.alpha
+    assert torch.allclose(buf.sum_tree[idx.long()], want, rtol=1e-12)
+    batch = buf.sample_batch(64)
+    assert (batch["rew"].round() % 5 == 0).float().mean() > 0.5   # 1 in 5 stored transitions, most of the sampled ones
+
+
 class _SyncTrap:
     """Stands for a device scalar: any attempt to read it on the host (a stream sync on a GPU) raises."""
 

@@ -160,7 +160,7 @@ struct SplitPolicy {
     // s_bias: [.][ldb] hidden biases; s_wo4: [256][4] head weights, feature-major, rows a >= A zero; s_bo: [4] head bias
     __device__ __forceinline__ float run(const RolloutParams& p, const float* xs, int ldx, char* xq, int rowb0, char* hq,
                                          float* s_part, const float* s_bias, int ldb, const float* s_wo4, const float* s_bo,
-                                         int tid, bool stash, size_t row0, DbgClock& dbg) {
+                                         int tid, bool stash, size_t row0, DbgClock& dbg, bool combine = true) {
         const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
         const MlpDev& M = p.pol;
         constexpr int ROWB1 = 2 * 256 + 16;
@@ -251,6 +251,7 @@ struct SplitPolicy {
         }
         DBG_TICK(2)
         __syncthreads();
+        if (!combine) return 0.f;   // (the caller sums the four waves' partials itself, in the thread layout of its env phase)
         const int hm = tid >> 4, la = tid & 15;
         float ya = 0.f;
         if (la < GOPS_MAX_ACT)
@@ -529,6 +530,21 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
     float veh_s = 0.f, veh_c = 1.f;   // sin/cos of the current heading, carried across steps
     __syncthreads();
     if (VEH) sincosf(s_state[(tid & 15) * 8 + 2], &veh_s, &veh_c);
+    // FASTV (plane-split stationary kernel, veh3dofconti = the headline workload): thread (m = tid & 15, part = tid >> 4) keeps the
+    // state and the done flag of trajectory m in registers across the steps, sums the head partials of ITS trajectory, squashes
+    // and wraps both actions itself - all 16 parts of a trajectory compute the same values - and walks its reference points.
+    // Against the general path below that is two barriers per step less (behind tanh / wrap, and inside the env phase) and no
+    // LDS round trip for actions, state and done flag.  Same functions in the same order: bit-identical results.
+    constexpr bool FASTV = SPLIT && ENV == GOPS_ENV_VEH3DOFCONTI;
+    float fs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, fdone = 0.f;
+    ActC fc0 = {}, fc1 = {};
+    if constexpr (FASTV) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) fs[i] = s_state[(tid & 15) * 8 + i];
+        fdone = s_done[tid & 15];
+        fc0 = act_const(s_ac, 0);
+        fc1 = act_const(s_ac, 1);
+    }
     settle_loads();
     for (int t = 0; t < p.H; ++t) {
         if (p.fh && tid < TB) xs[tid * ldx + O] = (float)(t + 1);
@@ -552,7 +568,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
             float y[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
             float ya_split = 0.f;
             if constexpr (SPLIT) {
-                ya_split = SP.run(p, xs, ldx, xq, rowb0, hq, s_part, s_bias, ldh, s_wo, s_bo, tid, p.need_grad != 0, row0, dbg);
+                ya_split = SP.run(p, xs, ldx, xq, rowb0, hq, s_part, s_bias, ldh, s_wo, s_bo, tid, p.need_grad != 0, row0, dbg, !FASTV);
             } else if constexpr (SS) {
 #ifdef GOPS_DUMP
                 float* dmp = (p.dbg != nullptr && VEH) ? reinterpret_cast<float*>(p.dbg) + ((((size_t)tile * p.H + t) * NTHREADS + tid) << 6) : nullptr;
@@ -585,7 +601,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                     DBG_TICK(6)
                 }
             }
-            {   // lane a of each 16-lane trajectory group squashes and wraps action a (row16_sum left y in every lane)
+            if constexpr (!FASTV) {   // lane a of each 16-lane trajectory group squashes and wraps action a (row16_sum left y in every lane)
                 const int hm = tid >> 4, la = tid & 15;
                 float ya = (la == 0) ? y[0] : (la == 1) ? y[1] : (la == 2) ? y[2] : y[3];
                 if constexpr (SPLIT || SS) ya = ya_split;
@@ -606,10 +622,12 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                 }
             }
         }
+        if constexpr (!FASTV) {
         DBG_TICK(7)
         __syncthreads();
         DBG_TICK(3)
-        if (p.need_grad && tid < TB) {   // env stash row: tanh outputs, done_t, state_t
+        }
+        if (!FASTV && p.need_grad && tid < TB) {   // env stash row: tanh outputs, done_t, state_t
             GLOBAL_AS f32x4* er = gptr(reinterpret_cast<f32x4*>(p.st.env + (row0 + tid) * ENV_STASH));
             f32x4 e0 = {s_th[tid * 4 + 0], s_th[tid * 4 + 1], s_th[tid * 4 + 2], s_th[tid * 4 + 3]};
             if (VEH) {   // two actions: the free slots carry the wrapped (steer, a_x) for the backward sweep
@@ -624,7 +642,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
             er[2] = e2;
         }
 
-        DBG_TICK(4)
+        if constexpr (!FASTV) DBG_TICK(4)
         // ---------------- env model step + MaskAtDone / ShapingReward / ClipObservation ---------
         float r = 0.f;          // raw model reward (threads tid < TB)
         bool done_m = false;    // done flag from the base model
@@ -824,6 +842,70 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                     for (int i = 1; i <= P; ++i) xo[3 + i] = sn[0] - tbl[i][1];
                 }
             }
+        } else if constexpr (FASTV) {   // GOPS_ENV_VEH3DOFCONTI on the plane-split stationary kernel: state / done flag / actions in registers
+            const int m = tid & 15, part = tid >> 4;
+            const int P = p.env.pre_horizon;
+            // head pre-activations of trajectory m: the four waves' partials, summed in the order of SplitPolicy::run's own combine
+            const float* sp = s_part + m * 4;
+            const float y0 = ((sp[0] + sp[TB * 4]) + (sp[2 * TB * 4] + sp[3 * TB * 4])) + s_bo[0];
+            const float y1 = ((sp[1] + sp[TB * 4 + 1]) + (sp[2 * TB * 4 + 1] + sp[3 * TB * 4 + 1])) + s_bo[1];
+            const float th0 = fast_tanh(y0), th1 = fast_tanh(y1);
+            const float steer = wrap_action(fc0, fc0.sc * th0 + fc0.of), ax = wrap_action(fc1, fc1.sc * th1 + fc1.of);
+            const float dflag = fdone;
+            DBG_TICK(7)
+            GLOBAL_AS f32x4* er = gptr(reinterpret_cast<f32x4*>(p.st.env + (row0 + tid) * ENV_STASH));
+            if (p.need_grad && tid < TB) {   // env stash row: tanh outputs + wrapped (steer, a_x), done_t, state_t
+                const f32x4 e0 = {th0, th1, steer, ax}, e1 = {dflag, fs[0], fs[1], fs[2]}, e2 = {fs[3], fs[4], fs[5], 0.f};
+                er[0] = e0;
+                er[1] = e1;
+                er[2] = e2;
+            }
+            DBG_TICK(4)
+            float sn[6];
+            VehStep w;
+            w.sphi = veh_s; w.cphi = veh_c;
+            veh_f_xu(VC, fs, steer, ax, sn, w);
+            if (part == 0) {
+                float o[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) o[i] = xs[m * ldx + i];
+                r = veh_reward(o, steer, ax);
+            }
+            const float s_old = veh_s, c_old = veh_c;
+            sincosf(sn[2], &veh_s, &veh_c);                 // also next step's f_xu heading terms
+            if (p.need_grad && tid < TB) {   // 4th quad of the env stash row: the backward sweep reuses both sin / cos pairs
+                const f32x4 e3 = {s_old, c_old, veh_s, veh_c};
+                er[3] = e3;
+            }
+            const float cn = veh_c, snn = -veh_s;           // cos(-phi'), sin(-phi')
+            const f32x4* tbl = s_ref + m * TL + (t + 1);
+            {   // point 0: the base model's done test reads its transform - every part evaluates it (the flag lives in registers)
+                const f32x4 rp = tbl[0];
+                const float dx = rp[0] - sn[0], dy = rp[1] - sn[1];
+                const float xtf = dx * cn - dy * snn;
+                const float ytf = dx * snn + dy * cn;
+                const float ptf = angle_normalize(rp[2] - sn[2]);
+                const float utf = rp[3] - sn[3];
+                done_m = (fabsf(xtf) > 10.f) || (fabsf(ytf) > 10.f) || (fabsf(ptf) > 3.14159265358979323846f);
+                if (part == 0 && dflag == 0.f) {
+                    xs[m * ldx + 0] = xtf; xs[m * ldx + 1] = ytf; xs[m * ldx + 2] = ptf;
+                    xs[m * ldx + 3] = utf; xs[m * ldx + 4] = sn[4]; xs[m * ldx + 5] = sn[5];
+                }
+            }
+            for (int j = (part == 0) ? 16 : part; j <= P; j += 16) {
+                const f32x4 rp = tbl[j];
+                const float dx = rp[0] - sn[0], dy = rp[1] - sn[1];
+                const float xtf = dx * cn - dy * snn;
+                const float ytf = dx * snn + dy * cn;
+                const float ptf = angle_normalize(rp[2] - sn[2]);
+                const float utf = rp[3] - sn[3];
+                if (dflag == 0.f) {
+                    float* dst = xs + m * ldx + 6 + 4 * (j - 1);
+                    dst[0] = xtf; dst[1] = ytf; dst[2] = ptf; dst[3] = utf;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) fs[i] = sn[i];
         } else {   // GOPS_ENV_VEH3DOFCONTI: all 256 threads, thread = (trajectory m, part)
             const int m = tid & 15, part = tid >> 4;
             const int P = p.env.pre_horizon;
@@ -966,7 +1048,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
             }
         }
         if (tid < TB) {
-            const float d = s_done[tid];
+            const float d = FASTV ? fdone : s_done[tid];
             float rr = (d != 0.f) ? 0.f : r;
             if (ENV != GOPS_ENV_NONE && p.env.shaping) rr = (rr + p.env.reward_shift) * p.env.reward_scale;
             v_acc += rr * p.gpow[t];
@@ -977,9 +1059,19 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
             }
 #endif
             if (p.out.rewards != nullptr && tid < nvalid) gptr(p.out.rewards)[(size_t)t * p.B + b0 + tid] = rr;
-            if (done_m && !p.env.no_mask_at_done) s_done[tid] = 1.f;
+            if (!FASTV && done_m && !p.env.no_mask_at_done) s_done[tid] = 1.f;
+        }
+        if constexpr (FASTV) {
+            if (done_m && !p.env.no_mask_at_done) fdone = 1.f;   // (every part evaluated the done test of its trajectory)
         }
         DBG_TICK(5)
+    }
+    if constexpr (FASTV) {   // back to the LDS copies the code behind the loop reads
+        if (tid < TB) {
+            s_done[tid] = fdone;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) s_state[tid * 8 + i] = fs[i];
+        }
     }
     __syncthreads();
     if (p.env.no_mask_at_done && !SURR && tid < TB) {

@@ -112,6 +112,17 @@ class PrecisionGuard:
         self.checks = 0
 
     @staticmethod
+    def applies_to(*modules, env_kind=None) -> bool:
+        """Is there anything to guard?  Plane-split kernels exist for networks whose hidden layers are all 256 wide
+        (csrc/rollout_fwd.hip: split_eligible / ss_shape_ok) - narrower nets run exact fp32 products anyway -, and two gradient
+        evaluations of the same batch are only comparable when the model is deterministic (pyth_mobilerobot draws its obstacle
+        noise per rollout)."""
+        from gops_amd import hip_backend as hb
+        if env_kind == hb.ENV_MOBILEROBOT:
+            return False
+        return any(all(l.out_features == 256 for l in m.linear_layers()[:-1]) for m in modules)
+
+    @staticmethod
     def fwd_exact_flags():
         from gops_amd import hip_backend as hb
         return hb.VF_NO_STATIONARY_SPLIT | hb.VF_NO_STREAMED_SPLIT_FWD | hb.VF_NO_STREAMED_SPLIT_VALUE

@@ -180,7 +180,10 @@ class INFADP(AlgorithmBase):
         `batch` is formed with the launch's own kernels and with the exact-fp32 forward; beyond the threshold that network's
         launches stay on the exact forward."""
         guard = self.precision_guard[mode]
-        if self.mlp_dtype != "fp32" or not guard.due():
+        if self.mlp_dtype != "fp32" or not PrecisionGuard.applies_to(self.networks.policy, self.networks.v,
+                                                                      env_kind=getattr(self.envmodel.unwrapped, "hip_kind", None)):
+            return
+        if not guard.due():
             return
 
         def flat_gradient(flags):

@@ -571,8 +571,10 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     if (!only_b) {
     // max|grad_v| belongs to THIS backward call: the sweep (fp32) / the upload kernel (half) only ever raise gscale[0], so a
     // second backward after the same forward with a much smaller grad_v would inherit the larger scale and push its scaled
-    // deltas into half subnormals (advisor finding, round 3).  One 1-block launch.
-    if ((e = launch_fill_zero(p.gscale, 4, s)) != hipSuccess) return (int)e;
+    // deltas into half subnormals (advisor finding, round 3).  Invariant: gscale[0] is ZERO when a backward call starts - the
+    // forward's prologue zeroes it, and every backward call leaves it zero behind its last reader: fp32 calls that end with the
+    // split-K reduce reset it there (ReduceJobs.reset: no extra launch - round 5; it was a 1-block fill in front of every sweep),
+    // the others (half precision: the reduce itself reads it; open loop / no parameter gradients: no reduce) with a fill at their end.
     if ((p.f16 || force_upload) && (e = launch_upload_params(p, plan.dev_params, s)) != hipSuccess) return (int)e;
     {
         ProfScope scope(desc.env.kind == GOPS_ENV_NONE ? 4 : 1, s);
@@ -597,7 +599,8 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
                 h[0] / p.H, h[10] / p.H, h[11] / p.H, h[1] / p.H, h[3] / p.H, h[4] / p.H, h[5] / p.H, h[6] / p.H, h[7] / p.H,
                 h[8] / p.H, h[9] / p.H, h[2] / p.H);
     }
-    if (p.open_loop || !want_params) return GOPS_OK;   // no parameters behind the rollout / none wanted
+    if (p.open_loop || !want_params)   // no parameters behind the rollout / none wanted: no reduce - gscale is reset here
+        return (int)launch_fill_zero(p.gscale, 4, s);
     ProfScope scope(desc.env.kind == GOPS_ENV_NONE ? 5 : 2, s);
     const int tile_rows = p.h64 ? 64 : TB;
     const long long S = (long long)((p.B + tile_rows - 1) / tile_rows) * tile_rows * p.H;
@@ -634,7 +637,10 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
         reduce_jobs_add(jobs, plan.dw_part[L], (int)splits, A, K, K, grad.weight[L]);
         reduce_jobs_add(jobs, plan.dw_part_b[L], (int)splits, 1, A, A, grad.bias[L]);
     }
+    // (two-phase backward: phase B's GEMM still reads the scale phase A's sweep left - the reset belongs to the LAST reduce of the call pair)
+    if (!p.f16 && !only_a && jobs.n > 0) jobs.reset = p.gscale;
     if ((e = launch_reduce(jobs, s)) != hipSuccess) return (int)e;
+    if ((p.f16 || jobs.n == 0) && !only_a && (e = launch_fill_zero(p.gscale, 4, s)) != hipSuccess) return (int)e;
     return GOPS_OK;
 }
 

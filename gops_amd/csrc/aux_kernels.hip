@@ -105,6 +105,17 @@ __device__ __forceinline__ void pack_split_tile(const float* __restrict__ W, int
     }
     if (tid == 0) inv[nt] = 1.f / s_r;
 }
+// The fp32 MFMA-fragment packings (wp / wpt) of the POLICY are read by the exact-fp32 kernels only.  A veh3dofconti launch on the
+// register-stationary plane-split kernels never reaches one - its sweep is the stationary plane-split sweep, and the calls that
+// would divert a backward to the fp32 kernels after the forward has planned (terminal adjoints / gops_rollout_backward_adj,
+// ActionRepeat, open loop: the EXT / GEN instantiations) do not exist for the vehicle models - so the 384 blocks of that packing
+// (obs -> 256 -> 256) would be written for nobody.  Every other launch keeps it (an lq / idpendulum rollout may get an `_adj`
+// backward, a value / MLP batch an `ext_delta` one, decided only at backward time).  The tail value net always keeps its packing
+// (exact-fp32 tail evaluation).  Returns the first net to pack.
+__host__ __device__ inline int fp32_pack_first_net(const RolloutParams& p) {
+    return (!p.f16 && p.sp.on && p.env.kind == GOPS_ENV_VEH3DOFCONTI) ? 1 : 0;
+}
+
 __host__ __device__ inline int split_pack_blocks(const RolloutParams& p) {
     if (p.ss || p.ssb) {   // streamed-split forward: one block per n-tile of every hidden layer of the policy (and the tail value net)
         int nb = 0;
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
         return;
     }
     b -= 1;
-    for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
+    for (int m = fp32_pack_first_net(p); m < (p.tail ? 2 : 1); ++m) {
         const MlpDev& d = m ? p.val : p.pol;
         for (int j = 0; j < d.nl - 1; ++j) {
             if (p.f16) {
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
 
 hipError_t launch_prologue(const RolloutParams& p, RolloutParams* dst, int P, float pdt, hipStream_t s) {
     int nb = 1;
-    for (int m = 0; m < (p.tail ? 2 : 1); ++m) {
+    for (int m = fp32_pack_first_net(p); m < (p.tail ? 2 : 1); ++m) {
         const MlpDev& d = m ? p.val : p.pol;
         if (!p.f16) { nb += pack_blocks(d); continue; }
         for (int j = 0; j < d.nl - 1; ++j) nb += pack_blocks_h(d, j);
@@ -1476,6 +1487,7 @@ hipError_t launch_dw_out(const float* dy, const float* h, bool h_is_half, int K,
 // deterministic).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs jobs) {
     __shared__ float red[4][64];
+    if (jobs.reset != nullptr && blockIdx.x == 0 && threadIdx.x == 0) jobs.reset[0] = 0.f;
     int j = 0;
     while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.block0[j + 1]) ++j;
     const float* __restrict__ part = jobs.part[j];

@@ -223,6 +223,8 @@ struct ReduceJobs {
     int splits[2 * GOPS_MAX_LAYERS], rows[2 * GOPS_MAX_LAYERS], cols[2 * GOPS_MAX_LAYERS], ld[2 * GOPS_MAX_LAYERS];
     int slab_rows[2 * GOPS_MAX_LAYERS];    // rows of one split's slab (>= rows: the slab of a padded output layer has more)
     const float* unscale;                  // f16: device pointer to max|grad_v| (RolloutParams::gscale), else null
+    float* reset;                          // fp32 launches: RolloutParams::gscale, zeroed here for the NEXT backward call (nothing in this
+                                           // kernel reads it, and every consumer of this call - sweep, weight-gradient GEMMs - is done)
 };
 
 // GOPS_DTYPE_F16 backward: the power of two s that brings max|grad_v| = m into [1, 2).  The whole sweep runs

@@ -133,6 +133,12 @@ def test_precision_guard_schedule_and_decision():
     assert g2.exact
     off = PrecisionGuard(interval=0)
     assert not any(off.due() for _ in range(5))
+    # nothing to guard for nets that never reach a plane-split kernel (hidden width != 256) or for a stochastic model
+    from gops_amd.create_pkg.create_alg import create_alg
+    narrow = create_alg(**_fhadp_kwargs()).networks.policy
+    wide = create_alg(**_fhadp_kwargs(policy_hidden_sizes=[256, 256])).networks.policy
+    assert not PrecisionGuard.applies_to(narrow) and PrecisionGuard.applies_to(wide) and PrecisionGuard.applies_to(narrow, wide)
+    assert not PrecisionGuard.applies_to(wide, env_kind=hb.ENV_MOBILEROBOT)
     # the exact-forward flags leave the sweep and the weight-gradient GEMM alone
     f = PrecisionGuard.fwd_exact_flags()
     assert f & (hb.VF_NO_STREAMED_SPLIT_BWD | hb.VF_DW_F32 | hb.VF_DW_EXACT | hb.VF_STREAMED_FP32) == 0

@@ -260,6 +260,16 @@ inline void lq_pad_env(GopsEnv& e) {
 #define ENV_LDS_FLOATS ((int)((sizeof(GopsEnv) + 15) / 16) * 4)
 __host__ __device__ constexpr bool env_in_lds(int env_kind, bool streamed_split) { return streamed_split && env_kind == GOPS_ENV_LQ; }
 
+// A uniform value of the parameter block, pinned to scalar registers for the duration of a kernel.  The rollout kernels read
+// their description through a `const RolloutParams&` in global memory; under register pressure hipcc does not keep such values -
+// it RELOADS them where they are used (s_load_dword + s_waitcnt lgkmcnt(0), which also drains the LDS queue): 12 - 22 scalar
+// round trips per rollout step in the round-4 plane-split kernels.  Passing the value through an empty asm makes it opaque: it
+// can no longer be rematerialised from memory and stays in an SGPR (or a VGPR lane) for the whole step loop.
+template <bool ON = true, class T>
+__device__ __forceinline__ T keep_s(T v) {
+    if constexpr (ON) asm volatile("" : "+s"(v));
+    return v;
+}
 // ---- activations ---------------------------------------------------------------------------
 #define SELU_SCALE 1.0507009873554804934193349852946f
 #define SELU_ALPHA 1.6732632423543772848170429916717f
@@ -413,6 +423,16 @@ __device__ __forceinline__ float wrap_action_bwd(const GopsEnv& e, int i, float 
     if (!(a2 >= e.act_low[i] && a2 <= e.act_high[i])) g = 0.f;   // both clamps see the same range
     g = g * (e.act_high[i] - e.act_low[i]) / (e.max_action[i] - e.min_action[i]);
     if (!(abar >= e.min_action[i] && abar <= e.max_action[i])) g = 0.f;
+    return g;
+}
+
+// the same adjoint on per-action constants held in registers (ActC: the sweep of the plane-split kernels pins them to SGPRs)
+__device__ __forceinline__ float wrap_action_bwd(const ActC& e, float abar, float g) {
+    const float a1 = clampf(abar, e.min_action, e.max_action);
+    const float a2 = e.act_low + (e.act_high - e.act_low) * ((a1 - e.min_action) / (e.max_action - e.min_action));
+    if (!(a2 >= e.act_low && a2 <= e.act_high)) g = 0.f;   // both clamps see the same range
+    g = g * (e.act_high - e.act_low) / (e.max_action - e.min_action);
+    if (!(abar >= e.min_action && abar <= e.max_action)) g = 0.f;
     return g;
 }
 

@@ -187,6 +187,19 @@ struct SplitSweep {
         if constexpr (STREAMT0) QT0.load(p.sp.w1t[0], p.sp.rt[0], p.sp.invt[0], M.kp[0] >> 4, tid);
         else QT0.load(p.sp.w1t[0], p.sp.rt[0], p.sp.invt[0], M.kp[0] >> 4, tid, rt0_lds);
         const int K = M.dims[2], A = M.dims[3], kk = lane >> 4;
+        hot.act = keep_s(M.act);
+        hot.A = keep_s(A);
+        const bool gelu_l = M.act == GOPS_ACT_GELU;
+        hot.a[0] = nullptr; hot.d[0] = nullptr;
+        {   // (pinned first, selected after: a select on the loaded pointers themselves may be formed on the vector unit)
+            const float* const h1 = keep_s<true, const float*>(p.st.h[1]), * const h2 = keep_s<true, const float*>(p.st.h[2]);
+            const float* const z1 = keep_s<true, const float*>(p.st.z[1]), * const z2 = keep_s<true, const float*>(p.st.z[2]);
+            hot.a[1] = gelu_l ? z1 : h1;
+            hot.a[2] = gelu_l ? z2 : h2;
+        }
+        hot.d[1] = keep_s(p.st.d[1]); hot.d[2] = keep_s(p.st.d[2]);
+        hot.dy = keep_s(p.st.dy);
+        hot.h2 = keep_s<true, const float*>(p.st.h[2]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) wo[q] = (kk < A) ? gptr(M.w[2])[kk * K + 64 * wave + 16 * q + (lane & 15)] : 0.f;
 #pragma unroll
@@ -217,9 +230,18 @@ struct SplitSweep {
     // The act' operands come straight from the FM stash into registers (one 16-byte vector per column), issued a phase
     // ahead of their use: H_2 at the top of the step (used after the env adjoint), H_1 right after the head (used after the
     // delta_1 contraction).  (The fp32-MFMA variants stage these tiles in LDS; here that LDS holds W_0's residual plane.)
-    __device__ __forceinline__ void fetch(const RolloutParams& p, int j, size_t row0, int tid) {
+    // what fetch() / run() read of the parameter block, pinned to scalar registers by the kernel (common.h keep_s)
+    struct Hot {
+        int act, A;
+        const float* a[3];   // act' operand tensors of hidden layers 1, 2: H_j, or gelu'(z_j) for GELU
+        float* d[3];         // delta stashes of hidden layers 1, 2
+        float* dy;
+        const float* h2;     // H_2 (fused output-layer gradient with GELU)
+    };
+    Hot hot;
+    __device__ __forceinline__ void fetch(const RolloutParams&, int j, size_t row0, int tid) {
         const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
-        const GLOBAL_AS float* src = gptr((p.pol.act == GOPS_ACT_GELU ? p.st.z[j] : p.st.h[j]) + row0 * 256);
+        const GLOBAL_AS float* src = gptr(hot.a[j] + row0 * 256);
 #pragma unroll
         for (int q = 0; q < 4; ++q) hv[q] = ld4(src + (64 * wave + 16 * q + (lane & 15)) * 16 + m0);
     }
@@ -228,14 +250,13 @@ struct SplitSweep {
                                         float* G, int ldg, int tid, size_t row0, int nvalid, bool want_gx, int ncols,
                                         DbgClock& dbg, Hook&& after_head, bool fuse_out) {
         const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
-        const MlpDev& M = p.pol;
         constexpr int ROWB = 2 * 256 + 16;
-        const int A = M.dims[3];
+        const int A = hot.A;
         const float s = s_scale[0], inv_s = s_scale[1];
         // delta tile of layer j from the contraction result `a`: * act'(.), zero for padding rows, -> stash + plane image
         auto finish = [&](int j, f32x4 (&a)[4], char* planes) {
-            float* dst = p.st.d[j] + row0 * 256;
-            act_dispatch(M.act, [&]<int ACT>() {
+            float* dst = hot.d[j] + row0 * 256;
+            act_dispatch(hot.act, [&]<int ACT>() {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = 64 * wave + 16 * q + (lane & 15);
@@ -251,10 +272,10 @@ struct SplitSweep {
             const float ga = (kk < A) ? s_gy[(lane & 15) * 4 + kk] : 0.f;   // A operand: delta_y[m = lane & 15][k = lane >> 4]
             // GELU with the fused output-layer gradient: hv holds gelu'(z_2), H_2 itself is fetched here and lands behind the
             // head delta's epilogue (a short live range: as a member held across the env adjoint it spilled)
-            const bool gelu_fuse = fuse_out && M.act == GOPS_ACT_GELU;
+            const bool gelu_fuse = fuse_out && hot.act == GOPS_ACT_GELU;
             f32x4 h2v[4] = {};
             if (gelu_fuse) {
-                const GLOBAL_AS float* s2 = gptr(p.st.h[2] + row0 * 256);
+                const GLOBAL_AS float* s2 = gptr(hot.h2 + row0 * 256);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) h2v[q] = ld4(s2 + (64 * wave + 16 * q + (lane & 15)) * 16 + m0);
             }
@@ -283,7 +304,7 @@ struct SplitSweep {
 #pragma unroll
                 for (int a = 0; a < GOPS_MAX_ACT; ++a)
                     if (a >= A || tid >= nvalid) v[a] = 0.f;
-                *gptr(reinterpret_cast<f32x4*>(p.st.dy + (row0 + tid) * 4)) = v;
+                *gptr(reinterpret_cast<f32x4*>(hot.dy + (row0 + tid) * 4)) = v;
             }
         }
         DBG_TICK(3)
@@ -595,8 +616,26 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
     // waves 0 / 1 and read by everyone after the end-of-step barrier (which drains the loads).
     constexpr int STAGE_TILES = SPLIT ? 0 : 2 * TB * 256;   // (SPLIT: act' operands go stash -> registers, SplitSweep::fetch)
     constexpr int STAGE_FLOATS = STAGE_TILES + TB * ENV_STASH + TB * 8;
+    // SPLIT: what the step loop reads of the parameter block, pinned to scalar registers (common.h keep_s) - left to hipcc each
+    // of these is an s_load + s_waitcnt lgkmcnt(0) per step (22 of them in the round-4 sweep)
+    const int hH = keep_s<SPLIT>(p.H), hP = keep_s<SPLIT>(p.env.pre_horizon), hshaping = keep_s<SPLIT>(p.env.shaping);
+    const float hrscale = keep_s<SPLIT>(p.env.reward_scale);
+    const float* const hst_env = keep_s<SPLIT, const float*>(p.st.env);
+    const float* const hst_x = keep_s<SPLIT, const float*>(p.st.x);
+    ActC ha0 = {}, ha1 = {};   // per-action constants of the policy squash and the wrapper chain (actions 0, 1)
+    if constexpr (VEH) {
+        // (sc / of are float arithmetic, i.e. vector-unit results: the INPUTS are pinned, the two operations stay where they are used)
+        const float ph0 = keep_s<SPLIT>(p.env.policy_high[0]), pl0 = keep_s<SPLIT>(p.env.policy_low[0]);
+        const float ph1 = keep_s<SPLIT>(p.env.policy_high[1]), pl1 = keep_s<SPLIT>(p.env.policy_low[1]);
+        ha0.sc = (ph0 - pl0) / 2.f; ha0.of = (ph0 + pl0) / 2.f;
+        ha1.sc = (ph1 - pl1) / 2.f; ha1.of = (ph1 + pl1) / 2.f;
+        ha0.min_action = keep_s<SPLIT>(p.env.min_action[0]); ha0.max_action = keep_s<SPLIT>(p.env.max_action[0]);
+        ha0.act_low = keep_s<SPLIT>(p.env.act_low[0]); ha0.act_high = keep_s<SPLIT>(p.env.act_high[0]);
+        ha1.min_action = keep_s<SPLIT>(p.env.min_action[1]); ha1.max_action = keep_s<SPLIT>(p.env.max_action[1]);
+        ha1.act_low = keep_s<SPLIT>(p.env.act_low[1]); ha1.act_high = keep_s<SPLIT>(p.env.act_high[1]);
+    }
     auto stage_step = [&](int tt) {
-        const size_t r0 = ((size_t)tile * p.H + tt) * TB;
+        const size_t r0 = ((size_t)tile * hH + tt) * TB;
         const float* dst = s_stage + (tt & 1) * STAGE_FLOATS;
         const bool gelu_s = p.pol.act == GOPS_ACT_GELU;
         const float* src2 = (gelu_s ? p.st.z[2] : p.st.h[2]) + r0 * 256;
@@ -611,9 +650,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
             }
         }
         if (wv == 0)        // env rows: 16 x 64 B, contiguous
-            async_copy16_to_lds(p.st.env + r0 * ENV_STASH + 4 * ln, dst + STAGE_TILES);
+            async_copy16_to_lds(hst_env + r0 * ENV_STASH + 4 * ln, dst + STAGE_TILES);
         if (wv == 1 && ln < 2 * TB)   // first 8 observation columns: 8 x 64 B, contiguous in the FM tile -> st_x[i * 16 + m]
-            async_copy16_to_lds(p.st.x + r0 * kp0 + 4 * ln, dst + STAGE_TILES + TB * ENV_STASH);
+            async_copy16_to_lds(hst_x + r0 * kp0 + 4 * ln, dst + STAGE_TILES + TB * ENV_STASH);
         if constexpr (SPLIT && ENV == GOPS_ENV_IDPENDULUM) {   // the forward's sub-step parking of the tile: 16 x 512 B, contiguous
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2)
@@ -699,14 +738,14 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
     __syncthreads();
 
     if constexpr (STAGE) {
-        stage_step(p.H - 1);
+        stage_step(hH - 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
     unsigned l2_sink = 0, l2_pf[TOUCH_SLOTS] = {0u, 0u, 0u, 0u};
-    for (int t = p.H - 1; t >= 0; --t) {
-        const size_t row0 = ((size_t)tile * p.H + t) * TB;   // tile-major stash rows
+    for (int t = hH - 1; t >= 0; --t) {
+        const size_t row0 = ((size_t)tile * hH + t) * TB;   // tile-major stash rows
         const size_t prow = row0 - TB;
         const float* st_cur = s_stage + (t & 1) * STAGE_FLOATS;       // this step's staged data (STAGE only)
         const float* st_env = st_cur + STAGE_TILES;
@@ -725,7 +764,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
         };
         DBG_TICK(0)
         float g_r = gv * p.gpow[t];                         // adjoint of the shaped reward
-        if (ENV != GOPS_ENV_NONE && p.env.shaping) g_r *= p.env.reward_scale;
+        if (ENV != GOPS_ENV_NONE && hshaping) g_r *= hrscale;
         if constexpr (STAGE) {
             // Next step's tiles travel HBM -> LDS during this whole step.  Issued AFTER the first use of a
             // loaded value in the iteration (g_r above): hipcc drains vmcnt(0) there on every trip, and the
@@ -1224,7 +1263,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
             }
         } else {   // GOPS_ENV_VEH3DOFCONTI
             const int m = tid & 15, part = tid >> 4, lane = tid & 63, wave = tid >> 6;
-            const int P = p.env.pre_horizon;
+            const int P = hP;
             float th0 = 0.f, th1 = 0.f, dflag = 1.f, st_steer = 0.f, st_ax = 0.f;
             float s[6] = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f};
             f32x4 e3 = {0.f, 1.f, 0.f, 1.f};   // sin / cos of the heading before and after the step (forward's values)
@@ -1241,10 +1280,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
                 s[0] = e1[1]; s[1] = e1[2]; s[2] = e1[3]; s[3] = e2[0]; s[4] = e2[1]; s[5] = e2[2];
             }
             const bool dn = dflag != 0.f;
-            const float sc0 = (p.env.policy_high[0] - p.env.policy_low[0]) / 2.f;
-            const float sc1 = (p.env.policy_high[1] - p.env.policy_low[1]) / 2.f;
-            const float abar0 = sc0 * th0 + (p.env.policy_high[0] + p.env.policy_low[0]) / 2.f;
-            const float abar1 = sc1 * th1 + (p.env.policy_high[1] + p.env.policy_low[1]) / 2.f;
+            const float sc0 = ha0.sc, sc1 = ha1.sc;
+            const float abar0 = sc0 * th0 + ha0.of;
+            const float abar1 = sc1 * th1 + ha1.of;
             const float steer = st_steer, ax = st_ax;   // = wrap_action(abar0 / abar1), stashed by the forward kernel
             float sn[6];
             VehStep w;
@@ -1414,8 +1452,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
                 }
                 g_steer += g_rm * ((SURR ? -2.f * p.env.reward_w[5] : -0.02f) * steer);
                 g_ax += g_rm * ((SURR ? -2.f * p.env.reward_w[6] : -0.02f) * ax);
-                s_gy[m * 4 + 0] = p.open_loop == 2 ? g_steer : wrap_action_bwd(p.env, 0, abar0, g_steer) * sc0 * (1.f - th0 * th0);
-                s_gy[m * 4 + 1] = p.open_loop == 2 ? g_ax : wrap_action_bwd(p.env, 1, abar1, g_ax) * sc1 * (1.f - th1 * th1);
+                // (open_loop == 2, the raw-action rollouts of OptController, never reaches a SPLIT kernel)
+                s_gy[m * 4 + 0] = (!SPLIT && p.open_loop == 2) ? g_steer : wrap_action_bwd(ha0, abar0, g_steer) * sc0 * (1.f - th0 * th0);
+                s_gy[m * 4 + 1] = (!SPLIT && p.open_loop == 2) ? g_ax : wrap_action_bwd(ha1, abar1, g_ax) * sc1 * (1.f - th1 * th1);
                 s_gy[m * 4 + 2] = 0.f;
                 s_gy[m * 4 + 3] = 0.f;
             }
@@ -1527,6 +1566,10 @@ bool ssb_eligible(const RolloutParams& p) {
 
 hipError_t launch_rollout_bwd_h64(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream);   // rollout_h64.hip
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream) {
+#ifdef GOPS_ONLY_TARGET   // register / spill studies (EXTRA=-DGOPS_ONLY_TARGET tools/kernel_regs.sh rollout_bwd.hip): ONE instantiation, seconds to compile
+    launch_with_lds(rollout_bwd_kernel<GOPS_ENV_VEH3DOFCONTI, 8, 8, false, 2, false, false, true>, dim3(1), dim3(NTHREADS), 0, stream, dp, q);
+    return hipGetLastError();
+#else
     if (p.h64) return launch_rollout_bwd_h64(p, dp, q, stream);   // half precision, 64-trajectory tiles
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
@@ -1638,4 +1681,5 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+#endif
 }

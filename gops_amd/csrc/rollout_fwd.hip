@@ -158,18 +158,22 @@ struct SplitPolicy {
         Q1.load(p.sp.w1[1], p.sp.r[1], p.sp.inv[1], M.dims[2] >> 4, tid);
     }
     // s_bias: [.][ldb] hidden biases; s_wo4: [256][4] head weights, feature-major, rows a >= A zero; s_bo: [4] head bias
-    __device__ __forceinline__ float run(const RolloutParams& p, const float* xs, int ldx, char* xq, int rowb0, char* hq,
+    // what run() reads of the parameter block, pinned to scalar registers by the caller (common.h keep_s)
+    struct Hot {
+        int kp0, act;
+        float *h1, *h2, *z1, *z2;
+    };
+    __device__ __forceinline__ float run(const Hot& hot, const float* xs, int ldx, char* xq, int rowb0, char* hq,
                                          float* s_part, const float* s_bias, int ldb, const float* s_wo4, const float* s_bo,
                                          int tid, bool stash, size_t row0, DbgClock& dbg, bool combine = true) {
         const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
-        const MlpDev& M = p.pol;
         constexpr int ROWB1 = 2 * 256 + 16;
         StreamRing<KC0> ring0;
         if constexpr (STREAM0) Q0.prime(ring0, 0);   // the first chunks of W_0's planes travel during the conversion pass
-        plane_convert_x(xs, ldx, M.kp[0], 32 * KC0, xq, rowb0, tid, SPLIT_FWD_SA);
+        plane_convert_x(xs, ldx, hot.kp0, 32 * KC0, xq, rowb0, tid, SPLIT_FWD_SA);
         __syncthreads();
         DBG_TICK(1)
-        const bool gelu = M.act == GOPS_ACT_GELU;
+        const bool gelu = hot.act == GOPS_ACT_GELU;
         // ---- hidden layer 0 ----
         {
             f32x4 acc[4] = {}, accr[4] = {};
@@ -185,10 +189,10 @@ struct SplitPolicy {
                 gemm_split(xq, rowb0, Q0, lane, acc, accr);
             }
             DBG_TICK(14)
-            float* hrow = stash ? p.st.h[1] + row0 * 256 : nullptr;
-            float* zrow = (stash && gelu) ? p.st.z[1] + row0 * 256 : nullptr;
+            float* hrow = stash ? hot.h1 + row0 * 256 : nullptr;
+            float* zrow = (stash && gelu) ? hot.z1 + row0 * 256 : nullptr;
             f32x4 hv[4];
-            act_dispatch(M.act, [&]<int ACT>() {
+            act_dispatch(hot.act, [&]<int ACT>() {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = 64 * wave + 16 * q + (lane & 15);
@@ -216,10 +220,10 @@ struct SplitPolicy {
             f32x4 acc[4] = {}, accr[4] = {};
             gemm_split(hq, ROWB1, Q1, lane, acc, accr);
             DBG_TICK(11)
-            float* hrow = stash ? p.st.h[2] + row0 * 256 : nullptr;
-            float* zrow = (stash && gelu) ? p.st.z[2] + row0 * 256 : nullptr;
+            float* hrow = stash ? hot.h2 + row0 * 256 : nullptr;
+            float* zrow = (stash && gelu) ? hot.z2 + row0 * 256 : nullptr;
             float part[4][AMAX] = {};
-            act_dispatch(M.act, [&]<int ACT>() {
+            act_dispatch(hot.act, [&]<int ACT>() {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = 64 * wave + 16 * q + (lane & 15);
@@ -481,6 +485,22 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
     if (dbg.on) dbg.acc[13] = dbg.last - t_entry;
 #endif
     const int ntiles = (p.B + TB - 1) / TB;
+    // SPLIT: everything the step loop reads of the parameter block, pinned to scalar registers (common.h keep_s) - left to
+    // hipcc each of these is an s_load + s_waitcnt lgkmcnt(0) per step (16 of them in the round-4 forward)
+    const int hH = keep_s<SPLIT>(p.H), hfh = keep_s<SPLIT>(p.fh), hng = keep_s<SPLIT>(p.need_grad), hB = keep_s<SPLIT>(p.B);
+    const int hkp0 = keep_s<SPLIT>(p.pol.kp[0]), hP = keep_s<SPLIT>(p.env.pre_horizon);
+    const int hnomask = keep_s<SPLIT>(p.env.no_mask_at_done), hshaping = keep_s<SPLIT>(p.env.shaping);
+    const float hrshift = keep_s<SPLIT>(p.env.reward_shift), hrscale = keep_s<SPLIT>(p.env.reward_scale);
+    float* const hst_x = keep_s<SPLIT>(p.st.x);
+    float* const hst_env = keep_s<SPLIT>(p.st.env);
+    float* const hrewards = keep_s<SPLIT>(p.out.rewards);
+    typename std::conditional<SPLIT, typename SplitPolicy<(SK0 > 0 ? SK0 : 1), AMAX>::Hot, NoSplit>::type sp_hot;
+    if constexpr (SPLIT) {
+        sp_hot.kp0 = hkp0;
+        sp_hot.act = keep_s(p.pol.act);
+        sp_hot.h1 = keep_s(p.st.h[1]); sp_hot.h2 = keep_s(p.st.h[2]);
+        sp_hot.z1 = keep_s(p.st.z[1]); sp_hot.z2 = keep_s(p.st.z[2]);
+    }
     do {   // ---- one tile of 16 trajectories (SPLIT: a grid-stride walk over the tiles) ----
     b0 = tile * TB;
     nvalid = min(TB, p.B - b0);
@@ -546,11 +566,12 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
         fc1 = act_const(s_ac, 1);
     }
     settle_loads();
-    for (int t = 0; t < p.H; ++t) {
-        if (p.fh && tid < TB) xs[tid * ldx + O] = (float)(t + 1);
+    for (int t = 0; t < hH; ++t) {
+        if (hfh && tid < TB) xs[tid * ldx + O] = (float)(t + 1);
         __syncthreads();
         DBG_TICK(0)
-        const size_t row0 = ((size_t)tile * p.H + t) * TB;   // tile-major stash: a tile's rows are contiguous over t
+        const float gpow_t = p.gpow[t];   // (requested at the top of the step: consumed by the reward bookkeeping at its end)
+        const size_t row0 = ((size_t)tile * hH + t) * TB;   // tile-major stash: a tile's rows are contiguous over t
         if constexpr (F16) {
             // half copy of the input tile (LDS, and the stash rows the weight-gradient GEMM reads); the env
             // adjoints get the first 8 observation columns in fp32
@@ -561,14 +582,14 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                     *reinterpret_cast<const f32x4*>(xs + (tid >> 1) * ldx + 4 * (tid & 1));
             __syncthreads();
         } else {
-            if (p.need_grad) stash_tile_fm(xs, ldx, p.pol.kp[0], p.st.x + row0 * p.pol.kp[0], tid);
+            if (hng) stash_tile_fm(xs, ldx, hkp0, hst_x + row0 * hkp0, tid);
         }
         if constexpr (!SPLIT) DBG_TICK(1)
         {
             float y[GOPS_MAX_ACT] = {0.f, 0.f, 0.f, 0.f};
             float ya_split = 0.f;
             if constexpr (SPLIT) {
-                ya_split = SP.run(p, xs, ldx, xq, rowb0, hq, s_part, s_bias, ldh, s_wo, s_bo, tid, p.need_grad != 0, row0, dbg, !FASTV);
+                ya_split = SP.run(sp_hot, xs, ldx, xq, rowb0, hq, s_part, s_bias, ldh, s_wo, s_bo, tid, hng != 0, row0, dbg, !FASTV);
             } else if constexpr (SS) {
 #ifdef GOPS_DUMP
                 float* dmp = (p.dbg != nullptr && VEH) ? reinterpret_cast<float*>(p.dbg) + ((((size_t)tile * p.H + t) * NTHREADS + tid) << 6) : nullptr;
@@ -844,7 +865,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
             }
         } else if constexpr (FASTV) {   // GOPS_ENV_VEH3DOFCONTI on the plane-split stationary kernel: state / done flag / actions in registers
             const int m = tid & 15, part = tid >> 4;
-            const int P = p.env.pre_horizon;
+            const int P = hP;
             // head pre-activations of trajectory m: the four waves' partials, summed in the order of SplitPolicy::run's own combine
             const float* sp = s_part + m * 4;
             const float y0 = ((sp[0] + sp[TB * 4]) + (sp[2 * TB * 4] + sp[3 * TB * 4])) + s_bo[0];
@@ -853,8 +874,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
             const float steer = wrap_action(fc0, fc0.sc * th0 + fc0.of), ax = wrap_action(fc1, fc1.sc * th1 + fc1.of);
             const float dflag = fdone;
             DBG_TICK(7)
-            GLOBAL_AS f32x4* er = gptr(reinterpret_cast<f32x4*>(p.st.env + (row0 + tid) * ENV_STASH));
-            if (p.need_grad && tid < TB) {   // env stash row: tanh outputs + wrapped (steer, a_x), done_t, state_t
+            GLOBAL_AS f32x4* er = gptr(reinterpret_cast<f32x4*>(hst_env + (row0 + tid) * ENV_STASH));
+            if (hng && tid < TB) {   // env stash row: tanh outputs + wrapped (steer, a_x), done_t, state_t
                 const f32x4 e0 = {th0, th1, steer, ax}, e1 = {dflag, fs[0], fs[1], fs[2]}, e2 = {fs[3], fs[4], fs[5], 0.f};
                 er[0] = e0;
                 er[1] = e1;
@@ -873,7 +894,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
             }
             const float s_old = veh_s, c_old = veh_c;
             sincosf(sn[2], &veh_s, &veh_c);                 // also next step's f_xu heading terms
-            if (p.need_grad && tid < TB) {   // 4th quad of the env stash row: the backward sweep reuses both sin / cos pairs
+            if (hng && tid < TB) {   // 4th quad of the env stash row: the backward sweep reuses both sin / cos pairs
                 const f32x4 e3 = {s_old, c_old, veh_s, veh_c};
                 er[3] = e3;
             }
@@ -1050,19 +1071,19 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
         if (tid < TB) {
             const float d = FASTV ? fdone : s_done[tid];
             float rr = (d != 0.f) ? 0.f : r;
-            if (ENV != GOPS_ENV_NONE && p.env.shaping) rr = (rr + p.env.reward_shift) * p.env.reward_scale;
-            v_acc += rr * p.gpow[t];
+            if (ENV != GOPS_ENV_NONE && hshaping) rr = (rr + hrshift) * hrscale;
+            v_acc += rr * gpow_t;
 #ifdef GOPS_DUMP
             if (SS && VEH && p.dbg != nullptr) {
                 float* dm = reinterpret_cast<float*>(p.dbg) + ((((size_t)tile * p.H + t) * NTHREADS + tid) << 6);
                 gptr(dm)[26] = rr; gptr(dm)[27] = v_acc;
             }
 #endif
-            if (p.out.rewards != nullptr && tid < nvalid) gptr(p.out.rewards)[(size_t)t * p.B + b0 + tid] = rr;
-            if (!FASTV && done_m && !p.env.no_mask_at_done) s_done[tid] = 1.f;
+            if (hrewards != nullptr && tid < nvalid) gptr(hrewards)[(size_t)t * hB + b0 + tid] = rr;
+            if (!FASTV && done_m && !hnomask) s_done[tid] = 1.f;
         }
         if constexpr (FASTV) {
-            if (done_m && !p.env.no_mask_at_done) fdone = 1.f;   // (every part evaluated the done test of its trajectory)
+            if (done_m && !hnomask) fdone = 1.f;   // (every part evaluated the done test of its trajectory)
         }
         DBG_TICK(5)
     }
@@ -1317,6 +1338,10 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
 // `p` is the host copy (for shape dispatch), `dp` the device copy the kernel reads.
 hipError_t launch_rollout_fwd_h64(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);   // rollout_h64.hip
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
+#ifdef GOPS_ONLY_TARGET   // register / ISA studies (EXTRA=-DGOPS_ONLY_TARGET tools/kernel_regs.sh rollout_fwd.hip): ONE instantiation, seconds to compile
+    launch_with_lds(rollout_fwd_kernel<GOPS_ENV_VEH3DOFCONTI, 4, 8, false, false, false, true>, dim3(1), dim3(NTHREADS), 0, stream, dp);
+    return hipGetLastError();
+#else
     if (p.h64) return launch_rollout_fwd_h64(p, dp, stream);   // half precision, 64-trajectory tiles
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
     const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0, p.f16 != 0,
@@ -1423,4 +1448,5 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+#endif
 }

@@ -171,7 +171,8 @@ template <int PT0, int AMAX>
 struct SplitSweep {
     float dwo[AMAX][4];          // dW_o[a][64 wave + 16 q + (lane & 15)], partial over rows 4 (lane >> 4) .. +3
     float dbo[AMAX];             // d b_o[a], same partial
-    StatQ<8, 4, false, GOPS_PIN_MODE> QT1;      // delta_2 -> delta_1 through W_1: both planes in registers
+    static constexpr int PIN1 = (AMAX == 2) ? 3 : GOPS_PIN_MODE;   // (rollout_fwd.hip SplitPolicy: both planes pinned for veh3dofconti: sweep 187.0 -> 183.8 us)
+    StatQ<8, 4, false, PIN1> QT1;      // delta_2 -> delta_1 through W_1: both planes in registers
     // delta_1 -> g_x through W_0: bf16 plane in registers, half residual plane in LDS; more than 128 inputs (PT0 > 2 n-tiles
     // per wave): both planes stream from L2 (StreamQ, common.h)
     static constexpr bool STREAMT0 = PT0 > 2;

@@ -149,7 +149,12 @@ template <int KC0, int AMAX>   // AMAX: compile-time bound of the action dimensi
 struct SplitPolicy {
     static constexpr bool STREAM0 = KC0 > SPLIT_MAX_RESIDENT_KC0;
     typename std::conditional<STREAM0, StreamQ<KC0, 4>, StatQ<KC0, 4, true>>::type Q0;   // layer 0: bf16 plane in registers, half residual plane in LDS - or both streamed
-    StatQ<8, 4, false, GOPS_PIN_MODE> Q1;       // layer 1: both planes in registers
+    // AGPR pinning of layer 1's planes (common.h pin_agpr): both planes for the veh3dofconti instantiations (AMAX == 2) - with the
+    // launch-time loads batched (round 5) pinning costs nothing at launch any more, and the 22 unpinned residual fragments that
+    // hipcc copied back to VGPRs in front of their MFMAs (88 x v_accvgpr_read per step) are gone: forward 181.7 -> 179.5 us; the
+    // idpendulum / lq instantiations measured better with the bf16 plane only (cfg2: 234.9 vs 236.9 us)
+    static constexpr int PIN1 = (AMAX == 2) ? 3 : GOPS_PIN_MODE;
+    StatQ<8, 4, false, PIN1> Q1;       // layer 1: both planes in registers
     // r0_lds: LDS region for layer 0's residual plane (16 n-tiles x KC0 chunks x 1 KiB); the caller's barrier publishes it
     __device__ __forceinline__ void load(const RolloutParams& p, int tid, f16x8* r0_lds) {
         const MlpDev& M = p.pol;

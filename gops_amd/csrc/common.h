@@ -332,6 +332,9 @@ __device__ __forceinline__ float act_fwd_t(float z) {
 // case, just above the switch point), the odd series up to x^7 below |x| = 1/8 (truncation 2e-10); branch-free.  libm's
 // tanhf is ~200 instructions with divergent branches and sat on the critical path of every step (head -> action).
 __device__ __forceinline__ float fast_tanh(float x) {
+#ifdef GOPS_EXACT_TANH   // A/B knob (make variant VFLAGS=-DGOPS_EXACT_TANH): libm's tanhf in the plane-split kernels too
+    return tanhf(x);
+#endif
     const float ax = fabsf(x), x2 = x * x;
     const float t = __expf(-2.f * ax);
     const float big = (1.f - t) * __builtin_amdgcn_rcpf(1.f + t);

@@ -79,6 +79,34 @@ __device__ __forceinline__ void pack_split_tile(const float* __restrict__ W, int
         if (!transposed) return (col < N && f < K) ? W[(size_t)col * K + f] : 0.f;   // W[out = col][in = f]
         return (f < N && col < K) ? W[(size_t)f * K + col] : 0.f;                     // W[out = f][in = col]
     };
+#if GOPS_SPLIT_F16X2
+    // two half planes of w s_w: wh = f16(w s_w) (round to nearest), wl = f16((w s_w - wh) 2^11); s_w = the power of two that brings the
+    // tile's largest |w| into [2^13, 2^14) - fp32's exponent range for the weights, and small-weight tiles use the half's normal range
+    float mx = 0.f;
+    for (int e = tid; e < total; e += 256) mx = fmaxf(mx, fabsf(wval(e)));
+    red[tid] = mx;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) red[tid] = fmaxf(red[tid], red[tid + h]);
+        __syncthreads();
+    }
+    mx = red[0];
+    float s_w = 1.f;
+    if (mx > 0.f && mx < 3.0e38f) {
+        int ex;
+        (void)frexpf(mx, &ex);   // mx = f * 2^ex, f in [0.5, 1)
+        s_w = ldexpf(1.f, 14 - ex);
+    }
+    const size_t off = (size_t)nt * total;
+    for (int e = tid; e < total; e += 256) {
+        const float w = wval(e) * s_w;   // (exact: a power of two)
+        const _Float16 h = (_Float16)w;
+        w1[off + e] = __builtin_bit_cast(unsigned short, h);
+        rf[off + e] = (_Float16)((w - (float)h) * SPLIT_LO_SCALE);
+    }
+    if (tid == 0) inv[nt] = 1.f / s_w;
+}
+#else
     float mx = 0.f;
     for (int e = tid; e < total; e += 256) {
         const float w = wval(e);
@@ -105,6 +133,7 @@ __device__ __forceinline__ void pack_split_tile(const float* __restrict__ W, int
     }
     if (tid == 0) inv[nt] = 1.f / s_r;
 }
+#endif
 // The fp32 MFMA-fragment packings (wp / wpt) of the POLICY are read by the exact-fp32 kernels only.  A veh3dofconti launch on the
 // register-stationary plane-split kernels never reaches one - its sweep is the stationary plane-split sweep, and the calls that
 // would divert a backward to the fp32 kernels after the forward has planned (terminal adjoints / gops_rollout_backward_adj,

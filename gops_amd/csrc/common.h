@@ -93,8 +93,52 @@ __host__ __device__ inline int ss_kc0(int kp32) { const int c = kp32 >> 5; retur
 #ifndef GOPS_PIN_MODE
 #define GOPS_PIN_MODE 2   // layer-1 bf16 planes of the split kernels pinned to AGPRs (StatQ PIN; modes 1 / 2 / 3 measured within 1 %, r03)
 #endif
+// ---- which plane split the contractions run on ----------------------------------------------------------------------------
+// GOPS_SPLIT_F16X2 = 1 (round 5, default): BOTH operands as two half planes.
+//     w s_w = wh + wl / 2^11   with wh = f16(w s_w) (round to nearest), wl = f16((w s_w - wh) 2^11), s_w the power of two that brings
+//                           the n-tile's largest |w| into [2^13, 2^14) (packing kernel): 22 significant bits - the systematic part
+//                           of the error (the same perturbed network for every sample: it does not average out over the batch)
+//                           is 2^-22 |w| against 2^-20 |w| of the bf16 + f16 pair;
+//     a s = ah + al / 2^11  with ah = f16(a s), al = f16((a s - ah) 2^11): 2^-22 |a|, independent from sample to sample;
+//     a w = [ah wh] + [al wh + ah wl] / 2^11   - THREE v_mfma_f32_16x16x32_f16 per 32-deep block and n-tile (two accumulators),
+//                           the dropped al wl term is 2^-22 |a w|; products of two halfs are exact in the fp32 accumulator.
+//   s: a power of two that keeps the planes inside the half range: 1 in the forward (activations and observations of a sane
+//   rollout are far below 65504; beyond it the conversion SATURATES - a diverged rollout yields finite garbage instead of the
+//   fp32 overflow the reference would show), per tile and step from max|delta_y| in the sweep (as before).
+//   Against the bf16x3 + f16 form: 3 instead of 4 matrix instructions, 2 instead of 4 plane images in LDS (half the plane
+//   stores and A-fragment reads), ~5 instead of ~8 VALU instructions per element split.
+// GOPS_SPLIT_F16X2 = 0: the round-3 form (three exact bf16 planes of the activation, bf16 + scaled f16 planes of the weight).
+#ifndef GOPS_SPLIT_F16X2
+#define GOPS_SPLIT_F16X2 1
+#endif
+#if GOPS_SPLIT_F16X2
+// forward scale of the activation planes: 2^-4 puts the top of the half range at |a| = 1.05e6 and keeps 22 bits down to
+// |a| = 1e-3 (below that the two planes still resolve 2^-32 ABSOLUTE: hi and lo both run into half subnormals, lo's at 2^-35 / s).
+// Beyond the range the conversion yields inf and the rollout returns non-finite values - loudly, like the reference's own overflow,
+// only earlier; the algorithm classes' PrecisionGuard treats a non-finite distance as exceeded and moves to the exact-fp32 forward.
+#define SPLIT_FWD_SA 0.0625f
+#define SPLIT_LO_SCALE 2048.0f   // 2^11: the residual planes of both operands
+#else
 #define SPLIT_FWD_SA 0.015625f  // forward: af = f16(a / 64): the correction term saturates only beyond |a| = 4.2e6; below |a| = 4e-3 af is a
                                 // subnormal half (absolute error 4e-6 * 2^-8 |w| per term: under the fp32 rounding of a unit-sized term)
+#endif
+// forward pre-activation z = a W + b from the two accumulators of a plane-split contraction (activation planes scaled by SPLIT_FWD_SA)
+__device__ __forceinline__ float split_preact(float acc, float accr, float inv, float bias) {
+#if GOPS_SPLIT_F16X2
+    return fmaf(fmaf(accr, 1.f / SPLIT_LO_SCALE, acc), inv * (1.f / SPLIT_FWD_SA), bias);   // inv = 1 / (the n-tile's weight scale)
+#else
+    return fmaf(accr, inv * (1.f / SPLIT_FWD_SA), acc) + bias;
+#endif
+}
+// result of a plane-split contraction from its two accumulators: `inv` = 1 / (the n-tile's weight scale; bf16 + f16 form: of its
+// residual plane), `inv_s` = 1 / (scale the caller put on the activation planes)
+__device__ __forceinline__ float split_combine(float acc, float accr, float inv, float inv_s) {
+#if GOPS_SPLIT_F16X2
+    return fmaf(accr, 1.f / SPLIT_LO_SCALE, acc) * (inv * inv_s);   // both planes of both operands carry their scale
+#else
+    return fmaf(accr, inv * inv_s, acc);      // only the half plane of the activation is scaled
+#endif
+}
 // position e of a hidden tile's plane row (the order plane_store writes, = the contraction order of the next GEMM) -> feature
 __host__ __device__ inline int split_perm(int e) { return 64 * (e >> 6) + 16 * (e & 3) + ((e & 63) >> 2); }
 // LDS image of a [TB][K] activation tile: 4 planes (a1, a2, a3 bf16; af f16), each [TB] rows of rowb bytes (16 bytes of pad)
@@ -493,15 +537,52 @@ __device__ __forceinline__ unsigned pk_half(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 
+// (a, b) * s -> packed half pairs hi, lo with x = hi + lo / 2^11 to 2^-22 |x| (x = a s): hi = f16(x) (round to nearest),
+// lo = f16((x - hi) 2^11) - x - hi is exact in fp32, |lo| <= |x|: lo never overflows before hi does
+// `ovf`: running packed maximum of |hi| as 16-bit patterns (v_pk_max_u16): any half >= 0x7c00 (inf / nan) means a value left the
+// half range - split_overflowed().  Non-finite values do NOT reliably reach the outputs on their own (relu's fmaxf drops a nan, tanh
+// squashes an inf), so the kernels test this flag at the end of a tile and poison the tile's results (rollout_fwd.hip / _bwd.hip).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h(float a, float b, float s, unsigned& hi, unsigned& lo, unsigned& ovf) {
+    const float xa = a * s, xb = b * s;      // (no clamp: beyond the half range hi = inf, lo = nan - see SPLIT_FWD_SA)
+    const f16x2 h = {(_Float16)xa, (_Float16)xb};
+    hi = __builtin_bit_cast(unsigned, h);
+    ovf = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, ovf), __builtin_bit_cast(u16x2, hi & 0x7fff7fffu)));
+    const f16x2 l = {(_Float16)((xa - (float)h[0]) * 2048.f), (_Float16)((xb - (float)h[1]) * 2048.f)};
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+__device__ __forceinline__ bool split_overflowed(unsigned ovf) { return (ovf & 0xffffu) >= 0x7c00u || (ovf >> 16) >= 0x7c00u; }
+// workgroup-wide OR of the per-thread overflow flags through four floats of LDS scratch the caller has free at that point
+// (no static LDS: the plane-split kernels size their dynamic LDS to the last KiB of the CU's 160); two barriers
+__device__ __forceinline__ bool split_overflow_any(unsigned ovf, float* scratch4, int tid) {
+    const bool wave_any = __builtin_amdgcn_ballot_w64(split_overflowed(ovf)) != 0ull;
+    if ((tid & 63) == 0) scratch4[tid >> 6] = wave_any ? 1.f : 0.f;
+    __syncthreads();
+    const bool any = (scratch4[0] != 0.f) || (scratch4[1] != 0.f) || (scratch4[2] != 0.f) || (scratch4[3] != 0.f);
+    __syncthreads();
+    return any;
+}
+
 // Plane image of a hidden tile, written from the MFMA result layout: lane (n = lane & 15, g = lane >> 4) of wave w holds
 // v[q][r] = element (row 4 g + r, feature 64 w + 16 q + n) of its four n-tiles q.  The four features of a row go out as
 // ONE 8-byte store per plane (16 consecutive lanes = 128 contiguous bytes), i.e. position 64 w + 4 n + q of the row holds
 // feature 64 w + 16 q + n: split_perm().  The weights of the consuming GEMM are packed in the same order.
-__device__ __forceinline__ void plane_store(char* planes, int rowb, int wave, int lane, const f32x4 (&v)[4], float s16) {
+// `s16`: F16X2 - the scale of BOTH planes; bf16x3 + f16 form - the scale of the half plane.
+__device__ __forceinline__ void plane_store(char* planes, int rowb, int wave, int lane, const f32x4 (&v)[4], float s16, unsigned& ovf) {
     const int pstride = TB * rowb;
     char* base = planes + ((lane >> 4) << 2) * rowb + 128 * wave + 8 * (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+#if GOPS_SPLIT_F16X2
+        u32x2 hi, lo;
+        unsigned h0, l0, h1, l1;
+        split2h(v[0][r], v[1][r], s16, h0, l0, ovf);
+        split2h(v[2][r], v[3][r], s16, h1, l1, ovf);
+        hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+        *reinterpret_cast<u32x2*>(base + r * rowb) = hi;
+        *reinterpret_cast<u32x2*>(base + r * rowb + pstride) = lo;
+#else
         unsigned p01[3], p23[3];
         split3(v[0][r], v[1][r], p01);
         split3(v[2][r], v[3][r], p23);
@@ -512,19 +593,30 @@ __device__ __forceinline__ void plane_store(char* planes, int rowb, int wave, in
         }
         const u32x2 h = {pk_half(v[0][r] * s16, v[1][r] * s16), pk_half(v[2][r] * s16, v[3][r] * s16)};
         *reinterpret_cast<u32x2*>(base + r * rowb + 3 * pstride) = h;
+#endif
     }
 }
 
 // Plane image of the fp32 input tile xs [TB][ldx] (columns < kp valid / zero) in natural column order, kp32 columns.
-__device__ __forceinline__ void plane_convert_x(const float* xs, int ldx, int kp, int kp32, char* planes, int rowb, int tid, float s16) {
+__device__ __forceinline__ void plane_convert_x(const float* xs, int ldx, int kp, int kp32, char* planes, int rowb, int tid, float s16, unsigned& ovf) {
     const int upr = kp32 >> 3, pstride = TB * rowb;
     for (int idx = tid; idx < TB * upr; idx += NTHREADS) {
         const int m = idx / upr, u = idx - m * upr, c = u << 3;
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
         if (c < kp) { a = *reinterpret_cast<const f32x4*>(xs + m * ldx + c); b = *reinterpret_cast<const f32x4*>(xs + m * ldx + c + 4); }
+        char* dst = planes + m * rowb + 16 * u;
+#if GOPS_SPLIT_F16X2
+        u32x4 hi, lo;
+        unsigned h, l;
+        split2h(a[0], a[1], s16, h, l, ovf); hi[0] = h; lo[0] = l;
+        split2h(a[2], a[3], s16, h, l, ovf); hi[1] = h; lo[1] = l;
+        split2h(b[0], b[1], s16, h, l, ovf); hi[2] = h; lo[2] = l;
+        split2h(b[2], b[3], s16, h, l, ovf); hi[3] = h; lo[3] = l;
+        *reinterpret_cast<u32x4*>(dst) = hi;
+        *reinterpret_cast<u32x4*>(dst + pstride) = lo;
+#else
         unsigned p0[3], p1[3], p2[3], p3[3];
         split3(a[0], a[1], p0); split3(a[2], a[3], p1); split3(b[0], b[1], p2); split3(b[2], b[3], p3);
-        char* dst = planes + m * rowb + 16 * u;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             const u32x4 w = {p0[pl], p1[pl], p2[pl], p3[pl]};
@@ -532,6 +624,7 @@ __device__ __forceinline__ void plane_convert_x(const float* xs, int ldx, int kp
         }
         const u32x4 h = {pk_half(a[0] * s16, a[1] * s16), pk_half(a[2] * s16, a[3] * s16), pk_half(b[0] * s16, b[1] * s16), pk_half(b[2] * s16, b[3] * s16)};
         *reinterpret_cast<u32x4*>(dst + 3 * pstride) = h;
+#endif
     }
 }
 
@@ -650,6 +743,35 @@ __device__ __forceinline__ void gemm_split(const char* planes, int rowb, const S
                                            f32x4 (&acc)[NT], f32x4 (&accr)[NT]) {
     const int pstride = TB * rowb;
     const char* arow = planes + (lane & 15) * rowb + (lane >> 4) * 16;
+#if GOPS_SPLIT_F16X2
+    // (the `w` plane of StatQ holds half values in this form: its bf16x8 type is the 16-byte container)
+    f16x8 ah = *reinterpret_cast<const f16x8*>(arow), al = *reinterpret_cast<const f16x8*>(arow + pstride);
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        f16x8 rr[NT];
+        if constexpr (RLDS) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) rr[j] = W.rl[(j * KCH + c) * 64];
+        }
+        f16x8 nh = ah, nl = al;
+        if (c + 1 < KCH) {
+            nl = *reinterpret_cast<const f16x8*>(arow + 64 * (c + 1) + pstride);
+            nh = *reinterpret_cast<const f16x8*>(arow + 64 * (c + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, W.w[c * NT + j]), acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) accr[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, __builtin_bit_cast(f16x8, W.w[c * NT + j]), accr[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if constexpr (RLDS) accr[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, rr[j], accr[j], 0, 0, 0);
+            else accr[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, W.r[c * NT + j], accr[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ah = nh; al = nl;
+    }
+#else
     bf16x8 a1 = *reinterpret_cast<const bf16x8*>(arow), a2 = *reinterpret_cast<const bf16x8*>(arow + pstride);
     bf16x8 a3 = *reinterpret_cast<const bf16x8*>(arow + 2 * pstride);
     f16x8 af = *reinterpret_cast<const f16x8*>(arow + 3 * pstride);
@@ -683,6 +805,7 @@ __device__ __forceinline__ void gemm_split(const char* planes, int rowb, const S
         __builtin_amdgcn_sched_barrier(0);
         a1 = n1; a2 = n2; a3 = n3; af = nf;
     }
+#endif
 }
 
 // Plane-split weights of a layer that does NOT stay on the CU (layer 0 of policies with more than 128 inputs: its planes
@@ -747,6 +870,34 @@ __device__ __forceinline__ void gemm_split_pair(const char* planes, int rowb, co
     const int pstride = TB * rowb;
     const int o[2] = {W.off(2 * pair), W.off(2 * pair + 1)};
     const char* arow = planes + (lane & 15) * rowb + (lane >> 4) * 16;
+#if GOPS_SPLIT_F16X2
+    f16x8 ah = *reinterpret_cast<const f16x8*>(arow), al = *reinterpret_cast<const f16x8*>(arow + pstride);
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        const int slot = c % PF;
+        f16x8 nh = ah, nl = al;
+        if (c + 1 < KCH) {
+            nl = *reinterpret_cast<const f16x8*>(arow + 64 * (c + 1) + pstride);
+            nh = *reinterpret_cast<const f16x8*>(arow + 64 * (c + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, ring.w[slot][j]), acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accr[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, __builtin_bit_cast(f16x8, ring.w[slot][j]), accr[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accr[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ring.r[slot][j], accr[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + PF < KCH) {   // refill the slot behind the MFMAs that read it: in flight during the next PF - 1 chunks
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                ring.w[slot][j] = W.frag_w(o[j], c + PF);
+                ring.r[slot][j] = W.frag_r(o[j], c + PF);
+            }
+        }
+        ah = nh; al = nl;
+    }
+#else
     bf16x8 a1 = *reinterpret_cast<const bf16x8*>(arow), a2 = *reinterpret_cast<const bf16x8*>(arow + pstride);
     bf16x8 a3 = *reinterpret_cast<const bf16x8*>(arow + 2 * pstride);
     f16x8 af = *reinterpret_cast<const f16x8*>(arow + 3 * pstride);
@@ -780,6 +931,7 @@ __device__ __forceinline__ void gemm_split_pair(const char* planes, int rowb, co
         }
         a1 = n1; a2 = n2; a3 = n3; af = nf;
     }
+#endif
 }
 
 // One layer of the streamed-split kernels: this wave's four n-tiles (of nt_tot; surplus tiles recompute tile 0) over KCH

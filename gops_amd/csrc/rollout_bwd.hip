@@ -240,6 +240,7 @@ struct SplitSweep {
         const float* h2;     // H_2 (fused output-layer gradient with GELU)
     };
     Hot hot;
+    unsigned ovf = 0;   // half-range overflow of a delta plane conversion (common.h split2h), tested at the end of a tile
     __device__ __forceinline__ void fetch(const RolloutParams&, int j, size_t row0, int tid) {
         const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
         const GLOBAL_AS float* src = gptr(hot.a[j] + row0 * 256);
@@ -266,7 +267,7 @@ struct SplitSweep {
                     __builtin_nontemporal_store(a[q], gptr(reinterpret_cast<f32x4*>(dst + n * 16 + m0)));
                 }
             });
-            plane_store(planes, ROWB, wave, lane, a, s);
+            plane_store(planes, ROWB, wave, lane, a, s, ovf);
         };
         {   // ---- head: delta_2 = (delta_y W_o) * act'(z_2) ----
             const int kk = lane >> 4;
@@ -318,9 +319,8 @@ struct SplitSweep {
             gemm_split(dq2, ROWB, QT1, lane, acc, accr);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float sc = QT1.inv[q] * inv_s;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[q][r] = fmaf(accr[q][r], sc, acc[q][r]);
+                for (int r = 0; r < 4; ++r) acc[q][r] = split_combine(acc[q][r], accr[q][r], QT1.inv[q], inv_s);
             }
             if constexpr (STREAMT0) {
                 if (want_gx) QT0.prime(ring0, 0);   // W_0's first chunks travel during delta_1's epilogue
@@ -341,10 +341,9 @@ struct SplitSweep {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int n = 16 * (PTS * wave + 2 * k + j) + (lane & 15);
-                        const float sc = QT0.inv[2 * k + j] * inv_s;
                         if (n < ncols) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) G[(m0 + r) * ldg + n] += fmaf(accr[j][r], sc, acc[j][r]);
+                            for (int r = 0; r < 4; ++r) G[(m0 + r) * ldg + n] += split_combine(acc[j][r], accr[j][r], QT0.inv[2 * k + j], inv_s);
                         }
                     }
                 }
@@ -364,10 +363,9 @@ struct SplitSweep {
 #pragma unroll
             for (int j = 0; j < PT0; ++j) {
                 const int n = 16 * (PT0 * wave + j) + (lane & 15);
-                const float sc = QT0.inv[j] * inv_s;
                 if (n < ncols) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) G[(m0 + r) * ldg + n] = gold[j][r] + fmaf(accr[j][r], sc, acc[j][r]);
+                    for (int r = 0; r < 4; ++r) G[(m0 + r) * ldg + n] = gold[j][r] + split_combine(acc[j][r], accr[j][r], QT0.inv[j], inv_s);
                 }
             }
             DBG_TICK(9)
@@ -387,6 +385,7 @@ bool ssb_fuses_out(const RolloutParams& p) { return p.ssb && ssb_fuse_kind(p.env
 struct SsOutGrad {
     float dwo[GOPS_MAX_ACT][4];
     float dbo[GOPS_MAX_ACT];
+    unsigned ovf;   // half-range overflow of a delta plane conversion (common.h split2h), tested at the end of a tile
 };
 // this workgroup's partial -> part[blockIdx.x][a][K], part_b[blockIdx.x][a]
 __device__ __forceinline__ void ss_store_out_grad(const SsOutGrad& og, int K, int A, float* part, float* part_b, int tid) {
@@ -439,7 +438,7 @@ __device__ __forceinline__ void ss_net_backward(const MlpDev& M, const SplitNetD
                 if (dst != nullptr) __builtin_nontemporal_store(a[q], gptr(reinterpret_cast<f32x4*>(dst + n * 16 + m0)));
             }
         });
-        plane_store(dq, ROWB, wave, lane, a, s);
+        plane_store(dq, ROWB, wave, lane, a, s, og.ovf);
     };
     f32x4 hvn[4];   // act' operands requested one phase ahead
     {   // ---- head: delta_L = (delta_y W_o) * act'(z_L): one K = 4 fp32 MFMA per n-tile ----
@@ -495,9 +494,8 @@ __device__ __forceinline__ void ss_net_backward(const MlpDev& M, const SplitNetD
         ss_layer_gemm<8>(dq, ROWB, ST.w1[j], ST.r[j], ST.inv[j], 16, tid, acc, accr, inv);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float sc = inv[q] * inv_s;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[q][r] = fmaf(accr[q][r], sc, acc[q][r]);
+            for (int r = 0; r < 4; ++r) acc[q][r] = split_combine(acc[q][r], accr[q][r], inv[q], inv_s);
         }
         if (j >= 2) fetch(j - 1, hvn);   // (before the barrier and this layer's epilogue)
         __syncthreads();   // every wave has read the delta image it is about to overwrite
@@ -511,10 +509,9 @@ __device__ __forceinline__ void ss_net_backward(const MlpDev& M, const SplitNetD
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = 16 * (4 * wave + q) + (lane & 15);
-            const float sc = inv[q] * inv_s;
             if (n < ncols) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) G[(m0 + r) * ldg + n] += fmaf(accr[q][r], sc, acc[q][r]);
+                for (int r = 0; r < 4; ++r) G[(m0 + r) * ldg + n] += split_combine(acc[q][r], accr[q][r], inv[q], inv_s);
             }
         }
     }
@@ -1520,6 +1517,17 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
     if constexpr (SSB && ssb_fuse_kind(ENV)) {
         if (q.out_part != nullptr && tile + (int)gridDim.x >= ntiles)
             ss_store_out_grad(og, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], q.out_part, q.out_part_b, tid);   // after the last tile
+    }
+    if constexpr (SPLIT || SSB) {
+        // A delta beyond the half range of the plane images (the per-step scale leaves 2^12 of headroom above max|delta_y|) made part of
+        // this tile's sweep non-finite, which act' = 0 can hide again: the tile poisons ONE element of its first hidden layer's delta
+        // stash (its own: feature 0, row 0 of step 0 was written by thread 0), so that the first layer's weight gradient comes out
+        // non-finite and the failure is loud
+        unsigned o = og.ovf;
+        og.ovf = 0;
+        if constexpr (SPLIT) { o = SS.ovf; SS.ovf = 0; }
+        if (split_overflow_any(o, red, tid) && tid == 0 && p.st.d[1] != nullptr)   // (red: the env adjoint's partials are consumed by now)
+            gptr(p.st.d[1])[(size_t)tile * hH * TB * 256] = __builtin_nanf("");
     }
     } while ((SPLIT || SSB) && MULTI && (tile += gridDim.x) < ntiles);   // (every step ends with a barrier: the next tile's set-up may overwrite G / s_ref)
     dbg.dump(q.dbg);

@@ -168,6 +168,7 @@ struct SplitPolicy {
         int kp0, act;
         float *h1, *h2, *z1, *z2;
     };
+    unsigned ovf = 0;   // half-range overflow of a plane conversion (common.h split2h), tested at the end of a tile
     __device__ __forceinline__ float run(const Hot& hot, const float* xs, int ldx, char* xq, int rowb0, char* hq,
                                          float* s_part, const float* s_bias, int ldb, const float* s_wo4, const float* s_bo,
                                          int tid, bool stash, size_t row0, DbgClock& dbg, bool combine = true) {
@@ -175,7 +176,7 @@ struct SplitPolicy {
         constexpr int ROWB1 = 2 * 256 + 16;
         StreamRing<KC0> ring0;
         if constexpr (STREAM0) Q0.prime(ring0, 0);   // the first chunks of W_0's planes travel during the conversion pass
-        plane_convert_x(xs, ldx, hot.kp0, 32 * KC0, xq, rowb0, tid, SPLIT_FWD_SA);
+        plane_convert_x(xs, ldx, hot.kp0, 32 * KC0, xq, rowb0, tid, SPLIT_FWD_SA, ovf);
         __syncthreads();
         DBG_TICK(1)
         const bool gelu = hot.act == GOPS_ACT_GELU;
@@ -201,11 +202,11 @@ struct SplitPolicy {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = 64 * wave + 16 * q + (lane & 15);
-                    const float sc = Q0.inv[q] * (1.f / SPLIT_FWD_SA), bn = s_bias[n];
+                    const float sc = Q0.inv[q], bn = s_bias[n];
                     f32x4 zv;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float z = fmaf(accr[q][r], sc, acc[q][r]) + bn;
+                        const float z = split_preact(acc[q][r], accr[q][r], sc, bn);
                         float hr, dr = z;
                         if constexpr (ACT == GOPS_ACT_GELU) gelu_pair(z, hr, dr);
                         else hr = act_fwd_t<ACT>(z);
@@ -215,7 +216,7 @@ struct SplitPolicy {
                     if (ACT == GOPS_ACT_GELU && zrow != nullptr) __builtin_nontemporal_store(zv, gptr(reinterpret_cast<f32x4*>(zrow + n * 16 + m0)));
                 }
             });
-            plane_store(hq, ROWB1, wave, lane, hv, SPLIT_FWD_SA);
+            plane_store(hq, ROWB1, wave, lane, hv, SPLIT_FWD_SA, ovf);
         }
         DBG_TICK(8)
         __syncthreads();
@@ -232,12 +233,12 @@ struct SplitPolicy {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = 64 * wave + 16 * q + (lane & 15);
-                    const float sc = Q1.inv[q] * (1.f / SPLIT_FWD_SA), bn = s_bias[ldb + n];
+                    const float sc = Q1.inv[q], bn = s_bias[ldb + n];
                     const f32x4 wq = *reinterpret_cast<const f32x4*>(s_wo4 + n * 4);
                     f32x4 h4, zv;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float z = fmaf(accr[q][r], sc, acc[q][r]) + bn;
+                        const float z = split_preact(acc[q][r], accr[q][r], sc, bn);
                         float hr, dr = z;
                         if constexpr (ACT == GOPS_ACT_GELU) gelu_pair(z, hr, dr);
                         else hr = act_fwd_t<ACT>(z);
@@ -281,12 +282,13 @@ struct NoSplit {};
 template <int AMAX>
 __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetDev& S, const float* xs, int ldx, char* xq, char* hq,
                                                 float* s_part, const float* s_bias, int ldb, const float* s_wo4, const float* s_bo,
-                                                int tid, float* const* stash_h, float* const* stash_z, size_t row0, DbgClock& dbg, float* dmp = nullptr) {
+                                                int tid, float* const* stash_h, float* const* stash_z, size_t row0, DbgClock& dbg, unsigned& ovf,
+                                                float* dmp = nullptr) {
     const int lane = tid & 63, wave = tid >> 6, m0 = (lane >> 4) << 2;
     constexpr int ROWB1 = 2 * 256 + 16;
     const int L = M.nl - 1, rowb0 = split_rowb(32 * S.kc[0]);
     const bool gelu = M.act == GOPS_ACT_GELU;
-    plane_convert_x(xs, ldx, M.kp[0], 32 * S.kc[0], xq, rowb0, tid, SPLIT_FWD_SA);
+    plane_convert_x(xs, ldx, M.kp[0], 32 * S.kc[0], xq, rowb0, tid, SPLIT_FWD_SA, ovf);
     __syncthreads();
     DBG_TICK(1)
     float part[4][AMAX] = {};
@@ -315,11 +317,11 @@ __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetD
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = 64 * wave + 16 * q + (lane & 15);
-                const float sc = inv[q] * (1.f / SPLIT_FWD_SA), bn = s_bias[j * ldb + n];
+                const float sc = inv[q], bn = s_bias[j * ldb + n];
                 f32x4 zv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float z = fmaf(accr[q][r], sc, acc[q][r]) + bn;
+                    const float z = split_preact(acc[q][r], accr[q][r], sc, bn);
                     float hr, dr = z;
                     if constexpr (ACT == GOPS_ACT_GELU) gelu_pair(z, hr, dr);
                     else hr = act_fwd_t<ACT>(z);
@@ -339,7 +341,7 @@ __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetD
 #endif
         DBG_TICK(8)
         if (!last) {
-            plane_store(hq, ROWB1, wave, lane, hv, SPLIT_FWD_SA);
+            plane_store(hq, ROWB1, wave, lane, hv, SPLIT_FWD_SA, ovf);
             __syncthreads();
             DBG_TICK(12)
         } else {
@@ -550,6 +552,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
         }
     }
     float v_acc = 0.f;
+    unsigned ss_ovf = 0;   // SS: half-range overflow of a plane conversion in this tile (SPLIT keeps it in SP.ovf)
     float c_ext = 0.f, c_lin = 0.f, c_int = 0.f, c_feas = 1.f;   // SURR: discounted constraint sums of trajectory tid (tid < TB)
     float c_mul[GOPS_MAX_CONSTRAINT] = {1.f, 1.f, 1.f}, c_safe[GOPS_MAX_CONSTRAINT] = {1.f, 1.f, 1.f};   // SPIL products
     float veh_s = 0.f, veh_c = 1.f;   // sin/cos of the current heading, carried across steps
@@ -603,11 +606,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                     for (int k = 0; k < 3; ++k) gptr(dmp)[28 + k] = xs[(tid >> 4) * ldx + (tid & 15) + 16 * k];
                 }
                 ya_split = ss_net_forward<AMAX>(p.pol, p.ssp, xs, ldx, xq, hq, s_part, s_bias, ldh, s_wo, s_bo, tid,
-                                                p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0, dbg, dmp);
+                                                p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0, dbg, ss_ovf, dmp);
                 if (dmp != nullptr) gptr(dmp)[0] = ya_split;
 #else
                 ya_split = ss_net_forward<AMAX>(p.pol, p.ssp, xs, ldx, xq, hq, s_part, s_bias, ldh, s_wo, s_bo, tid,
-                                                p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0, dbg);
+                                                p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr, row0, dbg, ss_ovf);
 #endif
             } else
             if (!p.open_loop) {
@@ -1151,7 +1154,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
             if (tid < GOPS_MAX_ACT) s_bo[tid] = (tid == 0) ? gptr(p.val.b[Lv])[0] : 0.f;
             __syncthreads();
             y[0] = ss_net_forward<1>(p.val, p.ssv, xs, ldx, xq, hq, s_part, s_bias, ldh, s_wo, s_bo, tid,
-                                     p.need_grad ? p.st.tail_h : nullptr, p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, dbg);
+                                     p.need_grad ? p.st.tail_h : nullptr, p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, dbg, ss_ovf);
         } else
         if constexpr (F16) {
             convert_x_h(xs, ldx, p.val.kp[0], p.val.kp32[0], x16, ldx16, nullptr, 0, tid);
@@ -1182,6 +1185,13 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
 #pragma unroll
         for (int k = 0; k < GOPS_MAX_CONSTRAINT; ++k)
             if (k < nc) { cp[(size_t)k * p.B] = c_mul[k]; cp[(size_t)(nc + k) * p.B] = c_safe[k]; }
+    }
+    if constexpr (SPLIT || SS) {
+        // A value beyond the half range of the plane images (common.h SPLIT_FWD_SA: |a| >= 1.05e6) made part of this tile's contractions
+        // non-finite - which relu / tanh can hide again: the tile's returns are poisoned instead, so that the failure is loud
+        unsigned o = ss_ovf;
+        if constexpr (SPLIT) { o = SP.ovf; SP.ovf = 0; }
+        if (split_overflow_any(o, s_part, tid)) v_acc = __builtin_nanf("");   // (s_part: the head partials are consumed by now)
     }
     if (tid < nvalid) {
         gptr(p.out.v_pi)[b0 + tid] = v_acc;

@@ -30,7 +30,7 @@ from oracle import adp_oracle as orc
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 VEH_HEADING_BOUND = 5e-4
-NEEDS_EXACT_FORWARD = {"t256_fhadp_lq_s4a2_elu_sat"}
+NEEDS_EXACT_FORWARD = set()   # (round 5, bf16 + f16 planes: the saturated LQ policy, 3.5e-4; two half planes per operand: 3.1e-5)
 
 FHADP_T256 = ["t256_fhadp_idp_h30_gelu", "t256_fhadp_veh_p30_elu", "t256_fhadp_lq_s4a2_elu_sat"]
 INFADP_T256 = ["t256_infadp_lq_s4a2_relu", "t256_infadp_lq_s4a2_gelu", "t256_infadp_veh_p10_relu3"]
@@ -236,27 +236,82 @@ def _load_alg(name, **extra):
 @pytest.mark.parametrize("name", FHADP_T256)
 def test_precision_guard_fhadp(name, dev):
     """The FHADP class on the trained fixtures: the first gradient is checked (a loaded checkpoint may already need the exact
-    forward).  The saturated LQ policy trips the guard - and the gradient the class then returns meets the bar; the others stay on
-    the plane-split kernels with their measured distance below the threshold."""
+    forward).  With two half planes per operand every fixture stays on the plane-split kernels, its measured distance to the
+    exact-fp32 forward far below the threshold; with the threshold set below that distance the guard trips, stays tripped, and
+    the class returns the exact-forward gradient."""
     alg, g, cfg = _load_alg(name)
     data = to_device(data_from_golden(g), dev)
     guard = alg.precision_guard
-    with pytest.warns(UserWarning, match="exact-fp32 forward") if name in NEEDS_EXACT_FORWARD else _no_context():
-        _, info = alg.get_remote_update_info(data, 0)
+    _, info = alg.get_remote_update_info(data, 0)
     torch.cuda.synchronize()
     assert guard.checks == 1 and guard.last_distance is not None
     grads = info["grad"]
     err = rel_l2(_flat(grads), _golden_flat(g, "grad/", len(grads)))
     print(f"{name}: guard distance {guard.last_distance:.2e} (threshold {guard.threshold:.0e}) -> exact forward: {guard.exact}; "
           f"gradient of the class vs the reference {err:.2e}")
-    assert guard.exact == (name in NEEDS_EXACT_FORWARD), (name, guard.last_distance)
+    assert not guard.exact and guard.last_distance < guard.threshold, (name, guard.last_distance)
     veh = cfg["env_id"] == "pyth_veh3dofconti"   # (the class evaluates the appended headings itself: exemption 1)
     assert err < (VEH_HEADING_BOUND if veh else bar_of(g)), (name, err)
-    # sticky, and no further checks once exact; an unexceptional network is checked again only after `interval` gradients
-    for it in range(1, 4):
+    for it in range(1, 4):   # an unexceptional network is checked again only after `interval` gradients
         alg.get_remote_update_info(data, it)
-    assert guard.checks == 1 and guard.exact == (name in NEEDS_EXACT_FORWARD)
+    assert guard.checks == 1 and not guard.exact
     assert alg._rollout_for(data["obs"].shape[0], dev).desc.variant_flags == guard.flags()
+    # the same network under a threshold below its measured distance: trips at the first gradient, and stays on the exact forward
+    alg2, _, _ = _load_alg(name, precision_threshold=guard.last_distance * 0.5)
+    with pytest.warns(UserWarning, match="exact-fp32 forward"):
+        _, info2 = alg2.get_remote_update_info(data, 0)
+    torch.cuda.synchronize()
+    g2 = alg2.precision_guard
+    assert g2.exact and g2.checks == 1
+    err2 = rel_l2(_flat(info2["grad"]), _golden_flat(g, "grad/", len(info2["grad"])))
+    assert err2 < (VEH_HEADING_BOUND if veh else bar_of(g)), (name, err2)
+    for it in range(1, 4):
+        alg2.get_remote_update_info(data, it)
+    assert g2.checks == 1 and g2.exact
+    from gops_amd.algorithm.base import PrecisionGuard
+    flags = alg2._rollout_for(data["obs"].shape[0], dev).desc.variant_flags
+    assert flags == g2.flags() and flags & PrecisionGuard.fwd_exact_flags() == PrecisionGuard.fwd_exact_flags()
+
+
+def test_half_range_overflow_is_loud_and_the_guard_catches_it(dev):
+    """The plane-split forward carries activations as two half planes scaled by 2^-4: beyond |a| = 1.05e6 the conversion overflows
+    and the rollout returns NON-FINITE values (never silently wrong ones).  A policy whose first layer is scaled so that H_1
+    reaches ~1e8: the raw plane-split launch is non-finite; the FHADP class measures a non-finite distance at its first gradient,
+    moves to the exact-fp32 forward and returns the reference gradient."""
+    from gops_amd import hip_backend as hb
+    from gops_amd.utils.synthetic import act_dim_of, make_batch, obs_dim_of
+    from helpers import reference_init_nets
+    cfg = dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=64, horizon=3, hidden=(256, 256), act="relu", gamma=0.99)
+    data = make_batch(cfg, 21)
+    nets = reference_init_nets(cfg, 21, obs_dim_of(cfg), act_dim_of(cfg))
+    with torch.no_grad():
+        nets["policy"]["w"][0].mul_(2.0e8)
+        nets["policy"]["b"][0].mul_(2.0e8)
+        nets["policy"]["w"][1].mul_(1.0e-8)
+    env = orc.make_env("pyth_lq", lq_config="s4a2")
+    ref = orc.fhadp_gradient(env, nets["policy"], data, cfg["horizon"], cfg["gamma"])
+    ddev = to_device(data, dev)
+    henv = hip_env_from_oracle(env, nets["policy"])
+    variant, loss, grads = _policy_gradient(henv, nets, cfg, ddev, dev, 0, tail=False)
+    assert variant == 1
+    assert not torch.isfinite(_flat(grads)).all() or not np.isfinite(loss), "beyond the half range the plane-split launch must not look sane"
+    # the class: same weights through the state_dict layout of the reference
+    from test_alg_gpu import _kwargs
+    from gops_amd.create_pkg.create_alg import create_alg
+    alg = create_alg(**_kwargs(cfg, {}, 21), gamma=cfg["gamma"])
+    alg.networks.cuda()
+    with torch.no_grad():
+        for layer, w, b in zip(alg.networks.policy.linear_layers(), nets["policy"]["w"], nets["policy"]["b"]):
+            layer.weight.copy_(w.detach())
+            layer.bias.copy_(b.detach())
+    alg.envmodel.unwrapped.dynamics.inv_IA = env["lq"]["inv_IA"].to(dev)
+    with pytest.warns(UserWarning, match="exact-fp32 forward"):
+        _, info = alg.get_remote_update_info(ddev, 0)
+    torch.cuda.synchronize()
+    assert alg.precision_guard.exact
+    got, want = _flat(info["grad"]), torch.cat([t.reshape(-1) for t in ref["grads"]])
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < TOL, rel_l2(got, want)
 
 
 class _no_context:
@@ -274,7 +329,7 @@ def test_precision_guard_interval_and_switch_off(dev):
         alg.get_remote_update_info(data, it)
     assert alg.precision_guard.checks == 3     # gradients 1, 3 and 6
     assert not alg.precision_guard.exact
-    alg2, g2, _ = _load_alg("t256_fhadp_lq_s4a2_elu_sat", precision_check_interval=0)
+    alg2, g2, _ = _load_alg("t256_fhadp_lq_s4a2_elu_sat", precision_check_interval=0, precision_threshold=1e-12)
     data2 = to_device(data_from_golden(g2), dev)
     alg2.get_remote_update_info(data2, 0)
     assert alg2.precision_guard.checks == 0 and not alg2.precision_guard.exact   # switched off: the caller's responsibility

@@ -313,9 +313,9 @@ def roofline_of(cfg, dt, kern, pmc, pmc_src, workload, variant=0):
     """Roofline record of the slowest of the three rollout kernels (forward, sweep, weight-gradient group).
 
     fp32 workloads on the exact-fp32 kernels are priced against the fp32 matrix roof (157.3 TF) with the ALGORITHMIC flops
-    2 * MAC.  When the plane-split kernels run (`variant` bits 0 / 2: 3 bf16 + 1 f16 MFMA per 32-deep block instead of 8 fp32
-    MFMAs, fp32-class results) `frac` is the ISSUED fraction - 4 x the algorithmic flops (3 x in the weight-gradient GEMM)
-    against the 2.5 PF dense bf16 / f16 roof - and `frac_vs_fp32_roof` keeps the algorithmic figure against 157.3 TF (how far
+    2 * MAC.  When the plane-split kernels run (`variant` bits 0 / 2: 3 f16 MFMAs per 32-deep block - two half planes per
+    operand - instead of 8 fp32 MFMAs, fp32-class results; the weight-gradient GEMM: 3 bf16 MFMAs) `frac` is the ISSUED fraction -
+    3 x the algorithmic flops against the 2.5 PF dense bf16 / f16 roof - and `frac_vs_fp32_roof` keeps the algorithmic figure against 157.3 TF (how far
     the kernel is above / below what an fp32-MFMA implementation could reach; may exceed 1)."""
     B, H = cfg["batch"], cfg["horizon"]
     tail = cfg["alg"] == "INFADP"
@@ -335,11 +335,11 @@ def roofline_of(cfg, dt, kern, pmc, pmc_src, workload, variant=0):
                     "unit": "TFLOP/s", "frac": achieved / peak_tf,
                     "traffic": pmc_traffic(pmc, pmc_src, KERNEL_NAMES[dom].split("(")[0]),
                     "algorithmic_flops_per_launch": flops[dom], "avg_ms": dom_ms}
-        if variant & 5:   # plane-split contractions (stationary: bit 0, streamed: bit 2): 4 MFMAs of 16x16x32 per fp32 block; the H2 weight-gradient GEMM: 3
+        if variant & 5:   # plane-split contractions (stationary: bit 0, streamed: bit 2): 3 MFMAs of 16x16x32 per fp32 block, in the H2 weight-gradient GEMM as well
             # The roof is the one of the instructions the kernel ISSUES (dense bf16 / f16 MFMA, 2.5 PF), `achieved` the issued
             # flops = products_per_mac x the algorithmic ones; the comparison with what an exact-fp32 contraction could reach on
             # this chip (157.3 TF fp32 matrix roof, algorithmic flops) is kept beside it as frac_vs_fp32_roof (can exceed 1).
-            mult = 3.0 if dom == 2 else 4.0
+            mult = 3.0   # (rounds 3-4: 4 in the rollout kernels - bf16x3 activations x bf16 + f16 weights)
             issued = {"tflops": mult * achieved, "peak_tflops": MFMA_PEAK_TFLOPS["f16"], "frac": mult * achieved / MFMA_PEAK_TFLOPS["f16"],
                       "products_per_mac": mult}
             roofline.update({"achieved": issued["tflops"], "peak": issued["peak_tflops"], "frac": issued["frac"],
@@ -348,7 +348,8 @@ def roofline_of(cfg, dt, kern, pmc, pmc_src, workload, variant=0):
                              "mfma_issued": issued,
                              "algorithmic": {"tflops": achieved, "frac_vs_bf16_f16_roof": achieved / MFMA_PEAK_TFLOPS["f16"],
                                              "frac_vs_fp32_matrix_roof": achieved / peak_tf},
-                             "arithmetic": "fp32 results from bf16 / f16 plane-split MFMAs (>= 19-bit weights, exact bf16x3 activations): "
+                             "arithmetic": "fp32 results from plane-split MFMAs (two half planes per operand: 22-bit weights and activations, "
+                                           "ah*wh + (al*wh + ah*wl) / 2^11; weight-gradient GEMM: exact bf16x3): "
                                            "achieved / peak / frac = ISSUED MFMA flops (products_per_mac x the algorithmic 2 MAC) against the dense "
                                            "bf16 / f16 roof (mfma_issued); `algorithmic` holds the 2 MAC flops against both roofs"})
             roofline["alg_hbm_gbs"] = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0

@@ -89,15 +89,16 @@ class AlgorithmBase(metaclass=ABCMeta):
 class PrecisionGuard:
     """When must a launch leave the plane-split kernels for exact fp32 products?  A measured rule.
 
-    The default 256-wide kernels carry a weight as bf16 + scaled f16 residual (>= 19 significant bits, csrc/common.h SplitDev),
-    i.e. they evaluate the network with weights moved by up to ~2^-20 relative - 8 - 16 fp32 ulps.  On random-init and on most
-    trained weights that is far inside the 1e-4 bar (measured 2e-6 .. 3e-5 against the reference, tests/test_trained256_gpu.py);
-    on an ill-conditioned closed loop it is not: the reference-trained pyth_lq policy with a saturated tanh head
-    (t256_fhadp_lq_s4a2_elu_sat: the REFERENCE's own gradient moves 6.6e-5 under 1-ulp weight moves) lands 3.5e-4 from the
-    reference on the plane-split forward and 3.2e-5 on the exact-fp32 forward.  Only the FORWARD matters (the sweep is linear once
-    the forward has fixed states and activations: plane-split sweep + weight-gradient GEMM behind an exact forward measure the same as
-    all-exact), and conditioning cannot be read off a description - so it is measured: every `interval` gradients (and at the
-    first one: a loaded checkpoint may already be there) the gradient of the current batch is formed twice, with the launch's own
+    The default 256-wide kernels carry every operand of a hidden-layer contraction as two half planes (22 significant bits,
+    csrc/common.h GOPS_SPLIT_F16X2), i.e. they evaluate the network with weights moved by up to 2^-22 relative - the same
+    perturbed network for every sample, so this part of the error does not average out over the batch.  On every fixture trained
+    by the reference (tests/test_trained256_gpu.py) that is at the level of the exact-fp32 kernels (2e-6 .. 3e-5 against the
+    reference; the round-3 planes, 2^-20, put an ill-conditioned closed loop - the pyth_lq policy with a saturated tanh head, whose
+    REFERENCE gradient moves 6.6e-5 under 1-ulp weight moves - at 3.5e-4), and activations beyond the half range of the forward
+    planes (|a| >= 1.05e6) make the launch return NaN.  Neither conditioning nor range can be read off a description - so the guard
+    MEASURES.  Only the FORWARD matters (the sweep is linear once the forward has fixed states and activations: plane-split sweep +
+    weight-gradient GEMM behind an exact forward measure the same as all-exact): every `interval` gradients (and at the first
+    one: a loaded checkpoint may already be there) the gradient of the current batch is formed twice, with the launch's own
     kernels and with `FWD_EXACT` added, and if their relative L2 distance exceeds `threshold` the algorithm stays on the
     exact-fp32 forward from then on (sticky).  Cost: two extra gradients per `interval` updates (0.4 % at the default 500), one
     host sync per check.  `GOPS_PRECISION_CHECK_INTERVAL=0` (or `precision_check_interval=0`) switches the guard off."""

@@ -81,16 +81,24 @@ __device__ __forceinline__ void pack_split_tile(const float* __restrict__ W, int
     };
 #if GOPS_SPLIT_F16X2
     // two half planes of w s_w: wh = f16(w s_w) (round to nearest), wl = f16((w s_w - wh) 2^11); s_w = the power of two that brings the
-    // tile's largest |w| into [2^13, 2^14) - fp32's exponent range for the weights, and small-weight tiles use the half's normal range
-    float mx = 0.f;
-    for (int e = tid; e < total; e += 256) mx = fmaxf(mx, fabsf(wval(e)));
-    red[tid] = mx;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
-        if (tid < h) red[tid] = fmaxf(red[tid], red[tid + h]);
-        __syncthreads();
+    // tile's largest |w| into [2^13, 2^14) - fp32's exponent range for the weights, and small-weight tiles use the half's normal range.
+    // The tile's <= 16 elements per thread are loaded ONCE, all loads in flight together (a load - use - load loop costs one L2 round
+    // trip per element: this kernel sits on the critical path of every update, round 5: 11 -> 5 us).
+    constexpr int PER = 16;   // kc <= 8: 16 * 32 * 8 / 256
+    float v[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int e = tid + 256 * q;
+        v[q] = e < total ? wval(e) : 0.f;
     }
-    mx = red[0];
+    float mx = 0.f;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) mx = fmaxf(mx, fabsf(v[q]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float s_w = 1.f;
     if (mx > 0.f && mx < 3.0e38f) {
         int ex;
@@ -98,11 +106,15 @@ __device__ __forceinline__ void pack_split_tile(const float* __restrict__ W, int
         s_w = ldexpf(1.f, 14 - ex);
     }
     const size_t off = (size_t)nt * total;
-    for (int e = tid; e < total; e += 256) {
-        const float w = wval(e) * s_w;   // (exact: a power of two)
-        const _Float16 h = (_Float16)w;
-        w1[off + e] = __builtin_bit_cast(unsigned short, h);
-        rf[off + e] = (_Float16)((w - (float)h) * SPLIT_LO_SCALE);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int e = tid + 256 * q;
+        if (e < total) {
+            const float w = v[q] * s_w;   // (exact: a power of two)
+            const _Float16 h = (_Float16)w;
+            w1[off + e] = __builtin_bit_cast(unsigned short, h);
+            rf[off + e] = (_Float16)((w - (float)h) * SPLIT_LO_SCALE);
+        }
     }
     if (tid == 0) inv[nt] = 1.f / s_w;
 }
@@ -290,13 +302,18 @@ __device__ __forceinline__ void ref_table_element(int B, int P, int H, const flo
     } else if (appended != nullptr) {   // bit-parity mode: the caller's points [B][H][4]
         v = reinterpret_cast<const f32x4*>(appended)[(size_t)b * H + (i - P - 1)];
     } else {
+        // the 24 path constants, the three per-trajectory scalars: loaded together up front (read where they are used, inside the
+        // branches of ref_xy, each costs a memory round trip of its own)
+        float c[24];
+#pragma unroll
+        for (int q = 0; q < 24; ++q) c[q] = refc[q];
+        const float pn = path_num[b], un = u_num[b];
         float t = ref_time[b];
         for (int s = 0; s < i - P; ++s) t = RADD(t, 0.1f);
-        const float pn = path_num[b], un = u_num[b];
         const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : (pn == 3.f) ? 3 : -1;
         const int us = (un == 0.f) ? 0 : (un == 1.f) ? 1 : -1;
         if (path < 0 || us < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};   // ids outside the registered sets
-        else v = ref_point(refc, RADD(t, pdt), path, us);
+        else v = ref_point(c, RADD(t, pdt), path, us);
     }
     reinterpret_cast<f32x4*>(table)[idx] = v;
 }
@@ -319,7 +336,18 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
     if (b == 0) {
         const unsigned* src = reinterpret_cast<const unsigned*>(&p);
         unsigned* d = reinterpret_cast<unsigned*>(dst);
-        for (unsigned i = threadIdx.x; i < sizeof(RolloutParams) / 4; i += blockDim.x) d[i] = src[i];
+        constexpr unsigned NW = sizeof(RolloutParams) / 4, PER = (NW + 255) / 256;
+        unsigned w[PER];   // all loads first, then the stores (a load - store loop: one round trip per 1 KB)
+#pragma unroll
+        for (unsigned q = 0; q < PER; ++q) {
+            const unsigned i = threadIdx.x + 256 * q;
+            w[q] = i < NW ? src[i] : 0u;
+        }
+#pragma unroll
+        for (unsigned q = 0; q < PER; ++q) {
+            const unsigned i = threadIdx.x + 256 * q;
+            if (i < NW) d[i] = w[q];
+        }
         if (p.gscale != nullptr && threadIdx.x == 0) p.gscale[0] = 0.f;   // max|grad_v| of the coming backward
         return;
     }
@@ -1655,13 +1683,30 @@ __global__ __launch_bounds__(256) void adam_kernel(const GopsAdamTensors T, Gops
     const float* __restrict__ g = T.grad[ti];
     float* __restrict__ m = T.exp_avg[ti];
     float* __restrict__ v = T.exp_avg_sq[ti];
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gsc;
-        const float mi = m[i] + (gi - m[i]) * omb1;
-        const float vi = v[i] * b2 + omb2 * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    // 4 elements per thread with all 16 loads in flight together: the kernel is a chain of memory round trips (load g, m, v, p - store),
+    // and a load - store loop pays one per element (65536-element layers, 64 blocks: 9.2 us; one element per thread on 256 blocks costs
+    // more than it saves - every block takes the ticket below)
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        float gq[4], mq[4], vq[4], pq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long i = i0 + q * stride;
+            const bool ok = i < n;
+            gq[q] = ok ? g[i] : 0.f; mq[q] = ok ? m[i] : 0.f; vq[q] = ok ? v[i] : 0.f; pq[q] = ok ? p[i] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long i = i0 + q * stride;
+            if (i < n) {
+                const float gi = gq[q] * gsc;
+                const float mi = mq[q] + (gi - mq[q]) * omb1;
+                const float vi = vq[q] * b2 + omb2 * gi * gi;
+                m[i] = mi;
+                v[i] = vi;
+                p[i] = pq[q] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+            }
+        }
     }
     // Every block has read the state (its values feed the arithmetic above) before it takes a ticket;
     // the last one publishes the advanced state.  No fence: the next reader is a later kernel.
@@ -1702,33 +1747,63 @@ hipError_t launch_polyak(const GopsAdamTensors& T, float omt, float tau, hipStre
 // (stats[2 ..]: GOPS_LOSS_STATS_FLOATS floats in all, the last one a ticket that must be zero on entry and is left zero); the last block to
 // finish adds the partials in block order - deterministic.
 #define LOSS_BLOCKS 64
+#define LOSS_ONE_BLOCK_MAX 8192   // up to here ONE block forms the sums (<= 32 elements per thread, no partials / ticket round)
+// sum of (s0, s1) over the block in a fixed order: butterfly inside each wave, then the four waves in order; every thread returns the totals
+__device__ __forceinline__ void block_sum2(double& s0, double& s1, double (*red)[4]) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+    }
+    __syncthreads();   // (red may still be read by a previous call)
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    s0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+}
 __global__ __launch_bounds__(256) void batch_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float gsc, float sc0,
                                                          float* __restrict__ grad, float* __restrict__ stats) {
-    __shared__ double red[2][256];
+    __shared__ double red[2][4];
     __shared__ bool last;
     double s0 = 0.0, s1 = 0.0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LOSS_BLOCKS * 256) {
-        const float ai = a[i];
-        if (b != nullptr) {
-            const float d = ai - b[i];
-            if (grad != nullptr) grad[i] = gsc * d;
-            s0 += (double)(d * d);
-        } else {
-            s0 += (double)ai;
+    // 8 elements per thread in flight (a load - add loop pays one memory round trip per element); added in index order
+    const int stride = gridDim.x * 256;
+    for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 8 * stride) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = i0 + q * stride;
+            av[q] = i < n ? a[i] : 0.f;
+            bv[q] = (b != nullptr && i < n) ? b[i] : 0.f;
         }
-        s1 += (double)ai;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = i0 + q * stride;
+            if (i < n) {
+                if (b != nullptr) {
+                    const float d = av[q] - bv[q];
+                    if (grad != nullptr) grad[i] = gsc * d;
+                    s0 += (double)(d * d);
+                } else {
+                    s0 += (double)av[q];
+                }
+                s1 += (double)av[q];
+            }
+        }
     }
-    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
-        __syncthreads();
+    block_sum2(s0, s1, red);
+    if (gridDim.x == 1) {
+        if (threadIdx.x == 0) {
+            stats[0] = (float)((b != nullptr ? 1.0 : (double)sc0) * s0 / (double)n);
+            stats[1] = (float)(s1 / (double)n);
+        }
+        return;
     }
     double* part = reinterpret_cast<double*>(stats + 2);               // [LOSS_BLOCKS][2]
     unsigned* ticket = reinterpret_cast<unsigned*>(stats + 2 + 4 * LOSS_BLOCKS);
     if (threadIdx.x == 0) {
-        part[2 * blockIdx.x] = red[0][0];
-        part[2 * blockIdx.x + 1] = red[1][0];
+        part[2 * blockIdx.x] = s0;
+        part[2 * blockIdx.x + 1] = s1;
         __threadfence();
         last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
@@ -1737,22 +1812,18 @@ __global__ __launch_bounds__(256) void batch_loss_kernel(const float* __restrict
         __threadfence();
         const volatile double* vp = part;
         const bool has = threadIdx.x < gridDim.x;
-        red[0][threadIdx.x] = has ? vp[2 * threadIdx.x] : 0.0;
-        red[1][threadIdx.x] = has ? vp[2 * threadIdx.x + 1] : 0.0;
-        __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) {
-            if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
-            __syncthreads();
-        }
+        s0 = has ? vp[2 * threadIdx.x] : 0.0;
+        s1 = has ? vp[2 * threadIdx.x + 1] : 0.0;
+        block_sum2(s0, s1, red);
         if (threadIdx.x == 0) {
-            stats[0] = (float)((b != nullptr ? 1.0 : (double)sc0) * red[0][0] / (double)n);
-            stats[1] = (float)(red[1][0] / (double)n);
+            stats[0] = (float)((b != nullptr ? 1.0 : (double)sc0) * s0 / (double)n);
+            stats[1] = (float)(s1 / (double)n);
             *ticket = 0u;
         }
     }
 }
 hipError_t launch_batch_loss(const float* a, const float* b, int n, float gsc, float sc0, float* grad, float* stats, hipStream_t s) {
-    hipLaunchKernelGGL(batch_loss_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, s, a, b, n, gsc, sc0, grad, stats);
+    hipLaunchKernelGGL(batch_loss_kernel, dim3(n <= LOSS_ONE_BLOCK_MAX ? 1 : LOSS_BLOCKS), dim3(256), 0, s, a, b, n, gsc, sc0, grad, stats);
     return hipGetLastError();
 }
 

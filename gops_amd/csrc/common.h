@@ -60,15 +60,12 @@ struct MlpDev {
     const f16x8* wpth[GOPS_MAX_LAYERS];
 };
 
-// Plane-split contractions of the register-stationary kernels (policy: obs -> 256 -> 256 -> act, fp32 results).
-// An fp32 weight w is carried as  w1 = bf16(w)  (round to nearest)  +  rf = f16((w - w1) * s_r)  - 2 + 2 bytes, the
-// same register footprint as the fp32 value, >= 19 significant bits (|w - w1 - rf / s_r| <= 2^-19 |w|, 6e-7 |w| rms); an fp32
-// activation a as its three exact bf16 truncation planes a = a1 + a2 + a3 plus af = f16(a * s_a).  Then
-//     a * w  =  (a1 + a2 + a3) * w1  [3 x v_mfma_f32_16x16x32_bf16, exact products, fp32 accumulation]
-//            +  af * rf / (s_a s_r)  [1 x v_mfma_f32_16x16x32_f16 into a second accumulator]     + O(2^-19 |a w|)
-// i.e. 4 x 16-cycle matrix instructions per 32-deep block against 8 x 32-cycle v_mfma_f32_16x16x4_f32.  The bf16 main
-// term has fp32's exponent range; only the 2^-9-sized correction goes through half precision (saturating conversion,
-// s_r per n-tile from the packing kernel, s_a a power of two: fixed forward, per tile and step from max|delta_y| backward).
+// Plane-split contractions of the register-stationary kernels (policy: obs -> 256 -> 256 -> act, fp32 results): every fp32
+// operand of a hidden-layer contraction is carried as two 16-bit planes (2 + 2 bytes, the register footprint of the fp32 value)
+// and the products run on 16-cycle v_mfma_f32_16x16x32_* with fp32 accumulation instead of 8 x 32-cycle v_mfma_f32_16x16x4_f32
+// per 32-deep block.  WHICH planes: the GOPS_SPLIT_F16X2 block below (default: two half planes per operand, 3 MFMAs; the
+// round-3 form - w = bf16(w) + f16 residual, a = three exact bf16 planes + one half plane, 4 MFMAs - stays behind the switch).
+// The member types name the round-3 planes; the F16X2 packing stores half bit patterns in both (gemm_split bit-casts).
 struct SplitDev {
     int on;                     // 1: the stationary kernels run the plane-split contractions (else fp32 MFMA)
     int kc[2];                  // 32-wide k-chunks of hidden layer j's input
@@ -102,9 +99,9 @@ __host__ __device__ inline int ss_kc0(int kp32) { const int c = kp32 >> 5; retur
 //     a s = ah + al / 2^11  with ah = f16(a s), al = f16((a s - ah) 2^11): 2^-22 |a|, independent from sample to sample;
 //     a w = [ah wh] + [al wh + ah wl] / 2^11   - THREE v_mfma_f32_16x16x32_f16 per 32-deep block and n-tile (two accumulators),
 //                           the dropped al wl term is 2^-22 |a w|; products of two halfs are exact in the fp32 accumulator.
-//   s: a power of two that keeps the planes inside the half range: 1 in the forward (activations and observations of a sane
-//   rollout are far below 65504; beyond it the conversion SATURATES - a diverged rollout yields finite garbage instead of the
-//   fp32 overflow the reference would show), per tile and step from max|delta_y| in the sweep (as before).
+//   s: a power of two that keeps the planes inside the half range: SPLIT_FWD_SA in the forward (below), per tile and step from
+//   max|delta_y| in the sweep (as before).  Nothing is clamped: a value beyond the range converts to inf, every conversion
+//   records it (split2h's `ovf`) and the kernels poison the tile's results with NaN at tile end - an overflow is LOUD.
 //   Against the bf16x3 + f16 form: 3 instead of 4 matrix instructions, 2 instead of 4 plane images in LDS (half the plane
 //   stores and A-fragment reads), ~5 instead of ~8 VALU instructions per element split.
 // GOPS_SPLIT_F16X2 = 0: the round-3 form (three exact bf16 planes of the activation, bf16 + scaled f16 planes of the weight).

@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
         const int Lv = p.val.nl - 1;
         if (SS && p.tail_fp32) {
             // relu / selu value net of a launch that keeps a gradient: exact fp32 products for THIS net (dV/d(obs) of a piecewise-linear
-            // net jumps where a pre-activation changes sign under the 2^-19 weight representation); the step loop stays plane-split
+            // net jumps where a pre-activation changes sign under the 22-bit plane representation); the step loop stays plane-split
             float* hcur = mlp_hidden_forward(p.val, NoW{}, NoW{}, xs, ldx, ha, hb, ldh, tid, s_bias,
                                              p.need_grad ? p.st.tail_h : nullptr,
                                              p.need_grad ? p.st.tail_z : nullptr, (size_t)b0, dbg);
@@ -1250,7 +1250,7 @@ int split_grid_limit() { return device_cus(); }
 // planes of both layers then fit the register file + LDS).  One workgroup per CU keeps the weights resident and walks
 // the tiles grid-stride, whatever the batch size.  GOPS_SPLIT=0 keeps the fp32-MFMA kernels.
 // Activations whose derivative jumps at 0 (relu, selu) in a launch with a tail value net that keeps a gradient: the gradient runs
-// through dV/d(obs_H) of a piecewise-linear net, and every pre-activation of THAT net which changes sign under the 2^-19 weight
+// through dV/d(obs_H) of a piecewise-linear net, and every pre-activation of THAT net which changes sign under the 22-bit plane
 // representation moves it by a finite amount - measured at cfg3 (relu, 256^3, B = 8192): 2.0e-4 from the reference with a
 // plane-split tail value net, < 1e-4 with exact fp32 products.  The tail value net of such a launch is therefore evaluated with
 // exact fp32 products (the stationary kernels do that for every tail; the streamed ones on RolloutParams.tail_fp32).  Launches

@@ -85,12 +85,15 @@ enum { GOPS_ACT_LINEAR = 0, GOPS_ACT_RELU = 1, GOPS_ACT_ELU = 2, GOPS_ACT_GELU =
 
 /* Arithmetic of the MLP contractions (BASELINE.json configs[4]: "fp16 MFMA MLP path").
  *   GOPS_DTYPE_F32: fp32 results at the 1e-4 parity bar (default).  NOT bit-level fp32 arithmetic where the plane-split
- *                   kernels run (gops_rollout_variant bits 0 / 2; every 256-wide net): a weight is carried as bf16 + scaled
- *                   f16 residual (>= 19 significant bits, fp32 has 24), activations / deltas as three exact bf16 planes +
- *                   one f16 plane, fp32 accumulation; the large weight-gradient GEMMs multiply two-half-plane operands
- *                   (22 significant bits, deltas scaled by max|grad_v| of the call, saturated blocks redone exactly).
- *                   Measured distance to the reference 4e-7 .. 8e-6.  GOPS_VF_STREAMED_FP32 |
- *                   GOPS_VF_DW_F32 in the descriptor's variant_flags select v_mfma_f32_16x16x4_f32 (an fmaf chain) throughout.
+ *                   kernels run (gops_rollout_variant bits 0 / 2; every 256-wide net): weights, activations and deltas are
+ *                   each carried as two IEEE-half planes x s = hi + lo / 2^11 (22 significant bits, fp32 has 24; s a power of
+ *                   two - per 16 output features for weights, 2^-4 for forward activations, from max|delta| in the sweep),
+ *                   a w = hi hi + (lo hi + hi lo) / 2^11 on three v_mfma_f32_16x16x32_f16 with fp32 accumulation; the large
+ *                   weight-gradient GEMMs likewise (deltas scaled by max|grad_v| of the call, saturated blocks redone exactly).
+ *                   Forward range |activation| < 1.05e6: beyond it the launch's results are NaN (never silently wrong).
+ *                   Measured distance to the reference on trained 256-wide networks 2e-6 .. 3e-5, at the level of the exact
+ *                   fp32 kernels.  GOPS_VF_STREAMED_FP32 | GOPS_VF_DW_F32 in the descriptor's
+ *                   variant_flags select v_mfma_f32_16x16x4_f32 (an fmaf chain) throughout.
  *   GOPS_DTYPE_F16: weights, hidden activations and deltas rounded to IEEE half, products accumulated
  *                   in fp32 by v_mfma_f32_16x16x32_f16; the activation stash is half (2 bytes/element).
  *                   Env model, wrapper chain, rewards, returns, observation / state adjoints, policy
@@ -431,9 +434,9 @@ int gops_value_loss(const float* v, const float* target, int32_t n, float* grad,
 int gops_mean_loss(const float* x, int32_t n, double scale, float* stats, void* stream);
 
 /* Which kernels a rollout description runs on this device (ABI v8; for benchmarks / profiles, no launch):
- * bit 0 (GOPS_VARIANT_SPLIT): the register-stationary kernels with plane-split contractions - hidden-layer weights as
- *        bf16 + scaled f16 residual planes, activations / deltas as three exact bf16 planes + one f16 plane,
- *        3 bf16 + 1 f16 MFMA (16x16x32) per 32-deep block, fp32 accumulation (>= 19-bit weights, fp32 results);
+ * bit 0 (GOPS_VARIANT_SPLIT): the register-stationary kernels with plane-split contractions - hidden-layer weights,
+ *        activations and deltas as two half planes each (22 bits), 3 f16 MFMAs (16x16x32) per 32-deep block, fp32
+ *        accumulation and results (GOPS_DTYPE_F32 above);
  * bit 1 (GOPS_VARIANT_STATIONARY_F32): the register-stationary kernels on exact fp32 MFMAs;
  * bit 2 (GOPS_VARIANT_STREAMED_SPLIT_FWD, ABI v9): the FORWARD rollout on the streamed plane-split kernel (any number of
  *        256-wide hidden layers, weight planes streamed from L2, tail value net included - except that the tail value net of a

@@ -542,7 +542,7 @@ def golden_trained():
 # 4b. 256-wide networks TRAINED by the unmodified reference (`FHADP._local_update`, fhadp.py:87-90;
 #     `INFADP.local_update`, infadp.py:101-104, incl. its Polyak step): a few hundred Adam updates on
 #     fresh synthetic batches, then one gradient evaluation on a held-out batch.  The BASELINE shapes
-#     are all 256-wide, i.e. they run the plane-split (bf16 + f16 weight planes) kernels; the shipped
+#     are all 256-wide, i.e. they run the plane-split (16-bit operand planes) kernels; the shipped
 #     checkpoints above are 64-wide.  These fixtures pin the 1e-4 bar on weights that have MOVED
 #     (larger magnitudes, a saturating tanh head in the *_sat case).
 # ------------------------------------------------------------------------------------------

@@ -1027,7 +1027,7 @@ def test_loss_scalars_and_polyak_update_match_torch():
     dev = torch.device("cuda", 0)
     g = torch.Generator(device="cpu").manual_seed(3)
     st = hb.LossStats(dev)
-    for n in (1, 77, 4096, 65536, 100003):
+    for n in (1, 77, 4096, 8192, 8193, 65536, 100003):   # (one block forms the sums up to 8192 elements)
         v = torch.randn(n, generator=g).to(dev) * 3 - 1
         b = torch.randn(n, generator=g).to(dev)
         grad = torch.empty(n, device=dev)

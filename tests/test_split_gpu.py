@@ -1,6 +1,6 @@
-"""GPU: the plane-split contractions of the register-stationary kernels (csrc/common.h SplitDev: bf16 + scaled f16 weight
-planes, exact bf16 planes + an f16 plane of the activations / deltas) against the oracle at the 1e-4 bar, and against the
-exact-fp32-MFMA kernels of the same library (GOPS_SPLIT=0) to see what the 19-bit weights cost: every env kind and
+"""GPU: the plane-split contractions of the register-stationary kernels (csrc/common.h GOPS_SPLIT_F16X2: two half planes per
+operand, 22 bits, three f16 MFMAs per block) against the oracle at the 1e-4 bar, and against the
+exact-fp32-MFMA kernels of the same library (GOPS_SPLIT=0) to see what the 16-bit planes cost: every env kind and
 layer-0 chunk count the split kernels are instantiated for, ragged batches, every hidden activation, INFADP's tail value."""
 import numpy as np
 import pytest

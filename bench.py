@@ -455,7 +455,7 @@ def parity_stamp(alg, cfg, workload, device, variant_name):
 
 
 
-def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, check_parity=False, overlap=True):
+def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, check_parity=False, overlap=True, label=None):
     """Times `steps` updates of one workload on this rank's GPU (all ranks call it together) and returns the
     measurements; rank 0 turns them into the record."""
     rank, world, device, dist = ctx["rank"], ctx["world"], ctx["device"], ctx["dist"]
@@ -470,7 +470,7 @@ def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, ch
         alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]
     parity = None
     if check_parity and rank == 0 and dtype == "fp32":
-        parity = parity_stamp(alg, cfg, workload, device, "exact fp32 MFMA (GOPS_VF_STREAMED_FP32 | GOPS_VF_DW_F32)" if flags else "default")
+        parity = parity_stamp(alg, cfg, workload, device, label or ("exact fp32 MFMA (GOPS_VF_STREAMED_FP32 | GOPS_VF_DW_F32)" if flags else "default"))
     data = {k: v.to(device) for k, v in make_batch(cfg, 1000 + rank).items()}   # per-rank shard
     reducer = GradAllReducer(overlap=overlap)   # (overlap=False: one flat all-reduce behind the whole backward)
 
@@ -687,6 +687,28 @@ def main():
         mm = run_workload(workload, "fp32", k_steps, k_warm, min(k_steps, 10), ctx, flags=hb.VF_STREAMED_FP32 | hb.VF_DW_F32, check_parity=True)
         others["exact_fp32"] = dict(brief(record_of(workload, "fp32", k_steps, k_warm, world, mm)), workload=workload,
                                     variant_flags="GOPS_VF_STREAMED_FP32 | GOPS_VF_DW_F32")
+        # ... and on the register-stationary exact-fp32 kernels (weights resident like the default, every product an fp32 MFMA): the
+        # fastest strict-fp32 configuration of this library at this shape
+        mm = run_workload(workload, "fp32", k_steps, k_warm, min(k_steps, 10), ctx, flags=hb.VF_NO_STATIONARY_SPLIT | hb.VF_NO_STREAMED_SPLIT_FWD
+                          | hb.VF_NO_STREAMED_SPLIT_BWD | hb.VF_DW_F32, check_parity=True, label="exact fp32 MFMA, register-stationary weights")
+        others["exact_fp32_stationary"] = dict(brief(record_of(workload, "fp32", k_steps, k_warm, world, mm)), workload=workload,
+                                               variant_flags="GOPS_VF_NO_STATIONARY_SPLIT | _NO_STREAMED_SPLIT_FWD | _NO_STREAMED_SPLIT_BWD | GOPS_VF_DW_F32")
+        # what the algorithm classes' PrecisionGuard (algorithm/base.py) falls back to when its measured rule trips: exact-fp32 rollout
+        # kernels (forward and sweep), the two-half-plane weight-gradient GEMM behind them - and what the guard itself costs while it does not trip
+        from gops_amd.algorithm.base import PrecisionGuard
+        mm = run_workload(workload, "fp32", k_steps, k_warm, min(k_steps, 10), ctx, flags=PrecisionGuard.exact_rollout_flags(), check_parity=True,
+                          label="exact-fp32 rollout kernels (forward and sweep), two-half-plane weight-gradient GEMM")
+        exact_ro = brief(record_of(workload, "fp32", k_steps, k_warm, world, mm))
+        g = PrecisionGuard()
+        others["guard_fallback"] = dict(exact_ro, workload=workload,
+                                       variant_flags="GOPS_VF_NO_STATIONARY_SPLIT | GOPS_VF_NO_STREAMED_SPLIT_FWD | GOPS_VF_NO_STREAMED_SPLIT_VALUE")
+        out["precision_guard"] = {
+            "interval": g.interval, "threshold": g.threshold,
+            "checks_in_timed_loop": 0 if g.interval <= 0 else (args.warmup + args.steps) // g.interval - args.warmup // g.interval,
+            "amortized_cost_fraction": ((out["ms_per_step"] + exact_ro["ms_per_step"]) / (g.interval * out["ms_per_step"])) if g.interval > 0 else 0.0,
+            "what": "every `interval` updates the algorithm classes form the batch's gradient twice more (own kernels, exact-fp32 rollout kernels) and "
+                    "compare; the bench loop times compute_gradient + Adam without it - amortized_cost_fraction = (t_default + t_guard_fallback) "
+                    "/ (interval * t_default) is what a training run pays on top of `value`"}
         out["workloads"] = others
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -96,19 +96,20 @@ class PrecisionGuard:
     reference; the round-3 planes, 2^-20, put an ill-conditioned closed loop - the pyth_lq policy with a saturated tanh head, whose
     REFERENCE gradient moves 6.6e-5 under 1-ulp weight moves - at 3.5e-4), and activations beyond the half range of the forward
     planes (|a| >= 1.05e6) make the launch return NaN.  Neither conditioning nor range can be read off a description - so the guard
-    MEASURES.  Only the FORWARD matters (the sweep is linear once the forward has fixed states and activations: plane-split sweep +
-    weight-gradient GEMM behind an exact forward measure the same as all-exact): every `interval` gradients (and at the first
-    one: a loaded checkpoint may already be there) the gradient of the current batch is formed twice, with the launch's own
-    kernels and with `FWD_EXACT` added, and if their relative L2 distance exceeds `threshold` the algorithm stays on the
-    exact-fp32 forward from then on (sticky).  Cost: two extra gradients per `interval` updates (0.4 % at the default 500), one
-    host sync per check.  `GOPS_PRECISION_CHECK_INTERVAL=0` (or `precision_check_interval=0`) switches the guard off."""
+    MEASURES: every `interval` gradients (and at the first one: a loaded checkpoint may already be there) the gradient of the
+    current batch is formed twice, with the launch's own kernels and with `exact_rollout_flags()` added - forward rollout and sweep on
+    exact fp32 MFMAs; the weight-gradient GEMM keeps its two-half-plane products, whose per-sample operand errors average out over
+    the B x H samples (exact rollout kernels + that GEMM measure the same as an all-exact launch on every trained fixture) - and if
+    their relative L2 distance exceeds `threshold` the algorithm stays on the exact-fp32 rollout kernels from then on (sticky;
+    0.59x the default's rate at the BASELINE target).  Cost: two extra gradients per `interval` updates (0.5 % at the default 500),
+    one host sync per check.  `GOPS_PRECISION_CHECK_INTERVAL=0` (or `precision_check_interval=0`) switches the guard off."""
 
     def __init__(self, interval=None, threshold=None):
         import os
         self.interval = int(os.environ.get("GOPS_PRECISION_CHECK_INTERVAL", 500)) if interval is None else int(interval)
         self.threshold = float(os.environ.get("GOPS_PRECISION_THRESHOLD", 5e-5)) if threshold is None else float(threshold)
         self.count = 0            # gradients seen
-        self.exact = False        # sticky: the forward runs on exact fp32 products from here on
+        self.exact = False        # sticky: the rollout kernels run on exact fp32 products from here on
         self.last_distance = None
         self.checks = 0
 
@@ -124,14 +125,14 @@ class PrecisionGuard:
         return any(all(l.out_features == 256 for l in m.linear_layers()[:-1]) for m in modules)
 
     @staticmethod
-    def fwd_exact_flags():
+    def exact_rollout_flags():
         from gops_amd import hip_backend as hb
         return hb.VF_NO_STATIONARY_SPLIT | hb.VF_NO_STREAMED_SPLIT_FWD | hb.VF_NO_STREAMED_SPLIT_VALUE
 
     def flags(self) -> int:
         """Variant flags of the owner's launches right now (on top of hip_backend.DEFAULT_VARIANT_FLAGS)."""
         from gops_amd import hip_backend as hb
-        return hb.DEFAULT_VARIANT_FLAGS | (self.fwd_exact_flags() if self.exact else 0)
+        return hb.DEFAULT_VARIANT_FLAGS | (self.exact_rollout_flags() if self.exact else 0)
 
     def due(self) -> bool:
         """Call once per computed gradient; True when this one is to be checked."""
@@ -142,11 +143,11 @@ class PrecisionGuard:
 
     def check(self, flat_gradient) -> float:
         """`flat_gradient(flags) -> 1-D device tensor`: the owner's gradient of the batch at hand under the given variant flags
-        (a fresh tensor).  Returns the measured distance and switches to the exact forward when it exceeds the threshold."""
+        (a fresh tensor).  Returns the measured distance and switches to the exact rollout kernels when it exceeds the threshold."""
         from gops_amd import hip_backend as hb
         base = hb.DEFAULT_VARIANT_FLAGS
         g_split = flat_gradient(base)
-        g_exact = flat_gradient(base | self.fwd_exact_flags())
+        g_exact = flat_gradient(base | self.exact_rollout_flags())
         d = (g_split.double() - g_exact.double()).norm() / g_exact.double().norm().clamp_min(1e-300)
         try:   # data-parallel replicas take the decision together (the largest distance any rank saw)
             import torch.distributed as dist
@@ -159,8 +160,8 @@ class PrecisionGuard:
         if not (self.last_distance <= self.threshold):   # (NaN counts as exceeded)
             self.exact = True
             import warnings
-            warnings.warn(f"gops_amd: plane-split and exact-fp32 forward differ by {self.last_distance:.2e} (relative L2 of the gradient, "
-                          f"threshold {self.threshold:.0e}) - this network stays on the exact-fp32 forward from here on")
+            warnings.warn(f"gops_amd: plane-split and exact-fp32 rollout kernels differ by {self.last_distance:.2e} (relative L2 of the "
+                          f"gradient, threshold {self.threshold:.0e}) - this network stays on the exact-fp32 rollout kernels from here on")
         return self.last_distance
 
 

@@ -150,7 +150,7 @@ class FHADP(AlgorithmBase):
 
     def _precision_check(self, batch):
         """PrecisionGuard (algorithm/base.py): every `interval` gradients the gradient of `batch` is formed with the launch's own
-        kernels and with the exact-fp32 forward; beyond the threshold the algorithm stays on the exact forward."""
+        kernels and with the exact-fp32 rollout kernels; beyond the threshold the algorithm stays on those."""
         if self.mlp_dtype != "fp32" or not PrecisionGuard.applies_to(self.networks.policy, env_kind=getattr(self.envmodel.unwrapped, "hip_kind", None)):
             return
         if not self.precision_guard.due():

@@ -177,8 +177,8 @@ class INFADP(AlgorithmBase):
 
     def _precision_check(self, mode: str, batch):
         """PrecisionGuard (algorithm/base.py) of the network this iteration trains: every `interval` of ITS gradients the gradient of
-        `batch` is formed with the launch's own kernels and with the exact-fp32 forward; beyond the threshold that network's
-        launches stay on the exact forward."""
+        `batch` is formed with the launch's own kernels and with the exact-fp32 rollout kernels; beyond the threshold that network's
+        launches stay on those."""
         guard = self.precision_guard[mode]
         if self.mlp_dtype != "fp32" or not PrecisionGuard.applies_to(self.networks.policy, self.networks.v,
                                                                       env_kind=getattr(self.envmodel.unwrapped, "hip_kind", None)):

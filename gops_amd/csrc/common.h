@@ -7,7 +7,7 @@
 
 // NOTE (round 4): this library is compiled with the `packed-fp32-ops` subtarget feature OFF (csrc/Makefile: NOPK) - a gfx950
 // hazard between dependent v_pk_*_f32 instructions that hipcc's SLP vectoriser forms out of plain scalar code made the streamed
-// plane-split kernels run-to-run non-deterministic (reproducer tools/microbench/pk_hazard.hip).
+// plane-split kernels run-to-run non-deterministic (DESIGN_LOG.md, round 4, reproducer tools/microbench/pk_hazard.hip).
 // tests/test_host_cpu.py disassembles the built library and fails on any v_pk_{mul,add,fma}_f32.
 
 #define TB GOPS_TILE      // trajectories per workgroup tile = MFMA M
@@ -112,7 +112,7 @@ __host__ __device__ inline int ss_kc0(int kp32) { const int c = kp32 >> 5; retur
 // forward scale of the activation planes: 2^-4 puts the top of the half range at |a| = 1.05e6 and keeps 22 bits down to
 // |a| = 1e-3 (below that the two planes still resolve 2^-32 ABSOLUTE: hi and lo both run into half subnormals, lo's at 2^-35 / s).
 // Beyond the range the conversion yields inf and the rollout returns non-finite values - loudly, like the reference's own overflow,
-// only earlier; the algorithm classes' PrecisionGuard treats a non-finite distance as exceeded and moves to the exact-fp32 forward.
+// only earlier; the algorithm classes' PrecisionGuard treats a non-finite distance as exceeded and moves to the exact-fp32 rollout kernels.
 #define SPLIT_FWD_SA 0.0625f
 #define SPLIT_LO_SCALE 2048.0f   // 2^11: the residual planes of both operands
 #else

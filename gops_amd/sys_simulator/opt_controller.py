@@ -64,9 +64,14 @@ class OptController:
             # The batched collocation needs a model whose observation is its state and whose forward takes no info (pyth_lq,
             # pyth_idpendulum, gym_cartpoleconti, gym_pendulum, pyth_mobilerobot).  For the others the reference itself drops to
             # its step-by-step rollout (opt_controller.py:292-294); callers that rely on the default mode keep working here
-            # through the shooting formulation (same optimum: the transition equalities are eliminated instead of imposed).
+            # through the shooting formulation: the transition equalities are eliminated instead of imposed - the same optimum
+            # UNLESS state bounds are active: collocation hands obs_lower_bound / obs_upper_bound to the solver as variable bounds
+            # (opt_controller.py:104-115), shooting has no state variables to bound and drops them.
             warnings.warn(f"OptController: mode='collocation' is not available for {type(base).__name__} (its forward needs `info`); "
-                          "falling back to mode='shooting'")
+                          "falling back to mode='shooting'.  The shooting formulation optimises the actions only: the model's "
+                          "obs_lower_bound / obs_upper_bound, which collocation imposes as variable bounds on the states, are NOT "
+                          "enforced - where they would be active the two modes find different optima (action bounds and the "
+                          "model's inequality constraints are kept)")
             mode = "shooting"
         self.model, self.base = model, base
         self.terminal_cost = None

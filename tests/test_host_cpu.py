@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_device_code_has_no_packed_fp32_instructions():
-    """DESIGN.md section 8.0 (round 4): on gfx950 a v_pk_fma_f32 that consumes the result of a v_pk_mul_f32 issued two slots
+    """DESIGN_LOG.md, round 4 (round 4): on gfx950 a v_pk_fma_f32 that consumes the result of a v_pk_mul_f32 issued two slots
     earlier reads zeros in lanes 48..63 when another wave of the SIMD streams MFMAs (stand-alone reproducer:
     tools/microbench/pk_hazard.hip) - the cause of the run-to-run non-determinism of the round-3 streamed plane-split kernels.
     The library is therefore built with the `packed-fp32-ops` subtarget feature off (csrc/Makefile NOPK); this test disassembles
@@ -120,12 +120,12 @@ def test_precision_guard_schedule_and_decision():
         seen.append(flags)
         return base * (1 + (1e-6 if flags else 0.0))
     d = g.check(close)
-    assert seen == [hb.DEFAULT_VARIANT_FLAGS, hb.DEFAULT_VARIANT_FLAGS | PrecisionGuard.fwd_exact_flags()]
+    assert seen == [hb.DEFAULT_VARIANT_FLAGS, hb.DEFAULT_VARIANT_FLAGS | PrecisionGuard.exact_rollout_flags()]
     assert 0.5e-6 < d < 2e-6 and not g.exact and g.flags() == hb.DEFAULT_VARIANT_FLAGS
-    with pytest.warns(UserWarning, match="exact-fp32 forward"):
+    with pytest.warns(UserWarning, match="exact-fp32 rollout kernels"):
         d = g.check(lambda flags: base * (1 + (3e-4 if flags else 0.0)))
     assert 2e-4 < d < 4e-4 and g.exact
-    assert g.flags() & PrecisionGuard.fwd_exact_flags() == PrecisionGuard.fwd_exact_flags()
+    assert g.flags() & PrecisionGuard.exact_rollout_flags() == PrecisionGuard.exact_rollout_flags()
     assert not any(g.due() for _ in range(20))   # sticky: nothing left to decide
     with pytest.warns(UserWarning):
         g2 = PrecisionGuard(interval=1, threshold=5e-5)
@@ -139,8 +139,8 @@ def test_precision_guard_schedule_and_decision():
     wide = create_alg(**_fhadp_kwargs(policy_hidden_sizes=[256, 256])).networks.policy
     assert not PrecisionGuard.applies_to(narrow) and PrecisionGuard.applies_to(wide) and PrecisionGuard.applies_to(narrow, wide)
     assert not PrecisionGuard.applies_to(wide, env_kind=hb.ENV_MOBILEROBOT)
-    # the exact-forward flags leave the sweep and the weight-gradient GEMM alone
-    f = PrecisionGuard.fwd_exact_flags()
+    # the exact-rollout flags leave the weight-gradient GEMM alone
+    f = PrecisionGuard.exact_rollout_flags()
     assert f & (hb.VF_NO_STREAMED_SPLIT_BWD | hb.VF_DW_F32 | hb.VF_DW_EXACT | hb.VF_STREAMED_FP32) == 0
 
 

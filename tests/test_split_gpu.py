@@ -218,7 +218,7 @@ def test_streamed_split_launches_are_reproducible(name, dev):
     """The same forward + backward launch pair TEN times with more tiles than CUs (two workgroups share a CU), the workspace
     filled with other garbage each time (zero bytes, NaN bytes, random bytes): returns AND every parameter gradient are
     bit-identical.  (Round 3: the veh3dofconti forward moved whole tiles by up to 5e-4 and every sweep left a 1e-8 .. 1e-6
-    spread - a gfx950 hazard between dependent packed-fp32 instructions; the library is built without
+    spread - a gfx950 hazard between dependent packed-fp32 instructions, DESIGN_LOG.md, round 4; the library is built without
     those instructions since round 4.)"""
     from gops_amd import hip_backend as hb
     cfg = dict(SS_CASES[name])

@@ -6,9 +6,9 @@ representation has to hold the north_star bar (1e-4 relative L2) - and where it 
 same library on the same fixture.  Every case prints all distances; DESIGN.md section 2 quotes them.
 
 What round 5 measured here (MI355X):
-  * the error of the plane-split path is carried by the FORWARD alone: an exact-fp32 forward with the plane-split sweep and
-    weight-gradient GEMM behind it is as close to the reference as the all-exact launch (the sweep is linear once the forward
-    has fixed states and activations);
+  * the error of the plane-split path sits in the ROLLOUT kernels (forward and sweep: the same perturbed weights for every sample);
+    exact-fp32 rollout kernels with the two-half-plane weight-gradient GEMM behind them ("exact_forward" below: what `PrecisionGuard`
+    falls back to) are as close to the reference as the all-exact launch - the GEMM's per-sample operand errors average out;
   * a weight error is SYSTEMATIC (the same perturbed network for every sample: it does not average out over the batch).  With the
     round-3 planes (bf16 + f16 residual, 2^-20 |w|) five of the six fixtures sat at 3e-6 .. 3e-5 but the reference-trained pyth_lq
     policy with a saturated tanh head (the REFERENCE's own gradient moves 6.6e-5 under 1-ulp weight moves) at 3.5e-4 - outside
@@ -59,7 +59,7 @@ def _variants():
     return {
         "default": 0,                                                  # what bench.py times: plane-split where eligible
         "streamed_split": hb.VF_NO_STATIONARY_SPLIT,                   # the streamed plane-split kernels (B > 4096 takes these)
-        "exact_forward": PrecisionGuard.fwd_exact_flags(),             # the guard's fallback: exact forward, plane-split sweep / dW
+        "exact_forward": PrecisionGuard.exact_rollout_flags(),         # the guard's fallback: exact forward AND sweep, two-half-plane dW GEMM
         "exact_fp32": hb.VF_STREAMED_FP32 | hb.VF_DW_F32,              # v_mfma_f32_16x16x4_f32 throughout
     }
 
@@ -210,7 +210,7 @@ def test_infadp_trained_256_wide_vs_reference(name, dev):
         _check_table(name, pim_rep, VEH_HEADING_BOUND if heading else bar_of(g, "meta/ref_fp32_scatter_pim"), mode + " PIM")
 
 
-# ---- the algorithm classes: PrecisionGuard decides between the plane-split and the exact-fp32 forward ------------------------
+# ---- the algorithm classes: PrecisionGuard decides between the plane-split and the exact-fp32 rollout kernels ------------------------
 def _load_alg(name, **extra):
     from test_alg_gpu import _kwargs
     from gops_amd.create_pkg.create_alg import create_alg
@@ -240,8 +240,8 @@ def _load_alg(name, **extra):
 def test_precision_guard_fhadp(name, dev):
     """The FHADP class on the trained fixtures: the first gradient is checked (a loaded checkpoint may already need the exact
     forward).  With two half planes per operand every fixture stays on the plane-split kernels, its measured distance to the
-    exact-fp32 forward far below the threshold; with the threshold set below that distance the guard trips, stays tripped, and
-    the class returns the exact-forward gradient."""
+    exact-fp32 rollout kernels far below the threshold; with the threshold set below that distance the guard trips, stays tripped, and
+    the class returns the exact kernels' gradient."""
     alg, g, cfg = _load_alg(name)
     data = to_device(data_from_golden(g), dev)
     guard = alg.precision_guard
@@ -261,7 +261,7 @@ def test_precision_guard_fhadp(name, dev):
     assert alg._rollout_for(data["obs"].shape[0], dev).desc.variant_flags == guard.flags()
     # the same network under a threshold below its measured distance: trips at the first gradient, and stays on the exact forward
     alg2, _, _ = _load_alg(name, precision_threshold=guard.last_distance * 0.5)
-    with pytest.warns(UserWarning, match="exact-fp32 forward"):
+    with pytest.warns(UserWarning, match="exact-fp32 rollout kernels"):
         _, info2 = alg2.get_remote_update_info(data, 0)
     torch.cuda.synchronize()
     g2 = alg2.precision_guard
@@ -273,14 +273,14 @@ def test_precision_guard_fhadp(name, dev):
     assert g2.checks == 1 and g2.exact
     from gops_amd.algorithm.base import PrecisionGuard
     flags = alg2._rollout_for(data["obs"].shape[0], dev).desc.variant_flags
-    assert flags == g2.flags() and flags & PrecisionGuard.fwd_exact_flags() == PrecisionGuard.fwd_exact_flags()
+    assert flags == g2.flags() and flags & PrecisionGuard.exact_rollout_flags() == PrecisionGuard.exact_rollout_flags()
 
 
 def test_half_range_overflow_is_loud_and_the_guard_catches_it(dev):
     """The plane-split forward carries activations as two half planes scaled by 2^-4: beyond |a| = 1.05e6 the conversion overflows
     and the rollout returns NON-FINITE values (never silently wrong ones).  A policy whose first layer is scaled so that H_1
     reaches ~1e8: the raw plane-split launch is non-finite; the FHADP class measures a non-finite distance at its first gradient,
-    moves to the exact-fp32 forward and returns the reference gradient."""
+    moves to the exact-fp32 rollout kernels and returns the reference gradient."""
     from gops_amd import hip_backend as hb
     from gops_amd.utils.synthetic import act_dim_of, make_batch, obs_dim_of
     from helpers import reference_init_nets
@@ -308,7 +308,7 @@ def test_half_range_overflow_is_loud_and_the_guard_catches_it(dev):
             layer.weight.copy_(w.detach())
             layer.bias.copy_(b.detach())
     alg.envmodel.unwrapped.dynamics.inv_IA = env["lq"]["inv_IA"].to(dev)
-    with pytest.warns(UserWarning, match="exact-fp32 forward"):
+    with pytest.warns(UserWarning, match="exact-fp32 rollout kernels"):
         _, info = alg.get_remote_update_info(ddev, 0)
     torch.cuda.synchronize()
     assert alg.precision_guard.exact

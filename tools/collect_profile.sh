@@ -14,6 +14,9 @@ out=$root/gpurun_out/${tag}_${wl}${sfx}
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 export GOPS_HIP_GRAPH=0
+# the algorithm classes' PrecisionGuard re-forms the first gradient (and every 500th) on the exact-fp32 kernels: 1 update in 8 of these
+# short runs would carry those launches - per-update averages of the DEFAULT kernels are wanted here
+export GOPS_PRECISION_CHECK_INTERVAL=0
 UPDATES=8
 timeout 400 python $root/bench.py --workload $wl --dtype $dt --steps 100 --warmup 20 > $out/bench.json 2> $out/bench.err
 rm -rf /tmp/stats

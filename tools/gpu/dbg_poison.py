@@ -1,4 +1,4 @@
-"""Reproducibility / uninitialised-read hunt: the same streamed-split launch pair with the workspace poisoned (NaN bytes / random bytes)
+"""Reproducibility / uninitialised-read hunt (DESIGN_LOG.md, round 4): the same streamed-split launch pair with the workspace poisoned (NaN bytes / random bytes)
 before the forward; every result must be finite and bit-identical to the clean run."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,4 +1,4 @@
-// Stand-alone reproducer for the run-to-run non-determinism of the streamed plane-split kernels (DESIGN.md section 8.0,
+// Stand-alone reproducer for the run-to-run non-determinism of the streamed plane-split kernels (DESIGN_LOG.md, round 4,
 // root-caused in round 4): a packed-fp32 VALU instruction (v_pk_fma_f32) that consumes the result of another packed-fp32
 // instruction (v_pk_mul_f32) two issue slots earlier - hipcc (ROCm 7.2, gfx950) leaves ONE instruction between them - sees
 // ZEROS instead of the producer's result in lanes 48..63 when a second wave shares the SIMD.

@@ -3,7 +3,7 @@
   python tools/scan_code_objects.py gops_amd/libgops_hip.so 'v_pk_(mul|add|fma)_f32' s_swappc_b64
 
 Used by tests/test_host_cpu.py to hold the shipped library to "no packed-fp32 VALU instructions, no device-side calls"
-(the gfx950 packed-fp32 hazard behind the round-3 non-determinism)."""
+(DESIGN_LOG.md, round 4: the gfx950 packed-fp32 hazard behind the round-3 non-determinism)."""
 import os, re, struct, subprocess, sys, tempfile
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"

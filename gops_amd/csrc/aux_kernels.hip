@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
             const unsigned i = threadIdx.x + 256 * q;
             if (i < NW) d[i] = w[q];
         }
-        if (p.gscale != nullptr && threadIdx.x == 0) p.gscale[0] = 0.f;   // max|grad_v| of the coming backward
+        if (p.gscale != nullptr && threadIdx.x == 0) p.gscale[0] = p.gscale[1] = 0.f;   // max|grad_v| / max|delta_y| of the coming backward
         return;
     }
     b -= 1;
@@ -701,6 +701,14 @@ __device__ __forceinline__ void split2h(const f32x4& lo4, const f32x4& hi4, floa
     pl = __builtin_bit_cast(f16x8, ul);
 }
 
+// What the hidden deltas of a backward call are measured against when they are scaled for the half planes (dscale =
+// RolloutParams::gscale): the largest |delta_y| of the sweep (slot 1: the plane-split sweeps track it, rollout_bwd.hip) where there
+// is one, else max|grad_v| (slot 0).  Whatever the choice, a block that still saturates is redone exactly.
+__device__ __forceinline__ float dw_delta_yardstick(const float* dscale) {
+    const float dy = gptr(dscale)[1], gv = gptr(dscale)[0];
+    return dy > 0.f ? dy : gv;
+}
+
 #define DWR_STAGES 2
 #define DWR_STAGE_FLOATS (4 * 2048)   // [D tile q0][D tile q0+1][X tile q0][X tile q0+1], each [128 features][16 rows]
 
@@ -754,7 +762,7 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
     f32x4 accx[TWO_ACC ? R : 1][TWO_ACC ? R : 1] = {};   // cross terms (dh * al + dl * ah), scaled by 2^11
     float bsum[R] = {0.f, 0.f, 0.f, 0.f};
     float sd = 1.f;
-    if constexpr (H2) sd = f16_grad_scale(gptr(dscale)[0]) * (GOPS_DW_H2_MODE == 2 ? 16.f : 0.015625f);
+    if constexpr (H2) sd = f16_grad_scale(dw_delta_yardstick(dscale)) * (GOPS_DW_H2_MODE == 2 ? 16.f : 0.015625f);
     auto block = [&]<bool LAST_HALF_EMPTY, bool M2>(int stage) {
         const float* st = ring + stage * DWR_STAGE_FLOATS;
         const float* da = st + (wn * 64 + f) * 16 + 4 * g;          // D fragments of row-tile i: + 256 i  (+ 2048: second tile)
@@ -1057,7 +1065,7 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
     // multiplying waves: 128 x 64 outputs each
     const int mw = wave & 3, wn = mw >> 1, wk = mw & 1;
     f32x4 acc[8][4] = {};
-    const float sd = f16_grad_scale(gptr(dscale)[0]) * 16.f;
+    const float sd = f16_grad_scale(dw_delta_yardstick(dscale)) * 16.f;
     auto block_h2 = [&](int stage) {
         const float* st = ring + stage * SF;
         const float* da = st + (wn * 128 + f) * 16 + 4 * g;            // D fragments of row-tile i: + 256 i  (lo plane: + DT)
@@ -1544,7 +1552,7 @@ hipError_t launch_dw_out(const float* dy, const float* h, bool h_is_half, int K,
 // deterministic).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs jobs) {
     __shared__ float red[4][64];
-    if (jobs.reset != nullptr && blockIdx.x == 0 && threadIdx.x == 0) jobs.reset[0] = 0.f;
+    if (jobs.reset != nullptr && blockIdx.x == 0 && threadIdx.x == 0) jobs.reset[0] = jobs.reset[1] = 0.f;
     int j = 0;
     while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.block0[j + 1]) ++j;
     const float* __restrict__ part = jobs.part[j];

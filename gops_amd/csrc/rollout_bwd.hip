@@ -679,6 +679,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
         const float mx = row16_max(fabsf(gv));
         if (tid == 0 && mx < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(p.gscale), __float_as_uint(mx));
     }
+    float dy_run = 0.f;   // SPLIT / SSB, thread 0: the largest |delta_y| of the tile's steps (-> gscale[1], below)
     float gc_ext = 0.f, gc_lin = 0.f, gc_int = 0.f;   // SURR: d(loss)/d(constraint sums) of trajectory tid
     if (CSTR && tid < nvalid && q.in.grad_constraint != nullptr) {
         const GLOBAL_AS float* gcp = gptr(q.in.grad_constraint) + b0 + tid;
@@ -1461,7 +1462,10 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
             if (tid < TB) {   // (the same 16 threads wrote s_gy above) -> this step's delta scale
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(s_gy + tid * 4);
                 const float mx = row16_max(fmaxf(fmaxf(fabsf(g4[0]), fabsf(g4[1])), fmaxf(fabsf(g4[2]), fabsf(g4[3]))));
-                if (tid == 0) split_delta_scale(mx, s_scale);
+                if (tid == 0) {
+                    split_delta_scale(mx, s_scale);
+                    dy_run = fmaxf(dy_run, mx);
+                }
             }
         }
         __syncthreads();
@@ -1517,6 +1521,13 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
     if constexpr (SSB && ssb_fuse_kind(ENV)) {
         if (q.out_part != nullptr && tile + (int)gridDim.x >= ntiles)
             ss_store_out_grad(og, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], q.out_part, q.out_part_b, tid);   // after the last tile
+    }
+    if constexpr ((SPLIT || SSB) && !F16) {
+        // The weight-gradient GEMMs scale the hidden deltas by a power of two before they split them into half planes.  max|grad_v|
+        // (gscale[0]) is a poor yardstick for that when the rollout amplifies adjoints over the horizon (H = 50, a half-trained
+        // policy: deltas 10^3 .. 10^4 x grad_v, saturated blocks, the exact redo doubled the GEMM's time - cfg4, round 5); the
+        // largest |delta_y| any step of the sweep saw is the right one: hidden deltas are within |W_o|, |W_j| row sums of it.
+        if (tid == 0 && p.gscale != nullptr && dy_run < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(p.gscale) + 1, __float_as_uint(dy_run));
     }
     if constexpr (SPLIT || SSB) {
         // A delta beyond the half range of the plane images (the per-step scale leaves 2^12 of headroom above max|delta_y|) made part of

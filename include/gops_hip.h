@@ -89,7 +89,7 @@ enum { GOPS_ACT_LINEAR = 0, GOPS_ACT_RELU = 1, GOPS_ACT_ELU = 2, GOPS_ACT_GELU =
  *                   each carried as two IEEE-half planes x s = hi + lo / 2^11 (22 significant bits, fp32 has 24; s a power of
  *                   two - per 16 output features for weights, 2^-4 for forward activations, from max|delta| in the sweep),
  *                   a w = hi hi + (lo hi + hi lo) / 2^11 on three v_mfma_f32_16x16x32_f16 with fp32 accumulation; the large
- *                   weight-gradient GEMMs likewise (deltas scaled by max|grad_v| of the call, saturated blocks redone exactly).
+ *                   weight-gradient GEMMs likewise (deltas scaled by the sweep's largest |delta_y|, saturated blocks redone exactly).
  *                   Forward range |activation| < 1.05e6: beyond it the launch's results are NaN (never silently wrong).
  *                   Measured distance to the reference on trained 256-wide networks 2e-6 .. 3e-5, at the level of the exact
  *                   fp32 kernels.  GOPS_VF_STREAMED_FP32 | GOPS_VF_DW_F32 in the descriptor's

@@ -519,6 +519,9 @@ def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, ch
         elapsed = t.item()
     kern = {k: hb.profile_read(k) for k in range(6)}
     hb.profile_reset()
+    # the networks after warmup + steps + profile updates on the fixed synthetic batch: still finite?  (outside the timed region; a
+    # half-range overflow of the plane-split kernels poisons gradients with NaN on purpose - it must not go unnoticed in a bench run)
+    finite = all(bool(torch.isfinite(p_).all()) for p_ in alg.networks.parameters())
     variant = 0
     for ro in list(getattr(alg, "_rollouts", {}).values()) + [o for o in getattr(alg, "_cache", {}).values() if hasattr(o, "desc")]:
         variant |= max(0, hb.lib().gops_rollout_variant(ro.desc))
@@ -529,7 +532,7 @@ def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, ch
     del alg, data
     torch.cuda.empty_cache()
     hb.DEFAULT_VARIANT_FLAGS = saved_flags
-    return {"elapsed": elapsed, "kern": kern, "variant": variant, "parity": parity, "allreduce_payload_bytes": payload}
+    return {"elapsed": elapsed, "kern": kern, "variant": variant, "parity": parity, "allreduce_payload_bytes": payload, "finite": finite}
 
 
 def record_of(workload, dtype, steps, warmup, world, m):
@@ -569,6 +572,7 @@ def record_of(workload, dtype, steps, warmup, world, m):
                                          "tflops": (flops[k] / (kern[k][0] * 1e-3) / 1e12) if kern[k][0] > 0 else 0.0}
                        for k in kern if kern[k][1] > 0},
         "kernel_variant": variant_label(m.get("variant", 0), dt),
+        "weights_finite_after_run": m.get("finite"),
         "host_sync_per_step": os.environ.get("GOPS_EAGER_LOG", "0") not in ("", "0"),
         "parity": m.get("parity"),
     }
@@ -676,7 +680,7 @@ def main():
             return {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "dtype": r["dtype"],
                     "roofline": {k: r["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_ms", "frac_vs_fp32_roof",
                                                                "products_per_mac", "mfma_issued") if k in r["roofline"]},
-                    "kernel_variant": r["kernel_variant"], "parity": r.get("parity"),
+                    "kernel_variant": r["kernel_variant"], "parity": r.get("parity"), "weights_finite_after_run": r.get("weights_finite_after_run"),
                     "kernels_ms": {k: v["avg_ms"] for k, v in r["kernels_ms"].items()}}
         k_steps, k_warm = min(args.steps, 20), min(args.warmup, 5)
         for name, dtype in ALL_WORKLOADS:

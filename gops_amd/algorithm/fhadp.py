@@ -8,6 +8,7 @@ autograd replay are ONE forward and ONE backward kernel sweep (gops_rollout_forw
 """
 __all__ = ["FHADP"]
 
+import os
 import time
 from typing import Tuple
 
@@ -68,7 +69,13 @@ class FHADP(AlgorithmBase):
         opt = self.networks.policy_optimizer
         self._precision_check(batch)
 
+        # the constrained variants bring their own gradient kernels; the plain ones fold loss mean and Adam step into the backward's
+        # last launch (ABI v12, gops_rollout_backward_update: two launches less per update)
+        fuse = type(self)._gradient_kernels is FHADP._gradient_kernels and os.environ.get("GOPS_FUSED_UPDATE", "1") != "0"   # (host-side A/B knob)
+
         def update(b):
+            if fuse:
+                return self._gradient_kernels(b, fused_opt=opt)
             loss = self._gradient_kernels(b)
             opt.step()
             return loss
@@ -192,9 +199,10 @@ class FHADP(AlgorithmBase):
                 self.networks.policy_optimizer.storage_signature(),
                 tuple(ro.workspace.data_ptr() for ro in self._rollouts.values()))
 
-    def _gradient_kernels(self, batch, phase=None):
+    def _gradient_kernels(self, batch, phase=None, fused_opt=None):
         """Enqueue forward rollout, backward sweep and the loss reduction; returns [-mean(v_pi), mean(v_pi)] (device tensor).  `phase`: None = all of it,
-        "a" = everything but the first hidden layer's weight gradient, "b" = that gradient (hip_backend.Rollout.backward)."""
+        "a" = everything but the first hidden layer's weight gradient, "b" = that gradient (hip_backend.Rollout.backward).
+        `fused_opt` (the policy's HipAdam, single-process update): loss mean and optimizer step ride on the backward's last launch."""
         B, device = batch["obs"].shape[0], batch["obs"].device
         ro = self._rollout_for(B, device)
         if phase == "b":
@@ -203,6 +211,17 @@ class FHADP(AlgorithmBase):
             return None
         v_pi = ro.forward(batch)["v_pi"]
         gw, gb = grad_buffers(self.networks.policy)
+        if fused_opt is not None:
+            fa = fused_opt.begin_fused()   # (p.grad of every parameter: grad_buffers' views into the flat buffer)
+            if fa is not None:
+                stats = self._loss_stats_slot(device)
+                ro.backward(self._grad_v(B, device), gw, gb, tail=hb.make_update_tail(fa, v_pi, -1.0, stats))
+                fused_opt.end_fused()
+                return stats.buf[:2]
+            ro.backward(self._grad_v(B, device), gw, gb)
+            out = self._mean_of(v_pi)
+            fused_opt.step()
+            return out
         ro.backward(self._grad_v(B, device), gw, gb, phase=phase)
         # loss = -mean(v_pi) (fhadp.py:121): ONE launch (gops_mean_loss) queued with every gradient - eager, captured or replayed -,
         # so that an update always contains the loss reduction the reference's `_compute_loss_policy` contains
@@ -210,15 +229,19 @@ class FHADP(AlgorithmBase):
 
     _LOSS_RING = 16
 
-    def _mean_of(self, v_pi):
-        """[-mean(v_pi), mean(v_pi)] on the device.  The result lands in one of a small ring of persistent buffers (no allocation, no
-        extra launch): a log entry (`LazyScalar`) read within `_LOSS_RING` updates of its own sees its own value."""
+    def _loss_stats_slot(self, device):
+        """The next of a small ring of persistent `LossStats` buffers (no allocation per update): a log entry (`LazyScalar`) read within
+        `_LOSS_RING` updates of its own sees its own value."""
         ring = self.__dict__.setdefault("_loss_ring", [])
-        if not ring or ring[0].buf.device != v_pi.device:
-            ring[:] = [hb.LossStats(v_pi.device) for _ in range(self._LOSS_RING)]
+        if not ring or ring[0].buf.device != device:
+            ring[:] = [hb.LossStats(device) for _ in range(self._LOSS_RING)]
             self._loss_slot = 0
         self._loss_slot = (self._loss_slot + 1) % len(ring)
-        return ring[self._loss_slot].mean_loss(v_pi, -1.0)
+        return ring[self._loss_slot]
+
+    def _mean_of(self, v_pi):
+        """[-mean(v_pi), mean(v_pi)] on the device (one `gops_mean_loss` launch into the ring's next buffer)."""
+        return self._loss_stats_slot(v_pi.device).mean_loss(v_pi, -1.0)
 
     def _after_gradient(self, out):
         """Host-side bookkeeping that belongs to ONE computed gradient (penalty / multiplier schedules of the

@@ -7,6 +7,7 @@ same quantity through policy, model and the target value's input), Adam + Polyak
 """
 __all__ = ["INFADP"]
 
+import os
 import time
 from copy import deepcopy
 from typing import Tuple
@@ -86,7 +87,15 @@ class INFADP(AlgorithmBase):
         opt = self.networks.optimizer_dict[mode]
         self._precision_check(mode, batch)
 
+        # PIM of the plain algorithm: loss mean and Adam step ride on the backward's last launch (ABI v12, gops_rollout_backward_update)
+        fuse = (mode == "policy" and type(self)._gradient_kernels is INFADP._gradient_kernels
+                and os.environ.get("GOPS_FUSED_UPDATE", "1") != "0")   # (host-side A/B knob)
+
         def update(b):
+            if fuse:
+                scalars, stepped = self._gradient_kernels(mode, b, fused_opt=opt)
+                self._update([mode], optimizer_stepped=stepped)
+                return scalars
             scalars = self._gradient_kernels(mode, b)
             self._update([mode])
             return scalars
@@ -127,10 +136,11 @@ class INFADP(AlgorithmBase):
         for net_name in names:   # a later local_update on this object must not inherit the 1/N
             self.networks.optimizer_dict[net_name].grad_scale = 1.0
 
-    def _update(self, update_list):
+    def _update(self, update_list, optimizer_stepped=False):
         tau = self.tau
         for net_name in update_list:
-            self.networks.optimizer_dict[net_name].step()
+            if not optimizer_stepped:   # (True: the step was part of the backward call, _gradient_kernels(fused_opt=))
+                self.networks.optimizer_dict[net_name].step()
         with torch.no_grad():
             for net_name in update_list:   # Polyak averaging (reference :124-133), all tensors of the network in one launch
                 online = list(self.networks.net_dict[net_name].parameters())
@@ -198,7 +208,7 @@ class INFADP(AlgorithmBase):
     def _mode(self, iteration) -> str:
         return "v" if iteration % (self.pev_step + self.pim_step) < self.pev_step else "policy"
 
-    def _gradient_kernels(self, mode: str, batch) -> torch.Tensor:
+    def _gradient_kernels(self, mode: str, batch, fused_opt=None) -> torch.Tensor:
         """Enqueue one policy-evaluation ("v") or policy-improvement ("policy") gradient; returns the
         device scalars the log needs ([loss_v, mean V] / [loss_policy]) without synchronising."""
         B, device = batch["obs"].shape[0], batch["obs"].device
@@ -217,6 +227,15 @@ class INFADP(AlgorithmBase):
         ro = self._rollout_for(B, device, need_grad=True)
         v_pi = ro.forward(batch)["v_pi"]
         gw, gb = grad_buffers(self.networks.policy)
+        if fused_opt is not None:   # -> (scalars, whether the optimizer step was part of the backward call)
+            fa = fused_opt.begin_fused()
+            stats = self._loss_stats("policy", device)
+            if fa is None:
+                ro.backward(self._grad_v(B, device), gw, gb)
+                return stats.mean_loss(v_pi, -1.0)[:1], False
+            ro.backward(self._grad_v(B, device), gw, gb, tail=hb.make_update_tail(fa, v_pi, -1.0, stats))
+            fused_opt.end_fused()
+            return stats.buf[:1], True
         ro.backward(self._grad_v(B, device), gw, gb)
         return self._loss_stats("policy", device).mean_loss(v_pi, -1.0)[:1]
 

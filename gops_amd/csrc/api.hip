@@ -381,7 +381,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
             }
         }
     }
-    p.gscale = c.take(4);   // max|grad_v| of a backward launch (f16 sweep scale; delta scale of the weight-gradient GEMM)
+    p.gscale = c.take(8);   // [4 ..]: the fused Adam step's scalar factors (adam_snapshot); [0 .. 1]: max|grad_v| / max|delta_y| of a backward launch (f16 sweep scale; delta scale of the weight-gradient GEMM)
     // stash rows: every tile stores all 16 rows of every step (tile-major order)
     const long long S = (long long)((p.B + tile_rows - 1) / tile_rows) * tile_rows * p.H;
     if (veh) p.ref_table = c.take((size_t)p.B * (e.pre_horizon + 1 + p.H) * 4);
@@ -499,7 +499,8 @@ int run_forward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const Gops
 
 int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const float* grad_v,
                  const GopsMlpGrad& grad, float* g_head_pre, void* ws, size_t ws_bytes, hipStream_t s,
-                 const float* ext_delta = nullptr, const GopsRolloutAdjoint* adj = nullptr, bool want_params = true) {
+                 const float* ext_delta = nullptr, const GopsRolloutAdjoint* adj = nullptr, bool want_params = true,
+                 const GopsUpdateTail* tail = nullptr) {
     if (!desc.need_grad || grad_v == nullptr) return GOPS_ERR_BAD_ARG;
     Plan plan;
     int rc = build_plan(desc, ws, plan);
@@ -516,6 +517,25 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     if (!p.open_loop && want_params)
         for (int j = 0; j < p.pol.nl - (ext_delta != nullptr ? 1 : 0); ++j)
             if (grad.weight[j] == nullptr || grad.bias[j] == nullptr) return GOPS_ERR_BAD_ARG;
+    if (tail != nullptr) {   // gops_rollout_backward_update: checked before anything is launched
+        if (p.open_loop || !want_params || ext_delta != nullptr || adj != nullptr) return GOPS_ERR_BAD_ARG;
+        if (desc.variant_flags & (GOPS_VF_BWD_PHASE_A | GOPS_VF_BWD_PHASE_B)) return GOPS_ERR_BAD_ARG;
+        if (tail->mean_x != nullptr && (tail->mean_stats == nullptr || tail->mean_n < 1)) return GOPS_ERR_BAD_ARG;
+        if (tail->adam != nullptr) {
+            const GopsAdamTensors& T = *tail->adam;
+            if (tail->adam_state == nullptr || T.n != 2 * p.pol.nl) return GOPS_ERR_BAD_ARG;
+            for (int j = 0; j < p.pol.nl; ++j) {   // every gradient tensor of the policy has its parameter / moments in the table
+                const long long nw = (long long)p.pol.dims[j + 1] * p.pol.dims[j], nb = p.pol.dims[j + 1];
+                int fw = -1, fb = -1;
+                for (int k = 0; k < T.n; ++k) {
+                    if (T.grad[k] == grad.weight[j] && T.numel[k] == nw) fw = k;
+                    if (T.grad[k] == grad.bias[j] && T.numel[k] == nb) fb = k;
+                }
+                if (fw < 0 || fb < 0 || !T.param[fw] || !T.exp_avg[fw] || !T.exp_avg_sq[fw] || !T.param[fb] || !T.exp_avg[fb] || !T.exp_avg_sq[fb])
+                    return GOPS_ERR_BAD_ARG;
+            }
+        }
+    }
     hipError_t e;
     if (desc.env.repeat_num > 1) p.ext = 1;   // ActionRepeatModel: the general (EXT) instantiations of the sweep
     if (adj != nullptr) {   // gops_rollout_backward_adj / gops_mlp_backward_x: the EXT kernels
@@ -563,6 +583,11 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     q.out_part = p.sp.out_part;
     q.out_part_b = p.sp.out_part_b;
     q.dbg = p.dbg;
+    if (tail != nullptr && tail->adam != nullptr) {   // the sweep's thread 0 advances the optimizer state and leaves this step's factors
+        q.ad_st = tail->adam_state;
+        q.ad_snap = p.gscale + 4;
+        q.ad_b1 = tail->beta1; q.ad_b2 = tail->beta2;
+    }
     const bool force_upload = (p.vflags & GOPS_VF_BWD_UPLOAD) != 0;   // measurement knob: the pre-patch launch sequence
     // GOPS_VF_BWD_PHASE_A / _B: the call is one half of a backward (see gops_hip.h); only_b skips the sweep
     const unsigned phase = p.vflags & (GOPS_VF_BWD_PHASE_A | GOPS_VF_BWD_PHASE_B);
@@ -639,6 +664,19 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     }
     // (two-phase backward: phase B's GEMM still reads the scale phase A's sweep left - the reset belongs to the LAST reduce of the call pair)
     if (!p.f16 && !only_a && jobs.n > 0) jobs.reset = p.gscale;
+    if (tail != nullptr) {   // the update's tail rides on the reduce: Adam per gradient element, the loss mean in one more block
+        if (tail->adam != nullptr) {
+            const GopsAdamTensors& T = *tail->adam;
+            for (int i = 0; i < jobs.n; ++i)
+                for (int k = 0; k < T.n; ++k)
+                    if (T.grad[k] == jobs.out[i]) { jobs.ad_p[i] = T.param[k]; jobs.ad_m[i] = T.exp_avg[k]; jobs.ad_v[i] = T.exp_avg_sq[k]; }
+            jobs.ad_snap = p.gscale + 4;
+            jobs.ad_b1 = tail->beta1; jobs.ad_b2 = tail->beta2; jobs.ad_eps = (float)tail->eps;
+        }
+        if (tail->mean_x != nullptr) {
+            jobs.mean_x = tail->mean_x; jobs.mean_n = tail->mean_n; jobs.mean_sc = (float)tail->mean_scale; jobs.mean_stats = tail->mean_stats;
+        }
+    }
     if ((e = launch_reduce(jobs, s)) != hipSuccess) return (int)e;
     if ((p.f16 || jobs.n == 0) && !only_a && (e = launch_fill_zero(p.gscale, 4, s)) != hipSuccess) return (int)e;
     return GOPS_OK;
@@ -836,6 +874,14 @@ int gops_rollout_backward(const GopsRolloutDesc* desc, const GopsRolloutIn* in, 
     if (!desc || !in || !policy_grad) return GOPS_ERR_BAD_ARG;
     return run_backward(*desc, *in, grad_v, *policy_grad, nullptr, workspace, workspace_bytes,
                         static_cast<hipStream_t>(stream));
+}
+
+int gops_rollout_backward_update(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const float* grad_v,
+                                 const GopsMlpGrad* policy_grad, const GopsUpdateTail* tail, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (!desc || !in || !policy_grad || !tail) return GOPS_ERR_BAD_ARG;
+    return run_backward(*desc, *in, grad_v, *policy_grad, nullptr, workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream), nullptr, nullptr, true, tail);
 }
 
 int gops_rollout_backward_adj(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const float* grad_v,

@@ -1550,9 +1550,58 @@ hipError_t launch_dw_out(const float* dy, const float* h, bool h_is_half, int K,
 // job of the table in ONE launch.  Block = 64 outputs x 4 split lanes; each lane sums every 4th split
 // with independent loads in flight, then the 4 lanes are combined through LDS (fixed order ->
 // deterministic).
+#define LOSS_BLOCKS 64
+#define LOSS_ONE_BLOCK_MAX 8192   // up to here ONE block forms the sums (<= 32 elements per thread, no partials / ticket round)
+// sum of (s0, s1) over the block in a fixed order: butterfly inside each wave, then the four waves in order; every thread returns the totals
+__device__ __forceinline__ void block_sum2(double& s0, double& s1, double (*red)[4]) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+    }
+    __syncthreads();   // (red may still be read by a previous call)
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    s0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+}
+// Sum of n values in double, one block, in batch_loss_kernel's single-block order (the two produce the same bits): mean_stats[0] =
+// sc * mean(x), mean_stats[1] = mean(x).
+__device__ __forceinline__ void mean_block(const float* __restrict__ a, int n, float sc, float* __restrict__ stats, double (*red2)[4]) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {
+        float av[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = i0 + q * 256;
+            av[q] = i < n ? a[i] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (i0 + q * 256 < n) { s0 += (double)av[q]; s1 += (double)av[q]; }
+    }
+    block_sum2(s0, s1, red2);
+    if (threadIdx.x == 0) {
+        stats[0] = (float)((double)sc * s0 / (double)n);
+        stats[1] = (float)(s1 / (double)n);
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs jobs) {
     __shared__ float red[4][64];
+    __shared__ double red2[2][4];
     if (jobs.reset != nullptr && blockIdx.x == 0 && threadIdx.x == 0) jobs.reset[0] = jobs.reset[1] = 0.f;
+    // fused Adam step (gops_rollout_backward_update): this step's scalar factors, left by the sweep kernel of the same call
+    // (common.h adam_snapshot: adam_kernel's, formed once instead of per block)
+    const bool adam = jobs.ad_snap != nullptr;
+    float step_size = 0.f, bc2_sqrt = 1.f, omb1 = 0.f, omb2 = 0.f, b2 = 0.f, gsc = 1.f;
+    if (adam) {
+        step_size = jobs.ad_snap[0]; bc2_sqrt = jobs.ad_snap[1]; gsc = jobs.ad_snap[2];
+        omb1 = (float)(1.0 - jobs.ad_b1); omb2 = (float)(1.0 - jobs.ad_b2); b2 = (float)jobs.ad_b2;
+    }
+    if ((int)blockIdx.x >= jobs.block0[jobs.n]) {   // the extra block: the loss mean
+        mean_block(jobs.mean_x, jobs.mean_n, jobs.mean_sc, jobs.mean_stats, red2);
+    } else {
     int j = 0;
     while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.block0[j + 1]) ++j;
     const float* __restrict__ part = jobs.part[j];
@@ -1560,6 +1609,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
     const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int idx = (blockIdx.x - jobs.block0[j]) * 64 + o;
     const bool valid = idx < rows * cols;
+    // the element's Adam operands travel with the partial sums (they are needed when the sums are)
+    float pm = 0.f, pv = 0.f, pp = 0.f;
+    const bool step_here = adam && jobs.ad_p[j] != nullptr && sl == 0 && valid;
+    if (step_here) { pm = jobs.ad_m[j][idx]; pv = jobs.ad_v[j][idx]; pp = jobs.ad_p[j][idx]; }
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     if (valid) {
         const int r = idx / cols, c = idx - r * cols;
@@ -1589,6 +1642,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
         float t = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
         if (jobs.unscale != nullptr) t *= 1.f / f16_grad_scale(*jobs.unscale);   // power of two: exact
         jobs.out[j][idx] = t;
+        if (step_here) {   // adam_kernel's arithmetic, operation for operation
+            const float gi = t * gsc;
+            const float mi = pm + (gi - pm) * omb1;
+            const float vi = pv * b2 + omb2 * gi * gi;
+            jobs.ad_m[j][idx] = mi;
+            jobs.ad_v[j][idx] = vi;
+            jobs.ad_p[j][idx] = pp - step_size * (mi / (sqrtf(vi) / bc2_sqrt + jobs.ad_eps));
+        }
+    }
     }
 }
 
@@ -1601,10 +1663,16 @@ void reduce_jobs_add(ReduceJobs& jobs, const float* part, int splits, int rows, 
     jobs.block0[i + 1] = jobs.block0[i] + (rows * cols + 63) / 64;
 }
 
-hipError_t launch_reduce(const ReduceJobs& jobs, hipStream_t s) {
-    if (jobs.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(jobs.block0[jobs.n]), dim3(256), 0, s, jobs);
-    return hipGetLastError();
+hipError_t launch_batch_loss(const float* a, const float* b, int n, float gsc, float sc0, float* grad, float* stats, hipStream_t s);
+hipError_t launch_reduce(const ReduceJobs& jobs_in, hipStream_t s) {
+    if (jobs_in.n == 0) return hipSuccess;
+    ReduceJobs jobs = jobs_in;
+    const bool own_mean = jobs.mean_x != nullptr && jobs.mean_n > LOSS_ONE_BLOCK_MAX;   // too long for one block: its own launch
+    if (own_mean) jobs.mean_x = nullptr;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(jobs.block0[jobs.n] + (jobs.mean_x != nullptr ? 1 : 0)), dim3(256), 0, s, jobs);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && own_mean) e = launch_batch_loss(jobs_in.mean_x, nullptr, jobs_in.mean_n, 0.f, jobs_in.mean_sc, nullptr, jobs_in.mean_stats, s);
+    return e;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1754,21 +1822,6 @@ hipError_t launch_polyak(const GopsAdamTensors& T, float omt, float tau, hipStre
 // stats[1] <- sum(a) / n.  Blocks add up their elements in double in a fixed order and park the partial sums behind the two results
 // (stats[2 ..]: GOPS_LOSS_STATS_FLOATS floats in all, the last one a ticket that must be zero on entry and is left zero); the last block to
 // finish adds the partials in block order - deterministic.
-#define LOSS_BLOCKS 64
-#define LOSS_ONE_BLOCK_MAX 8192   // up to here ONE block forms the sums (<= 32 elements per thread, no partials / ticket round)
-// sum of (s0, s1) over the block in a fixed order: butterfly inside each wave, then the four waves in order; every thread returns the totals
-__device__ __forceinline__ void block_sum2(double& s0, double& s1, double (*red)[4]) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s0 += __shfl_xor(s0, o);
-        s1 += __shfl_xor(s1, o);
-    }
-    __syncthreads();   // (red may still be read by a previous call)
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
-    __syncthreads();
-    s0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    s1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-}
 __global__ __launch_bounds__(256) void batch_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float gsc, float sc0,
                                                          float* __restrict__ grad, float* __restrict__ stats) {
     __shared__ double red[2][4];

@@ -218,7 +218,24 @@ struct BwdPatch {
     float* out_part;
     float* out_part_b;
     unsigned long long* dbg;
+    // gops_rollout_backward_update: the Adam step that rides on this call's reduce launch.  ONE thread of the sweep advances the
+    // device-resident optimizer state and leaves the step's scalar factors in `ad_snap` (adam_snapshot below) - the ~1500 blocks of
+    // the reduce then read three floats instead of each taking a ticket on the state (1500 atomics on one address: 15 us, measured)
+    GopsAdamState* ad_st;
+    float* ad_snap;
+    double ad_b1, ad_b2;
 };
+// adam_kernel's scalar factors of THIS step (formed in double like torch's host code, rounded to fp32) -> snap[0 .. 2] = step_size,
+// sqrt(1 - beta2^t), grad_scale; the state moves on to the next step
+__device__ __forceinline__ void adam_snapshot(GopsAdamState* st, float* snap, double beta1, double beta2) {
+    const double b1p = st->beta1_pow * beta1, b2p = st->beta2_pow * beta2;   // beta^t, t = step + 1
+    snap[0] = (float)(st->lr / (1.0 - b1p));
+    snap[1] = (float)sqrt(1.0 - b2p);
+    snap[2] = (float)st->grad_scale;
+    st->step += 1;
+    st->beta1_pow = b1p;
+    st->beta2_pow = b2p;
+}
 
 // upload_params_kernel / prologue_kernel take the block BY VALUE: it has to fit the 4 KiB kernel-argument segment
 static_assert(sizeof(RolloutParams) <= 4000, "RolloutParams outgrew the kernel-argument segment (move gpow[] out)");
@@ -266,6 +283,18 @@ struct ReduceJobs {
     const float* unscale;                  // f16: device pointer to max|grad_v| (RolloutParams::gscale), else null
     float* reset;                          // fp32 launches: RolloutParams::gscale, zeroed here for the NEXT backward call (nothing in this
                                            // kernel reads it, and every consumer of this call - sweep, weight-gradient GEMMs - is done)
+    // gops_rollout_backward_update (ABI v12): the Adam step on every gradient element as this kernel forms it, and the loss mean
+    // in one extra block (block0[n])
+    float* ad_p[2 * GOPS_MAX_LAYERS];      // parameter / first / second moment tensor behind out[j] (null: no step for job j)
+    float* ad_m[2 * GOPS_MAX_LAYERS];
+    float* ad_v[2 * GOPS_MAX_LAYERS];
+    const float* ad_snap;                  // this step's scalar factors (adam_snapshot, written by the sweep kernel of the same call); null: no optimizer step
+    double ad_b1, ad_b2;
+    float ad_eps;
+    int mean_n;
+    const float* mean_x;                   // null: no loss mean
+    float* mean_stats;
+    float mean_sc;
 };
 
 // GOPS_DTYPE_F16 backward: the power of two s that brings max|grad_v| = m into [1, 2).  The whole sweep runs

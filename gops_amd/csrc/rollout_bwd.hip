@@ -1542,6 +1542,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
     }
     } while ((SPLIT || SSB) && MULTI && (tile += gridDim.x) < ntiles);   // (every step ends with a barrier: the next tile's set-up may overwrite G / s_ref)
     dbg.dump(q.dbg);
+    if (q.ad_st != nullptr && blockIdx.x == 0 && threadIdx.x == 0) adam_snapshot(q.ad_st, q.ad_snap, q.ad_b1, q.ad_b2);   // (gops_rollout_backward_update)
 }
 
 // ref_points: reference-table points per trajectory (veh3dofconti), 30 (= 5 x 24 / 4) for the

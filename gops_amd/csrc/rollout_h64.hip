@@ -596,6 +596,7 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
         DBG_TICK(9)
     }
     dbg.dump(q.dbg);
+    if (q.ad_st != nullptr && blockIdx.x == 0 && threadIdx.x == 0) adam_snapshot(q.ad_st, q.ad_snap, q.ad_b1, q.ad_b2);   // (gops_rollout_backward_update)
 }
 
 hipError_t launch_rollout_fwd_h64(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {

@@ -112,6 +112,12 @@ class GopsAdamTensors(C.Structure):
                 ("exp_avg", C.c_void_p * ADAM_MAX), ("exp_avg_sq", C.c_void_p * ADAM_MAX)]
 
 
+class GopsUpdateTail(C.Structure):   # ABI v12: gops_rollout_backward_update
+    _fields_ = [("adam", C.POINTER(GopsAdamTensors)), ("adam_state", C.c_void_p), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("eps", C.c_double), ("mean_x", C.c_void_p), ("mean_n", C.c_int32), ("reserved", C.c_int32),
+                ("mean_scale", C.c_double), ("mean_stats", C.c_void_p)]
+
+
 class GopsStepIO(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "action", "done", "state", "ref_points", "path_num",
                                           "u_num", "ref_time", "next_obs", "reward", "next_done",
@@ -143,6 +149,9 @@ def lib() -> C.CDLL:
         l.gops_rollout_backward.restype = C.c_int
         l.gops_rollout_backward.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn), C.c_void_p,
                                             C.POINTER(GopsMlpGrad), C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gops_rollout_backward_update.restype = C.c_int
+        l.gops_rollout_backward_update.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn), C.c_void_p,
+                                                   C.POINTER(GopsMlpGrad), C.POINTER(GopsUpdateTail), C.c_void_p, C.c_size_t, C.c_void_p]
         l.gops_rollout_backward_adj.restype = C.c_int
         l.gops_rollout_backward_adj.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn), C.c_void_p,
                                                 C.POINTER(GopsMlpGrad), C.POINTER(GopsRolloutAdjoint), C.c_void_p,
@@ -196,7 +205,7 @@ EXPORTED_SYMBOLS = ("gops_hip_version", "gops_rollout_workspace_bytes", "gops_ro
                     "gops_value_forward", "gops_value_backward", "gops_mlp_workspace_bytes", "gops_mlp_forward",
                     "gops_mlp_backward", "gops_mlp_backward_x", "gops_adam_step", "gops_profile_enable",
                     "gops_profile_reset", "gops_profile_read", "gops_rollout_variant", "gops_rollout_backward_open_loop_adj",
-                    "gops_env_constraint", "gops_polyak_update", "gops_value_loss", "gops_mean_loss")
+                    "gops_env_constraint", "gops_polyak_update", "gops_value_loss", "gops_mean_loss", "gops_rollout_backward_update")
 
 _ERR = {-1: "GOPS_ERR_BAD_ARG", -2: "GOPS_ERR_UNSUPPORTED", -3: "GOPS_ERR_WORKSPACE"}
 
@@ -445,13 +454,18 @@ class Rollout:
 
     def backward(self, grad_v: torch.Tensor, grad_w: List[torch.Tensor], grad_b: List[torch.Tensor],
                  grad_constraint: Optional[torch.Tensor] = None, grad_constraint_prod: Optional[torch.Tensor] = None,
-                 grad_constraint_step: Optional[torch.Tensor] = None, phase: Optional[str] = None):
+                 grad_constraint_step: Optional[torch.Tensor] = None, phase: Optional[str] = None,
+                 tail: Optional["GopsUpdateTail"] = None):
         """`grad_constraint` (models with constraint outputs): d(loss)/d(constraint_sums rows 0..2), [3, B];
         `grad_constraint_prod`: d(loss)/d(P_k) * P_k for the Phi-products P_k = constraint_prods[k], [n_constraint, B];
         `grad_constraint_step`: d(loss)/d(per-step constraint values), [H, B, n_constraint].
         `phase`: None = the whole backward; "a" = sweep + every gradient except the first hidden layer's, "b" (after "a", same
         arguments) = the first hidden layer's (GOPS_VF_BWD_PHASE_A / _B): lets a data-parallel trainer start the all-reduce of the
-        gradients that are ready first while the rest is being formed."""
+        gradients that are ready first while the rest is being formed.
+        `tail` (ABI v12, `gops_rollout_backward_update`; not with `phase`): the Adam step and / or the loss mean of a single-process
+        update, folded into the launch that forms the final gradients (`HipAdam.begin_fused`, `make_update_tail`)."""
+        if tail is not None and phase is not None:
+            raise ValueError("Rollout.backward: an update tail cannot ride on half a backward (phase)")
         if phase == "b":
             # phase B reuses the inputs (and the delta stash) phase A left in this workspace: it must follow one, directly
             if getattr(self, "_last_phase", None) != "a":
@@ -464,15 +478,20 @@ class Rollout:
         self._in.grad_constraint_prod = _ptr(grad_constraint_prod)
         self._in.grad_constraint_step = _ptr(grad_constraint_step)
         self._grad_c = (grad_constraint, grad_constraint_prod, grad_constraint_step)
-        self._backward_call(grad_v, g, VF_BWD_PHASE_A if phase == "a" else 0)
+        self._backward_call(grad_v, g, VF_BWD_PHASE_A if phase == "a" else 0, tail)
 
-    def _backward_call(self, grad_v, g, phase_bits):
+    def _backward_call(self, grad_v, g, phase_bits, tail=None):
         flags = self.desc.variant_flags
         self.desc.variant_flags = flags | phase_bits
         try:
-            check(lib().gops_rollout_backward(C.byref(self.desc), C.byref(self._in), _ptr(grad_v), C.byref(g),
-                                              self.workspace.data_ptr(), self.workspace.numel(), _stream()),
-                  "gops_rollout_backward")
+            if tail is not None:
+                check(lib().gops_rollout_backward_update(C.byref(self.desc), C.byref(self._in), _ptr(grad_v), C.byref(g), C.byref(tail),
+                                                         self.workspace.data_ptr(), self.workspace.numel(), _stream()),
+                      "gops_rollout_backward_update")
+            else:
+                check(lib().gops_rollout_backward(C.byref(self.desc), C.byref(self._in), _ptr(grad_v), C.byref(g),
+                                                  self.workspace.data_ptr(), self.workspace.numel(), _stream()),
+                      "gops_rollout_backward")
         finally:
             self.desc.variant_flags = flags
 
@@ -729,6 +748,39 @@ class HipAdam(torch.optim.Optimizer):
             if gi in self._dev and self._dev[gi]["step"] is not None:
                 self._dev[gi]["step"] += n
 
+    def begin_fused(self):
+        """The table / device state / hyper-parameters of THIS step for a caller that folds it into another launch
+        (`gops_rollout_backward_update`): `(GopsAdamTensors, state pointer, beta1, beta2, eps, keep-alive)` - or None when the
+        optimizer is not one group whose parameters fit one table (the caller then calls `step()` as usual).  Exactly the
+        preparation `step()` does; the caller reports the enqueued launch with `end_fused()`."""
+        if len(self.param_groups) != 1:
+            return None
+        group = self.param_groups[0]
+        ps, dev = self._prepare(0, group)
+        if ps is None or len(ps) > ADAM_MAX or len(ps) != len(group["params"]):
+            return None
+        t = GopsAdamTensors()
+        t.n = len(ps)
+        keep = []
+        for i, p in enumerate(ps):
+            st = self.state[p]
+            if not p.grad.is_contiguous():
+                return None
+            keep.append(p.grad)
+            t.numel[i], t.param[i], t.grad[i] = p.numel(), _ptr(p.data), _ptr(p.grad)
+            t.exp_avg[i], t.exp_avg_sq[i] = _ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"])
+        b1, b2 = group["betas"]
+        self._fused = (ps, dev)
+        return t, dev["state"][0].data_ptr(), float(b1), float(b2), float(group["eps"]), keep
+
+    def end_fused(self):
+        """Host-side step bookkeeping of the launch `begin_fused` prepared (what `step()` does after its launch)."""
+        ps, dev = self._fused
+        self._fused = None
+        for p in ps:
+            self.state[p]["step"] = int(self.state[p]["step"]) + 1
+        dev["step"] += 1
+
     @torch.no_grad()
     def step(self, closure=None):
         for gi, group in enumerate(self.param_groups):
@@ -774,6 +826,25 @@ class LossStats:
         """-> [scale * mean(x), mean(x)] (`-v_pi.mean()`: infadp.py:213, fhadp.py:123)."""
         check(lib().gops_mean_loss(_ptr(x), x.numel(), float(scale), self.buf.data_ptr(), _stream()), "gops_mean_loss")
         return self.buf[:2]
+
+
+def make_update_tail(fused_adam=None, mean_of: Optional[torch.Tensor] = None, mean_scale: float = -1.0,
+                     stats: Optional["LossStats"] = None) -> "GopsUpdateTail":
+    """`GopsUpdateTail` for `Rollout.backward(..., tail=)`: `fused_adam` = what `HipAdam.begin_fused()` returned (or None),
+    `mean_of` / `stats`: the values whose mean lands in `stats.buf[:2]` as `gops_mean_loss` would leave it.  The returned struct keeps
+    the tensors it points to alive."""
+    t = GopsUpdateTail()
+    keep = []
+    if fused_adam is not None:
+        table, state_ptr, b1, b2, eps, kp = fused_adam
+        t.adam = C.pointer(table)
+        t.adam_state, t.beta1, t.beta2, t.eps = state_ptr, b1, b2, eps
+        keep += [table, kp]
+    if mean_of is not None:
+        t.mean_x, t.mean_n, t.mean_scale, t.mean_stats = _ptr(mean_of), mean_of.numel(), float(mean_scale), stats.buf.data_ptr()
+        keep += [mean_of, stats]
+    t._keep = keep
+    return t
 
 
 class PolyakUpdater:

@@ -45,7 +45,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GOPS_HIP_ABI_VERSION 11
+#define GOPS_HIP_ABI_VERSION 12
 
 #define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
 #define GOPS_MAX_ACT 4      /* action dimensions */
@@ -415,6 +415,28 @@ typedef struct GopsAdamState {   /* 48 bytes of device memory */
 } GopsAdamState;
 int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, double beta1, double beta2,
                    double eps, void* stream);
+
+/* ABI v12.  A single-process update - compute_gradient, then optimizer.step() (gops/algorithm/fhadp.py:87-90, infadp.py:101-104) - in
+ * ONE call: gops_rollout_backward with what follows it folded into its last kernel, the split-K reduce that forms the final
+ * gradients: the Adam step of gops_adam_step on every gradient element as it is formed (`adam`), and the loss mean of
+ * gops_mean_loss in one more block of the same launch (`mean_x`; more than 8192 values: its own launch, still inside this call).
+ * Element for element the arithmetic of the three separate calls (tests: bit-equal weights, moments and loss scalars); two
+ * launches and their gaps less per update.  The gradients are written to policy_grad as well.  Not with GOPS_VF_BWD_PHASE_A / _B
+ * (a data-parallel update all-reduces between gradient and optimizer step) and not for open-loop rollouts. */
+typedef struct GopsUpdateTail {
+    const GopsAdamTensors* adam;   /* NULL: no optimizer step.  grad[i] must be one of policy_grad's tensors with numel[i] its element
+                                    * count, and EVERY tensor of policy_grad must appear (a parameter without its step is a bug) */
+    GopsAdamState* adam_state;     /* device memory, as for gops_adam_step */
+    double beta1, beta2, eps;
+    const float* mean_x;           /* NULL: no loss mean; else mean_n device values (the forward's v_pi) */
+    int32_t mean_n;
+    int32_t reserved;
+    double mean_scale;             /* mean_stats[0] = mean_scale * mean(x), mean_stats[1] = mean(x) */
+    float* mean_stats;             /* GOPS_LOSS_STATS_FLOATS floats, as for gops_mean_loss */
+} GopsUpdateTail;
+int gops_rollout_backward_update(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const float* grad_v,
+                                 const GopsMlpGrad* policy_grad, const GopsUpdateTail* tail,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ABI v11.  Polyak averaging of a target network, every tensor in one launch - replaces the two passes of
  * gops/algorithm/infadp.py:124-133 (`p_targ.mul_(1 - tau); p_targ.add_(tau * p)`), same roundings per element.

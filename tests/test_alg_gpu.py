@@ -10,6 +10,7 @@ from helpers import data_from_golden
 from gops_amd import hip_backend as hb
 from gops_amd.create_pkg.create_alg import create_alg
 from gops_amd.utils.synthetic import act_dim_of, make_batch, obs_dim_of
+from gops_amd.utils.tensorboard_setup import tb_tags
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -1052,3 +1053,107 @@ def test_loss_scalars_and_polyak_update_match_torch():
     pk.step(tau)
     for t, w in zip(target, want):
         assert torch.allclose(t, w, rtol=0, atol=1.2e-7 * float(w.abs().max()))   # (torch may fuse alpha * x + y into one fma)
+
+
+def test_fused_update_tail_equals_separate_calls(monkeypatch):
+    """ABI v12, `gops_rollout_backward_update`: loss mean + Adam step folded into the backward's last launch against the three separate
+    calls (`gops_rollout_backward`, `gops_mean_loss`, `gops_adam_step`) - the same arithmetic element for element, so weights, Adam
+    moments, step counts and the logged loss scalars are BIT-equal after several updates.  Shapes: a 64-wide net (exact fp32 kernels),
+    the 256-wide plane-split kernels, and a batch beyond one block's loss-mean limit (8192: the mean then takes its own launch inside the
+    same call)."""
+    from gops_amd import hip_backend as hb
+    from gops_amd.utils.synthetic import make_batch
+    dev = torch.device("cuda", 0)
+    cases = [dict(alg="FHADP", env_id="pyth_idpendulum", batch=96, horizon=8, hidden=(64, 64), act="gelu", gamma=0.99),
+             dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=200, horizon=6, pre_horizon=10, hidden=(256, 256), act="elu", gamma=1.0),
+             dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=8192 + 40, horizon=3, hidden=(256, 256), act="relu", gamma=0.99)]
+    for cfg in cases:
+        def make():
+            torch.manual_seed(7)
+            alg = create_alg(**_kwargs(cfg, {}, 7), precision_check_interval=0)
+            alg.networks.to(dev)
+            return alg
+        fused, plain = make(), make()
+        monkeypatch.setattr(plain.networks.policy_optimizer, "begin_fused", lambda: None)   # -> backward, mean_loss, step() as three calls
+        calls = []
+        real = hb.lib().gops_rollout_backward_update
+        for it in range(4):
+            data = {k: v.to(dev) for k, v in make_batch(cfg, 40 + it).items()}
+            tb_f = fused.local_update(data, it)
+            tb_p = plain.local_update(data, it)
+            assert float(tb_f[tb_tags["loss_actor"]]) == float(tb_p[tb_tags["loss_actor"]])
+        torch.cuda.synchronize()
+        assert fused.networks.policy_optimizer._fused is None and not hasattr(plain.networks.policy_optimizer, "_fused")
+        for (name, a), b in zip(fused.networks.policy.named_parameters(), plain.networks.policy.parameters()):
+            assert torch.equal(a, b), (cfg["env_id"], name)
+            assert torch.equal(a.grad, b.grad), (cfg["env_id"], name)
+            sa, sb = fused.networks.policy_optimizer.state[a], plain.networks.policy_optimizer.state[b]
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]) and int(sa["step"]) == int(sb["step"]) == 4
+        # the device-resident step count / beta powers advanced alike
+        df, dp = fused.networks.policy_optimizer._dev[0]["state"][0], plain.networks.policy_optimizer._dev[0]["state"][0]
+        assert torch.equal(df, dp)
+        moved = max((a - b).abs().max().item() for a, b in zip(make().networks.policy.parameters(), fused.networks.policy.parameters()))
+        assert moved > 1e-4   # (the updates did move the weights)
+
+
+def test_update_tail_is_refused_where_it_does_not_belong():
+    """`GopsUpdateTail`: an Adam table that does not cover the policy's gradient tensors, or a tail on half a backward, is an error
+    before anything is launched - never a silently skipped optimizer step."""
+    from gops_amd import hip_backend as hb
+    from gops_amd.utils.synthetic import make_batch
+    dev = torch.device("cuda", 0)
+    cfg = dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=64, horizon=3, hidden=(64, 64), act="elu", gamma=0.99)
+    torch.manual_seed(3)
+    alg = create_alg(**_kwargs(cfg, {}, 3), precision_check_interval=0)
+    alg.networks.to(dev)
+    data = {k: v.to(dev) for k, v in make_batch(cfg, 9).items()}
+    alg.local_update(data, 0)   # (allocates gradients, optimizer state, workspace)
+    opt = alg.networks.policy_optimizer
+    before = [p.detach().clone() for p in alg.networks.policy.parameters()]
+    ro = alg._rollout_for(64, dev)
+    batch = alg._device_batch(data)
+    v_pi = ro.forward(batch)["v_pi"]
+    from gops_amd.algorithm.base import grad_buffers
+    gw, gb = grad_buffers(alg.networks.policy)
+    fa = opt.begin_fused()
+    table = fa[0]
+    table.n -= 1                                  # one tensor short
+    with pytest.raises(RuntimeError, match="gops_rollout_backward_update"):
+        ro.backward(alg._grad_v(64, dev), gw, gb, tail=hb.make_update_tail(fa, v_pi, -1.0, hb.LossStats(dev)))
+    table.n += 1
+    with pytest.raises(ValueError):
+        ro.backward(alg._grad_v(64, dev), gw, gb, phase="a", tail=hb.make_update_tail(fa, v_pi, -1.0, hb.LossStats(dev)))
+    opt._fused = None
+    torch.cuda.synchronize()
+    for a, b in zip(alg.networks.policy.parameters(), before):
+        assert torch.equal(a, b)                  # nothing stepped
+
+
+def test_fused_update_tail_infadp_pim(monkeypatch):
+    """The same for INFADP's policy-improvement updates (the policy's backward carries loss mean + Adam; policy evaluation and the
+    Polyak steps are untouched): bit-equal networks, targets and optimizer state after alternating PEV / PIM updates."""
+    dev = torch.device("cuda", 0)
+    cfg = dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=300, horizon=5, hidden=(256, 256), act="gelu", gamma=0.99)
+
+    def make():
+        torch.manual_seed(5)
+        alg = create_alg(**_kwargs(cfg, {}, 5), precision_check_interval=0)
+        alg.forward_step, alg.gamma = cfg["horizon"], cfg["gamma"]
+        alg.networks.to(dev)
+        return alg
+    fused, plain = make(), make()
+    monkeypatch.setenv("GOPS_HIP_GRAPH", "0")
+    monkeypatch.setattr(plain.networks.optimizer_dict["policy"], "begin_fused", lambda: None)
+    for it in range(6):
+        data = {k: v.to(dev) for k, v in make_batch(cfg, 70 + it).items()}
+        tf, tp = fused.local_update(data, it), plain.local_update(data, it)
+        for k in tf:
+            if k != tb_tags["alg_time"]:
+                assert float(tf[k]) == float(tp[k]), k
+    torch.cuda.synchronize()
+    for (name, a), b in zip(fused.networks.named_parameters(), plain.networks.parameters()):
+        assert torch.equal(a, b), name
+    for net in ("policy", "v"):
+        of, op = fused.networks.optimizer_dict[net], plain.networks.optimizer_dict[net]
+        for a, b in zip(fused.networks.net_dict[net].parameters(), plain.networks.net_dict[net].parameters()):
+            assert torch.equal(of.state[a]["exp_avg"], op.state[b]["exp_avg"]) and int(of.state[a]["step"]) == int(op.state[b]["step"]) == 3

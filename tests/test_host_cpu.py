@@ -65,7 +65,7 @@ def test_ctypes_mirror_matches_the_header_layout(tmp_path):
     from gops_amd import hip_backend as hb
     pairs = {"GopsMlp": hb.GopsMlp, "GopsMlpGrad": hb.GopsMlpGrad, "GopsEnv": hb.GopsEnv, "GopsRolloutDesc": hb.GopsRolloutDesc,
              "GopsRolloutIn": hb.GopsRolloutIn, "GopsRolloutOut": hb.GopsRolloutOut, "GopsRolloutAdjoint": hb.GopsRolloutAdjoint,
-             "GopsStepIO": hb.GopsStepIO, "GopsAdamTensors": hb.GopsAdamTensors}
+             "GopsStepIO": hb.GopsStepIO, "GopsAdamTensors": hb.GopsAdamTensors, "GopsUpdateTail": hb.GopsUpdateTail}
     header = open(os.path.join(ROOT, "include", "gops_hip.h")).read()
     declared = set(re.findall(r"typedef struct (Gops[A-Za-z]+) \{", header))
     assert declared - {"GopsAdamState"} == set(pairs), "a struct of the header has no ctypes mirror (or the reverse)"

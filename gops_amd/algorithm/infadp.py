@@ -87,14 +87,15 @@ class INFADP(AlgorithmBase):
         opt = self.networks.optimizer_dict[mode]
         self._precision_check(mode, batch)
 
-        # PIM of the plain algorithm: loss mean and Adam step ride on the backward's last launch (ABI v12, gops_rollout_backward_update)
-        fuse = (mode == "policy" and type(self)._gradient_kernels is INFADP._gradient_kernels
+        # The plain algorithm: Adam step, Polyak step of the target (and, for PIM, the loss mean) ride on the backward's last launch
+        # (ABI v12, gops_rollout_backward_update / gops_value_backward_update)
+        fuse = (type(self)._gradient_kernels is INFADP._gradient_kernels and type(self)._update is INFADP._update
                 and os.environ.get("GOPS_FUSED_UPDATE", "1") != "0")   # (host-side A/B knob)
 
         def update(b):
             if fuse:
                 scalars, stepped = self._gradient_kernels(mode, b, fused_opt=opt)
-                self._update([mode], optimizer_stepped=stepped)
+                self._update([mode], optimizer_stepped=stepped)   # (stepped: Adam AND Polyak were part of the backward call)
                 return scalars
             scalars = self._gradient_kernels(mode, b)
             self._update([mode])
@@ -138,9 +139,10 @@ class INFADP(AlgorithmBase):
 
     def _update(self, update_list, optimizer_stepped=False):
         tau = self.tau
+        if optimizer_stepped:   # Adam and Polyak step were part of the backward call (_gradient_kernels(fused_opt=))
+            return
         for net_name in update_list:
-            if not optimizer_stepped:   # (True: the step was part of the backward call, _gradient_kernels(fused_opt=))
-                self.networks.optimizer_dict[net_name].step()
+            self.networks.optimizer_dict[net_name].step()
         with torch.no_grad():
             for net_name in update_list:   # Polyak averaging (reference :124-133), all tensors of the network in one launch
                 online = list(self.networks.net_dict[net_name].parameters())
@@ -221,23 +223,44 @@ class INFADP(AlgorithmBase):
             gdiff = self._scratch("gdiff", B, device)
             scalars = self._loss_stats("v", device).value_loss(v, backup, gdiff)
             gw, gb = grad_buffers(self.networks.v)
+            if fused_opt is not None:   # -> (scalars, whether Adam + Polyak were part of the backward call)
+                fa, pk = self._fused_parts("v", fused_opt)
+                if fa is None:
+                    vn.backward(batch["obs"], gdiff, gw, gb)
+                    return scalars, False
+                vn.backward(batch["obs"], gdiff, gw, gb, tail=hb.make_update_tail(fa, polyak=pk, tau=self.tau))
+                fused_opt.end_fused()
+                return scalars, True
             vn.backward(batch["obs"], gdiff, gw, gb)
             return scalars
         # PIM: loss = -mean(sum_t gamma^t r_t + (~d) gamma^n V_target(o_n)), grads into the policy
         ro = self._rollout_for(B, device, need_grad=True)
         v_pi = ro.forward(batch)["v_pi"]
         gw, gb = grad_buffers(self.networks.policy)
-        if fused_opt is not None:   # -> (scalars, whether the optimizer step was part of the backward call)
-            fa = fused_opt.begin_fused()
+        if fused_opt is not None:   # -> (scalars, whether Adam + Polyak were part of the backward call)
+            fa, pk = self._fused_parts("policy", fused_opt)
             stats = self._loss_stats("policy", device)
             if fa is None:
                 ro.backward(self._grad_v(B, device), gw, gb)
                 return stats.mean_loss(v_pi, -1.0)[:1], False
-            ro.backward(self._grad_v(B, device), gw, gb, tail=hb.make_update_tail(fa, v_pi, -1.0, stats))
+            ro.backward(self._grad_v(B, device), gw, gb, tail=hb.make_update_tail(fa, v_pi, -1.0, stats, polyak=pk, tau=self.tau))
             fused_opt.end_fused()
             return stats.buf[:1], True
         ro.backward(self._grad_v(B, device), gw, gb)
         return self._loss_stats("policy", device).mean_loss(v_pi, -1.0)[:1]
+
+    def _fused_parts(self, net_name, opt):
+        """(what `HipAdam.begin_fused` returns, the network's one-table PolyakUpdater) for a backward call that carries the update's
+        tail - or (None, None) when optimizer or target averaging do not fit one table each (the separate launches then)."""
+        online = list(self.networks.net_dict[net_name].parameters())
+        target = list(self.networks.target_net_dict[net_name].parameters())
+        pk = self._polyak.get(net_name)
+        if pk is None or not pk.matches(target, online):
+            pk = self._polyak[net_name] = hb.PolyakUpdater(target, online)
+        if len(pk.tables) != 1:
+            return None, None
+        fa = opt.begin_fused()
+        return (fa, pk) if fa is not None else (None, None)
 
     def _scratch(self, name, n, device):
         t = self._bufs.get(name)

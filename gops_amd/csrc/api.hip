@@ -535,6 +535,15 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
                     return GOPS_ERR_BAD_ARG;
             }
         }
+        if (tail->polyak != nullptr) {   // every online tensor of the averaging table is a parameter this call steps
+            if (tail->adam == nullptr || tail->polyak->n != tail->adam->n) return GOPS_ERR_BAD_ARG;
+            for (int k = 0; k < tail->polyak->n; ++k) {
+                bool found = false;
+                for (int i = 0; i < tail->adam->n; ++i)
+                    found = found || (tail->polyak->grad[k] == tail->adam->param[i] && tail->polyak->numel[k] == tail->adam->numel[i]);
+                if (!found || tail->polyak->param[k] == nullptr) return GOPS_ERR_BAD_ARG;
+            }
+        }
     }
     hipError_t e;
     if (desc.env.repeat_num > 1) p.ext = 1;   // ActionRepeatModel: the general (EXT) instantiations of the sweep
@@ -672,6 +681,13 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
                     if (T.grad[k] == jobs.out[i]) { jobs.ad_p[i] = T.param[k]; jobs.ad_m[i] = T.exp_avg[k]; jobs.ad_v[i] = T.exp_avg_sq[k]; }
             jobs.ad_snap = p.gscale + 4;
             jobs.ad_b1 = tail->beta1; jobs.ad_b2 = tail->beta2; jobs.ad_eps = (float)tail->eps;
+            if (tail->polyak != nullptr) {
+                for (int i = 0; i < jobs.n; ++i)
+                    for (int k = 0; k < tail->polyak->n; ++k)
+                        if (jobs.ad_p[i] != nullptr && tail->polyak->grad[k] == jobs.ad_p[i]) jobs.pk_t[i] = tail->polyak->param[k];
+                jobs.pk_omt = (float)(1.0 - tail->polyak_tau);
+                jobs.pk_tau = (float)tail->polyak_tau;
+            }
         }
         if (tail->mean_x != nullptr) {
             jobs.mean_x = tail->mean_x; jobs.mean_n = tail->mean_n; jobs.mean_sc = (float)tail->mean_scale; jobs.mean_stats = tail->mean_stats;
@@ -979,6 +995,16 @@ int gops_value_backward(const GopsMlp* value, int32_t batch, const float* obs, c
     memset(&in, 0, sizeof(in));
     in.obs = obs;
     return run_backward(d, in, grad_v, *grad, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int gops_value_backward_update(const GopsMlp* value, int32_t batch, const float* obs, const float* grad_v,
+                               const GopsMlpGrad* grad, const GopsUpdateTail* tail, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!value || !obs || !grad_v || !grad || !tail) return GOPS_ERR_BAD_ARG;
+    const GopsRolloutDesc d = value_desc(*value, batch);
+    GopsRolloutIn in;
+    memset(&in, 0, sizeof(in));
+    in.obs = obs;
+    return run_backward(d, in, grad_v, *grad, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr, true, tail);
 }
 
 int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, double beta1, double beta2,

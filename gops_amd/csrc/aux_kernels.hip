@@ -1612,7 +1612,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
     // the element's Adam operands travel with the partial sums (they are needed when the sums are)
     float pm = 0.f, pv = 0.f, pp = 0.f;
     const bool step_here = adam && jobs.ad_p[j] != nullptr && sl == 0 && valid;
+    float pt = 0.f;
+    const bool avg_here = step_here && jobs.pk_t[j] != nullptr;
     if (step_here) { pm = jobs.ad_m[j][idx]; pv = jobs.ad_v[j][idx]; pp = jobs.ad_p[j][idx]; }
+    if (avg_here) pt = jobs.pk_t[j][idx];
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     if (valid) {
         const int r = idx / cols, c = idx - r * cols;
@@ -1648,7 +1651,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
             const float vi = pv * b2 + omb2 * gi * gi;
             jobs.ad_m[j][idx] = mi;
             jobs.ad_v[j][idx] = vi;
-            jobs.ad_p[j][idx] = pp - step_size * (mi / (sqrtf(vi) / bc2_sqrt + jobs.ad_eps));
+            const float pn = pp - step_size * (mi / (sqrtf(vi) / bc2_sqrt + jobs.ad_eps));
+            jobs.ad_p[j][idx] = pn;
+            if (avg_here) jobs.pk_t[j][idx] = rn_add(rn_mul(pt, jobs.pk_omt), rn_mul(jobs.pk_tau, pn));   // polyak_kernel's roundings
         }
     }
     }

@@ -295,6 +295,8 @@ struct ReduceJobs {
     const float* mean_x;                   // null: no loss mean
     float* mean_stats;
     float mean_sc;
+    float* pk_t[2 * GOPS_MAX_LAYERS];      // Polyak target tensor behind out[j] (null: none): averaged with the new parameter value
+    float pk_omt, pk_tau;                  // (1 - tau, tau as gops_polyak_update rounds them)
 };
 
 // GOPS_DTYPE_F16 backward: the power of two s that brings max|grad_v| = m into [1, 2).  The whole sweep runs

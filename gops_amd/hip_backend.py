@@ -115,7 +115,7 @@ class GopsAdamTensors(C.Structure):
 class GopsUpdateTail(C.Structure):   # ABI v12: gops_rollout_backward_update
     _fields_ = [("adam", C.POINTER(GopsAdamTensors)), ("adam_state", C.c_void_p), ("beta1", C.c_double), ("beta2", C.c_double),
                 ("eps", C.c_double), ("mean_x", C.c_void_p), ("mean_n", C.c_int32), ("reserved", C.c_int32),
-                ("mean_scale", C.c_double), ("mean_stats", C.c_void_p)]
+                ("mean_scale", C.c_double), ("mean_stats", C.c_void_p), ("polyak", C.POINTER(GopsAdamTensors)), ("polyak_tau", C.c_double)]
 
 
 class GopsStepIO(C.Structure):
@@ -152,6 +152,9 @@ def lib() -> C.CDLL:
         l.gops_rollout_backward_update.restype = C.c_int
         l.gops_rollout_backward_update.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn), C.c_void_p,
                                                    C.POINTER(GopsMlpGrad), C.POINTER(GopsUpdateTail), C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gops_value_backward_update.restype = C.c_int
+        l.gops_value_backward_update.argtypes = [C.POINTER(GopsMlp), C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(GopsMlpGrad),
+                                                 C.POINTER(GopsUpdateTail), C.c_void_p, C.c_size_t, C.c_void_p]
         l.gops_rollout_backward_adj.restype = C.c_int
         l.gops_rollout_backward_adj.argtypes = [C.POINTER(GopsRolloutDesc), C.POINTER(GopsRolloutIn), C.c_void_p,
                                                 C.POINTER(GopsMlpGrad), C.POINTER(GopsRolloutAdjoint), C.c_void_p,
@@ -205,7 +208,8 @@ EXPORTED_SYMBOLS = ("gops_hip_version", "gops_rollout_workspace_bytes", "gops_ro
                     "gops_value_forward", "gops_value_backward", "gops_mlp_workspace_bytes", "gops_mlp_forward",
                     "gops_mlp_backward", "gops_mlp_backward_x", "gops_adam_step", "gops_profile_enable",
                     "gops_profile_reset", "gops_profile_read", "gops_rollout_variant", "gops_rollout_backward_open_loop_adj",
-                    "gops_env_constraint", "gops_polyak_update", "gops_value_loss", "gops_mean_loss", "gops_rollout_backward_update")
+                    "gops_env_constraint", "gops_polyak_update", "gops_value_loss", "gops_mean_loss", "gops_rollout_backward_update",
+                    "gops_value_backward_update")
 
 _ERR = {-1: "GOPS_ERR_BAD_ARG", -2: "GOPS_ERR_UNSUPPORTED", -3: "GOPS_ERR_WORKSPACE"}
 
@@ -561,8 +565,14 @@ class ValueNet:
               "gops_value_forward")
         return v
 
-    def backward(self, obs: torch.Tensor, grad_v: torch.Tensor, grad_w, grad_b):
+    def backward(self, obs: torch.Tensor, grad_v: torch.Tensor, grad_w, grad_b, tail: Optional["GopsUpdateTail"] = None):
+        """`tail` (ABI v12, `gops_value_backward_update`): Adam step (+ Polyak step of the target) folded into the launch that forms the gradients."""
         g = make_mlp_grad(grad_w, grad_b)
+        if tail is not None:
+            check(lib().gops_value_backward_update(C.byref(self.mlp), self.batch, _ptr(obs), _ptr(grad_v), C.byref(g), C.byref(tail),
+                                                   self.workspace.data_ptr(), self.workspace.numel(), _stream()),
+                  "gops_value_backward_update")
+            return
         check(lib().gops_value_backward(C.byref(self.mlp), self.batch, _ptr(obs), _ptr(grad_v), C.byref(g),
                                         self.workspace.data_ptr(), self.workspace.numel(), _stream()),
               "gops_value_backward")
@@ -829,10 +839,11 @@ class LossStats:
 
 
 def make_update_tail(fused_adam=None, mean_of: Optional[torch.Tensor] = None, mean_scale: float = -1.0,
-                     stats: Optional["LossStats"] = None) -> "GopsUpdateTail":
-    """`GopsUpdateTail` for `Rollout.backward(..., tail=)`: `fused_adam` = what `HipAdam.begin_fused()` returned (or None),
-    `mean_of` / `stats`: the values whose mean lands in `stats.buf[:2]` as `gops_mean_loss` would leave it.  The returned struct keeps
-    the tensors it points to alive."""
+                     stats: Optional["LossStats"] = None, polyak: Optional["PolyakUpdater"] = None, tau: float = 0.0) -> "GopsUpdateTail":
+    """`GopsUpdateTail` for `Rollout.backward(..., tail=)` / `ValueNet.backward(..., tail=)`: `fused_adam` = what
+    `HipAdam.begin_fused()` returned (or None), `mean_of` / `stats`: the values whose mean lands in `stats.buf[:2]` as `gops_mean_loss`
+    would leave it, `polyak` / `tau`: the target-network averaging of the stepped network (a one-table `PolyakUpdater`).  The
+    returned struct keeps the tensors it points to alive."""
     t = GopsUpdateTail()
     keep = []
     if fused_adam is not None:
@@ -843,6 +854,10 @@ def make_update_tail(fused_adam=None, mean_of: Optional[torch.Tensor] = None, me
     if mean_of is not None:
         t.mean_x, t.mean_n, t.mean_scale, t.mean_stats = _ptr(mean_of), mean_of.numel(), float(mean_scale), stats.buf.data_ptr()
         keep += [mean_of, stats]
+    if polyak is not None:
+        assert fused_adam is not None and len(polyak.tables) == 1
+        t.polyak, t.polyak_tau = C.pointer(polyak.tables[0]), float(tau)
+        keep.append(polyak)
     t._keep = keep
     return t
 

@@ -433,10 +433,21 @@ typedef struct GopsUpdateTail {
     int32_t reserved;
     double mean_scale;             /* mean_stats[0] = mean_scale * mean(x), mean_stats[1] = mean(x) */
     float* mean_stats;             /* GOPS_LOSS_STATS_FLOATS floats, as for gops_mean_loss */
+    const GopsAdamTensors* polyak; /* NULL: no target-network averaging; else the table of gops_polyak_update (param[i] = target tensor,
+                                    * grad[i] = online tensor) for the network `adam` steps: every online tensor must be one of adam's
+                                    * param[] - the target element is averaged with the NEW parameter value right where Adam forms it
+                                    * (infadp.py:124-133 after :104), same two roundings as gops_polyak_update.  Needs `adam` */
+    double polyak_tau;
 } GopsUpdateTail;
 int gops_rollout_backward_update(const GopsRolloutDesc* desc, const GopsRolloutIn* in, const float* grad_v,
                                  const GopsMlpGrad* policy_grad, const GopsUpdateTail* tail,
                                  void* workspace, size_t workspace_bytes, void* stream);
+/* The same for a value / MLP batch: gops_value_backward with the tail (INFADP's policy-evaluation update: Adam step of the value
+ * net + Polyak step of its target in the launch that forms the gradients; tail->mean_x is usually NULL there - gops_value_loss
+ * has to run BEFORE the backward, it produces grad_v). */
+int gops_value_backward_update(const GopsMlp* value, int32_t batch, const float* obs, const float* grad_v,
+                               const GopsMlpGrad* grad, const GopsUpdateTail* tail,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ABI v11.  Polyak averaging of a target network, every tensor in one launch - replaces the two passes of
  * gops/algorithm/infadp.py:124-133 (`p_targ.mul_(1 - tau); p_targ.add_(tau * p)`), same roundings per element.

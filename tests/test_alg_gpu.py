@@ -1129,9 +1129,10 @@ def test_update_tail_is_refused_where_it_does_not_belong():
         assert torch.equal(a, b)                  # nothing stepped
 
 
-def test_fused_update_tail_infadp_pim(monkeypatch):
-    """The same for INFADP's policy-improvement updates (the policy's backward carries loss mean + Adam; policy evaluation and the
-    Polyak steps are untouched): bit-equal networks, targets and optimizer state after alternating PEV / PIM updates."""
+def test_fused_update_tail_infadp(monkeypatch):
+    """The same for INFADP: the policy's backward carries loss mean + Adam + the Polyak step of policy_target (PIM,
+    `gops_rollout_backward_update`), the value net's backward carries Adam + the Polyak step of v_target (PEV,
+    `gops_value_backward_update`) - bit-equal networks, TARGETS and optimizer state after alternating PEV / PIM updates."""
     dev = torch.device("cuda", 0)
     cfg = dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=300, horizon=5, hidden=(256, 256), act="gelu", gamma=0.99)
 
@@ -1143,7 +1144,8 @@ def test_fused_update_tail_infadp_pim(monkeypatch):
         return alg
     fused, plain = make(), make()
     monkeypatch.setenv("GOPS_HIP_GRAPH", "0")
-    monkeypatch.setattr(plain.networks.optimizer_dict["policy"], "begin_fused", lambda: None)
+    for net in ("policy", "v"):   # -> backward, mean_loss / step() / gops_polyak_update as separate calls
+        monkeypatch.setattr(plain.networks.optimizer_dict[net], "begin_fused", lambda: None)
     for it in range(6):
         data = {k: v.to(dev) for k, v in make_batch(cfg, 70 + it).items()}
         tf, tp = fused.local_update(data, it), plain.local_update(data, it)
@@ -1151,8 +1153,12 @@ def test_fused_update_tail_infadp_pim(monkeypatch):
             if k != tb_tags["alg_time"]:
                 assert float(tf[k]) == float(tp[k]), k
     torch.cuda.synchronize()
+    names = [n for n, _ in fused.networks.named_parameters()]
+    assert any("target" in n for n in names)   # (the comparison below covers the Polyak-averaged copies)
     for (name, a), b in zip(fused.networks.named_parameters(), plain.networks.parameters()):
         assert torch.equal(a, b), name
+    init = make()
+    assert max((a - b).abs().max().item() for (n, a), b in zip(init.networks.named_parameters(), fused.networks.parameters()) if "target" in n) > 1e-6
     for net in ("policy", "v"):
         of, op = fused.networks.optimizer_dict[net], plain.networks.optimizer_dict[net]
         for a, b in zip(fused.networks.net_dict[net].parameters(), plain.networks.net_dict[net].parameters()):

@@ -167,6 +167,19 @@ def test_workspace_query_and_rejections_need_no_gpu():
     assert hb.lib().gops_rollout_workspace_bytes(ctypes.byref(d)) == 0
 
 
+def test_update_tail_entry_points_reject_bad_arguments_without_a_gpu():
+    """ABI v12: `gops_rollout_backward_update` / `gops_value_backward_update` check their arguments before anything is launched - a
+    missing tail, a missing descriptor or gradient table is GOPS_ERR_BAD_ARG (-1), never a crash and never a silent plain backward."""
+    from gops_amd import hip_backend as hb
+    lib = hb.lib()
+    d, i, g, t, m = hb.GopsRolloutDesc(), hb.GopsRolloutIn(), hb.GopsMlpGrad(), hb.GopsUpdateTail(), hb.GopsMlp()
+    assert lib.gops_rollout_backward_update(ctypes.byref(d), ctypes.byref(i), None, ctypes.byref(g), None, None, 0, None) < 0
+    assert lib.gops_rollout_backward_update(None, ctypes.byref(i), None, ctypes.byref(g), ctypes.byref(t), None, 0, None) < 0
+    assert lib.gops_rollout_backward_update(ctypes.byref(d), ctypes.byref(i), None, ctypes.byref(g), ctypes.byref(t), None, 0, None) < 0   # (no grad_v, empty descriptor)
+    assert lib.gops_value_backward_update(ctypes.byref(m), 64, None, None, ctypes.byref(g), ctypes.byref(t), None, 0, None) < 0
+    assert lib.gops_value_backward_update(ctypes.byref(m), 64, 1, 1, ctypes.byref(g), None, None, 0, None) < 0
+
+
 def test_variant_selection_is_part_of_the_description_not_of_the_process():
     """ABI v10: kernel variants are chosen by GopsRolloutDesc.variant_flags - two callers in one process can choose
     differently (the library keeps no global state) - and the library source reads the process environment in ONE

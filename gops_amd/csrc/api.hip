@@ -16,6 +16,8 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
 size_t rollout_fwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, int split_k0, bool ss = false);
 size_t rollout_bwd_lds_bytes(int ldx, int ldh, int ref_points, bool f16, bool split, bool ssb = false);
 bool split_eligible(const RolloutParams& p);
+bool h64_fuses_dw0(const RolloutParams& p);   // rollout_h64.hip
+int h64_sweep_grid(const RolloutParams& p);
 int split_grid_limit();
 int ssb_grid_limit();     // rollout_bwd.hip
 bool ssb_fuses_out(const RolloutParams& p);
@@ -138,7 +140,7 @@ const EnvOverride& env_override() {
             {"GOPS_SPLIT", '0', GOPS_VF_NO_STATIONARY_SPLIT, 0}, {"GOPS_SS", '0', GOPS_VF_NO_STREAMED_SPLIT_FWD, 0},
             {"GOPS_SSB", '0', GOPS_VF_NO_STREAMED_SPLIT_BWD, 0}, {"GOPS_SS_VALUE", '0', GOPS_VF_NO_STREAMED_SPLIT_VALUE, 0},
             {"GOPS_SPLIT_STREAM0", '0', GOPS_VF_NO_SPLIT_STREAM0, 0}, {"GOPS_SPLIT_TAIL_MULTI", 0, GOPS_VF_SPLIT_TAIL_MULTI, 0},
-            {"GOPS_DW_EXACT", 0, GOPS_VF_DW_EXACT, 0}, {"GOPS_DW_F32", 0, GOPS_VF_DW_F32, 0}, {"GOPS_DW_NOGUARD", 0, GOPS_VF_DW_NO_GUARD, 0},
+            {"GOPS_DW_EXACT", 0, GOPS_VF_DW_EXACT, 0}, {"GOPS_DW_F32", 0, GOPS_VF_DW_F32, 0}, {"GOPS_DW_NOGUARD", 0, GOPS_VF_DW_NO_GUARD, 0}, {"GOPS_NO_FUSED_DW0", 0, GOPS_VF_NO_FUSED_DW0, 0},
             {"GOPS_DW_SKINNY", '0', GOPS_VF_DW_NO_SKINNY, 0}, {"GOPS_DW_SPEC", '0', GOPS_VF_DW_NO_SPEC, 0}, {"GOPS_DW_DIRECT", 0, GOPS_VF_DW_DIRECT, 0},
             {"GOPS_NO_FUSED_DWOUT", 0, GOPS_VF_NO_FUSED_DWOUT, 0}, {"GOPS_H64", '0', GOPS_VF_NO_HALF_TILE64, 0}, {"GOPS_BWD_UPLOAD", 0, GOPS_VF_BWD_UPLOAD, 0},
             {"GOPS_SK", 0, 0, 1}, {"GOPS_TOUCH", 0, 0, 2}, {"GOPS_DW_WGS", 0, 0, 3}, {"GOPS_DBG_TIMING", 0, 0, 4}};
@@ -413,8 +415,13 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         for (int j = 0; j < p.pol.nl - 1; ++j) {
             const int Kp = f16 ? p.pol.kp32[j] : p.pol.kp[j];
             const DwPlan d = plan_dw(p.pol.dims[j + 1], Kp, S, f16, p.vflags, p.dw_wgs);
-            plan.dw_part[j] = c.take((size_t)d.splits * p.pol.dims[j + 1] * Kp);
-            plan.dw_part_b[j] = c.take((size_t)d.splits * p.pol.dims[j + 1]);
+            size_t nw = (size_t)d.splits * p.pol.dims[j + 1] * Kp, nb = (size_t)d.splits * p.pol.dims[j + 1];
+            if (j == 0 && h64_fuses_dw0(p)) {   // one slab [256][8] / [256] per workgroup of the 64-row sweep instead (rollout_h64.hip)
+                nw = std::max(nw, (size_t)h64_sweep_grid(p) * 256 * 8);
+                nb = std::max(nb, (size_t)h64_sweep_grid(p) * 256);
+            }
+            plan.dw_part[j] = c.take(nw);
+            plan.dw_part_b[j] = c.take(nb);
         }
         const int Lh = p.pol.nl - 1;
         plan.dw_part[Lh] = c.take((size_t)DW_OUT_SPLITS * GOPS_MAX_ACT * p.pol.dims[Lh]);
@@ -592,6 +599,12 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     q.out_part = p.sp.out_part;
     q.out_part_b = p.sp.out_part_b;
     q.dbg = p.dbg;
+    const bool fuse_dw0 = h64_fuses_dw0(p) && want_params && ext_delta == nullptr && adj == nullptr &&
+                          !(p.vflags & (GOPS_VF_BWD_PHASE_A | GOPS_VF_BWD_PHASE_B));
+    if (fuse_dw0) {
+        q.w0_part = plan.dw_part[0];
+        q.w0_part_b = plan.dw_part_b[0];
+    }
     if (tail != nullptr && tail->adam != nullptr) {   // the sweep's thread 0 advances the optimizer state and leaves this step's factors
         q.ad_st = tail->adam_state;
         q.ad_snap = p.gscale + 4;
@@ -653,6 +666,11 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
         const int N = p.pol.dims[j + 1], Kp = p.f16 ? p.pol.kp32[j] : p.pol.kp[j], K = p.pol.dims[j];
         const DwPlan d = plan_dw(N, Kp, S, p.f16 != 0, p.vflags, p.dw_wgs);
         const float* X = (j == 0) ? p.st.x : p.st.h[j];
+        if (j == 0 && fuse_dw0) {   // formed inside the 64-row sweep: one slab per workgroup
+            reduce_jobs_add(jobs, plan.dw_part[0], h64_sweep_grid(p), N, K, 8, grad.weight[0]);
+            reduce_jobs_add(jobs, plan.dw_part_b[0], h64_sweep_grid(p), 1, N, N, grad.bias[0]);
+            continue;
+        }
         if (p.f16) {
             if ((e = launch_dw_gemm_f16(p.st.d[j + 1], N, X, Kp, S, d.splits, d.chunks_per_split, plan.dw_part[j],
                                         plan.dw_part_b[j], s)) != hipSuccess) return (int)e;

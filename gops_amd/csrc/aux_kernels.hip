@@ -1624,6 +1624,16 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
         int s = sl;
         // 8 independent loads in flight per thread (the kernel is latency-bound: one 256-byte row segment per wave and
         // split); the pairs are added in a fixed order, so the result does not depend on the unrolling
+        // (jobs with hundreds of splits - one slab per sweep workgroup, rollout_h64.hip's fused first-layer gradient: 1024 at cfg5 -
+        // take 16 at a time; element i of a thread's sequence goes to accumulator i % 4 in every form of the loop, so the sums
+        // do not depend on which form ran)
+        for (; s + 60 < splits; s += 64) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(s + 4 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { acc0 += v[u]; acc1 += v[u + 1]; acc2 += v[u + 2]; acc3 += v[u + 3]; }
+        }
         for (; s + 28 < splits; s += 32) {
             const float v0 = p[(size_t)s * stride], v1 = p[(size_t)(s + 4) * stride], v2 = p[(size_t)(s + 8) * stride],
                         v3 = p[(size_t)(s + 12) * stride], v4 = p[(size_t)(s + 16) * stride], v5 = p[(size_t)(s + 20) * stride],

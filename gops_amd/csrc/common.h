@@ -224,6 +224,11 @@ struct BwdPatch {
     GopsAdamState* ad_st;
     float* ad_snap;
     double ad_b1, ad_b2;
+    // 64-row half sweep (rollout_h64.hip), policy input of <= 8 columns (pyth_lq): the first layer's weight / bias gradient is
+    // formed INSIDE the sweep, one slab [256][8] / [256] per workgroup - its delta tile never goes to the stash and the layer's
+    // GEMM launch disappears (null: the GEMM path)
+    float* w0_part;
+    float* w0_part_b;
 };
 // adam_kernel's scalar factors of THIS step (formed in double like torch's host code, rounded to fp32) -> snap[0 .. 2] = step_size,
 // sqrt(1 - beta2^t), grad_scale; the state moves on to the next step

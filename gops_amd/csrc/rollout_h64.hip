@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void rollout_fwd_h64_kernel(const Roll
 template <int RG, class WP, class Hook>
 __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw, const float* s_gy, _Float16* dbuf, float* G, int ldg, int tid,
                                                  float* const* st_h, float* const* st_z, float* const* st_d, float* stash_dy, size_t row0,
-                                                 int nvalid, bool want_gx, int ncols, DbgClock& dbg, Hook&& after_head) {
+                                                 int nvalid, bool want_gx, int ncols, DbgClock& dbg, Hook&& after_head, bool skip_d1 = false) {
     const int lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
     const int L = M.nl - 1, A = M.dims[M.nl];
     const bool gelu = (M.act == GOPS_ACT_GELU);
@@ -362,7 +362,7 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
                         dv[e] = sat_h(ok ? acc * d : 0.f);
                     }
                     *reinterpret_cast<f16x8*>(dbuf + row * H64_LD + k) = dv;
-                    if (st_d != nullptr)
+                    if (st_d != nullptr && !(skip_d1 && L == 1))
                         H64_STORE(dv, gptr(reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(st_d[L]) + (row0 + row) * 256 + k)));
                 }
             }
@@ -413,7 +413,7 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
                     }
                 *reinterpret_cast<f16x8*>(dbuf + row * H64_LD + f0) = o[0];
                 *reinterpret_cast<f16x8*>(dbuf + row * H64_LD + f0 + 8) = o[1];
-                if (st_d != nullptr) {
+                if (st_d != nullptr && !(skip_d1 && j == 1)) {   // (skip_d1: the caller forms the first layer's gradient from the LDS tile)
                     _Float16* dst = reinterpret_cast<_Float16*>(st_d[j]) + (row0 + row) * 256 + f0;
                     H64_STORE(o[0], gptr(reinterpret_cast<f16x8*>(dst)));
                     H64_STORE(o[1], gptr(reinterpret_cast<f16x8*>(dst + 8)));
@@ -452,8 +452,11 @@ __device__ __forceinline__ void mlp_backward_h64(const MlpDev& M, WP Wo, int ldw
 #define H64_BWD_RG 4
 #endif
 #define H64_BWD_WGS (H64_BWD_RG == 4 ? 2 : 3)
+// (+ the fused first-layer gradient: the policy-input rows of two steps [2][TBW][8] and the workgroup's accumulators [256][9])
+#define H64_W0_COLS 8
 size_t rollout_bwd_h64_lds_bytes(int ldx, int ldh) {
-    return sizeof(float) * (size_t)(16 * H64_BWD_RG * ldx + 16 * H64_BWD_RG * 4 + 4 * ldh + ENV_LDS_FLOATS) + sizeof(_Float16) * (size_t)(16 * H64_BWD_RG * H64_LD);
+    return sizeof(float) * (size_t)(16 * H64_BWD_RG * ldx + 16 * H64_BWD_RG * 4 + 4 * ldh + ENV_LDS_FLOATS + 2 * 16 * H64_BWD_RG * H64_W0_COLS + 256 * (H64_W0_COLS + 1)) +
+           sizeof(_Float16) * (size_t)(16 * H64_BWD_RG * H64_LD);
 }
 
 template <int ENV, bool TAIL, int RG>
@@ -478,7 +481,43 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
     float* s_env = s_wo + 4 * ldh;    // GopsEnv copy
     const GopsEnv& env = *reinterpret_cast<const GopsEnv*>(s_env);
     for (int idx = tid; idx < (int)(sizeof(GopsEnv) / 4); idx += NTHREADS) s_env[idx] = gptr(reinterpret_cast<const float*>(&p.env))[idx];
-    _Float16* dbuf = reinterpret_cast<_Float16*>(s_env + ENV_LDS_FLOATS);   // [64][H64_LD]
+    float* s_x = s_env + ENV_LDS_FLOATS;                 // [2][TBW][8]  policy-input rows of this step / the step before (fused first-layer gradient)
+    float* s_w0 = s_x + 2 * TBW * H64_W0_COLS;           // [256][9]     this workgroup's sums of delta_1^T x and of delta_1, by feature
+    _Float16* dbuf = reinterpret_cast<_Float16*>(s_w0 + 256 * (H64_W0_COLS + 1));   // [64][H64_LD]
+    // The first layer's weight / bias gradient formed here (BwdPatch::w0_part; ENV_LQ, <= 8 policy inputs): delta_1 never goes to the
+    // stash (a third of the sweep's HBM writes) and the layer's GEMM launch (which read it back: 0.38 GB at cfg5) is gone.  The sums
+    // of step t are formed by waves 1 .. 3 during the env phase of step t - 1, which occupies wave 0 only (delta_1 of step t stays in
+    // `dbuf` until the network sweep of step t - 1 starts behind that phase's barrier); step 0's by everybody behind the loop.
+    const bool fuse_w0 = ENV == GOPS_ENV_LQ && q.w0_part != nullptr;
+    const int K0 = p.pol.dims[0];
+    auto w0_accumulate = [&](int feature, const float* xrows) {
+        const _Float16* dcol = dbuf + feature;
+        float* acc = s_w0 + feature * (H64_W0_COLS + 1);
+        if (K0 <= 4) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, ab = 0.f;
+#pragma unroll 8
+            for (int row = 0; row < TBW; ++row) {
+                const float d = (float)dcol[row * H64_LD];
+                const f32x4 x = *reinterpret_cast<const f32x4*>(xrows + row * H64_W0_COLS);
+                a0 = fmaf(d, x[0], a0); a1 = fmaf(d, x[1], a1); a2 = fmaf(d, x[2], a2); a3 = fmaf(d, x[3], a3);
+                ab += d;
+            }
+            acc[0] += a0; acc[1] += a1; acc[2] += a2; acc[3] += a3; acc[H64_W0_COLS] += ab;
+        } else {
+            float a[H64_W0_COLS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ab = 0.f;
+#pragma unroll 4
+            for (int row = 0; row < TBW; ++row) {
+                const float d = (float)dcol[row * H64_LD];
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrows + row * H64_W0_COLS), x1 = *reinterpret_cast<const f32x4*>(xrows + row * H64_W0_COLS + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a[k] = fmaf(d, x0[k], a[k]); a[4 + k] = fmaf(d, x1[k], a[4 + k]); }
+                ab += d;
+            }
+#pragma unroll
+            for (int k = 0; k < H64_W0_COLS; ++k) acc[k] += a[k];
+            acc[H64_W0_COLS] += ab;
+        }
+    };
     {
         const int Lh = p.pol.nl - 1, K = p.pol.dims[Lh], Ao = p.pol.dims[p.pol.nl];
         for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
@@ -486,6 +525,8 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
             s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
         }
     }
+    if (fuse_w0)
+        for (int idx = tid; idx < 256 * (H64_W0_COLS + 1); idx += NTHREADS) s_w0[idx] = 0.f;
     for (int idx = tid; idx < TBW * ldx; idx += NTHREADS) G[idx] = 0.f;
     DbgClock dbg;   // phase counters of thread 0 (GOPS_DBG_BUILD + GOPS_DBG_TIMING=1, tools/dbg_run.py)
     dbg.init(false);
@@ -529,8 +570,25 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
         const size_t row0 = step_row0(t);
         float g_r = gv * p.gpow[t];
         if (ENV != GOPS_ENV_NONE && env.shaping) g_r *= env.reward_scale;
+        if (fuse_w0 && tid >= TBW && t < p.H - 1) {   // waves 1 .. 3, while wave 0 steps the env adjoint: the sums of step t + 1
+            const int u = tid - TBW;                   // 192 threads, 256 features: the first 64 take two
+            const float* xrows = s_x + ((t + 1) & 1) * (TBW * H64_W0_COLS);
+            w0_accumulate(u, xrows);
+            if (u < 256 - (NTHREADS - TBW)) w0_accumulate(u + (NTHREADS - TBW), xrows);
+        }
         if (tid < TBW) {
             const int m = tid;
+            if (fuse_w0) {   // the row's policy input as the GEMM would read it from the half X stash (rows beyond the batch: zeros)
+                f32x4 xa = cur.xa, xb = cur.xb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xa[i] = (m < nvalid && i < K0) ? (float)(_Float16)xa[i] : 0.f;
+                    xb[i] = (m < nvalid && 4 + i < K0) ? (float)(_Float16)xb[i] : 0.f;
+                }
+                float* xr = s_x + (t & 1) * (TBW * H64_W0_COLS) + m * H64_W0_COLS;
+                *reinterpret_cast<f32x4*>(xr) = xa;
+                *reinterpret_cast<f32x4*>(xr + 4) = xb;
+            }
             if (ENV == GOPS_ENV_NONE) {
                 s_gy[m * 4 + 0] = g_r;
                 s_gy[m * 4 + 1] = s_gy[m * 4 + 2] = s_gy[m * 4 + 3] = 0.f;
@@ -590,12 +648,21 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
         __syncthreads();
         DBG_TICK(1)
         mlp_backward_h64<RG>(p.pol, s_wo, ldh, s_gy, dbuf, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0, nvalid,
-                         /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, [&] { fetch_env(t - 1, nxt); });
+                         /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, [&] { fetch_env(t - 1, nxt); }, fuse_w0);
         cur = nxt;
         __syncthreads();
         DBG_TICK(9)
     }
     dbg.dump(q.dbg);
+    if (fuse_w0) {   // step 0's sums (thread n <-> feature n; the loop's closing barrier published delta_1), then this workgroup's slab
+        w0_accumulate(tid, s_x);   // (step 0: buffer 0)
+        const float* acc = s_w0 + tid * (H64_W0_COLS + 1);
+        f32x4 lo = {acc[0], acc[1], acc[2], acc[3]}, hi = {acc[4], acc[5], acc[6], acc[7]};
+        float* dst = q.w0_part + ((size_t)blockIdx.x * 256 + tid) * H64_W0_COLS;
+        *gptr(reinterpret_cast<f32x4*>(dst)) = lo;
+        *gptr(reinterpret_cast<f32x4*>(dst + 4)) = hi;
+        gptr(q.w0_part_b)[(size_t)blockIdx.x * 256 + tid] = acc[H64_W0_COLS];
+    }
     if (q.ad_st != nullptr && blockIdx.x == 0 && threadIdx.x == 0) adam_snapshot(q.ad_st, q.ad_snap, q.ad_b1, q.ad_b2);   // (gops_rollout_backward_update)
 }
 
@@ -630,6 +697,14 @@ hipError_t launch_rollout_bwd_h64(const RolloutParams& p, const RolloutParams* d
         return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+// Launches whose first-layer weight gradient the sweep forms itself (BwdPatch::w0_part): pyth_lq policies with <= 8 inputs
+// (GOPS_VF_NO_FUSED_DW0: the GEMM path, for A/B)
+int h64_sweep_grid(const RolloutParams& p) { return (p.B + 16 * H64_BWD_RG - 1) / (16 * H64_BWD_RG); }
+bool h64_fuses_dw0(const RolloutParams& p) {
+    return p.f16 && p.h64 && p.env.kind == GOPS_ENV_LQ && p.pol.dims[0] <= H64_W0_COLS && p.pol.dims[1] == 256 && p.need_grad &&
+           !(p.vflags & GOPS_VF_NO_FUSED_DW0);
 }
 
 // The launches the 64-row half kernels take (api.hip build_plan; GOPS_VF_NO_HALF_TILE64 keeps the 16-row kernels)

@@ -83,7 +83,7 @@ VF_STREAMED_FP32, VF_STREAM_LAYER0, VF_STATIONARY_ANY_BATCH, VF_NO_SPLIT_STREAM0
 VF_NO_HALF_TILE64 = 0x200
 VF_DW_EXACT, VF_DW_F32, VF_DW_NO_GUARD, VF_DW_NO_SKINNY, VF_DW_NO_SPEC, VF_DW_DIRECT = 0x10000, 0x20000, 0x40000, 0x80000, 0x100000, 0x200000
 VF_NO_FUSED_DWOUT, VF_BWD_UPLOAD = 0x400000, 0x800000
-VF_BWD_PHASE_A, VF_BWD_PHASE_B = 0x1000000, 0x2000000   # a backward in two halves (overlapped gradient all-reduce, trainer/grad_sync.py)
+VF_BWD_PHASE_A, VF_BWD_PHASE_B, VF_NO_FUSED_DW0 = 0x1000000, 0x2000000, 0x4000000   # a backward in two halves (overlapped gradient all-reduce, trainer/grad_sync.py)
 DEFAULT_VARIANT_FLAGS = 0
 
 

@@ -497,6 +497,7 @@ int gops_mean_loss(const float* x, int32_t n, double scale, float* stats, void* 
 #define GOPS_VF_DW_NO_SPEC 0x100000u         /*   no wave-specialised kernel                                  (GOPS_DW_SPEC=0) */
 #define GOPS_VF_DW_DIRECT 0x200000u          /*   register-direct kernel for the large layers too             (GOPS_DW_DIRECT) */
 #define GOPS_VF_NO_FUSED_DWOUT 0x400000u     /*   output layer's gradient in its own pass                     (GOPS_NO_FUSED_DWOUT) */
+#define GOPS_VF_NO_FUSED_DW0 0x4000000u      /*   GOPS_DTYPE_F16, 64-row kernels: the first layer's gradient by its GEMM, not inside the sweep (A/B) */
 #define GOPS_VF_BWD_UPLOAD 0x800000u         /*   measurement: parameter upload launch in front of the sweep  (GOPS_BWD_UPLOAD) */
 /* A backward call in two halves, so that a data-parallel caller can put the all-reduce of the gradients that are ready
  * first on a side stream while the rest is still being formed (gops_amd/trainer/grad_sync.py):

@@ -248,3 +248,40 @@ def test_f16_algorithm_class_updates(dev):
     for a, b in zip(losses["fp32"], losses["fp16"]):
         for x, y in zip(a, b):
             assert abs(x - y) <= 1e-2 * max(1.0, abs(x)), (losses["fp32"], losses["fp16"])
+
+
+@pytest.mark.parametrize("finite_horizon", [True, False])
+def test_f16_first_layer_gradient_inside_the_sweep_equals_its_gemm(finite_horizon, dev):
+    """pyth_lq on the 64-row half kernels: the first layer's weight / bias gradient is formed inside the sweep (one slab per
+    workgroup; delta_1 never goes to the stash, the layer's GEMM launch is gone) - against the same launch with
+    GOPS_VF_NO_FUSED_DW0 (delta_1 stashed, dw_gemm_f16_kernel): the same half operands, fp32 sums in another order.  Ragged batch with
+    more tiles than one, finite-horizon policy (5 inputs: the 8-column form) and the stationary one (4 inputs)."""
+    from gops_amd import hip_backend as hb
+    cfg = dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=64 * 5 + 23, horizon=9, hidden=(256, 256), act="gelu", gamma=0.99)
+    data = make_batch(cfg, 77)
+    data["done"][3::7] = 1.0
+    nets = reference_init_nets(cfg, 77, obs_dim_of(cfg), act_dim_of(cfg))
+    if not finite_horizon:   # DetermPolicy: no time column
+        nets["policy"]["w"][0] = nets["policy"]["w"][0][:, :obs_dim_of(cfg)].contiguous()
+    env = orc.make_env("pyth_lq", lq_config="s4a2")
+    henv = hip_env_from_oracle(env, nets["policy"])
+    mlp, ws, bs = hip_mlp_from_net(nets["policy"], dev)
+    B = cfg["batch"]
+    out = {}
+    for tag, flags in (("fused", 0), ("gemm", hb.VF_NO_FUSED_DW0)):
+        ro = hb.Rollout(henv, mlp, batch=B, horizon=cfg["horizon"], gamma=cfg["gamma"], finite_horizon=finite_horizon, dtype="fp16",
+                        variant_flags=flags)
+        assert hb.lib().gops_rollout_variant(ro.desc) & 8   # GOPS_VARIANT_HALF_TILE64
+        res = ro.forward(to_device(data, dev))
+        gw, gb = [torch.full_like(w, float("nan")) for w in ws], [torch.full_like(b, float("nan")) for b in bs]
+        ro.backward(torch.full((B,), -1.0 / B, device=dev), gw, gb)
+        torch.cuda.synchronize()
+        out[tag] = (res["v_pi"].clone(), gw, gb)
+    assert torch.equal(out["fused"][0], out["gemm"][0])
+    for j in range(len(ws)):
+        for a, b in ((out["fused"][1][j], out["gemm"][1][j]), (out["fused"][2][j], out["gemm"][2][j])):
+            assert torch.isfinite(a).all()
+            if j == 0:
+                assert rel_l2(a.cpu(), b.cpu()) < 2e-6, (j, rel_l2(a.cpu(), b.cpu()))
+            else:
+                assert torch.equal(a, b), j   # the other layers' gradients do not know the difference

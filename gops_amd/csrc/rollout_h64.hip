@@ -488,7 +488,7 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
     // stash (a third of the sweep's HBM writes) and the layer's GEMM launch (which read it back: 0.38 GB at cfg5) is gone.  The sums
     // of step t are formed by waves 1 .. 3 during the env phase of step t - 1, which occupies wave 0 only (delta_1 of step t stays in
     // `dbuf` until the network sweep of step t - 1 starts behind that phase's barrier); step 0's by everybody behind the loop.
-    const bool fuse_w0 = ENV == GOPS_ENV_LQ && q.w0_part != nullptr;
+    const bool fuse_w0 = q.w0_part != nullptr;   // (pyth_lq rollouts and plain value batches: api.hip h64_fuses_dw0)
     const int K0 = p.pol.dims[0];
     auto w0_accumulate = [&](int feature, const float* xrows) {
         const _Float16* dcol = dbuf + feature;
@@ -539,12 +539,14 @@ __global__ __launch_bounds__(NTHREADS, H64_BWD_WGS) void rollout_bwd_h64_kernel(
     auto fetch_env = [&](int t, EnvRow& r) {
         r.e0 = r.xa = r.xb = f32x4{0.f, 0.f, 0.f, 0.f};
         r.dflag = 1.f;
-        if (ENV != GOPS_ENV_NONE && t >= 0 && tid < nvalid) {
+        if ((ENV != GOPS_ENV_NONE || fuse_w0) && t >= 0 && tid < nvalid) {
             const size_t row = step_row0(t) + tid;
-            const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + row * ENV_STASH));
             const GLOBAL_AS f32x4* xr = gptr(reinterpret_cast<const f32x4*>(p.st.xf + row * 8));
-            r.e0 = er[0];
-            r.dflag = er[1][0];
+            if (ENV != GOPS_ENV_NONE) {
+                const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + row * ENV_STASH));
+                r.e0 = er[0];
+                r.dflag = er[1][0];
+            }
             r.xa = xr[0];
             r.xb = xr[1];
         }
@@ -699,11 +701,12 @@ hipError_t launch_rollout_bwd_h64(const RolloutParams& p, const RolloutParams* d
     return hipGetLastError();
 }
 
-// Launches whose first-layer weight gradient the sweep forms itself (BwdPatch::w0_part): pyth_lq policies with <= 8 inputs
+// Launches whose first-layer weight gradient the sweep forms itself (BwdPatch::w0_part): pyth_lq policies and value nets with <= 8 inputs
 // (GOPS_VF_NO_FUSED_DW0: the GEMM path, for A/B)
 int h64_sweep_grid(const RolloutParams& p) { return (p.B + 16 * H64_BWD_RG - 1) / (16 * H64_BWD_RG); }
 bool h64_fuses_dw0(const RolloutParams& p) {
-    return p.f16 && p.h64 && p.env.kind == GOPS_ENV_LQ && p.pol.dims[0] <= H64_W0_COLS && p.pol.dims[1] == 256 && p.need_grad &&
+    return p.f16 && p.h64 && (p.env.kind == GOPS_ENV_LQ || p.env.kind == GOPS_ENV_NONE) && p.pol.dims[0] <= H64_W0_COLS && p.pol.dims[1] == 256 &&
+           p.need_grad &&
            !(p.vflags & GOPS_VF_NO_FUSED_DW0);
 }
 

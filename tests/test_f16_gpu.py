@@ -285,3 +285,32 @@ def test_f16_first_layer_gradient_inside_the_sweep_equals_its_gemm(finite_horizo
                 assert rel_l2(a.cpu(), b.cpu()) < 2e-6, (j, rel_l2(a.cpu(), b.cpu()))
             else:
                 assert torch.equal(a, b), j   # the other layers' gradients do not know the difference
+
+
+def test_f16_value_net_first_layer_gradient_inside_the_sweep_equals_its_gemm(dev):
+    """The same for a plain value batch (`gops_value_backward`, GOPS_ENV_NONE on the 64-row half kernels): first-layer gradient formed
+    inside the sweep against `GopsMlp.variant_flags = GOPS_VF_NO_FUSED_DW0`."""
+    from gops_amd import hip_backend as hb
+    cfg = dict(alg="INFADP", env_id="pyth_lq", lq_config="s4a2", batch=64 * 3 + 11, horizon=4, hidden=(256, 256), act="gelu", gamma=0.99)
+    nets = reference_init_nets(cfg, 31, obs_dim_of(cfg), act_dim_of(cfg))
+    data = to_device(make_batch(cfg, 31), dev)
+    B = cfg["batch"]
+    gv = torch.randn(B, generator=torch.Generator().manual_seed(2)).to(dev) / B
+    out = {}
+    for tag, flags in (("fused", 0), ("gemm", hb.VF_NO_FUSED_DW0)):
+        v, vw, vb = hip_mlp_from_net(nets["v"], dev)
+        v.dtype, v.variant_flags = hb.dtype_id("fp16"), flags
+        vn = hb.ValueNet(v, B)
+        vo = vn.forward(data["obs"]).clone()
+        gw, gb = [torch.full_like(w, float("nan")) for w in vw], [torch.full_like(b, float("nan")) for b in vb]
+        vn.backward(data["obs"], gv, gw, gb)
+        torch.cuda.synchronize()
+        out[tag] = (vo, gw, gb)
+    assert torch.equal(out["fused"][0], out["gemm"][0])
+    for j in range(len(out["fused"][1])):
+        for a, b in ((out["fused"][1][j], out["gemm"][1][j]), (out["fused"][2][j], out["gemm"][2][j])):
+            assert torch.isfinite(a).all()
+            if j == 0:
+                assert rel_l2(a.cpu(), b.cpu()) < 2e-6, (j, rel_l2(a.cpu(), b.cpu()))
+            else:
+                assert torch.equal(a, b), j

@@ -92,7 +92,9 @@ __device__ __forceinline__ void mlp_hidden_forward_h64(const MlpDev& M, const _F
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) bv[jj] = *reinterpret_cast<const f32x4*>(s_bias + j * ldb + f0 + 4 * jj);
         const bool gelu = M.act == GOPS_ACT_GELU;
-        act_dispatch(M.act, [&]<int ACT>() {
+        // (gradient-free launches - INFADP's policy-evaluation rollout - keep no stash: the GELU epilogue then skips gelu'(z) and its
+        // conversion, ~4 of its ~26 issue slots per element; the epilogues are what this kernel is bound by)
+        auto epilogue = [&]<int ACT, bool WANT_DH>() {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int row = 16 * rg + m;
@@ -104,10 +106,12 @@ __device__ __forceinline__ void mlp_hidden_forward_h64(const MlpDev& M, const _F
                         const int e = 4 * jj + r;
                         const float z = acc[jj][rg][r] + bv[jj][r];
                         float h, dh = 0.f;
-                        if (ACT == GOPS_ACT_GELU) gelu_pair_h(z, h, dh);
-                        else h = act_fwd_t<ACT>(z);
+                        if (ACT == GOPS_ACT_GELU) {
+                            gelu_pair_h(z, h, dh);
+                            if (!WANT_DH) dh = 0.f;   // (dead: the compiler drops its two instructions and the conversion below)
+                        } else h = act_fwd_t<ACT>(z);
                         o[e >> 3][e & 7] = (_Float16)h;
-                        gd[e >> 3][e & 7] = (_Float16)dh;
+                        if (WANT_DH) gd[e >> 3][e & 7] = (_Float16)dh;
                     }
                 *reinterpret_cast<f16x8*>(hbuf + row * H64_LD + f0) = o[0];
                 *reinterpret_cast<f16x8*>(hbuf + row * H64_LD + f0 + 8) = o[1];
@@ -115,13 +119,17 @@ __device__ __forceinline__ void mlp_hidden_forward_h64(const MlpDev& M, const _F
                     _Float16* hrow = reinterpret_cast<_Float16*>(stash_h[j + 1]) + (row0 + row) * 256;
                     H64_STORE(o[0], gptr(reinterpret_cast<f16x8*>(hrow + f0)));
                     H64_STORE(o[1], gptr(reinterpret_cast<f16x8*>(hrow + f0 + 8)));
-                    if (ACT == GOPS_ACT_GELU && gelu && stash_g != nullptr) {
+                    if (WANT_DH && ACT == GOPS_ACT_GELU && gelu && stash_g != nullptr) {
                         _Float16* grow = reinterpret_cast<_Float16*>(stash_g[j + 1]) + (row0 + row) * 256;
                         H64_STORE(gd[0], gptr(reinterpret_cast<f16x8*>(grow + f0)));
                         H64_STORE(gd[1], gptr(reinterpret_cast<f16x8*>(grow + f0 + 8)));
                     }
                 }
             }
+        };
+        act_dispatch(M.act, [&]<int ACT>() {
+            if (ACT == GOPS_ACT_GELU && stash_h == nullptr) epilogue.template operator()<ACT, false>();
+            else epilogue.template operator()<ACT, true>();
         });
         DBG_TICK(3 + 3 * (j > 0))
         __syncthreads();

@@ -1109,3 +1109,47 @@ def test_prioritized_replay_buffer_matches_reference_side_by_side():
         assert abs(buf.beta - float(g[f"u{k}/beta"])) < 1e-12
     from gops_amd.create_pkg.create_buffer import create_buffer
     assert isinstance(create_buffer(buffer_name="prioritized_replay_buffer", buffer_device="cpu", **kw), PrioritizedReplayBuffer)
+
+
+_GUARD_WORKER = r"""
+import os, sys, warnings
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from gops_amd.algorithm.base import PrecisionGuard
+dist.init_process_group("gloo")
+r = dist.get_rank()
+# the SAME network on both replicas, but only rank 1's batch shows a distance beyond the threshold: the decision is taken with a
+# MAX over the ranks, so BOTH move to the exact kernels (replicas that chose kernels on their own would stop computing the same update)
+g = PrecisionGuard(interval=1, threshold=1e-4)
+base = torch.ones(8)
+def flat_gradient(flags):
+    exact = bool(flags & PrecisionGuard.exact_rollout_flags())
+    return base.clone() if exact else base * (1.0 + (1e-3 if r == 1 else 1e-6))
+assert g.due()
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    d = g.check(flat_gradient)
+assert g.exact and abs(d - 1e-3) < 1e-5, (r, g.exact, d)
+assert any("exact-fp32 rollout kernels" in str(x.message) for x in w)
+assert g.flags() & PrecisionGuard.exact_rollout_flags() == PrecisionGuard.exact_rollout_flags() and not g.due()
+# ... and a distance below the threshold on every rank leaves both on the plane-split kernels
+g2 = PrecisionGuard(interval=1, threshold=1e-4)
+g2.due()
+d2 = g2.check(lambda flags: base.clone() if flags & PrecisionGuard.exact_rollout_flags() else base * (1.0 + 1e-6 * (r + 1)))
+assert not g2.exact and abs(d2 - 2e-6) < 1e-7, (r, d2)
+dist.barrier()
+dist.destroy_process_group()
+open(os.path.join(sys.argv[2], f"ok_{r}"), "w").write("ok")
+"""
+
+
+def test_precision_guard_decides_for_all_replicas_world_size_2(tmp_path):
+    """Data-parallel replicas take the plane-split / exact-kernel decision TOGETHER (MAX all-reduce of the measured distance)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GUARD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29677", str(script), ROOT, str(tmp_path)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()

@@ -183,7 +183,7 @@ class FHADP(AlgorithmBase):
         self.tb_info[tb_tags["alg_time"]] = (time.time() - self._t0) * 1000  # ms
 
     def _device_batch(self, data):
-        return batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
+        return self._attach_reference_points(data, batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS))
 
     def _extra_signature(self):
         """Host-side values a subclass bakes into the captured kernels' inputs (penalty coefficients ...)."""

@@ -95,7 +95,7 @@ class FHADP2(AlgorithmBase):
     def _compute_gradient(self, data):
         t0 = time.time()
         device = cuda_device_of(self.networks)
-        batch = batch_to_device(data, device, ("obs", "done") + _INFO_KEYS)
+        batch = self._attach_reference_points(data, batch_to_device(data, device, ("obs", "done") + _INFO_KEYS))
         B = batch["obs"].shape[0]
         policy = self.networks.policy
         # ONE evaluation of the full-horizon policy emits all H actions (fhadp2.py:100-104): hidden stack on the rollout

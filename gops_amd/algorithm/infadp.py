@@ -82,7 +82,7 @@ class INFADP(AlgorithmBase):
         # gradient + Adam + Polyak of the iteration's mode as one HIP graph when the update is launch-bound
         # (replay batches of the shipped examples are 64-256 samples); eager kernels otherwise
         start_time = time.time()
-        batch = batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
+        batch = self._attach_reference_points(data, batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS))
         mode = self._mode(iteration)
         opt = self.networks.optimizer_dict[mode]
         self._precision_check(mode, batch)
@@ -115,7 +115,7 @@ class INFADP(AlgorithmBase):
         # Data-parallel path: no host sync between the backward sweep and the gradient all-reduce - the loss
         # scalars stay on the device in tb_info and are read at log time.
         start_time = time.time()
-        batch = batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
+        batch = self._attach_reference_points(data, batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS))
         mode = self._mode(iteration)
         self._precision_check(mode, batch)
         scalars = self._gradient_kernels(mode, batch)
@@ -290,7 +290,7 @@ class INFADP(AlgorithmBase):
 
     def _compute_gradient(self, data, iteration):
         start_time = time.time()
-        batch = batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
+        batch = self._attach_reference_points(data, batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS))
         mode = self._mode(iteration)
         self._log(mode, self._gradient_kernels(mode, batch), start_time)
         return [mode]

@@ -110,7 +110,7 @@ class SPIL(AlgorithmBase):
         start_time = time.time()
         if self.reward_scale != 1.0:
             raise RuntimeError("SPIL.reward_scale != 1 is not supported by the HIP rollout (the terminal value is unscaled)")
-        batch = batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS)
+        batch = self._attach_reference_points(data, batch_to_device(data, cuda_device_of(self.networks), ("obs", "done") + _INFO_KEYS))
         B, device, nc = batch["obs"].shape[0], batch["obs"].device, self.n_constraint
         # ---- policy evaluation -----------------------------------------------------------------
         res = self._rollout_for(B, device, need_grad=False).forward(batch)

@@ -31,8 +31,13 @@ class WrappedEnvModel:
 
     def __init__(self, model, *, min_action, max_action, clip_obs: bool,
                  reward_scale: Optional[float], reward_shift: Optional[float], obs_scale=None, obs_shift=None,
-                 repeat_num: Optional[int] = None, sum_reward: bool = True, mask_at_done: bool = True):
+                 repeat_num: Optional[int] = None, sum_reward: bool = True, mask_at_done: bool = True,
+                 strict_reference_points: bool = False):
         self.model = model
+        # opt-in (models with reference trajectories): `forward` takes the appended reference point from the host's torch CPU ops -
+        # the reference's own fp32 values on this host - instead of the kernel's evaluation (env/env_ocp/resources/ref_traj_host.py)
+        self.strict_reference_points = bool(strict_reference_points) and model.hip_kind in (hb.ENV_VEH, hb.ENV_VEH_SURR, hb.ENV_VEH2DOF)
+        self._host_traj = None
         self.mask_at_done = mask_at_done   # False: no MaskAtDoneModel in the chain (GopsEnv.no_mask_at_done)
         self.repeat_num, self.sum_reward = repeat_num, sum_reward   # ActionRepeatModel constants (None: no such wrapper)
         self.obs_scale, self.obs_shift = obs_scale, obs_shift   # ScaleObservationModel constants (None: no such wrapper)
@@ -79,8 +84,15 @@ class WrappedEnvModel:
             raise RuntimeError("env_model.forward runs on the MI355X only (tensors must be on 'cuda'); "
                                "there is no CPU fallback in gops_amd")
         f = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
-        dev_info = {k: f(info[k]) for k in ("state", "ref_points", "path_num", "u_num", "ref_time", "surr_state", "noise")
+        dev_info = {k: f(info[k]) for k in ("state", "ref_points", "path_num", "u_num", "ref_time", "surr_state", "noise", "ref_appended")
                     if isinstance(info, dict) and k in info and info[k] is not None}
+        if self.strict_reference_points and "ref_appended" not in dev_info:
+            # the point this step appends, at (ref_time + dt) + pre_horizon * dt (pyth_veh3dofconti_model.py:106-128), from the host
+            if self._host_traj is None:
+                from gops_amd.env.env_ocp.resources.ref_traj_host import HostRefTraj
+                self._host_traj = HostRefTraj(getattr(self.model, "ref_c", None), dt=self.model.dt)
+            pts = self._host_traj.appended_points(dev_info["ref_time"], dev_info["path_num"], dev_info["u_num"], 1, self.model.pre_horizon)
+            dev_info["ref_appended"] = pts[:, 0].contiguous().to(obs.device)
         nobs, rew, ndone, ninfo = hb.env_step(self.hip_env(), f(obs), f(action), f(done), dev_info)
         if "constraint" not in ninfo:
             ninfo["constraint"] = None
@@ -102,6 +114,7 @@ def create_env_model(
     action_scale: bool = True,
     min_action: Union[float, int, np.ndarray, list] = -1.0,
     max_action: Union[float, int, np.ndarray, list] = 1.0,
+    strict_reference_points: bool = False,
     **kwargs,
 ) -> object:
     """Build the model `<env_id>_model` and apply the wrappers selected by the arguments (same
@@ -137,7 +150,8 @@ def create_env_model(
         # create_env_model.py:115-118: either one given -> the wrapper is applied with the other at its neutral value
         obs_scale=(1.0 if obs_scale is None else obs_scale) if scaled else None,
         obs_shift=(0.0 if obs_shift is None else obs_shift) if scaled else None,
-        repeat_num=None if repeat_num is None else int(repeat_num), sum_reward=bool(sum_reward), mask_at_done=bool(mask_at_done))
+        repeat_num=None if repeat_num is None else int(repeat_num), sum_reward=bool(sum_reward), mask_at_done=bool(mask_at_done),
+        strict_reference_points=strict_reference_points)
 
 
 # fill the registry: every env/env_*/env_model/<id>.py exporting env_model_creator or the CamelCase class

@@ -241,7 +241,8 @@ __device__ __forceinline__ float rn_sub(float a, float b) {
 // first version of this file had spelled out (x + 0.0f and 1.0f * x are exact).
 __device__ __forceinline__ float ref_arc(const float* __restrict__ c, float t, int u_num) {
     if (u_num == 0) return RADD(RADD(RMUL(c[0], COSF_CR(RADD(RMUL(c[1], t), c[2]))), RMUL(c[3], t)), c[4]);
-    return RMUL(c[6], t);
+    if (u_num == 1) return RMUL(c[6], t);
+    return 0.f;   // a speed id outside the registered set selects no profile: every mask of the reference's sum is false
 }
 
 __device__ __forceinline__ void ref_xy(const float* __restrict__ c, float t, int path, int u_num, float& x, float& y) {
@@ -275,9 +276,19 @@ __device__ __forceinline__ f32x4 ref_point(const float* __restrict__ c, float t,
     ref_xy(c, t, path, u_num, x0, y0);
     ref_xy(c, RADD(t, 0.001f), path, u_num, x1, y1);
     const float phi = (float)atan2((double)RSUB(y1, y0), (double)RSUB(x1, x0));
-    const float u = (u_num == 0) ? RADD(RMUL(c[5], SINF_CR(RADD(RMUL(c[1], t), c[2]))), c[3]) : c[6];
+    const float u = (u_num == 0) ? RADD(RMUL(c[5], SINF_CR(RADD(RMUL(c[1], t), c[2]))), c[3]) : (u_num == 1) ? c[6] : 0.f;
     f32x4 r = {x0, y0, phi, u};
     return r;
+}
+
+// The point (x, y, phi, u)(t) for the float ids the batches carry (info["path_num"], info["u_num"]).  Ids outside the registered
+// sets behave like the reference's masked sums `sum_i (id == i) * f_i(t)` (ref_traj_model.py:54-84, 138-142): an unknown path
+// selects nothing (zeros), an unknown speed profile leaves arc length and speed at zero under a known path.
+__device__ __forceinline__ f32x4 ref_point_ids(const float* __restrict__ c, float t, float pn, float un) {
+    const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : (pn == 3.f) ? 3 : -1;
+    const int us = (un == 0.f) ? 0 : (un == 1.f) ? 1 : -1;
+    if (path < 0) return f32x4{0.f, 0.f, 0.f, 0.f};
+    return ref_point(c, t, path, us);
 }
 
 // table[b][i] : i <= P copies info["ref_points"][b][i]; i = P + s (s >= 1) is the point the model
@@ -310,10 +321,7 @@ __device__ __forceinline__ void ref_table_element(int B, int P, int H, const flo
         const float pn = path_num[b], un = u_num[b];
         float t = ref_time[b];
         for (int s = 0; s < i - P; ++s) t = RADD(t, 0.1f);
-        const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : (pn == 3.f) ? 3 : -1;
-        const int us = (un == 0.f) ? 0 : (un == 1.f) ? 1 : -1;
-        if (path < 0 || us < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};   // ids outside the registered sets
-        else v = ref_point(c, RADD(t, pdt), path, us);
+        v = ref_point_ids(c, RADD(t, pdt), pn, un);
     }
     reinterpret_cast<f32x4*>(table)[idx] = v;
 }
@@ -2032,9 +2040,8 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         veh2_f_xu(C2, s, u[0], sphi, cphi, sn);
         const float nt = RADD(io.ref_time[b], 0.1f);
         const float pn = io.path_num[b], un = io.u_num[b];
-        const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : 3;
         const f32x4 newp = io.ref_appended != nullptr ? reinterpret_cast<const f32x4*>(io.ref_appended)[b]
-                                                      : ref_point(env.ref_c, RADD(nt, pdt), path, un == 0.f ? 0 : 1);
+                                                      : ref_point_ids(env.ref_c, RADD(nt, pdt), pn, un);
         const float* rin = io.ref_points + (size_t)b * (P + 1) * 2;
         float* rout = io.next_ref_points + (size_t)b * (P + 1) * 2;
         for (int i = 0; i < P; ++i) { rout[2 * i] = rin[2 * (i + 1)]; rout[2 * i + 1] = rin[2 * (i + 1) + 1]; }
@@ -2073,9 +2080,8 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         }
         const float nt = RADD(io.ref_time[b], 0.1f);
         const float pn = io.path_num[b], un = io.u_num[b];
-        const int path = (pn == 0.f) ? 0 : (pn == 1.f) ? 1 : (pn == 2.f) ? 2 : 3;
         const f32x4 newp = io.ref_appended != nullptr ? reinterpret_cast<const f32x4*>(io.ref_appended)[b]
-                                                      : ref_point(env.ref_c, RADD(nt, pdt), path, un == 0.f ? 0 : 1);
+                                                      : ref_point_ids(env.ref_c, RADD(nt, pdt), pn, un);
         const f32x4* rin = reinterpret_cast<const f32x4*>(io.ref_points) + (size_t)b * (P + 1);
         f32x4* rout = reinterpret_cast<f32x4*>(io.next_ref_points) + (size_t)b * (P + 1);
         float cn, snn;

@@ -1,0 +1,261 @@
+"""Strict reference points: the reference trajectories of the veh3dofconti / veh2dofconti families evaluated on the HOST.
+
+Why this exists.  Every rollout step of these models appends one reference point (x, y, phi, u)(t) to the preview window
+(gops/env/env_ocp/env_model/pyth_veh3dofconti_model.py:108-129), and its heading is a 1 ms finite difference evaluated in
+fp32 (gops/env/env_ocp/resources/ref_traj_model.py:144-148): `atan2(y(t + 0.001) - y(t), x(t + 0.001) - x(t))`.  The difference
+amplifies the LAST BIT of `torch.sin` / `torch.cos` ~1e3 times.  The kernels (csrc/aux_kernels.hip `ref_point`) round every
+product and sum like the reference, but evaluate sin / cos correctly rounded; the reference's values come from the vector math
+library behind `torch.sin` on the host (MKL VML in high-accuracy mode for contiguous fp32 tensors: faithfully, not always
+correctly, rounded; closed source), so ~5 % of the sines differ by one ulp and up to 8 of 48 appended headings of a step move
+by <= 1.25e-3 rad.  A random-init policy ignores that; the gradient of a TRAINED tracking policy moves by 4e-5 .. 1.6e-4.
+
+What this is.  `HostRefTraj.appended_points` evaluates the appended points of a whole rollout, [B, H, 4], with the very torch
+CPU operations the reference executes - the same operands rounded at the same places, the same library behind sin / cos -, so
+its values ARE the reference's on the host it runs on.  Algorithms built with `strict_reference_points=True` hand them to the
+kernels as `GopsRolloutIn.ref_appended` (include/gops_hip.h; `gops_env_step`: `GopsStepIO.ref_appended`); nothing else of the
+step is computed on the host.  It is policy independent, so `ReferencePointPipeline` evaluates the points of the NEXT batch on a
+side thread while the GPU works on the current one (trainers call `alg.prefetch_reference_points(next_batch)`).
+
+Work saved against the reference without changing a bit: the reference evaluates all 4 paths x 2 speed profiles for every
+sample and selects by `sum_i (id == i) * f_i(t)` (ref_traj_model.py:54-84, 138-142, 158-163).  With finite f_i that sum is
+f_selected(t) + 0.0 exactly (the other terms are +-0), so each sample is evaluated on ITS profile only - rows are grouped by
+(path, speed) - and `+ 0.0` is applied where the reference sums (it turns -0 into +0, as the sum does).  sin / cos of MKL VML are
+position independent (tests/test_host_cpu.py checks that on the running host).  `torch.atan2` is Sleef's u10 routine inside full
+vectors (its loop takes two vectors per trip) and libm's atan2f in the loop's scalar tail: evaluation jobs are padded to multiples
+of 32 so that every element takes the vector routine, and the headings of the samples that sit in the tail of the REFERENCE's
+[B]-shaped call (the last B mod 32 of a batch) are redone through the scalar routine (`_scalar_tail`), as the reference's are.
+"""
+import os
+import threading
+from concurrent.futures import Future, ThreadPoolExecutor
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from gops_amd.env.env_ocp.resources.ref_traj_params import ref_constants
+
+_FD_DT = 0.001   # ref_traj_model.py:145
+
+
+class HostRefTraj:
+    """The reference trajectories with torch CPU ops.  `ref_c`: the 24 folded constants of `ref_traj_params.ref_constants` (the
+    same table the kernels read as `GopsEnv.ref_c`; Python floats - torch rounds them to fp32 where they meet an fp32 tensor, which
+    is where the reference's Python scalars are rounded)."""
+
+    def __init__(self, ref_c: Optional[Sequence[float]] = None, dt: float = 0.1, workers: Optional[int] = None):
+        self.c = [float(v) for v in (ref_c if ref_c is not None else ref_constants())]
+        self.dt = float(dt)
+        # evaluation jobs (<= _CHUNK elements of one profile each) CAN run side by side, but 10 us torch ops under one GIL do
+        # not scale (measured: 8 threads are 4x slower than one) - one worker unless told otherwise
+        self.workers = 1 if workers is None else int(workers)
+        self._pool: Optional[ThreadPoolExecutor] = None
+
+    def _executor(self) -> ThreadPoolExecutor:
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="gops-reftraj")
+        return self._pool
+
+    # -- one profile each: t is a contiguous fp32 CPU tensor ---------------------------------------------------------------------
+    def _arc(self, t, speed: int):
+        """compute_integrate_u (ref_traj_model.py:104-124)."""
+        c = self.c
+        if speed == 0:
+            return c[0] * torch.cos(c[1] * t + c[2]) + c[3] * t + c[4]
+        if speed == 1:
+            return c[6] * t
+        return torch.zeros_like(t)   # a speed id outside the registered set: no term of the reference's sum is selected
+
+    def _x_path(self, t, path: int, speed: int):
+        """RefTrajModel.compute_x of one path (:158-163, 180-184, 203-207, 222-226): the speed sum is `+ 0.0`."""
+        arc = self._arc(t, speed) + 0.0
+        if path == 3:
+            return self.c[22] * torch.sin(arc / self.c[22])
+        return arc
+
+    def _y_path(self, t, path: int, speed: int):
+        c = self.c
+        if path == 0:      # SineRefTrajModel.compute_y :165-166
+            return c[7] * torch.sin(c[8] * t + c[9])
+        if path == 1:      # DoubleLaneRefTrajModel.compute_y :186-198 (values times 0 / 1 masks, summed)
+            y2 = c[16] * (t - c[10]) + c[14]
+            y4 = c[17] * (t - c[12]) + c[15]
+            f = lambda m: m.to(torch.float32)   # noqa: E731  (bool * float promotes the mask to 1.0 / 0.0: converted once here)
+            le1, le2, le3, le4 = t <= c[10], t <= c[11], t <= c[12], t <= c[13]
+            m1, m2, m3, m4, m5 = f(le1), f(~le1 & le2), f(~le2 & le3), f(~le3 & le4), f(~le4)
+            return c[14] * m1 + y2 * m2 + c[15] * m3 + y4 * m4 + c[14] * m5
+        if path == 2:      # TriangleRefTrajModel.compute_y :209-216
+            s = torch.remainder(t, c[18])
+            up = s <= c[21]
+            return (c[19] * s) * up.to(torch.float32) + (c[20] * (s - c[18])) * (~up & (s < c[18])).to(torch.float32)
+        arc = self._arc(t, speed) + 0.0   # CircleRefTrajModel.compute_y :228-232
+        return c[22] * (torch.cos(arc / c[22]) - 1)
+
+    def _u(self, t, speed: int):
+        c = self.c
+        if speed == 0:     # SineRefSpeedModel.compute_u :115-116
+            return c[5] * torch.sin(c[1] * t + c[2]) + c[3]
+        if speed == 1:
+            return c[6] * torch.ones_like(t)
+        return torch.zeros_like(t)
+
+    def _point(self, t, path: int, speed: int):
+        """(x, y, phi, u, dy, dx)(t) of one profile, [6, n]: MultiRefTrajModel.compute_{x, y, phi, u} (:54-84) for rows whose ids
+        select it; phi from torch.atan2's vector routine (n is a multiple of 32), dy / dx for the rows `_scalar_tail` redoes."""
+        x0, y0 = self._x_path(t, path, speed), self._y_path(t, path, speed)
+        t1 = t + _FD_DT
+        dx = self._x_path(t1, path, speed) - x0
+        dy = self._y_path(t1, path, speed) - y0
+        return torch.stack((x0 + 0.0, y0 + 0.0, torch.atan2(dy, dx) + 0.0, (self._u(t, speed) + 0.0) + 0.0, dy, dx))
+
+    @staticmethod
+    def _atan2_loop_width():
+        """Elements per trip of the vectorised loop behind `torch.atan2` on this host (two vectors), or None when unknown."""
+        return {"AVX512": 32, "AVX2": 16}.get(torch.backends.cpu.get_cpu_capability())
+
+    def _scalar_tail(self, out: torch.Tensor) -> None:
+        """The reference calls `torch.atan2` on [B] tensors, one per step: on one thread (B below torch's grain size of 32 768) the
+        vectorised loop covers B - B mod W elements and the LAST B mod W samples go through the scalar libm routine, which may
+        differ from the vector one by an ulp.  Redo those samples' headings the same way (a tensor shorter than W takes the
+        scalar routine for every element).  out: [B, L, 6]."""
+        B, W = out.shape[0], self._atan2_loop_width()
+        if W is None or B >= 32768 or B % W == 0:
+            return
+        tail = B - B % W
+        dy, dx = out[tail:, :, 4].reshape(-1), out[tail:, :, 5].reshape(-1)
+        phi = torch.cat([torch.atan2(dy[i:i + W - 1].contiguous(), dx[i:i + W - 1].contiguous()) for i in range(0, dy.numel(), W - 1)])
+        out[tail:, :, 2] = (phi + 0.0).reshape(B - tail, -1)   # (rows of an unknown path: atan2(0, 0) = 0, as before)
+
+    _CHUNK = 16384   # elements per evaluation job: a multiple of 32, below torch's intra-op grain size (every op of a job runs on
+                     # the calling thread, and no element of torch.atan2's loop lands in a scalar tail)
+
+    def points_at(self, t: torch.Tensor, path_num: torch.Tensor, u_num: torch.Tensor) -> torch.Tensor:
+        """(x, y, phi, u) at times `t` [..., B] for per-sample ids [B]: [..., B, 4] (fp32, CPU).  Ids outside the registered sets
+        select nothing, as every mask of the reference's sums is false: an unknown path gives zeros, an unknown speed profile
+        zero arc length and speed under a known path."""
+        t = t.detach().to(device="cpu", dtype=torch.float32)
+        lead, B = t.shape[:-1], t.shape[-1]
+        t2 = t.reshape(-1, B)
+        L = t2.shape[0]
+        pn = path_num.detach().to(device="cpu", dtype=torch.float32).reshape(B)
+        un = u_num.detach().to(device="cpu", dtype=torch.float32).reshape(B)
+        valid = (pn == 0) | (pn == 1) | (pn == 2) | (pn == 3)
+        speed = torch.where((un == 0) | (un == 1), un, torch.full_like(un, 2.0))   # 2: a speed id outside the registered set
+        combo = torch.where(valid, 3 * pn + speed, torch.full_like(pn, -1.0)).to(torch.int64)
+        order = torch.argsort(combo, stable=True)           # samples grouped by profile
+        counts = torch.bincount(combo[order] + 1, minlength=13).tolist()   # [unknown path, (path, speed) 0 .. 11]
+        tg = t2[:, order].t().contiguous().reshape(-1)      # sample-major: one profile's elements are one contiguous run
+        jobs, pos = [], counts[0] * L
+        for cid in range(12):
+            n = counts[cid + 1] * L
+            for a in range(pos, pos + n, self._CHUNK):
+                jobs.append((cid, a, min(a + self._CHUNK, pos + n)))
+            pos += n
+        res = torch.zeros(6, B * L, dtype=torch.float32)
+
+        def run(job):
+            cid, a, b = job
+            seg = tg[a:b]
+            pad = (-(b - a)) % 32
+            if pad:
+                seg = torch.cat((seg, seg[-1:].expand(pad)))
+            res[:, a:b] = self._point(seg, cid // 3, cid % 3)[:, :b - a]
+
+        if len(jobs) > 1 and self.workers > 1:
+            list(self._executor().map(run, jobs))
+        else:
+            for j in jobs:
+                run(j)
+        out = torch.empty(B, L, 6, dtype=torch.float32)
+        out[order] = res.t().reshape(B, L, 6)
+        self._scalar_tail(out)
+        return out[:, :, :4].permute(1, 0, 2).reshape(*lead, B, 4).contiguous()
+
+    def appended_points(self, ref_time: torch.Tensor, path_num: torch.Tensor, u_num: torch.Tensor, horizon: int,
+                        pre_horizon: int) -> torch.Tensor:
+        """The `horizon` points a rollout from `ref_time` appends: [B, horizon, 4].  Step k appends the point at
+        (t_k + dt) + pre_horizon * dt with t_{k+1} = t_k + dt accumulated in fp32 (pyth_veh3dofconti_model.py:106-128)."""
+        t = ref_time.detach().to(device="cpu", dtype=torch.float32).reshape(-1)
+        steps = []
+        for _ in range(int(horizon)):
+            t = t + self.dt
+            steps.append(t)
+        times = torch.stack(steps) + pre_horizon * self.dt     # [H, B]; `pre_horizon * dt` is folded in double first, as in Python
+        return self.points_at(times, path_num, u_num).permute(1, 0, 2).contiguous()
+
+
+class ReferencePointPipeline:
+    """Device-side delivery of `HostRefTraj.appended_points`: `request(data)` starts the evaluation for a batch on a side thread
+    (device -> host copy of the three per-sample scalars, the CPU evaluation, host -> device copy of the [B, H, 4] table on a side
+    stream), `collect(data)` returns the device tensor - waiting on the side thread only if it has not finished, computing on the
+    spot if nothing was requested.  Requests are matched by the identity of `data["ref_time"]`."""
+
+    def __init__(self, traj: HostRefTraj, pre_horizon: int):
+        self.traj, self.pre_horizon = traj, int(pre_horizon)
+        self._pool: Optional[ThreadPoolExecutor] = None
+        self._pending: Dict[int, tuple] = {}
+        self._lock = threading.Lock()
+        self._stream = None
+        self.evaluated = 0   # batches evaluated (tests / the bench line read it)
+
+    def _side_stream(self, device):
+        if self._stream is None or self._stream.device != device:
+            self._stream = torch.cuda.Stream(device=device)
+        return self._stream
+
+    def _evaluate(self, data, horizon: int, device, produced: Optional["torch.cuda.Event"]):
+        keys = [data["ref_time"], data["path_num"], data["u_num"]]
+        if device is None or device.type != "cuda":
+            pts = self.traj.appended_points(*keys, horizon, self.pre_horizon)
+            self.evaluated += 1
+            return pts, None
+        side = self._side_stream(device)
+        with torch.cuda.stream(side):
+            if produced is not None:
+                side.wait_event(produced)
+            host = []
+            for k in keys:
+                if k.is_cuda:
+                    h = torch.empty(k.shape, dtype=k.dtype, pin_memory=True)
+                    h.copy_(k, non_blocking=True)
+                    host.append(h)
+                else:
+                    host.append(k)
+            side.synchronize()
+            pts = self.traj.appended_points(*host, horizon, self.pre_horizon).pin_memory()
+            dev = pts.to(device, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(side)
+            self._keep = pts   # the pinned source outlives the copy
+        self.evaluated += 1
+        return dev, ready
+
+    def request(self, data, horizon: int, device) -> None:
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gops-refpoints")
+        produced = None
+        if device is not None and device.type == "cuda" and data["ref_time"].is_cuda:
+            produced = torch.cuda.Event()
+            produced.record(torch.cuda.current_stream(device))   # the batch may still be in flight on the caller's stream
+        fut: Future = self._pool.submit(self._evaluate, data, int(horizon), device, produced)
+        with self._lock:
+            if len(self._pending) > 8:   # requests nobody collected
+                self._pending.pop(next(iter(self._pending)))
+            self._pending[id(data["ref_time"])] = (data["ref_time"], int(horizon), fut)
+
+    def collect(self, data, horizon: int, device) -> torch.Tensor:
+        with self._lock:
+            entry = self._pending.pop(id(data["ref_time"]), None)
+        if entry is not None and entry[0] is data["ref_time"] and entry[1] == int(horizon):
+            dev, ready = entry[2].result()
+        else:
+            dev, ready = self._evaluate(data, int(horizon), device, None)
+        if ready is not None:
+            cur = torch.cuda.current_stream(device)
+            cur.wait_event(ready)
+            dev.record_stream(cur)
+        return dev
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None

@@ -164,10 +164,10 @@ def cpu_baseline(cfg, seed, workload, eager_gpu=False):
 
     def sweep(fn):
         res = {}
-        for nthreads in sorted({4, min(16, ncpu), min(64, ncpu)}):
+        for nthreads in sorted({4, min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
             torch.set_num_threads(nthreads)
             times = []
-            for i in range(3):
+            for i in range(4):
                 t0 = time.perf_counter()
                 fn()
                 times.append((time.perf_counter() - t0) / calls_per_unit)
@@ -208,7 +208,7 @@ def cpu_baseline(cfg, seed, workload, eager_gpu=False):
            "by_threads": {str(n): steps_per_call / t for n, t in timed.items()},
            "port_by_threads": {str(n): steps_per_call / t for n, t in port.items()},
            "eager_gpu_steps_per_s": eager,
-           "sample": f"{B} of the workload's {full_batch} trajectories x H={cfg['horizon']}; per thread count 1 warm-up + 2 "
+           "sample": f"{B} of the workload's {full_batch} trajectories x H={cfg['horizon']}; per thread count 1 warm-up + 3 "
                      f"timed gradient evaluations (fwd+bwd{', PEV and PIM averaged' if calls_per_unit == 2 else ''}), best; "
                      + ", ".join(f"{n} threads: {t * 1e3:.0f} ms" for n, t in timed.items())
                      + f"; host: {host['cpu_model']}, {host['sockets']} socket(s), {host['physical_cores']} physical cores, "
@@ -267,11 +267,18 @@ def kernel_bytes(c):
 
 
 def pmc_traffic(pmc, source, kernel_key):
+    """Flat scalars of the dominant kernel from the committed counters: HBM bytes per launch (None without a profile of this
+    workload), where they come from, and the share of cycles its matrix pipe was busy."""
     if pmc is None:
-        return None
+        return {"traffic": None, "traffic_bytes": None, "traffic_source": None, "mfma_busy_pct": None}
     # several instantiations can share the name (the value net runs the ENV_NONE one): the rollout's is the largest
-    hits = [kernel_bytes(c) for name, c in pmc.items() if kernel_key in name and kernel_bytes(c) is not None]
-    return {"bytes": max(hits), "source": source} if hits else None
+    hits = [(kernel_bytes(c), c) for name, c in pmc.items() if kernel_key in name and kernel_bytes(c) is not None]
+    if not hits:
+        return {"traffic": None, "traffic_bytes": None, "traffic_source": source, "mfma_busy_pct": None}
+    nbytes, c = max(hits, key=lambda h: h[0])
+    gui = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0   # (summed over the 8 XCDs)
+    busy = 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * gui) if gui and "SQ_VALU_MFMA_BUSY_CYCLES" in c else None
+    return {"traffic": nbytes, "traffic_bytes": nbytes, "traffic_source": source, "mfma_busy_pct": busy}
 
 
 def free_port():
@@ -333,8 +340,8 @@ def roofline_of(cfg, dt, kern, pmc, pmc_src, workload, variant=0):
         achieved = flops[dom] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": peak_tf,
                     "unit": "TFLOP/s", "frac": achieved / peak_tf,
-                    "traffic": pmc_traffic(pmc, pmc_src, KERNEL_NAMES[dom].split("(")[0]),
-                    "algorithmic_flops_per_launch": flops[dom], "avg_ms": dom_ms}
+                    **pmc_traffic(pmc, pmc_src, KERNEL_NAMES[dom].split("(")[0]),
+                    "algorithmic_flops_per_launch": flops[dom], "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_ms": dom_ms}
         if variant & 5:   # plane-split contractions (stationary: bit 0, streamed: bit 2): 3 MFMAs of 16x16x32 per fp32 block, in the H2 weight-gradient GEMM as well
             # The roof is the one of the instructions the kernel ISSUES (dense bf16 / f16 MFMA, 2.5 PF), `achieved` the issued
             # flops = products_per_mac x the algorithmic ones; the comparison with what an exact-fp32 contraction could reach on
@@ -357,8 +364,10 @@ def roofline_of(cfg, dt, kern, pmc, pmc_src, workload, variant=0):
         achieved = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic(pmc, pmc_src, KERNEL_NAMES[dom].split("(")[0]),
+                    **pmc_traffic(pmc, pmc_src, KERNEL_NAMES[dom].split("(")[0]),
                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_ms": dom_ms}
+    # the one scalar that says whether the kernel re-reads: counter bytes over algorithmic bytes of the same launch
+    roofline["traffic_over_algorithmic"] = (roofline["traffic_bytes"] / alg_bytes[dom]) if roofline.get("traffic_bytes") else None
     return roofline, flops
 
 
@@ -455,16 +464,23 @@ def parity_stamp(alg, cfg, workload, device, variant_name):
 
 
 
-def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, check_parity=False, overlap=True, label=None):
+def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, check_parity=False, overlap=True, label=None,
+                 strict_refpoints=False, dp_path=False):
     """Times `steps` updates of one workload on this rank's GPU (all ranks call it together) and returns the
-    measurements; rank 0 turns them into the record."""
+    measurements; rank 0 turns them into the record.
+    strict_refpoints: the algorithm is built with `strict_reference_points=True` (the appended reference points of every update's
+    batch are evaluated on the host with the reference's own torch CPU ops, env/env_ocp/resources/ref_traj_host.py); the loop then
+    rotates over four batches and asks for the next batch's points before it queues the current update - what a trainer that
+    draws its batches one ahead pays.  dp_path (one rank): the update runs as the data-parallel trainers run it -
+    get_remote_update_info (two-phase backward, the collectives' start points) -> average_ -> remote_update - with the
+    collectives themselves left out: the fixed cost of that path against the fused local update."""
     rank, world, device, dist = ctx["rank"], ctx["world"], ctx["device"], ctx["dist"]
     cfg = CONFIGS[workload]
     torch.manual_seed(0)   # identical random-init weights on every replica
     # kernel variants travel in the descriptors (GopsRolloutDesc.variant_flags); the algorithm classes build theirs from this default
     saved_flags, hb.DEFAULT_VARIANT_FLAGS = hb.DEFAULT_VARIANT_FLAGS, flags
     with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
-        alg = create_alg(**alg_kwargs(cfg, 0), mlp_dtype=dtype)
+        alg = create_alg(**alg_kwargs(cfg, 0), mlp_dtype=dtype, strict_reference_points=strict_refpoints)
     alg.networks.to(device)
     if cfg["alg"] == "INFADP":   # cfg3 / cfg5: one step = one local_update, PEV and PIM alternate
         alg.gamma, alg.forward_step = cfg["gamma"], cfg["horizon"]
@@ -472,10 +488,17 @@ def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, ch
     if check_parity and rank == 0 and dtype == "fp32":
         parity = parity_stamp(alg, cfg, workload, device, label or ("exact fp32 MFMA (GOPS_VF_STREAMED_FP32 | GOPS_VF_DW_F32)" if flags else "default"))
     data = {k: v.to(device) for k, v in make_batch(cfg, 1000 + rank).items()}   # per-rank shard
-    reducer = GradAllReducer(overlap=overlap)   # (overlap=False: one flat all-reduce behind the whole backward)
+    rotation = [data] + [{k: v.to(device) for k, v in make_batch(cfg, 2000 + 10 * j + rank).items()} for j in range(3)] if strict_refpoints else None
+    reducer = GradAllReducer(overlap=overlap, single_rank_phases=dp_path)   # (overlap=False: one flat all-reduce behind the whole backward)
+    if rotation is not None:
+        alg.prefetch_reference_points(rotation[0])
 
     def step(it):
-        if world == 1:
+        if rotation is not None:   # a fresh batch per update: its points were asked for one update ago, the next one's are asked for now
+            cur = rotation[it % len(rotation)]
+            alg.prefetch_reference_points(rotation[(it + 1) % len(rotation)])
+            alg.local_update(cur, it)
+        elif world == 1 and not dp_path:
             alg.local_update(data, it)
         else:
             if getattr(alg, "supports_overlapped_reduce", False):   # the all-reduce of the early gradients overlaps the rest of the backward
@@ -526,13 +549,20 @@ def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, ch
     for ro in list(getattr(alg, "_rollouts", {}).values()) + [o for o in getattr(alg, "_cache", {}).values() if hasattr(o, "desc")]:
         variant |= max(0, hb.lib().gops_rollout_variant(ro.desc))
     payload = None
+    if strict_refpoints and alg._reference_pipeline() is not None:
+        alg._reference_pipeline().close()
     if world > 1:   # what one update all-reduces: the flat gradient buffer(s) of the network(s) it trains
         payload = {name: sum(p.numel() for p in net.parameters()) * 4 for name, net in alg.networks.net_dict.items()} \
             if hasattr(alg.networks, "net_dict") else {"policy": sum(p.numel() for p in alg.networks.policy.parameters()) * 4}
-    del alg, data
+    evaluated = None
+    if strict_refpoints:
+        pipe = alg._reference_pipeline()
+        evaluated = None if pipe is None else pipe.evaluated
+    del alg, data, rotation
     torch.cuda.empty_cache()
     hb.DEFAULT_VARIANT_FLAGS = saved_flags
-    return {"elapsed": elapsed, "kern": kern, "variant": variant, "parity": parity, "allreduce_payload_bytes": payload, "finite": finite}
+    return {"elapsed": elapsed, "kern": kern, "variant": variant, "parity": parity, "allreduce_payload_bytes": payload, "finite": finite,
+            "refpoint_batches_evaluated": evaluated}
 
 
 def record_of(workload, dtype, steps, warmup, world, m):
@@ -547,17 +577,22 @@ def record_of(workload, dtype, steps, warmup, world, m):
     bps = bytes_per_step(cfg, dt)
     # whole-update fractions of both roofs (SURVEY 8d asks for both next to each other)
     per_step_flops = 6.0 * mac_per_step(cfg)
-    hbm_measured = None
+    hbm_measured, update_bytes = None, None
     if pmc is not None:   # counter bytes of every kernel of one update / the update's time
         tot = [kernel_bytes(c) * c.get("launches_per_update", 1.0) for c in pmc.values() if kernel_bytes(c) is not None]
         if tot:
-            hbm_measured = sum(tot) / (elapsed / steps) / 1e9 / HBM_PEAK_GBS
+            update_bytes = sum(tot)
+            hbm_measured = update_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS
+    split = bool(m.get("variant", 0) & 5)
+    arithmetic = ("f16 storage + MFMA, fp32 accumulate/env/results" if dt == "f16" else
+                  "2xf16 planes (22-bit operands), fp32 accumulate" if split else "fp32 MFMA (v_mfma_f32_16x16x4_f32)")
     alg_name = cfg["alg"]
     return {
         "metric": f"env-model steps/sec (batch x H), {alg_name} compute_gradient + update",
         "value": value, "unit": "env-model steps/s", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt,
+        "arithmetic": arithmetic,
         "data": "synthetic (seeded initial states, random-init networks)",
         "config": {"workload": workload, "env_id": cfg["env_id"], "algorithm": alg_name,
                    "batch_per_gpu": B, "horizon": H, "policy_mlp": mlp_sizes(cfg),
@@ -568,6 +603,9 @@ def record_of(workload, dtype, steps, warmup, world, m):
         "alg_hbm_fraction": value / world * bps / (HBM_PEAK_GBS * 1e9),
         "hbm_fraction": hbm_measured,
         "hbm_fraction_source": pmc_src if hbm_measured is not None else None,
+        "update_traffic_bytes": update_bytes,                        # counters, every kernel of one update
+        "update_algorithmic_bytes": 1.5 * bps * B * H,               # stash written once, read by the sweep, read by the weight-gradient GEMMs
+        "update_traffic_over_algorithmic": (update_bytes / (1.5 * bps * B * H)) if update_bytes else None,
         "kernels_ms": {KERNEL_NAMES[k]: {"avg_ms": kern[k][0], "launches": kern[k][1],
                                          "tflops": (flops[k] / (kern[k][0] * 1e-3) / 1e12) if kern[k][0] > 0 else 0.0}
                        for k in kern if kern[k][1] > 0},
@@ -597,6 +635,11 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16"],
                     help="arithmetic of the MLP contractions: fp32 (exact, parity path) or fp16 (half-precision MFMA, BASELINE cfg5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-path", action="store_true",
+                    help="one rank: time the data-parallel update path (get_remote_update_info with the two-phase backward -> average_ -> "
+                         "remote_update) without collectives instead of the fused local update")
+    ap.add_argument("--strict-refpoints", action="store_true",
+                    help="build the algorithm with strict_reference_points=True (host-evaluated appended reference points, one batch ahead)")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--eager-gpu-baseline", action=argparse.BooleanOptionalAction, default=True,
                     help="also time the oracle restatement as PyTorch eager ops on the GPU (FHADP workloads; ~1 s; reported "
@@ -638,7 +681,8 @@ def main():
     ctx = {"rank": rank, "world": world, "device": device, "dist": dist}
 
     workload = args.workload or HEADLINE
-    m = run_workload(workload, args.dtype, args.steps, args.warmup, min(args.steps, 100), ctx, check_parity=True)
+    m = run_workload(workload, args.dtype, args.steps, args.warmup, min(args.steps, 100), ctx, check_parity=True,
+                     dp_path=args.dp_path and world == 1, strict_refpoints=args.strict_refpoints)
     out = record_of(workload, args.dtype, args.steps, args.warmup, world, m) if rank == 0 else None
     if world > 1:
         # N > 1: say what carried the gradients, time the collective alone, and time the update loop a second time with the
@@ -678,8 +722,10 @@ def main():
 
         def brief(r):
             return {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "dtype": r["dtype"],
+                    "arithmetic": r["arithmetic"],
                     "roofline": {k: r["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_ms", "frac_vs_fp32_roof",
-                                                               "products_per_mac", "mfma_issued") if k in r["roofline"]},
+                                                               "products_per_mac", "traffic", "traffic_over_algorithmic", "mfma_busy_pct")
+                                 if k in r["roofline"]},
                     "kernel_variant": r["kernel_variant"], "parity": r.get("parity"), "weights_finite_after_run": r.get("weights_finite_after_run"),
                     "kernels_ms": {k: v["avg_ms"] for k, v in r["kernels_ms"].items()}}
         k_steps, k_warm = min(args.steps, 20), min(args.warmup, 5)
@@ -713,6 +759,26 @@ def main():
             "what": "every `interval` updates the algorithm classes form the batch's gradient twice more (own kernels, exact-fp32 rollout kernels) and "
                     "compare; the bench loop times compute_gradient + Adam without it - amortized_cost_fraction = (t_default + t_guard_fallback) "
                     "/ (interval * t_default) is what a training run pays on top of `value`"}
+        # strict reference points (opt-in parity mode): the appended points of every update's batch from the host's torch
+        # CPU ops, a fresh batch per update, the next batch's points evaluated on a side thread while the GPU works on this one -
+        # rate and parity stamp of the target and of cfg3 (whose default stamp is the appended-heading effect)
+        for name, key in ((workload, "target_strict_refpoints"), ("cfg3_veh3dof_infadp_b8192", "cfg3_strict_refpoints")):
+            mm = run_workload(name, "fp32", k_steps, k_warm, 0, ctx, check_parity=True, strict_refpoints=True,
+                              label="default kernels, strict_reference_points=True")
+            cfgn = CONFIGS[name]
+            others[key] = {"workload": name, "value": cfgn["batch"] * cfgn["horizon"] * k_steps / mm["elapsed"],
+                           "ms_per_step": mm["elapsed"] / k_steps * 1e3, "steps": k_steps, "parity": mm["parity"],
+                           "refpoint_batches_evaluated": mm["refpoint_batches_evaluated"],
+                           "what": "strict_reference_points=True: [B, H, 4] appended reference points per update from the host "
+                                   "(torch CPU ops = the reference's own values), prefetched one batch ahead; the update is host-bound"}
+        # the data-parallel update path on ONE rank, collectives left out: get_remote_update_info (two-phase backward) -> average_ ->
+        # remote_update against the fused local update of the headline - the path's fixed cost, so that an N > 1 efficiency is
+        # attributable to the collective alone
+        mm = run_workload(workload, "fp32", k_steps, k_warm, min(k_steps, 10), ctx, dp_path=True)
+        others["dp_path_n1"] = dict(brief(record_of(workload, "fp32", k_steps, k_warm, world, mm)), workload=workload,
+                                    what="the N > 1 update path (two-phase backward, average_, remote_update) on one rank without collectives")
+        others["dp_path_n1"]["vs_headline"] = others["dp_path_n1"]["value"] / out["value"]
+        out["strict_fp32_value"] = others["exact_fp32_stationary"]["value"]   # every product an fp32 MFMA (workloads.exact_fp32_stationary)
         out["workloads"] = others
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

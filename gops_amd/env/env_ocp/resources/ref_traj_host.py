@@ -37,6 +37,20 @@ from gops_amd.env.env_ocp.resources.ref_traj_params import ref_constants
 _FD_DT = 0.001   # ref_traj_model.py:145
 
 
+class _single_threaded:
+    """Context: torch's intra-op thread count of the CALLING thread set to one, restored on exit (`torch.set_num_threads` sets the
+    calling thread's OpenMP ICV and MKL's thread-local count: other threads keep theirs)."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        if self.n != 1:
+            torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        if self.n != 1:
+            torch.set_num_threads(self.n)
+
+
 class HostRefTraj:
     """The reference trajectories with torch CPU ops.  `ref_c`: the 24 folded constants of `ref_traj_params.ref_constants` (the
     same table the kernels read as `GopsEnv.ref_c`; Python floats - torch rounds them to fp32 where they meet an fp32 tensor, which
@@ -45,14 +59,18 @@ class HostRefTraj:
     def __init__(self, ref_c: Optional[Sequence[float]] = None, dt: float = 0.1, workers: Optional[int] = None):
         self.c = [float(v) for v in (ref_c if ref_c is not None else ref_constants())]
         self.dt = float(dt)
-        # evaluation jobs (<= _CHUNK elements of one profile each) CAN run side by side, but 10 us torch ops under one GIL do
-        # not scale (measured: 8 threads are 4x slower than one) - one worker unless told otherwise
+        # Every op runs with ONE intra-op thread (`_single_threaded`): the ops are 10 - 50 us each, and the vector math library's own
+        # threading (MKL VML spreads a 16 K-element sin over every core it may use) makes them SLOWER - measured on the 2 x 64-core
+        # GPU host: 76 ms per [4096, 30] batch with torch's default 128 threads, 4.0 ms with one.  Evaluation jobs (<= _CHUNK
+        # elements of one profile each) CAN run side by side on `workers` threads, but such small ops serialise on the GIL
+        # (same host: 2 workers 4.9 ms, 4 workers 8.1 ms) - one worker unless told otherwise
         self.workers = 1 if workers is None else int(workers)
         self._pool: Optional[ThreadPoolExecutor] = None
 
     def _executor(self) -> ThreadPoolExecutor:
         if self._pool is None:
-            self._pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="gops-reftraj")
+            self._pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="gops-reftraj",
+                                            initializer=torch.set_num_threads, initargs=(1,))   # (per-thread setting: OpenMP ICV, MKL local)
         return self._pool
 
     # -- one profile each: t is a contiguous fp32 CPU tensor ---------------------------------------------------------------------
@@ -129,6 +147,10 @@ class HostRefTraj:
                      # the calling thread, and no element of torch.atan2's loop lands in a scalar tail)
 
     def points_at(self, t: torch.Tensor, path_num: torch.Tensor, u_num: torch.Tensor) -> torch.Tensor:
+        with _single_threaded():
+            return self._points_at(t, path_num, u_num)
+
+    def _points_at(self, t: torch.Tensor, path_num: torch.Tensor, u_num: torch.Tensor) -> torch.Tensor:
         """(x, y, phi, u) at times `t` [..., B] for per-sample ids [B]: [..., B, 4] (fp32, CPU).  Ids outside the registered sets
         select nothing, as every mask of the reference's sums is false: an unknown path gives zeros, an unknown speed profile
         zero arc length and speed under a known path."""
@@ -174,13 +196,14 @@ class HostRefTraj:
                         pre_horizon: int) -> torch.Tensor:
         """The `horizon` points a rollout from `ref_time` appends: [B, horizon, 4].  Step k appends the point at
         (t_k + dt) + pre_horizon * dt with t_{k+1} = t_k + dt accumulated in fp32 (pyth_veh3dofconti_model.py:106-128)."""
-        t = ref_time.detach().to(device="cpu", dtype=torch.float32).reshape(-1)
-        steps = []
-        for _ in range(int(horizon)):
-            t = t + self.dt
-            steps.append(t)
-        times = torch.stack(steps) + pre_horizon * self.dt     # [H, B]; `pre_horizon * dt` is folded in double first, as in Python
-        return self.points_at(times, path_num, u_num).permute(1, 0, 2).contiguous()
+        with _single_threaded():
+            t = ref_time.detach().to(device="cpu", dtype=torch.float32).reshape(-1)
+            steps = []
+            for _ in range(int(horizon)):
+                t = t + self.dt
+                steps.append(t)
+            times = torch.stack(steps) + pre_horizon * self.dt     # [H, B]; `pre_horizon * dt` is folded in double first, as in Python
+            return self._points_at(times, path_num, u_num).permute(1, 0, 2).contiguous()
 
 
 class ReferencePointPipeline:

@@ -43,21 +43,26 @@ def _as_one_buffer(tensors: List[torch.Tensor]):
 class GradAllReducer:
     """In-place mean of `update_info` (dict: name -> list of gradient tensors) over all ranks."""
 
-    def __init__(self, group=None, overlap: bool = True):
+    def __init__(self, group=None, overlap: bool = True, single_rank_phases: bool = False):
         self.group = group
         self.overlap = overlap
+        # measurement aid (bench.py --dp-path): with ONE rank, still let the algorithms take the N > 1 code path - two-phase
+        # backward, start points, `_pending` - with nothing to exchange, so that the path's fixed cost can be timed on one GPU
+        self.single_rank_phases = single_rank_phases
         self._works = []
 
     def overlap_enabled(self) -> bool:
         """More than one rank and not switched off: algorithms that can (`supports_overlapped_reduce`) start the all-reduce of
         the gradients that are ready first themselves (`start_`), behind the kernels that produced them."""
-        return self.overlap and world_size() > 1
+        return self.overlap and (world_size() > 1 or self.single_rank_phases)
 
     def start_(self, tensors: List[torch.Tensor]):
         """Asynchronous in-place SUM all-reduce of gradient tensors that tile ONE contiguous slice of a network's gradient
         buffer (`algorithm/base.py:grad_buffers`): the collective waits for what is queued on the current stream so far and runs
         on the process group's own stream - kernels queued afterwards overlap it.  `average_` waits for it.  Tensors that do not
         tile one buffer (gradients installed from outside) are reduced through a flattened copy - slower, never an error."""
+        if world_size() == 1:   # (single_rank_phases: nothing to exchange)
+            return
         flat = _as_one_buffer(tensors)
         if flat is None:
             flat = _flatten_dense_tensors(tensors)
@@ -83,6 +88,7 @@ class GradAllReducer:
         the optimizer step.  Entries whose name starts with "_", and entries that are not lists of tensors, are left alone."""
         n = world_size()
         if n == 1:
+            update_info.pop("_pending", None)
             return update_info
         if update_info.pop("_pending", False):   # the algorithm started the collectives itself (start_): only wait for them
             works, self._works = self._works, []   # (taken over first: whatever happens below, no stale handle survives this call)

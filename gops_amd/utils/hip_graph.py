@@ -44,7 +44,10 @@ class GraphedStep:
         self._dst = [self.static_in[k] for k in self.keys]
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: a side thread may be talking to the runtime while this thread captures (the reference-point pipeline of
+        # `strict_reference_points` evaluates the next batch and copies it over on its own stream, ref_traj_host.py) - under the
+        # default "global" mode its synchronise / allocation calls would invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = fn(self.static_in)
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:

@@ -111,8 +111,11 @@ def test_prefetched_points_equal_the_ones_computed_on_the_spot_and_updates_repla
     cfg = dict(alg="FHADP", env_id="pyth_veh3dofconti", batch=64, horizon=10, pre_horizon=10, hidden=(64, 64), act="elu", gamma=1.0)
     batches = [make_batch(cfg, 40 + i) for i in range(6)]
 
+    sd0 = {k: v.clone() for k, v in create_alg(**_kwargs(cfg, {}, 3)).state_dict().items()}
+
     def run(prefetch):
         alg = create_alg(**dict(_kwargs(cfg, {}, 3), strict_reference_points=True))
+        alg.load_state_dict(sd0)   # (the factories draw fresh initial weights per call)
         alg.networks.cuda()
         dbs = [to_device(b, dev) for b in batches]
         if prefetch:
@@ -122,9 +125,12 @@ def test_prefetched_points_equal_the_ones_computed_on_the_spot_and_updates_repla
                 alg.prefetch_reference_points(dbs[i + 1])
             alg.local_update(b, i)
         torch.cuda.synchronize()
+        assert alg._update_graph.graph is not None and not alg._update_graph.failed   # (B x H = 640: the update replays as a graph)
         return [p.detach().clone() for p in alg.networks.policy.parameters()], alg._reference_pipeline().evaluated
 
     w_a, n_a = run(False)
+    w_a2, _ = run(False)
+    assert all(torch.equal(a, b) for a, b in zip(w_a, w_a2)), "two identical runs differ"
     w_b, n_b = run(True)
     assert n_a == n_b == len(batches)
     assert all(torch.equal(a, b) for a, b in zip(w_a, w_b))

@@ -57,6 +57,16 @@ class AlgorithmBase(metaclass=ABCMeta):
                 self._ref_pipeline = ReferencePointPipeline(HostRefTraj(getattr(m, "ref_c", None), dt=m.dt), m.pre_horizon)
         return self._ref_pipeline or None
 
+    def precision_guards(self):
+        g = getattr(self, "precision_guard", None)
+        return [] if g is None else (list(g.values()) if isinstance(g, dict) else [g])
+
+    def set_lockstep_replicas(self, lockstep: bool = True, group=None) -> None:
+        """Called by trainers whose ranks compute every gradient together (on_sync / off_sync): the precision guards then take
+        their decision with a collective over `group`.  Never called by the asynchronous trainer."""
+        for g in self.precision_guards():
+            g.lockstep, g.group = bool(lockstep), group
+
     def prefetch_reference_points(self, data: dict) -> None:
         """Start evaluating the appended reference points of `data` (a batch a later update / gradient call will receive - the
         same dict, or one holding the same `ref_time` tensor) on the side thread.  No-op unless `strict_reference_points`."""
@@ -156,6 +166,21 @@ class PrecisionGuard:
         self.exact = False        # sticky: the rollout kernels run on exact fp32 products from here on
         self.last_distance = None
         self.checks = 0
+        self.forced = False       # a logged loss was not finite: check the next gradient, whatever the schedule says
+        # Replicas that update in LOCKSTEP (on_sync / off_sync trainers: every rank computes gradient k at the same time) take the
+        # decision together - MAX all-reduce of the measured distance over `group`.  Anything else (a single process, the
+        # asynchronous trainer whose ranks keep their own gradient counts and talk point to point) decides locally: a collective
+        # there would wait for ranks that never enter it.  Set by the trainer (`AlgorithmBase.set_lockstep_replicas`), never
+        # inferred from torch.distributed being initialised.
+        self.lockstep = False
+        self.group = None
+
+    def observe_loss(self, value: float) -> None:
+        """Hook of the algorithms' lazily read loss scalars: a non-finite loss (the plane-split kernels answer a half-range overflow
+        with NaN; the optimizer kernels skip non-finite gradient elements, so the weights are still intact) makes the next
+        gradient a checked one."""
+        if not (value == value and abs(value) != float("inf")) and not self.exact and self.interval > 0:
+            self.forced = True
 
     @staticmethod
     def applies_to(*modules, env_kind=None) -> bool:
@@ -166,7 +191,8 @@ class PrecisionGuard:
         from gops_amd import hip_backend as hb
         if env_kind == hb.ENV_MOBILEROBOT:
             return False
-        return any(all(l.out_features == 256 for l in m.linear_layers()[:-1]) for m in modules)
+        # (a net without a hidden layer has nothing to split: all([]) must not count as "every hidden layer is 256 wide")
+        return any(len(m.linear_layers()) > 1 and all(l.out_features == 256 for l in m.linear_layers()[:-1]) for m in modules)
 
     @staticmethod
     def exact_rollout_flags():
@@ -183,6 +209,9 @@ class PrecisionGuard:
         self.count += 1
         if self.exact or self.interval <= 0 or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
             return False
+        if self.forced and not self.lockstep:   # (lockstep replicas keep to the common schedule: a forced check on one rank only would hang the collective)
+            self.forced = False
+            return True
         return self.count == 1 or self.count % self.interval == 0
 
     def check(self, flat_gradient) -> float:
@@ -193,12 +222,11 @@ class PrecisionGuard:
         g_split = flat_gradient(base)
         g_exact = flat_gradient(base | self.exact_rollout_flags())
         d = (g_split.double() - g_exact.double()).norm() / g_exact.double().norm().clamp_min(1e-300)
-        try:   # data-parallel replicas take the decision together (the largest distance any rank saw)
+        if self.lockstep:   # replicas in lockstep take the decision together (the largest distance any rank saw; NaN from any rank wins)
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                dist.all_reduce(d, op=dist.ReduceOp.MAX)
-        except RuntimeError:
-            pass
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                d = torch.where(torch.isfinite(d), d, torch.full_like(d, float("inf")))
+                dist.all_reduce(d, op=dist.ReduceOp.MAX, group=self.group)
         self.last_distance = float(d.item())
         self.checks += 1
         if not (self.last_distance <= self.threshold):   # (NaN counts as exceeded)

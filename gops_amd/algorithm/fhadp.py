@@ -176,7 +176,7 @@ class FHADP(AlgorithmBase):
         """`out` is what `_gradient_kernels` returned - here the pair [-mean(v_pi), mean(v_pi)] of `gops_mean_loss`; entry 0 is the
         loss.  lazy: leave a device tensor in tb_info (data-parallel path: a view, no launch); else a LazyScalar
         (utils/lazy_scalar.py: read back on first use; GOPS_EAGER_LOG=1: `.item()` right here, as the reference does)."""
-        self.tb_info[tb_tags["loss_actor"]] = out[0] if lazy else scalar(out, 0)
+        self.tb_info[tb_tags["loss_actor"]] = out[0] if lazy else scalar(out, 0, on_value=self.precision_guard.observe_loss)
 
     def _log(self, out):
         self._fill_tb(out)   # host sync, as in the reference
@@ -192,6 +192,7 @@ class FHADP(AlgorithmBase):
     def _signature(self, batch):
         """What a captured graph is specialised on: shapes, rollout settings, parameter / gradient storage."""
         return (tuple((k, tuple(v.shape)) for k, v in batch.items()), self.pre_horizon, float(self.gamma), self._extra_signature(),
+                self._variant_flags(),   # kernel variants are baked into a captured chain: a guard that trips must force a re-capture
                 tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr())
                       for p in self.networks.policy.parameters()),
                 # everything else a captured kernel chain holds raw pointers to: Adam moments / device state

@@ -283,9 +283,10 @@ class INFADP(AlgorithmBase):
     def _log(self, mode: str, scalars: torch.Tensor, start_time: float):
         # (LazyScalar: read back on first use; GOPS_EAGER_LOG=1: host sync here, as in the reference)
         if mode == "v":
-            self.tb_info[tb_tags["loss_critic"]], self.tb_info[tb_tags["critic_avg_value"]] = scalar(scalars, 0), scalar(scalars, 1)
+            self.tb_info[tb_tags["loss_critic"]] = scalar(scalars, 0, on_value=self.precision_guard["v"].observe_loss)
+            self.tb_info[tb_tags["critic_avg_value"]] = scalar(scalars, 1)
         else:
-            self.tb_info[tb_tags["loss_actor"]] = scalar(scalars, 0)
+            self.tb_info[tb_tags["loss_actor"]] = scalar(scalars, 0, on_value=self.precision_guard["policy"].observe_loss)
         self.tb_info[tb_tags["alg_time"]] = (time.time() - start_time) * 1000  # ms
 
     def _compute_gradient(self, data, iteration):
@@ -299,7 +300,7 @@ class INFADP(AlgorithmBase):
         nets = self.networks
         mods = (nets.v, nets.v_target, nets.policy) if mode == "v" else (nets.policy, nets.policy_target, nets.v_target)
         return (mode, tuple((k, tuple(v.shape)) for k, v in batch.items()), self.forward_step, float(self.gamma),
-                float(self.tau), tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr())
-                                       for m in mods for p in m.parameters()),
+                float(self.tau), self._variant_flags(mode), self._variant_flags("v"),   # (a tripped guard forces a re-capture)
+                tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr()) for m in mods for p in m.parameters()),
                 nets.optimizer_dict[mode].storage_signature(),   # Adam moments / device state, workspaces: raw pointers
                 tuple(sorted(obj.workspace.data_ptr() for obj in self._cache.values())))

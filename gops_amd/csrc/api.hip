@@ -698,6 +698,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
                 for (int k = 0; k < T.n; ++k)
                     if (T.grad[k] == jobs.out[i]) { jobs.ad_p[i] = T.param[k]; jobs.ad_m[i] = T.exp_avg[k]; jobs.ad_v[i] = T.exp_avg_sq[k]; }
             jobs.ad_snap = p.gscale + 4;
+            jobs.ad_skipped = &tail->adam_state->skipped_nonfinite;
             jobs.ad_b1 = tail->beta1; jobs.ad_b2 = tail->beta2; jobs.ad_eps = (float)tail->eps;
             if (tail->polyak != nullptr) {
                 for (int i = 0; i < jobs.n; ++i)

@@ -1663,7 +1663,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
         float t = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
         if (jobs.unscale != nullptr) t *= 1.f / f16_grad_scale(*jobs.unscale);   // power of two: exact
         jobs.out[j][idx] = t;
-        if (step_here) {   // adam_kernel's arithmetic, operation for operation
+        if (step_here && !grad_is_finite(t * gsc)) {
+            atomicAdd(jobs.ad_skipped, 1u);   // (only on the failure path: no contention in a healthy update)
+        } else if (step_here) {   // adam_kernel's arithmetic, operation for operation
             const float gi = t * gsc;
             const float mi = pm + (gi - pm) * omb1;
             const float vi = pv * b2 + omb2 * gi * gi;
@@ -1797,7 +1799,9 @@ __global__ __launch_bounds__(256) void adam_kernel(const GopsAdamTensors T, Gops
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long long i = i0 + q * stride;
-            if (i < n) {
+            if (i < n && !grad_is_finite(gq[q] * gsc)) {
+                atomicAdd(&st->skipped_nonfinite, 1u);   // no step for this element (common.h grad_is_finite)
+            } else if (i < n) {
                 const float gi = gq[q] * gsc;
                 const float mi = mq[q] + (gi - mq[q]) * omb1;
                 const float vi = vq[q] * b2 + omb2 * gi * gi;

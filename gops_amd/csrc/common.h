@@ -242,6 +242,12 @@ __device__ __forceinline__ void adam_snapshot(GopsAdamState* st, float* snap, do
     st->beta2_pow = b2p;
 }
 
+// A gradient element that is not finite takes NO optimizer step (ABI v13): parameter, both moments and - in the fused tail - the
+// Polyak target of that element stay as they are, and GopsAdamState::skipped_nonfinite counts it.  The plane-split kernels
+// answer a half-range overflow with NaN gradients on purpose (a loud failure instead of a wrong number); without this gate one
+// such update would write NaN into every weight and target before the host - which reads losses lazily - could react.
+__device__ __forceinline__ bool grad_is_finite(float g) { return (__float_as_uint(g) & 0x7f800000u) != 0x7f800000u; }
+
 // upload_params_kernel / prologue_kernel take the block BY VALUE: it has to fit the 4 KiB kernel-argument segment
 static_assert(sizeof(RolloutParams) <= 4000, "RolloutParams outgrew the kernel-argument segment (move gpow[] out)");
 
@@ -294,6 +300,7 @@ struct ReduceJobs {
     float* ad_m[2 * GOPS_MAX_LAYERS];
     float* ad_v[2 * GOPS_MAX_LAYERS];
     const float* ad_snap;                  // this step's scalar factors (adam_snapshot, written by the sweep kernel of the same call); null: no optimizer step
+    unsigned* ad_skipped;                  // GopsAdamState::skipped_nonfinite of the stepped optimizer (ABI v13)
     double ad_b1, ad_b2;
     float ad_eps;
     int mean_n;

@@ -702,11 +702,11 @@ class HipAdam(torch.optim.Optimizer):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("HipAdam: device step count out of date while capturing a graph")
             b1, b2 = group["betas"]
-            for t in dev["state"]:   # GopsAdamState: lr, step, beta1^step, beta2^step, ticket
+            for t in dev["state"]:   # GopsAdamState: lr, step, beta1^step, beta2^step, (ticket, skipped_nonfinite), grad_scale
                 t[1] = step
                 t.view(torch.float64)[2] = float(b1) ** step
                 t.view(torch.float64)[3] = float(b2) ** step
-                t[4] = 0
+                t.view(torch.int32)[8] = 0   # ticket (the skipped-element counter next to it keeps counting)
             dev["step"] = step
         self._sync_lr(dev, group)
         return ps, dev
@@ -722,6 +722,12 @@ class HipAdam(torch.optim.Optimizer):
             for t in dev["state"]:
                 t.view(torch.float64)[5] = gs
             dev["gs"] = gs
+
+    def skipped_nonfinite(self) -> int:
+        """Gradient elements that were not finite and therefore took no step since the device state was created
+        (`GopsAdamState.skipped_nonfinite`, ABI v13: parameter, moments and a fused Polyak target of such an element stay
+        untouched).  Reads device memory: one host sync."""
+        return sum(int(t.view(torch.int32)[9].item()) & 0xFFFFFFFF for dev in self._dev.values() for t in dev["state"])
 
     def sync_hyper(self):
         """Push a changed `lr` (schedulers) to the device copies; call before replaying a graph."""

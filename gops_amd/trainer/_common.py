@@ -91,9 +91,22 @@ class TrainerBase:
             self._host_networks.load_state_dict(self.networks.state_dict())
 
     # ---- one iteration = subclass `step()`, then this -------------------------------------------
+    def _warn_skipped_steps(self):
+        """Log points only (one host read per optimizer): the optimizer kernels skip gradient elements that are not finite
+        (`GopsAdamState.skipped_nonfinite`) - say so instead of training on silently."""
+        seen = self.__dict__.setdefault("_skipped_seen", {})
+        for name, opt in getattr(self.networks, "optimizer_dict", {}).items():
+            n = opt.skipped_nonfinite() if hasattr(opt, "skipped_nonfinite") else 0
+            if n > seen.get(name, 0):
+                import warnings
+                warnings.warn(f"gops_amd: {n - seen.get(name, 0)} non-finite gradient element(s) of '{name}' took no optimizer step since the "
+                              f"last log point (iteration {self.iteration}); weights and moments of those elements are unchanged")
+                seen[name] = n
+
     def _after_update(self, alg_tb_dict):
         if self.iteration % self.log_save_interval == 0:
             print("Iter = ", self.iteration)
+            self._warn_skipped_steps()
             add_scalars(alg_tb_dict, self.writer, step=self.iteration)
             add_scalars(self.sampler_tb_dict.pop(), self.writer, step=self.iteration)
         if self.iteration % self.apprfunc_save_interval == 0:

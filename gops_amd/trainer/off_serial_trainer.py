@@ -48,7 +48,11 @@ class OffSerialTrainer(TrainerBase):
         replay_samples = self.buffer.sample_batch(self.replay_batch_size)
         self.networks.train()
         if self.per_flag:   # (off_serial_trainer.py:96-100)
-            alg_tb_dict, idx, new_priority = self.alg.local_update(replay_samples, self.iteration)
+            out = self.alg.local_update(replay_samples, self.iteration)
+            if not (isinstance(out, tuple) and len(out) == 3):
+                raise RuntimeError(f"{type(self.alg).__name__}.local_update returns no (tb_info, idx, new_priority): this algorithm does "
+                                   "not support buffer_name='prioritized_replay_buffer' (the reference's DSAC-family algorithms do)")
+            alg_tb_dict, idx, new_priority = out
             self.buffer.update_batch(idx, new_priority)
         else:
             alg_tb_dict = self.alg.local_update(replay_samples, self.iteration)

@@ -31,6 +31,8 @@ class OffSyncTrainer(OffSerialTrainer):
         alg = alg.unwrap() if hasattr(alg, "unwrap") else alg   # create_alg's in-process actor handle
         super().__init__(alg, sampler, buffer, evaluator, **kwargs)
         self.reducer = GradAllReducer()
+        if hasattr(self.alg, "set_lockstep_replicas"):   # every rank computes gradient k together: the precision guards may use a collective
+            self.alg.set_lockstep_replicas(True)
         broadcast_parameters(self.networks, src=0)   # identical replicas (TrainerBase already moved them to the GPU)
         self._refresh_sampler_networks()
         self.is_chief = rank() == 0

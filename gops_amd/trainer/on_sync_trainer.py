@@ -25,6 +25,8 @@ class OnSyncTrainer(OnSerialTrainer):
             sampler = sampler[rank() % len(sampler)]
         super().__init__(alg, sampler, evaluator, **kwargs)
         self.reducer = GradAllReducer()
+        if hasattr(self.alg, "set_lockstep_replicas"):   # every rank computes gradient k together: the precision guards may use a collective
+            self.alg.set_lockstep_replicas(True)
         if next(self.networks.parameters()).is_cuda or world_size() == 1 or not torch.cuda.is_available():
             broadcast_parameters(self.networks, src=0)
         else:   # replicas must live on their GPU before the first RCCL collective

@@ -19,11 +19,12 @@ def lazy_enabled() -> bool:
 
 
 class LazyScalar:
-    __slots__ = ("_t", "_i", "_sign", "_mean", "_v")
+    __slots__ = ("_t", "_i", "_sign", "_mean", "_v", "_seen")
 
-    def __init__(self, tensor, index=None, negate: bool = False, mean: bool = False):
-        """`mean`: `tensor` is a vector whose mean is the value - the reduction kernel, too, only runs if the value is read."""
-        self._t, self._i, self._sign, self._mean, self._v = tensor, index, (-1.0 if negate else 1.0), mean, None
+    def __init__(self, tensor, index=None, negate: bool = False, mean: bool = False, on_value=None):
+        """`mean`: `tensor` is a vector whose mean is the value - the reduction kernel, too, only runs if the value is read.
+        `on_value(v)`: called once, when the value is fetched (the algorithms hang their non-finite-loss watch on it: no extra sync)."""
+        self._t, self._i, self._sign, self._mean, self._v, self._seen = tensor, index, (-1.0 if negate else 1.0), mean, None, on_value
 
     def _get(self) -> float:
         if self._v is None:
@@ -32,6 +33,9 @@ class LazyScalar:
                 t = t.mean()
             self._v = self._sign * float(t)   # the host sync happens here, once
             self._t = None
+            if self._seen is not None:
+                seen, self._seen = self._seen, None
+                seen(self._v)
         return self._v
 
     def item(self) -> float:
@@ -96,7 +100,7 @@ for _n in ("__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__", "__add__"
     setattr(LazyScalar, _n, _binary(_n))
 
 
-def scalar(tensor, index=None, negate: bool = False, mean: bool = False):
+def scalar(tensor, index=None, negate: bool = False, mean: bool = False, on_value=None):
     """tb_info entry for a device scalar: lazy by default, a Python float (host sync now) under GOPS_EAGER_LOG=1."""
-    s = LazyScalar(tensor, index, negate, mean)
+    s = LazyScalar(tensor, index, negate, mean, on_value)
     return s if lazy_enabled() else s.item()

@@ -45,7 +45,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define GOPS_HIP_ABI_VERSION 12
+#define GOPS_HIP_ABI_VERSION 13
 
 #define GOPS_MAX_LAYERS 5   /* Linear layers per MLP (<= 4 hidden + output) */
 #define GOPS_MAX_ACT 4      /* action dimensions */
@@ -410,7 +410,8 @@ typedef struct GopsAdamState {   /* 48 bytes of device memory */
     int64_t step;
     double beta1_pow, beta2_pow;
     uint32_t ticket;
-    uint32_t reserved;
+    uint32_t skipped_nonfinite;   /* ABI v13 (was `reserved`): gradient elements that were NOT finite and therefore took no step (parameter,
+                                   * moments and - in a fused tail - Polyak target untouched), cumulative; the caller reads / clears it */
     double grad_scale;
 } GopsAdamState;
 int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, double beta1, double beta2,

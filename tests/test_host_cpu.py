@@ -1121,6 +1121,7 @@ r = dist.get_rank()
 # the SAME network on both replicas, but only rank 1's batch shows a distance beyond the threshold: the decision is taken with a
 # MAX over the ranks, so BOTH move to the exact kernels (replicas that chose kernels on their own would stop computing the same update)
 g = PrecisionGuard(interval=1, threshold=1e-4)
+g.lockstep = True   # what on_sync / off_sync trainers declare (AlgorithmBase.set_lockstep_replicas); never inferred from dist.is_initialized()
 base = torch.ones(8)
 def flat_gradient(flags):
     exact = bool(flags & PrecisionGuard.exact_rollout_flags())
@@ -1134,9 +1135,28 @@ assert any("exact-fp32 rollout kernels" in str(x.message) for x in w)
 assert g.flags() & PrecisionGuard.exact_rollout_flags() == PrecisionGuard.exact_rollout_flags() and not g.due()
 # ... and a distance below the threshold on every rank leaves both on the plane-split kernels
 g2 = PrecisionGuard(interval=1, threshold=1e-4)
+g2.lockstep = True
 g2.due()
 d2 = g2.check(lambda flags: base.clone() if flags & PrecisionGuard.exact_rollout_flags() else base * (1.0 + 1e-6 * (r + 1)))
 assert not g2.exact and abs(d2 - 2e-6) < 1e-7, (r, d2)
+# ranks that are NOT in lockstep (off_async_trainer: own gradient counts, point-to-point messages) decide locally - no collective
+# is entered, so a rank that checks while the other does not cannot hang: only rank 1 checks here, and only rank 1 trips
+g3 = PrecisionGuard(interval=1, threshold=1e-4)
+assert not g3.lockstep
+if r == 1:
+    g3.due()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g3.check(flat_gradient)
+assert g3.exact == (r == 1)
+# a non-finite logged loss forces the next gradient to be a checked one (local decision only)
+g4 = PrecisionGuard(interval=1000, threshold=1e-4)
+assert g4.due() and not g4.due()
+g4.observe_loss(float("nan"))
+assert g4.due() and not g4.due()
+g4.lockstep = True
+g4.observe_loss(float("inf"))
+assert not g4.due()
 dist.barrier()
 dist.destroy_process_group()
 open(os.path.join(sys.argv[2], f"ok_{r}"), "w").write("ok")

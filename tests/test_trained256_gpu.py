@@ -352,3 +352,94 @@ def test_precision_guard_infadp(name, dev):
     print(f"{name}: guard distances PEV {gv.last_distance:.2e} PIM {gp.last_distance:.2e}; class vs reference PEV {pev:.2e} PIM {pim:.2e}")
     assert gv.checks == 1 and gp.checks == 1 and not gv.exact and not gp.exact
     assert pev < bar_of(g, "meta/ref_fp32_scatter_pev") and pim < bar_of(g, "meta/ref_fp32_scatter_pim")
+
+
+def _overflowing_fhadp(dev, **more):
+    """An FHADP object on 256-wide nets whose first layer drives H_1 to ~1e8 (beyond the half range of the plane-split forward),
+    its device batch, and the oracle's reference gradient."""
+    from gops_amd.utils.synthetic import act_dim_of, make_batch, obs_dim_of
+    from helpers import reference_init_nets
+    from test_alg_gpu import _kwargs
+    from gops_amd.create_pkg.create_alg import create_alg
+    cfg = dict(alg="FHADP", env_id="pyth_lq", lq_config="s4a2", batch=64, horizon=3, hidden=(256, 256), act="relu", gamma=0.99)
+    data = make_batch(cfg, 21)
+    nets = reference_init_nets(cfg, 21, obs_dim_of(cfg), act_dim_of(cfg))
+    alg = create_alg(**dict(_kwargs(cfg, {}, 21), gamma=cfg["gamma"], **more))
+    alg.networks.cuda()
+    with torch.no_grad():
+        for layer, w, b in zip(alg.networks.policy.linear_layers(), nets["policy"]["w"], nets["policy"]["b"]):
+            layer.weight.copy_(w.detach())
+            layer.bias.copy_(b.detach())
+    return alg, to_device(data, dev)
+
+
+def _blow_up(alg):
+    with torch.no_grad():
+        l0, l1 = alg.networks.policy.linear_layers()[:2]
+        l0.weight.mul_(2.0e8)
+        l0.bias.mul_(2.0e8)
+        l1.weight.mul_(1.0e-8)
+
+
+def test_overflow_between_guard_checks_leaves_the_weights_intact_and_forces_a_check(dev):
+    """The guard checks every `interval` gradients; an overflow in between must not reach the weights.  Healthy first gradient
+    (check passes), then the first layer is blown up: the plane-split kernels answer with NaN gradients, the optimizer kernels -
+    here the fused tail of the backward's last launch, then the stand-alone Adam of `remote_update` - take no step for them
+    (weights and moments bit-identical, `skipped_nonfinite` counts), and reading the logged loss makes the NEXT gradient a
+    checked one, which moves the network to the exact-fp32 rollout kernels."""
+    import warnings
+    alg, data = _overflowing_fhadp(dev, precision_check_interval=1000)
+    opt = alg.networks.policy_optimizer
+    tb = alg.local_update(data, 0)
+    assert np.isfinite(float(tb["Loss/Actor loss-RL iter"])) and alg.precision_guard.checks == 1 and not alg.precision_guard.exact
+    assert opt.skipped_nonfinite() == 0
+    _blow_up(alg)
+    before = [p.detach().clone() for p in alg.networks.policy.parameters()]
+    moments = [opt.state[p]["exp_avg"].clone() for p in alg.networks.policy.parameters()]
+    tb = alg.local_update(data, 1)                                   # fused tail (gops_rollout_backward_update)
+    torch.cuda.synchronize()
+    n_params = sum(p.numel() for p in before)
+    assert opt.skipped_nonfinite() == n_params
+    assert all(torch.equal(a, b) for a, b in zip(alg.networks.policy.parameters(), before))
+    assert all(torch.equal(opt.state[p]["exp_avg"], m) for p, m in zip(alg.networks.policy.parameters(), moments))
+    tb2, info = alg.get_remote_update_info(data, 2)                   # the data-parallel path: stand-alone gops_adam_step
+    alg.remote_update(info)
+    torch.cuda.synchronize()
+    assert opt.skipped_nonfinite() == 2 * n_params
+    assert all(torch.equal(a, b) for a, b in zip(alg.networks.policy.parameters(), before))
+    assert not alg.precision_guard.exact and alg.precision_guard.checks == 1
+    assert not np.isfinite(float(tb["Loss/Actor loss-RL iter"]))     # reading the lazily logged loss arms the guard ...
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tb = alg.local_update(data, 3)                               # ... and this gradient is checked
+    assert alg.precision_guard.exact and alg.precision_guard.checks == 2
+    assert any("exact-fp32 rollout kernels" in str(x.message) for x in w)
+    assert np.isfinite(float(tb["Loss/Actor loss-RL iter"]))
+    assert any((a - b).abs().max() > 0 for a, b in zip(alg.networks.policy.parameters(), before))   # the exact kernels step again
+    assert all(torch.isfinite(p).all() for p in alg.networks.policy.parameters())
+
+
+def test_a_tripped_guard_drops_the_captured_update_graph(dev):
+    """B x H = 192: the update replays as a HIP graph after two eager calls.  The graph bakes the kernel variant in, so a guard
+    that trips later must lead to a re-capture on the exact kernels - replaying the plane-split graph would keep producing NaN."""
+    import warnings
+    alg, data = _overflowing_fhadp(dev, precision_check_interval=6)
+    for it in range(4):                                              # check at gradient 1; captured at the third update
+        alg.local_update(data, it)
+    assert alg._update_graph.graph is not None and not alg.precision_guard.exact
+    sig_flags = alg._variant_flags()
+    _blow_up(alg)
+    before = [p.detach().clone() for p in alg.networks.policy.parameters()]
+    alg.local_update(data, 4)                                        # gradient 5: replayed plane-split graph, NaN, no step taken
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(alg.networks.policy.parameters(), before))
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        tb = alg.local_update(data, 5)                               # gradient 6: scheduled check trips
+    assert alg.precision_guard.exact and alg._variant_flags() != sig_flags
+    assert np.isfinite(float(tb["Loss/Actor loss-RL iter"]))
+    for it in range(6, 10):                                          # eager, eager, re-captured, replayed - all on the exact kernels
+        tb = alg.local_update(data, it)
+        assert np.isfinite(float(tb["Loss/Actor loss-RL iter"])), it
+    assert alg._update_graph.graph is not None
+    assert all(torch.isfinite(p).all() for p in alg.networks.policy.parameters())

@@ -655,6 +655,7 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
     ReduceJobs jobs;
     memset(&jobs, 0, sizeof(jobs));
     if (p.f16) jobs.unscale = p.gscale;   // the sweep ran on gradients scaled by f16_grad_scale(max|grad_v|)
+    else jobs.poison = reinterpret_cast<const unsigned*>(p.gscale) + 3;   // (set by a plane-split forward / sweep whose conversions overflowed)
     // Two-half-plane weight-gradient GEMM (launch_dw_gemm): its delta scale is derived from max|grad_v|, which bounds the
     // deltas only when grad_v is the sweep's one gradient source - a terminal observation adjoint or constraint-sum
     // gradients can be orders of magnitude larger, so those launches keep the exact three-plane product.

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(const RolloutParams p, Ro
             const unsigned i = threadIdx.x + 256 * q;
             if (i < NW) d[i] = w[q];
         }
-        if (p.gscale != nullptr && threadIdx.x == 0) p.gscale[0] = p.gscale[1] = 0.f;   // max|grad_v| / max|delta_y| of the coming backward
+        if (p.gscale != nullptr && threadIdx.x == 0) p.gscale[0] = p.gscale[1] = p.gscale[3] = 0.f;   // max|grad_v| / max|delta_y| of the coming backward; [3]: the overflow mark of forward + sweep
         return;
     }
     b -= 1;
@@ -1662,6 +1662,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
     if (sl == 0 && valid) {
         float t = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
         if (jobs.unscale != nullptr) t *= 1.f / f16_grad_scale(*jobs.unscale);   // power of two: exact
+        // a plane conversion of the forward or of the sweep left the half range (their tiles' returns / one delta are NaN already):
+        // no element of this call's gradient is to be trusted - all of them leave as NaN, and none takes an optimizer step
+        if (jobs.poison != nullptr && *jobs.poison != 0u) t = __builtin_nanf("");
         jobs.out[j][idx] = t;
         if (step_here && !grad_is_finite(t * gsc)) {
             atomicAdd(jobs.ad_skipped, 1u);   // (only on the failure path: no contention in a healthy update)

@@ -292,6 +292,7 @@ struct ReduceJobs {
     int splits[2 * GOPS_MAX_LAYERS], rows[2 * GOPS_MAX_LAYERS], cols[2 * GOPS_MAX_LAYERS], ld[2 * GOPS_MAX_LAYERS];
     int slab_rows[2 * GOPS_MAX_LAYERS];    // rows of one split's slab (>= rows: the slab of a padded output layer has more)
     const float* unscale;                  // f16: device pointer to max|grad_v| (RolloutParams::gscale), else null
+    const unsigned* poison;                // fp32 launches: RolloutParams::gscale + 3, the overflow mark of this call's forward / sweep (null: none)
     float* reset;                          // fp32 launches: RolloutParams::gscale, zeroed here for the NEXT backward call (nothing in this
                                            // kernel reads it, and every consumer of this call - sweep, weight-gradient GEMMs - is done)
     // gops_rollout_backward_update (ABI v12): the Adam step on every gradient element as this kernel forms it, and the loss mean

@@ -1537,8 +1537,10 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
         unsigned o = og.ovf;
         og.ovf = 0;
         if constexpr (SPLIT) { o = SS.ovf; SS.ovf = 0; }
-        if (split_overflow_any(o, red, tid) && tid == 0 && p.st.d[1] != nullptr)   // (red: the env adjoint's partials are consumed by now)
-            gptr(p.st.d[1])[(size_t)tile * hH * TB * 256] = __builtin_nanf("");
+        if (split_overflow_any(o, red, tid) && tid == 0) {   // (red: the env adjoint's partials are consumed by now)
+            if (p.st.d[1] != nullptr) gptr(p.st.d[1])[(size_t)tile * hH * TB * 256] = __builtin_nanf("");
+            if (p.gscale != nullptr) atomicOr(reinterpret_cast<unsigned*>(p.gscale) + 3, 1u);   // the reduce poisons every gradient element of the call
+        }
     }
     } while ((SPLIT || SSB) && MULTI && (tile += gridDim.x) < ntiles);   // (every step ends with a barrier: the next tile's set-up may overwrite G / s_ref)
     dbg.dump(q.dbg);

@@ -1191,7 +1191,12 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
         // non-finite - which relu / tanh can hide again: the tile's returns are poisoned instead, so that the failure is loud
         unsigned o = ss_ovf;
         if constexpr (SPLIT) { o = SP.ovf; SP.ovf = 0; }
-        if (split_overflow_any(o, s_part, tid)) v_acc = __builtin_nanf("");   // (s_part: the head partials are consumed by now)
+        if (split_overflow_any(o, s_part, tid)) {   // (s_part: the head partials are consumed by now)
+            v_acc = __builtin_nanf("");
+            // ... and the launch is marked (RolloutParams::gscale[3], re-armed by the next forward's prologue): a backward after this
+            // forward returns NaN for EVERY gradient element - its stash is fp32 and finite, but it belongs to a rollout that went wrong
+            if (tid == 0 && p.gscale != nullptr) atomicOr(reinterpret_cast<unsigned*>(p.gscale) + 3, 1u);
+        }
     }
     if (tid < nvalid) {
         gptr(p.out.v_pi)[b0 + tid] = v_acc;

@@ -402,13 +402,14 @@ def test_overflow_between_guard_checks_leaves_the_weights_intact_and_forces_a_ch
     assert opt.skipped_nonfinite() == n_params
     assert all(torch.equal(a, b) for a, b in zip(alg.networks.policy.parameters(), before))
     assert all(torch.equal(opt.state[p]["exp_avg"], m) for p, m in zip(alg.networks.policy.parameters(), moments))
+    lost = tb["Loss/Actor loss-RL iter"]                              # (tb is the algorithm's own dict: keep the entry of THIS update)
     tb2, info = alg.get_remote_update_info(data, 2)                   # the data-parallel path: stand-alone gops_adam_step
     alg.remote_update(info)
     torch.cuda.synchronize()
     assert opt.skipped_nonfinite() == 2 * n_params
     assert all(torch.equal(a, b) for a, b in zip(alg.networks.policy.parameters(), before))
     assert not alg.precision_guard.exact and alg.precision_guard.checks == 1
-    assert not np.isfinite(float(tb["Loss/Actor loss-RL iter"]))     # reading the lazily logged loss arms the guard ...
+    assert not np.isfinite(float(lost))                               # reading the lazily logged loss arms the guard ...
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         tb = alg.local_update(data, 3)                               # ... and this gradient is checked

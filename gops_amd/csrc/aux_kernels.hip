@@ -709,6 +709,34 @@ __device__ __forceinline__ void split2h(const f32x4& lo4, const f32x4& hi4, floa
     pl = __builtin_bit_cast(f16x8, ul);
 }
 
+// The same split for the wave-specialised kernel's converting waves, spelled in the instructions it should cost: v_fma_mixlo / mixhi_f16
+// form f16(s x) and f16(s x - hi) in ONE instruction each (fp32 product-sum, one rounding to half, written to one half of the
+// destination) - 4 VALU per element pair instead of the 6 hipcc emits for the expression above (v_mul x 2, v_cvt_pkrtz, v_fma_mix x 2,
+// v_cvt_pkrtz).  Rounding is to nearest here (toward zero there): lo then needs one bit less, the pair carries the same 22 bits;
+// |s x| >= 65520 becomes inf instead of saturating - the callers' range watch (vmax < 65504) is on the fp32 values and unchanged.
+#if GOPS_DW_H2_MODE == 2
+__device__ __forceinline__ void split2h_mix(const f32x4& lo4, const f32x4& hi4, float s, f16x8& ph, f16x8& pl) {
+    u32x4 uh, ul;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = e < 2 ? lo4[2 * e] : hi4[2 * e - 4], x1 = e < 2 ? lo4[2 * e + 1] : hi4[2 * e - 3];
+        unsigned h, l;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(s), "v"(x0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(s), "v"(x1));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(s), "v"(x0), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(s), "v"(x1), "v"(h));
+        uh[e] = h;
+        ul[e] = l;
+    }
+    ph = __builtin_bit_cast(f16x8, uh);
+    pl = __builtin_bit_cast(f16x8, ul);
+}
+#else
+#define split2h_mix split2h
+#endif
+// running maximum of |a|, |b| in one instruction (hipcc spells fmaxf(m, fmaxf(fabsf(a), fabsf(b))) as two canonicalising v_max + v_max3)
+__device__ __forceinline__ void absmax2(float& m, float a, float b) { asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(a), "v"(b)); }
+
 // What the hidden deltas of a backward call are measured against when they are scaled for the half planes (dscale =
 // RolloutParams::gscale): the largest |delta_y| of the sweep (slot 1: the plane-split sweeps track it, rollout_bwd.hip) where there
 // is one, else max|grad_v| (slot 0).  Whatever the choice, a block that still saturates is redone exactly.
@@ -985,6 +1013,57 @@ __device__ __forceinline__ void dw_spec_copy(const DwSpecGeo& G, float* ring, in
         async_copy16_to_lds(src, dst + u * 256);
     }
 }
+// The same copies with their address arithmetic taken out of the loop.  A piece is wave-uniform (only the 16 bytes per lane inside
+// it differ), its source moves by a constant number of bytes from block to block: the base lives in an SGPR pair that one
+// s_add_u32 / s_addc_u32 advances, the lane's offset in ONE VGPR, and the copy is `global_load_lds_dwordx4 voff, s[base]`.
+// dw_spec_copy above recomputes every piece's 64-bit address with ~25 VALU / SALU instructions - 150 per wave and block in all
+// eight waves, next to the 96 MFMAs of a multiplying wave and the ~150 VALU of a converting one, and VALU and MFMA issue time ADD
+// on a SIMD.  Not for the last block of a split whose second sample tile does not exist (clamped there: dw_spec_copy).
+struct DwSpecSrc {
+    unsigned long long p[DwSpec::PIECES];   // source of this wave's piece u in the NEXT block to copy (wave-uniform, without the lane offset)
+    unsigned long long stride_d, stride_x;  // bytes from block c to block c + 1 of a split
+};
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v) |   // (the builtin returns int: no sign extension)
+           ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32);
+}
+__device__ __forceinline__ void dw_spec_src_init(const DwSpecGeo& G, int wave, DwSpecSrc& S) {
+    constexpr int T = DwSpec::T, TN = DwSpec::TN, PC = DwSpec::PIECES;
+    const long long b0 = (long long)G.split * 2;
+#pragma unroll
+    for (int u = 0; u < PC; ++u) {
+        const int pc = wave * PC + u;
+        const bool isx = pc >= 2 * (TN / 16);
+        const int q = isx ? pc - 2 * (TN / 16) : pc, per = isx ? T / 16 : TN / 16;
+        const int st_tile = q / per;
+        int grp = q - st_tile * per;
+        if (isx && grp >= G.xgroups) grp %= G.xgroups;
+        const size_t bq = (size_t)(b0 + st_tile);
+        const float* src = (isx ? G.xbase + bq * ((size_t)G.Kp * 16) : G.dbase + bq * ((size_t)G.N * 16)) + grp * 256;
+        S.p[u] = uniform64((unsigned long long)(size_t)src);
+    }
+    S.stride_d = uniform64((unsigned long long)G.splits * 2ull * (unsigned long long)G.N * 64ull);
+    S.stride_x = uniform64((unsigned long long)G.splits * 2ull * (unsigned long long)G.Kp * 64ull);
+}
+__device__ __forceinline__ void dw_spec_copy_next(DwSpecSrc& S, float* ring, int stage, int wave, int lane) {
+    constexpr int TN = DwSpec::TN, PC = DwSpec::PIECES;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(const __attribute__((address_space(3))) void*)(ring + stage * DwSpec::STAGE_FLOATS + wave * PC * 256));
+    const unsigned voff = 16u * (unsigned)lane;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+#pragma unroll
+    for (int u = 0; u < PC; ++u) {
+        const unsigned long long src = uniform64(S.p[u]);   // (loop-carried: hipcc may keep it in VGPRs - two v_readfirstlane then)
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(lds0 + 1024u * u) : "memory");
+        S.p[u] += (wave * PC + u >= 2 * (TN / 16)) ? S.stride_x : S.stride_d;
+    }
+    asm volatile("s_mov_b32 m0, %0" : : "s"(keep));
+}
+__device__ __forceinline__ void dw_spec_skip(DwSpecSrc& S, int wave) {   // a block copied by dw_spec_copy: keep the running sources in step
+#pragma unroll
+    for (int u = 0; u < DwSpec::PIECES; ++u) S.p[u] += (wave * DwSpec::PIECES + u >= 2 * (DwSpec::TN / 16)) ? S.stride_x : S.stride_d;
+}
 __device__ __forceinline__ void dw_spec_store(const DwSpecGeo& G, const f32x4 (&acc)[8][4], int wn, int wk, int f, int g, float unscale) {
     const int nb = G.tile_n * DwSpec::TN + wn * 128, kb = G.tile_k * DwSpec::T + wk * 64;
 #pragma unroll
@@ -1107,8 +1186,9 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
 
     // converting waves (threads 0 .. 255): items k < 4: D feature (tid >> 2) + 64 k, k = 4, 5: X feature (tid >> 2) + 64 (k - 4);
     // sample group tid & 3.  The same items every block: the bias column sums accumulate in the converting thread.
-    float vmax = 0.f;
+    float vmax = 0.f, vmax_d = 0.f, vmax_x = 0.f;   // largest |delta| / |activation| this thread converted (unscaled; folded into vmax at the end)
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_csum = part_b != nullptr && G.tile_k == 0;   // (the bias gradient = column sums of D: once per row of output tiles)
     auto convert_stage = [&]<bool LAST_HALF_EMPTY>(int stage) {
         float* st = ring + stage * SF;
 #pragma unroll
@@ -1119,13 +1199,12 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(at);
             const f32x4 v1 = LAST_HALF_EMPTY ? zero4 : *reinterpret_cast<const f32x4*>(at + second);
-            if (isd) csum[k & 3] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
-            const float sc = isd ? sd : DW_H2_SA;
-            const float m0 = fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3])));
-            const float m1 = fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3])));
-            vmax = fmaxf(vmax, fmaxf(m0, m1) * sc);
+            if (isd && want_csum) csum[k & 3] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+            float& vm = isd ? vmax_d : vmax_x;
+            absmax2(vm, v0[0], v0[1]); absmax2(vm, v0[2], v0[3]);
+            absmax2(vm, v1[0], v1[1]); absmax2(vm, v1[2], v1[3]);
             f16x8 ph, pl;
-            split2h(v0, v1, sc, ph, pl);
+            split2h_mix(v0, v1, isd ? sd : DW_H2_SA, ph, pl);
             *reinterpret_cast<f16x8*>(at) = ph;
             *reinterpret_cast<f16x8*>(at + second) = pl;
         }
@@ -1137,8 +1216,15 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
 
     unsigned* sat = reinterpret_cast<unsigned*>(ring + NST * SF);
     if (tid == 0) *sat = 0u;
-    dw_spec_copy(G, ring, 0, 0, wave, lane);
-    if (nblk > 1) dw_spec_copy(G, ring, 1, 1, wave, lane);
+    DwSpecSrc SRC;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);   // (the compiler cannot see that tid >> 6 is wave-uniform: keeps the sources in SGPRs)
+    dw_spec_src_init(G, uwave, SRC);
+    auto copy_block = [&](int c) {   // blocks are copied in order 0, 1, 2, ...; only a split's last block may lack its second sample tile
+        if (c < nfull) dw_spec_copy_next(SRC, ring, c % NST, uwave, lane);
+        else { dw_spec_copy(G, ring, c, c % NST, wave, lane); dw_spec_skip(SRC, uwave); }
+    };
+    copy_block(0);
+    if (nblk > 1) copy_block(1);
     landed_and_sync();
     if (!mul_wave) {
         if (0 < nfull) convert_stage.template operator()<false>(0);
@@ -1146,7 +1232,7 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
     }
     __syncthreads();
     for (int c = 0; c < nblk; ++c) {
-        if (c + 2 < nblk) dw_spec_copy(G, ring, c + 2, (c + 2) % NST, wave, lane);
+        if (c + 2 < nblk) copy_block(c + 2);
         if (mul_wave) {
             block_h2(c % NST);
         } else if (c + 1 < nblk) {
@@ -1156,8 +1242,9 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
         landed_and_sync();
     }
     if (!mul_wave) {
+        vmax = fmaxf(vmax_d * sd, vmax_x * DW_H2_SA);
         if (!(vmax < 65504.f)) *sat = 1u;
-        if (part_b != nullptr && G.tile_k == 0) {   // groups gg = tid & 3 of a feature sit in 4 adjacent lanes (formed from the fp32 values)
+        if (want_csum) {   // groups gg = tid & 3 of a feature sit in 4 adjacent lanes (formed from the fp32 values)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float t = csum[k];

@@ -140,7 +140,7 @@ def test_weight_gradient_gemm_redoes_saturated_blocks_exactly(dev, monkeypatch):
     _, grads_ng = _run(cfg, nets, data, env, dev, monkeypatch, split=True, extra_flags=hb.VF_DW_NO_GUARD)
     worst_ng = rel_l2(grads_ng[2].cpu(), ref["grads"][2])   # dW of layer 1 = D_2^T H_1
     print(f"saturated H_1: worst tensor with the guard {worst:.2e}; layer-1 weight gradient without it {worst_ng:.2e}")
-    assert worst_ng > 10 * TOL
+    assert not (worst_ng <= 10 * TOL)   # wrong by orders of magnitude (round-toward-zero planes, rounds 3-5) or non-finite (round-to-nearest planes: inf)
 
 
 # ---- streamed-split forward kernels (GOPS_VARIANT_STREAMED_SPLIT_FWD): any number of 256-wide hidden layers, planes of every

@@ -198,6 +198,32 @@ __global__ __launch_bounds__(256) void upload_params_kernel(const RolloutParams 
     }
 }
 
+// Streams that are read ONCE (stash operands of the weight-gradient GEMMs, split-K partials) are loaded with the non-temporal
+// policy: MI355X_MICROARCH.md measures LDS-DMA fills 18 % earlier with `nt` and 6.5 - 6.8 instead of 6.4 TB/s chip-wide; here the
+// wave-specialised GEMM went from 4.2 to 4.9 TB/s (target: weight-gradient group 140 -> 126 us) - the data does not displace
+// the other kernels' working set in L2 / MALL either.  GOPS_DW_NT=0: default policy (A/B).
+#ifndef GOPS_DW_NT
+#define GOPS_DW_NT 1
+#endif
+#if GOPS_DW_NT
+#define DW_STREAM_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#define DW_NT_SUFFIX " nt"
+#else
+#define DW_STREAM_LOAD(ptr) (*(ptr))
+#define DW_NT_SUFFIX ""
+#endif
+
+// common.h async_copy16_to_lds with the stream policy above (the weight-gradient GEMMs' stash operands)
+__device__ __forceinline__ void dw_async_copy16_to_lds(const float* gsrc, const float* lds_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off" DW_NT_SUFFIX "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gptr(gsrc)), "s"(m0v)
+                 : "memory");
+}
+
 hipError_t launch_upload_params(const RolloutParams& p, RolloutParams* dst, hipStream_t s) {
     static_assert(sizeof(RolloutParams) % 4 == 0, "parameter block must be dword sized");
     int nb = (p.B + 4095) / 4096;
@@ -789,7 +815,7 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int feat = u * 16 + (lane >> 2);
-            async_copy16_to_lds(feat < kvalid ? src + u * 256 : src + u * 256 - (size_t)(feat - (feat % kvalid)) * 16, dst + u * 256);
+            dw_async_copy16_to_lds(feat < kvalid ? src + u * 256 : src + u * 256 - (size_t)(feat - (feat % kvalid)) * 16, dst + u * 256);
         }
     };
 
@@ -1010,7 +1036,7 @@ __device__ __forceinline__ void dw_spec_copy(const DwSpecGeo& G, float* ring, in
         if (isx && grp >= G.xgroups) grp %= G.xgroups;
         const size_t bq = (size_t)min(b0 + st_tile, G.Q - 1);
         const float* src = (isx ? G.xbase + bq * ((size_t)G.Kp * 16) : G.dbase + bq * ((size_t)G.N * 16)) + grp * 256 + 4 * lane;
-        async_copy16_to_lds(src, dst + u * 256);
+        dw_async_copy16_to_lds(src, dst + u * 256);
     }
 }
 // The same copies with their address arithmetic taken out of the loop.  A piece is wave-uniform (only the 16 bytes per lane inside
@@ -1055,7 +1081,7 @@ __device__ __forceinline__ void dw_spec_copy_next(DwSpecSrc& S, float* ring, int
 #pragma unroll
     for (int u = 0; u < PC; ++u) {
         const unsigned long long src = uniform64(S.p[u]);   // (loop-carried: hipcc may keep it in VGPRs - two v_readfirstlane then)
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(lds0 + 1024u * u) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" DW_NT_SUFFIX : : "v"(voff), "s"(src), "s"(lds0 + 1024u * u) : "memory");
         S.p[u] += (wave * PC + u >= 2 * (TN / 16)) ? S.stride_x : S.stride_d;
     }
     asm volatile("s_mov_b32 m0, %0" : : "s"(keep));
@@ -1232,12 +1258,18 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
     }
     __syncthreads();
     for (int c = 0; c < nblk; ++c) {
+#ifndef DW_KO_COPY   // (knock-out builds: tools/gpu/scratch - what does each kind of work cost?)
         if (c + 2 < nblk) copy_block(c + 2);
+#endif
         if (mul_wave) {
+#ifndef DW_KO_MFMA
             block_h2(c % NST);
+#endif
         } else if (c + 1 < nblk) {
+#ifndef DW_KO_CONV
             if (c + 1 < nfull) convert_stage.template operator()<false>((c + 1) % NST);
             else convert_stage.template operator()<true>((c + 1) % NST);
+#endif
         }
         landed_and_sync();
     }
@@ -1299,8 +1331,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void dw_skinny_kernel(const float* __r
             const long long q = q0 + (long long)u * splits;
             const size_t qq = (size_t)min(q, Q - 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) b.d[u][i] = *reinterpret_cast<const GLOBAL_AS f32x4*>(Dg + qq * dtile + doff[i]);
-            b.x[u] = *reinterpret_cast<const GLOBAL_AS f32x4*>(Xg + qq * 256 + xoff);
+            for (int i = 0; i < 4; ++i) b.d[u][i] = DW_STREAM_LOAD(reinterpret_cast<const GLOBAL_AS f32x4*>(Dg + qq * dtile + doff[i]));
+            b.x[u] = DW_STREAM_LOAD(reinterpret_cast<const GLOBAL_AS f32x4*>(Xg + qq * 256 + xoff));
         }
     };
     f32x4 acc[4] = {};
@@ -1446,6 +1478,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void dw_gemm_f16_kernel(const _Float16
             const long long srow = s0 + 4 * s4 + r;
             const int n = n0 + 8 * c8, k = k0 + 8 * c8;
             const u32x4 z = {0u, 0u, 0u, 0u};
+            // (default cache policy: with 128 x 128 output tiles every operand slice is read by two workgroups, the second time from
+            // L2 - the non-temporal policy measured 2 % slower here, cfg5 fp16)
             dreg[r] = (srow < S && n < N) ? *reinterpret_cast<const u32x4*>(D + srow * N + n) : z;
             xreg[r] = (srow < S && k < Kp) ? *reinterpret_cast<const u32x4*>(X + srow * Kp + k) : z;
         }
@@ -1725,14 +1759,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceJobs j
         for (; s + 60 < splits; s += 64) {
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(s + 4 * u) * stride];
+            for (int u = 0; u < 16; ++u) v[u] = DW_STREAM_LOAD(p + (size_t)(s + 4 * u) * stride);
 #pragma unroll
             for (int u = 0; u < 16; u += 4) { acc0 += v[u]; acc1 += v[u + 1]; acc2 += v[u + 2]; acc3 += v[u + 3]; }
         }
         for (; s + 28 < splits; s += 32) {
-            const float v0 = p[(size_t)s * stride], v1 = p[(size_t)(s + 4) * stride], v2 = p[(size_t)(s + 8) * stride],
-                        v3 = p[(size_t)(s + 12) * stride], v4 = p[(size_t)(s + 16) * stride], v5 = p[(size_t)(s + 20) * stride],
-                        v6 = p[(size_t)(s + 24) * stride], v7 = p[(size_t)(s + 28) * stride];
+            const float v0 = DW_STREAM_LOAD(p + (size_t)s * stride), v1 = DW_STREAM_LOAD(p + (size_t)(s + 4) * stride),
+                        v2 = DW_STREAM_LOAD(p + (size_t)(s + 8) * stride), v3 = DW_STREAM_LOAD(p + (size_t)(s + 12) * stride),
+                        v4 = DW_STREAM_LOAD(p + (size_t)(s + 16) * stride), v5 = DW_STREAM_LOAD(p + (size_t)(s + 20) * stride),
+                        v6 = DW_STREAM_LOAD(p + (size_t)(s + 24) * stride), v7 = DW_STREAM_LOAD(p + (size_t)(s + 28) * stride);
             acc0 += v0; acc1 += v1; acc2 += v2; acc3 += v3;
             acc0 += v4; acc1 += v5; acc2 += v6; acc3 += v7;
         }

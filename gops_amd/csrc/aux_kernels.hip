@@ -1003,6 +1003,9 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
 // Saturated half planes (a diverged rollout): the workgroup repeats its blocks with the exact three-plane split on the same
 // four multiplying waves, from unconverted stages.
 // ---------------------------------------------------------------------------------------------
+#ifndef DW_SPEC_REGDIRECT
+#define DW_SPEC_REGDIRECT 1
+#endif
 struct DwSpec {
     static constexpr int NW = 8, NT = 512, TN = 256, T = 128;
     static constexpr int DT = TN * 16;                       // floats of one D sample tile
@@ -1175,6 +1178,7 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
     G.pbase = part + (size_t)split * N * Kp;
     const int nblk = G.nblk, nfull = G.nfull;
 
+#if !DW_SPEC_REGDIRECT
     // multiplying waves: 128 x 64 outputs each
     const int mw = wave & 3, wn = mw >> 1, wk = mw & 1;
     f32x4 acc[8][4] = {};
@@ -1210,6 +1214,10 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
         }
     };
 
+#else
+    const int mw = wave & 3, wn = mw >> 1, wk = mw & 1;
+    const float sd = f16_grad_scale(dw_delta_yardstick(dscale)) * 16.f;
+#endif
     // converting waves (threads 0 .. 255): items k < 4: D feature (tid >> 2) + 64 k, k = 4, 5: X feature (tid >> 2) + 64 (k - 4);
     // sample group tid & 3.  The same items every block: the bias column sums accumulate in the converting thread.
     float vmax = 0.f, vmax_d = 0.f, vmax_x = 0.f;   // largest |delta| / |activation| this thread converted (unscaled; folded into vmax at the end)
@@ -1242,6 +1250,122 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
 
     unsigned* sat = reinterpret_cast<unsigned*>(ring + NST * SF);
     if (tid == 0) *sat = 0u;
+#if DW_SPEC_REGDIRECT
+    // Register-direct feed (round 6).  The LDS-DMA ring gave a block's copies ONE iteration to land and kept <= 48 KiB per CU in
+    // flight - knock-out builds: without the MFMAs -10 us, without the conversion -1 us, i.e. the copy path set the pace (4.2 TB/s).
+    // Here the four converting waves LOAD the fp32 fragments themselves (non-temporal 16-byte loads: a wave's instruction covers
+    // 1 KiB of contiguous stash), hold two blocks in registers (2 x 48 of their 256), convert from registers and store only the
+    // half planes: block c + 2 is converted while block c is multiplied, blocks c + 3 and c + 4 are in flight - two full
+    // iterations of latency cover, ~96 KiB per CU in flight, and 144 instead of 240 KiB of LDS traffic per block.
+    struct Raw { f32x4 v[6][2]; };
+    Raw r0, r1;
+    const int gg = tid & 3;
+    long long lofs[6];   // float offset of item k inside a sample tile of its operand (+ operand / tile_k base)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const bool isd = k < 4;
+        int fe = (tid >> 2) + 64 * (isd ? k : k - 4);
+        if (!isd) { int grp = fe >> 4; if (grp >= G.xgroups) grp %= G.xgroups; fe = (grp << 4) | (fe & 15); }   // partial last K-tile: finite stand-ins
+        lofs[k] = (long long)fe * 16 + 4 * gg;
+    }
+    const size_t dtile = (size_t)N * 16, xtile = (size_t)Kp * 16;
+    auto load_block = [&](int c, Raw& r) {
+        const size_t q0 = (size_t)(((long long)split + (long long)c * splits) * 2);
+        const bool second = c < nfull;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float* base = (k < 4 ? G.dbase + q0 * dtile : G.xbase + q0 * xtile) + lofs[k];
+            r.v[k][0] = DW_STREAM_LOAD(reinterpret_cast<const f32x4*>(base));
+            r.v[k][1] = second ? DW_STREAM_LOAD(reinterpret_cast<const f32x4*>(base + (k < 4 ? dtile : xtile))) : zero4;
+        }
+    };
+    auto convert_block = [&](const Raw& r, int stage) {
+        float* st = ring + stage * SF;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const bool isd = k < 4;
+            const int fe = (tid >> 2) + 64 * (isd ? k : k - 4), second = isd ? DT : 2048;
+            float* at = st + (isd ? 0 : 2 * DT) + fe * 16 + 4 * gg;
+            const f32x4 v0 = r.v[k][0], v1 = r.v[k][1];
+            if (isd && want_csum) csum[k & 3] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+            float& vm = isd ? vmax_d : vmax_x;
+            absmax2(vm, v0[0], v0[1]); absmax2(vm, v0[2], v0[3]);
+            absmax2(vm, v1[0], v1[1]); absmax2(vm, v1[2], v1[3]);
+            f16x8 ph, pl;
+            split2h_mix(v0, v1, isd ? sd : DW_H2_SA, ph, pl);
+            *reinterpret_cast<f16x8*>(at) = ph;
+            *reinterpret_cast<f16x8*>(at + second) = pl;
+        }
+    };
+    // The two kinds of waves run SEPARATE loops with the same number of barriers: the multiplying waves' 128 accumulator
+    // registers and the converting waves' 96 raw-fragment registers are then live in different regions of the control-flow graph
+    // and share the 256-register budget (one loop with a role branch inside keeps both live across it: spills).
+    if (mul_wave) {
+        f32x4 acc[8][4] = {};
+        auto block_h2 = [&](int stage) {
+            const float* st = ring + stage * SF;
+            const float* da = st + (wn * 128 + f) * 16 + 4 * g;            // D fragments of row-tile i: + 256 i  (lo plane: + DT)
+            const float* xa = st + 2 * DT + (wk * 64 + f) * 16 + 4 * g;    // X fragments of column-tile j: + 256 j  (lo plane: + 2048)
+            f16x8 bh[4], bl[4];
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(xa + 256 * j);
+                bl[j] = *reinterpret_cast<const f16x8*>(xa + 256 * j + 2048);
+            }
+            // D fragments double-buffered behind scheduling barriers (left alone, hipcc hoists all sixteen reads: 64 registers, spills)
+            f16x8 ah = *reinterpret_cast<const f16x8*>(da), al = *reinterpret_cast<const f16x8*>(da + DT);
+    #pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f16x8 nh = ah, nl = al;
+                if (i + 1 < 8) {
+                    nh = *reinterpret_cast<const f16x8*>(da + 256 * (i + 1));
+                    nl = *reinterpret_cast<const f16x8*>(da + 256 * (i + 1) + DT);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc[i][j], 0, 0, 0);
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc[i][j], 0, 0, 0);
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ah = nh; al = nl;
+            }
+        };
+
+        __syncthreads();                                  // blocks 0, 1 converted
+        for (int c = 0; c < nblk; ++c) {
+            block_h2(c % NST);
+            __syncthreads();
+        }
+        __syncthreads();                                  // the converting waves' verdict on the half range
+        if (*sat != 0u && guard) {   // a diverged rollout: time, never a wrong gradient
+            dw_spec_exact_pass(G, ring);
+            return;
+        }
+        dw_spec_store(G, acc, wn, wk, f, g, 1.f / (sd * DW_H2_SA));   // (powers of two: exact)
+        return;
+    }
+    load_block(0, r0);   // blocks 0, 1 converted, blocks 2, 3 in flight
+    if (nblk > 1) load_block(1, r1);
+    convert_block(r0, 0);
+    if (nblk > 2) load_block(2, r0);
+    if (nblk > 1) convert_block(r1, 1);
+    if (nblk > 3) load_block(3, r1);
+    __syncthreads();
+    auto iteration = [&](int c, Raw& r) {   // r holds block c + 2
+        if (c + 2 < nblk) {
+            convert_block(r, (c + 2) % NST);   // (stage of block c - 1: its multiplication ended before the last barrier)
+            if (c + 4 < nblk) load_block(c + 4, r);
+        }
+        __syncthreads();
+    };
+    for (int c = 0; c < nblk; c += 2) {
+        iteration(c, r0);
+        if (c + 1 < nblk) iteration(c + 1, r1);
+    }
+#else
     DwSpecSrc SRC;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);   // (the compiler cannot see that tid >> 6 is wave-uniform: keeps the sources in SGPRs)
     dw_spec_src_init(G, uwave, SRC);
@@ -1273,6 +1397,7 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
         }
         landed_and_sync();
     }
+#endif
     if (!mul_wave) {
         vmax = fmaxf(vmax_d * sd, vmax_x * DW_H2_SA);
         if (!(vmax < 65504.f)) *sat = 1u;
@@ -1291,7 +1416,9 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
         dw_spec_exact_pass(G, ring);
         return;
     }
+#if !DW_SPEC_REGDIRECT
     if (mul_wave) dw_spec_store(G, acc, wn, wk, f, g, 1.f / (sd * DW_H2_SA));   // (powers of two: exact)
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

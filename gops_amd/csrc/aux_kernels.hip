@@ -1006,6 +1006,9 @@ __global__ __launch_bounds__(NTHREADS, (H2 && GOPS_DW_H2_MODE == 1) ? 1 : 2) voi
 #ifndef DW_SPEC_REGDIRECT
 #define DW_SPEC_REGDIRECT 1
 #endif
+#ifndef DW_SPEC_RAW3
+#define DW_SPEC_RAW3 0   // three (1) or two (0) blocks of raw fragments in the converting waves' registers
+#endif
 struct DwSpec {
     static constexpr int NW = 8, NT = 512, TN = 256, T = 128;
     static constexpr int DT = TN * 16;                       // floats of one D sample tile
@@ -1336,7 +1339,9 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
 
         __syncthreads();                                  // blocks 0, 1 converted
         for (int c = 0; c < nblk; ++c) {
+#ifndef DW_KO_MFMA   // (knock-out builds: what does each kind of work cost?)
             block_h2(c % NST);
+#endif
             __syncthreads();
         }
         __syncthreads();                                  // the converting waves' verdict on the half range
@@ -1347,6 +1352,29 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
         dw_spec_store(G, acc, wn, wk, f, g, 1.f / (sd * DW_H2_SA));   // (powers of two: exact)
         return;
     }
+#if DW_SPEC_RAW3
+    Raw r2;
+    load_block(0, r0);   // blocks 0, 1 converted, blocks 2, 3, 4 in flight
+    if (nblk > 1) load_block(1, r1);
+    if (nblk > 2) load_block(2, r2);
+    convert_block(r0, 0);
+    if (nblk > 3) load_block(3, r0);
+    if (nblk > 1) convert_block(r1, 1);
+    if (nblk > 4) load_block(4, r1);
+    __syncthreads();
+    auto iteration = [&](int c, Raw& r) {   // r holds block c + 2
+        if (c + 2 < nblk) {
+            convert_block(r, (c + 2) % NST);
+            if (c + 5 < nblk) load_block(c + 5, r);
+        }
+        __syncthreads();
+    };
+    for (int c = 0; c < nblk; c += 3) {   // block c + 2 sits in r2, r0, r1, r2, ...
+        iteration(c, r2);
+        if (c + 1 < nblk) iteration(c + 1, r0);
+        if (c + 2 < nblk) iteration(c + 2, r1);
+    }
+#else
     load_block(0, r0);   // blocks 0, 1 converted, blocks 2, 3 in flight
     if (nblk > 1) load_block(1, r1);
     convert_block(r0, 0);
@@ -1356,8 +1384,12 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
     __syncthreads();
     auto iteration = [&](int c, Raw& r) {   // r holds block c + 2
         if (c + 2 < nblk) {
+#ifndef DW_KO_CONV
             convert_block(r, (c + 2) % NST);   // (stage of block c - 1: its multiplication ended before the last barrier)
+#endif
+#ifndef DW_KO_COPY
             if (c + 4 < nblk) load_block(c + 4, r);
+#endif
         }
         __syncthreads();
     };
@@ -1365,6 +1397,7 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
         iteration(c, r0);
         if (c + 1 < nblk) iteration(c + 1, r1);
     }
+#endif
 #else
     DwSpecSrc SRC;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);   // (the compiler cannot see that tid >> 6 is wave-uniform: keeps the sources in SGPRs)

@@ -8,6 +8,9 @@
 #include <type_traits>
 
 #include "common.h"
+#ifndef GOPS_SWEEP_STAGE_NT
+#define GOPS_SWEEP_STAGE_NT true   // the stash rows the sweep stages one step ahead are read once by this launch
+#endif
 #include "env_models.h"
 #include "rollout_f16.h"
 
@@ -643,18 +646,18 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
         if constexpr (!SPLIT) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                async_copy16_to_lds(src2 + wv * 1024 + q * 256 + 4 * ln, dst + wv * 1024 + q * 256);
-                async_copy16_to_lds(src1 + wv * 1024 + q * 256 + 4 * ln, dst + TB * 256 + wv * 1024 + q * 256);
+                async_copy16_to_lds<GOPS_SWEEP_STAGE_NT>(src2 + wv * 1024 + q * 256 + 4 * ln, dst + wv * 1024 + q * 256);
+                async_copy16_to_lds<GOPS_SWEEP_STAGE_NT>(src1 + wv * 1024 + q * 256 + 4 * ln, dst + TB * 256 + wv * 1024 + q * 256);
             }
         }
         if (wv == 0)        // env rows: 16 x 64 B, contiguous
-            async_copy16_to_lds(hst_env + r0 * ENV_STASH + 4 * ln, dst + STAGE_TILES);
+            async_copy16_to_lds<GOPS_SWEEP_STAGE_NT>(hst_env + r0 * ENV_STASH + 4 * ln, dst + STAGE_TILES);
         if (wv == 1 && ln < 2 * TB)   // first 8 observation columns: 8 x 64 B, contiguous in the FM tile -> st_x[i * 16 + m]
-            async_copy16_to_lds(hst_x + r0 * kp0 + 4 * ln, dst + STAGE_TILES + TB * ENV_STASH);
+            async_copy16_to_lds<GOPS_SWEEP_STAGE_NT>(hst_x + r0 * kp0 + 4 * ln, dst + STAGE_TILES + TB * ENV_STASH);
         if constexpr (SPLIT && ENV == GOPS_ENV_IDPENDULUM) {   // the forward's sub-step parking of the tile: 16 x 512 B, contiguous
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2)
-                async_copy16_to_lds(p.st.idp + r0 * IDP_PARK + (wv * 2 + q2) * 256 + 4 * ln, s_idp + (tt & 1) * (TB * IDP_PARK) + (wv * 2 + q2) * 256);
+                async_copy16_to_lds<GOPS_SWEEP_STAGE_NT>(p.st.idp + r0 * IDP_PARK + (wv * 2 + q2) * 256 + 4 * ln, s_idp + (tt & 1) * (TB * IDP_PARK) + (wv * 2 + q2) * 256);
         }
     };
     const int ntiles = (p.B + TB - 1) / TB;

@@ -473,7 +473,20 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fm
 // then processed in parallel lanes instead of one after the other.
 struct ActC {
     float sc, of, min_action, max_action, act_low, act_high;   // abar = sc * tanh(y) + of, then the wrapper chain
+    // 1 / (max_action - min_action) when that range is a power of two - the pipeline's [-1, 1]: 2 - else 0: dividing by a power of
+    // two IS multiplying by its reciprocal, bit for bit, and an IEEE division is ten dependent instructions on the step's
+    // critical path (the sweep's env phase carried four of them per step for two actions)
+    float inv_range = 0.f;
 };
+__device__ __forceinline__ float exact_inverse_or_zero(float range) {
+    const unsigned b = __float_as_uint(range);
+    const bool pow2 = (b & 0x007fffffu) == 0u && range >= 9.313225746154785e-10f && range <= 1073741824.f;   // 2^-30 .. 2^30: no subnormal results
+    return pow2 ? 1.f / range : 0.f;
+}
+__device__ __forceinline__ float div_range(const ActC& e, float x) {   // x / (max_action - min_action)
+    if (e.inv_range != 0.f) return x * e.inv_range;
+    return x / (e.max_action - e.min_action);
+}
 __device__ __forceinline__ void stage_act_const(const GopsEnv& e, float* s_ac, int tid) {
     if (tid < GOPS_MAX_ACT) {
         float* c = s_ac + tid * 8;
@@ -486,11 +499,11 @@ __device__ __forceinline__ void stage_act_const(const GopsEnv& e, float* s_ac, i
 }
 __device__ __forceinline__ ActC act_const(const float* s_ac, int a) {
     const f32x4 c0 = *reinterpret_cast<const f32x4*>(s_ac + a * 8), c1 = *reinterpret_cast<const f32x4*>(s_ac + a * 8 + 4);
-    return ActC{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1]};
+    return ActC{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], exact_inverse_or_zero(c0[3] - c0[2])};
 }
 __device__ __forceinline__ float wrap_action(const ActC& e, float abar) {   // same arithmetic as the GopsEnv form below
     const float a1 = clampf(abar, e.min_action, e.max_action);
-    const float a2 = e.act_low + (e.act_high - e.act_low) * ((a1 - e.min_action) / (e.max_action - e.min_action));
+    const float a2 = e.act_low + (e.act_high - e.act_low) * div_range(e, a1 - e.min_action);
     const float a3 = clampf(a2, e.act_low, e.act_high);
     return clampf(a3, e.act_low, e.act_high);
 }
@@ -517,9 +530,9 @@ __device__ __forceinline__ float wrap_action_bwd(const GopsEnv& e, int i, float 
 // the same adjoint on per-action constants held in registers (ActC: the sweep of the plane-split kernels pins them to SGPRs)
 __device__ __forceinline__ float wrap_action_bwd(const ActC& e, float abar, float g) {
     const float a1 = clampf(abar, e.min_action, e.max_action);
-    const float a2 = e.act_low + (e.act_high - e.act_low) * ((a1 - e.min_action) / (e.max_action - e.min_action));
+    const float a2 = e.act_low + (e.act_high - e.act_low) * div_range(e, a1 - e.min_action);   // (the forward's value: the clamp decision below)
     if (!(a2 >= e.act_low && a2 <= e.act_high)) g = 0.f;   // both clamps see the same range
-    g = g * (e.act_high - e.act_low) / (e.max_action - e.min_action);
+    g = div_range(e, g * (e.act_high - e.act_low));
     if (!(abar >= e.min_action && abar <= e.max_action)) g = 0.f;
     return g;
 }

@@ -460,7 +460,9 @@ __device__ __forceinline__ void veh_f_xu_bwd(const VehConst& C, const float* s, 
                                              float& g_steer, float& g_ax) {
     const float u = s[3], v = s[4], om = s[5];
     const float lx = lam[0], ly = lam[1], lp = lam[2], lu = lam[3], lv = lam[4], lw = lam[5];
-    const float ivD = 1.f / w.Dv, iwD = 1.f / w.Dw;
+    // (adjoint only - no decision hangs on these, the reference's own autograd rounds differently anyway: the hardware reciprocal,
+    // 1 ulp, instead of two IEEE divisions = twenty dependent instructions of the sweep's one-wave env phase)
+    const float ivD = __builtin_amdgcn_rcpf(w.Dv), iwD = __builtin_amdgcn_rcpf(w.Dw);
     const float dv_du = (C.m * v - C.dt_kf * steer - 2.f * C.dt_m * u * om) * ivD - w.Nv * C.m * ivD * ivD;
     const float dw_du = (C.Iz * om - C.dt_lfkf * steer) * iwD - w.Nw * C.Iz * iwD * iwD;
     ls[0] = lx;

@@ -634,6 +634,8 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
         ha0.act_low = keep_s<SPLIT>(p.env.act_low[0]); ha0.act_high = keep_s<SPLIT>(p.env.act_high[0]);
         ha1.min_action = keep_s<SPLIT>(p.env.min_action[1]); ha1.max_action = keep_s<SPLIT>(p.env.max_action[1]);
         ha1.act_low = keep_s<SPLIT>(p.env.act_low[1]); ha1.act_high = keep_s<SPLIT>(p.env.act_high[1]);
+        ha0.inv_range = exact_inverse_or_zero(ha0.max_action - ha0.min_action);
+        ha1.inv_range = exact_inverse_or_zero(ha1.max_action - ha1.min_action);
     }
     auto stage_step = [&](int tt) {
         const size_t r0 = ((size_t)tile * hH + tt) * TB;

@@ -75,6 +75,8 @@ def bytes_per_step(cfg, dtype):
     return 2 * (2 if dtype == "f16" else 4) * sum(sizes)
 
 
+PREHEAT_UPDATES = 150   # untimed updates in front of the warm-up steps (run_workload): the GPU's clock ramp takes ~40 updates / 20 ms at the
+                        # target; 150 + W + K stays below the precision guard's 500-update interval for the usual K
 CPU_SAMPLE_MAX_BATCH = 8192   # bounded sample: larger batches are timed on this many trajectories
 
 
@@ -465,7 +467,7 @@ def parity_stamp(alg, cfg, workload, device, variant_name):
 
 
 def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, check_parity=False, overlap=True, label=None,
-                 strict_refpoints=False, dp_path=False):
+                 strict_refpoints=False, dp_path=False, cold_start=False):
     """Times `steps` updates of one workload on this rank's GPU (all ranks call it together) and returns the
     measurements; rank 0 turns them into the record.
     strict_refpoints: the algorithm is built with `strict_reference_points=True` (the appended reference points of every update's
@@ -513,14 +515,43 @@ def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, ch
             dist.barrier()
         torch.cuda.synchronize()
 
-    for it in range(warmup):
+    # Two things stay out of the K timed steps, both measured on the GPU box (tools/gpu/scratch):
+    # * the interpreter's cyclic garbage collector (what `timeit` does as well): a generation-2 pass over this process's heap takes
+    #   60 - 110 ms on the GPU host (`gc.callbacks`) - ten times a 20-step timed region; it hit one in two short runs and turned a
+    #   0.46 ms update into a "4.8 ms" one.  Collected BEFORE any GPU work of this workload, disabled until the timed steps are over;
+    # * the GPU's clock ramp: after >= 10 ms of idleness the same 20 updates take 0.51 - 0.52 ms each instead of 0.455 ms (and the
+    #   kernels' own HIP-event times move with them), and ~40 updates pass before the steady state - W = 5 warm-up steps are 2.5 ms.
+    #   PREHEAT_UPDATES untimed updates run IN FRONT of the W warm-up steps, with no host work between them and the timed region.
+    # The timed region still is exactly K complete updates behind W warm-up updates; this only decides at which clocks they run.
+    import gc
+    gc.collect()
+    gc.disable()
+    preheat = 0 if (strict_refpoints or os.environ.get("GOPS_BENCH_PREHEAT", "1") == "0") else PREHEAT_UPDATES
+    cold_elapsed = None
+    if cold_start and preheat:   # the same W + K protocol from a GPU that has just been idle: reported beside `value`, never as `value`
+        for it in range(warmup):
+            step(it)
+        barrier()
+        t0 = time.perf_counter()
+        for it in range(steps):
+            step(warmup + it)
+        barrier()
+        cold_elapsed = time.perf_counter() - t0
+        if world > 1:
+            tc = torch.tensor([cold_elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            cold_elapsed = tc.item()
+    for it in range(preheat):
         step(it)
+    for it in range(warmup):
+        step(preheat + it)
     barrier()
     t0 = time.perf_counter()
     for it in range(steps):
-        step(warmup + it)
+        step(preheat + warmup + it)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     # Per-kernel durations (roofline): HIP events around each launch on the launch stream.  Events
     # cannot be read back from inside a replayed graph, so the same steps are issued once more as
     # plain launches (same kernels, same batch, same stream) right after the timed region.
@@ -529,7 +560,7 @@ def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, ch
     hb.profile_reset()
     hb.profile_enable(True)
     for it in range(profile_steps):
-        step(warmup + steps + it)
+        step(preheat + warmup + steps + it)
     barrier()
     hb.profile_enable(False)
     if graph_mode is None:
@@ -562,7 +593,7 @@ def run_workload(workload, dtype, steps, warmup, profile_steps, ctx, flags=0, ch
     torch.cuda.empty_cache()
     hb.DEFAULT_VARIANT_FLAGS = saved_flags
     return {"elapsed": elapsed, "kern": kern, "variant": variant, "parity": parity, "allreduce_payload_bytes": payload, "finite": finite,
-            "refpoint_batches_evaluated": evaluated}
+            "refpoint_batches_evaluated": evaluated, "preheat": preheat, "cold_elapsed": cold_elapsed}
 
 
 def record_of(workload, dtype, steps, warmup, world, m):
@@ -591,6 +622,11 @@ def record_of(workload, dtype, steps, warmup, world, m):
         "metric": f"env-model steps/sec (batch x H), {alg_name} compute_gradient + update",
         "value": value, "unit": "env-model steps/s", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "preheat_updates": m.get("preheat"),   # untimed, in front of the warm-up steps (clock ramp; GOPS_BENCH_PREHEAT=0: none)
+        "cold_start": None if m.get("cold_elapsed") is None else {
+            "value": world * B * H * steps / m["cold_elapsed"], "ms_per_step": m["cold_elapsed"] / steps * 1e3,
+            "what": "the same W warm-up + K timed steps measured first, on a GPU that had been idle (no pre-heat): the clock ramp of the "
+                    "first ~20 ms of load is inside this figure; `value` is the steady state a training run sees"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt,
         "arithmetic": arithmetic,
         "data": "synthetic (seeded initial states, random-init networks)",
@@ -682,7 +718,7 @@ def main():
 
     workload = args.workload or HEADLINE
     m = run_workload(workload, args.dtype, args.steps, args.warmup, min(args.steps, 100), ctx, check_parity=True,
-                     dp_path=args.dp_path and world == 1, strict_refpoints=args.strict_refpoints)
+                     dp_path=args.dp_path and world == 1, strict_refpoints=args.strict_refpoints, cold_start=True)
     out = record_of(workload, args.dtype, args.steps, args.warmup, world, m) if rank == 0 else None
     if world > 1:
         # N > 1: say what carried the gradients, time the collective alone, and time the update loop a second time with the

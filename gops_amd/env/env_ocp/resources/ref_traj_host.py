@@ -218,6 +218,8 @@ class ReferencePointPipeline:
         self._pending: Dict[int, tuple] = {}
         self._lock = threading.Lock()
         self._stream = None
+        self._pin_in = self._pin_out = None
+        self._ring, self._slot, self._last_slot = [], 0, None
         self.evaluated = 0   # batches evaluated (tests / the bench line read it)
 
     def _side_stream(self, device):
@@ -232,29 +234,50 @@ class ReferencePointPipeline:
             self.evaluated += 1
             return pts, None
         side = self._side_stream(device)
+        B = keys[0].numel()
+        # PERSISTENT pinned staging buffers (re-made only when the batch shape changes): a pinned allocation per call stalled every
+        # third evaluation for ~90 ms on the GPU box (the caching host allocator waiting on the busy device) - 40 instead of 5 ms
+        # per update.  Re-use is safe: `side.synchronize()` below also covers the previous call's host -> device copy.
+        if self._pin_in is None or self._pin_in.shape[1] != B:
+            self._pin_in = torch.empty(3, B, dtype=torch.float32, pin_memory=True)
+        if self._pin_out is None or tuple(self._pin_out.shape) != (B, horizon, 4):
+            self._pin_out = torch.empty(B, horizon, 4, dtype=torch.float32, pin_memory=True)
         with torch.cuda.stream(side):
             if produced is not None:
                 side.wait_event(produced)
             host = []
-            for k in keys:
+            for i, k in enumerate(keys):
                 if k.is_cuda:
-                    h = torch.empty(k.shape, dtype=k.dtype, pin_memory=True)
-                    h.copy_(k, non_blocking=True)
-                    host.append(h)
+                    self._pin_in[i].copy_(k.reshape(-1).to(torch.float32), non_blocking=True)
+                    host.append(self._pin_in[i])
                 else:
                     host.append(k)
             side.synchronize()
-            pts = self.traj.appended_points(*host, horizon, self.pre_horizon).pin_memory()
-            dev = pts.to(device, non_blocking=True)
+            self._pin_out.copy_(self.traj.appended_points(*host, horizon, self.pre_horizon))
+            # a small ring of persistent DEVICE tables as well (no allocation, no cross-stream `record_stream` bookkeeping per call):
+            # slot k is overwritten again four evaluations later, behind the event `collect` records once its consumer's kernels
+            # are queued
+            if not self._ring or tuple(self._ring[0][0].shape) != (B, horizon, 4) or self._ring[0][0].device != device:
+                self._ring = [[torch.empty(B, horizon, 4, dtype=torch.float32, device=device), None] for _ in range(4)]
+                self._slot = 0
+            slot = self._ring[self._slot]
+            self._slot = (self._slot + 1) % len(self._ring)
+            if slot[1] is not None:
+                side.wait_event(slot[1])
+                slot[1] = None
+            slot[0].copy_(self._pin_out, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(side)
-            self._keep = pts   # the pinned source outlives the copy
         self.evaluated += 1
-        return dev, ready
+        return slot, ready
 
     def request(self, data, horizon: int, device) -> None:
         if self._pool is None:
-            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gops-refpoints")
+            # one intra-op thread for the side thread's whole life: toggling the count per call (`_single_threaded`) made the first
+            # multi-threaded op behind it - a 2 MB copy - re-form a 128-thread OpenMP team from a non-main thread: ~90 ms, every third
+            # evaluation on the GPU host (measured phase by phase)
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gops-refpoints",
+                                            initializer=torch.set_num_threads, initargs=(1,))
         produced = None
         if device is not None and device.type == "cuda" and data["ref_time"].is_cuda:
             produced = torch.cuda.Event()
@@ -272,11 +295,16 @@ class ReferencePointPipeline:
             dev, ready = entry[2].result()
         else:
             dev, ready = self._evaluate(data, int(horizon), device, None)
-        if ready is not None:
-            cur = torch.cuda.current_stream(device)
-            cur.wait_event(ready)
-            dev.record_stream(cur)
-        return dev
+        if ready is None:
+            return dev
+        cur = torch.cuda.current_stream(device)
+        if self._last_slot is not None:   # the previous table's consumer is fully queued by now: its slot may be rewritten behind this point
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._last_slot[1] = ev
+        cur.wait_event(ready)
+        self._last_slot = dev
+        return dev[0]
 
     def close(self):
         if self._pool is not None:

@@ -106,16 +106,24 @@ __device__ __forceinline__ void mlp_hidden_forward_h64(const MlpDev& M, const _F
                         const int e = 4 * jj + r;
                         const float z = acc[jj][rg][r] + bv[jj][r];
                         float h, dh = 0.f;
+#ifdef H64_KO_MATH   // (knock-out build: what do the epilogue's transcendentals cost?)
+                        h = z; dh = z;
+#else
                         if (ACT == GOPS_ACT_GELU) {
                             gelu_pair_h(z, h, dh);
                             if (!WANT_DH) dh = 0.f;   // (dead: the compiler drops its two instructions and the conversion below)
                         } else h = act_fwd_t<ACT>(z);
+#endif
                         o[e >> 3][e & 7] = (_Float16)h;
                         if (WANT_DH) gd[e >> 3][e & 7] = (_Float16)dh;
                     }
                 *reinterpret_cast<f16x8*>(hbuf + row * H64_LD + f0) = o[0];
                 *reinterpret_cast<f16x8*>(hbuf + row * H64_LD + f0 + 8) = o[1];
+#ifdef H64_KO_STORE   // (knock-out build: what do the stash stores cost?)
+                if (false) {
+#else
                 if (stash_h != nullptr && row < stash_rows) {
+#endif
                     _Float16* hrow = reinterpret_cast<_Float16*>(stash_h[j + 1]) + (row0 + row) * 256;
                     H64_STORE(o[0], gptr(reinterpret_cast<f16x8*>(hrow + f0)));
                     H64_STORE(o[1], gptr(reinterpret_cast<f16x8*>(hrow + f0 + 8)));

@@ -77,12 +77,12 @@ class AlgorithmBase(metaclass=ABCMeta):
     def _attach_reference_points(self, data: dict, batch: dict) -> dict:
         """`batch` (device tensors of `data`) with `ref_appended` [B, H, 4] in strict mode: the caller's own, the prefetched, or
         evaluated on the spot."""
-        pipe = self._reference_pipeline()
-        if pipe is None:
-            return batch
         device = batch["obs"].device
-        pts = data.get("ref_appended")
+        pts = data.get("ref_appended")   # a caller's own table is honoured in either mode
         if pts is None:
+            pipe = self._reference_pipeline()
+            if pipe is None:
+                return batch
             pts = pipe.collect(data, self._rollout_horizon(), device)
         batch["ref_appended"] = pts.to(device=device, dtype=torch.float32).contiguous()
         return batch

@@ -139,3 +139,17 @@ def test_pipeline_request_and_collect_on_the_host():
     for d, got in ((a, got_a), (b, got_b), (a, got_a2)):
         assert torch.equal(got, HostRefTraj().appended_points(d["ref_time"], d["path_num"], d["u_num"], H, P))
     pipe.close()
+
+
+def test_single_rank_phases_reducer_takes_the_multi_rank_code_path_without_collectives():
+    """bench.py --dp-path: one rank, the algorithms still run the two-phase backward; nothing is exchanged, `_pending` is consumed."""
+    from gops_amd.trainer.grad_sync import GradAllReducer
+    plain, phased = GradAllReducer(), GradAllReducer(single_rank_phases=True)
+    assert not plain.overlap_enabled() and phased.overlap_enabled()
+    g = [torch.ones(4), torch.ones(2)]
+    phased.start_(g)                      # world size 1: no collective, no handle
+    assert phased._works == []
+    info = {"grad": g, "_pending": True}
+    out = phased.average_(info, defer_scale=True)
+    assert "_pending" not in out and "_grad_scale" not in out and torch.equal(out["grad"][0], torch.ones(4))
+    assert not GradAllReducer(overlap=False, single_rank_phases=True).overlap_enabled()

@@ -138,3 +138,48 @@ def test_prefetched_points_equal_the_ones_computed_on_the_spot_and_updates_repla
     alg = create_alg(**_kwargs(cfg, {}, 3))
     alg.networks.cuda()
     assert alg._reference_pipeline() is None
+
+
+@pytest.mark.parametrize("algname", ["INFADP", "FHADP2"])
+def test_strict_mode_equals_handing_the_same_points_in(algname, dev):
+    """The mode is plumbing around `ref_appended`: an algorithm in strict mode and the same algorithm fed the provider's table by
+    hand produce identical gradients (INFADP: both modes of an update pair; FHADP2: the open-loop rollout)."""
+    from gops_amd.env.env_ocp.resources.ref_traj_host import HostRefTraj
+    from gops_amd.utils.synthetic import make_batch
+    if algname == "INFADP":
+        cfg = dict(alg="INFADP", env_id="pyth_veh3dofconti", batch=96, horizon=6, pre_horizon=10, hidden=(64, 64), act="relu", gamma=0.99)
+        extra = {}
+    else:
+        cfg = dict(alg="FHADP2", env_id="pyth_veh3dofconti", batch=96, horizon=8, pre_horizon=8, hidden=(64, 64), act="elu", gamma=1.0)
+        extra = dict(policy_func_name="FiniteHorizonFullPolicy")
+    data = to_device(make_batch(dict(cfg, alg="FHADP" if algname == "FHADP2" else cfg["alg"]), 5), dev)
+    kw = dict(_kwargs(dict(cfg, alg="FHADP" if algname == "FHADP2" else "INFADP"), {}, 9), algorithm=algname, **extra)
+    sd0 = None
+    grads = {}
+    for mode in ("strict", "by_hand"):
+        alg = create_alg(**dict(kw, strict_reference_points=(mode == "strict")))
+        if sd0 is None:
+            sd0 = {k: v.clone() for k, v in alg.state_dict().items()}
+        alg.load_state_dict(sd0)
+        alg.networks.cuda()
+        d = dict(data)
+        if mode == "by_hand":
+            H = cfg["horizon"]
+            if algname == "INFADP":
+                alg.forward_step = H
+            d["ref_appended"] = HostRefTraj().appended_points(data["ref_time"], data["path_num"], data["u_num"], H, cfg["pre_horizon"]).to(dev)
+        elif algname == "INFADP":
+            alg.forward_step = cfg["horizon"]
+        if algname == "INFADP":
+            alg.gamma = cfg["gamma"]
+            out = []
+            for it in (0, 1):
+                _, info = alg.get_remote_update_info(d, it)
+                out += [g.clone() for g in list(info.values())[0]]
+            grads[mode] = out
+        else:
+            alg.gamma = cfg["gamma"]
+            _, info = alg.get_remote_update_info(d, 0)
+            grads[mode] = [g.clone() for g in info["grad"]]
+    assert all(torch.equal(a, b) for a, b in zip(grads["strict"], grads["by_hand"]))
+    assert any(g.abs().max() > 0 for g in grads["strict"])

@@ -221,6 +221,7 @@ class ReferencePointPipeline:
         self._pool: Optional[ThreadPoolExecutor] = None
         self._pending: Dict[int, tuple] = {}
         self._lock = threading.Lock()
+        self._eval_lock = threading.Lock()
         self._stream = None
         self._pin_in = self._pin_out = None
         self._ring, self._slot, self._last_slot = [], 0, None
@@ -232,6 +233,10 @@ class ReferencePointPipeline:
         return self._stream
 
     def _evaluate(self, data, horizon: int, device, produced: Optional["torch.cuda.Event"]):
+        with self._eval_lock:   # the staging buffers are shared: a caller that evaluates on the spot must not meet the side thread in here
+            return self._evaluate_locked(data, horizon, device, produced)
+
+    def _evaluate_locked(self, data, horizon: int, device, produced: Optional["torch.cuda.Event"]):
         keys = [data["ref_time"], data["path_num"], data["u_num"]]
         if device is None or device.type != "cuda":
             pts = self.traj.appended_points(*keys, horizon, self.pre_horizon)
@@ -288,8 +293,8 @@ class ReferencePointPipeline:
             produced.record(torch.cuda.current_stream(device))   # the batch may still be in flight on the caller's stream
         fut: Future = self._pool.submit(self._evaluate, data, int(horizon), device, produced)
         with self._lock:
-            if len(self._pending) > 8:   # requests nobody collected
-                self._pending.pop(next(iter(self._pending)))
+            if len(self._pending) >= 3:   # at most three tables wait to be collected (the device ring has four slots); the oldest
+                self._pending.pop(next(iter(self._pending)))   # request nobody collected is dropped - its batch is evaluated on the spot if it comes
             self._pending[id(data["ref_time"])] = (data["ref_time"], int(horizon), fut)
 
     def collect(self, data, horizon: int, device) -> torch.Tensor:

@@ -223,10 +223,12 @@ class FHADP(AlgorithmBase):
             out = self._mean_of(v_pi)
             fused_opt.step()
             return out
-        ro.backward(self._grad_v(B, device), gw, gb, phase=phase)
-        # loss = -mean(v_pi) (fhadp.py:121): ONE launch (gops_mean_loss) queued with every gradient - eager, captured or replayed -,
-        # so that an update always contains the loss reduction the reference's `_compute_loss_policy` contains
-        return self._mean_of(v_pi)
+        # loss = -mean(v_pi) (fhadp.py:121) is queued with every gradient - eager, captured or replayed -, so that an update always
+        # contains the loss reduction the reference's `_compute_loss_policy` contains; it rides on the reduce launch of the backward
+        # (of its phase A on the data-parallel path: the mean needs no gradient), one launch less than `gops_mean_loss` behind it
+        stats = self._loss_stats_slot(device)
+        ro.backward(self._grad_v(B, device), gw, gb, phase=phase, tail=hb.make_update_tail(None, v_pi, -1.0, stats))
+        return stats.buf[:2]
 
     _LOSS_RING = 16
 

@@ -526,7 +526,10 @@ int run_backward(const GopsRolloutDesc& desc, const GopsRolloutIn& in, const flo
             if (grad.weight[j] == nullptr || grad.bias[j] == nullptr) return GOPS_ERR_BAD_ARG;
     if (tail != nullptr) {   // gops_rollout_backward_update: checked before anything is launched
         if (p.open_loop || !want_params || ext_delta != nullptr || adj != nullptr) return GOPS_ERR_BAD_ARG;
-        if (desc.variant_flags & (GOPS_VF_BWD_PHASE_A | GOPS_VF_BWD_PHASE_B)) return GOPS_ERR_BAD_ARG;
+        // half a backward (GOPS_VF_BWD_PHASE_A / _B: a data-parallel update all-reduces between gradient and optimizer step) can carry
+        // the LOSS MEAN on phase A's reduce launch - it needs no gradient - but never an optimizer / Polyak step
+        const unsigned ph = desc.variant_flags & (GOPS_VF_BWD_PHASE_A | GOPS_VF_BWD_PHASE_B);
+        if (ph != 0 && (ph != GOPS_VF_BWD_PHASE_A || tail->adam != nullptr || tail->polyak != nullptr)) return GOPS_ERR_BAD_ARG;
         if (tail->mean_x != nullptr && (tail->mean_stats == nullptr || tail->mean_n < 1)) return GOPS_ERR_BAD_ARG;
         if (tail->adam != nullptr) {
             const GopsAdamTensors& T = *tail->adam;

@@ -466,10 +466,10 @@ class Rollout:
         `phase`: None = the whole backward; "a" = sweep + every gradient except the first hidden layer's, "b" (after "a", same
         arguments) = the first hidden layer's (GOPS_VF_BWD_PHASE_A / _B): lets a data-parallel trainer start the all-reduce of the
         gradients that are ready first while the rest is being formed.
-        `tail` (ABI v12, `gops_rollout_backward_update`; not with `phase`): the Adam step and / or the loss mean of a single-process
+        `tail` (ABI v12, `gops_rollout_backward_update`; with `phase="a"` only a loss-mean tail): the Adam step and / or the loss mean of a single-process
         update, folded into the launch that forms the final gradients (`HipAdam.begin_fused`, `make_update_tail`)."""
-        if tail is not None and phase is not None:
-            raise ValueError("Rollout.backward: an update tail cannot ride on half a backward (phase)")
+        if tail is not None and phase is not None and (phase != "a" or tail.adam or tail.polyak):
+            raise ValueError("Rollout.backward: only a loss-mean tail can ride on half a backward, and only on phase 'a'")
         if phase == "b":
             # phase B reuses the inputs (and the delta stash) phase A left in this workspace: it must follow one, directly
             if getattr(self, "_last_phase", None) != "a":

@@ -422,8 +422,9 @@ int gops_adam_step(const GopsAdamTensors* tensors, GopsAdamState* state_dev, dou
  * gradients: the Adam step of gops_adam_step on every gradient element as it is formed (`adam`), and the loss mean of
  * gops_mean_loss in one more block of the same launch (`mean_x`; more than 8192 values: its own launch, still inside this call).
  * Element for element the arithmetic of the three separate calls (tests: bit-equal weights, moments and loss scalars); two
- * launches and their gaps less per update.  The gradients are written to policy_grad as well.  Not with GOPS_VF_BWD_PHASE_A / _B
- * (a data-parallel update all-reduces between gradient and optimizer step) and not for open-loop rollouts. */
+ * launches and their gaps less per update.  The gradients are written to policy_grad as well.  With GOPS_VF_BWD_PHASE_A only a tail
+ * WITHOUT `adam` / `polyak` is accepted (round 6: the loss mean rides on phase A's reduce launch; a data-parallel update all-reduces
+ * between gradient and optimizer step), never with GOPS_VF_BWD_PHASE_B, and not for open-loop rollouts. */
 typedef struct GopsUpdateTail {
     const GopsAdamTensors* adam;   /* NULL: no optimizer step.  grad[i] must be one of policy_grad's tensors with numel[i] its element
                                     * count, and EVERY tensor of policy_grad must appear (a parameter without its step is a bug) */

@@ -246,8 +246,9 @@ class INFADP(AlgorithmBase):
             ro.backward(self._grad_v(B, device), gw, gb, tail=hb.make_update_tail(fa, v_pi, -1.0, stats, polyak=pk, tau=self.tau))
             fused_opt.end_fused()
             return stats.buf[:1], True
-        ro.backward(self._grad_v(B, device), gw, gb)
-        return self._loss_stats("policy", device).mean_loss(v_pi, -1.0)[:1]
+        stats = self._loss_stats("policy", device)   # (the loss mean rides on the backward's reduce launch: it needs no gradient)
+        ro.backward(self._grad_v(B, device), gw, gb, tail=hb.make_update_tail(None, v_pi, -1.0, stats))
+        return stats.buf[:1]
 
     def _fused_parts(self, net_name, opt):
         """(what `HipAdam.begin_fused` returns, the network's one-table PolyakUpdater) for a backward call that carries the update's

@@ -959,7 +959,7 @@ int gops_env_step(const GopsEnv* env, int32_t batch, const GopsStepIO* io, void*
     if (env->kind < GOPS_ENV_LQ || env->kind > GOPS_ENV_MOBILEROBOT) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_MOBILEROBOT &&
         (env->obs_dim != MOB_OBS || env->act_dim != 2 || env->n_constraint != 1 || env->scale_obs || !io->constraint)) return GOPS_ERR_BAD_ARG;
-    if (env->data_env && (env->kind == GOPS_ENV_PENDULUM || env->kind == GOPS_ENV_MOBILEROBOT || (env->kind == GOPS_ENV_VEH2DOF && env->cstr_err)))
+    if (env->data_env && (env->kind == GOPS_ENV_PENDULUM || (env->kind == GOPS_ENV_VEH2DOF && env->cstr_err)))
         return GOPS_ERR_UNSUPPORTED;   // these data envs are not restated
     if (!io->obs || !io->action || !io->next_obs || !io->reward || !io->next_done) return GOPS_ERR_BAD_ARG;
     if (env->kind == GOPS_ENV_VEH3DOF_SURR &&

@@ -2312,11 +2312,12 @@ __global__ void env_step_kernel(const GopsEnv env, int B, const GopsStepIO io, f
         const float nv = io.noise != nullptr ? io.noise[(size_t)b * 2 + 0] : 0.f;
         const float nw = io.noise != nullptr ? io.noise[(size_t)b * 2 + 1] : 0.f;
         MobStep w;
-        mob_forward(MC, x, u[0], u[1], nv, nw, xn, r, c, done_m, w);
+        if (data) mob_forward<true>(MC, x, u[0], u[1], nv, nw, xn, r, c, done_m, w);   // pyth_mobilerobot.py:108-152: headings clipped to +-pi
+        else mob_forward(MC, x, u[0], u[1], nv, nw, xn, r, c, done_m, w);
         io.constraint[b] = c;   // of the model's new state, whatever `done` says
         for (int i = 0; i < MOB_OBS; ++i) {
             const float v = dn ? x[i] : xn[i];
-            nob[i] = env.clip_obs ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;
+            nob[i] = (env.clip_obs && !data) ? clampf(v, env.obs_low[i], env.obs_high[i]) : v;   // (the data env clips nothing)
         }
     } else if (env.kind == GOPS_ENV_VEH2DOF) {
         const Veh2Const C2 = veh2_const();

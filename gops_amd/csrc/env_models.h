@@ -297,6 +297,9 @@ struct MobStep {   // intermediates shared by forward and adjoint
 
 __device__ __forceinline__ bool mob_inside(float v, float lim) { return v >= -lim && v <= lim; }
 
+// clip_heading: the DATA env's Robot.f_xu (env_ocp/pyth_mobilerobot.py:271-311) clips both new headings to +-pi (the model
+// does not); everything behind it - tracking error, constraint, reward, termination test - is the model's arithmetic
+template <bool CLIP_HEADING = false>
 __device__ __forceinline__ void mob_forward(const MobConst& C, const float* x, float a0, float a1, float nv, float nw,
                                             float* xn, float& r, float& c, bool& done, MobStep& w) {
     const float dvr = a0 - x[3], dwr = a1 - x[4];
@@ -310,6 +313,7 @@ __device__ __forceinline__ void mob_forward(const MobConst& C, const float* x, f
     xn[0] = x[0] + (C.T * w.cth) * w.vc;
     xn[1] = x[1] + (C.T * w.sth) * w.vc;
     xn[2] = x[2] + C.T * w.wc;
+    if (CLIP_HEADING) xn[2] = clampf(xn[2], -3.14159265358979323846f, 3.14159265358979323846f);
     xn[3] = w.vc;
     xn[4] = w.wc;
     xn[5] = xn[1];
@@ -322,6 +326,7 @@ __device__ __forceinline__ void mob_forward(const MobConst& C, const float* x, f
     xn[8] = x[8] + (C.T * w.coth) * w.ovc;
     xn[9] = x[9] + (C.T * w.soth) * w.ovc;
     xn[10] = x[10] + C.T * w.owc;
+    if (CLIP_HEADING) xn[10] = clampf(xn[10], -3.14159265358979323846f, 3.14159265358979323846f);
     xn[11] = w.ovc;
     xn[12] = w.owc;
     w.dx = xn[8] - xn[0];

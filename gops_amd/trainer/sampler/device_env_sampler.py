@@ -6,7 +6,8 @@ section 8(f) rank 3).  The data environments of this path share their dynamics a
 models but NOT their termination rules or terminal reward (pyth_veh3dofconti.py:224-226,263-271: -100 at done,
 world-frame |dx| > 5, |dy| > 2 against the model's ego-frame 10 / 10; lq_base.py:224-239: done when the state leaves
 its bounds, -100, no clipping; pyth_idpendulum.py:71-87 is identical to its model; gym_cartpoleconti.py:102-137: reward 1
-also for the step that ends an episode; pyth_veh2dofconti.py:179-219: the model's step, -100 at done).  `env_step="data"` (default)
+also for the step that ends an episode; pyth_veh2dofconti.py:179-219: the model's step, -100 at done; pyth_mobilerobot.py:108-152:
+the model's step with both headings clipped to +-pi, obstacle noise drawn on the device per step).  `env_step="data"` (default)
 selects those data-env semantics in the step kernel (`GopsEnv.data_env`, checked against transitions recorded from the
 reference's numpy envs: tests/golden/dataenv_*.npz); `env_step="model"` steps the env model instead.  N environment
 instances are advanced together by `gops_env_step`:
@@ -50,11 +51,11 @@ class DeviceEnvSampler:
             raise ValueError("env_step must be 'data' (the data environment's step) or 'model' (the env model's)")
         self.data_env = env_step == "data"
         kind = getattr(getattr(env_model, "unwrapped", env_model), "hip_kind", None)
-        if self.data_env and (kind not in (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_VEH, hb.ENV_CARTPOLE, hb.ENV_VEH2DOF)
+        if self.data_env and (kind not in (hb.ENV_LQ, hb.ENV_IDP, hb.ENV_VEH, hb.ENV_CARTPOLE, hb.ENV_VEH2DOF, hb.ENV_MOBILEROBOT)
                               or self.cfg.get("env_id", "").endswith("errcstr")):
             raise RuntimeError(f"the DATA environment of {self.cfg.get('env_id')} is not restated in the step kernel "
-                               "(pyth_lq, pyth_idpendulum, pyth_veh3dofconti, pyth_veh2dofconti and gym_cartpoleconti are): "
-                               "pass env_step='model'")
+                               "(pyth_lq, pyth_idpendulum, pyth_veh3dofconti, pyth_veh2dofconti, pyth_mobilerobot and "
+                               "gym_cartpoleconti are): pass env_step='model'")
         self.networks = None
         self.total = 0
         self._pool, self._pool_pos, self._pools_made = None, 0, 0
@@ -72,6 +73,15 @@ class DeviceEnvSampler:
         size = self.pool_factor * self.n
         if self._pool is None or self._pool_pos + k > size:
             host = make_batch(self.cfg, self.seed + 7919 * self._pools_made, batch=size)
+            if self.cfg["env_id"] == "pyth_mobilerobot" and self.data_env:
+                # the data env's own reset distribution (pyth_mobilerobot.py:31-54, 95-106: robot and obstacle uniform in the work
+                # space, w = 0, tracking errors of the robot state); make_batch's near-collision starts exist for the parity fixtures
+                rng = np.random.RandomState(self.seed + 7919 * self._pools_made)
+                ego = rng.uniform([0.0, -1.0, -0.6, 0.0, 0.0], [2.7, 1.0, 0.6, 0.3, 0.0], size=(size, 5))
+                obst = rng.uniform([3.5, -3.0, np.pi / 2 - 0.3, 0.0, 0.0], [6.0, 3.0, np.pi / 2 + 0.3, 0.5, 0.0], size=(size, 5))
+                ego, obst = ego.astype(np.float32), obst.astype(np.float32)   # (reset casts the drawn state first, :100-101)
+                track = np.stack((ego[:, 1], ego[:, 2], ego[:, 3] - np.float32(0.3)), axis=1)   # path y = 0, phi = 0, v_desired 0.3
+                host["obs"] = torch.from_numpy(np.concatenate((ego, track, obst), axis=1))
             if self.cfg["env_id"] == "gym_cartpoleconti" and self.data_env:
                 # the data env's own reset distribution (env_gym/gym_cartpoleconti.py:139-147: uniform +-0.05 in every state);
                 # make_batch's wide cartpole states exist to exercise the done thresholds inside short rollouts
@@ -118,7 +128,9 @@ class DeviceEnvSampler:
             self.t += 1
             over = (done != 0) | (self.t >= self.max_steps)
             n_over = int(over.sum().item())
-            self.obs, self.info = obs2, dict(info2)
+            # (pyth_mobilerobot's info["constraint"] is a zero-size replay slot in the reference, pyth_mobilerobot.py:86-92:
+            # the step's constraint output is not a stored column)
+            self.obs, self.info = obs2, {k: info2[k] for k in info}
             if n_over:
                 fresh = self._draw(n_over)
                 idx = over.nonzero(as_tuple=True)[0]

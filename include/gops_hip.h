@@ -169,7 +169,8 @@ typedef struct GopsEnv {
      * of the env MODEL's: same dynamics and stage reward, but the data env's termination tests (veh3dofconti: world-frame
      * |x - x_ref| > 5, |y - y_ref| > 2, |dphi| > pi; lq: next state outside the state bounds), a -100 terminal penalty
      * (veh3dofconti, lq), no observation clipping and no MaskAtDone (an episode that is done gets reset by the caller:
-     * the `done` input is ignored). */
+     * the `done` input is ignored).  GOPS_ENV_MOBILEROBOT (round 6; pyth_mobilerobot.py:108-152): the model's step with both new
+     * headings clipped to +-pi, no terminal penalty. */
     int32_t data_env;
     /* ScaleObservationModel (gops/env/wrapper/scale_observation.py:74-119; create_env_model.py:115-118 puts it between
      * ShapingReward and ClipObservation): the observations the policy and the caller see are (obs + obs_shift) * obs_scale;

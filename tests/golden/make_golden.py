@@ -908,6 +908,9 @@ DATA_ENV_CASES = {
     "dataenv_lq_s2a1_shaped": dict(env_id="pyth_lq", lq_config="s2a1", reward_scale=0.5, reward_shift=1.0),
     "dataenv_cartpole": dict(env_id="gym_cartpoleconti", reward_scale=0.5),
     "dataenv_veh2dof_p10": dict(env_id="pyth_veh2dofconti", pre_horizon=10),
+    # pyth_mobilerobot.py:108-152: Robot.f_xu with the heading CLIPPED to +-pi (the model does not clip), obstacle driven by its own
+    # (v, w) + np.random.normal draws (recorded per transition: t/noise), no terminal penalty, the model's done test
+    "dataenv_mobilerobot": dict(env_id="pyth_mobilerobot"),
 }
 
 
@@ -928,7 +931,15 @@ def golden_data_envs(only=None):
         while len(rows) < 400:
             episodes += 1
             env.seed(int(rng.randint(1 << 30)))
-            ret = env.reset()
+            reset_kw = {}
+            if cfg["env_id"] == "pyth_mobilerobot" and episodes % 4 != 1:
+                # the reset distribution alone (robot x in [0, 2.7], obstacle x in [3.5, 6]) never reaches a termination or the heading clip
+                # inside 40 steps: every second episode starts on a collision course, on the |y| = 4 edge, or with a heading next to pi
+                reset_kw = dict(init_state=[
+                    [3.0, 0.1, 0.0, 0.3, 0.0, 0, 0, 0, 3.9, 0.2, 3.1, 0.4, 0.0],
+                    [1.0, 3.9, 1.5, 0.3, 0.0, 0, 0, 0, 5.0, -2.0, 1.6, 0.2, 0.0],
+                    [1.0, 0.0, 3.05, 0.2, 0.9, 0, 0, 0, 5.0, 2.0, -3.1, 0.3, -0.9]][episodes % 4 - 2 if episodes % 4 >= 2 else 2])
+            ret = env.reset(**reset_kw)
             obs, info = ret if isinstance(ret, tuple) else (ret, getattr(env, "info", {}))
             if not info:
                 info = getattr(env.unwrapped, "info", {}) or {}
@@ -937,10 +948,16 @@ def golden_data_envs(only=None):
             for t in range(40):
                 act = rng.uniform(-amp, amp, size=env.action_space.shape).astype(np.float32)
                 cur_info = {k: np.array(info[k], dtype=np.float32).copy() for k in info_keys if k in info}
-                step = env.step(act)
+                extra_cols = {}
+                if cfg["env_id"] == "pyth_mobilerobot":
+                    with record_normal() as rec:
+                        step = env.step(act)
+                    extra_cols = dict(noise=rec.obstacle_draws()[0][0], constraint=np.float32(np.asarray(step[-1]["constraint"]).reshape(-1)[0]))
+                else:
+                    step = env.step(act)
                 obs2, rew, done, info2 = step[0], step[1], step[2], step[-1]
-                rows.append(dict(obs=np.array(obs, np.float32), act=act, rew=np.float32(rew), done=np.float32(done),
-                                 obs2=np.array(obs2, np.float32),
+                rows.append(dict(obs=np.array(obs, np.float32), act=act, rew=np.float32(rew), done=np.float32(np.asarray(done).reshape(-1)[0]),
+                                 obs2=np.array(obs2, np.float32), **extra_cols,
                                  **{"info_" + k: v for k, v in cur_info.items()},
                                  **{"next_" + k: np.array(info2[k], dtype=np.float32) for k in cur_info}))
                 obs, info = obs2, info2
@@ -1077,6 +1094,8 @@ if __name__ == "__main__":
         golden_data_envs(only=("dataenv_cartpole",))
     if "dataenv_veh2dof" in which:
         golden_data_envs(only=("dataenv_veh2dof_p10",))
+    if "dataenv_mobilerobot" in which:
+        golden_data_envs(only=("dataenv_mobilerobot",))
     if "constrained" in which:
         golden_constrained()
     if "fhadp2" in which:

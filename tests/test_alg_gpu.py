@@ -328,6 +328,43 @@ def test_device_env_sampler_closed_loop(env_id, tmp_path):
 
 
 @pytest.mark.gpu
+def test_device_env_sampler_steps_the_mobilerobot_data_env(monkeypatch):
+    """pyth_mobilerobot under DeviceEnvSampler(env_step="data"): resets come from the data env's own reset box, every stored
+    transition is the oracle's DATA-env step of (obs, act) with the obstacle draws the step used, headings stay within +-pi, and
+    terminated instances restart."""
+    from helpers import oracle_env
+    from oracle import adp_oracle as orc
+    from gops_amd import hip_backend as hb
+    from gops_amd.trainer.sampler.device_env_sampler import DeviceEnvSampler
+    cfg = dict(alg="FHADP", env_id="pyth_mobilerobot", batch=64, horizon=4, hidden=(64, 64), act="relu", gamma=0.99)
+    torch.manual_seed(2)
+    alg = create_alg(**_kwargs(cfg, {}, 2))
+    alg.networks.to("cuda")
+    draws = []
+    real = hb.mobilerobot_noise
+    monkeypatch.setattr(hb, "mobilerobot_noise", lambda shape, device: draws.append(real(shape, device)) or draws[-1])
+    smp = DeviceEnvSampler(cfg, alg.envmodel, n_envs=256, steps_per_sample=40, max_episode_steps=30, seed=5, noise_std=0.6)
+    first = smp.obs.cpu()
+    assert (first[:, 0] >= 0).all() and (first[:, 0] <= 2.7).all() and (first[:, 4] == 0).all() and (first[:, 8] >= 3.5).all()
+    assert torch.equal(first[:, 5:8], torch.stack((first[:, 1], first[:, 2], first[:, 3] - 0.3), 1))
+    smp.networks = alg.networks
+    batch, _ = smp.sample()
+    n = 256 * 40
+    assert len(draws) == 40 and set(batch) == {"obs", "act", "rew", "done", "obs2", "logp"}
+    env = oracle_env(cfg, {})
+    o2, r, d, _ = orc.data_env_forward(env, batch["obs"].cpu(), batch["act"].cpu(), dict(noise=torch.cat(draws).cpu()))
+    assert rel_l2(batch["obs2"].cpu(), o2) < 1e-5 and rel_l2(batch["rew"].cpu(), r) < 1e-5
+    assert np.array_equal(batch["done"].cpu().numpy() != 0, d.numpy() != 0)
+    assert batch["obs2"][:, [2, 10]].abs().max().item() <= np.float32(np.pi)
+    # restarts: a finished / timed-out instance continues from a fresh reset state
+    obs_s, obs2_s, done_s = batch["obs"].view(40, 256, -1), batch["obs2"].view(40, 256, -1), batch["done"].view(40, 256)
+    cont = (done_s[:29] == 0)
+    assert torch.equal(obs_s[1:30][cont], obs2_s[:29][cont])
+    never = (done_s[:30] == 0).all(0)   # these ran into the 30-step time-out together
+    assert never.sum() > 100 and (obs_s[30][never][:, 4] == 0).all() and (obs2_s[29][never][:, 4] != 0).any()
+
+
+@pytest.mark.gpu
 def test_infadp_graph_replay_matches_eager_updates(monkeypatch):
     """INFADP's PEV and PIM updates (gradient + Adam + Polyak) captured as HIP graphs replay exactly
     the eager updates: two learners stay bit-identical over alternating iterations and fresh batches."""

@@ -511,7 +511,8 @@ def test_stationary_staged_variants_match_oracle(cfg, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped", "dataenv_cartpole", "dataenv_veh2dof_p10"])
+@pytest.mark.parametrize("name", ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped", "dataenv_cartpole", "dataenv_veh2dof_p10",
+                                  "dataenv_mobilerobot"])
 def test_data_env_step_vs_reference_numpy_envs(name, dev):
     """gops_env_step with GopsEnv.data_env = 1 (what DeviceEnvSampler steps) against transitions recorded from the
     reference's numpy DATA envs: terminal -100, data-env termination tests, no observation clipping."""
@@ -525,6 +526,8 @@ def test_data_env_step_vs_reference_numpy_envs(name, dev):
     if oenv["kind"] == "lq":   # the data env's state bounds drive its done test (never a clip in this mode)
         assert henv.clip_obs == 1
     t, info = _dataenv_inputs(g)
+    if oenv["kind"] == "mob":   # the obstacle's np.random.normal draws were recorded with every transition
+        info = dict(info, noise=t["noise"])
     dinfo = {k: v.to(dev).contiguous() for k, v in info.items()}
     B = t["obs"].shape[0]
     # `done` is ignored in data-env mode: pass ones to prove it
@@ -532,10 +535,17 @@ def test_data_env_step_vs_reference_numpy_envs(name, dev):
     check_data_env_transitions(nobs.cpu().numpy(), r.cpu().numpy(), done.cpu().numpy(),
                                {k: v.cpu().numpy() for k, v in ninfo.items()}, t,
                                "veh2" if oenv["kind"] == "veh2" else oenv["kind"] == "veh")
+    if oenv["kind"] == "mob":
+        np.testing.assert_allclose(ninfo["constraint"].cpu().numpy().reshape(-1), t["constraint"].numpy(), rtol=1e-5, atol=2e-5)
     # the model-step mode on the same inputs differs exactly where the two sets of rules differ
     henv.data_env = 0
-    _, r_m, done_m, _ = hb.env_step(henv, t["obs"].to(dev), t["act"].to(dev), torch.zeros(B, device=dev), dinfo)
-    if oenv["kind"] != "idp" and t["done"].sum() > 0:
+    nobs_m, r_m, done_m, _ = hb.env_step(henv, t["obs"].to(dev), t["act"].to(dev), torch.zeros(B, device=dev), dinfo)
+    if oenv["kind"] == "mob":   # same reward and termination test; the data env clips both headings to +-pi, the model wraps nothing
+        clipped = (t["obs2"][:, [2, 10]].abs() >= 3.14159).any(1)
+        beyond = nobs_m.cpu()[clipped][:, [2, 10]].abs().max(1).values
+        assert clipped.sum() > 10 and (beyond >= 3.14159).all() and (beyond > 3.1416).sum() > 10
+        assert torch.allclose(nobs_m.cpu()[~clipped], t["obs2"][~clipped], rtol=1e-5, atol=2e-5)
+    elif oenv["kind"] != "idp" and t["done"].sum() > 0:
         assert not torch.equal(done_m.cpu() != 0, t["done"] != 0) or not torch.allclose(r_m.cpu(), t["rew"], atol=1e-3)
     with pytest.raises(RuntimeError):   # rollouts take the env MODEL only
         henv.data_env = 1

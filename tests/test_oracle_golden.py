@@ -137,7 +137,8 @@ def test_fhadp2_gradient_matches_reference(name):
         assert rel_l2(gr, g[f"grad/{i}"]) < 1e-5, (name, i)
 
 
-DATA_ENV_CASES = ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped", "dataenv_cartpole", "dataenv_veh2dof_p10"]
+DATA_ENV_CASES = ["dataenv_veh_p10", "dataenv_lq_s4a2", "dataenv_idp", "dataenv_lq_s2a1_shaped", "dataenv_cartpole", "dataenv_veh2dof_p10",
+                  "dataenv_mobilerobot"]
 
 
 def _dataenv_inputs(g):
@@ -185,8 +186,13 @@ def test_data_env_step_matches_reference_numpy_envs(name):
     env = oracle_env(meta["cfg"], meta["extra"], g)
     t, info = _dataenv_inputs(g)
     assert t["done"].sum() > 0 or "shaped" in name
+    if env["kind"] == "mob":   # the obstacle's np.random.normal draws of every transition were recorded with it
+        info = dict(info, noise=t["noise"])
     nobs, r, done, ninfo = orc.data_env_forward(env, t["obs"], t["act"], info)
     check_data_env_transitions(nobs, r, done, ninfo, t, "veh2" if env["kind"] == "veh2" else env["kind"] == "veh")
+    if env["kind"] == "mob":
+        np.testing.assert_allclose(ninfo["constraint"].numpy().reshape(-1), t["constraint"].numpy(), rtol=1e-5, atol=2e-5)
+        assert (t["obs2"][:, 2].abs() >= 3.14159).sum() > 10 and (t["obs2"][:, 10].abs() >= 3.14159).sum() > 10   # both heading clips are in the fixture
 
 
 CSTR_STEP_CASES = ["step_veh_surrcstr_p10", "step_veh_detour_p10", "step_veh_surrcstr_p5_n2", "step_veh_surrpen_p10",

@@ -315,7 +315,7 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
     p.ldh = hmax + 4;
     const bool veh = env_has_ref_table(e.kind);
     const int ref_pts = veh ? e.pre_horizon + 1 + desc.horizon
-                                                          : (e.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
+                                                          : (e.kind == GOPS_ENV_IDPENDULUM ? IDP_POINTS(false) : 0);
     if (rollout_fwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16, 0) > 160 * 1024 || rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, f16, false) > 160 * 1024)
         return GOPS_ERR_UNSUPPORTED;
     p.sp.on = split_eligible(p) ? 1 : 0;
@@ -401,7 +401,17 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         }
         p.st.dy = c.take((size_t)S * 4);
         p.st.env = c.take((size_t)S * ENV_STASH);
-        if (p.sp.on && e.kind == GOPS_ENV_IDPENDULUM) p.st.idp = c.take((size_t)S * IDP_PARK);
+        if (e.kind == GOPS_ENV_IDPENDULUM && e.repeat_num <= 1) {
+            // the sub-step parking of the forward: read by the plane-split stationary sweep and by the sweeps that stage nothing
+            // else (streamed fp32 - also its EXT form -, streamed-split); the exact-fp32 stationary sweep and the half kernels recompute
+            bool park = p.sp.on != 0;
+            if (!park && !f16) {
+                int sk[2];
+                rollout_variant(p, sk, true);
+                park = p.ssb || sk[1] == 0;
+            }
+            if (park) p.st.idp = c.take((size_t)S * IDP_PARK);
+        }
         if (p.tail) {
             for (int j = 1; j < p.val.nl; ++j) {
                 const size_t rows = (size_t)((p.B + tile_rows - 1) / tile_rows) * tile_rows;   // whole tiles (FM stash tiles are written whole)

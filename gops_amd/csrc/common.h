@@ -17,7 +17,7 @@
 #define MOB_OBS 13        // pyth_mobilerobot: observation = state columns
 // LDS "reference points" (x 4 TB floats) of the idpendulum sweeps: one [TB][5][24] parking, or - plane-split stationary sweep -
 // the two parity halves of the staged [TB][IDP_PARK] parking the forward wrote
-#define IDP_POINTS(split) ((split) ? 64 : 30)
+#define IDP_POINTS(split) ((split) ? 64 : 32)
 #define IDP_PARK 128      // floats of the idpendulum sub-step parking per (t, b): [k][24] (state, sin / cos, M^-1, qdd), [120..125] final state
 #define ENV_STASH 16      // floats of per-(t,b) env stash: [0..3] abar, [4] done_t, [5..10] state_t, [12..15] veh3dof: sin, cos of the heading before / after the step
 

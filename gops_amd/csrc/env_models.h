@@ -144,6 +144,9 @@ __device__ __forceinline__ void pend_backward(const float* x, float a, const flo
 }
 
 // ================================ pyth_idpendulum =============================================
+#ifndef GOPS_IDP_FAST
+#define GOPS_IDP_FAST 1
+#endif
 struct IdpConst {   // products of the Python-double constants, rounded once like torch does
     float a, b, e, f, h, k, gb, ge, l1, l2;
 };
@@ -205,7 +208,15 @@ __device__ __forceinline__ void idp_substep(const IdpConst& C, const float* s, f
     const float c11 = m00 * m22 - m02 * m02;
     const float c12 = m01 * m02 - m00 * m12;
     const float c22 = m00 * m11 - m01 * m01;
-    const float rdet = 1.f / (m00 * c00 + m01 * c01 + m02 * c02);
+    const float det = m00 * c00 + m01 * c01 + m02 * c02;
+#if GOPS_IDP_FAST
+    // hardware reciprocal + one Newton step (<= 1 ulp of the IEEE quotient; det is 0.1 .. 2, never scaled): 3 instead of 10
+    // instructions of the sub-step's dependent chain
+    float rdet = __builtin_amdgcn_rcpf(det);
+    rdet = rdet * (2.f - det * rdet);
+#else
+    const float rdet = 1.f / det;
+#endif
     w.inv[0] = c00 * rdet; w.inv[1] = c01 * rdet; w.inv[2] = c02 * rdet;
     w.inv[3] = c11 * rdet; w.inv[4] = c12 * rdet; w.inv[5] = c22 * rdet;
     w.qdd[0] = w.inv[0] * f0 + w.inv[1] * f1 + w.inv[2] * f2;
@@ -262,6 +273,12 @@ __device__ __forceinline__ float idp_reward(const float* s, float a) {
 
 __device__ __forceinline__ bool idp_done(const IdpConst& C, const float* s) {
     const float tip_y = C.l1 * cosf(s[1]) + C.l2 * cosf(s[2]);
+    return (tip_y <= 1.0f) || (fabsf(s[0]) >= 15.f);
+}
+// the same test with the cosines of the new angles at hand (idp_advance_trig of the last sub-step: within 3e-7 of cosf, the
+// reference's own torch.cos is within 1 ulp of it): two rotations instead of two libm cosf on the step's dependent chain
+__device__ __forceinline__ bool idp_done_trig(const IdpConst& C, const float* s, float c1, float c2) {
+    const float tip_y = C.l1 * c1 + C.l2 * c2;
     return (tip_y <= 1.0f) || (fabsf(s[0]) >= 15.f);
 }
 

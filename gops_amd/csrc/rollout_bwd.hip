@@ -11,6 +11,9 @@
 #ifndef GOPS_SWEEP_STAGE_NT
 #define GOPS_SWEEP_STAGE_NT true   // the stash rows the sweep stages one step ahead are read once by this launch
 #endif
+#ifndef GOPS_IDP_BWD_UNROLL
+#define GOPS_IDP_BWD_UNROLL 1   // the five sub-step adjoints of pyth_idpendulum unrolled: the parking reads of all of them issue up front (cfg2 sweep 197 -> 181 us)
+#endif
 #include "env_models.h"
 #include "rollout_f16.h"
 
@@ -662,6 +665,23 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
                 async_copy16_to_lds<GOPS_SWEEP_STAGE_NT>(p.st.idp + r0 * IDP_PARK + (wv * 2 + q2) * 256 + 4 * ln, s_idp + (tt & 1) * (TB * IDP_PARK) + (wv * 2 + q2) * 256);
         }
     };
+    // pyth_idpendulum on the kernels that stage nothing else (streamed fp32, EXT, streamed-split): the forward's sub-step parking
+    // of step tt (p.st.idp, 16 x 512 B contiguous) -> s_idp, issued one step ahead behind the head of step tt + 1 (after_head:
+    // the env phase that read s_idp is over, nothing latency-critical follows) and drained by the step's closing barrier.  Without
+    // it the env adjoint recomputes the five Euler sub-steps (libm sincosf included): 9.7 - 10.9 k of a 19.5 k-cycle step at cfg1.
+    constexpr bool IDPPARK = (ENV == GOPS_ENV_IDPENDULUM) && !STAGE && !F16;
+    const bool idp_parked = IDPPARK && p.st.idp != nullptr;
+    auto stage_idp = [&](int tt) {
+        if constexpr (IDPPARK) {
+            if (idp_parked) {
+                const size_t r0 = ((size_t)tile * hH + tt) * TB;
+                const int ln = tid & 63, wv = tid >> 6;
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+                    async_copy16_to_lds<GOPS_SWEEP_STAGE_NT>(p.st.idp + r0 * IDP_PARK + (wv * 2 + q2) * 256 + 4 * ln, s_idp + (wv * 2 + q2) * 256);
+            }
+        }
+    };
     const int ntiles = (p.B + TB - 1) / TB;
     SsOutGrad og = {};   // (SSB with the fused output-layer gradient; otherwise unused)
     do {   // ---- one tile of 16 trajectories ----
@@ -746,6 +766,13 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if constexpr (IDPPARK) {
+        if (idp_parked) {
+            stage_idp(hH - 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
 
     unsigned l2_sink = 0, l2_pf[TOUCH_SLOTS] = {0u, 0u, 0u, 0u};
     for (int t = hH - 1; t >= 0; --t) {
@@ -761,6 +788,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
         // so they are issued where no latency-critical load follows for thousands of cycles - right
         // after the head, ahead of the hidden-layer GEMMs - never in front of the env-row / act' loads.
         auto warm_up = [&]() {
+            if (t > 0) stage_idp(t - 1);
             if (tmode != 0) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) l2_pf[q] = touch_fetch(p.pol, p.st, prow, tid + NTHREADS * q);
@@ -1091,6 +1119,10 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
                         park = s_idp + (t & 1) * (TB * IDP_PARK) + m * IDP_PARK;
 #pragma unroll
                         for (int i = 0; i < 6; ++i) sc_[i] = park[120 + i];   // the state after the step
+                    } else if (idp_parked) {   // parked by the forward, copied one step ahead (stage_idp)
+                        park = s_idp + m * IDP_PARK;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) sc_[i] = park[120 + i];
                     } else {
                         float* parkw = s_idp + m * (5 * 24);
                         park = parkw;
@@ -1124,7 +1156,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
                     g[4] += g_rm * (-1.f * sc_[4]);
                     g[5] += g_rm * (-2.f * sc_[5]);
                     float gforce = 0.f;
+#if GOPS_IDP_BWD_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
                     for (int k = 4; k >= 0; --k) {
                         const float* pk = park + k * 24;
                         IdpSub w;
@@ -1497,17 +1533,20 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
             mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
                          nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up, st_cur, st_cur + TB * 256,
                          ENV == GOPS_ENV_NONE ? q.ext_delta : nullptr);
-        } else if (tid < nvalid) {   // open loop: the head adjoint IS the result; no policy input adjoint
-            GLOBAL_AS float* gp = gptr(q.g_head_pre) + ((size_t)(b0 + tid) * p.H + t) * A;
+        } else {   // open loop: the head adjoint IS the result; no policy input adjoint
+            if (t > 0) stage_idp(t - 1);
+            if (tid < nvalid) {
+                GLOBAL_AS float* gp = gptr(q.g_head_pre) + ((size_t)(b0 + tid) * p.H + t) * A;
 #pragma unroll
-            for (int a = 0; a < GOPS_MAX_ACT; ++a)
-                if (a < A) gp[a] = s_gy[tid * 4 + a];
+                for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                    if (a < A) gp[a] = s_gy[tid * 4 + a];
+            }
         }
         // retire this step's warm-up loads inside the same iteration: the compiler can then count the
         // memory operations issued since (exact vmcnt) instead of draining everything at the back-edge
 #pragma unroll
         for (int q = 0; q < TOUCH_SLOTS; ++q) l2_sink ^= l2_pf[q];
-        if constexpr (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next step's staged data has landed
+        if constexpr (STAGE || IDPPARK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next step's staged data has landed
         __syncthreads();
         DBG_TICK(2)
     }
@@ -1570,7 +1609,7 @@ int ssb_grid_limit() { return 2 * split_grid_limit(); }   // workgroups of the s
 bool ssb_eligible(const RolloutParams& p) {
     if (!p.ss) return false;
     if (p.vflags & GOPS_VF_NO_STREAMED_SPLIT_BWD) return false;
-    const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
+    const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? IDP_POINTS(false) : 0);
     return rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false, true) + (env_in_lds(p.env.kind, true) ? 4 * ENV_LDS_FLOATS : 0) <= 80 * 1024;
 }
 
@@ -1600,7 +1639,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
 #else
     if (p.h64) return launch_rollout_bwd_h64(p, dp, q, stream);   // half precision, 64-trajectory tiles
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? 30 : 0);
+    const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? IDP_POINTS(false) : 0);
     size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, p.f16 != 0, false);
     if (p.ext) {   // adjoint I/O / ActionRepeat: streamed fp32 kernels of the obs == state kinds
         if (p.f16) return hipErrorInvalidValue;

@@ -11,6 +11,9 @@
 
 #define GOPS_STREAMB_EXACT_REFILL   // (this translation unit only: the backward kernels' register allocation degrades with it)
 #include "common.h"
+#ifndef GOPS_IDP_FWD_UNROLL
+#define GOPS_IDP_FWD_UNROLL 0
+#endif
 #include "env_models.h"
 #include "rollout_f16.h"
 
@@ -777,7 +780,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                     IdpSub w;
                     idp_substep<true>(IC, s, u, 0.002f, sn, w);
                     park_store(0, w);
+#if GOPS_IDP_FWD_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
                     for (int k = 1; k < 5; ++k) {
                         idp_advance_trig(s, 0.002f, w, w);   // sin / cos of the new angles from the old ones (rotation by tau * theta_dot)
 #pragma unroll
@@ -785,12 +792,19 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                         idp_substep<false>(IC, s, u, 0.002f, sn, w);
                         park_store(k, w);
                     }
+#if GOPS_IDP_FAST
+                    idp_advance_trig(s, 0.002f, w, w);   // cosines of the new angles for the termination test
+#endif
 #pragma unroll
                     for (int i = 0; i < 6; ++i) s[i] = sn[i];
                     if (parkg != nullptr) { parkg[30] = f32x4{s[0], s[1], s[2], s[3]}; parkg[31] = f32x4{s[4], s[5], 0.f, 0.f}; }
                     r = idp_reward(s, a);
                     rs = (GEN && !p.env.repeat_last_reward) ? rs + r : r;
+#if GOPS_IDP_FAST
+                    done_m = idp_done_trig(IC, s, w.c1, w.c2);
+#else
                     done_m = idp_done(IC, s);
+#endif
                 }
                 r = rs;
                 if (s_done[m] == 0.f) {

@@ -142,7 +142,7 @@ const EnvOverride& env_override() {
             {"GOPS_SPLIT_STREAM0", '0', GOPS_VF_NO_SPLIT_STREAM0, 0}, {"GOPS_SPLIT_TAIL_MULTI", 0, GOPS_VF_SPLIT_TAIL_MULTI, 0},
             {"GOPS_DW_EXACT", 0, GOPS_VF_DW_EXACT, 0}, {"GOPS_DW_F32", 0, GOPS_VF_DW_F32, 0}, {"GOPS_DW_NOGUARD", 0, GOPS_VF_DW_NO_GUARD, 0}, {"GOPS_NO_FUSED_DW0", 0, GOPS_VF_NO_FUSED_DW0, 0},
             {"GOPS_DW_SKINNY", '0', GOPS_VF_DW_NO_SKINNY, 0}, {"GOPS_DW_SPEC", '0', GOPS_VF_DW_NO_SPEC, 0}, {"GOPS_DW_DIRECT", 0, GOPS_VF_DW_DIRECT, 0},
-            {"GOPS_NO_FUSED_DWOUT", 0, GOPS_VF_NO_FUSED_DWOUT, 0}, {"GOPS_H64", '0', GOPS_VF_NO_HALF_TILE64, 0}, {"GOPS_BWD_UPLOAD", 0, GOPS_VF_BWD_UPLOAD, 0},
+            {"GOPS_NO_FUSED_DWOUT", 0, GOPS_VF_NO_FUSED_DWOUT, 0}, {"GOPS_H64", '0', GOPS_VF_NO_HALF_TILE64, 0}, {"GOPS_NARROW", '0', GOPS_VF_NO_NARROW_LDS, 0}, {"GOPS_BWD_UPLOAD", 0, GOPS_VF_BWD_UPLOAD, 0},
             {"GOPS_SK", 0, 0, 1}, {"GOPS_TOUCH", 0, 0, 2}, {"GOPS_DW_WGS", 0, 0, 3}, {"GOPS_DBG_TIMING", 0, 0, 4}};
         EnvOverride r;
         for (const Knob& k : knobs) {
@@ -381,6 +381,24 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
                 sn.r[j] = reinterpret_cast<const f16x8*>(c.take((elems + 1) / 2));
                 sn.inv[j] = c.take(nin >> 4);
             }
+        }
+    }
+    // narrow nets on the plain streamed fp32 kernels (neither plane-split nor register-stationary nor half): the policy's packed
+    // hidden-layer weights live in LDS for the whole launch (common.h gemm_layer_lds) - the shapes of the reference's example scripts
+    p.narrow = 0;
+    if (!f16 && !p.sp.on && !p.ss && !p.ssb && !p.h64 && !p.open_loop && !(p.vflags & GOPS_VF_NO_NARROW_LDS)) {
+        int skf[2], skb[2], nf = 0;
+        rollout_variant(p, skf, false);
+        rollout_variant(p, skb, true);
+        for (int j = 0; j < p.pol.nl - 1; ++j) nf += p.pol.kp[j] * p.pol.dims[j + 1];
+        const size_t lf = (rollout_fwd_lds_bytes(p.ldx, p.ldh, veh ? ref_pts : 0, false, 0) + 15) & ~(size_t)15;
+        const size_t lb = (rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, false, false) + 15) & ~(size_t)15;
+        if (skf[0] == 0 && skf[1] == 0 && skb[0] == 0 && skb[1] == 0 && nf > 0 && nf <= NARROW_MAX_FLOATS && (nf & 3) == 0 &&
+            std::max(lf, lb) + 4 * (size_t)nf <= 52 * 1024) {   // three workgroups per CU stay resident
+            p.narrow = 1;
+            p.narrow_floats = nf;
+            p.narrow_off_fwd = (int)(lf / 4);
+            p.narrow_off_bwd = (int)(lb / 4);
         }
     }
     p.gscale = c.take(8);   // [4 ..]: the fused Adam step's scalar factors (adam_snapshot); [0 .. 1]: max|grad_v| / max|delta_y| of a backward launch (f16 sweep scale; delta scale of the weight-gradient GEMM)

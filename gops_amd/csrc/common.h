@@ -198,6 +198,9 @@ struct RolloutParams {
     unsigned vflags;                  // GOPS_VF_* of the description (| the debug override of the process environment, read once at load)
     int dw_wgs;                       // target workgroup count of a weight-gradient GEMM
     int h64;                          // 1: GOPS_DTYPE_F16 launch on the 64-trajectory-tile kernels (rollout_h64.hip): stash rows in 64-row tiles
+    int narrow;                       // 1: plain streamed fp32 kernels with the packed hidden-layer weights of the POLICY resident in LDS (narrow nets:
+                                      //    all of them <= NARROW_MAX_FLOATS; forward: wp[0 .. L-1], sweep: wpt[L-1 .. 0], narrow_floats each)
+    int narrow_floats, narrow_off_fwd, narrow_off_bwd;   //    size of the image, its offset (floats from the start of dynamic LDS) in either kernel
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double
 };
 
@@ -1146,6 +1149,39 @@ struct StatW {
     }
 };
 struct NoW {};   // placeholder for a streamed layer
+// Narrow nets (every hidden layer of the policy <= 64 wide or so: the shapes of the reference's example scripts) on the streamed fp32
+// kernels: at one n-tile per wave a layer is a handful of MFMAs behind the L2 round trip of its weight fragments (prime -> first
+// MFMA, once per layer per step).  The packed fragments of all hidden layers (<= NARROW_MAX_FLOATS) are copied to LDS once per
+// launch instead; fragment (nt, c) of a layer is the 1 KiB at Wl + (nt * kch + c) * 64 (one 16-byte read per lane, conflict-free).
+// Same products in the same order as the streamed path: bit-identical results (tests/test_narrow_gpu.py).  cfg1 (idpendulum,
+// 64-64 net) per step: forward GEMM phases 4.1 k -> 3.0 k cycles, sweep 3.1 k + 2.2 k -> 2.1 k + 1.4 k; update 175 -> 164 us.
+// (Reading a layer's fragments in one batch instead of chunk by chunk was measured: no gain.)
+#define NARROW_MAX_FLOATS 8192   // 32 KiB: (16 + 64) x 64 is 5120
+template <class Epi>
+__device__ __forceinline__ void gemm_layer_lds(const float* A, int lda, int kch, int nt_tot, const f32x4* Wl, int tid, Epi&& epi) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int per = (nt_tot + 3) >> 2;
+    const int nt_end = min(nt_tot, (wave + 1) * per);
+    const float* arow = A + (lane & 15) * lda + 4 * (lane >> 4);
+    for (int nt = wave * per; nt < nt_end; ++nt) {
+        const f32x4* wl = Wl + (size_t)nt * kch * 64 + lane;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 a = *reinterpret_cast<const f32x4*>(arow), b = wl[0];
+        for (int c = 0; c < kch; ++c) {
+            const int cn = (c + 1 < kch) ? c + 1 : c;
+            const f32x4 an = *reinterpret_cast<const f32x4*>(arow + 16 * cn), bn = wl[cn * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
+            a = an; b = bn;
+        }
+        f32x4 out[4] = {acc, {}, {}, {}};
+        epi.template operator()<1>(out, nt);
+    }
+}
+// copies `n4` 16-byte vectors of packed weights to LDS (all threads; the caller's next barrier publishes them)
+__device__ __forceinline__ void narrow_fill(f32x4* dst, const f32x4* src, int n4, int tid) {
+    for (int idx = tid; idx < n4; idx += NTHREADS) dst[idx] = gptr(src)[idx];
+}
 // every load issued so far complete (a real S_WAITCNT vmcnt(0) that the waitcnt pass accounts for)
 __device__ __forceinline__ void settle_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 

@@ -43,7 +43,9 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
                                              float* const* stash_d, float* stash_dy, size_t row0,
                                              int nvalid, bool want_gx, int ncols, DbgClock& dbg,
                                              Hook&& after_head, const float* stage_head = nullptr,
-                                             const float* stage_h1 = nullptr, const float* ext_delta = nullptr) {
+                                             const float* stage_h1 = nullptr, const float* ext_delta = nullptr,
+                                             const f32x4* narrow = nullptr) {
+    // narrow: LDS image of the transposed packings wpt[L-1], .., wpt[1], wpt[0] in this order (common.h gemm_layer_lds), or null
     // stage_head / stage_h1: LDS images (direct global->LDS loads issued at the top of the step) of the FM tiles
     // the head / the layer-1 epilogue take act' from; each wave reads only the 4 KiB its own lanes fetched.
     const int lane = tid & 63;
@@ -129,7 +131,14 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
         if constexpr (!std::is_same<W1T, NoW>::value) {
             if (j == 1) { gemm_layer_stat(cur, ldh, WT1, nt_tot, tid, epi); done = true; }
         }
-        if (!done) gemm_layer(cur, ldh, kch, nt_tot, M.wpt[j], tid, epi);
+        if (!done) {
+            if (narrow != nullptr) {
+                gemm_layer_lds(cur, ldh, kch, nt_tot, narrow, tid, epi);
+                narrow += kch * nt_tot * 64;
+            } else {
+                gemm_layer(cur, ldh, kch, nt_tot, M.wpt[j], tid, epi);
+            }
+        }
         DBG_TICK(6)
         __syncthreads();
         DBG_TICK(7)
@@ -159,6 +168,7 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
             }
         };
         if constexpr (!std::is_same<W0T, NoW>::value) gemm_layer_stat(cur, ldh, WT0, nt_tot, tid, epi, kch, M.wpt[0]);
+        else if (narrow != nullptr) gemm_layer_lds(cur, ldh, kch, nt_tot, narrow, tid, epi);
         else gemm_layer(cur, ldh, kch, nt_tot, M.wpt[0], tid, epi);
         DBG_TICK(9)
     }
@@ -597,6 +607,21 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
             for (int idx = tid; idx < Ao * K; idx += NTHREADS) {
                 const int a = idx / K, k = idx - a * K;
                 s_wo[a * ldh + k] = gptr(p.pol.w[Lh])[idx];
+            }
+        }
+    }
+    // narrow nets on the plain streamed fp32 sweeps: the transposed packings of the policy's hidden layers resident in LDS, in the
+    // order the sweep walks them (common.h gemm_layer_lds)
+    constexpr bool NARROWABLE = (SK0 == 0) && (SK1 == 0) && !F16 && !SPLIT && !SSB;
+    const f32x4* s_narrow = nullptr;
+    if constexpr (NARROWABLE) {
+        if (p.narrow) {
+            f32x4* dst = reinterpret_cast<f32x4*>(smem_raw + p.narrow_off_bwd);
+            s_narrow = dst;
+            for (int j = p.pol.nl - 2; j >= 0; --j) {
+                const int n4 = (p.pol.kp[j] * p.pol.dims[j + 1]) >> 2;
+                narrow_fill(dst, p.pol.wpt[j], n4, tid);
+                dst += n4;
             }
         }
     }
@@ -1528,11 +1553,11 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
                 mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z,
                              keep ? p.st.d : nullptr, keep ? p.st.dy : nullptr, row0, nvalid,
                              /*want_gx=*/(t > 0 && ENV != GOPS_ENV_NONE) || q.adj_gobs != nullptr, O, dbg, warm_up, st_cur,
-                             st_cur + TB * 256, ENV == GOPS_ENV_NONE ? q.ext_delta : nullptr);
+                             st_cur + TB * 256, ENV == GOPS_ENV_NONE ? q.ext_delta : nullptr, s_narrow);
             } else
             mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
                          nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up, st_cur, st_cur + TB * 256,
-                         ENV == GOPS_ENV_NONE ? q.ext_delta : nullptr);
+                         ENV == GOPS_ENV_NONE ? q.ext_delta : nullptr, s_narrow);
         } else {   // open loop: the head adjoint IS the result; no policy input adjoint
             if (t > 0) stage_idp(t - 1);
             if (tid < nvalid) {
@@ -1641,6 +1666,7 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
     const int ref_pts = env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : (p.env.kind == GOPS_ENV_IDPENDULUM ? IDP_POINTS(false) : 0);
     size_t lds = rollout_bwd_lds_bytes(p.ldx, p.ldh, ref_pts, p.f16 != 0, false);
+    if (p.narrow) lds = 4 * ((size_t)p.narrow_off_bwd + p.narrow_floats);   // (api.hip: only ever set for the plain streamed fp32 sweeps, EXT included)
     if (p.ext) {   // adjoint I/O / ActionRepeat: streamed fp32 kernels of the obs == state kinds
         if (p.f16) return hipErrorInvalidValue;
 #define LAUNCH_BWD_EXT(ENV)                                                                                             \

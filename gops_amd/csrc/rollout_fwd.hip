@@ -12,7 +12,7 @@
 #define GOPS_STREAMB_EXACT_REFILL   // (this translation unit only: the backward kernels' register allocation degrades with it)
 #include "common.h"
 #ifndef GOPS_IDP_FWD_UNROLL
-#define GOPS_IDP_FWD_UNROLL 0
+#define GOPS_IDP_FWD_UNROLL 1   // sub-steps 2 .. 5 of pyth_idpendulum unrolled (cfg2 forward 213 -> 208 us)
 #endif
 #include "env_models.h"
 #include "rollout_f16.h"
@@ -21,12 +21,13 @@
 // LDS buffer that holds the last hidden activation.  When stash_h is non-null the activations
 // (and GELU pre-activations) of the tile are written to stash_h[j] + row0 * dims[j].  Layers 0 / 1
 // use the register-stationary fragments W0 / W1 when those are StatW, else stream from L2.
+// narrow: LDS image of the packed weights of ALL hidden layers, layer after layer (common.h gemm_layer_lds), or null.
 template <class W0T, class W1T>
 __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T& W0, const W1T& W1,
                                                      const float* in, int ld_in, float* ha, float* hb,
                                                      int ldh, int tid, const float* s_bias,
                                                      float* const* stash_h, float* const* stash_z,
-                                                     size_t row0, DbgClock& dbg) {
+                                                     size_t row0, DbgClock& dbg, const f32x4* narrow = nullptr) {
     const int lane = tid & 63;
     const int L = M.nl - 1;
     const float* cur = in;
@@ -73,7 +74,14 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
         if constexpr (!std::is_same<W1T, NoW>::value) {
             if (j == 1) { gemm_layer_stat(cur, ldc, W1, nt_tot, tid, epi); done = true; }
         }
-        if (!done) gemm_layer(cur, ldc, kch, nt_tot, M.wp[j], tid, epi);
+        if (!done) {
+            if (narrow != nullptr) {
+                gemm_layer_lds(cur, ldc, kch, nt_tot, narrow, tid, epi);
+                narrow += kch * nt_tot * 64;
+            } else {
+                gemm_layer(cur, ldc, kch, nt_tot, M.wp[j], tid, epi);
+            }
+        }
         DBG_TICK(8 + 3 * (j & 1))
         __syncthreads();
         DBG_TICK(9 + 3 * (j & 1))
@@ -464,6 +472,20 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                                           },
                                           [&](int idx, float v) { s_bias[idx] = v; });
     }
+    // narrow nets on the plain streamed fp32 kernels: the packed hidden-layer weights of the policy, resident in LDS (common.h)
+    constexpr bool NARROWABLE = (SK0 == 0) && (SK1 == 0) && !F16 && !SPLIT && !SS;
+    const f32x4* s_narrow = nullptr;
+    if constexpr (NARROWABLE) {
+        if (p.narrow) {
+            f32x4* dst = reinterpret_cast<f32x4*>(smem_raw + p.narrow_off_fwd);
+            s_narrow = dst;
+            for (int j = 0; j < p.pol.nl - 1; ++j) {
+                const int n4 = (p.pol.kp[j] * p.pol.dims[j + 1]) >> 2;
+                narrow_fill(dst, p.pol.wp[j], n4, tid);
+                dst += n4;
+            }
+        }
+    }
     typename std::conditional<(SK0 > 0 && !SPLIT), StatW<(SK0 > 0 ? SK0 : 1), 4>, NoW>::type W0;
     typename std::conditional<(SK1 > 0 && !SPLIT), StatW<(SK1 > 0 ? SK1 : 1), 4>, NoW>::type W1;
     if constexpr (SK0 > 0 && !SPLIT) W0.load(p.pol.wp[0], p.pol.dims[1] >> 4, tid, p.pol.kp[0] >> 4);
@@ -627,7 +649,7 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                 } else {
                     float* hcur = mlp_hidden_forward(p.pol, W0, W1, xs, ldx, ha, hb, ldh, tid, s_bias,
                                                      p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
-                                                     row0, dbg);
+                                                     row0, dbg, s_narrow);
                     DBG_TICK(2)
                     mlp_head<true>(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ldh, tid, y);
                     DBG_TICK(6)
@@ -1378,8 +1400,9 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
 #else
     if (p.h64) return launch_rollout_fwd_h64(p, dp, stream);   // half precision, 64-trajectory tiles
     const dim3 grid((p.B + TB - 1) / TB), block(NTHREADS);
-    const size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0, p.f16 != 0,
-                                             p.sp.on ? 32 * p.sp.kc[0] : 0);
+    size_t lds = rollout_fwd_lds_bytes(p.ldx, p.ldh, env_has_ref_table(p.env.kind) ? p.env.pre_horizon + 1 + p.H : 0, p.f16 != 0,
+                                       p.sp.on ? 32 * p.sp.kc[0] : 0);
+    if (p.narrow) lds = 4 * ((size_t)p.narrow_off_fwd + p.narrow_floats);   // (api.hip: only ever set for the plain streamed fp32 kernels)
     int sk[2];
     rollout_variant(p, sk, false);
     const int key = sk[0] * 100 + sk[1];

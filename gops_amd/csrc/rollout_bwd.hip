@@ -1658,7 +1658,10 @@ bool ssb_eligible(const RolloutParams& p) {
 
 hipError_t launch_rollout_bwd_h64(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream);   // rollout_h64.hip
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream) {
-#ifdef GOPS_ONLY_TARGET   // register / spill studies (EXTRA=-DGOPS_ONLY_TARGET tools/kernel_regs.sh rollout_bwd.hip): ONE instantiation, seconds to compile
+#ifdef GOPS_ONLY_NARROW   // the same for the plain streamed fp32 kernel of pyth_idpendulum (cfg1, the example scripts' shapes): EXTRA=-DGOPS_ONLY_NARROW
+    launch_with_lds(rollout_bwd_kernel<GOPS_ENV_IDPENDULUM, 0, 0, false>, dim3(1), dim3(NTHREADS), 0, stream, dp, q);
+    return hipGetLastError();
+#elif defined(GOPS_ONLY_TARGET)   // register / spill studies (EXTRA=-DGOPS_ONLY_TARGET tools/kernel_regs.sh rollout_bwd.hip): ONE instantiation, seconds to compile
     launch_with_lds(rollout_bwd_kernel<GOPS_ENV_VEH3DOFCONTI, 8, 8, false, 2, false, false, true>, dim3(1), dim3(NTHREADS), 0, stream, dp, q);
     return hipGetLastError();
 #else

@@ -1394,7 +1394,10 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
 // `p` is the host copy (for shape dispatch), `dp` the device copy the kernel reads.
 hipError_t launch_rollout_fwd_h64(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);   // rollout_h64.hip
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
-#ifdef GOPS_ONLY_TARGET   // register / ISA studies (EXTRA=-DGOPS_ONLY_TARGET tools/kernel_regs.sh rollout_fwd.hip): ONE instantiation, seconds to compile
+#ifdef GOPS_ONLY_NARROW   // the same for the plain streamed fp32 kernel of pyth_idpendulum (cfg1, the example scripts' shapes): EXTRA=-DGOPS_ONLY_NARROW
+    launch_with_lds(rollout_fwd_kernel<GOPS_ENV_IDPENDULUM, 0, 0, false>, dim3(1), dim3(NTHREADS), 0, stream, dp);
+    return hipGetLastError();
+#elif defined(GOPS_ONLY_TARGET)   // register / ISA studies (EXTRA=-DGOPS_ONLY_TARGET tools/kernel_regs.sh rollout_fwd.hip): ONE instantiation, seconds to compile
     launch_with_lds(rollout_fwd_kernel<GOPS_ENV_VEH3DOFCONTI, 4, 8, false, false, false, true>, dim3(1), dim3(NTHREADS), 0, stream, dp);
     return hipGetLastError();
 #else

@@ -21,6 +21,8 @@ CASES = [
     ("pyth_veh3dofconti", dict(pre_horizon=10), (64, 64), "elu", 64, 10),    # 46 inputs -> three k-chunks in layer 0
     ("pyth_lq", dict(lq_config="s4a2"), (64, 64, 64), "relu", 48, 8),        # three hidden layers: 9216 floats, NOT resident (stays streamed)
     ("pyth_lq", dict(lq_config="s4a2"), (64, 32, 16), "relu", 48, 8),        # three hidden layers, resident
+    ("pyth_idpendulum", {}, (64, 64), "elu", 1, 1),                          # one trajectory, one step (no input adjoint GEMM at t = 0)
+    ("pyth_lq", dict(lq_config="s4a2"), (16,), "tanh", 33, 3),               # ONE hidden layer of one n-tile: three of four waves idle
 ]
 
 

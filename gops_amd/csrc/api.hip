@@ -142,7 +142,7 @@ const EnvOverride& env_override() {
             {"GOPS_SPLIT_STREAM0", '0', GOPS_VF_NO_SPLIT_STREAM0, 0}, {"GOPS_SPLIT_TAIL_MULTI", 0, GOPS_VF_SPLIT_TAIL_MULTI, 0},
             {"GOPS_DW_EXACT", 0, GOPS_VF_DW_EXACT, 0}, {"GOPS_DW_F32", 0, GOPS_VF_DW_F32, 0}, {"GOPS_DW_NOGUARD", 0, GOPS_VF_DW_NO_GUARD, 0}, {"GOPS_NO_FUSED_DW0", 0, GOPS_VF_NO_FUSED_DW0, 0},
             {"GOPS_DW_SKINNY", '0', GOPS_VF_DW_NO_SKINNY, 0}, {"GOPS_DW_SPEC", '0', GOPS_VF_DW_NO_SPEC, 0}, {"GOPS_DW_DIRECT", 0, GOPS_VF_DW_DIRECT, 0},
-            {"GOPS_NO_FUSED_DWOUT", 0, GOPS_VF_NO_FUSED_DWOUT, 0}, {"GOPS_H64", '0', GOPS_VF_NO_HALF_TILE64, 0}, {"GOPS_NARROW", '0', GOPS_VF_NO_NARROW_LDS, 0}, {"GOPS_BWD_UPLOAD", 0, GOPS_VF_BWD_UPLOAD, 0},
+            {"GOPS_NO_FUSED_DWOUT", 0, GOPS_VF_NO_FUSED_DWOUT, 0}, {"GOPS_H64", '0', GOPS_VF_NO_HALF_TILE64, 0}, {"GOPS_NARROW", '0', GOPS_VF_NO_NARROW_LDS, 0}, {"GOPS_N64", '0', GOPS_VF_NO_NARROW_N64, 0}, {"GOPS_BWD_UPLOAD", 0, GOPS_VF_BWD_UPLOAD, 0},
             {"GOPS_SK", 0, 0, 1}, {"GOPS_TOUCH", 0, 0, 2}, {"GOPS_DW_WGS", 0, 0, 3}, {"GOPS_DBG_TIMING", 0, 0, 4}};
         EnvOverride r;
         for (const Knob& k : knobs) {
@@ -396,6 +396,8 @@ int build_plan(const GopsRolloutDesc& desc, void* ws, Plan& plan) {
         if (skf[0] == 0 && skf[1] == 0 && skb[0] == 0 && skb[1] == 0 && nf > 0 && nf <= NARROW_MAX_FLOATS && (nf & 3) == 0 &&
             std::max(lf, lb) + 4 * (size_t)nf <= 52 * 1024) {   // three workgroups per CU stay resident
             p.narrow = 1;
+            // obs -> 64 -> 64 -> act (<= 64 padded inputs): the kernels' form with these shapes as compile-time constants
+            if (p.pol.nl == 3 && p.pol.dims[1] == 64 && p.pol.dims[2] == 64 && p.pol.kp[0] <= 64 && !(p.vflags & GOPS_VF_NO_NARROW_N64)) p.narrow = 2;
             p.narrow_floats = nf;
             p.narrow_off_fwd = (int)(lf / 4);
             p.narrow_off_bwd = (int)(lb / 4);

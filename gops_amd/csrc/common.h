@@ -198,7 +198,8 @@ struct RolloutParams {
     unsigned vflags;                  // GOPS_VF_* of the description (| the debug override of the process environment, read once at load)
     int dw_wgs;                       // target workgroup count of a weight-gradient GEMM
     int h64;                          // 1: GOPS_DTYPE_F16 launch on the 64-trajectory-tile kernels (rollout_h64.hip): stash rows in 64-row tiles
-    int narrow;                       // 1: plain streamed fp32 kernels with the packed hidden-layer weights of the POLICY resident in LDS (narrow nets:
+    int narrow;                       // 1 / 2: plain streamed fp32 kernels with the packed hidden-layer weights of the POLICY resident in LDS (narrow nets;
+                                      //    2: obs -> 64 -> 64 -> act, the N64 instantiations:
                                       //    all of them <= NARROW_MAX_FLOATS; forward: wp[0 .. L-1], sweep: wpt[L-1 .. 0], narrow_floats each)
     int narrow_floats, narrow_off_fwd, narrow_off_bwd;   //    size of the image, its offset (floats from the start of dynamic LDS) in either kernel
     float gpow[GOPS_MAX_HORIZON + 1]; // gamma^t rounded from double

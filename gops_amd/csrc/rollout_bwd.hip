@@ -174,6 +174,88 @@ __device__ __forceinline__ void mlp_backward(const MlpDev& M, const W0T& WT0, co
     }
 }
 
+// obs -> 64 -> 64 -> act policies on the narrow launches (rollout_fwd.hip: mlp_hidden_forward_n64): mlp_backward written out for
+// that shape - one n-tile per wave in every phase, no layer loop, nothing of the parameter block read inside the step loop (Hot64B,
+// pinned once per launch), and BOTH act' vectors of the wave's tile requested at the top of the step's backward (this instantiation
+// has the registers for it: the streamed GEMM's fragment ring is not part of it).  Same products in the same order as mlp_backward.
+struct Hot64B {
+    int act, A, nt0;               // activation kind, action dimension, 16-wide n-tiles of the (padded) policy input
+    const float *a1, *a2;          // act' sources of the two hidden layers: H_j, or Z_j (= gelu'(z)) for GELU
+    float *d1, *d2, *dy;           // delta stashes (null: not written)
+    const f32x4 *w1t, *w0t;        // LDS images of the transposed packings wpt[1], wpt[0] (narrow_fill)
+};
+template <class WP, class Hook>
+__device__ __forceinline__ void mlp_backward_n64(const Hot64B& hn, WP Wo, int ldw, const float* s_gy, float* da, float* db, int ldh,
+                                                 float* G, int ldg, int tid, size_t row0, int nvalid, bool want_gx, int ncols,
+                                                 DbgClock& dbg, Hook&& after_head) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = (wave << 4) + (lane & 15), m0 = (lane >> 4) << 2, kk = lane >> 4;
+    const f32x4 hv2 = ld4(gptr(hn.a2 + row0 * 64) + n * 16 + m0);
+    const f32x4 hv1 = ld4(gptr(hn.a1 + row0 * 64) + n * 16 + m0);
+    auto delta_tile = [&](const f32x4& acc, const f32x4& hv, float* out, float* dst) {
+        act_dispatch(hn.act, [&]<int ACT>() {
+            f32x4 dv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dv[r] = (m0 + r < nvalid) ? acc[r] * act_bwd_t<ACT>(hv[r], hv[r]) : 0.f;
+                out[(m0 + r) * ldh + n] = dv[r];
+            }
+            if (dst != nullptr) __builtin_nontemporal_store(dv, gptr(reinterpret_cast<f32x4*>(dst + row0 * 64 + n * 16 + m0)));
+        });
+    };
+    {   // ---- head: delta_2 = (delta_y W_o) * act'(z_2): ONE v_mfma_f32_16x16x4_f32 ----
+        const float ga = (kk < hn.A) ? s_gy[(lane & 15) * 4 + kk] : 0.f;   // A operand: delta_y[m = lane & 15][k = lane >> 4]
+        const float bw = (kk < hn.A) ? Wo[kk * ldw + n] : 0.f;             // B: W_o[k][n]
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, bw, acc, 0, 0, 0);
+        delta_tile(acc, hv2, da, hn.d2);
+        if (hn.dy != nullptr && tid < TB) {
+            f32x4 v = {s_gy[tid * 4 + 0], s_gy[tid * 4 + 1], s_gy[tid * 4 + 2], s_gy[tid * 4 + 3]};
+#pragma unroll
+            for (int a = 0; a < GOPS_MAX_ACT; ++a)
+                if (a >= hn.A || tid >= nvalid) v[a] = 0.f;
+            *gptr(reinterpret_cast<f32x4*>(hn.dy + (row0 + tid) * 4)) = v;
+        }
+    }
+    DBG_TICK(3)
+    __syncthreads();
+    DBG_TICK(4)
+    after_head();
+    DBG_TICK(5)
+    auto gemm64 = [&](const float* Atile, const f32x4* Wl) -> f32x4 {   // [16 x 64] x this wave's [64 x 16] tile: 8 reads, 16 MFMAs
+        const float* arow = Atile + (lane & 15) * ldh + 4 * (lane >> 4);
+        const f32x4* wl = Wl + (wave * 4 * 64 + lane);
+        f32x4 a[4], b[4], acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { a[c] = *reinterpret_cast<const f32x4*>(arow + 16 * c); b[c] = wl[c * 64]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], b[c][i], acc, 0, 0, 0);
+        return acc;
+    };
+    {   // ---- delta_1 = (delta_2 W_1) * act'(z_1) ----
+        const f32x4 acc = gemm64(da, hn.w1t);
+        delta_tile(acc, hv1, db, hn.d1);
+    }
+    DBG_TICK(6)
+    __syncthreads();
+    DBG_TICK(7)
+    DBG_TICK(8)
+    if (want_gx && wave < hn.nt0) {   // ---- input adjoint g_x = delta_1 W_0 ----
+        const f32x4 acc = gemm64(db, hn.w0t);
+        const int nr = min(n, ncols - 1);
+        float gold[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gold[r] = G[(m0 + r) * ldg + nr];
+        if (n < ncols) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) G[(m0 + r) * ldg + n] = gold[r] + acc[r];
+        }
+    }
+    DBG_TICK(9)
+}
+
 // Plane-split backward through the policy MLP (common.h SplitDev): delta_y (s_gy) -> delta_2 -> delta_1 -> g_x.
 // The head delta is one exact fp32 MFMA per n-tile as in mlp_backward; every delta tile leaves its epilogue registers
 // three ways: one 16-byte vector to the fp32 FM stash (weight-gradient GEMM), and - through plane_store - as the bf16 / f16
@@ -546,7 +628,8 @@ __device__ __forceinline__ void ss_net_backward(const MlpDev& M, const SplitNetD
 // MULTI (SPLIT only): more tiles than workgroups - grid-stride walk over the tiles
 // SSB: streamed-split sweep (ss_net_backward): plane-split MFMAs with all (transposed) weight planes streamed from L2, two
 // workgroups per CU; the tail value net's input adjoint on the same routine
-template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, bool EXT = false, bool SPLIT = false, bool MULTI = false, bool SSB = false>
+// N64 (narrow launches of obs -> 64 -> 64 -> act policies: RolloutParams.narrow == 2): the policy's backward by mlp_backward_n64
+template <int ENV, int SK0, int SK1, bool TAIL, int PT0 = 1, bool F16 = false, bool EXT = false, bool SPLIT = false, bool MULTI = false, bool SSB = false, bool N64 = false>
 __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 == 0) ? 3 : 1))) void rollout_bwd_kernel(const RolloutParams* __restrict__ pp, const BwdPatch q) {
     extern __shared__ __attribute__((aligned(16))) float smem_raw[];
     const RolloutParams& p = *pp;
@@ -624,6 +707,19 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
                 dst += n4;
             }
         }
+    }
+    Hot64B hot64 = {};
+    if constexpr (N64) {
+        static_assert(NARROWABLE && !EXT, "N64 is a variant of the plain streamed fp32 sweep");
+        const bool gl = p.pol.act == GOPS_ACT_GELU;
+        hot64.act = keep_s(p.pol.act);
+        hot64.A = keep_s(p.pol.dims[3]);
+        hot64.nt0 = keep_s(p.pol.kp[0] >> 4);
+        hot64.a1 = keep_s(gl ? p.st.z[1] : p.st.h[1]);
+        hot64.a2 = keep_s(gl ? p.st.z[2] : p.st.h[2]);
+        hot64.d1 = keep_s(p.st.d[1]); hot64.d2 = keep_s(p.st.d[2]); hot64.dy = keep_s(p.st.dy);
+        hot64.w1t = s_narrow;
+        hot64.w0t = s_narrow + 4 * 4 * 64;
     }
     typename std::conditional<(SK0 > 0 && !SPLIT), StatW<(SK0 > 0 ? SK0 : 1), PT0>, NoW>::type WT0;
     typename std::conditional<(SK1 > 0 && !SPLIT), StatW<16, 4>, NoW>::type WT1;
@@ -1555,6 +1651,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
                              /*want_gx=*/(t > 0 && ENV != GOPS_ENV_NONE) || q.adj_gobs != nullptr, O, dbg, warm_up, st_cur,
                              st_cur + TB * 256, ENV == GOPS_ENV_NONE ? q.ext_delta : nullptr, s_narrow);
             } else
+            if constexpr (N64)
+                mlp_backward_n64(hot64, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, row0, nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up);
+            else
             mlp_backward<STAGE>(p.pol, WT0, WT1, s_wo, ldh, s_gy, da, db, ldh, G, ldx, tid, p.st.h, p.st.z, p.st.d, p.st.dy, row0,
                          nvalid, /*want_gx=*/t > 0 && ENV != GOPS_ENV_NONE, O, dbg, warm_up, st_cur, st_cur + TB * 256,
                          ENV == GOPS_ENV_NONE ? q.ext_delta : nullptr, s_narrow);
@@ -1643,6 +1742,14 @@ bool ssb_eligible(const RolloutParams& p) {
         if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, A, B, true>, grid, block, lds, stream, dp, q);   \
         else launch_with_lds(rollout_bwd_kernel<ENV, A, B, false>, grid, block, lds, stream, dp, q);         \
     } while (0)
+// the plain streamed fp32 sweep, or its obs -> 64 -> 64 -> act form (RolloutParams.narrow == 2: mlp_backward_n64)
+#define LAUNCH_BWD_PLAIN(ENV)                                                                                                                       \
+    do {                                                                                                                                            \
+        if (p.narrow == 2 && q.ext_delta == nullptr) {   /* (gops_mlp_backward with a wide output layer: the generic head) */                       \
+            if (p.tail) launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, true, 1, false, false, false, false, false, true>, grid, block, lds, stream, dp, q);  \
+            else launch_with_lds(rollout_bwd_kernel<ENV, 0, 0, false, 1, false, false, false, false, false, true>, grid, block, lds, stream, dp, q);        \
+        } else LAUNCH_BWD(ENV, 0, 0);                                                                                                               \
+    } while (0)
 
 #define LAUNCH_BWD_H(ENV)                                                                                       \
     do {                                                                                                        \
@@ -1659,7 +1766,11 @@ bool ssb_eligible(const RolloutParams& p) {
 hipError_t launch_rollout_bwd_h64(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream);   // rollout_h64.hip
 hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, const BwdPatch& q, hipStream_t stream) {
 #ifdef GOPS_ONLY_NARROW   // the same for the plain streamed fp32 kernel of pyth_idpendulum (cfg1, the example scripts' shapes): EXTRA=-DGOPS_ONLY_NARROW
-    launch_with_lds(rollout_bwd_kernel<GOPS_ENV_IDPENDULUM, 0, 0, false>, dim3(1), dim3(NTHREADS), 0, stream, dp, q);
+#if GOPS_ONLY_NARROW == 2
+    launch_with_lds(rollout_bwd_kernel<GOPS_ENV_IDPENDULUM, 0, 0, false, 1, false, false, false, false, false, true>, dim3((p.B + TB - 1) / TB), dim3(NTHREADS), 4 * ((size_t)p.narrow_off_bwd + p.narrow_floats), stream, dp, q);
+#else
+    launch_with_lds(rollout_bwd_kernel<GOPS_ENV_IDPENDULUM, 0, 0, false>, dim3((p.B + TB - 1) / TB), dim3(NTHREADS), 4 * ((size_t)p.narrow_off_bwd + p.narrow_floats), stream, dp, q);
+#endif
     return hipGetLastError();
 #elif defined(GOPS_ONLY_TARGET)   // register / spill studies (EXTRA=-DGOPS_ONLY_TARGET tools/kernel_regs.sh rollout_bwd.hip): ONE instantiation, seconds to compile
     launch_with_lds(rollout_bwd_kernel<GOPS_ENV_VEH3DOFCONTI, 8, 8, false, 2, false, false, true>, dim3(1), dim3(NTHREADS), 0, stream, dp, q);
@@ -1757,23 +1868,23 @@ hipError_t launch_rollout_bwd(const RolloutParams& p, const RolloutParams* dp, c
         return hipGetLastError();
     }
     switch (p.env.kind) {
-        case GOPS_ENV_NONE: LAUNCH_BWD(GOPS_ENV_NONE, 0, 0); break;
+        case GOPS_ENV_NONE: LAUNCH_BWD_PLAIN(GOPS_ENV_NONE); break;
         case GOPS_ENV_LQ:
-            if (key == 1616) LAUNCH_BWD(GOPS_ENV_LQ, 16, 16); else LAUNCH_BWD(GOPS_ENV_LQ, 0, 0);
+            if (key == 1616) LAUNCH_BWD(GOPS_ENV_LQ, 16, 16); else LAUNCH_BWD_PLAIN(GOPS_ENV_LQ);
             break;
         case GOPS_ENV_IDPENDULUM:
-            if (key == 1616) LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 16, 16); else LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 0, 0);
+            if (key == 1616) LAUNCH_BWD(GOPS_ENV_IDPENDULUM, 16, 16); else LAUNCH_BWD_PLAIN(GOPS_ENV_IDPENDULUM);
             break;
         case GOPS_ENV_VEH3DOFCONTI:
             if (key == 1216) LAUNCH_BWD2(GOPS_ENV_VEH3DOFCONTI, 12, 16, 2);
             else if (key == 16) LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 0, 16);
-            else LAUNCH_BWD(GOPS_ENV_VEH3DOFCONTI, 0, 0);
+            else LAUNCH_BWD_PLAIN(GOPS_ENV_VEH3DOFCONTI);
             break;
-        case GOPS_ENV_VEH3DOF_SURR: LAUNCH_BWD(GOPS_ENV_VEH3DOF_SURR, 0, 0); break;
-        case GOPS_ENV_CARTPOLE: LAUNCH_BWD(GOPS_ENV_CARTPOLE, 0, 0); break;
-        case GOPS_ENV_PENDULUM: LAUNCH_BWD(GOPS_ENV_PENDULUM, 0, 0); break;
-        case GOPS_ENV_VEH2DOF: LAUNCH_BWD(GOPS_ENV_VEH2DOF, 0, 0); break;
-        case GOPS_ENV_MOBILEROBOT: LAUNCH_BWD(GOPS_ENV_MOBILEROBOT, 0, 0); break;
+        case GOPS_ENV_VEH3DOF_SURR: LAUNCH_BWD_PLAIN(GOPS_ENV_VEH3DOF_SURR); break;
+        case GOPS_ENV_CARTPOLE: LAUNCH_BWD_PLAIN(GOPS_ENV_CARTPOLE); break;
+        case GOPS_ENV_PENDULUM: LAUNCH_BWD_PLAIN(GOPS_ENV_PENDULUM); break;
+        case GOPS_ENV_VEH2DOF: LAUNCH_BWD_PLAIN(GOPS_ENV_VEH2DOF); break;
+        case GOPS_ENV_MOBILEROBOT: LAUNCH_BWD_PLAIN(GOPS_ENV_MOBILEROBOT); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -93,6 +93,68 @@ __device__ __forceinline__ float* mlp_hidden_forward(const MlpDev& M, const W0T&
     return const_cast<float*>(cur);
 }
 
+// obs -> 64 -> 64 -> act policies (the shape of nearly every script under the reference's example_train/) on the narrow launches:
+// the two hidden layers written out with their shapes as compile-time constants - one n-tile per wave, no layer loop, and nothing of
+// the parameter block read inside the step loop (Hot64: pinned once per launch).  The generic layer loop spends ~1 k cycles per layer
+// on its own set-up before the first MFMA (knock-outs of the narrow kernel); same products in the same order.
+struct Hot64 {
+    int kch0, act;              // 16-wide k-chunks of the (padded) policy input; activation kind
+    float *h1, *h2, *z1, *z2;   // stash tensors of the two hidden layers (null: nothing is stashed)
+    const f32x4 *w0, *w1;       // LDS images of the packed weights (narrow_fill)
+};
+__device__ __forceinline__ float* mlp_hidden_forward_n64(const Hot64& hn, const float* in, int ld_in, float* ha, float* hb, int ldh, int tid,
+                                                         const float* s_bias, size_t row0, DbgClock& dbg) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = (wave << 4) + (lane & 15), m0 = (lane >> 4) << 2;
+    auto layer = [&]<int J>(const float* A, int lda, float* out) {
+        const int kch = (J == 0) ? hn.kch0 : 4;
+        const float* arow = A + (lane & 15) * lda + 4 * (lane >> 4);
+        const f32x4* wl = (J == 0 ? hn.w0 : hn.w1) + (wave * kch * 64 + lane);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (J == 1) {   // K = 64: the eight fragment reads up front, then the 16 MFMAs
+            f32x4 a[4], b[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { a[c] = *reinterpret_cast<const f32x4*>(arow + 16 * c); b[c] = wl[c * 64]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], b[c][i], acc, 0, 0, 0);
+        } else {
+            for (int c = 0; c < kch; ++c) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * c), b = wl[c * 64];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
+            }
+        }
+        DBG_TICK(14)
+        const float bn = s_bias[J * ldh + n];
+        float* hs = (J == 0) ? hn.h1 : hn.h2;
+        float* zs = (J == 0) ? hn.z1 : hn.z2;
+        float* hrow = (hs != nullptr) ? hs + row0 * 64 : nullptr;
+        float* zrow = (zs != nullptr) ? zs + row0 * 64 : nullptr;
+        act_dispatch(hn.act, [&]<int ACT>() {
+            f32x4 hv, zv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = acc[r] + bn;
+                float hr, dr = z;
+                if constexpr (ACT == GOPS_ACT_GELU) gelu_pair(z, hr, dr);   // dr: gelu'(z), what the sweep needs
+                else hr = act_fwd_t<ACT>(z);
+                hv[r] = hr; zv[r] = dr;
+                out[(m0 + r) * ldh + n] = hr;
+            }
+            if (hrow != nullptr) __builtin_nontemporal_store(hv, gptr(reinterpret_cast<f32x4*>(hrow + n * 16 + m0)));
+            if (ACT == GOPS_ACT_GELU && zrow != nullptr) __builtin_nontemporal_store(zv, gptr(reinterpret_cast<f32x4*>(zrow + n * 16 + m0)));
+        });
+        DBG_TICK(8 + 3 * J)
+        __syncthreads();
+        DBG_TICK(9 + 3 * J)
+    };
+    layer.template operator()<0>(in, ld_in, ha);
+    layer.template operator()<1>(ha, ldh, hb);
+    return hb;
+}
+
 // Output layer (width A <= 4) on the VALU: thread (hm = tid>>4, hp = tid&15) strides over k.
 // Wo is [4][ldw] in LDS with the rows a >= A ZERO-FILLED (staged once per launch) and bo likewise: all four
 // outputs are formed unconditionally, so the 5 x (K / 64) vector reads of a thread are issued back to back.  (With an
@@ -397,7 +459,8 @@ __device__ __forceinline__ float ss_net_forward(const MlpDev& M, const SplitNetD
 // MULTI (SPLIT only): more tiles than workgroups - the kernel walks its tiles grid-stride (the single-tile instantiation
 // keeps fewer values live across the step loop)
 // SS: streamed-split forward (ss_net_forward): plane-split MFMAs with all weight planes streamed from L2, two workgroups per CU
-template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false, bool GEN = false, bool SPLIT = false, bool MULTI = false, bool SS = false>
+// N64 (narrow launches of obs -> 64 -> 64 -> act policies: RolloutParams.narrow == 2): the hidden stack by mlp_hidden_forward_n64
+template <int ENV, int SK0, int SK1, bool TAIL, bool F16 = false, bool GEN = false, bool SPLIT = false, bool MULTI = false, bool SS = false, bool N64 = false>
 __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 0) ? 3 : 1))) void rollout_fwd_kernel(const RolloutParams* __restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem_raw[];
     const RolloutParams& p = *pp;   // parameters live in device memory: uniform scalar loads
@@ -485,6 +548,18 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                 dst += n4;
             }
         }
+    }
+    Hot64 hot64 = {};
+    if constexpr (N64) {
+        static_assert(NARROWABLE, "N64 is a variant of the plain streamed fp32 kernel");
+        hot64.kch0 = keep_s(p.pol.kp[0] >> 4);
+        hot64.act = keep_s(p.pol.act);
+        const bool st = p.need_grad != 0;
+        hot64.h1 = st ? keep_s(p.st.h[1]) : nullptr; hot64.h2 = st ? keep_s(p.st.h[2]) : nullptr;
+        hot64.z1 = (st && p.pol.act == GOPS_ACT_GELU) ? keep_s(p.st.z[1]) : nullptr;
+        hot64.z2 = (st && p.pol.act == GOPS_ACT_GELU) ? keep_s(p.st.z[2]) : nullptr;
+        hot64.w0 = s_narrow;
+        hot64.w1 = s_narrow + hot64.kch0 * 4 * 64;
     }
     typename std::conditional<(SK0 > 0 && !SPLIT), StatW<(SK0 > 0 ? SK0 : 1), 4>, NoW>::type W0;
     typename std::conditional<(SK1 > 0 && !SPLIT), StatW<(SK1 > 0 ? SK1 : 1), 4>, NoW>::type W1;
@@ -647,9 +722,13 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
                     DBG_TICK(2)
                     mlp_head_h<true>(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ld16, tid, y);
                 } else {
-                    float* hcur = mlp_hidden_forward(p.pol, W0, W1, xs, ldx, ha, hb, ldh, tid, s_bias,
-                                                     p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
-                                                     row0, dbg, s_narrow);
+                    float* hcur;
+                    if constexpr (N64)
+                        hcur = mlp_hidden_forward_n64(hot64, xs, ldx, ha, hb, ldh, tid, s_bias, row0, dbg);
+                    else
+                        hcur = mlp_hidden_forward(p.pol, W0, W1, xs, ldx, ha, hb, ldh, tid, s_bias,
+                                                  p.need_grad ? p.st.h : nullptr, p.need_grad ? p.st.z : nullptr,
+                                                  row0, dbg, s_narrow);
                     DBG_TICK(2)
                     mlp_head<true>(s_wo, ldh, s_bo, p.pol.dims[p.pol.nl - 1], p.pol.dims[p.pol.nl], hcur, ldh, tid, y);
                     DBG_TICK(6)
@@ -1385,6 +1464,14 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
         if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, A, B, true>, grid, block, lds, stream, dp);   \
         else launch_with_lds(rollout_fwd_kernel<ENV, A, B, false>, grid, block, lds, stream, dp);         \
     } while (0)
+// the plain streamed fp32 kernel, or its obs -> 64 -> 64 -> act form (RolloutParams.narrow == 2: mlp_hidden_forward_n64)
+#define LAUNCH_FWD_PLAIN(ENV)                                                                                                              \
+    do {                                                                                                                                   \
+        if (p.narrow == 2) {                                                                                                               \
+            if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, true, false, false, false, false, false, true>, grid, block, lds, stream, dp);  \
+            else launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, false, false, false, false, false, false, true>, grid, block, lds, stream, dp);        \
+        } else LAUNCH_FWD(ENV, 0, 0);                                                                                                      \
+    } while (0)
 #define LAUNCH_FWD_H(ENV)                                                                                          \
     do {                                                                                                           \
         if (p.tail) launch_with_lds(rollout_fwd_kernel<ENV, 0, 0, true, true>, grid, block, lds, stream, dp);       \
@@ -1395,7 +1482,11 @@ void rollout_variant(const RolloutParams& p, int sk[2], bool backward) {
 hipError_t launch_rollout_fwd_h64(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream);   // rollout_h64.hip
 hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, hipStream_t stream) {
 #ifdef GOPS_ONLY_NARROW   // the same for the plain streamed fp32 kernel of pyth_idpendulum (cfg1, the example scripts' shapes): EXTRA=-DGOPS_ONLY_NARROW
-    launch_with_lds(rollout_fwd_kernel<GOPS_ENV_IDPENDULUM, 0, 0, false>, dim3(1), dim3(NTHREADS), 0, stream, dp);
+#if GOPS_ONLY_NARROW == 2
+    launch_with_lds(rollout_fwd_kernel<GOPS_ENV_IDPENDULUM, 0, 0, false, false, false, false, false, false, true>, dim3((p.B + TB - 1) / TB), dim3(NTHREADS), 4 * ((size_t)p.narrow_off_fwd + p.narrow_floats), stream, dp);
+#else
+    launch_with_lds(rollout_fwd_kernel<GOPS_ENV_IDPENDULUM, 0, 0, false>, dim3((p.B + TB - 1) / TB), dim3(NTHREADS), 4 * ((size_t)p.narrow_off_fwd + p.narrow_floats), stream, dp);
+#endif
     return hipGetLastError();
 #elif defined(GOPS_ONLY_TARGET)   // register / ISA studies (EXTRA=-DGOPS_ONLY_TARGET tools/kernel_regs.sh rollout_fwd.hip): ONE instantiation, seconds to compile
     launch_with_lds(rollout_fwd_kernel<GOPS_ENV_VEH3DOFCONTI, 4, 8, false, false, false, true>, dim3(1), dim3(NTHREADS), 0, stream, dp);
@@ -1487,24 +1578,24 @@ hipError_t launch_rollout_fwd(const RolloutParams& p, const RolloutParams* dp, h
         return hipGetLastError();
     }
     switch (p.env.kind) {
-        case GOPS_ENV_NONE: LAUNCH_FWD(GOPS_ENV_NONE, 0, 0); break;
+        case GOPS_ENV_NONE: LAUNCH_FWD_PLAIN(GOPS_ENV_NONE); break;
         case GOPS_ENV_LQ:
-            if (key == 116) LAUNCH_FWD(GOPS_ENV_LQ, 1, 16); else LAUNCH_FWD(GOPS_ENV_LQ, 0, 0);
+            if (key == 116) LAUNCH_FWD(GOPS_ENV_LQ, 1, 16); else LAUNCH_FWD_PLAIN(GOPS_ENV_LQ);
             break;
         case GOPS_ENV_IDPENDULUM:
-            if (key == 116) LAUNCH_FWD(GOPS_ENV_IDPENDULUM, 1, 16); else LAUNCH_FWD(GOPS_ENV_IDPENDULUM, 0, 0);
+            if (key == 116) LAUNCH_FWD(GOPS_ENV_IDPENDULUM, 1, 16); else LAUNCH_FWD_PLAIN(GOPS_ENV_IDPENDULUM);
             break;
         case GOPS_ENV_VEH3DOFCONTI:
             if (key == 616) LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 6, 16);
             else if (key == 316) LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 3, 16);
             else if (key == 16) LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 0, 16);
-            else LAUNCH_FWD(GOPS_ENV_VEH3DOFCONTI, 0, 0);
+            else LAUNCH_FWD_PLAIN(GOPS_ENV_VEH3DOFCONTI);
             break;
-        case GOPS_ENV_VEH3DOF_SURR: LAUNCH_FWD(GOPS_ENV_VEH3DOF_SURR, 0, 0); break;
-        case GOPS_ENV_CARTPOLE: LAUNCH_FWD(GOPS_ENV_CARTPOLE, 0, 0); break;
-        case GOPS_ENV_PENDULUM: LAUNCH_FWD(GOPS_ENV_PENDULUM, 0, 0); break;
-        case GOPS_ENV_VEH2DOF: LAUNCH_FWD(GOPS_ENV_VEH2DOF, 0, 0); break;
-        case GOPS_ENV_MOBILEROBOT: LAUNCH_FWD(GOPS_ENV_MOBILEROBOT, 0, 0); break;
+        case GOPS_ENV_VEH3DOF_SURR: LAUNCH_FWD_PLAIN(GOPS_ENV_VEH3DOF_SURR); break;
+        case GOPS_ENV_CARTPOLE: LAUNCH_FWD_PLAIN(GOPS_ENV_CARTPOLE); break;
+        case GOPS_ENV_PENDULUM: LAUNCH_FWD_PLAIN(GOPS_ENV_PENDULUM); break;
+        case GOPS_ENV_VEH2DOF: LAUNCH_FWD_PLAIN(GOPS_ENV_VEH2DOF); break;
+        case GOPS_ENV_MOBILEROBOT: LAUNCH_FWD_PLAIN(GOPS_ENV_MOBILEROBOT); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

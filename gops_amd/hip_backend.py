@@ -80,7 +80,7 @@ class GopsRolloutDesc(C.Structure):
 # (tests patch it to steer the algorithm classes).
 VF_NO_STATIONARY_SPLIT, VF_NO_STREAMED_SPLIT_FWD, VF_NO_STREAMED_SPLIT_BWD, VF_NO_STREAMED_SPLIT_VALUE = 0x1, 0x2, 0x4, 0x8
 VF_STREAMED_FP32, VF_STREAM_LAYER0, VF_STATIONARY_ANY_BATCH, VF_NO_SPLIT_STREAM0, VF_SPLIT_TAIL_MULTI = 0x10, 0x20, 0x40, 0x80, 0x100
-VF_NO_HALF_TILE64, VF_NO_NARROW_LDS = 0x200, 0x400
+VF_NO_HALF_TILE64, VF_NO_NARROW_LDS, VF_NO_NARROW_N64 = 0x200, 0x400, 0x800
 VF_DW_EXACT, VF_DW_F32, VF_DW_NO_GUARD, VF_DW_NO_SKINNY, VF_DW_NO_SPEC, VF_DW_DIRECT = 0x10000, 0x20000, 0x40000, 0x80000, 0x100000, 0x200000
 VF_NO_FUSED_DWOUT, VF_BWD_UPLOAD = 0x400000, 0x800000
 VF_BWD_PHASE_A, VF_BWD_PHASE_B, VF_NO_FUSED_DW0 = 0x1000000, 0x2000000, 0x4000000   # a backward in two halves (overlapped gradient all-reduce, trainer/grad_sync.py)

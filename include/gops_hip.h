@@ -494,6 +494,7 @@ int gops_mean_loss(const float* x, int32_t n, double scale, float* stats, void* 
 #define GOPS_VF_SPLIT_TAIL_MULTI 0x100u      /* stationary plane-split kernels also for tail + more tiles than CUs (GOPS_SPLIT_TAIL_MULTI) */
 #define GOPS_VF_NO_HALF_TILE64 0x200u        /* GOPS_DTYPE_F16: the 16-trajectory-tile kernels instead of the 64-row ones (A/B) */
 #define GOPS_VF_NO_NARROW_LDS 0x400u         /* narrow policies on the streamed fp32 kernels: hidden-layer weights from L2 every step, not LDS-resident (GOPS_NARROW=0; A/B) */
+#define GOPS_VF_NO_NARROW_N64 0x800u         /* obs-64-64-act policies on the generic narrow kernels, not the ones written out for that shape (GOPS_N64=0; A/B, identical results) */
 #define GOPS_VF_DW_EXACT 0x10000u            /* weight-gradient GEMM: exact three-plane bf16 split           (GOPS_DW_EXACT) */
 #define GOPS_VF_DW_F32 0x20000u              /*   fp32-MFMA GEMM                                              (GOPS_DW_F32) */
 #define GOPS_VF_DW_NO_GUARD 0x40000u         /*   test knob: no exact redo of saturated blocks                (GOPS_DW_NOGUARD) */

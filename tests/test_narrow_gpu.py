@@ -1,6 +1,6 @@
 """GPU: narrow policies on the plain streamed fp32 kernels keep their packed hidden-layer weights in LDS for the whole launch
 (csrc/common.h gemm_layer_lds; the shapes of the reference's example scripts, e.g. example_train/fhadp/fhadp_mlp_idpendulum_serial.py:67-83:
-MLP(64, 64)).  The LDS-resident path multiplies the same fragments in the same order as the path that streams them from L2 every
+MLP(64, 64) - which additionally runs kernel instantiations written out for exactly that shape, mlp_hidden_forward_n64 / mlp_backward_n64).  The LDS-resident path multiplies the same fragments in the same order as the path that streams them from L2 every
 step (GOPS_VF_NO_NARROW_LDS): value, rewards and every gradient element must be IDENTICAL, and both match the oracle."""
 import ctypes
 
@@ -50,10 +50,12 @@ def test_lds_resident_weights_equal_streamed_weights_bit_for_bit(env_id, extra, 
     cfg = dict(alg="FHADP", env_id=env_id, batch=batch, horizon=horizon, hidden=hidden, act=act, gamma=0.99, **extra)
     cfg.setdefault("pre_horizon", horizon)
     v_a, g_a, (env, nets, data) = _run(cfg, 0, dev)
-    v_b, g_b, _ = _run(cfg, hb.VF_NO_NARROW_LDS, dev)
-    assert torch.equal(v_a, v_b)
-    for a, b in zip(g_a, g_b):
-        assert torch.equal(a, b)
+    # default (obs-64-64-act: the kernels written out for that shape), generic LDS-resident path, weights streamed from L2
+    for flags in (hb.VF_NO_NARROW_N64, hb.VF_NO_NARROW_LDS):
+        v_b, g_b, _ = _run(cfg, flags, dev)
+        assert torch.equal(v_a, v_b), flags
+        for a, b in zip(g_a, g_b):
+            assert torch.equal(a, b), flags
     ref = orc.fhadp_gradient(env, nets["policy"], data, horizon, 0.99)
     got = torch.cat([t.reshape(-1).cpu() for t in g_a]).double()
     want = torch.cat([t.reshape(-1) for t in ref["grads"]]).double()

@@ -1250,6 +1250,7 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_spec_kernel(const float* __res
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
+    (void)convert_stage; (void)landed_and_sync;   // (used by the LDS-DMA ring form only: DW_SPEC_REGDIRECT 0)
 
     unsigned* sat = reinterpret_cast<unsigned*>(ring + NST * SF);
     if (tid == 0) *sat = 0u;

@@ -1019,6 +1019,12 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SSB ? 2 : ((SK0 == 0 && SK1 ==
 #pragma unroll
                         for (int i = 0; i < GOPS_MAX_LQ_STATE; ++i)
                             if (i < O) x[i] = st_x[i * 16 + m];
+                    } else if (IDPPARK && idp_parked) {
+                        // tanh(head) and the done flag ride in the parking (slots 126 / 127, rollout_fwd.hip): already in LDS, and the
+                        // observation is not needed (the sub-step states are parked) - no global load at the top of the step
+                        const float* pk = s_idp + m * IDP_PARK;
+                        e0 = f32x4{pk[126], 0.f, 0.f, 0.f};
+                        e1 = f32x4{pk[127], 0.f, 0.f, 0.f};
                     } else {
                         const GLOBAL_AS f32x4* er = gptr(reinterpret_cast<const f32x4*>(p.st.env + (row0 + m) * ENV_STASH));
                         e0 = er[0]; e1 = er[1];

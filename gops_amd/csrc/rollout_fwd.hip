@@ -898,7 +898,9 @@ __global__ __launch_bounds__(NTHREADS, F16 ? 4 : (SS ? 2 : ((SK0 == 0 && SK1 == 
 #endif
 #pragma unroll
                     for (int i = 0; i < 6; ++i) s[i] = sn[i];
-                    if (parkg != nullptr) { parkg[30] = f32x4{s[0], s[1], s[2], s[3]}; parkg[31] = f32x4{s[4], s[5], 0.f, 0.f}; }
+                    // ([126], [127]: tanh(head) and the done flag the step started with - what the sweep's env adjoint needs of the env row:
+                    // the sweeps that read the parking fetch nothing else at the top of a step)
+                    if (parkg != nullptr) { parkg[30] = f32x4{s[0], s[1], s[2], s[3]}; parkg[31] = f32x4{s[4], s[5], s_th[m * 4], s_done[m]}; }
                     r = idp_reward(s, a);
                     rs = (GEN && !p.env.repeat_last_reward) ? rs + r : r;
 #if GOPS_IDP_FAST
